@@ -1,0 +1,39 @@
+"""CPU oracle for the instant-nsr-pl volumetric-rendering hot path.
+
+THIS PACKAGE IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import, call, link or execute anything under ``oracle/``.  The product path
+(``instant-nsr-pl_amd/``) never imports it and has no CPU fallback.
+
+What it restates
+----------------
+The reference (bennyguo/instant-nsr-pl) owns only the *glue* of this path; the
+arithmetic lives in two third-party CUDA packages that are absent from
+``/root/reference`` and not installable here:
+
+* ``tinycudann`` -- NVlabs/tiny-cuda-nn ``bindings/torch``, UN-PINNED (git master
+  at install time, reference ``README.md:34``).  Call sites:
+  ``models/network_utils.py:47,90,181,209``, ``models/utils.py:119``.
+  Restated in :mod:`oracle.tcnn_ref` from the published algorithm (Instant-NGP
+  paper section 3 + tcnn's documented JSON schema and weight layout, the latter
+  corroborated in-reference at ``models/network_utils.py:142-173``).
+* ``nerfacc==0.3.3`` (reference ``requirements.txt:3``).  Call sites:
+  ``models/nerf.py:11,37,55,83,105-108``, ``models/neus.py:11-12,64,70,109,111,
+  153,159,181-184,210,237-242``, ``models/geometry.py:14``.
+  Restated in :mod:`oracle.nerfacc_ref` (+ ``oracle/csrc/nerfacc_ref.c`` for the
+  sequential fp32 marcher).
+
+The reference-owned glue (``contract_to_unisphere``, ``trunc_exp``, ``get_alpha``,
+``VolumeDensity/VolumeSDF/VolumeRadiance.forward``, ``NeRFModel/NeuSModel.forward_``)
+is restated in :mod:`oracle.glue_ref`.
+
+PARITY STATUS:  **parity unpinned for the third-party arithmetic.**  The reference
+ships no tests, golden vectors or fixtures, and neither
+dependency can be executed here, so the tcnn/nerfacc restatements are pinned only
+by hand-derived known-answer values (``tests/test_oracle_kat.py``) and property
+tests.  The *glue* restatement IS pinned: ``tests/gen_golden.py`` imports the
+reference's own ``models/*.py`` unchanged from ``/root/reference`` (on top of the
+oracle's ``tinycudann``/``nerfacc`` stand-ins) and the committed fixtures under
+``tests/golden/`` hold its outputs; ``tests/test_golden_glue.py`` checks
+:mod:`oracle.glue_ref` against them.
+"""
