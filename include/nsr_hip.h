@@ -1,0 +1,234 @@
+/* nsr_hip.h -- C ABI of libnsr_hip.so: the MI355X (gfx950) kernels behind the `tinycudann` and
+ * `nerfacc` Python surfaces that bennyguo/instant-nsr-pl calls.
+ *
+ * The reference never binds a C symbol: its FFI for this path is the *Python import surface* of two
+ * third-party CUDA packages.  Each entry point below names the reference call
+ * site (file:line under /root/reference) whose third-party kernel it replaces.  The Python packages in
+ * instant-nsr-pl_amd/{tinycudann,nerfacc}/ bind these with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller unless marked host;
+ *   - the library never allocates or frees device memory and keeps no global device state;
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns without syncing;
+ *   - return 0 on success, <0 on error; nsr_last_error() gives a thread-local message;
+ *   - "accumulate" outputs (grad_table, grad_params) are ADDED to: the caller zeroes them;
+ *   - half = IEEE binary16 (uint16_t storage).
+ */
+#ifndef NSR_HIP_H
+#define NSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSR_OK 0
+#define NSR_ERR_INVALID (-1)
+#define NSR_ERR_LAUNCH (-2)
+#define NSR_ERR_UNSUPPORTED (-3)
+
+#define NSR_MAX_LEVELS 32
+
+typedef uint16_t nsr_half;
+
+const char *nsr_last_error(void);
+/* ABI version of this header (bumped on any signature change) */
+int nsr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multiresolution hash grid  -- replaces tcnn.Encoding(HashGrid)
+ *   constructed at models/network_utils.py:47,90 and (fused) :209 ; evaluated at
+ *   models/geometry.py:124,134,169,195,214
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct NsrGridDesc {
+    uint32_t n_levels;          /* L  (<= NSR_MAX_LEVELS) */
+    uint32_t n_features;        /* F  in {1,2,4,8} */
+    uint32_t log2_hashmap_size; /* T = 2^log2 */
+    uint32_t base_resolution;
+    float per_level_scale;
+    uint32_t n_entries;                 /* sum of size[] ; n_params = n_entries * F */
+    float scale[NSR_MAX_LEVELS];        /* fp32: exp2f(l*log2f(s))*base - 1 */
+    uint32_t resolution[NSR_MAX_LEVELS]; /* ceilf(scale)+1 */
+    uint32_t size[NSR_MAX_LEVELS];      /* entries in level (dense: res^3 rounded up to 8; capped at T) */
+    uint32_t offset[NSR_MAX_LEVELS + 1]; /* entry offset of each level */
+} NsrGridDesc;
+
+/* host-only: fill `out` (host memory) with fp32 level geometry computed with log2f/exp2f/ceilf */
+int nsr_hashgrid_make_desc(NsrGridDesc *out, uint32_t n_levels, uint32_t n_features,
+                           uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale);
+
+/* y[n, y_stride] (half) <- encode(x[n,3] in [0,1], table[n_entries*F] half).  L*F columns written.
+ * `level_mask_count`: levels >= this count are written as zeros WITHOUT touching the table
+ * (ProgressiveBandHashGrid, models/network_utils.py:55-65); pass n_levels for the plain encoding. */
+int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                         uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
+
+/* grad_table[n_entries*F] (fp32, accumulate) += scatter(dy).  dy_is_f32: 0 = half, 1 = float.
+ * grad_scale multiplies dy on load (pass 1.0f). */
+int nsr_hashgrid_backward_params(const float *x, const void *dy, int dy_is_f32, uint32_t dy_stride,
+                                 float *grad_table, uint32_t n, uint32_t level_mask_count, float grad_scale,
+                                 const NsrGridDesc *desc, void *stream);
+
+/* dx[n,3] (fp32) = (d y / d x)^T dy  -- the NeuS analytic normal, models/geometry.py:177-180 */
+int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
+                                uint32_t dy_stride, float *dx, uint32_t n, uint32_t level_mask_count,
+                                const NsrGridDesc *desc, void *stream);
+
+/* double backward of backward_input (eikonal loss through create_graph=True normals,
+ * models/geometry.py:177-180 -> systems/neus.py:106).  Given g = dL/d(dx) [n,3]:
+ *   d_dy[n, L*F] (fp32, may be NULL)       = J g
+ *   grad_table (fp32, accumulate, may be NULL) += d(dx.g)/d table
+ *   dx2[n,3] (fp32, may be NULL)           = d(dx.g)/d x                                           */
+int nsr_hashgrid_backward_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
+                                         uint32_t dy_stride, const float *g, float *d_dy, uint32_t d_dy_stride,
+                                         float *grad_table, float *dx2, uint32_t n, uint32_t level_mask_count,
+                                         const NsrGridDesc *desc, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spherical harmonics degree 4 -- replaces tcnn.Encoding(SphericalHarmonics), models/texture.py:25
+ *   u[n,3] in [0,1] (the reference pre-maps (d+1)/2) -> y[n, y_stride] half, 16 columns
+ * ------------------------------------------------------------------------------------------------ */
+int nsr_sh4_forward(const float *u, nsr_half *y, uint32_t n, uint32_t y_stride, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fully fused 64-wide MLP -- replaces tcnn.Network(FullyFusedMLP), models/network_utils.py:181,209
+ *   weights: half, row-major [out,in] matrices concatenated: W0[64,in_pad] | (n_hidden-1) x [64,64] |
+ *   Wlast[out_pad,64]  (layout documented at models/network_utils.py:142-173); no biases; ReLU.
+ *   in_pad in {16,32,48,64}; out_pad == 16; 1 <= n_hidden <= 4.
+ * ------------------------------------------------------------------------------------------------ */
+#define NSR_ACT_NONE 0
+#define NSR_ACT_SIGMOID 1
+
+typedef struct NsrMlpDesc {
+    uint32_t n_in;     /* logical input columns (<= in_pad); columns [n_in,in_pad) are the constant 1.0 */
+    uint32_t in_pad;
+    uint32_t n_out;    /* logical outputs (<= out_pad) */
+    uint32_t out_pad;
+    uint32_t n_hidden; /* hidden layers of width 64 */
+    uint32_t output_activation; /* NSR_ACT_* */
+} NsrMlpDesc;
+
+/* x: [n, x_stride] half (x_is_f32=0) or float (x_is_f32=1); out: [n, out_pad] half.
+ * acts (may be NULL for inference): n_hidden * [n,64] half post-ReLU activations saved for backward. */
+int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *weights, nsr_half *out,
+                    nsr_half *acts, uint32_t n, const NsrMlpDesc *desc, void *stream);
+
+/* dout: [n, dout_stride] half/float grads w.r.t. the (activated) outputs; out: forward outputs (needed
+ * for the sigmoid derivative, may be NULL for NSR_ACT_NONE); x/acts as given to / saved by forward.
+ * grad_weights (fp32, accumulate, same layout as weights, may be NULL).
+ * dx (may be NULL): [n, dx_stride] float, first n_in columns written.
+ * partials: caller-provided fp32 workspace of nsr_mlp_backward_workspace_floats() floats.
+ * grad_scale: dout is multiplied by it before the fp16 backward chain and results divided by it. */
+uint64_t nsr_mlp_backward_workspace_floats(const NsrMlpDesc *desc, uint32_t n);
+int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, const nsr_half *out,
+                     const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *acts,
+                     const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
+                     float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * nerfacc 0.3.3 kernels
+ * ------------------------------------------------------------------------------------------------ */
+#define NSR_CONTRACT_AABB 0
+#define NSR_CONTRACT_UN_BOUNDED_TANH 1
+#define NSR_CONTRACT_UN_BOUNDED_SPHERE 2
+
+/* nerfacc.intersection.ray_aabb_intersect -- models/neus.py:153 ; inside ray_marching when scene_aabb
+ * is given (models/nerf.py:85, models/neus.py:212).  miss => t_min=t_max=1e10 ; t_min clamped >= 0 */
+int nsr_ray_aabb_intersect(const float *rays_o, const float *rays_d, const float *aabb /*device[6]*/,
+                           float *t_min, float *t_max, uint32_t n_rays, void *stream);
+
+/* nerfacc.ray_marching -- models/nerf.py:83 ; models/neus.py:159,210.   Two-call protocol:
+ *   count: num_steps[n_rays] (int32)   <- samples each ray will emit
+ *   (caller: exclusive scan -> packed_info[n_rays,2] = (start,count); reads the total back)
+ *   write: ray_indices[total] int64, t_starts[total], t_ends[total]
+ * roi: device[6]; grid_binary: uint8/bool [res_x*res_y*res_z]; bit-exact fp32 stepping. */
+int nsr_ray_march_count(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                        const float *roi, const uint8_t *grid_binary, int res_x, int res_y, int res_z,
+                        int contraction, float step_size, float cone_angle, int32_t *num_steps,
+                        uint32_t n_rays, void *stream);
+int nsr_ray_march_write(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                        const float *roi, const uint8_t *grid_binary, int res_x, int res_y, int res_z,
+                        int contraction, float step_size, float cone_angle, const int32_t *packed_info,
+                        int64_t *ray_indices, float *t_starts, float *t_ends, uint32_t n_rays, void *stream);
+
+/* exclusive scan of num_steps -> packed_info[n_rays,2]; *total (device int32[1]) <- sum */
+int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
+                         void *stream);
+/* packed_info[n_rays,2] from sorted ray_indices[n] (binary search per ray) */
+int nsr_pack_info(const int64_t *ray_indices, int32_t *packed_info, uint32_t n, uint32_t n_rays, void *stream);
+
+/* contraction / inverse / grid query -- OccupancyGrid._update behind models/nerf.py:55, neus.py:109-111 */
+int nsr_contract(const float *x, const float *roi, int contraction, float *out, uint32_t n, void *stream);
+int nsr_contract_inv(const float *x, const float *roi, int contraction, float *out, uint32_t n, void *stream);
+int nsr_grid_query_u8(const float *x, const float *roi, const uint8_t *grid, int res_x, int res_y, int res_z,
+                      int contraction, uint8_t *out, uint32_t n, void *stream);
+
+/* sample positions p = o[ray] + d[ray] * (t0+t1)/2 and per-sample dirs (the gather at
+ * models/nerf.py:66-69,95-99 ; models/neus.py:222-227).  dirs_out may be NULL. */
+int nsr_sample_positions(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                         const float *t_starts, const float *t_ends, float *positions, float *dirs_out,
+                         uint32_t n, void *stream);
+
+/* nerfacc.render_weight_from_density / render_weight_from_alpha / render_visibility
+ *   models/nerf.py:105 ; models/neus.py:181,237 ; inside ray_marching (sigma_fn pruning, nerf.py:87)
+ * Segments = contiguous runs of equal ray index; packed_info[n_rays,2] = (start,count).
+ *   from_sigma: T_i = exp(-sum_{j<i} sigma_j*(t1_j-t0_j)) ; from_alpha: T_i = prod_{j<i}(1-alpha_j)
+ *   backward:   d/d(sigma*dt)_j = -sum_{i>j} gT_i T_i ; d/d alpha_j = that / max(1-alpha_j,1e-10) */
+int nsr_transmittance_from_sigma_forward(const int32_t *packed_info, const float *t_starts, const float *t_ends,
+                                         const float *sigmas, float *trans, uint32_t n_rays, void *stream);
+int nsr_transmittance_from_sigma_backward(const int32_t *packed_info, const float *t_starts, const float *t_ends,
+                                          const float *trans, const float *grad_trans, float *grad_sigmas,
+                                          uint32_t n_rays, void *stream);
+int nsr_transmittance_from_alpha_forward(const int32_t *packed_info, const float *alphas, float *trans,
+                                         uint32_t n_rays, void *stream);
+int nsr_transmittance_from_alpha_backward(const int32_t *packed_info, const float *alphas, const float *trans,
+                                          const float *grad_trans, float *grad_alphas, uint32_t n_rays,
+                                          void *stream);
+
+/* nerfacc.accumulate_along_rays -- models/nerf.py:106-108 ; models/neus.py:182-184,238-242
+ *   out[r, d] = sum_{i in ray r} w_i * v_i[d]   (values==NULL: D=1, v=1).  Deterministic per-ray reduce. */
+int nsr_accumulate_along_rays_forward(const int32_t *packed_info, const float *weights, const float *values,
+                                      uint32_t dim, float *out, uint32_t n_rays, void *stream);
+int nsr_accumulate_along_rays_backward(const int64_t *ray_indices, const float *weights, const float *values,
+                                       uint32_t dim, const float *grad_out, float *grad_weights,
+                                       float *grad_values, uint32_t n, void *stream);
+
+/* stream compaction by a byte mask (the boolean filter after render_visibility): writes the kept
+ * samples in order; *n_kept (device int32[1]).  Outputs must hold n elements. */
+int nsr_compact_samples(const uint8_t *mask, const int64_t *ray_indices, const float *t_starts,
+                        const float *t_ends, int64_t *ray_indices_out, float *t_starts_out, float *t_ends_out,
+                        int32_t *n_kept, int32_t *block_scratch, uint32_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reference-owned glue, fused (rows a8-a10, a18 of SURVEY.md section 8a)
+ * ------------------------------------------------------------------------------------------------ */
+/* contract_to_unisphere, models/geometry.py:17-29 (AABB and UN_BOUNDED_SPHERE) */
+int nsr_contract_to_unisphere(const float *x, float radius, int contraction, float *out, uint32_t n,
+                              void *stream);
+/* trunc_exp(out[:,0] + bias) forward (models/utils.py:53-68 ; models/geometry.py:125-127):
+ * mlp_out [n, stride] half -> density[n] float ; feature[n, n_feat] float (may be NULL) */
+int nsr_density_activation_forward(const nsr_half *mlp_out, uint32_t stride, uint32_t n_feat, float bias,
+                                   float *density, float *feature, uint32_t n, void *stream);
+/* NeuS SDF->alpha, models/neus.py:117-139.  inv_s: device float[1] (already exp(10*variance)). */
+int nsr_neus_alpha_forward(const float *sdf, const float *normal, const float *dirs, const float *dists,
+                           const float *inv_s, float cos_anneal_ratio, float *alpha, uint32_t n, void *stream);
+int nsr_neus_alpha_backward(const float *sdf, const float *normal, const float *dirs, const float *dists,
+                            const float *inv_s, float cos_anneal_ratio, const float *grad_alpha,
+                            float *grad_sdf, float *grad_normal, float *grad_inv_s, /* grad_inv_s: device[1], accumulated */
+                            uint32_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:
+ * AdamW lr 0.01 betas (0.9,0.99) eps 1e-15, systems/utils.py:314-325) that also refreshes the fp16
+ * shadow the kernels read and zeroes the gradient.
+ * ------------------------------------------------------------------------------------------------ */
+int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, nsr_half *shadow_half,
+                   uint64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad,
+                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_HIP_H */

@@ -1,0 +1,453 @@
+// Multiresolution hash-grid encoding for gfx950 (replaces tcnn.Encoding(HashGrid); reference call sites
+// models/network_utils.py:47,90,209 ; models/geometry.py:124,169,177-180,195).
+//
+// Work decomposition (MI355X-first, not tcnn's (N/512, L) grid):
+//   * one lane = one (sample, level); a wavefront = 64 consecutive samples of ONE level, so the x-loads
+//     are coalesced and the 8 corner gathers of neighbouring samples (ray-ordered => spatially coherent)
+//     fall into the same or adjacent 64-B sectors of that level's table;
+//   * the 1-D grid is XCD-aware: hardware places block b on XCD (b % 8) and every XCD has a private
+//     4 MiB L2, so level l is only ever touched by XCD (l % 8).  With L=16, T=2^19, F=2 (fp16) an XCD
+//     serves two levels = 4 MiB of table: the fine levels stay L2-resident instead of thrashing all
+//     eight L2s with the whole 24 MiB table.  Placement is a speed assumption only, never correctness.
+//   * level geometry (scale/resolution/size/offset) arrives precomputed in fp32 from the host
+//     (NsrGridDesc) and is read through scalar loads (block-uniform level).
+//   * gradients are accumulated with hardware fp32 atomics (global_atomic_add_f32) straight into the
+//     fp32 gradient of the flat parameter -- no fp16 atomics, no loss-scale hack.
+#include <string.h>
+
+#include "nsr_common.h"
+
+namespace {
+
+constexpr uint32_t PRIME_Y = 2654435761u;
+constexpr uint32_t PRIME_Z = 805459861u;
+constexpr int GRID_BLOCK = 256;
+
+struct LevelGeom {
+    float scale;
+    uint32_t res;
+    uint32_t size;
+    uint32_t offset;
+    bool dense;
+};
+
+__device__ __forceinline__ LevelGeom load_level(const NsrGridDesc &d, uint32_t level)
+{
+    LevelGeom g;
+    g.scale = d.scale[level];
+    g.res = d.resolution[level];
+    g.size = d.size[level];
+    g.offset = d.offset[level];
+    g.dense = (uint64_t)g.res * g.res * g.res <= (uint64_t)g.size;
+    return g;
+}
+
+// entry index of an integer corner (tcnn grid_index: x-fastest dense while the stride fits, else hash)
+__device__ __forceinline__ uint32_t corner_index(const LevelGeom &g, uint32_t cx, uint32_t cy, uint32_t cz)
+{
+    if (g.dense) {
+        uint32_t idx = cx + g.res * (cy + g.res * cz);
+        return idx >= g.size ? idx % g.size : idx;  // only the x==1.0 border can exceed
+    }
+    uint32_t h = cx ^ (cy * PRIME_Y) ^ (cz * PRIME_Z);
+    return h & (g.size - 1);  // hashed levels are capped at T = 2^log2 entries
+}
+
+struct Cell {
+    float w[3];      // fractional position inside the cell
+    uint32_t c[3];   // integer corner (lower)
+};
+
+__device__ __forceinline__ Cell locate(const LevelGeom &g, float x0, float x1, float x2)
+{
+    Cell c;
+    const float p0 = fmaf(g.scale, x0, 0.5f), p1 = fmaf(g.scale, x1, 0.5f), p2 = fmaf(g.scale, x2, 0.5f);
+    const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+    c.w[0] = p0 - f0; c.w[1] = p1 - f1; c.w[2] = p2 - f2;
+    c.c[0] = (uint32_t)(int)f0; c.c[1] = (uint32_t)(int)f1; c.c[2] = (uint32_t)(int)f2;
+    return c;
+}
+
+template <int F> struct FeatVec;
+template <> struct FeatVec<1> { using T = __half; };
+template <> struct FeatVec<2> { using T = __half2; };
+
+template <int F>
+__device__ __forceinline__ void load_feat(const __half *__restrict__ table, uint32_t entry, float (&v)[F])
+{
+    const __half *p = table + (uint64_t)entry * F;
+    if constexpr (F == 1) {
+        v[0] = __half2float(p[0]);
+    } else if constexpr (F == 2) {
+        const __half2 h = *reinterpret_cast<const __half2 *>(p);
+        v[0] = __low2float(h); v[1] = __high2float(h);
+    } else if constexpr (F == 4) {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+        const __half2 a = *reinterpret_cast<const __half2 *>(&raw.x), b = *reinterpret_cast<const __half2 *>(&raw.y);
+        v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+    } else {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const __half2 a = *reinterpret_cast<const __half2 *>(&r[k]);
+            v[2 * k] = __low2float(a); v[2 * k + 1] = __high2float(a);
+        }
+    }
+}
+
+template <bool F32> struct GradT { using T = __half; };
+template <> struct GradT<true> { using T = float; };
+
+template <bool F32>
+__device__ __forceinline__ float load_grad(const void *p, uint64_t i)
+{
+    if constexpr (F32) return reinterpret_cast<const float *>(p)[i];
+    else return __half2float(reinterpret_cast<const __half *>(p)[i]);
+}
+
+// XCD-aware (block -> level, sample-block) mapping.  lpx = ceil(L/8) levels per XCD.
+__device__ __forceinline__ bool map_block(uint32_t n_levels, uint32_t lpx, uint32_t &level, uint32_t &blk)
+{
+    const uint32_t b = blockIdx.x, xcd = b & 7u, q = b >> 3;
+    level = xcd + 8u * (q % lpx);
+    blk = q / lpx;
+    return level < n_levels;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int F>
+__global__ void __launch_bounds__(GRID_BLOCK)
+k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
+               uint32_t y_stride, uint32_t mask_count, uint32_t lpx, const NsrGridDesc d)
+{
+    uint32_t level, blk;
+    if (!map_block(d.n_levels, lpx, level, blk)) return;
+    const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    __half *yo = y + (uint64_t)i * y_stride + level * F;
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    if (level < mask_count) {
+        const LevelGeom g = load_level(d, level);
+        const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
+        float v[8][F];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t e = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1));
+            load_feat<F>(table, g.offset + e, v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
+            w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
+            w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[k][f], acc[f]);
+        }
+    }
+    if constexpr (F == 1) {
+        yo[0] = __float2half_rn(acc[0]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; f += 2)
+            *reinterpret_cast<__half2 *>(yo + f) = __floats2half2_rn(acc[f], acc[f + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward w.r.t. the table: scatter-add with fp32 hardware atomics
+// ------------------------------------------------------------------------------------------------
+template <int F, bool DY_F32>
+__global__ void __launch_bounds__(GRID_BLOCK)
+k_grid_backward_params(const float *__restrict__ x, const void *__restrict__ dy, uint32_t dy_stride,
+                       float *__restrict__ grad_table, uint32_t n, uint32_t mask_count, uint32_t lpx,
+                       float grad_scale, const NsrGridDesc d)
+{
+    uint32_t level, blk;
+    if (!map_block(d.n_levels, lpx, level, blk)) return;
+    if (level >= mask_count) return;
+    const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float g_out[F];
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        g_out[f] = load_grad<DY_F32>(dy, (uint64_t)i * dy_stride + level * F + f) * grad_scale;
+        any |= (g_out[f] != 0.f);
+    }
+    if (!any) return;
+    const LevelGeom g = load_level(d, level);
+    const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t e = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1));
+        float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
+        w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
+        w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
+        float *gp = grad_table + (uint64_t)(g.offset + e) * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) unsafeAtomicAdd(gp + f, w * g_out[f]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward w.r.t. the input (and its double backward): one lane = one sample, loop over levels.
+// dy/dx is recomputed from the (cache-resident) table instead of being stored by the forward pass.
+// ------------------------------------------------------------------------------------------------
+template <int F, bool DY_F32>
+__global__ void __launch_bounds__(GRID_BLOCK)
+k_grid_backward_input(const float *__restrict__ x, const __half *__restrict__ table, const void *__restrict__ dy,
+                      uint32_t dy_stride, float *__restrict__ dx, uint32_t n, uint32_t mask_count,
+                      const NsrGridDesc d)
+{
+    const uint32_t i = blockIdx.x * GRID_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = x[3ull * i], x1 = x[3ull * i + 1], x2 = x[3ull * i + 2];
+    float gx[3] = {0.f, 0.f, 0.f};
+    const uint32_t nl = min(d.n_levels, mask_count);
+    for (uint32_t level = 0; level < nl; ++level) {
+        const LevelGeom g = load_level(d, level);
+        const Cell c = locate(g, x0, x1, x2);
+        float gy[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) gy[f] = load_grad<DY_F32>(dy, (uint64_t)i * dy_stride + level * F + f);
+        // s[k] = sum_f dy_f * table[corner k][f]
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t e = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1));
+            float v[F];
+            load_feat<F>(table, g.offset + e, v);
+            float a = 0.f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) a = fmaf(gy[f], v[f], a);
+            s[k] = a;
+        }
+        const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
+        // d/dx0: corners differ in bit0; weight = w1(bit1) * w2(bit2)
+        const float d0 = (1.f - w1) * (1.f - w2) * (s[1] - s[0]) + w1 * (1.f - w2) * (s[3] - s[2]) +
+                         (1.f - w1) * w2 * (s[5] - s[4]) + w1 * w2 * (s[7] - s[6]);
+        const float d1 = (1.f - w0) * (1.f - w2) * (s[2] - s[0]) + w0 * (1.f - w2) * (s[3] - s[1]) +
+                         (1.f - w0) * w2 * (s[6] - s[4]) + w0 * w2 * (s[7] - s[5]);
+        const float d2 = (1.f - w0) * (1.f - w1) * (s[4] - s[0]) + w0 * (1.f - w1) * (s[5] - s[1]) +
+                         (1.f - w0) * w1 * (s[6] - s[2]) + w0 * w1 * (s[7] - s[3]);
+        gx[0] = fmaf(g.scale, d0, gx[0]);
+        gx[1] = fmaf(g.scale, d1, gx[1]);
+        gx[2] = fmaf(g.scale, d2, gx[2]);
+    }
+    dx[3ull * i] = gx[0]; dx[3ull * i + 1] = gx[1]; dx[3ull * i + 2] = gx[2];
+}
+
+// Double backward of  dx = J(x; table)^T dy  given g = dL/d(dx):
+//   d_dy[l,f]            = sum_d g_d * dJ_{lf,d}
+//   grad_table[corner,f] += dy_lf * scale * sum_d g_d * sign_d(corner) * prod_{e!=d} w_e(corner)
+//   dx2_e                = sum_{d!=e} g_d * sum_lf dy_lf * scale^2 * sum_corner sign_d sign_e w_third T[corner,f]
+template <int F, bool DY_F32>
+__global__ void __launch_bounds__(GRID_BLOCK)
+k_grid_bwd_bwd_input(const float *__restrict__ x, const __half *__restrict__ table, const void *__restrict__ dy,
+                     uint32_t dy_stride, const float *__restrict__ gin, float *__restrict__ d_dy,
+                     uint32_t d_dy_stride, float *__restrict__ grad_table, float *__restrict__ dx2, uint32_t n,
+                     uint32_t mask_count, const NsrGridDesc d)
+{
+    const uint32_t i = blockIdx.x * GRID_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = x[3ull * i], x1 = x[3ull * i + 1], x2 = x[3ull * i + 2];
+    const float g0 = gin[3ull * i], g1 = gin[3ull * i + 1], g2 = gin[3ull * i + 2];
+    float acc2[3] = {0.f, 0.f, 0.f};
+    const uint32_t nl = min(d.n_levels, mask_count);
+    for (uint32_t level = 0; level < d.n_levels; ++level) {
+        if (level >= nl) {
+            if (d_dy)
+                for (int f = 0; f < F; ++f) d_dy[(uint64_t)i * d_dy_stride + level * F + f] = 0.f;
+            continue;
+        }
+        const LevelGeom g = load_level(d, level);
+        const Cell c = locate(g, x0, x1, x2);
+        const float w[3] = {c.w[0], c.w[1], c.w[2]};
+        float gy[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) gy[f] = load_grad<DY_F32>(dy, (uint64_t)i * dy_stride + level * F + f);
+        float ddy[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) ddy[f] = 0.f;
+        float m01 = 0.f, m02 = 0.f, m12 = 0.f;  // mixed second derivatives contracted with dy
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t e = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1));
+            float v[F];
+            load_feat<F>(table, g.offset + e, v);
+            const float a0 = (k & 1) ? w[0] : 1.f - w[0], a1 = (k & 2) ? w[1] : 1.f - w[1],
+                        a2 = (k & 4) ? w[2] : 1.f - w[2];
+            const float s0 = (k & 1) ? 1.f : -1.f, s1 = (k & 2) ? 1.f : -1.f, s2 = (k & 4) ? 1.f : -1.f;
+            // coefficient of table[corner] in  sum_d g_d * dy/dx_d  (without scale)
+            const float coef = g0 * s0 * a1 * a2 + g1 * s1 * a0 * a2 + g2 * s2 * a0 * a1;
+            float sv = 0.f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                ddy[f] = fmaf(coef, v[f], ddy[f]);
+                sv = fmaf(gy[f], v[f], sv);
+            }
+            if (grad_table) {
+                float *gp = grad_table + (uint64_t)(g.offset + e) * F;
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float t = g.scale * coef * gy[f];
+                    if (t != 0.f) unsafeAtomicAdd(gp + f, t);
+                }
+            }
+            m01 = fmaf(s0 * s1 * a2, sv, m01);
+            m02 = fmaf(s0 * s2 * a1, sv, m02);
+            m12 = fmaf(s1 * s2 * a0, sv, m12);
+        }
+        if (d_dy) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) d_dy[(uint64_t)i * d_dy_stride + level * F + f] = g.scale * ddy[f];
+        }
+        const float sc2 = g.scale * g.scale;
+        acc2[0] = fmaf(sc2, g1 * m01 + g2 * m02, acc2[0]);
+        acc2[1] = fmaf(sc2, g0 * m01 + g2 * m12, acc2[1]);
+        acc2[2] = fmaf(sc2, g0 * m02 + g1 * m12, acc2[2]);
+    }
+    if (dx2) { dx2[3ull * i] = acc2[0]; dx2[3ull * i + 1] = acc2[1]; dx2[3ull * i + 2] = acc2[2]; }
+}
+
+int check_desc(const NsrGridDesc *d, const char *who)
+{
+    NSR_REQUIRE(d != nullptr, "%s: desc is NULL", who);
+    NSR_REQUIRE(d->n_levels >= 1 && d->n_levels <= NSR_MAX_LEVELS, "%s: n_levels=%u out of range", who, d->n_levels);
+    NSR_REQUIRE(d->n_features == 1 || d->n_features == 2 || d->n_features == 4 || d->n_features == 8,
+                "%s: n_features=%u unsupported (1,2,4,8)", who, d->n_features);
+    return NSR_OK;
+}
+
+}  // namespace
+
+#define DISPATCH_F(F_, ...)                  \
+    switch (F_) {                            \
+    case 1: { constexpr int F = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int F = 2; __VA_ARGS__; } break; \
+    case 4: { constexpr int F = 4; __VA_ARGS__; } break; \
+    default: { constexpr int F = 8; __VA_ARGS__; } break; \
+    }
+
+extern "C" int nsr_hashgrid_make_desc(NsrGridDesc *out, uint32_t n_levels, uint32_t n_features,
+                                      uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale)
+{
+    NSR_REQUIRE(out != nullptr, "nsr_hashgrid_make_desc: out is NULL");
+    NSR_REQUIRE(n_levels >= 1 && n_levels <= NSR_MAX_LEVELS, "nsr_hashgrid_make_desc: n_levels=%u", n_levels);
+    NSR_REQUIRE(log2_hashmap_size >= 3 && log2_hashmap_size <= 28, "nsr_hashgrid_make_desc: log2_hashmap_size=%u",
+                log2_hashmap_size);
+    memset(out, 0, sizeof(*out));
+    out->n_levels = n_levels;
+    out->n_features = n_features;
+    out->log2_hashmap_size = log2_hashmap_size;
+    out->base_resolution = base_resolution;
+    out->per_level_scale = per_level_scale;
+    const float log2s = log2f(per_level_scale);
+    uint32_t off = 0;
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        volatile float a = (float)l * log2s;  // every op separately rounded to fp32
+        volatile float e = exp2f(a);
+        volatile float m = e * (float)base_resolution;
+        const float scale = m - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+        uint64_t cells = (uint64_t)res * res * res;
+        if (cells > 0xFFFFFFFFull) cells = 0xFFFFFFFFull;
+        cells = (cells + 7ull) / 8ull * 8ull;
+        const uint64_t cap = 1ull << log2_hashmap_size;
+        const uint32_t size = (uint32_t)(cells < cap ? cells : cap);
+        out->scale[l] = scale;
+        out->resolution[l] = res;
+        out->size[l] = size;
+        out->offset[l] = off;
+        off += size;
+    }
+    out->offset[n_levels] = off;
+    out->n_entries = off;
+    return check_desc(out, "nsr_hashgrid_make_desc");
+}
+
+extern "C" int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                                    uint32_t level_mask_count, const NsrGridDesc *desc, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_forward")) return rc;
+    NSR_REQUIRE(y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward: y_stride too small");
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && table && y, "nsr_hashgrid_forward: NULL pointer");
+    const uint32_t lpx = (desc->n_levels + 7) / 8;
+    const uint32_t grid = 8u * lpx * nsr_div_up(n, GRID_BLOCK);
+    DISPATCH_F(desc->n_features,
+               hipLaunchKernelGGL((k_grid_forward<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
+                                  (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, *desc));
+    NSR_CHECK_LAUNCH("nsr_hashgrid_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int dy_is_f32, uint32_t dy_stride,
+                                            float *grad_table, uint32_t n, uint32_t level_mask_count,
+                                            float grad_scale, const NsrGridDesc *desc, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_backward_params")) return rc;
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && dy && grad_table, "nsr_hashgrid_backward_params: NULL pointer");
+    const uint32_t lpx = (desc->n_levels + 7) / 8;
+    const uint32_t grid = 8u * lpx * nsr_div_up(n, GRID_BLOCK);
+    DISPATCH_F(desc->n_features, {
+        if (dy_is_f32)
+            hipLaunchKernelGGL((k_grid_backward_params<F, true>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream,
+                               x, dy, dy_stride, grad_table, n, level_mask_count, lpx, grad_scale, *desc);
+        else
+            hipLaunchKernelGGL((k_grid_backward_params<F, false>), dim3(grid), dim3(GRID_BLOCK), 0,
+                               (hipStream_t)stream, x, dy, dy_stride, grad_table, n, level_mask_count, lpx,
+                               grad_scale, *desc);
+    });
+    NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params");
+    return NSR_OK;
+}
+
+extern "C" int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
+                                           uint32_t dy_stride, float *dx, uint32_t n, uint32_t level_mask_count,
+                                           const NsrGridDesc *desc, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_backward_input")) return rc;
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && table && dy && dx, "nsr_hashgrid_backward_input: NULL pointer");
+    const uint32_t grid = nsr_div_up(n, GRID_BLOCK);
+    DISPATCH_F(desc->n_features, {
+        if (dy_is_f32)
+            hipLaunchKernelGGL((k_grid_backward_input<F, true>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream,
+                               x, (const __half *)table, dy, dy_stride, dx, n, level_mask_count, *desc);
+        else
+            hipLaunchKernelGGL((k_grid_backward_input<F, false>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream,
+                               x, (const __half *)table, dy, dy_stride, dx, n, level_mask_count, *desc);
+    });
+    NSR_CHECK_LAUNCH("nsr_hashgrid_backward_input");
+    return NSR_OK;
+}
+
+extern "C" int nsr_hashgrid_backward_backward_input(const float *x, const nsr_half *table, const void *dy,
+                                                    int dy_is_f32, uint32_t dy_stride, const float *g, float *d_dy,
+                                                    uint32_t d_dy_stride, float *grad_table, float *dx2, uint32_t n,
+                                                    uint32_t level_mask_count, const NsrGridDesc *desc, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_backward_backward_input")) return rc;
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && table && dy && g, "nsr_hashgrid_backward_backward_input: NULL pointer");
+    const uint32_t grid = nsr_div_up(n, GRID_BLOCK);
+    DISPATCH_F(desc->n_features, {
+        if (dy_is_f32)
+            hipLaunchKernelGGL((k_grid_bwd_bwd_input<F, true>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
+                               (const __half *)table, dy, dy_stride, g, d_dy, d_dy_stride, grad_table, dx2, n,
+                               level_mask_count, *desc);
+        else
+            hipLaunchKernelGGL((k_grid_bwd_bwd_input<F, false>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream,
+                               x, (const __half *)table, dy, dy_stride, g, d_dy, d_dy_stride, grad_table, dx2, n,
+                               level_mask_count, *desc);
+    });
+    NSR_CHECK_LAUNCH("nsr_hashgrid_backward_backward_input");
+    return NSR_OK;
+}

@@ -1,0 +1,495 @@
+// Occupancy-grid ray marching for gfx950 (replaces nerfacc 0.3.3 ray_aabb_intersect / ray_marching /
+// contraction / grid query; reference call sites models/nerf.py:83, models/neus.py:153,159,210).
+//
+// Parity contract: ray_indices / packed_info / sample counts are BIT-EXACT against the oracle
+// (oracle/csrc/nerfacc_ref.c) and t_starts / t_ends are bit-exact fp32: every arithmetic op below is a
+// separately rounded IEEE op (this translation unit is built with -ffp-contract=off; hipcc's default
+// fp32 division and sqrt are correctly rounded), except the sample position  p = fmaf(t, d, o).
+//
+// MI355X notes: one lane = one ray (the step recurrence is sequential in fp32 by definition); rays of a
+// training batch are drawn i.i.d. so trip counts diverge inside a wavefront -- the kernel is latency /
+// divergence bound, not bandwidth bound (a 128^3 bool grid is 2 MiB and stays in the XCD's L2).  The
+// two passes (count, write) share one code path through a template flag so both see identical floats.
+#include "nsr_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int MARCH_BLOCK = 128;  // 2 waves/block: more blocks in flight for the divergent loop
+constexpr int EW_BLOCK = 256;
+
+struct Roi { float lo[3], hi[3]; };
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float signf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+__device__ __forceinline__ void aabb_one(const float *o, const float *d, const float *aabb, float &near, float &far)
+{
+    float tmin = (aabb[0] - o[0]) / d[0], tmax = (aabb[3] - o[0]) / d[0];
+    if (tmin > tmax) { float s = tmin; tmin = tmax; tmax = s; }
+    float tymin = (aabb[1] - o[1]) / d[1], tymax = (aabb[4] - o[1]) / d[1];
+    if (tymin > tymax) { float s = tymin; tymin = tymax; tymax = s; }
+    if (tmin > tymax || tymin > tmax) { near = 1e10f; far = 1e10f; return; }
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (aabb[2] - o[2]) / d[2], tzmax = (aabb[5] - o[2]) / d[2];
+    if (tzmin > tzmax) { float s = tzmin; tzmin = tzmax; tzmax = s; }
+    if (tmin > tzmax || tzmin > tmax) { near = 1e10f; far = 1e10f; return; }
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    near = tmin > 0.f ? tmin : 0.f;
+    far = tmax;
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_ray_aabb(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ aabb,
+           float *__restrict__ t_min, float *__restrict__ t_max, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float o[3] = {rays_o[3ull * i], rays_o[3ull * i + 1], rays_o[3ull * i + 2]};
+    const float d[3] = {rays_d[3ull * i], rays_d[3ull * i + 1], rays_d[3ull * i + 2]};
+    const float bb[6] = {aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5]};
+    float a, b;
+    aabb_one(o, d, bb, a, b);
+    t_min[i] = a;
+    t_max[i] = b;
+}
+
+__device__ __forceinline__ void roi_to_unit(const float *p, const Roi &r, float *u)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] = (p[k] - r.lo[k]) / (r.hi[k] - r.lo[k]);
+}
+
+__device__ __forceinline__ void apply_contraction(const float *p, const Roi &r, int type, float *u)
+{
+    roi_to_unit(p, r, u);
+    if (type == NSR_CONTRACT_UN_BOUNDED_SPHERE) {
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = u[k] * 2.f - 1.f;
+        const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (n > 1.f) {
+            const float s = 2.f - 1.f / n;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = s * (v[k] / n);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = v[k] * 0.25f + 0.5f;
+    } else if (type == NSR_CONTRACT_UN_BOUNDED_TANH) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = tanhf((u[k] - 0.5f) * 1.0986122886681098f) * 0.5f + 0.5f;
+    }
+}
+
+__device__ __forceinline__ void apply_contraction_inv(const float *u, const Roi &r, int type, float *p)
+{
+    float w[3] = {u[0], u[1], u[2]};
+    if (type == NSR_CONTRACT_UN_BOUNDED_SPHERE) {
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = (u[k] - 0.5f) * 4.f;
+        const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (n > 1.f) {
+            const float s = 1.f / (2.f - n);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = (v[k] / n) * s;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] = v[k] * 0.5f + 0.5f;
+    } else if (type == NSR_CONTRACT_UN_BOUNDED_TANH) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = clampf((u[k] - 0.5f) * 2.f, -1.f + 1e-6f, 1.f - 1e-6f);
+            w[k] = atanhf(t) / 1.0986122886681098f + 0.5f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = w[k] * (r.hi[k] - r.lo[k]) + r.lo[k];
+}
+
+__device__ __forceinline__ int grid_idx_at(const float *u, const int3 res)
+{
+    int ix = (int)(u[0] * (float)res.x), iy = (int)(u[1] * (float)res.y), iz = (int)(u[2] * (float)res.z);
+    ix = min(max(ix, 0), res.x - 1);
+    iy = min(max(iy, 0), res.y - 1);
+    iz = min(max(iz, 0), res.z - 1);
+    return ix * res.y * res.z + iy * res.z + iz;
+}
+
+__device__ __forceinline__ bool outside_roi(const float *p, const Roi &r)
+{
+    return p[0] < r.lo[0] || p[0] > r.hi[0] || p[1] < r.lo[1] || p[1] > r.hi[1] || p[2] < r.lo[2] || p[2] > r.hi[2];
+}
+
+__device__ __forceinline__ bool grid_occupied_at(const float *p, const Roi &r, int type, const int3 res,
+                                                 const uint8_t *__restrict__ grid)
+{
+    if (type == NSR_CONTRACT_AABB && outside_roi(p, r)) return false;
+    float u[3];
+    apply_contraction(p, r, type, u);
+    return grid[grid_idx_at(u, res)] != 0;
+}
+
+__device__ __forceinline__ float calc_dt(float t, float cone_angle, float dt_min, float dt_max)
+{
+    return clampf(t * cone_angle, dt_min, dt_max);
+}
+
+__device__ __forceinline__ float distance_to_next_voxel(const float *p, const float *d, const float *inv_d,
+                                                        const Roi &r, const int3 res)
+{
+    float u[3];
+    roi_to_unit(p, r, u);
+    const float rr[3] = {(float)res.x, (float)res.y, (float)res.z};
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x = u[k] * rr[k];
+        const float tk = ((floorf(x + 0.5f + 0.5f * signf(d[k])) - x) * inv_d[k]) / rr[k] * (r.hi[k] - r.lo[k]);
+        t = (k == 0) ? tk : fminf(t, tk);
+    }
+    return fmaxf(t, 0.f);
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(MARCH_BLOCK)
+k_ray_march(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ t_min,
+            const float *__restrict__ t_max, const float *__restrict__ roi, const uint8_t *__restrict__ grid,
+            int3 res, int type, float step, float cone_angle, const int32_t *__restrict__ packed_info,
+            int32_t *__restrict__ num_steps, int64_t *__restrict__ ray_indices, float *__restrict__ t_starts,
+            float *__restrict__ t_ends, uint32_t n_rays)
+{
+    const uint32_t i = blockIdx.x * MARCH_BLOCK + threadIdx.x;
+    if (i >= n_rays) return;
+    Roi r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = roi[k]; r.hi[k] = roi[3 + k]; }
+    const float o[3] = {rays_o[3ull * i], rays_o[3ull * i + 1], rays_o[3ull * i + 2]};
+    const float d[3] = {rays_d[3ull * i], rays_d[3ull * i + 1], rays_d[3ull * i + 2]};
+    const float inv_d[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
+    const float near = t_min[i], far = t_max[i];
+    const float dt_min = step, dt_max = 1e10f;
+    int64_t base = 0;
+    if (WRITE) base = packed_info[2ull * i];
+
+    int j = 0;
+    float t0 = near;
+    float dt = calc_dt(t0, cone_angle, dt_min, dt_max);
+    float t1 = t0 + dt;
+    float t_mid = (t0 + t1) * 0.5f;
+    while (t_mid < far) {
+        const float p[3] = {__builtin_fmaf(t_mid, d[0], o[0]), __builtin_fmaf(t_mid, d[1], o[1]),
+                            __builtin_fmaf(t_mid, d[2], o[2])};
+        if (grid_occupied_at(p, r, type, res, grid)) {
+            if (WRITE) {
+                t_starts[base + j] = t0;
+                t_ends[base + j] = t1;
+                ray_indices[base + j] = (int64_t)i;
+            }
+            ++j;
+            t0 = t1;
+            t1 = t0 + calc_dt(t0, cone_angle, dt_min, dt_max);
+            t_mid = (t0 + t1) * 0.5f;
+        } else if (type == NSR_CONTRACT_AABB) {
+            const float t_target = t_mid + distance_to_next_voxel(p, d, inv_d, r, res);
+            do { t_mid += dt_min; } while (t_mid < t_target);
+            dt = calc_dt(t_mid, cone_angle, dt_min, dt_max);
+            t0 = t_mid - dt * 0.5f;
+            t1 = t_mid + dt * 0.5f;
+        } else {
+            t0 = t1;
+            t1 = t0 + calc_dt(t0, cone_angle, dt_min, dt_max);
+            t_mid = (t0 + t1) * 0.5f;
+        }
+    }
+    if (!WRITE) num_steps[i] = j;
+}
+
+// exclusive scan of per-ray counts by ONE workgroup (n_rays is a few thousand): 1024 lanes, each owns a
+// contiguous chunk; wave scan + LDS across the 16 waves.  Removes torch.cumsum + stack from the step.
+__global__ void __launch_bounds__(1024)
+k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ packed, int32_t *__restrict__ total,
+                   uint32_t n)
+{
+    __shared__ int32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, chunk = (n + 1023) / 1024;
+    const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    int32_t s = 0;
+    for (uint32_t k = lo; k < hi; ++k) s += counts[k];
+    // inclusive scan of s across the block
+    int32_t v = s;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    if (lane == 63) wave_tot[w] = v;
+    __syncthreads();
+    int32_t prefix = 0;
+    for (int k = 0; k < w; ++k) prefix += wave_tot[k];
+    int32_t run = prefix + v - s;  // exclusive prefix of this lane's chunk
+    for (uint32_t k = lo; k < hi; ++k) {
+        const int32_t c = counts[k];
+        packed[2ull * k] = run;
+        packed[2ull * k + 1] = c;
+        run += c;
+    }
+    if (tid == 1023) total[0] = prefix + v;
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_pack_info(const int64_t *__restrict__ ray_indices, int32_t *__restrict__ packed, uint32_t n, uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (r >= n_rays) return;
+    // lower_bound(r) and lower_bound(r+1) on the sorted ray_indices
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (ray_indices[m] < (int64_t)r) lo = m + 1; else hi = m; }
+    const uint32_t a = lo;
+    hi = n;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (ray_indices[m] <= (int64_t)r) lo = m + 1; else hi = m; }
+    packed[2ull * r] = (int32_t)a;
+    packed[2ull * r + 1] = (int32_t)(lo - a);
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(EW_BLOCK)
+k_contract(const float *__restrict__ x, const float *__restrict__ roi, int type, float *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Roi r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = roi[k]; r.hi[k] = roi[3 + k]; }
+    const float p[3] = {x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]};
+    float q[3];
+    if (INV) apply_contraction_inv(p, r, type, q);
+    else apply_contraction(p, r, type, q);
+    out[3ull * i] = q[0]; out[3ull * i + 1] = q[1]; out[3ull * i + 2] = q[2];
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_grid_query_u8(const float *__restrict__ x, const float *__restrict__ roi, const uint8_t *__restrict__ grid, int3 res,
+                int type, uint8_t *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Roi r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = roi[k]; r.hi[k] = roi[3 + k]; }
+    const float p[3] = {x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]};
+    out[i] = grid_occupied_at(p, r, type, res, grid) ? 1 : 0;
+}
+
+// ---- order-preserving stream compaction (the boolean mask after render_visibility) ---------------
+// pass 1: per-block kept counts; pass 2 (single block): exclusive scan of block counts; pass 3: scatter.
+constexpr int CP_BLOCK = 256;
+
+__device__ __forceinline__ int block_excl_scan(int v, int *lds /*[4]*/, int &block_total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    int prefix = 0;
+    for (int k = 0; k < w; ++k) prefix += lds[k];
+    block_total = lds[0] + lds[1] + lds[2] + lds[3];
+    return prefix + inc - v;
+}
+
+__global__ void __launch_bounds__(CP_BLOCK)
+k_compact_count(const uint8_t *__restrict__ mask, int32_t *__restrict__ block_counts, uint32_t n)
+{
+    __shared__ int lds[4];
+    const uint32_t i = blockIdx.x * CP_BLOCK + threadIdx.x;
+    const int keep = (i < n && mask[i]) ? 1 : 0;
+    int tot;
+    block_excl_scan(keep, lds, tot);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024)
+k_compact_scan_blocks(int32_t *__restrict__ block_counts, int32_t *__restrict__ n_kept, uint32_t n_blocks)
+{
+    __shared__ int32_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, chunk = (n_blocks + 1023) / 1024;
+    const uint32_t lo = min(tid * chunk, n_blocks), hi = min(lo + chunk, n_blocks);
+    int32_t s = 0;
+    for (uint32_t k = lo; k < hi; ++k) s += block_counts[k];
+    int32_t v = s;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    if (lane == 63) wave_tot[w] = v;
+    __syncthreads();
+    int32_t prefix = 0;
+    for (int k = 0; k < w; ++k) prefix += wave_tot[k];
+    int32_t run = prefix + v - s;
+    for (uint32_t k = lo; k < hi; ++k) {
+        const int32_t c = block_counts[k];
+        block_counts[k] = run;
+        run += c;
+    }
+    if (tid == 1023) n_kept[0] = prefix + v;
+}
+
+__global__ void __launch_bounds__(CP_BLOCK)
+k_compact_scatter(const uint8_t *__restrict__ mask, const int32_t *__restrict__ block_offsets,
+                  const int64_t *__restrict__ ri, const float *__restrict__ t0, const float *__restrict__ t1,
+                  int64_t *__restrict__ ri_o, float *__restrict__ t0_o, float *__restrict__ t1_o, uint32_t n)
+{
+    __shared__ int lds[4];
+    const uint32_t i = blockIdx.x * CP_BLOCK + threadIdx.x;
+    const int keep = (i < n && mask[i]) ? 1 : 0;
+    int tot;
+    const int pos = block_excl_scan(keep, lds, tot);
+    if (keep) {
+        const uint32_t dst = (uint32_t)block_offsets[blockIdx.x] + (uint32_t)pos;
+        ri_o[dst] = ri[i];
+        t0_o[dst] = t0[i];
+        t1_o[dst] = t1[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int nsr_ray_aabb_intersect(const float *rays_o, const float *rays_d, const float *aabb, float *t_min,
+                                      float *t_max, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(rays_o && rays_d && aabb && t_min && t_max, "nsr_ray_aabb_intersect: NULL pointer");
+    hipLaunchKernelGGL(k_ray_aabb, dim3(nsr_div_up(n_rays, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, rays_o,
+                       rays_d, aabb, t_min, t_max, n_rays);
+    NSR_CHECK_LAUNCH("nsr_ray_aabb_intersect");
+    return NSR_OK;
+}
+
+static int check_march(const void *a, const void *b, const void *c, const void *d, const void *e, const void *f,
+                       int rx, int ry, int rz, int type, float step)
+{
+    NSR_REQUIRE(a && b && c && d && e && f, "nsr_ray_march: NULL pointer");
+    NSR_REQUIRE(rx > 0 && ry > 0 && rz > 0, "nsr_ray_march: bad grid resolution %d %d %d", rx, ry, rz);
+    NSR_REQUIRE(type >= 0 && type <= 2, "nsr_ray_march: bad contraction type %d", type);
+    NSR_REQUIRE(step > 0.f, "nsr_ray_march: render_step_size must be > 0");
+    return NSR_OK;
+}
+
+extern "C" int nsr_ray_march_count(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                                   const float *roi, const uint8_t *grid_binary, int res_x, int res_y, int res_z,
+                                   int contraction, float step_size, float cone_angle, int32_t *num_steps,
+                                   uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    if (int rc = check_march(rays_o, rays_d, t_min, t_max, roi, grid_binary, res_x, res_y, res_z, contraction, step_size))
+        return rc;
+    NSR_REQUIRE(num_steps, "nsr_ray_march_count: num_steps is NULL");
+    hipLaunchKernelGGL((k_ray_march<false>), dim3(nsr_div_up(n_rays, MARCH_BLOCK)), dim3(MARCH_BLOCK), 0,
+                       (hipStream_t)stream, rays_o, rays_d, t_min, t_max, roi, grid_binary,
+                       make_int3(res_x, res_y, res_z), contraction, step_size, cone_angle, (const int32_t *)nullptr,
+                       num_steps, (int64_t *)nullptr, (float *)nullptr, (float *)nullptr, n_rays);
+    NSR_CHECK_LAUNCH("nsr_ray_march_count");
+    return NSR_OK;
+}
+
+extern "C" int nsr_ray_march_write(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                                   const float *roi, const uint8_t *grid_binary, int res_x, int res_y, int res_z,
+                                   int contraction, float step_size, float cone_angle, const int32_t *packed_info,
+                                   int64_t *ray_indices, float *t_starts, float *t_ends, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    if (int rc = check_march(rays_o, rays_d, t_min, t_max, roi, grid_binary, res_x, res_y, res_z, contraction, step_size))
+        return rc;
+    NSR_REQUIRE(packed_info && ray_indices && t_starts && t_ends, "nsr_ray_march_write: NULL output");
+    hipLaunchKernelGGL((k_ray_march<true>), dim3(nsr_div_up(n_rays, MARCH_BLOCK)), dim3(MARCH_BLOCK), 0,
+                       (hipStream_t)stream, rays_o, rays_d, t_min, t_max, roi, grid_binary,
+                       make_int3(res_x, res_y, res_z), contraction, step_size, cone_angle, packed_info,
+                       (int32_t *)nullptr, ray_indices, t_starts, t_ends, n_rays);
+    NSR_CHECK_LAUNCH("nsr_ray_march_write");
+    return NSR_OK;
+}
+
+extern "C" int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
+                                    void *stream)
+{
+    NSR_REQUIRE(total, "nsr_pack_from_counts: total is NULL");
+    NSR_REQUIRE(n_rays == 0 || (num_steps && packed_info), "nsr_pack_from_counts: NULL pointer");
+    hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, num_steps, packed_info, total,
+                       n_rays);
+    NSR_CHECK_LAUNCH("nsr_pack_from_counts");
+    return NSR_OK;
+}
+
+extern "C" int nsr_pack_info(const int64_t *ray_indices, int32_t *packed_info, uint32_t n, uint32_t n_rays,
+                             void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && (n == 0 || ray_indices), "nsr_pack_info: NULL pointer");
+    hipLaunchKernelGGL(k_pack_info, dim3(nsr_div_up(n_rays, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       ray_indices, packed_info, n, n_rays);
+    NSR_CHECK_LAUNCH("nsr_pack_info");
+    return NSR_OK;
+}
+
+extern "C" int nsr_contract(const float *x, const float *roi, int contraction, float *out, uint32_t n, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && roi && out, "nsr_contract: NULL pointer");
+    hipLaunchKernelGGL((k_contract<false>), dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x,
+                       roi, contraction, out, n);
+    NSR_CHECK_LAUNCH("nsr_contract");
+    return NSR_OK;
+}
+
+extern "C" int nsr_contract_inv(const float *x, const float *roi, int contraction, float *out, uint32_t n,
+                                void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && roi && out, "nsr_contract_inv: NULL pointer");
+    hipLaunchKernelGGL((k_contract<true>), dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, roi,
+                       contraction, out, n);
+    NSR_CHECK_LAUNCH("nsr_contract_inv");
+    return NSR_OK;
+}
+
+extern "C" int nsr_grid_query_u8(const float *x, const float *roi, const uint8_t *grid, int res_x, int res_y,
+                                 int res_z, int contraction, uint8_t *out, uint32_t n, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && roi && grid && out, "nsr_grid_query_u8: NULL pointer");
+    hipLaunchKernelGGL(k_grid_query_u8, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, roi,
+                       grid, make_int3(res_x, res_y, res_z), contraction, out, n);
+    NSR_CHECK_LAUNCH("nsr_grid_query_u8");
+    return NSR_OK;
+}
+
+extern "C" int nsr_compact_samples(const uint8_t *mask, const int64_t *ray_indices, const float *t_starts,
+                                   const float *t_ends, int64_t *ray_indices_out, float *t_starts_out,
+                                   float *t_ends_out, int32_t *n_kept, int32_t *block_scratch, uint32_t n,
+                                   void *stream)
+{
+    NSR_REQUIRE(n_kept && block_scratch, "nsr_compact_samples: NULL scratch");
+    const uint32_t nb = nsr_div_up(n, CP_BLOCK);
+    if (n > 0) {
+        NSR_REQUIRE(mask && ray_indices && t_starts && t_ends && ray_indices_out && t_starts_out && t_ends_out,
+                    "nsr_compact_samples: NULL pointer");
+        hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(CP_BLOCK), 0, (hipStream_t)stream, mask, block_scratch, n);
+    }
+    hipLaunchKernelGGL(k_compact_scan_blocks, dim3(1), dim3(1024), 0, (hipStream_t)stream, block_scratch, n_kept, nb);
+    if (n > 0)
+        hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(CP_BLOCK), 0, (hipStream_t)stream, mask, block_scratch,
+                           ray_indices, t_starts, t_ends, ray_indices_out, t_starts_out, t_ends_out, n);
+    NSR_CHECK_LAUNCH("nsr_compact_samples");
+    return NSR_OK;
+}

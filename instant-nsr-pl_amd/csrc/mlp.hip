@@ -1,0 +1,585 @@
+// Fully fused 64-wide MLP on gfx950 MFMA (replaces tcnn.Network(FullyFusedMLP); reference call sites
+// models/network_utils.py:181,209 ; weight layout documented at models/network_utils.py:142-173).
+//
+// Design (CDNA4-first; NOT tcnn's 128-thread / warp-WMMA / smem-weights tiling):
+//   * everything is computed TRANSPOSED:  H^T = W . X^T  with  v_mfma_f32_16x16x32_f16.
+//     A = 16 weight rows x 32 k, B = 32 k x 16 samples, D = 16 outputs x 16 samples.
+//     In the D layout lane (n = lane&15, g = lane>>4) holds outputs {ob*16 + 4g + r, r<4} of ITS OWN
+//     sample n.  The MFMA reduction index k is a dummy, so the next layer's B operand may enumerate
+//     the hidden units in any order as long as A (the weights) uses the same order: we pick
+//       sigma(kc, g, j) = (2kc + (j>>2))*16 + 4g + (j&3)
+//     i.e. exactly the 8 values lane (n,g) already holds from o-blocks 2kc and 2kc+1.  Activations
+//     therefore NEVER leave the lane's registers between layers: no LDS round trip, no shuffles.
+//   * a wavefront owns all weights of the net in VGPRs (A fragments, permuted by sigma at load time:
+//     72 VGPRs for 32->64->64->16) and streams 16-sample tiles through them (grid-stride).
+//   * fp16 weights/activations, fp32 accumulation (tcnn accumulates in fp16).
+//   * backward: dgrad uses the same trick with W^T fragments; wgrad (dW = dY^T . X, reduction over
+//     samples) needs the sample index on the MFMA k axis, i.e. a 16x16 transpose of what the lanes
+//     hold -- done through a small per-wave LDS tile (b16 scatter, b64 gather), v_mfma_f32_16x16x16_f16
+//     with K = the 16 samples of the tile, dW accumulated in fp32 VGPRs over all tiles of the wave,
+//     reduced across the block with ds_add_f32, written as one fp32 partial per block and summed by a
+//     tiny second kernel (deterministic, no global atomics).
+#include "nsr_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MLP_BLOCK = 256;
+constexpr int WAVES = MLP_BLOCK / 64;
+constexpr int WIDTH = 64;
+
+__device__ __forceinline__ f32x4 mfma32(half8 a, half8 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(half4 a, half4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int sigma(int kc, int g, int j) { return (2 * kc + (j >> 2)) * 16 + 4 * g + (j & 3); }
+
+// A fragment of a row-major [rows, ld] half matrix W for output block ob, k-chunk kc.
+//   natural: k = kc*32 + 8g + j        (first layer: B comes from memory in natural order)
+//   permuted: k = sigma(kc, g, j)      (hidden layers: B is the previous layer's D registers)
+__device__ __forceinline__ half8 load_a_natural(const _Float16 *__restrict__ W, int ld, int row, int kc, int g, int kmax)
+{
+    half8 a;
+    const int k0 = kc * 32 + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        a[j] = (k < kmax) ? W[row * ld + k] : (_Float16)0;
+    }
+    return a;
+}
+__device__ __forceinline__ half8 load_a_sigma(const _Float16 *__restrict__ W, int ld, int row, int kc, int g)
+{
+    half8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = W[row * ld + sigma(kc, g, j)];
+    return a;
+}
+// transposed fragments (dgrad): A[i][k] = W[k_index][i]
+__device__ __forceinline__ half8 load_at_sigma(const _Float16 *__restrict__ W, int ld, int col, int kc, int g)
+{
+    half8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = W[sigma(kc, g, j) * ld + col];
+    return a;
+}
+__device__ __forceinline__ half8 load_at_natural(const _Float16 *__restrict__ W, int ld, int col, int g, int kmax)
+{
+    half8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        a[j] = (k < kmax) ? W[k * ld + col] : (_Float16)0;
+    }
+    return a;
+}
+
+// pack two D-layout accumulators (o-blocks 2kc, 2kc+1) into the next layer's B fragment
+__device__ __forceinline__ half8 pack_b(const f32x4 &lo, const f32x4 &hi)
+{
+    half8 b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b[r] = (_Float16)lo[r]; b[4 + r] = (_Float16)hi[r]; }
+    return b;
+}
+
+// 8 consecutive input columns [c0, c0+8) of one sample row as fp16 (columns >= n_in are the constant 1)
+__device__ __forceinline__ half8 load_x8(const void *__restrict__ x, bool x_f32, uint64_t row_off, int c0, int n_in,
+                                         int in_pad, bool valid)
+{
+    half8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (_Float16)0;
+    if (!valid || c0 >= in_pad) return b;
+    if (!x_f32 && c0 + 8 <= n_in && ((row_off + c0) & 7) == 0) {
+        b = *reinterpret_cast<const half8 *>(reinterpret_cast<const __half *>(x) + row_off + c0);
+        return b;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        if (c < n_in)
+            b[j] = x_f32 ? (_Float16) reinterpret_cast<const float *>(x)[row_off + c]
+                         : reinterpret_cast<const _Float16 *>(x)[row_off + c];
+        else if (c < in_pad)
+            b[j] = (_Float16)1;
+    }
+    return b;
+}
+
+// 4 consecutive columns (D layout) as fp32
+__device__ __forceinline__ f32x4 load_x4(const void *__restrict__ x, bool x_f32, uint64_t row_off, int c0, int n_in,
+                                         int in_pad, bool valid)
+{
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!valid) return v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = c0 + r;
+        if (c < n_in)
+            v[r] = x_f32 ? reinterpret_cast<const float *>(x)[row_off + c]
+                         : __half2float(reinterpret_cast<const __half *>(x)[row_off + c]);
+        else if (c < in_pad)
+            v[r] = 1.f;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void store_h4(__half *p, const f32x4 &v)
+{
+    __half2 h[2] = {__floats2half2_rn(v[0], v[1]), __floats2half2_rn(v[2], v[3])};
+    *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<uint2 *>(h);
+}
+__device__ __forceinline__ f32x4 load_h4(const __half *p)
+{
+    const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+    const __half2 a = *reinterpret_cast<const __half2 *>(&raw.x), b = *reinterpret_cast<const __half2 *>(&raw.y);
+    f32x4 v = {__low2float(a), __high2float(a), __low2float(b), __high2float(b)};
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int KIN /* in_pad/16 */, int NH>
+__global__ void __launch_bounds__(MLP_BLOCK)
+k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __half *__restrict__ W_,
+              __half *__restrict__ out, __half *__restrict__ acts, uint32_t n, uint32_t n_in, int out_act)
+{
+    constexpr int IN_PAD = KIN * 16;
+    constexpr int KC0 = (IN_PAD + 31) / 32;
+    const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4;
+    const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
+    const uint32_t n_tiles = (n + 15) / 16;
+    const _Float16 *W = reinterpret_cast<const _Float16 *>(W_);
+
+    // ---- weights -> registers ----
+    half8 a0[4][KC0];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int kc = 0; kc < KC0; ++kc) a0[ob][kc] = load_a_natural(W, IN_PAD, ob * 16 + nl, kc, g, IN_PAD);
+    half8 ah[NH > 1 ? NH - 1 : 1][4][2];
+#pragma unroll
+    for (int h = 0; h < NH - 1; ++h) {
+        const _Float16 *Wh = W + WIDTH * IN_PAD + h * WIDTH * WIDTH;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) ah[h][ob][kc] = load_a_sigma(Wh, WIDTH, ob * 16 + nl, kc, g);
+    }
+    const _Float16 *Wl = W + WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH;
+    half8 al[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) al[kc] = load_a_sigma(Wl, WIDTH, nl, kc, g);
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t s = tile * 16 + nl;
+        const bool valid = s < n;
+        const uint64_t row = (uint64_t)s * x_stride;
+        f32x4 acc[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC0; ++kc) {
+            const half8 b = load_x8(x, x_f32 != 0, row, kc * 32 + 8 * g, (int)n_in, IN_PAD, valid);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma32(a0[ob][kc], b, acc[ob]);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            // ReLU, save, repack as next B
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ob][r] = fmaxf(acc[ob][r], 0.f);
+                if (acts && valid) store_h4(acts + ((uint64_t)h * n + s) * WIDTH + ob * 16 + 4 * g, acc[ob]);
+            }
+            const half8 b0 = pack_b(acc[0], acc[1]), b1 = pack_b(acc[2], acc[3]);
+            if (h < NH - 1) {
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma32(ah[h][ob][0], b0, c);
+                    acc[ob] = mfma32(ah[h][ob][1], b1, c);
+                }
+            } else {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                c = mfma32(al[0], b0, c);
+                c = mfma32(al[1], b1, c);
+                if (out_act == NSR_ACT_SIGMOID) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = 1.f / (1.f + __expf(-c[r]));
+                }
+                if (valid) store_h4(out + (uint64_t)s * 16 + 4 * g, c);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (dgrad + wgrad)
+// ------------------------------------------------------------------------------------------------
+constexpr int TROW = 20;  // halfs per row of the transposed [64][16] tile (40 B: conflict-free b16 scatter)
+
+// scatter a D-layout value set (lane (n,g): cols cb*16+4g+r) into the transposed tile T[col][n]
+__device__ __forceinline__ void lds_scatter(_Float16 *T, int cb, int g, int nl, const f32x4 &v)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[(cb * 16 + 4 * g + r) * TROW + nl] = (_Float16)v[r];
+}
+// gather the wgrad fragment: lane (c = lane&15, g) <- T[cb*16 + c][4g .. 4g+3]
+__device__ __forceinline__ half4 lds_gather(const _Float16 *T, int cb, int g, int nl)
+{
+    return *reinterpret_cast<const half4 *>(T + (cb * 16 + nl) * TROW + 4 * g);
+}
+
+template <int KIN, int NH>
+__global__ void __launch_bounds__(MLP_BLOCK)
+k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, const __half *__restrict__ out,
+               const void *__restrict__ x, int x_f32, uint32_t x_stride, const __half *__restrict__ acts,
+               const __half *__restrict__ W_, float *__restrict__ dx, uint32_t dx_stride, float *__restrict__ partials,
+               uint32_t n, uint32_t n_in, uint32_t n_out, int out_act, float grad_scale, int need_dw)
+{
+    constexpr int IN_PAD = KIN * 16;
+    constexpr int N_PARAMS = WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH + 16 * WIDTH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds_dw = reinterpret_cast<float *>(smem);                                  // [N_PARAMS]
+    _Float16 *lds_t = reinterpret_cast<_Float16 *>(smem + sizeof(float) * N_PARAMS);  // per wave: 2 tiles
+    const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    _Float16 *TP = lds_t + wv * (2 * 64 * TROW);  // dY^T tile  [64][TROW]
+    _Float16 *TQ = TP + 64 * TROW;                // In^T tile  [64][TROW]
+    const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
+    const uint32_t n_tiles = (n + 15) / 16;
+
+    const _Float16 *W = reinterpret_cast<const _Float16 *>(W_);
+    if (need_dw) {
+        for (int k = threadIdx.x; k < N_PARAMS; k += MLP_BLOCK) lds_dw[k] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- transposed weight fragments for dgrad ----
+    const _Float16 *Wl = W + WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH;  // [16, 64]
+    half8 atl[4];  // dH^T(64 x n) = Wl^T (64 x 16) . dOut^T : K = 16 real (upper half of K=32 is zero)
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) atl[ib] = load_at_natural(Wl, WIDTH, ib * 16 + nl, g, 16);
+    half8 ath[NH > 1 ? NH - 1 : 1][4][2];
+#pragma unroll
+    for (int h = 0; h < NH - 1; ++h) {
+        const _Float16 *Wh = W + WIDTH * IN_PAD + h * WIDTH * WIDTH;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) ath[h][ib][kc] = load_at_sigma(Wh, WIDTH, ib * 16 + nl, kc, g);
+    }
+    half8 at0[KIN][2];
+    if (dx) {
+#pragma unroll
+        for (int ib = 0; ib < KIN; ++ib)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) at0[ib][kc] = load_at_sigma(W, IN_PAD, ib * 16 + nl, kc, g);
+    }
+
+    // ---- fp32 weight-gradient accumulators (D layout of dW blocks: lane (c,g): dW[ob*16+4g+r][kb*16+c]) ----
+    f32x4 dw0[4][KIN];
+    f32x4 dwh[NH > 1 ? NH - 1 : 1][4][4];
+    f32x4 dwl[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < KIN; ++b) dw0[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NH - 1; ++h)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dwh[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dwl[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const float inv_scale = 1.f / grad_scale;
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t s = tile * 16 + nl;
+        const bool valid = s < n;
+        // ---- dOut (D layout: cols 4g+r), output-activation derivative, scale ----
+        f32x4 d_o = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t c = 4 * g + r;
+                if (c < n_out) {
+                    const uint64_t off = (uint64_t)s * dout_stride + c;
+                    float v = dout_f32 ? reinterpret_cast<const float *>(dout)[off]
+                                       : __half2float(reinterpret_cast<const __half *>(dout)[off]);
+                    if (out_act == NSR_ACT_SIGMOID) {
+                        const float o = __half2float(out[(uint64_t)s * 16 + c]);
+                        v *= o * (1.f - o);
+                    }
+                    d_o[r] = v * grad_scale;
+                }
+            }
+        }
+        // ---- last layer: wgrad dWl[o][k] += dOut[n][o] * act_{NH-1}[n][k] ; dgrad dH = Wl^T dOut ----
+        f32x4 hact[4];  // post-ReLU activation of the layer feeding the current matrix (D layout)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+            hact[ib] = valid ? load_h4(acts + ((uint64_t)(NH - 1) * n + s) * WIDTH + ib * 16 + 4 * g)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (need_dw) {
+            lds_scatter(TP, 0, g, nl, d_o);
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) lds_scatter(TQ, ib, g, nl, hact[ib]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const half4 pa = lds_gather(TP, 0, g, nl);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dwl[kb] = mfma16(pa, lds_gather(TQ, kb, g, nl), dwl[kb]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // B fragment of dOut^T: k = 8g+j real for k<16 -> lanes g<2 hold cols 8g..8g+7.  We have cols 4g+r
+        // (D layout); rebuild the natural fragment through the LDS tile we may have just written, or
+        // cheaper: gather with shuffles from lanes (n, 2g') / (n, 2g'+1).
+        half8 bo;
+        {
+            // lane (n,g) needs cols 8g+j, j<8, g<2: from lane (n, 2g) regs r=j (j<4) and lane (n, 2g+1) regs r=j-4
+            const int src_lo = nl + 16 * ((2 * g) & 3), src_hi = nl + 16 * ((2 * g + 1) & 3);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float lo = __shfl(d_o[r], src_lo, 64), hi = __shfl(d_o[r], src_hi, 64);
+                bo[r] = (g < 2) ? (_Float16)lo : (_Float16)0;
+                bo[4 + r] = (g < 2) ? (_Float16)hi : (_Float16)0;
+            }
+        }
+        f32x4 dh[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            dh[ib] = mfma32(atl[ib], bo, c);
+        }
+        // ---- hidden layers, top down ----
+#pragma unroll
+        for (int h = NH - 1; h >= 0; --h) {
+            // ReLU backward with the saved post-activation of layer h
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[ib][r] = hact[ib][r] > 0.f ? dh[ib][r] : 0.f;
+            // input of matrix h: previous activation (h>0) or x (h==0)
+            f32x4 inp[4];
+            if (h > 0) {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+                    inp[ib] = valid ? load_h4(acts + ((uint64_t)(h - 1) * n + s) * WIDTH + ib * 16 + 4 * g)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < KIN; ++ib)
+                    inp[ib] = load_x4(x, x_f32 != 0, (uint64_t)s * x_stride, ib * 16 + 4 * g, (int)n_in, IN_PAD, valid);
+            }
+            if (need_dw) {
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) lds_scatter(TP, ob, g, nl, dh[ob]);
+                if (h > 0) {
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) lds_scatter(TQ, ib, g, nl, inp[ib]);
+                } else {
+#pragma unroll
+                    for (int ib = 0; ib < KIN; ++ib) lds_scatter(TQ, ib, g, nl, inp[ib]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                half4 pa[4];
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) pa[ob] = lds_gather(TP, ob, g, nl);
+                if (h > 0) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const half4 qb = lds_gather(TQ, kb, g, nl);
+#pragma unroll
+                        for (int ob = 0; ob < 4; ++ob) dwh[h > 0 ? h - 1 : 0][ob][kb] = mfma16(pa[ob], qb, dwh[h > 0 ? h - 1 : 0][ob][kb]);
+                    }
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < KIN; ++kb) {
+                        const half4 qb = lds_gather(TQ, kb, g, nl);
+#pragma unroll
+                        for (int ob = 0; ob < 4; ++ob) dw0[ob][kb] = mfma16(pa[ob], qb, dw0[ob][kb]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // dgrad to the layer below
+            const half8 b0 = pack_b(dh[0], dh[1]), b1 = pack_b(dh[2], dh[3]);
+            if (h > 0) {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma32(ath[h > 0 ? h - 1 : 0][ib][0], b0, c);
+                    dh[ib] = mfma32(ath[h > 0 ? h - 1 : 0][ib][1], b1, c);
+                    hact[ib] = inp[ib];
+                }
+            } else if (dx) {
+#pragma unroll
+                for (int ib = 0; ib < KIN; ++ib) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma32(at0[ib][0], b0, c);
+                    c = mfma32(at0[ib][1], b1, c);
+                    if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t col = ib * 16 + 4 * g + r;
+                            if (col < n_in) dx[(uint64_t)s * dx_stride + col] = c[r] * inv_scale;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (!need_dw) return;
+    // ---- block reduction of dW in LDS (ds_add_f32), then one fp32 partial per block ----
+    // D layout of a dW block: lane (c = nl, g) holds dW[ob*16 + 4g + r][kb*16 + c]
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+#pragma unroll
+        for (int kb = 0; kb < KIN; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&lds_dw[(ob * 16 + 4 * g + r) * IN_PAD + kb * 16 + nl], dw0[ob][kb][r]);
+#pragma unroll
+        for (int h = 0; h < NH - 1; ++h)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    atomicAdd(&lds_dw[WIDTH * IN_PAD + h * WIDTH * WIDTH + (ob * 16 + 4 * g + r) * WIDTH + kb * 16 + nl],
+                              dwh[h][ob][kb][r]);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            atomicAdd(&lds_dw[WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH + (4 * g + r) * WIDTH + kb * 16 + nl], dwl[kb][r]);
+    __syncthreads();
+    float *dst = partials + (uint64_t)blockIdx.x * N_PARAMS;
+    for (int k = threadIdx.x; k < N_PARAMS; k += MLP_BLOCK) dst[k] = lds_dw[k];
+}
+
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float *__restrict__ partials, float *__restrict__ grad, uint32_t n_params, uint32_t n_blocks,
+                  float inv_scale)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_params) return;
+    float s = 0.f;
+    for (uint32_t b = 0; b < n_blocks; ++b) s += partials[(uint64_t)b * n_params + k];
+    grad[k] += s * inv_scale;
+}
+
+int check_mlp(const NsrMlpDesc *d, const char *who)
+{
+    NSR_REQUIRE(d != nullptr, "%s: desc is NULL", who);
+    NSR_REQUIRE(d->in_pad % 16 == 0 && d->in_pad >= 16 && d->in_pad <= 64, "%s: in_pad=%u unsupported (16..64)", who,
+                d->in_pad);
+    NSR_REQUIRE(d->n_in >= 1 && d->n_in <= d->in_pad, "%s: n_in=%u > in_pad=%u", who, d->n_in, d->in_pad);
+    NSR_REQUIRE(d->out_pad == 16, "%s: out_pad=%u unsupported (only 16)", who, d->out_pad);
+    NSR_REQUIRE(d->n_out >= 1 && d->n_out <= d->out_pad, "%s: n_out=%u > out_pad", who, d->n_out);
+    NSR_REQUIRE(d->n_hidden >= 1 && d->n_hidden <= 4, "%s: n_hidden_layers=%u unsupported (1..4)", who, d->n_hidden);
+    NSR_REQUIRE(d->output_activation <= NSR_ACT_SIGMOID, "%s: unknown output activation %u", who, d->output_activation);
+    return NSR_OK;
+}
+
+uint32_t n_params_of(const NsrMlpDesc *d) { return WIDTH * d->in_pad + (d->n_hidden - 1) * WIDTH * WIDTH + 16 * WIDTH; }
+
+uint32_t bwd_blocks(uint32_t n)
+{
+    const uint32_t n_tiles = (n + 15) / 16;
+    uint32_t nb = (n_tiles + WAVES * 8 - 1) / (WAVES * 8);
+    return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+}
+
+}  // namespace
+
+#define DISPATCH_MLP(KIN_, NH_, ...)                                                                     \
+    switch ((KIN_) * 10 + (NH_)) {                                                                       \
+    case 11: { constexpr int KIN = 1, NH = 1; __VA_ARGS__; } break;                                      \
+    case 12: { constexpr int KIN = 1, NH = 2; __VA_ARGS__; } break;                                      \
+    case 13: { constexpr int KIN = 1, NH = 3; __VA_ARGS__; } break;                                      \
+    case 14: { constexpr int KIN = 1, NH = 4; __VA_ARGS__; } break;                                      \
+    case 21: { constexpr int KIN = 2, NH = 1; __VA_ARGS__; } break;                                      \
+    case 22: { constexpr int KIN = 2, NH = 2; __VA_ARGS__; } break;                                      \
+    case 23: { constexpr int KIN = 2, NH = 3; __VA_ARGS__; } break;                                      \
+    case 24: { constexpr int KIN = 2, NH = 4; __VA_ARGS__; } break;                                      \
+    case 31: { constexpr int KIN = 3, NH = 1; __VA_ARGS__; } break;                                      \
+    case 32: { constexpr int KIN = 3, NH = 2; __VA_ARGS__; } break;                                      \
+    case 33: { constexpr int KIN = 3, NH = 3; __VA_ARGS__; } break;                                      \
+    case 34: { constexpr int KIN = 3, NH = 4; __VA_ARGS__; } break;                                      \
+    case 41: { constexpr int KIN = 4, NH = 1; __VA_ARGS__; } break;                                      \
+    case 42: { constexpr int KIN = 4, NH = 2; __VA_ARGS__; } break;                                      \
+    case 43: { constexpr int KIN = 4, NH = 3; __VA_ARGS__; } break;                                      \
+    default: { constexpr int KIN = 4, NH = 4; __VA_ARGS__; } break;                                      \
+    }
+
+extern "C" int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *weights, nsr_half *out,
+                               nsr_half *acts, uint32_t n, const NsrMlpDesc *desc, void *stream)
+{
+    if (int rc = check_mlp(desc, "nsr_mlp_forward")) return rc;
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && weights && out, "nsr_mlp_forward: NULL pointer");
+    NSR_REQUIRE(x_stride >= desc->n_in, "nsr_mlp_forward: x_stride < n_in");
+    const uint32_t n_tiles = (n + 15) / 16;
+    uint32_t blocks = (n_tiles + WAVES * 8 - 1) / (WAVES * 8);
+    if (blocks > 2048) blocks = 2048;
+    DISPATCH_MLP(desc->in_pad / 16, desc->n_hidden,
+                 hipLaunchKernelGGL((k_mlp_forward<KIN, NH>), dim3(blocks), dim3(MLP_BLOCK), 0, (hipStream_t)stream, x,
+                                    x_is_f32, x_stride, (const __half *)weights, (__half *)out, (__half *)acts, n,
+                                    desc->n_in, (int)desc->output_activation));
+    NSR_CHECK_LAUNCH("nsr_mlp_forward");
+    return NSR_OK;
+}
+
+extern "C" uint64_t nsr_mlp_backward_workspace_floats(const NsrMlpDesc *desc, uint32_t n)
+{
+    if (!desc || check_mlp(desc, "nsr_mlp_backward_workspace_floats")) return 0;
+    return (uint64_t)bwd_blocks(n) * n_params_of(desc);
+}
+
+extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, const nsr_half *out,
+                                const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *acts,
+                                const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
+                                float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream)
+{
+    if (int rc = check_mlp(desc, "nsr_mlp_backward")) return rc;
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(dout && x && acts && weights, "nsr_mlp_backward: NULL pointer");
+    NSR_REQUIRE(desc->output_activation == NSR_ACT_NONE || out, "nsr_mlp_backward: sigmoid backward needs `out`");
+    NSR_REQUIRE(!grad_weights || partials, "nsr_mlp_backward: grad_weights needs the partials workspace");
+    NSR_REQUIRE(!dx || dx_stride >= desc->n_in, "nsr_mlp_backward: dx_stride < n_in");
+    NSR_REQUIRE(grad_scale > 0.f, "nsr_mlp_backward: grad_scale must be > 0");
+    const uint32_t nb = bwd_blocks(n), np = n_params_of(desc);
+    const size_t lds = sizeof(float) * np + WAVES * 2 * 64 * TROW * sizeof(_Float16);
+    DISPATCH_MLP(desc->in_pad / 16, desc->n_hidden, {
+        (void)hipFuncSetAttribute((const void *)k_mlp_backward<KIN, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_mlp_backward<KIN, NH>), dim3(nb), dim3(MLP_BLOCK), lds, (hipStream_t)stream, dout,
+                           dout_is_f32, dout_stride, (const __half *)out, x, x_is_f32, x_stride, (const __half *)acts,
+                           (const __half *)weights, dx, dx_stride, partials, n, desc->n_in, desc->n_out,
+                           (int)desc->output_activation, grad_scale, grad_weights ? 1 : 0);
+    });
+    NSR_CHECK_LAUNCH("nsr_mlp_backward");
+    if (grad_weights) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(nsr_div_up(np, 256)), dim3(256), 0, (hipStream_t)stream, partials,
+                           grad_weights, np, nb, 1.f / grad_scale);
+        NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
+    }
+    return NSR_OK;
+}

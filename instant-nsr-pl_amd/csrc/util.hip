@@ -1,0 +1,319 @@
+// Error reporting + the small fused elementwise pieces of the reference glue.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "nsr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void nsr_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *nsr_last_error(void) { return g_err; }
+extern "C" int nsr_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+
+// ---- spherical harmonics, degree 4 (tcnn SphericalHarmonics; reference models/texture.py:25) ----
+__global__ void __launch_bounds__(EW_BLOCK)
+k_sh4(const float *__restrict__ u, __half *__restrict__ out, uint32_t n, uint32_t stride)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x = u[3ull * i] * 2.f - 1.f, y = u[3ull * i + 1] * 2.f - 1.f, z = u[3ull * i + 2] * 2.f - 1.f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float o[16];
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * (x2 - y2);
+    o[9] = 0.59004358992664352f * y * (-3.f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.f - 5.f * z2);
+    o[12] = 0.3731763325901154f * z * (5.f * z2 - 3.f);
+    o[13] = 0.45704579946446572f * x * (1.f - 5.f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.f * y2);
+    __half *p = out + (uint64_t)i * stride;
+    if ((stride & 7u) == 0) {  // 16-byte aligned rows: two 16-B stores
+        __half2 h[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = __floats2half2_rn(o[2 * k], o[2 * k + 1]);
+        reinterpret_cast<uint4 *>(p)[0] = *reinterpret_cast<uint4 *>(&h[0]);
+        reinterpret_cast<uint4 *>(p)[1] = *reinterpret_cast<uint4 *>(&h[4]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p[k] = __float2half_rn(o[k]);
+    }
+}
+
+// ---- contract_to_unisphere (reference models/geometry.py:17-29) ----------------------------------
+__global__ void __launch_bounds__(EW_BLOCK)
+k_contract_to_unisphere(const float *__restrict__ x, float radius, int type, float *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    // scale_anything(x, (-r, r), (0, 1)) = (x + r) / (2r) * 1 + 0
+    const float den = radius - (-radius);
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = (x[3ull * i + k] - (-radius)) / den;
+    if (type == NSR_CONTRACT_UN_BOUNDED_SPHERE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] * 2.f - 1.f;
+        const float mag = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (mag > 1.f) {
+            const float s = 2.f - 1.f / mag;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = s * (v[k] / mag);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] / 4.f + 0.5f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[3ull * i + k] = v[k];
+}
+
+// ---- density = exp(out[:,0] + bias); feature = out (fp32) (reference models/geometry.py:124-129) --
+__global__ void __launch_bounds__(EW_BLOCK)
+k_density_activation(const __half *__restrict__ mlp_out, uint32_t stride, uint32_t n_feat, float bias,
+                     float *__restrict__ density, float *__restrict__ feature, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const __half *p = mlp_out + (uint64_t)i * stride;
+    density[i] = expf(__half2float(p[0]) + bias);
+    if (feature)
+        for (uint32_t k = 0; k < n_feat; ++k) feature[(uint64_t)i * n_feat + k] = __half2float(p[k]);
+}
+
+// ---- sample positions: p = o[r] + d[r] * (t0 + t1) / 2 (reference models/nerf.py:95-99) ----------
+__global__ void __launch_bounds__(EW_BLOCK)
+k_sample_positions(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                   const int64_t *__restrict__ ray_indices, const float *__restrict__ t0,
+                   const float *__restrict__ t1, float *__restrict__ pos, float *__restrict__ dirs, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ray_indices[i];
+    const float tm = (t0[i] + t1[i]) / 2.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float d = rays_d[3 * r + k];
+        // torch evaluates t_dirs * midpoints then adds the origin: two roundings, no fma
+        pos[3ull * i + k] = __fadd_rn(rays_o[3 * r + k], __fmul_rn(d, tm));
+        if (dirs) dirs[3ull * i + k] = d;
+    }
+}
+
+// ---- NeuS SDF -> alpha (reference models/neus.py:117-139) ----------------------------------------
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_neus_alpha_fwd(const float *__restrict__ sdf, const float *__restrict__ normal, const float *__restrict__ dirs,
+                 const float *__restrict__ dists, const float *__restrict__ inv_s_p, float anneal,
+                 float *__restrict__ alpha, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float inv_s = fminf(fmaxf(inv_s_p[0], 1e-6f), 1e6f);
+    const float tc = dirs[3ull * i] * normal[3ull * i] + dirs[3ull * i + 1] * normal[3ull * i + 1] +
+                     dirs[3ull * i + 2] * normal[3ull * i + 2];
+    const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.f) * (1.f - anneal) + fmaxf(-tc, 0.f) * anneal);
+    const float h = ic * dists[i] * 0.5f;
+    const float prev = sigmoidf((sdf[i] - h) * inv_s), next = sigmoidf((sdf[i] + h) * inv_s);
+    const float a = ((prev - next) + 1e-5f) / (prev + 1e-5f);
+    alpha[i] = fminf(fmaxf(a, 0.f), 1.f);
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_neus_alpha_bwd(const float *__restrict__ sdf, const float *__restrict__ normal, const float *__restrict__ dirs,
+                 const float *__restrict__ dists, const float *__restrict__ inv_s_p, float anneal,
+                 const float *__restrict__ g_alpha, float *__restrict__ g_sdf, float *__restrict__ g_normal,
+                 float *__restrict__ g_inv_s, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    float gs_local = 0.f;
+    if (i < n) {
+        const float raw_inv_s = inv_s_p[0];
+        const float inv_s = fminf(fmaxf(raw_inv_s, 1e-6f), 1e6f);
+        const bool s_live = raw_inv_s >= 1e-6f && raw_inv_s <= 1e6f;
+        const float d0 = dirs[3ull * i], d1 = dirs[3ull * i + 1], d2 = dirs[3ull * i + 2];
+        const float tc = d0 * normal[3ull * i] + d1 * normal[3ull * i + 1] + d2 * normal[3ull * i + 2];
+        const float u1 = -tc * 0.5f + 0.5f, u2 = -tc;
+        const float ic = -(fmaxf(u1, 0.f) * (1.f - anneal) + fmaxf(u2, 0.f) * anneal);
+        // d ic / d tc
+        const float dic_dtc = -((u1 > 0.f ? -0.5f : 0.f) * (1.f - anneal) + (u2 > 0.f ? -1.f : 0.f) * anneal);
+        const float dist = dists[i], s = sdf[i];
+        const float h = ic * dist * 0.5f;
+        const float ep = (s - h), en = (s + h);
+        const float prev = sigmoidf(ep * inv_s), next = sigmoidf(en * inv_s);
+        const float num = (prev - next) + 1e-5f, den = prev + 1e-5f;
+        const float a = num / den;
+        float ga = g_alpha[i];
+        if (!(a >= 0.f && a <= 1.f)) ga = 0.f;  // clip(0,1) kills the gradient outside
+        // a = num/den ; d a/d prev = (den - num)/den^2 ; d a/d next = -1/den
+        const float da_dprev = (den - num) / (den * den), da_dnext = -1.f / den;
+        const float gp = ga * da_dprev * prev * (1.f - prev);  // grad w.r.t. (ep*inv_s)
+        const float gn = ga * da_dnext * next * (1.f - next);  // grad w.r.t. (en*inv_s)
+        if (g_sdf) g_sdf[i] = (gp + gn) * inv_s;
+        const float g_h = (-gp + gn) * inv_s;  // ep = s-h, en = s+h
+        const float g_tc = g_h * dist * 0.5f * dic_dtc;
+        if (g_normal) {
+            g_normal[3ull * i] = g_tc * d0; g_normal[3ull * i + 1] = g_tc * d1; g_normal[3ull * i + 2] = g_tc * d2;
+        }
+        gs_local = s_live ? (gp * ep + gn * en) : 0.f;
+    }
+    if (g_inv_s) {
+        gs_local = wave_sum(gs_local);
+        if ((threadIdx.x & 63) == 0 && gs_local != 0.f) unsafeAtomicAdd(g_inv_s, gs_local);
+    }
+}
+
+// ---- fused AdamW (torch.optim.AdamW semantics) + fp16 shadow refresh + grad zeroing --------------
+__global__ void __launch_bounds__(EW_BLOCK)
+k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+        __half *__restrict__ shadow, uint64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
+        float bc2, float unscale, int zero_grad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 4;
+    for (uint64_t base = ((uint64_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 4; base < n; base += stride) {
+        if (base + 4 <= n) {
+            float4 pp = *reinterpret_cast<float4 *>(p + base), gg = *reinterpret_cast<float4 *>(g + base);
+            float4 mm = *reinterpret_cast<float4 *>(m + base), vv = *reinterpret_cast<float4 *>(v + base);
+            float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gr = ga[k] * unscale;
+                pa[k] *= (1.f - lr * wd);
+                ma[k] = b1 * ma[k] + (1.f - b1) * gr;
+                va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
+                const float denom = sqrtf(va[k]) / sqrtf(bc2) + eps;
+                pa[k] -= (lr / bc1) * (ma[k] / denom);
+            }
+            *reinterpret_cast<float4 *>(p + base) = pp;
+            *reinterpret_cast<float4 *>(m + base) = mm;
+            *reinterpret_cast<float4 *>(v + base) = vv;
+            if (zero_grad) *reinterpret_cast<float4 *>(g + base) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (shadow) {
+                __half2 h[2] = {__floats2half2_rn(pa[0], pa[1]), __floats2half2_rn(pa[2], pa[3])};
+                *reinterpret_cast<uint2 *>(shadow + base) = *reinterpret_cast<uint2 *>(h);
+            }
+        } else {
+            for (uint64_t j = base; j < n; ++j) {
+                const float gr = g[j] * unscale;
+                float pj = p[j] * (1.f - lr * wd);
+                const float mj = b1 * m[j] + (1.f - b1) * gr, vj = b2 * v[j] + (1.f - b2) * gr * gr;
+                pj -= (lr / bc1) * (mj / (sqrtf(vj) / sqrtf(bc2) + eps));
+                p[j] = pj; m[j] = mj; v[j] = vj;
+                if (zero_grad) g[j] = 0.f;
+                if (shadow) shadow[j] = __float2half_rn(pj);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nsr_sh4_forward(const float *u, nsr_half *y, uint32_t n, uint32_t y_stride, void *stream)
+{
+    NSR_REQUIRE(y_stride >= 16, "nsr_sh4_forward: y_stride < 16");
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(u && y, "nsr_sh4_forward: NULL pointer");
+    hipLaunchKernelGGL(k_sh4, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, u, (__half *)y, n,
+                       y_stride);
+    NSR_CHECK_LAUNCH("nsr_sh4_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_contract_to_unisphere(const float *x, float radius, int contraction, float *out, uint32_t n,
+                                         void *stream)
+{
+    NSR_REQUIRE(contraction == NSR_CONTRACT_AABB || contraction == NSR_CONTRACT_UN_BOUNDED_SPHERE,
+                "nsr_contract_to_unisphere: contraction type %d not implemented (reference raises too)", contraction);
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && out, "nsr_contract_to_unisphere: NULL pointer");
+    hipLaunchKernelGGL(k_contract_to_unisphere, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       x, radius, contraction, out, n);
+    NSR_CHECK_LAUNCH("nsr_contract_to_unisphere");
+    return NSR_OK;
+}
+
+extern "C" int nsr_density_activation_forward(const nsr_half *mlp_out, uint32_t stride, uint32_t n_feat, float bias,
+                                              float *density, float *feature, uint32_t n, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(mlp_out && density, "nsr_density_activation_forward: NULL pointer");
+    hipLaunchKernelGGL(k_density_activation, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const __half *)mlp_out, stride, n_feat, bias, density, feature, n);
+    NSR_CHECK_LAUNCH("nsr_density_activation_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_sample_positions(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                                    const float *t_starts, const float *t_ends, float *positions, float *dirs_out,
+                                    uint32_t n, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && positions,
+                "nsr_sample_positions: NULL pointer");
+    hipLaunchKernelGGL(k_sample_positions, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       rays_o, rays_d, ray_indices, t_starts, t_ends, positions, dirs_out, n);
+    NSR_CHECK_LAUNCH("nsr_sample_positions");
+    return NSR_OK;
+}
+
+extern "C" int nsr_neus_alpha_forward(const float *sdf, const float *normal, const float *dirs, const float *dists,
+                                      const float *inv_s, float cos_anneal_ratio, float *alpha, uint32_t n,
+                                      void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(sdf && normal && dirs && dists && inv_s && alpha, "nsr_neus_alpha_forward: NULL pointer");
+    hipLaunchKernelGGL(k_neus_alpha_fwd, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, sdf,
+                       normal, dirs, dists, inv_s, cos_anneal_ratio, alpha, n);
+    NSR_CHECK_LAUNCH("nsr_neus_alpha_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_neus_alpha_backward(const float *sdf, const float *normal, const float *dirs, const float *dists,
+                                       const float *inv_s, float cos_anneal_ratio, const float *grad_alpha,
+                                       float *grad_sdf, float *grad_normal, float *grad_inv_s, uint32_t n,
+                                       void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(sdf && normal && dirs && dists && inv_s && grad_alpha, "nsr_neus_alpha_backward: NULL pointer");
+    hipLaunchKernelGGL(k_neus_alpha_bwd, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, sdf,
+                       normal, dirs, dists, inv_s, cos_anneal_ratio, grad_alpha, grad_sdf, grad_normal, grad_inv_s, n);
+    NSR_CHECK_LAUNCH("nsr_neus_alpha_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, nsr_half *shadow_half,
+                              uint64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad,
+                              void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(params && grad && exp_avg && exp_avg_sq, "nsr_adamw_step: NULL pointer");
+    NSR_REQUIRE((((uintptr_t)params | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "nsr_adamw_step: buffers must be 16-byte aligned");
+    uint64_t blocks = (n / 4 + EW_BLOCK - 1) / EW_BLOCK + 1;
+    if (blocks > 2048) blocks = 2048;  // grid-stride: ~8 blocks per CU
+    hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, params, grad, exp_avg,
+                       exp_avg_sq, (__half *)shadow_half, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
+                       bias_correction2, grad_unscale, zero_grad);
+    NSR_CHECK_LAUNCH("nsr_adamw_step");
+    return NSR_OK;
+}

@@ -1,0 +1,138 @@
+"""ctypes binding of ``libnsr_hip.so`` (the C ABI declared in ``include/nsr_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every compute kernel of the hot
+path is in the shared library.  There is NO CPU fallback: importing this package without the built
+library, or calling an op with a non-GPU tensor, raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsr_hip.so")
+
+NSR_MAX_LEVELS = 32
+ABI_VERSION = 1
+
+
+class NsrGridDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_levels", ctypes.c_uint32),
+        ("n_features", ctypes.c_uint32),
+        ("log2_hashmap_size", ctypes.c_uint32),
+        ("base_resolution", ctypes.c_uint32),
+        ("per_level_scale", ctypes.c_float),
+        ("n_entries", ctypes.c_uint32),
+        ("scale", ctypes.c_float * NSR_MAX_LEVELS),
+        ("resolution", ctypes.c_uint32 * NSR_MAX_LEVELS),
+        ("size", ctypes.c_uint32 * NSR_MAX_LEVELS),
+        ("offset", ctypes.c_uint32 * (NSR_MAX_LEVELS + 1)),
+    ]
+
+
+class NsrMlpDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_in", ctypes.c_uint32),
+        ("in_pad", ctypes.c_uint32),
+        ("n_out", ctypes.c_uint32),
+        ("out_pad", ctypes.c_uint32),
+        ("n_hidden", ctypes.c_uint32),
+        ("output_activation", ctypes.c_uint32),
+    ]
+
+
+_P, _I, _U, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_uint64
+_GD, _MD = ctypes.POINTER(NsrGridDesc), ctypes.POINTER(NsrMlpDesc)
+
+# name -> argtypes  (restype is int unless listed in _RESTYPES); mirrors include/nsr_hip.h one to one
+SIGNATURES = {
+    "nsr_last_error": [],
+    "nsr_abi_version": [],
+    "nsr_hashgrid_make_desc": [_GD, _U, _U, _U, _U, _F],
+    "nsr_hashgrid_forward": [_P, _P, _P, _U, _U, _U, _GD, _P],
+    "nsr_hashgrid_backward_params": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P],
+    "nsr_hashgrid_backward_input": [_P, _P, _P, _I, _U, _P, _U, _U, _GD, _P],
+    "nsr_hashgrid_backward_backward_input": [_P, _P, _P, _I, _U, _P, _P, _U, _P, _P, _U, _U, _GD, _P],
+    "nsr_sh4_forward": [_P, _P, _U, _U, _P],
+    "nsr_mlp_forward": [_P, _I, _U, _P, _P, _P, _U, _MD, _P],
+    "nsr_mlp_backward_workspace_floats": [_MD, _U],
+    "nsr_mlp_backward": [_P, _I, _U, _P, _P, _I, _U, _P, _P, _P, _P, _U, _P, _U, _F, _MD, _P],
+    "nsr_ray_aabb_intersect": [_P, _P, _P, _P, _P, _U, _P],
+    "nsr_ray_march_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _U, _P],
+    "nsr_ray_march_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _U, _P],
+    "nsr_pack_from_counts": [_P, _P, _P, _U, _P],
+    "nsr_pack_info": [_P, _P, _U, _U, _P],
+    "nsr_contract": [_P, _P, _I, _P, _U, _P],
+    "nsr_contract_inv": [_P, _P, _I, _P, _U, _P],
+    "nsr_grid_query_u8": [_P, _P, _P, _I, _I, _I, _I, _P, _U, _P],
+    "nsr_sample_positions": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_transmittance_from_sigma_forward": [_P, _P, _P, _P, _P, _U, _P],
+    "nsr_transmittance_from_sigma_backward": [_P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_transmittance_from_alpha_forward": [_P, _P, _P, _U, _P],
+    "nsr_transmittance_from_alpha_backward": [_P, _P, _P, _P, _P, _U, _P],
+    "nsr_accumulate_along_rays_forward": [_P, _P, _P, _U, _P, _U, _P],
+    "nsr_accumulate_along_rays_backward": [_P, _P, _P, _U, _P, _P, _P, _U, _P],
+    "nsr_compact_samples": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_contract_to_unisphere": [_P, _F, _I, _P, _U, _P],
+    "nsr_density_activation_forward": [_P, _U, _U, _F, _P, _P, _U, _P],
+    "nsr_neus_alpha_forward": [_P, _P, _P, _P, _P, _F, _P, _U, _P],
+    "nsr_neus_alpha_backward": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _U, _P],
+    "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P],
+}
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64}
+
+
+class NsrError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `bash instant-nsr-pl_amd/csrc/build.sh` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    if lib.nsr_abi_version() != ABI_VERSION:
+        raise ImportError(f"libnsr_hip.so ABI {lib.nsr_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = load_library()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise NsrError(f"{what}: rc={rc}: {lib.nsr_last_error().decode()}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a contiguous GPU tensor (None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NsrError("nsr_hip ops need GPU tensors (there is no CPU path in the product library)")
+    if not t.is_contiguous():
+        raise NsrError("nsr_hip ops need contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def make_grid_desc(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale):
+    d = NsrGridDesc()
+    check(lib.nsr_hashgrid_make_desc(ctypes.byref(d), int(n_levels), int(n_features), int(log2_hashmap_size),
+                                     int(base_resolution), float(per_level_scale)), "nsr_hashgrid_make_desc")
+    return d
+
+
+def make_mlp_desc(n_in, n_out, n_hidden, output_activation):
+    pad = lambda v: (v + 15) // 16 * 16  # noqa: E731
+    act = {"none": 0, "sigmoid": 1}[str(output_activation).lower()]
+    return NsrMlpDesc(int(n_in), pad(int(n_in)), int(n_out), pad(int(n_out)), int(n_hidden), act)

@@ -1,0 +1,489 @@
+"""Tensor-level wrappers and autograd Functions over the C ABI (``include/nsr_hip.h``).
+
+Everything here is host-side plumbing: allocate outputs with torch, pass raw pointers + the current HIP
+stream to ``libnsr_hip.so``.  No arithmetic of the hot path happens in Python.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import NsrError, check, lib, ptr, stream_ptr
+
+_byref = ctypes.byref
+F32, F16 = torch.float32, torch.float16
+
+
+def _f32c(t):
+    return t.detach().to(F32).contiguous()
+
+
+def _is_f32(t):
+    if t.dtype == F32:
+        return 1
+    if t.dtype == F16:
+        return 0
+    raise NsrError(f"expected float16/float32 tensor, got {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------
+# hash grid
+# ------------------------------------------------------------------------------------------------
+def hashgrid_forward(x, table_half, desc, mask_count=None, out=None):
+    n = x.shape[0]
+    C = desc.n_levels * desc.n_features
+    y = torch.empty((n, C), dtype=F16, device=x.device) if out is None else out
+    mc = desc.n_levels if mask_count is None else int(mask_count)
+    with torch.cuda.device(x.device):
+        check(lib.nsr_hashgrid_forward(ptr(x), ptr(table_half), ptr(y), n, y.stride(0), mc, _byref(desc),
+                                       stream_ptr()), "nsr_hashgrid_forward")
+    return y
+
+
+def hashgrid_backward_params(x, dy, grad_table, desc, mask_count=None, grad_scale=1.0):
+    mc = desc.n_levels if mask_count is None else int(mask_count)
+    with torch.cuda.device(x.device):
+        check(lib.nsr_hashgrid_backward_params(ptr(x), ptr(dy), _is_f32(dy), dy.stride(0), ptr(grad_table),
+                                               x.shape[0], mc, float(grad_scale), _byref(desc), stream_ptr()),
+              "nsr_hashgrid_backward_params")
+    return grad_table
+
+
+def hashgrid_backward_input(x, table_half, dy, desc, mask_count=None):
+    mc = desc.n_levels if mask_count is None else int(mask_count)
+    dx = torch.empty((x.shape[0], 3), dtype=F32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.nsr_hashgrid_backward_input(ptr(x), ptr(table_half), ptr(dy), _is_f32(dy), dy.stride(0), ptr(dx),
+                                              x.shape[0], mc, _byref(desc), stream_ptr()),
+              "nsr_hashgrid_backward_input")
+    return dx
+
+
+def hashgrid_backward_backward_input(x, table_half, dy, g, desc, mask_count=None, want_d_dy=True,
+                                     grad_table=None, want_dx2=True):
+    mc = desc.n_levels if mask_count is None else int(mask_count)
+    n, C = x.shape[0], desc.n_levels * desc.n_features
+    d_dy = torch.empty((n, C), dtype=F32, device=x.device) if want_d_dy else None
+    dx2 = torch.empty((n, 3), dtype=F32, device=x.device) if want_dx2 else None
+    with torch.cuda.device(x.device):
+        check(lib.nsr_hashgrid_backward_backward_input(
+            ptr(x), ptr(table_half), ptr(dy), _is_f32(dy), dy.stride(0), ptr(g), ptr(d_dy), C, ptr(grad_table),
+            ptr(dx2), n, mc, _byref(desc), stream_ptr()), "nsr_hashgrid_backward_backward_input")
+    return d_dy, dx2
+
+
+class _GridEncode(Function):
+    """y = encode(x; params).  ``owner`` supplies desc / fp16 shadow / progressive mask count."""
+
+    @staticmethod
+    def forward(ctx, x, params, owner):
+        table = owner.table_half(params)
+        mc = owner.level_mask_count()
+        y = hashgrid_forward(x, table, owner.grid_desc, mc)
+        ctx.save_for_backward(x, params)
+        ctx.owner, ctx.table, ctx.mc = owner, table, mc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, params = ctx.saved_tensors
+        need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx, dp = _GridEncodeBackward.apply(ctx.owner, ctx.table, ctx.mc, need_x, need_p, x, params, dy.contiguous())
+        return (dx if need_x else None), (dp if need_p else None), None
+
+
+class _GridEncodeBackward(Function):
+    """First-order backward as a Function so that d(dx)/d{dy, params, x} exists (NeuS eikonal term)."""
+
+    @staticmethod
+    def forward(ctx, owner, table, mc, need_x, need_p, x, params, dy):
+        desc = owner.grid_desc
+        dx = hashgrid_backward_input(x, table, dy, desc, mc) if need_x else torch.zeros_like(x)
+        if need_p:
+            dp = torch.zeros_like(params, dtype=F32)
+            hashgrid_backward_params(x, dy, owner.grid_slice(dp), desc, mc)
+        else:
+            dp = torch.zeros(1, dtype=F32, device=x.device)
+        ctx.save_for_backward(x, params, dy)
+        ctx.owner, ctx.table, ctx.mc = owner, table, mc
+        return dx, dp
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_dx, g_dp):
+        # only the dx branch is differentiated again (tcnn: "bwd_bwd_input"); d(dp)/d* is not needed by
+        # the reference (no second-order term through the parameter gradient).
+        x, params, dy = ctx.saved_tensors
+        owner, desc = ctx.owner, ctx.owner.grid_desc
+        need_x, need_p, need_dy = ctx.needs_input_grad[5], ctx.needs_input_grad[6], ctx.needs_input_grad[7]
+        if g_dx is None or not (need_x or need_p or need_dy):
+            return (None,) * 8
+        g = _f32c(g_dx)
+        dp2 = torch.zeros_like(params, dtype=F32) if need_p else None
+        d_dy, dx2 = hashgrid_backward_backward_input(
+            x, ctx.table, dy, g, desc, ctx.mc, want_d_dy=need_dy,
+            grad_table=owner.grid_slice(dp2) if need_p else None, want_dx2=need_x)
+        if d_dy is not None:
+            d_dy = d_dy.to(dy.dtype)
+        return None, None, None, None, None, dx2, dp2, d_dy
+
+
+def grid_encode(x, params, owner):
+    return _GridEncode.apply(x, params, owner)
+
+
+# ------------------------------------------------------------------------------------------------
+# spherical harmonics
+# ------------------------------------------------------------------------------------------------
+def sh4_forward(u, out=None):
+    n = u.shape[0]
+    y = torch.empty((n, 16), dtype=F16, device=u.device) if out is None else out
+    with torch.cuda.device(u.device):
+        check(lib.nsr_sh4_forward(ptr(u), ptr(y), n, y.stride(0), stream_ptr()), "nsr_sh4_forward")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# fused MLP
+# ------------------------------------------------------------------------------------------------
+def mlp_forward(x, weights_half, desc, save_acts):
+    n = x.shape[0]
+    out = torch.empty((n, desc.out_pad), dtype=F16, device=x.device)
+    acts = torch.empty((desc.n_hidden, n, 64), dtype=F16, device=x.device) if save_acts else None
+    with torch.cuda.device(x.device):
+        check(lib.nsr_mlp_forward(ptr(x), _is_f32(x), x.stride(0), ptr(weights_half), ptr(out), ptr(acts), n,
+                                  _byref(desc), stream_ptr()), "nsr_mlp_forward")
+    return out, acts
+
+
+def mlp_backward(dout, out, x, acts, weights_half, desc, grad_weights=None, want_dx=False, grad_scale=128.0):
+    n = x.shape[0]
+    dx = torch.empty((n, desc.n_in), dtype=F32, device=x.device) if want_dx else None
+    partials = None
+    if grad_weights is not None:
+        nws = lib.nsr_mlp_backward_workspace_floats(_byref(desc), n)
+        partials = torch.empty(int(nws), dtype=F32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.nsr_mlp_backward(ptr(dout), _is_f32(dout), dout.stride(0), ptr(out), ptr(x), _is_f32(x), x.stride(0),
+                                   ptr(acts), ptr(weights_half), ptr(grad_weights), ptr(dx),
+                                   desc.n_in if want_dx else 0, ptr(partials), n, float(grad_scale), _byref(desc),
+                                   stream_ptr()), "nsr_mlp_backward")
+    return dx
+
+
+class _Mlp(Function):
+    @staticmethod
+    def forward(ctx, x, params, owner, train):
+        w = owner.weights_half(params)
+        desc = owner.mlp_desc
+        out, acts = mlp_forward(x, w, desc, save_acts=train)
+        ctx.save_for_backward(x, params)
+        ctx.owner, ctx.w, ctx.out, ctx.acts = owner, w, out, acts
+        return out[:, :desc.n_out]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, params = ctx.saved_tensors
+        owner, desc = ctx.owner, ctx.owner.mlp_desc
+        if ctx.acts is None:
+            raise NsrError("MLP backward without saved activations (forward ran with grad disabled)")
+        need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dout = dout.contiguous()
+        dp = torch.zeros_like(params, dtype=F32) if need_p else None
+        dx = mlp_backward(dout, ctx.out, x, ctx.acts, ctx.w, desc, grad_weights=owner.mlp_slice(dp) if need_p else None,
+                          want_dx=need_x, grad_scale=owner.loss_scale)
+        if dx is not None and dx.dtype != x.dtype:
+            dx = dx.to(x.dtype)
+        return dx, dp, None, None
+
+
+def _wants_grad(x, params):
+    # Function.forward runs with grad mode off, so "do we need to save activations" is decided here
+    return torch.is_grad_enabled() and (x.requires_grad or params.requires_grad)
+
+
+def mlp(x, params, owner):
+    return _Mlp.apply(x, params, owner, _wants_grad(x, params))
+
+
+class _GridMlp(Function):
+    """tcnn.NetworkWithInputEncoding: encode -> MLP with ONE flat parameter ([network | grid])."""
+
+    @staticmethod
+    def forward(ctx, x, params, owner, train):
+        table, w = owner.table_half(params), owner.weights_half(params)
+        enc = hashgrid_forward(x, table, owner.grid_desc, owner.level_mask_count())
+        out, acts = mlp_forward(enc, w, owner.mlp_desc, save_acts=train)
+        ctx.save_for_backward(x, params)
+        ctx.owner, ctx.table, ctx.w, ctx.enc, ctx.out, ctx.acts = owner, table, w, enc, out, acts
+        return out[:, :owner.mlp_desc.n_out]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, params = ctx.saved_tensors
+        owner = ctx.owner
+        if ctx.acts is None:
+            raise NsrError("backward without saved activations (forward ran with grad disabled)")
+        need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dp = torch.zeros_like(params, dtype=F32) if need_p else None
+        # grads w.r.t. the encoding leave the MLP in fp32 and go straight into the fp32 atomics
+        d_enc = mlp_backward(dout.contiguous(), ctx.out, ctx.enc, ctx.acts, ctx.w, owner.mlp_desc,
+                             grad_weights=owner.mlp_slice(dp) if need_p else None, want_dx=True,
+                             grad_scale=owner.loss_scale)
+        if need_p:
+            hashgrid_backward_params(x, d_enc, owner.grid_slice(dp), owner.grid_desc, owner.level_mask_count())
+        dx = hashgrid_backward_input(x, ctx.table, d_enc, owner.grid_desc, owner.level_mask_count()) if need_x else None
+        return dx, dp, None, None
+
+
+def grid_mlp(x, params, owner):
+    return _GridMlp.apply(x, params, owner, _wants_grad(x, params))
+
+
+# ------------------------------------------------------------------------------------------------
+# marching / contraction / packing
+# ------------------------------------------------------------------------------------------------
+def ray_aabb_intersect(rays_o, rays_d, aabb):
+    n = rays_o.shape[0]
+    t_min = torch.empty(n, dtype=F32, device=rays_o.device)
+    t_max = torch.empty(n, dtype=F32, device=rays_o.device)
+    with torch.cuda.device(rays_o.device):
+        check(lib.nsr_ray_aabb_intersect(ptr(rays_o), ptr(rays_d), ptr(aabb), ptr(t_min), ptr(t_max), n, stream_ptr()),
+              "nsr_ray_aabb_intersect")
+    return t_min, t_max
+
+
+def ray_march(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone_angle):
+    """two-call protocol; ONE host sync (the sample count).  Returns packed_info, ray_indices, t_starts, t_ends."""
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    rx, ry, rz = (int(s) for s in binary.shape)
+    grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    packed = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        s = stream_ptr()
+        check(lib.nsr_ray_march_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(grid_u8), rx, ry,
+                                      rz, int(contraction), float(step), float(cone_angle), ptr(counts), n, s),
+              "nsr_ray_march_count")
+        check(lib.nsr_pack_from_counts(ptr(counts), ptr(packed), ptr(total), n, s), "nsr_pack_from_counts")
+        m = int(total.item())  # the marcher's one intrinsic host sync
+        ray_indices = torch.empty(m, dtype=torch.int64, device=dev)
+        t_starts = torch.empty((m, 1), dtype=F32, device=dev)
+        t_ends = torch.empty((m, 1), dtype=F32, device=dev)
+        if m > 0:
+            check(lib.nsr_ray_march_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(grid_u8), rx,
+                                          ry, rz, int(contraction), float(step), float(cone_angle), ptr(packed),
+                                          ptr(ray_indices), ptr(t_starts), ptr(t_ends), n, s), "nsr_ray_march_write")
+    return packed, ray_indices, t_starts, t_ends
+
+
+def pack_info(ray_indices, n_rays):
+    packed = torch.empty((n_rays, 2), dtype=torch.int32, device=ray_indices.device)
+    with torch.cuda.device(ray_indices.device):
+        check(lib.nsr_pack_info(ptr(ray_indices), ptr(packed), ray_indices.shape[0], n_rays, stream_ptr()),
+              "nsr_pack_info")
+    return packed
+
+
+def contract(x, roi, contraction, inverse=False):
+    out = torch.empty_like(x)
+    fn = lib.nsr_contract_inv if inverse else lib.nsr_contract
+    with torch.cuda.device(x.device):
+        check(fn(ptr(x), ptr(roi), int(contraction), ptr(out), x.shape[0], stream_ptr()), "nsr_contract")
+    return out
+
+
+def grid_query(x, roi, binary, contraction):
+    rx, ry, rz = (int(s) for s in binary.shape)
+    grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
+    out = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.nsr_grid_query_u8(ptr(x), ptr(roi), ptr(grid_u8), rx, ry, rz, int(contraction), ptr(out), x.shape[0],
+                                    stream_ptr()), "nsr_grid_query_u8")
+    return out.bool()
+
+
+def sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends, want_dirs=True):
+    n = ray_indices.shape[0]
+    pos = torch.empty((n, 3), dtype=F32, device=rays_o.device)
+    dirs = torch.empty((n, 3), dtype=F32, device=rays_o.device) if want_dirs else None
+    with torch.cuda.device(rays_o.device):
+        check(lib.nsr_sample_positions(ptr(rays_o), ptr(rays_d), ptr(ray_indices), ptr(t_starts), ptr(t_ends), ptr(pos),
+                                       ptr(dirs), n, stream_ptr()), "nsr_sample_positions")
+    return pos, dirs
+
+
+def compact_samples(mask, ray_indices, t_starts, t_ends):
+    """order-preserving compaction by a bool mask; one host sync for the kept count."""
+    n = ray_indices.shape[0]
+    dev = ray_indices.device
+    mask_u8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    ri = torch.empty_like(ray_indices)
+    t0, t1 = torch.empty_like(t_starts), torch.empty_like(t_ends)
+    n_kept = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty((n + 255) // 256 + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nsr_compact_samples(ptr(mask_u8), ptr(ray_indices), ptr(t_starts), ptr(t_ends), ptr(ri), ptr(t0),
+                                      ptr(t1), ptr(n_kept), ptr(scratch), n, stream_ptr()), "nsr_compact_samples")
+    k = int(n_kept.item())
+    return ri[:k], t0[:k], t1[:k]
+
+
+# ------------------------------------------------------------------------------------------------
+# compositing
+# ------------------------------------------------------------------------------------------------
+class _TransFromSigma(Function):
+    @staticmethod
+    def forward(ctx, sigmas, t_starts, t_ends, packed, n_rays):
+        sig = _f32c(sigmas)
+        T = torch.empty_like(sig)
+        with torch.cuda.device(sig.device):
+            check(lib.nsr_transmittance_from_sigma_forward(ptr(packed), ptr(t_starts), ptr(t_ends), ptr(sig), ptr(T),
+                                                           n_rays, stream_ptr()), "transmittance_from_sigma_forward")
+        ctx.save_for_backward(T, t_starts, t_ends, packed)
+        ctx.n_rays = n_rays
+        return T
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gT):
+        T, t_starts, t_ends, packed = ctx.saved_tensors
+        g = torch.empty_like(T)
+        gT = _f32c(gT)
+        with torch.cuda.device(T.device):
+            check(lib.nsr_transmittance_from_sigma_backward(ptr(packed), ptr(t_starts), ptr(t_ends), ptr(T), ptr(gT),
+                                                            ptr(g), ctx.n_rays, stream_ptr()),
+                  "transmittance_from_sigma_backward")
+        return g, None, None, None, None
+
+
+class _TransFromAlpha(Function):
+    @staticmethod
+    def forward(ctx, alphas, packed, n_rays):
+        a = _f32c(alphas)
+        T = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            check(lib.nsr_transmittance_from_alpha_forward(ptr(packed), ptr(a), ptr(T), n_rays, stream_ptr()),
+                  "transmittance_from_alpha_forward")
+        ctx.save_for_backward(T, a, packed)
+        ctx.n_rays = n_rays
+        return T
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gT):
+        T, a, packed = ctx.saved_tensors
+        g = torch.empty_like(T)
+        gT = _f32c(gT)
+        with torch.cuda.device(T.device):
+            check(lib.nsr_transmittance_from_alpha_backward(ptr(packed), ptr(a), ptr(T), ptr(gT), ptr(g), ctx.n_rays,
+                                                            stream_ptr()), "transmittance_from_alpha_backward")
+        return g, None, None
+
+
+def transmittance_from_sigma(sigmas, t_starts, t_ends, packed, n_rays):
+    return _TransFromSigma.apply(sigmas, t_starts.contiguous(), t_ends.contiguous(), packed, n_rays)
+
+
+def transmittance_from_alpha(alphas, packed, n_rays):
+    return _TransFromAlpha.apply(alphas, packed, n_rays)
+
+
+class _Accumulate(Function):
+    @staticmethod
+    def forward(ctx, weights, values, ray_indices, packed, n_rays):
+        w = _f32c(weights).view(-1)
+        v = None if values is None else _f32c(values)
+        dim = 1 if v is None else v.shape[-1]
+        out = torch.empty((n_rays, dim), dtype=F32, device=w.device)
+        with torch.cuda.device(w.device):
+            check(lib.nsr_accumulate_along_rays_forward(ptr(packed), ptr(w), ptr(v), dim, ptr(out), n_rays,
+                                                        stream_ptr()), "accumulate_along_rays_forward")
+        ctx.save_for_backward(w, v, ray_indices)
+        ctx.dim, ctx.wshape = dim, weights.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        w, v, ray_indices = ctx.saved_tensors
+        need_w, need_v = ctx.needs_input_grad[0], (v is not None and ctx.needs_input_grad[1])
+        g_out = _f32c(g_out)
+        gw = torch.empty_like(w) if need_w else None
+        gv = torch.empty_like(v) if need_v else None
+        with torch.cuda.device(w.device):
+            check(lib.nsr_accumulate_along_rays_backward(ptr(ray_indices), ptr(w), ptr(v), ctx.dim, ptr(g_out), ptr(gw),
+                                                         ptr(gv), w.shape[0], stream_ptr()),
+                  "accumulate_along_rays_backward")
+        return (gw.view(ctx.wshape) if need_w else None), gv, None, None, None
+
+
+def accumulate_along_rays(weights, values, ray_indices, packed, n_rays):
+    return _Accumulate.apply(weights, values, ray_indices, packed, n_rays)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused reference glue
+# ------------------------------------------------------------------------------------------------
+def contract_to_unisphere(x, radius, contraction):
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib.nsr_contract_to_unisphere(ptr(x), float(radius), int(contraction), ptr(out), x.shape[0], stream_ptr()),
+              "nsr_contract_to_unisphere")
+    return out
+
+
+def density_activation(mlp_out, n_feat, bias, want_feature=True):
+    n = mlp_out.shape[0]
+    density = torch.empty(n, dtype=F32, device=mlp_out.device)
+    feature = torch.empty((n, n_feat), dtype=F32, device=mlp_out.device) if want_feature else None
+    with torch.cuda.device(mlp_out.device):
+        check(lib.nsr_density_activation_forward(ptr(mlp_out), mlp_out.stride(0), n_feat, float(bias), ptr(density),
+                                                 ptr(feature), n, stream_ptr()), "nsr_density_activation_forward")
+    return density, feature
+
+
+class _NeusAlpha(Function):
+    @staticmethod
+    def forward(ctx, sdf, normal, dirs, dists, inv_s, anneal):
+        sdf, normal, dirs, dists = _f32c(sdf).view(-1), _f32c(normal), _f32c(dirs), _f32c(dists).view(-1)
+        inv_s_c = _f32c(inv_s).view(-1)[:1]
+        alpha = torch.empty_like(sdf)
+        with torch.cuda.device(sdf.device):
+            check(lib.nsr_neus_alpha_forward(ptr(sdf), ptr(normal), ptr(dirs), ptr(dists), ptr(inv_s_c), float(anneal),
+                                             ptr(alpha), sdf.shape[0], stream_ptr()), "nsr_neus_alpha_forward")
+        ctx.save_for_backward(sdf, normal, dirs, dists, inv_s_c)
+        ctx.anneal, ctx.inv_s_shape = float(anneal), inv_s.shape
+        return alpha
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_alpha):
+        sdf, normal, dirs, dists, inv_s_c = ctx.saved_tensors
+        g_alpha = _f32c(g_alpha).view(-1)
+        g_sdf, g_normal = torch.empty_like(sdf), torch.empty_like(normal)
+        g_inv_s = torch.zeros(1, dtype=F32, device=sdf.device)
+        with torch.cuda.device(sdf.device):
+            check(lib.nsr_neus_alpha_backward(ptr(sdf), ptr(normal), ptr(dirs), ptr(dists), ptr(inv_s_c), ctx.anneal,
+                                              ptr(g_alpha), ptr(g_sdf), ptr(g_normal), ptr(g_inv_s), sdf.shape[0],
+                                              stream_ptr()), "nsr_neus_alpha_backward")
+        return g_sdf, g_normal, None, None, g_inv_s.view(ctx.inv_s_shape), None
+
+
+def neus_alpha(sdf, normal, dirs, dists, inv_s, cos_anneal_ratio):
+    return _NeusAlpha.apply(sdf, normal, dirs, dists, inv_s, cos_anneal_ratio)
+
+
+def adamw_step(params, grad, exp_avg, exp_avg_sq, shadow_half, lr, beta1, beta2, eps, weight_decay, step,
+               grad_unscale=1.0, zero_grad=True):
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    with torch.cuda.device(params.device):
+        check(lib.nsr_adamw_step(ptr(params), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(shadow_half),
+                                 params.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                 float(bc1), float(bc2), float(grad_unscale), int(zero_grad), stream_ptr()),
+              "nsr_adamw_step")

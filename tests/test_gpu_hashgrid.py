@@ -1,0 +1,115 @@
+"""HIP hash grid vs the oracle (oracle/tcnn_ref.py), through the C ABI.  Tolerances per SURVEY.md A.8."""
+import pytest
+import torch
+
+from conftest import NERF_GRID, NEUS_GRID
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg, n, seed=0, table_scale=0.1, F=None):
+    from oracle import tcnn_ref
+    import nsr_hip
+    cfg = dict(cfg)
+    if F is not None:
+        cfg["n_features_per_level"] = F
+    od = tcnn_ref.GridDesc.from_config(cfg)
+    hd = nsr_hip.make_grid_desc(cfg["n_levels"], cfg["n_features_per_level"], cfg["log2_hashmap_size"],
+                                cfg["base_resolution"], cfg["per_level_scale"])
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 3, generator=g)
+    x[0] = 0.0
+    x[1] = 1.0  # the x == 1 border (corner coordinate reaches res)
+    table = (torch.randn(od.n_params, generator=g) * table_scale).half().float()
+    return od, hd, x, table
+
+
+@pytest.mark.parametrize("cfg", [NERF_GRID, NEUS_GRID], ids=["nerf16", "neus32"])
+def test_desc_matches_oracle(cfg):
+    od, hd, _, _ = _setup(cfg, 4)
+    assert hd.n_entries == od.n_entries
+    for l in range(od.L):
+        assert hd.scale[l] == od.scale[l] and hd.resolution[l] == od.res[l]
+        assert hd.size[l] == od.size[l] and hd.offset[l] == od.offset[l]
+
+
+@pytest.mark.parametrize("cfg,F", [(NERF_GRID, 2), (NEUS_GRID, 2), (NERF_GRID, 1), (NERF_GRID, 4), (NERF_GRID, 8)],
+                         ids=["nerf16", "neus32", "F1", "F4", "F8"])
+def test_forward_parity(cfg, F):
+    from oracle import tcnn_ref
+    from nsr_hip import ops
+    od, hd, x, table = _setup(cfg, 4099, F=F)
+    ref = tcnn_ref.hashgrid_encode(x, table.view(-1, od.F), od)
+    y = ops.hashgrid_forward(x.cuda(), table.half().cuda(), hd).float().cpu()
+    # both round an fp32 blend of the same fp16 table values to fp16: at most 1 fp16 ulp apart
+    err = (y - ref).abs()
+    tol = ref.abs() * 2 ** -10 + 1e-6
+    assert bool((err <= tol).all()), f"max err {err.max()} at {err.argmax()}"
+    assert float((y != ref).float().mean()) < 0.01  # and almost always bit-identical
+
+
+def test_forward_mask_count_zeroes_levels():
+    from oracle import tcnn_ref
+    from nsr_hip import ops
+    od, hd, x, table = _setup(NEUS_GRID, 1000)
+    ref = tcnn_ref.hashgrid_encode(x, table.view(-1, od.F), od)
+    y = ops.hashgrid_forward(x.cuda(), table.half().cuda(), hd, mask_count=5).float().cpu()
+    assert bool((y[:, 10:] == 0).all())
+    assert torch.allclose(y[:, :10], ref[:, :10], rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("dy_f32", [False, True])
+def test_backward_params_parity(dy_f32):
+    from oracle import tcnn_ref
+    from nsr_hip import ops
+    od, hd, x, table = _setup(NERF_GRID, 3001)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(x.shape[0], 32, generator=g)
+    if not dy_f32:
+        dy = dy.half().float()
+    t = table.clone().requires_grad_(True)
+    tcnn_ref.hashgrid_encode(x, t.view(-1, od.F), od, fp16=False).backward(dy)
+    grad = torch.zeros(od.n_params, device="cuda")
+    ops.hashgrid_backward_params(x.cuda(), (dy if dy_f32 else dy.half()).cuda(), grad, hd)
+    grad = grad.cpu()
+    rel = (grad - t.grad).norm() / t.grad.norm()
+    assert rel < 1e-5, rel  # fp32 atomics: only summation order differs
+    assert bool(((grad != 0) == (t.grad != 0)).all())
+
+
+def test_backward_input_and_double_backward():
+    from oracle import tcnn_ref
+    from nsr_hip import ops
+    od, hd, x, table = _setup(NEUS_GRID, 1531, table_scale=0.05)
+    g = torch.Generator().manual_seed(7)
+    dy = torch.randn(x.shape[0], 32, generator=g)
+    gin = torch.randn(x.shape[0], 3, generator=g)
+    xo = x.clone().requires_grad_(True)
+    to = table.clone().requires_grad_(True)
+    dyo = dy.clone().requires_grad_(True)
+    y = tcnn_ref.hashgrid_encode(xo, to.view(-1, od.F), od, fp16=False)
+    (dx_ref,) = torch.autograd.grad(y, xo, dyo, create_graph=True)
+    d_dy_ref, dt_ref, dx2_ref = torch.autograd.grad(dx_ref, [dyo, to, xo], gin)
+    xc, tc, dyc = x.cuda(), table.half().cuda(), dy.cuda()
+    dx = ops.hashgrid_backward_input(xc, tc, dyc, hd).cpu()
+    assert (dx - dx_ref.detach()).norm() / dx_ref.norm() < 1e-5
+    gt = torch.zeros(od.n_params, device="cuda")
+    d_dy, dx2 = ops.hashgrid_backward_backward_input(xc, tc, dyc, gin.cuda(), hd, grad_table=gt)
+    assert (d_dy.cpu() - d_dy_ref).norm() / d_dy_ref.norm() < 1e-5
+    assert (gt.cpu() - dt_ref).norm() / dt_ref.norm() < 1e-5
+    assert (dx2.cpu() - dx2_ref).norm() / dx2_ref.norm() < 1e-4
+
+
+def test_full_size_properties():
+    """BASELINE config C2 at one training step's size: partition of unity + linearity (size-independent)."""
+    from nsr_hip import ops
+    import nsr_hip
+    hd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
+    n = 1 << 18
+    x = torch.rand(n, 3, device="cuda")
+    ones = torch.ones(hd.n_entries * 2, dtype=torch.float16, device="cuda")
+    y = ops.hashgrid_forward(x, ones, hd).float()
+    assert float((y - 1).abs().max()) < 2e-3  # trilinear weights sum to one on every level
+    a = (torch.randn(hd.n_entries * 2, device="cuda") * 0.1).half()
+    ya, y2a = ops.hashgrid_forward(x, a, hd).float(), ops.hashgrid_forward(x, (a.float() * 2).half(), hd).float()
+    assert torch.allclose(y2a, 2 * ya, rtol=2e-3, atol=1e-4)
