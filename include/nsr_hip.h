@@ -70,6 +70,17 @@ int nsr_hashgrid_backward_params(const float *x, const void *dy, int dy_is_f32, 
                                  float *grad_table, uint32_t n, uint32_t level_mask_count, float grad_scale,
                                  const NsrGridDesc *desc, void *stream);
 
+/* Same result WITHOUT global atomics ("owner computes", the default path): every workgroup owns a slice of one
+ * level's gradient in LDS, scans all samples, and stores its slice once.  dy_layout: 0 = half row-major
+ * [n,dy_stride], 1 = float row-major, 2 = float level-major [L][n][F] (dy_stride ignored, no workspace needed).
+ * workspace: nsr_hashgrid_backward_params_workspace_floats() floats (always required: chunk slabs of the small
+ * dense levels + the level-major copy of a row-major dy).
+ * accumulate=0 OVERWRITES grad_table (every entry is written, so the caller need not zero it); 1 adds. */
+uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n);
+int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
+                                       float *grad_table, float *workspace, uint32_t n, uint32_t level_mask_count,
+                                       float grad_scale, int accumulate, const NsrGridDesc *desc, void *stream);
+
 /* dx[n,3] (fp32) = (d y / d x)^T dy  -- the NeuS analytic normal, models/geometry.py:177-180 */
 int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
                                 uint32_t dy_stride, float *dx, uint32_t n, uint32_t level_mask_count,
@@ -151,6 +162,25 @@ int nsr_ray_march_write(const float *rays_o, const float *rays_d, const float *t
                         const float *roi, const uint8_t *grid_binary, int res_x, int res_y, int res_z,
                         int contraction, float step_size, float cone_angle, const int32_t *packed_info,
                         int64_t *ray_indices, float *t_starts, float *t_ends, uint32_t n_rays, void *stream);
+
+/* Brick-packed variant (the default path of the Python packages): same samples, bit for bit.
+ *   nsr_grid_pack_bricks: bool grid [rx,ry,rz] (multiples of 4) -> 4x4x4 bricks of 64 bits + one any-bit per brick
+ *     (`bricks` holds nsr_grid_bricks_words64() uint64 words; re-pack whenever the grid changes).
+ *   count: with scratch (n_rays * capacity float2, capacity = nsr_ray_march_capacity(roi, step) > 0, AABB type
+ *     only) it is the ONLY marching pass and also stores (t0,t1) per ray; write then just packs the rows.
+ *     Without scratch (capacity 0) it counts, and write marches a second time (any contraction type). */
+uint64_t nsr_grid_bricks_words64(int res_x, int res_y, int res_z);
+int nsr_grid_pack_bricks(const uint8_t *grid_binary, int res_x, int res_y, int res_z, uint64_t *bricks, void *stream);
+uint32_t nsr_ray_march_capacity(const float *roi_host /*host[6]*/, float step_size);
+int nsr_ray_march_bricks_count(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                               const float *roi, const uint64_t *bricks, int res_x, int res_y, int res_z,
+                               int contraction, float step_size, float cone_angle, int32_t *num_steps, float *scratch,
+                               uint32_t capacity, uint32_t n_rays, void *stream);
+int nsr_ray_march_bricks_write(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                               const float *roi, const uint64_t *bricks, int res_x, int res_y, int res_z,
+                               int contraction, float step_size, float cone_angle, const int32_t *packed_info,
+                               const float *scratch, uint32_t capacity, int64_t *ray_indices, float *t_starts,
+                               float *t_ends, uint32_t n_rays, void *stream);
 
 /* exclusive scan of num_steps -> packed_info[n_rays,2]; *total (device int32[1]) <- sum */
 int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,

@@ -194,6 +194,196 @@ k_grid_backward_params(const float *__restrict__ x, const void *__restrict__ dy,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward w.r.t. the table, "owner computes" (the default): NO global atomics.
+//
+// Measured on MI355X: device-scope fp32 atomics retire at ~22 G/s chip-wide (they execute memory-side so
+// that the 8 non-coherent XCD L2s stay consistent) -- 1.13 ms for one 98 k-sample step, 3x everything else.
+// Rays of a batch are i.i.d., so fine-level entries are touched ~once per step: there is no reuse to cache,
+// only the atomic *rate* hurts.  So instead every workgroup OWNS a contiguous slice of one level's gradient
+// that fits the CU's 160 KiB LDS (20480 fp32 pairs), scans ALL samples of that level, recomputes the 8
+// corner indices (a few dozen VALU ops -- the chip has ~100x more VALU than atomic throughput), accumulates
+// the corners that fall into its slice with LDS atomics (ds_add_f32) and finally stores the slice with plain
+// coalesced 16-B stores.  314 workgroups cover L=16,T=2^19,F=2; each grad entry is written exactly once, so the
+// 50 MB gradient needs no memset either (accumulate=0).  dy is read level-major ([L][N][F], 8-B coalesced).
+// ------------------------------------------------------------------------------------------------
+constexpr int OWN_BLOCK = 1024;
+constexpr int OWN_LDS_FLOATS = 40960;   // 160 KiB: the whole LDS of a CU
+constexpr int OWN_POW2_LOG2 = 14;       // hashed levels: 16384-entry slices (128 KiB at F=2) -> owner = hash bits
+constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decomposition aims for
+
+// Decomposition of one level: R slices of its gradient x C sample chunks.  C > 1 (small dense levels, where one
+// slice would see every sample and serialise on same-address LDS atomics) writes per-chunk slabs that a second
+// tiny kernel sums; C == 1 stores straight into the gradient.
+struct OwnerMap {
+    uint32_t block_start[NSR_MAX_LEVELS + 1];
+    uint32_t n_slices[NSR_MAX_LEVELS];
+    uint32_t n_chunks[NSR_MAX_LEVELS];
+    uint32_t slab_offset[NSR_MAX_LEVELS];  // floats, into the slab workspace (levels with n_chunks > 1)
+    uint32_t entries_per_slice[NSR_MAX_LEVELS];
+};
+
+template <int F>
+__device__ __forceinline__ void lds_add(float *acc, uint32_t rel, float w, const float (&g)[F])
+{
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(&acc[rel * F + f], w * g[f]);
+}
+
+template <int F>
+__global__ void __launch_bounds__(OWN_BLOCK)
+k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_lm /* [L][n][F] */,
+                      float *__restrict__ grad_table, float *__restrict__ slabs, uint32_t n, uint32_t mask_count,
+                      float grad_scale, int accumulate, const OwnerMap om, const NsrGridDesc d)
+{
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    uint32_t level = 0;
+    while (level + 1 < d.n_levels && blockIdx.x >= om.block_start[level + 1]) ++level;
+    const uint32_t C = om.n_chunks[level], epb = om.entries_per_slice[level];
+    const uint32_t local = blockIdx.x - om.block_start[level];
+    const uint32_t slice = local / C, chunk = local % C;
+    const uint32_t r0 = slice * epb;
+    const LevelGeom g = load_level(d, level);
+    const uint32_t cnt = min(epb, g.size - r0);
+    for (uint32_t k = threadIdx.x; k < cnt * F; k += OWN_BLOCK) acc[k] = 0.f;
+    __syncthreads();
+    if (level < mask_count) {
+        const uint32_t per = ((n + C - 1) / C + 63u) & ~63u;  // samples per chunk, wave aligned
+        const uint32_t i_end = min(n, (chunk + 1) * per);
+        const float *dyl = dy_lm + (uint64_t)level * n * F;
+        // hashed level cut into power-of-two slices: x never reaches the slice bits, so ownership is decided once
+        // per (y,z) corner pair instead of once per corner
+        const bool pow2 = !g.dense && epb == (1u << OWN_POW2_LOG2) && g.res < (1u << OWN_POW2_LOG2);
+        for (uint32_t i = chunk * per + threadIdx.x; i < i_end; i += OWN_BLOCK) {
+            float g_out[F];
+            bool any = false;
+            if constexpr (F == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(dyl + 2ull * i);
+                g_out[0] = v.x * grad_scale; g_out[1] = v.y * grad_scale;
+                any = (v.x != 0.f) | (v.y != 0.f);
+            } else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) { g_out[f] = dyl[(uint64_t)i * F + f] * grad_scale; any |= g_out[f] != 0.f; }
+            }
+            if (!any) continue;
+            const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
+            if (pow2) {
+                const uint32_t hy0 = c.c[1] * PRIME_Y, hz0 = c.c[2] * PRIME_Z;
+                const uint32_t lowmask = (1u << OWN_POW2_LOG2) - 1u, topmask = g.size - 1u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t h = (hy0 + ((k & 1) ? PRIME_Y : 0u)) ^ (hz0 + ((k & 2) ? PRIME_Z : 0u));
+                    if (((h & topmask) >> OWN_POW2_LOG2) == slice) {
+                        const float wyz = ((k & 1) ? c.w[1] : 1.f - c.w[1]) * ((k & 2) ? c.w[2] : 1.f - c.w[2]);
+                        lds_add<F>(acc, (c.c[0] ^ h) & lowmask, (1.f - c.w[0]) * wyz, g_out);
+                        lds_add<F>(acc, ((c.c[0] + 1u) ^ h) & lowmask, c.w[0] * wyz, g_out);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t e = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1));
+                    const uint32_t rel = e - r0;
+                    if (rel < cnt) {
+                        float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
+                        w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
+                        w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
+                        lds_add<F>(acc, rel, w, g_out);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nf = cnt * F;  // multiple of 8 floats: level sizes are multiples of 8 entries
+    if (C > 1) {
+        float *dst = slabs + om.slab_offset[level] + ((uint64_t)chunk * g.size + r0) * F;
+        for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4)
+            *reinterpret_cast<float4 *>(dst + k) = *reinterpret_cast<const float4 *>(acc + k);
+    } else {
+        float *dst = grad_table + (uint64_t)(g.offset + r0) * F;
+        for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4) {
+            float4 v = *reinterpret_cast<const float4 *>(acc + k);
+            if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4 *>(dst + k);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4 *>(dst + k) = v;
+        }
+    }
+}
+
+// grad[level] (+)= sum over that level's chunk slabs (levels with n_chunks > 1 only)
+template <int F>
+__global__ void __launch_bounds__(256)
+k_grid_reduce_slabs(const float *__restrict__ slabs, float *__restrict__ grad_table, int accumulate, const OwnerMap om,
+                    const NsrGridDesc d)
+{
+    const uint32_t level = blockIdx.y;
+    const uint32_t C = om.n_chunks[level];
+    if (C <= 1) return;
+    const uint32_t nf = d.size[level] * F;
+    const float *src = slabs + om.slab_offset[level];
+    float *dst = grad_table + (uint64_t)d.offset[level] * F;
+    for (uint32_t k = (blockIdx.x * 256 + threadIdx.x) * 4; k < nf; k += gridDim.x * 256 * 4) {
+        float4 s = accumulate ? *reinterpret_cast<const float4 *>(dst + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t c = 0; c < C; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + (uint64_t)c * nf + k);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(dst + k) = s;
+    }
+}
+
+// host: build the decomposition; returns the number of blocks, *slab_floats the slab workspace size
+static uint32_t make_owner_map(const NsrGridDesc *desc, OwnerMap *om, uint64_t *slab_floats)
+{
+    const uint32_t F = desc->n_features, L = desc->n_levels;
+    uint32_t nb = 0;
+    uint64_t slab = 0;
+    for (uint32_t l = 0; l < L; ++l) {
+        const uint32_t size = desc->size[l], res = desc->resolution[l];
+        const bool dense = (uint64_t)res * res * res <= (uint64_t)size;
+        const uint32_t max_epb = OWN_LDS_FLOATS / F;
+        uint32_t epb = max_epb;
+        const uint32_t p2 = 1u << OWN_POW2_LOG2;
+        if (!dense && (size & (size - 1)) == 0 && size >= p2 && p2 <= max_epb && res < p2) epb = p2;
+        const uint32_t R = nsr_div_up(size, epb);
+        uint32_t C = 1;
+        if (R < OWN_TARGET_WGS) C = (OWN_TARGET_WGS + R - 1) / R;  // few slices: split the samples instead
+        om->block_start[l] = nb;
+        om->n_slices[l] = R;
+        om->n_chunks[l] = C;
+        om->entries_per_slice[l] = epb;
+        om->slab_offset[l] = (uint32_t)slab;
+        if (C > 1) slab += (uint64_t)C * size * F;
+        nb += R * C;
+    }
+    for (uint32_t l = L; l <= NSR_MAX_LEVELS; ++l) om->block_start[l] = nb;
+    for (uint32_t l = L; l < NSR_MAX_LEVELS; ++l) om->n_slices[l] = om->n_chunks[l] = om->slab_offset[l] = om->entries_per_slice[l] = 0;
+    *slab_floats = slab;
+    return nb;
+}
+
+// row-major dy [n, stride] (half or float) -> level-major fp32 [L][n][F]; 64 samples x all columns per block
+template <int F, bool DY_F32>
+__global__ void __launch_bounds__(256)
+k_dy_to_level_major(const void *__restrict__ dy, uint32_t dy_stride, float *__restrict__ out, uint32_t n, uint32_t L)
+{
+    extern __shared__ float tile[];  // [64][C+1]
+    const uint32_t C = L * F, i0 = blockIdx.x * 64;
+    for (uint32_t k = threadIdx.x; k < 64 * C; k += 256) {
+        const uint32_t r = k / C, c = k % C;
+        tile[r * (C + 1) + c] = (i0 + r < n) ? load_grad<DY_F32>(dy, (uint64_t)(i0 + r) * dy_stride + c) : 0.f;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 64 * C; k += 256) {
+        const uint32_t l = k / (64 * F), rem = k % (64 * F), r = rem / F, f = rem % F;
+        if (i0 + r < n) out[((uint64_t)l * n + i0 + r) * F + f] = tile[r * (C + 1) + l * F + f];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward w.r.t. the input (and its double backward): one lane = one sample, loop over levels.
 // dy/dx is recomputed from the (cache-resident) table instead of being stored by the forward pass.
@@ -406,6 +596,63 @@ extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int 
                                grad_scale, *desc);
     });
     NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params");
+    return NSR_OK;
+}
+
+
+extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n)
+{
+    if (!desc || check_desc(desc, "nsr_hashgrid_backward_params_workspace_floats")) return 0;
+    OwnerMap om;
+    uint64_t slab = 0;
+    make_owner_map(desc, &om, &slab);
+    return slab + (uint64_t)desc->n_levels * desc->n_features * n;  // [slabs | level-major dy]
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
+                                                  float *grad_table, float *workspace, uint32_t n,
+                                                  uint32_t level_mask_count, float grad_scale, int accumulate,
+                                                  const NsrGridDesc *desc, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
+    NSR_REQUIRE(grad_table && workspace, "nsr_hashgrid_backward_params_owner: grad_table / workspace is NULL");
+    NSR_REQUIRE(n == 0 || (x && dy), "nsr_hashgrid_backward_params_owner: NULL pointer");
+    NSR_REQUIRE(dy_layout >= 0 && dy_layout <= 2, "nsr_hashgrid_backward_params_owner: dy_layout must be 0 (half "
+                "row-major), 1 (float row-major) or 2 (float level-major)");
+    const uint32_t F = desc->n_features, L = desc->n_levels;
+    OwnerMap om;
+    uint64_t slab_floats = 0;
+    const uint32_t nb = make_owner_map(desc, &om, &slab_floats);
+    const float *dy_lm = (const float *)dy;
+    if (dy_layout != 2 && n > 0) {
+        float *lm = workspace + slab_floats;
+        const uint32_t C = L * F;
+        const size_t lds = 64 * (C + 1) * sizeof(float);
+        DISPATCH_F(F, {
+            if (dy_layout == 1)
+                hipLaunchKernelGGL((k_dy_to_level_major<F, true>), dim3(nsr_div_up(n, 64)), dim3(256), lds,
+                                   (hipStream_t)stream, dy, dy_stride, lm, n, L);
+            else
+                hipLaunchKernelGGL((k_dy_to_level_major<F, false>), dim3(nsr_div_up(n, 64)), dim3(256), lds,
+                                   (hipStream_t)stream, dy, dy_stride, lm, n, L);
+        });
+        NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(transpose)");
+        dy_lm = lm;
+    }
+    const size_t lds = OWN_LDS_FLOATS * sizeof(float);
+    DISPATCH_F(F, {
+        static bool attr_set = false;  // per instantiation
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_grid_backward_owner<F>), dim3(nb), dim3(OWN_BLOCK), lds, (hipStream_t)stream, x, dy_lm,
+                           grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc);
+        if (slab_floats > 0)
+            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(32, L), dim3(256), 0, (hipStream_t)stream, workspace,
+                               grad_table, accumulate, om, *desc);
+    });
+    NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner");
     return NSR_OK;
 }
 

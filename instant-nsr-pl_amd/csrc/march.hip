@@ -10,6 +10,8 @@
 // training batch are drawn i.i.d. so trip counts diverge inside a wavefront -- the kernel is latency /
 // divergence bound, not bandwidth bound (a 128^3 bool grid is 2 MiB and stays in the XCD's L2).  The
 // two passes (count, write) share one code path through a template flag so both see identical floats.
+#include <math.h>
+
 #include "nsr_common.h"
 
 #pragma clang fp contract(off)
@@ -206,6 +208,151 @@ k_ray_march(const float *__restrict__ rays_o, const float *__restrict__ rays_d, 
         }
     }
     if (!WRITE) num_steps[i] = j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Brick-packed occupancy grid + single-pass marching (the default path).
+//
+// Profile of the byte-grid two-pass marcher at 8192 rays: 2 x 445 us per step, 30 % of the whole training step.
+// It is a pure dependent-load chain: every voxel visit waits ~700 clk on an L2 byte load and only 128 wavefronts
+// exist.  Same booleans, same fp32 recurrence, far fewer and cheaper loads:
+//   * the bool grid is re-packed into 4x4x4 BRICKS of 64 bits (one 8-B load serves ~5 voxel visits / ~20 steps)
+//     plus one "any voxel set" bit per brick; the any-bits (4 KiB for 128^3, 32 KiB for 256^3) are staged in LDS,
+//     so empty space is skipped without touching global memory at all;
+//   * ONE marching pass writes (t0,t1) into a per-ray scratch row of the provable capacity, then a wave-per-ray
+//     copy packs them: the loop runs once instead of twice.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pack_bricks(const uint8_t *__restrict__ grid, int3 res, unsigned long long *__restrict__ bricks,
+              uint32_t *__restrict__ any_bits, uint32_t n_bricks)
+{
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long bits = 0ull;
+    if (b < n_bricks) {
+        const int nby = res.y >> 2, nbz = res.z >> 2;
+        const int bz = b % nbz, by = (b / nbz) % nby, bx = b / (nbz * nby);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(
+                    grid + ((size_t)(bx * 4 + i) * res.y + (by * 4 + j)) * res.z + bz * 4);
+                for (int k = 0; k < 4; ++k)
+                    if ((v >> (8 * k)) & 0xffu) bits |= 1ull << ((i * 4 + j) * 4 + k);
+            }
+        bricks[b] = bits;
+    }
+    // one any-bit per brick, 32 bricks per word (wave ballot: lanes 0-31 -> word 2w, lanes 32-63 -> word 2w+1)
+    const unsigned long long m = __ballot(bits != 0ull);
+    const uint32_t lane = threadIdx.x & 63;
+    if (lane == 0 && b < n_bricks) any_bits[b >> 5] = (uint32_t)m;
+    if (lane == 32 && b < n_bricks) any_bits[b >> 5] = (uint32_t)(m >> 32);
+}
+
+struct BrickGrid {
+    const unsigned long long *bricks;
+    const uint32_t *any_lds;  // LDS copy of the any-bits
+    int3 res;
+    int nby, nbz;
+    uint32_t cur_id;
+    unsigned long long cur_bits;
+};
+
+__device__ __forceinline__ bool brick_occupied_at(const float *p, const Roi &r, int type, BrickGrid &bg)
+{
+    if (type == NSR_CONTRACT_AABB && outside_roi(p, r)) return false;
+    float u[3];
+    apply_contraction(p, r, type, u);
+    int ix = (int)(u[0] * (float)bg.res.x), iy = (int)(u[1] * (float)bg.res.y), iz = (int)(u[2] * (float)bg.res.z);
+    ix = min(max(ix, 0), bg.res.x - 1);
+    iy = min(max(iy, 0), bg.res.y - 1);
+    iz = min(max(iz, 0), bg.res.z - 1);
+    const uint32_t id = (uint32_t)(((ix >> 2) * bg.nby + (iy >> 2)) * bg.nbz + (iz >> 2));
+    if (id != bg.cur_id) {
+        bg.cur_id = id;
+        bg.cur_bits = ((bg.any_lds[id >> 5] >> (id & 31u)) & 1u) ? bg.bricks[id] : 0ull;
+    }
+    return (bg.cur_bits >> (((ix & 3) * 4 + (iy & 3)) * 4 + (iz & 3))) & 1ull;
+}
+
+// MODE 0: count only (num_steps) ; MODE 1: write at packed_info ; MODE 2: single pass into scratch rows of `cap`
+template <int MODE>
+__global__ void __launch_bounds__(MARCH_BLOCK)
+k_ray_march_bricks(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ t_min,
+                   const float *__restrict__ t_max, const float *__restrict__ roi,
+                   const unsigned long long *__restrict__ bricks, const uint32_t *__restrict__ any_bits,
+                   uint32_t n_any_words, int3 res, int type, float step, float cone_angle,
+                   const int32_t *__restrict__ packed_info, int32_t *__restrict__ num_steps,
+                   int64_t *__restrict__ ray_indices, float *__restrict__ t_starts, float *__restrict__ t_ends,
+                   float2 *__restrict__ scratch, uint32_t cap, uint32_t n_rays)
+{
+    extern __shared__ uint32_t any_lds[];
+    for (uint32_t k = threadIdx.x; k < n_any_words; k += MARCH_BLOCK) any_lds[k] = any_bits[k];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * MARCH_BLOCK + threadIdx.x;
+    if (i >= n_rays) return;
+    Roi r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = roi[k]; r.hi[k] = roi[3 + k]; }
+    const float o[3] = {rays_o[3ull * i], rays_o[3ull * i + 1], rays_o[3ull * i + 2]};
+    const float d[3] = {rays_d[3ull * i], rays_d[3ull * i + 1], rays_d[3ull * i + 2]};
+    const float inv_d[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
+    const float near = t_min[i], far = t_max[i];
+    const float dt_min = step, dt_max = 1e10f;
+    BrickGrid bg{bricks, any_lds, res, res.y >> 2, res.z >> 2, 0xffffffffu, 0ull};
+    int64_t base = 0;
+    if (MODE == 1) base = packed_info[2ull * i];
+    float2 *row = (MODE == 2) ? scratch + (uint64_t)i * cap : nullptr;
+
+    uint32_t j = 0;
+    float t0 = near;
+    float dt = calc_dt(t0, cone_angle, dt_min, dt_max);
+    float t1 = t0 + dt;
+    float t_mid = (t0 + t1) * 0.5f;
+    while (t_mid < far) {
+        const float p[3] = {__builtin_fmaf(t_mid, d[0], o[0]), __builtin_fmaf(t_mid, d[1], o[1]),
+                            __builtin_fmaf(t_mid, d[2], o[2])};
+        if (brick_occupied_at(p, r, type, bg)) {
+            if (MODE == 1) {
+                t_starts[base + j] = t0;
+                t_ends[base + j] = t1;
+                ray_indices[base + j] = (int64_t)i;
+            } else if (MODE == 2) {
+                if (j < cap) row[j] = make_float2(t0, t1);
+            }
+            ++j;
+            t0 = t1;
+            t1 = t0 + calc_dt(t0, cone_angle, dt_min, dt_max);
+            t_mid = (t0 + t1) * 0.5f;
+        } else if (type == NSR_CONTRACT_AABB) {
+            const float t_target = t_mid + distance_to_next_voxel(p, d, inv_d, r, res);
+            do { t_mid += dt_min; } while (t_mid < t_target);
+            dt = calc_dt(t_mid, cone_angle, dt_min, dt_max);
+            t0 = t_mid - dt * 0.5f;
+            t1 = t_mid + dt * 0.5f;
+        } else {
+            t0 = t1;
+            t1 = t0 + calc_dt(t0, cone_angle, dt_min, dt_max);
+            t_mid = (t0 + t1) * 0.5f;
+        }
+    }
+    if (MODE != 1) num_steps[i] = (int32_t)j;
+}
+
+// wave per ray: copy the ray's scratch row to its packed position
+__global__ void __launch_bounds__(256)
+k_pack_scratch(const float2 *__restrict__ scratch, uint32_t cap, const int32_t *__restrict__ packed_info,
+               int64_t *__restrict__ ray_indices, float *__restrict__ t_starts, float *__restrict__ t_ends,
+               uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const uint32_t start = (uint32_t)packed_info[2ull * r], count = (uint32_t)packed_info[2ull * r + 1];
+    const float2 *row = scratch + (uint64_t)r * cap;
+    for (uint32_t k = lane; k < count; k += 64) {
+        const float2 v = row[k];
+        t_starts[start + k] = v.x;
+        t_ends[start + k] = v.y;
+        ray_indices[start + k] = (int64_t)r;
+    }
 }
 
 // exclusive scan of per-ray counts by ONE workgroup (n_rays is a few thousand): 1024 lanes, each owns a
@@ -417,6 +564,102 @@ extern "C" int nsr_ray_march_write(const float *rays_o, const float *rays_d, con
                        make_int3(res_x, res_y, res_z), contraction, step_size, cone_angle, packed_info,
                        (int32_t *)nullptr, ray_indices, t_starts, t_ends, n_rays);
     NSR_CHECK_LAUNCH("nsr_ray_march_write");
+    return NSR_OK;
+}
+
+extern "C" uint64_t nsr_grid_bricks_words64(int res_x, int res_y, int res_z)
+{
+    if (res_x <= 0 || res_y <= 0 || res_z <= 0 || (res_x & 3) || (res_y & 3) || (res_z & 3)) return 0;
+    const uint64_t nb = (uint64_t)(res_x >> 2) * (res_y >> 2) * (res_z >> 2);
+    return nb + ((nb + 31) / 32 + 1) / 2;  // bricks (u64 each) followed by the any-bits (u32 words)
+}
+
+extern "C" int nsr_grid_pack_bricks(const uint8_t *grid_binary, int res_x, int res_y, int res_z, uint64_t *bricks,
+                                    void *stream)
+{
+    const uint64_t words = nsr_grid_bricks_words64(res_x, res_y, res_z);
+    NSR_REQUIRE(words > 0, "nsr_grid_pack_bricks: resolution %dx%dx%d must be positive multiples of 4", res_x, res_y, res_z);
+    NSR_REQUIRE(grid_binary && bricks, "nsr_grid_pack_bricks: NULL pointer");
+    const uint32_t nb = (uint32_t)((res_x >> 2) * (res_y >> 2) * (res_z >> 2));
+    NSR_REQUIRE((nb & 63u) == 0, "nsr_grid_pack_bricks: brick count must be a multiple of 64");
+    hipLaunchKernelGGL(k_pack_bricks, dim3(nsr_div_up(nb, 256)), dim3(256), 0, (hipStream_t)stream, grid_binary,
+                       make_int3(res_x, res_y, res_z), (unsigned long long *)bricks, (uint32_t *)(bricks + nb), nb);
+    NSR_CHECK_LAUNCH("nsr_grid_pack_bricks");
+    return NSR_OK;
+}
+
+extern "C" uint32_t nsr_ray_march_capacity(const float *roi_host, float step_size)
+{
+    // samples are only emitted inside the roi (AABB type): at most diag/step of them, +3 for rounding slack
+    const float dx = roi_host[3] - roi_host[0], dy = roi_host[4] - roi_host[1], dz = roi_host[5] - roi_host[2];
+    const double diag = sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+    const double n = diag / (double)step_size + 3.0;
+    return n > 65536.0 ? 0u : (uint32_t)n;
+}
+
+static int launch_bricks(int mode, const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                         const float *roi, const uint64_t *bricks, int rx, int ry, int rz, int type, float step,
+                         float cone, const int32_t *packed, int32_t *num_steps, int64_t *ri, float *t0, float *t1,
+                         float *scratch, uint32_t cap, uint32_t n_rays, void *stream)
+{
+    const uint32_t nb = (uint32_t)((rx >> 2) * (ry >> 2) * (rz >> 2));
+    const uint32_t n_words = (nb + 31) / 32;
+    const uint32_t *any_bits = (const uint32_t *)(bricks + nb);
+    const size_t lds = n_words * sizeof(uint32_t);
+    NSR_REQUIRE(lds <= 64 * 1024, "nsr_ray_march(bricks): grid too large for the LDS any-bit table");
+    const dim3 grid(nsr_div_up(n_rays, MARCH_BLOCK)), block(MARCH_BLOCK);
+    const int3 res = make_int3(rx, ry, rz);
+#define NSR_LAUNCH_BRICKS(M)                                                                                          \
+    hipLaunchKernelGGL((k_ray_march_bricks<M>), grid, block, lds, (hipStream_t)stream, rays_o, rays_d, t_min, t_max, \
+                       roi, (const unsigned long long *)bricks, any_bits, n_words, res, type, step, cone, packed,     \
+                       num_steps, ri, t0, t1, (float2 *)scratch, cap, n_rays)
+    if (mode == 0) NSR_LAUNCH_BRICKS(0);
+    else if (mode == 1) NSR_LAUNCH_BRICKS(1);
+    else NSR_LAUNCH_BRICKS(2);
+#undef NSR_LAUNCH_BRICKS
+    return NSR_OK;
+}
+
+extern "C" int nsr_ray_march_bricks_count(const float *rays_o, const float *rays_d, const float *t_min,
+                                          const float *t_max, const float *roi, const uint64_t *bricks, int res_x,
+                                          int res_y, int res_z, int contraction, float step_size, float cone_angle,
+                                          int32_t *num_steps, float *scratch, uint32_t capacity, uint32_t n_rays,
+                                          void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    if (int rc = check_march(rays_o, rays_d, t_min, t_max, roi, bricks, res_x, res_y, res_z, contraction, step_size))
+        return rc;
+    NSR_REQUIRE(num_steps, "nsr_ray_march_bricks_count: num_steps is NULL");
+    NSR_REQUIRE((scratch == nullptr) == (capacity == 0), "nsr_ray_march_bricks_count: scratch and capacity go together");
+    if (int rc = launch_bricks(scratch ? 2 : 0, rays_o, rays_d, t_min, t_max, roi, bricks, res_x, res_y, res_z,
+                               contraction, step_size, cone_angle, nullptr, num_steps, nullptr, nullptr, nullptr,
+                               scratch, capacity, n_rays, stream))
+        return rc;
+    NSR_CHECK_LAUNCH("nsr_ray_march_bricks_count");
+    return NSR_OK;
+}
+
+extern "C" int nsr_ray_march_bricks_write(const float *rays_o, const float *rays_d, const float *t_min,
+                                          const float *t_max, const float *roi, const uint64_t *bricks, int res_x,
+                                          int res_y, int res_z, int contraction, float step_size, float cone_angle,
+                                          const int32_t *packed_info, const float *scratch, uint32_t capacity,
+                                          int64_t *ray_indices, float *t_starts, float *t_ends, uint32_t n_rays,
+                                          void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && ray_indices && t_starts && t_ends, "nsr_ray_march_bricks_write: NULL output");
+    if (scratch) {
+        hipLaunchKernelGGL(k_pack_scratch, dim3(nsr_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float2 *)scratch, capacity, packed_info, ray_indices, t_starts, t_ends, n_rays);
+    } else {
+        if (int rc = check_march(rays_o, rays_d, t_min, t_max, roi, bricks, res_x, res_y, res_z, contraction, step_size))
+            return rc;
+        if (int rc = launch_bricks(1, rays_o, rays_d, t_min, t_max, roi, bricks, res_x, res_y, res_z, contraction,
+                                   step_size, cone_angle, packed_info, nullptr, ray_indices, t_starts, t_ends, nullptr, 0,
+                                   n_rays, stream))
+            return rc;
+    }
+    NSR_CHECK_LAUNCH("nsr_ray_march_bricks_write");
     return NSR_OK;
 }
 

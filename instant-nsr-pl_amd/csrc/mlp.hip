@@ -475,15 +475,29 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
     for (int k = threadIdx.x; k < N_PARAMS; k += MLP_BLOCK) dst[k] = lds_dw[k];
 }
 
+// grad[k] += inv_scale * sum_b partials[b][k].  2-D grid: x = 256-parameter column blocks, y = row segments; each
+// block sums its rows with 4 independent accumulators and finishes with one fp32 atomic per parameter
+// (n_params * RED_SEGS atomics in total: a few tens of thousands).
+constexpr int RED_SEGS = 8;
 __global__ void __launch_bounds__(256)
 k_reduce_partials(const float *__restrict__ partials, float *__restrict__ grad, uint32_t n_params, uint32_t n_blocks,
                   float inv_scale)
 {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n_params) return;
-    float s = 0.f;
-    for (uint32_t b = 0; b < n_blocks; ++b) s += partials[(uint64_t)b * n_params + k];
-    grad[k] += s * inv_scale;
+    const uint32_t per = (n_blocks + RED_SEGS - 1) / RED_SEGS;
+    const uint32_t b0 = blockIdx.y * per, b1 = min(n_blocks, b0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    uint32_t b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        s0 += partials[(uint64_t)(b + 0) * n_params + k];
+        s1 += partials[(uint64_t)(b + 1) * n_params + k];
+        s2 += partials[(uint64_t)(b + 2) * n_params + k];
+        s3 += partials[(uint64_t)(b + 3) * n_params + k];
+    }
+    for (; b < b1; ++b) s0 += partials[(uint64_t)b * n_params + k];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (b1 > b0) unsafeAtomicAdd(grad + k, s * inv_scale);
 }
 
 int check_mlp(const NsrMlpDesc *d, const char *who)
@@ -577,7 +591,7 @@ extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout
     });
     NSR_CHECK_LAUNCH("nsr_mlp_backward");
     if (grad_weights) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3(nsr_div_up(np, 256)), dim3(256), 0, (hipStream_t)stream, partials,
+        hipLaunchKernelGGL(k_reduce_partials, dim3(nsr_div_up(np, 256), RED_SEGS), dim3(256), 0, (hipStream_t)stream, partials,
                            grad_weights, np, nb, 1.f / grad_scale);
         NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
     }

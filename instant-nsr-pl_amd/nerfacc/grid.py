@@ -44,6 +44,7 @@ class OccupancyGrid(Grid):
         self._contraction_type = contraction_type
         self.register_buffer("resolution", resolution.clone())
         self.register_buffer("occs", torch.zeros(self.num_cells))
+        self._roi_host = [float(v) for v in roi_aabb.detach().cpu().tolist()]  # host copy: sample-capacity bound
 
     @property
     def roi_aabb(self):

@@ -35,15 +35,17 @@ def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid=N
         t_max = torch.clamp(t_max, max=far_plane)
     if stratified:
         t_min = t_min + torch.rand_like(t_min) * render_step_size
+    roi_host = None
     if grid is not None:
         roi, binary, ctype = grid.roi_aabb, grid.binary, grid.contraction_type
+        roi_host = getattr(grid, "_roi_host", None)
     else:
         roi = torch.tensor([-1e10, -1e10, -1e10, 1e10, 1e10, 1e10], dtype=torch.float32, device=rays_o.device)
         binary = torch.ones([1, 1, 1], dtype=torch.bool, device=rays_o.device)
         ctype = ContractionType.AABB
     packed, ray_indices, t_starts, t_ends = _ops.ray_march(
         rays_o, rays_d, t_min.float().contiguous(), t_max.float().contiguous(), roi.float().contiguous(),
-        binary.contiguous(), ctype.value, render_step_size, cone_angle)
+        binary.contiguous(), ctype.value, render_step_size, cone_angle, roi_host=roi_host)
     ray_indices._nsr_packed = (n_rays, ray_indices.shape[0], packed)
 
     if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):

@@ -1,0 +1,106 @@
+"""One-process-per-GPU training step around the hot path (mirror of reference ``systems/nerf.py:87-122``,
+``systems/base.py:54-57``): sample rays -> refresh occupancy -> render -> loss -> backward -> all-reduce -> AdamW.
+
+Multi-GPU: rays shard naturally.  Every rank draws its OWN ray batch (rank-offset RNG: the reference seeds all ranks
+identically, launch.py:62-64, so its DDP ranks render duplicate batches), replicates the 50 MB model, and the only
+data-path collective is one mean all-reduce of the gradients per step over RCCL (``torch.distributed`` backend "nccl").
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+import tinycudann as tcnn
+from nsr_hip import ops as _ops
+
+
+class FusedAdamW:
+    """AdamW over the flat fp32 parameters with ONE kernel per tensor that also unscales, refreshes the fp16 shadow
+    the kernels read and zeroes the gradient (configs/nerf-blender.yaml:74-79: lr 0.01, betas (0.9,0.99), eps 1e-15)."""
+
+    def __init__(self, named_modules, other_params, lr=0.01, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.01):
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.tcnn_modules = [m for m in named_modules if isinstance(m, tcnn.Module) and m.params.numel() > 0]
+        self.state = {}
+        for m in self.tcnn_modules:
+            p = m.params
+            self.state[p] = (torch.zeros_like(p), torch.zeros_like(p), torch.empty_like(p, dtype=torch.float16))
+            p.grad = torch.zeros_like(p)
+        self.other = torch.optim.AdamW(other_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) \
+            if other_params else None
+
+    def step(self, lr_scale=1.0, grad_unscale=1.0):
+        self.step_count += 1
+        for m in self.tcnn_modules:
+            p = m.params
+            exp_avg, exp_avg_sq, shadow = self.state[p]
+            _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr * lr_scale, self.betas[0],
+                            self.betas[1], self.eps, self.wd, self.step_count, grad_unscale=grad_unscale, zero_grad=True)
+            # the kernel already wrote the fp16 copy: hand it to the module instead of re-casting 12.6 M floats
+            m._shadow, m._shadow_key = shadow, (p.data_ptr(), p._version, p.device)
+        if self.other is not None:
+            for g in self.other.param_groups:
+                g["lr"] = self.lr * lr_scale
+            self.other.step()
+            self.other.zero_grad(set_to_none=False)
+
+
+def multistep_lr_scale(step, milestones=(10000, 15000, 18000), gamma=0.33):
+    """configs/nerf-blender.yaml:80-85"""
+    return gamma ** sum(step >= m for m in milestones)
+
+
+class Trainer:
+    def __init__(self, model, dataset, config, rank=0, world_size=1, seed=42):
+        self.model, self.dataset, self.config = model, dataset, config
+        self.rank, self.world_size = rank, world_size
+        self.device = next(model.parameters()).device
+        self.train_num_samples = config["train_num_rays"] * config["num_samples_per_ray"]  # systems/nerf.py:27
+        self.train_num_rays = config["train_num_rays"]
+        self.global_step = 0
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed + 1000 * rank)  # per-rank ray batches (see module docstring)
+        for m in model.modules():  # grads leave the fused modules in fp32: no GradScaler, no fp16 underflow
+            if isinstance(m, tcnn.Module):
+                m.dtype = torch.float32
+        tc = [m for m in model.modules() if isinstance(m, tcnn.Module)]
+        tc_params = {id(m.params) for m in tc}
+        other = [p for p in model.parameters() if id(p) not in tc_params]
+        self.opt = FusedAdamW(tc, other)
+        self.last = {}
+
+    def _all_reduce_grads(self):
+        if self.world_size == 1:
+            return
+        for p in self.model.parameters():
+            if p.grad is not None and p.numel() > 0:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
+
+    def loss_fn(self, out, rgb, fg):
+        valid = out["rays_valid"][..., 0]
+        return F.smooth_l1_loss(out["comp_rgb"][valid], rgb[valid])  # systems/nerf.py:97
+
+    def train_step(self):
+        model = self.model
+        with _ops.timed("phase:sample_rays"):
+            rays, rgb, fg, bg = self.dataset.sample_rays(self.train_num_rays, self.gen, self.config["background_color"])
+        model.background_color = bg
+        with _ops.timed("phase:occupancy_update"):
+            model.update_step(0, self.global_step)
+        with _ops.timed("phase:forward"):
+            out = model(rays)
+        n_samples = int(out["num_samples_full" if "num_samples_full" in out else "num_samples"].sum().item())
+        if self.config["dynamic_ray_sampling"] and n_samples > 0:  # systems/nerf.py:93-95
+            t = int(self.train_num_rays * (self.train_num_samples / n_samples))
+            self.train_num_rays = min(int(self.train_num_rays * 0.9 + t * 0.1), self.config["max_train_num_rays"])
+        with _ops.timed("phase:loss"):
+            loss = self.loss_fn(out, rgb, fg)
+        with _ops.timed("phase:backward"):
+            loss.backward()
+        with _ops.timed("phase:all_reduce"):
+            self._all_reduce_grads()
+        with _ops.timed("phase:optimizer"):
+            self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
+        self.global_step += 1
+        self.last = {"loss": loss.detach(), "n_rays": rays.shape[0], "n_samples": n_samples}
+        return self.last

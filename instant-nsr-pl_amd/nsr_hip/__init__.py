@@ -52,6 +52,8 @@ SIGNATURES = {
     "nsr_hashgrid_make_desc": [_GD, _U, _U, _U, _U, _F],
     "nsr_hashgrid_forward": [_P, _P, _P, _U, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_params": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P],
+    "nsr_hashgrid_backward_params_workspace_floats": [_GD, _U],
+    "nsr_hashgrid_backward_params_owner": [_P, _P, _I, _U, _P, _P, _U, _U, _F, _I, _GD, _P],
     "nsr_hashgrid_backward_input": [_P, _P, _P, _I, _U, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_backward_input": [_P, _P, _P, _I, _U, _P, _P, _U, _P, _P, _U, _U, _GD, _P],
     "nsr_sh4_forward": [_P, _P, _U, _U, _P],
@@ -61,6 +63,11 @@ SIGNATURES = {
     "nsr_ray_aabb_intersect": [_P, _P, _P, _P, _P, _U, _P],
     "nsr_ray_march_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _U, _P],
     "nsr_ray_march_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _U, _P],
+    "nsr_grid_bricks_words64": [_I, _I, _I],
+    "nsr_grid_pack_bricks": [_P, _I, _I, _I, _P, _P],
+    "nsr_ray_march_capacity": [ctypes.POINTER(ctypes.c_float), _F],
+    "nsr_ray_march_bricks_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _U, _P],
+    "nsr_ray_march_bricks_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _P, _P, _P, _U, _P],
     "nsr_pack_from_counts": [_P, _P, _P, _U, _P],
     "nsr_pack_info": [_P, _P, _U, _U, _P],
     "nsr_contract": [_P, _P, _I, _P, _U, _P],
@@ -80,7 +87,9 @@ SIGNATURES = {
     "nsr_neus_alpha_backward": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _U, _P],
     "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P],
 }
-_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64}
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
+             "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,
+             "nsr_grid_bricks_words64": ctypes.c_uint64, "nsr_ray_march_capacity": ctypes.c_uint32}
 
 
 class NsrError(RuntimeError):

@@ -14,6 +14,44 @@ from . import NsrError, check, lib, ptr, stream_ptr
 _byref = ctypes.byref
 F32, F16 = torch.float32, torch.float16
 
+# ---- optional HIP-event timing of the hot kernels (bench.py's roofline leg) -----------------------------------
+# Events are recorded on torch's current stream, which is the stream every kernel here is launched on.
+_PROFILE = None
+
+
+def profile_begin():
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_end():
+    """-> {name: (total_ms, launches, units)}; synchronises."""
+    global _PROFILE
+    prof, _PROFILE = _PROFILE or {}, None
+    torch.cuda.synchronize()
+    return {k: (sum(a.elapsed_time(b) for a, b, _ in v), len(v), sum(u for _, _, u in v)) for k, v in prof.items()}
+
+
+class _timed:
+    def __init__(self, name, units):
+        self.name, self.units = name, units
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROFILE.setdefault(self.name, []).append((self.a, b, self.units))
+
+
+def timed(name, units=1):
+    """phase timers for bench.py / the trainer (no-ops unless profile_begin() was called)"""
+    return _timed(name, units)
+
 
 def _f32c(t):
     return t.detach().to(F32).contiguous()
@@ -35,18 +73,32 @@ def hashgrid_forward(x, table_half, desc, mask_count=None, out=None):
     C = desc.n_levels * desc.n_features
     y = torch.empty((n, C), dtype=F16, device=x.device) if out is None else out
     mc = desc.n_levels if mask_count is None else int(mask_count)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed("hashgrid_forward", n):
         check(lib.nsr_hashgrid_forward(ptr(x), ptr(table_half), ptr(y), n, y.stride(0), mc, _byref(desc),
                                        stream_ptr()), "nsr_hashgrid_forward")
     return y
 
 
-def hashgrid_backward_params(x, dy, grad_table, desc, mask_count=None, grad_scale=1.0):
+def hashgrid_backward_params(x, dy, grad_table, desc, mask_count=None, grad_scale=1.0, accumulate=True,
+                             method="owner", level_major=False):
+    """grad_table (+)= scatter(dy).  method "owner": atomic-free owner-computes kernel (default);
+    "atomic": one lane per (sample, level) with global fp32 atomics (always accumulates)."""
     mc = desc.n_levels if mask_count is None else int(mask_count)
-    with torch.cuda.device(x.device):
-        check(lib.nsr_hashgrid_backward_params(ptr(x), ptr(dy), _is_f32(dy), dy.stride(0), ptr(grad_table),
-                                               x.shape[0], mc, float(grad_scale), _byref(desc), stream_ptr()),
-              "nsr_hashgrid_backward_params")
+    n = x.shape[0]
+    with torch.cuda.device(x.device), _timed("hashgrid_backward_params", n):
+        if method == "atomic":
+            if not accumulate:
+                grad_table.zero_()
+            check(lib.nsr_hashgrid_backward_params(ptr(x), ptr(dy), _is_f32(dy), dy.stride(0), ptr(grad_table), n, mc,
+                                                   float(grad_scale), _byref(desc), stream_ptr()),
+                  "nsr_hashgrid_backward_params")
+        else:
+            layout, stride = (2, 0) if level_major else (_is_f32(dy), dy.stride(0))
+            nws = lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), n)
+            ws = torch.empty(int(nws), dtype=F32, device=x.device)
+            check(lib.nsr_hashgrid_backward_params_owner(ptr(x), ptr(dy), layout, stride, ptr(grad_table), ptr(ws), n, mc,
+                                                         float(grad_scale), int(bool(accumulate)), _byref(desc),
+                                                         stream_ptr()), "nsr_hashgrid_backward_params_owner")
     return grad_table
 
 
@@ -83,7 +135,8 @@ class _GridEncode(Function):
         y = hashgrid_forward(x, table, owner.grid_desc, mc)
         ctx.save_for_backward(x, params)
         ctx.owner, ctx.table, ctx.mc = owner, table, mc
-        return y
+        # dtype=float32 modules convert INSIDE the Function so the incoming gradient stays fp32
+        return y.float() if owner.dtype == torch.float32 else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -101,8 +154,8 @@ class _GridEncodeBackward(Function):
         desc = owner.grid_desc
         dx = hashgrid_backward_input(x, table, dy, desc, mc) if need_x else torch.zeros_like(x)
         if need_p:
-            dp = torch.zeros_like(params, dtype=F32)
-            hashgrid_backward_params(x, dy, owner.grid_slice(dp), desc, mc)
+            dp = torch.empty_like(params, dtype=F32)  # the owner kernel writes every entry: no memset
+            hashgrid_backward_params(x, dy, owner.grid_slice(dp), desc, mc, accumulate=False)
         else:
             dp = torch.zeros(1, dtype=F32, device=x.device)
         ctx.save_for_backward(x, params, dy)
@@ -151,7 +204,7 @@ def mlp_forward(x, weights_half, desc, save_acts):
     n = x.shape[0]
     out = torch.empty((n, desc.out_pad), dtype=F16, device=x.device)
     acts = torch.empty((desc.n_hidden, n, 64), dtype=F16, device=x.device) if save_acts else None
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed(f"mlp_forward_h{desc.n_hidden}", n):
         check(lib.nsr_mlp_forward(ptr(x), _is_f32(x), x.stride(0), ptr(weights_half), ptr(out), ptr(acts), n,
                                   _byref(desc), stream_ptr()), "nsr_mlp_forward")
     return out, acts
@@ -164,7 +217,7 @@ def mlp_backward(dout, out, x, acts, weights_half, desc, grad_weights=None, want
     if grad_weights is not None:
         nws = lib.nsr_mlp_backward_workspace_floats(_byref(desc), n)
         partials = torch.empty(int(nws), dtype=F32, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed(f"mlp_backward_h{desc.n_hidden}", n):
         check(lib.nsr_mlp_backward(ptr(dout), _is_f32(dout), dout.stride(0), ptr(out), ptr(x), _is_f32(x), x.stride(0),
                                    ptr(acts), ptr(weights_half), ptr(grad_weights), ptr(dx),
                                    desc.n_in if want_dx else 0, ptr(partials), n, float(grad_scale), _byref(desc),
@@ -180,7 +233,8 @@ class _Mlp(Function):
         out, acts = mlp_forward(x, w, desc, save_acts=train)
         ctx.save_for_backward(x, params)
         ctx.owner, ctx.w, ctx.out, ctx.acts = owner, w, out, acts
-        return out[:, :desc.n_out]
+        res = out[:, :desc.n_out]
+        return res.float() if owner.dtype == torch.float32 else res
 
     @staticmethod
     @once_differentiable
@@ -218,7 +272,8 @@ class _GridMlp(Function):
         out, acts = mlp_forward(enc, w, owner.mlp_desc, save_acts=train)
         ctx.save_for_backward(x, params)
         ctx.owner, ctx.table, ctx.w, ctx.enc, ctx.out, ctx.acts = owner, table, w, enc, out, acts
-        return out[:, :owner.mlp_desc.n_out]
+        res = out[:, :owner.mlp_desc.n_out]
+        return res.float() if owner.dtype == torch.float32 else res
 
     @staticmethod
     @once_differentiable
@@ -228,13 +283,17 @@ class _GridMlp(Function):
         if ctx.acts is None:
             raise NsrError("backward without saved activations (forward ran with grad disabled)")
         need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dp = torch.zeros_like(params, dtype=F32) if need_p else None
-        # grads w.r.t. the encoding leave the MLP in fp32 and go straight into the fp32 atomics
+        dp = None
+        if need_p:  # only the (tiny) MLP slice needs zeroing; the grid slice is overwritten by the owner kernel
+            dp = torch.empty_like(params, dtype=F32)
+            owner.mlp_slice(dp).zero_()
+        # grads w.r.t. the encoding leave the MLP in fp32 and feed the table backward directly
         d_enc = mlp_backward(dout.contiguous(), ctx.out, ctx.enc, ctx.acts, ctx.w, owner.mlp_desc,
                              grad_weights=owner.mlp_slice(dp) if need_p else None, want_dx=True,
                              grad_scale=owner.loss_scale)
         if need_p:
-            hashgrid_backward_params(x, d_enc, owner.grid_slice(dp), owner.grid_desc, owner.level_mask_count())
+            hashgrid_backward_params(x, d_enc, owner.grid_slice(dp), owner.grid_desc, owner.level_mask_count(),
+                                     accumulate=False)
         dx = hashgrid_backward_input(x, ctx.table, d_enc, owner.grid_desc, owner.level_mask_count()) if need_x else None
         return dx, dp, None, None
 
@@ -256,29 +315,78 @@ def ray_aabb_intersect(rays_o, rays_d, aabb):
     return t_min, t_max
 
 
-def ray_march(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone_angle):
-    """two-call protocol; ONE host sync (the sample count).  Returns packed_info, ray_indices, t_starts, t_ends."""
+def grid_bricks(binary):
+    """4x4x4-brick bit packing of a bool grid, cached on the tensor object (keyed by its version counter).
+    None when the resolution is not brick-able (then the byte-grid kernels are used)."""
+    rx, ry, rz = (int(s) for s in binary.shape)
+    words = int(lib.nsr_grid_bricks_words64(rx, ry, rz))
+    if words == 0 or ((rx >> 2) * (ry >> 2) * (rz >> 2)) % 64 != 0:
+        return None
+    tag = getattr(binary, "_nsr_bricks", None)
+    if tag is not None and tag[0] == binary._version and tag[1] == binary.data_ptr():
+        return tag[2]
+    grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
+    bricks = torch.empty(words, dtype=torch.int64, device=binary.device)
+    with torch.cuda.device(binary.device):
+        check(lib.nsr_grid_pack_bricks(ptr(grid_u8), rx, ry, rz, ptr(bricks), stream_ptr()), "nsr_grid_pack_bricks")
+    try:
+        binary._nsr_bricks = (binary._version, binary.data_ptr(), bricks)
+    except Exception:  # noqa: BLE001
+        pass
+    return bricks
+
+
+def ray_march(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone_angle, roi_host=None,
+              method="bricks"):
+    """occupancy-grid marching; ONE host sync (the sample count).  -> packed_info, ray_indices, t_starts, t_ends.
+
+    method "bricks" (default): bit-packed 4^3 bricks + LDS any-bits, single marching pass into per-ray scratch when
+    the sample capacity is provable (AABB contraction with a finite roi: pass ``roi_host`` = 6 python floats);
+    method "bytes": the plain two-pass byte-grid kernels.  Both are bit-exact against the oracle."""
     n = rays_o.shape[0]
     dev = rays_o.device
     rx, ry, rz = (int(s) for s in binary.shape)
-    grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
     counts = torch.empty(n, dtype=torch.int32, device=dev)
     packed = torch.empty((n, 2), dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int32, device=dev)
+    bricks = grid_bricks(binary) if method == "bricks" else None
     with torch.cuda.device(dev):
         s = stream_ptr()
-        check(lib.nsr_ray_march_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(grid_u8), rx, ry,
-                                      rz, int(contraction), float(step), float(cone_angle), ptr(counts), n, s),
-              "nsr_ray_march_count")
+        if bricks is None:
+            grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
+            with _timed("ray_march_count", n):
+                check(lib.nsr_ray_march_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(grid_u8),
+                                              rx, ry, rz, int(contraction), float(step), float(cone_angle), ptr(counts),
+                                              n, s), "nsr_ray_march_count")
+            cap, scratch = 0, None
+        else:
+            cap = 0
+            if roi_host is not None and int(contraction) == 0:
+                cap = int(lib.nsr_ray_march_capacity((ctypes.c_float * 6)(*[float(v) for v in roi_host]), float(step)))
+            scratch = torch.empty(n * cap * 2, dtype=F32, device=dev) if cap > 0 else None
+            with _timed("ray_march_count", n):
+                check(lib.nsr_ray_march_bricks_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
+                                                     ptr(bricks), rx, ry, rz, int(contraction), float(step),
+                                                     float(cone_angle), ptr(counts), ptr(scratch), cap, n, s),
+                      "nsr_ray_march_bricks_count")
         check(lib.nsr_pack_from_counts(ptr(counts), ptr(packed), ptr(total), n, s), "nsr_pack_from_counts")
         m = int(total.item())  # the marcher's one intrinsic host sync
         ray_indices = torch.empty(m, dtype=torch.int64, device=dev)
         t_starts = torch.empty((m, 1), dtype=F32, device=dev)
         t_ends = torch.empty((m, 1), dtype=F32, device=dev)
         if m > 0:
-            check(lib.nsr_ray_march_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(grid_u8), rx,
-                                          ry, rz, int(contraction), float(step), float(cone_angle), ptr(packed),
-                                          ptr(ray_indices), ptr(t_starts), ptr(t_ends), n, s), "nsr_ray_march_write")
+            with _timed("ray_march_write", n):
+                if bricks is None:
+                    check(lib.nsr_ray_march_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
+                                                  ptr(grid_u8), rx, ry, rz, int(contraction), float(step),
+                                                  float(cone_angle), ptr(packed), ptr(ray_indices), ptr(t_starts),
+                                                  ptr(t_ends), n, s), "nsr_ray_march_write")
+                else:
+                    check(lib.nsr_ray_march_bricks_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
+                                                         ptr(bricks), rx, ry, rz, int(contraction), float(step),
+                                                         float(cone_angle), ptr(packed), ptr(scratch), cap,
+                                                         ptr(ray_indices), ptr(t_starts), ptr(t_ends), n, s),
+                          "nsr_ray_march_bricks_write")
     return packed, ray_indices, t_starts, t_ends
 
 

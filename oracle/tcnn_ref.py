@@ -118,7 +118,8 @@ def hashgrid_encode(x, table, desc, fp16=True):
         g = torch.floor(pos.detach())
         w = pos - g
         gi = g.to(torch.int64)
-        acc = None
+        # all 8 corners in ONE gather per level (one dense scatter in backward instead of eight)
+        idxs, wgts = [], []
         for c in range(8):
             wgt = None
             corner = []
@@ -127,9 +128,12 @@ def hashgrid_encode(x, table, desc, fp16=True):
                 wd = w[:, d] if bit else (1.0 - w[:, d])
                 wgt = wd if wgt is None else wgt * wd
                 corner.append(gi[:, d] + bit)
-            idx = grid_index(corner[0], corner[1], corner[2], res, size)
-            term = wgt[:, None] * table[off + idx]
-            acc = term if acc is None else acc + term
+            idxs.append(grid_index(corner[0], corner[1], corner[2], res, size))
+            wgts.append(wgt)
+        idx = torch.stack(idxs, dim=1)                      # [N, 8]
+        wgt = torch.stack(wgts, dim=1)                      # [N, 8]
+        feat = table[off + idx]                             # [N, 8, F]
+        acc = (wgt[..., None] * feat).sum(dim=1)
         outs.append(acc)
     y = torch.cat(outs, dim=-1)
     if fp16:

@@ -58,23 +58,45 @@ def test_forward_mask_count_zeroes_levels():
     assert torch.allclose(y[:, :10], ref[:, :10], rtol=2e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("method", ["owner", "atomic"])
 @pytest.mark.parametrize("dy_f32", [False, True])
-def test_backward_params_parity(dy_f32):
+def test_backward_params_parity(dy_f32, method):
     from oracle import tcnn_ref
     from nsr_hip import ops
     od, hd, x, table = _setup(NERF_GRID, 3001)
     g = torch.Generator().manual_seed(5)
     dy = torch.randn(x.shape[0], 32, generator=g)
+    dy[7] = 0.0  # a sample with zero upstream gradient
     if not dy_f32:
         dy = dy.half().float()
     t = table.clone().requires_grad_(True)
     tcnn_ref.hashgrid_encode(x, t.view(-1, od.F), od, fp16=False).backward(dy)
-    grad = torch.zeros(od.n_params, device="cuda")
-    ops.hashgrid_backward_params(x.cuda(), (dy if dy_f32 else dy.half()).cuda(), grad, hd)
-    grad = grad.cpu()
-    rel = (grad - t.grad).norm() / t.grad.norm()
-    assert rel < 1e-5, rel  # fp32 atomics: only summation order differs
-    assert bool(((grad != 0) == (t.grad != 0)).all())
+    grad = torch.full((od.n_params,), 7.0, device="cuda")  # garbage: accumulate=False must overwrite everything
+    dyc = (dy if dy_f32 else dy.half()).cuda()
+    ops.hashgrid_backward_params(x.cuda(), dyc, grad, hd, accumulate=False, method=method)
+    g1 = grad.clone()
+    ops.hashgrid_backward_params(x.cuda(), dyc, grad, hd, accumulate=True, method=method)
+    assert torch.allclose(grad, 2 * g1, rtol=1e-5, atol=1e-7)
+    g1 = g1.cpu()
+    rel = (g1 - t.grad).norm() / t.grad.norm()
+    assert rel < 1e-5, rel  # fp32 accumulation everywhere: only the summation order differs
+    assert bool(((g1 != 0) == (t.grad != 0)).all())
+
+
+def test_backward_params_owner_level_major_masked_and_features():
+    from nsr_hip import ops
+    for F in (1, 2, 4, 8):
+        od, hd, x, table = _setup(NEUS_GRID, 1000, F=F)
+        C = 16 * F
+        dy = torch.randn(1000, C).cuda()
+        xc = x.cuda()
+        a = torch.zeros(od.n_params, device="cuda")
+        b = torch.empty(od.n_params, device="cuda")
+        ops.hashgrid_backward_params(xc, dy, a, hd, mask_count=9, method="atomic")
+        dy_lm = dy.view(1000, 16, F).permute(1, 0, 2).contiguous()
+        ops.hashgrid_backward_params(xc, dy_lm, b, hd, mask_count=9, accumulate=False, level_major=True)
+        assert (a - b).norm() / a.norm() < 1e-5
+        assert bool((b[hd.offset[9] * F:] == 0).all())  # masked levels are written as zeros
 
 
 def test_backward_input_and_double_backward():

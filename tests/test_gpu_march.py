@@ -31,8 +31,9 @@ def test_ray_aabb_bit_exact():
     assert bool((a[:100] == 0).all())
 
 
+@pytest.mark.parametrize("method", ["bricks1", "bricks2", "bytes"])
 @pytest.mark.parametrize("n_rays,stepdiv", [(1, 1024), (257, 1024), (4096, 1024), (1000, 128)])
-def test_march_aabb_bit_exact(n_rays, stepdiv):
+def test_march_aabb_bit_exact(n_rays, stepdiv, method):
     from oracle import nerfacc_ref as N
     from nsr_hip import ops
     o, d, roi, binary = _scene(n_rays, seed=n_rays)
@@ -40,8 +41,10 @@ def test_march_aabb_bit_exact(n_rays, stepdiv):
     t_min, t_max = N.ray_aabb_intersect(o, d, roi)
     packed_ref, ri_ref, t0_ref, t1_ref = N.march_rays_packed(o, d, t_min, t_max, roi, binary, N.ContractionType.AABB,
                                                              step, 0.0)
+    # bricks1: single pass into per-ray scratch; bricks2: brick grid, two passes; bytes: byte grid, two passes
     packed, ri, t0, t1 = ops.ray_march(o.cuda(), d.cuda(), t_min.cuda(), t_max.cuda(), roi.cuda(), binary.cuda(), 0,
-                                       step, 0.0)
+                                       step, 0.0, roi_host=roi.tolist() if method == "bricks1" else None,
+                                       method="bytes" if method == "bytes" else "bricks")
     assert torch.equal(packed.cpu(), packed_ref)
     assert torch.equal(ri.cpu(), ri_ref)
     assert torch.equal(t0.cpu(), t0_ref) and torch.equal(t1.cpu(), t1_ref)
@@ -64,6 +67,21 @@ def test_march_unbounded_sphere_cone_bit_exact():
                                        cone)
     assert torch.equal(packed.cpu(), packed_ref) and torch.equal(ri.cpu(), ri_ref)
     assert torch.equal(t0.cpu(), t0_ref) and torch.equal(t1.cpu(), t1_ref)
+
+
+def test_brick_cache_follows_in_place_grid_edits():
+    from oracle import nerfacc_ref as N
+    from nsr_hip import ops
+    o, d, roi, binary = _scene(300, seed=2)
+    bg = binary.cuda()
+    t_min, t_max = N.ray_aabb_intersect(o, d, roi)
+    args = (o.cuda(), d.cuda(), t_min.cuda(), t_max.cuda(), roi.cuda())
+    _, ri_a, _, _ = ops.ray_march(*args, bg, 0, 0.005, 0.0, roi_host=roi.tolist())
+    bg[:, :64] = False  # in-place edit bumps the version: the cached bricks must be rebuilt
+    binary[:, :64] = False
+    _, ri_b, _, _ = ops.ray_march(*args, bg, 0, 0.005, 0.0, roi_host=roi.tolist())
+    _, ri_ref, _, _ = N.march_rays_packed(o, d, t_min, t_max, roi, binary, N.ContractionType.AABB, 0.005, 0.0)
+    assert torch.equal(ri_b.cpu(), ri_ref) and ri_a.numel() != ri_b.numel()
 
 
 def test_march_no_grid_and_empty():
