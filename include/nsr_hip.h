@@ -137,6 +137,16 @@ int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, co
                      const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                      float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream);
 
+/* Extended form used by the fused training step: `dout_extra_col0` (float[n], may be NULL) is added to column 0 of
+ * dout on load (the density gradient joining the feature gradient, models/geometry.py:125); with
+ * dx_level_major_features = F > 0, dx is written level-major [n_in/F][n][F] (what the owner-computes hash-grid
+ * backward reads) and dx_stride is ignored. */
+int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                        const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *acts,
+                        const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
+                        uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
+                        const NsrMlpDesc *desc, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * nerfacc 0.3.3 kernels
  * ------------------------------------------------------------------------------------------------ */
@@ -247,6 +257,47 @@ int nsr_neus_alpha_backward(const float *sdf, const float *normal, const float *
                             const float *inv_s, float cos_anneal_ratio, const float *grad_alpha,
                             float *grad_sdf, float *grad_normal, float *grad_inv_s, /* grad_inv_s: device[1], accumulated */
                             uint32_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused training-step glue, see csrc/fused.hip
+ * ------------------------------------------------------------------------------------------------ */
+/* x01 = contract_to_unisphere(o[r] + d[r]*(t0+t1)/2); dirs_out (may be NULL) = d[r]   (nerf.py:66-69,95-99) */
+int nsr_sample_positions_unit(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                              const float *t_starts, const float *t_ends, float radius, int contraction, float *x01,
+                              float *dirs_out, uint32_t n, void *stream);
+/* kept_counts[r] = number of leading samples of ray r with transmittance >= early_stop_eps, where alpha comes from
+ * trunc_exp(mlp_out[:,0] + density_bias) -- nerfacc's render_visibility with alpha_thre == 0 (nerf.py:82-93) */
+int nsr_visibility_prefix(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                          const float *t_ends, const int32_t *packed_info, float early_stop_eps, int32_t *kept_counts,
+                          uint32_t n_rays, void *stream);
+int nsr_copy_ray_prefixes(const int32_t *packed_old, const int32_t *packed_new, const float *t_starts,
+                          const float *t_ends, int64_t *ray_indices_out, float *t_starts_out, float *t_ends_out,
+                          uint32_t n_rays, void *stream);
+/* tex_in[n,32] (half) = [mlp_out[:, :16] | SH4((dirs+1)/2)]   (texture.py:24-26) */
+int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in, uint32_t n,
+                      void *stream);
+/* density = exp(mlp_out[:,0] + bias); weights/trans [n]; comp_rgb[R,3] = sum w*rgb + background*(1-opacity)
+ * (nerf.py:105-109); rgb: half rows of rgb_stride, first 3 columns */
+int nsr_composite_forward(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                          const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
+                          const float *background, float *weights, float *trans, float *comp_rgb, float *opacity,
+                          float *depth, uint32_t n_rays, void *stream);
+int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                           const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
+                           const float *background, const float *weights, const float *trans,
+                           const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
+                           float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream);
+/* acc2[0] += sum of smooth_l1 over valid rays (opacity > 0) x 3 channels, acc2[1] += number of valid rays
+ * (loss = acc2[0] / (3*acc2[1]), systems/nerf.py:97); backward writes grad_scale * dloss/dcomp_rgb */
+int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,
+                        uint32_t n_rays, void *stream);
+int nsr_smooth_l1_valid_backward(const float *comp_rgb, const float *opacity, const float *gt_rgb, const float *acc2,
+                                 float grad_scale, float *grad_comp_rgb, uint32_t n_rays, void *stream);
+/* training-ray gather (systems/nerf.py:38-79, models/ray_utils.py:23-43): rays[n,6], rgb[n,3], fg[n] */
+int nsr_gather_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,
+                          const int64_t *index, const int64_t *px, const int64_t *py, const float *background,
+                          int height, int width, int apply_mask, float *rays, float *rgb, float *fg, uint32_t n,
+                          void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:

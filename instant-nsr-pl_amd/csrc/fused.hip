@@ -1,0 +1,444 @@
+// Fused glue of the NeRF training step for gfx950: the ~100 small elementwise / indexing / autograd kernels that
+// the reference runs between its tcnn and nerfacc calls (models/nerf.py:61-127, models/geometry.py:122-130,
+// models/texture.py:23-30, systems/nerf.py:33-99) collapsed into a handful of launches.
+//
+//   sample_positions_unit : o[r] + d[r]*(t0+t1)/2 -> contract_to_unisphere           (nerf.py:66-69,95-99; geometry.py:17-29)
+//   visibility_prefix     : sigma_fn -> alpha -> transmittance -> T >= eps, per ray  (nerfacc render_visibility inside
+//                           ray_marching; T is non-increasing so the kept samples of a ray are a PREFIX -> counts only)
+//   copy_ray_prefixes     : order-preserving compaction of those prefixes
+//   texture_input         : [feature | SH4((d+1)/2)] as the fp16 MLP input              (texture.py:24-26)
+//   composite_forward     : trunc_exp density -> weights -> opacity/depth/rgb + background blend  (nerf.py:105-109)
+//   smooth_l1_valid       : F.smooth_l1_loss(comp_rgb[valid], rgb[valid]) and its gradient        (systems/nerf.py:97)
+//   composite_backward    : d comp_rgb -> d rgb, d density-logit (transmittance scan backward + trunc_exp backward)
+//   gather_train_rays     : pixel gather + get_rays + normalise + background blend     (systems/nerf.py:38-79)
+//
+// One wavefront per ray for everything segmented (shuffle scans, no LDS, deterministic order).
+#include "nsr_common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+constexpr int R_BLOCK = 256;
+constexpr int RAYS_PER_BLOCK = R_BLOCK / NSR_WAVE;
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_sample_positions_unit(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                        const int64_t *__restrict__ ray_indices, const float *__restrict__ t0,
+                        const float *__restrict__ t1, float radius, int type, float *__restrict__ x01,
+                        float *__restrict__ dirs, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ray_indices[i];
+    const float tm = (t0[i] + t1[i]) / 2.f;
+    const float den = radius - (-radius);
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float d = rays_d[3 * r + k];
+        const float p = __fadd_rn(rays_o[3 * r + k], __fmul_rn(d, tm));
+        v[k] = (p - (-radius)) / den;
+        if (dirs) dirs[3ull * i + k] = d;
+    }
+    if (type == NSR_CONTRACT_UN_BOUNDED_SPHERE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] * 2.f - 1.f;
+        const float mag = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (mag > 1.f) {
+            const float s = 2.f - 1.f / mag;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = s * (v[k] / mag);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] / 4.f + 0.5f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x01[3ull * i + k] = v[k];
+}
+
+__device__ __forceinline__ bool wave_ray(const int32_t *__restrict__ packed, uint32_t n_rays, uint32_t &r,
+                                         uint32_t &start, uint32_t &count)
+{
+    r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= n_rays) return false;
+    start = (uint32_t)packed[2ull * r];
+    count = (uint32_t)packed[2ull * r + 1];
+    return true;
+}
+
+// kept[r] = #{ i in ray r : T_i >= eps },  T_i = prod_{j<i} (1 - alpha_j),  alpha = 1 - exp(-exp(logit+bias) * dt)
+__global__ void __launch_bounds__(R_BLOCK)
+k_visibility_prefix(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
+                    const float *__restrict__ t1, const int32_t *__restrict__ packed, float eps,
+                    int32_t *__restrict__ kept, uint32_t n_rays)
+{
+    uint32_t r, start, count;
+    if (!wave_ray(packed, n_rays, r, start, count)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    float carry = 1.f;
+    uint32_t n_kept = 0;
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        float one_minus_alpha = 1.f;
+        if (ok) {
+            const float sigma = expf(__half2float(mlp_out[(uint64_t)(start + k) * stride]) + bias);
+            const float alpha = 1.f - expf(-sigma * (t1[start + k] - t0[start + k]));
+            one_minus_alpha = 1.f - alpha;
+        }
+        const float inc = wave_incl_scan_mul(one_minus_alpha);
+        float exc = __shfl_up(inc, 1, 64);
+        if (lane == 0) exc = 1.f;
+        const float T = carry * exc;
+        const unsigned long long m = __ballot(ok && T >= eps);
+        n_kept += (uint32_t)__popcll(m);
+        carry *= __shfl(inc, 63, 64);
+        if (carry < eps) break;  // wave-uniform: everything after is invisible
+    }
+    if (lane == 0) kept[r] = (int32_t)n_kept;
+}
+
+__global__ void __launch_bounds__(R_BLOCK)
+k_copy_ray_prefixes(const int32_t *__restrict__ packed_old, const int32_t *__restrict__ packed_new,
+                    const float *__restrict__ t0, const float *__restrict__ t1, int64_t *__restrict__ ri_o,
+                    float *__restrict__ t0_o, float *__restrict__ t1_o, uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const uint32_t src = (uint32_t)packed_old[2ull * r];
+    const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        t0_o[dst + k] = t0[src + k];
+        t1_o[dst + k] = t1[src + k];
+        ri_o[dst + k] = (int64_t)r;
+    }
+}
+
+// tex_in[n,32] half = [ mlp_out[:, :16] | SH4((d+1)/2) ]  (the fp16 feature IS what .float() then fp16-cast returns)
+__global__ void __launch_bounds__(EW_BLOCK)
+k_texture_input(const __half *__restrict__ mlp_out, uint32_t stride, const float *__restrict__ dirs,
+                __half *__restrict__ tex_in, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(mlp_out + (uint64_t)i * stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(tex_in + (uint64_t)i * 32);
+    dst[0] = src[0];
+    dst[1] = src[1];
+    // dirs01 = (d + 1)/2 ; SH maps back 2u - 1 (two roundings each way, exactly as texture.py:24 + tcnn do)
+    const float u0 = (dirs[3ull * i] + 1.f) / 2.f, u1 = (dirs[3ull * i + 1] + 1.f) / 2.f, u2 = (dirs[3ull * i + 2] + 1.f) / 2.f;
+    const float x = u0 * 2.f - 1.f, y = u1 * 2.f - 1.f, z = u2 * 2.f - 1.f;
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float o[16];
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * (x2 - y2);
+    o[9] = 0.59004358992664352f * y * (-3.f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.f - 5.f * z2);
+    o[12] = 0.3731763325901154f * z * (5.f * z2 - 3.f);
+    o[13] = 0.45704579946446572f * x * (1.f - 5.f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.f * y2);
+    __half2 h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = __floats2half2_rn(o[2 * k], o[2 * k + 1]);
+    dst[2] = *reinterpret_cast<uint4 *>(&h[0]);
+    dst[3] = *reinterpret_cast<uint4 *>(&h[4]);
+}
+
+// per ray: sigma = exp(logit + bias); w_i = T_i (1 - exp(-sigma_i dt_i)); comp_rgb = sum w rgb + bg (1 - sum w)
+__global__ void __launch_bounds__(R_BLOCK)
+k_composite_forward(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
+                    const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
+                    const int32_t *__restrict__ packed, const float *__restrict__ bg, float *__restrict__ weights,
+                    float *__restrict__ trans, float *__restrict__ comp_rgb, float *__restrict__ opacity,
+                    float *__restrict__ depth, uint32_t n_rays)
+{
+    uint32_t r, start, count;
+    if (!wave_ray(packed, n_rays, r, start, count)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    float carry = 0.f;  // running sum of sigma*dt
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // opacity, depth, r, g, b
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        float sd = 0.f, a = 0.f, mid = 0.f;
+        if (ok) {
+            const float ts = t0[start + k], te = t1[start + k];
+            const float sigma = expf(__half2float(mlp_out[(uint64_t)(start + k) * stride]) + bias);
+            sd = sigma * (te - ts);
+            a = 1.f - expf(-sd);
+            mid = (ts + te) / 2.f;
+        }
+        const float inc = wave_incl_scan_add(sd);
+        const float T = expf(-(carry + (inc - sd)));
+        const float w = T * a;
+        if (ok) {
+            weights[start + k] = w;
+            trans[start + k] = T;
+            const __half *c3 = rgb + (uint64_t)(start + k) * rgb_stride;
+            acc[0] += w;
+            acc[1] += w * mid;
+            acc[2] += w * __half2float(c3[0]);
+            acc[3] += w * __half2float(c3[1]);
+            acc[4] += w * __half2float(c3[2]);
+        }
+        carry += __shfl(inc, 63, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0) {
+        opacity[r] = acc[0];
+        depth[r] = acc[1];
+        const float rest = 1.f - acc[0];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) comp_rgb[3ull * r + q] = acc[2 + q] + bg[q] * rest;
+    }
+}
+
+// loss = mean over valid rays x 3 channels of smooth_l1(comp - gt), valid = opacity > 0
+__global__ void __launch_bounds__(EW_BLOCK)
+k_smooth_l1_valid(const float *__restrict__ comp_rgb, const float *__restrict__ opacity, const float *__restrict__ gt,
+                  float *__restrict__ acc /* [0]=sum, [1]=valid rays */, uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * EW_BLOCK + threadIdx.x;
+    float s = 0.f, c = 0.f;
+    if (r < n_rays && opacity[r] > 0.f) {
+        c = 1.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float d = fabsf(comp_rgb[3ull * r + q] - gt[3ull * r + q]);
+            s += d < 1.f ? 0.5f * d * d : d - 0.5f;
+        }
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0 && c > 0.f) {
+        unsafeAtomicAdd(acc, s);
+        unsafeAtomicAdd(acc + 1, c);
+    }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_smooth_l1_valid_bwd(const float *__restrict__ comp_rgb, const float *__restrict__ opacity,
+                      const float *__restrict__ gt, const float *__restrict__ acc, float scale,
+                      float *__restrict__ g_comp, uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (r >= n_rays) return;
+    const bool valid = opacity[r] > 0.f;
+    const float inv = scale / fmaxf(3.f * acc[1], 1.f);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float d = comp_rgb[3ull * r + q] - gt[3ull * r + q];
+        const float g = fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+        g_comp[3ull * r + q] = valid ? g * inv : 0.f;
+    }
+}
+
+// backward of composite_forward w.r.t. rgb and the density logit (trunc_exp backward folded in)
+__global__ void __launch_bounds__(R_BLOCK)
+k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
+                     const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
+                     const int32_t *__restrict__ packed, const float *__restrict__ bg,
+                     const float *__restrict__ weights, const float *__restrict__ trans,
+                     const float *__restrict__ g_comp, const float *__restrict__ g_opacity,
+                     const float *__restrict__ g_depth, float *__restrict__ d_rgb, float *__restrict__ d_logit,
+                     uint32_t n_rays)
+{
+    uint32_t r, start, count;
+    if (!wave_ray(packed, n_rays, r, start, count)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const float g0 = g_comp[3ull * r], g1 = g_comp[3ull * r + 1], g2 = g_comp[3ull * r + 2];
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    const float gop = g_opacity ? g_opacity[r] : 0.f, gdp = g_depth ? g_depth[r] : 0.f;
+    float carry = 0.f;  // sum_{i > j} gT_i T_i, walking the ray from its end
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        const uint32_t idx = start + count - 1 - k;
+        float v = 0.f, gw = 0.f, T = 0.f, a = 0.f, dt = 0.f, z = 0.f;
+        if (ok) {
+            const float ts = t0[idx], te = t1[idx];
+            dt = te - ts;
+            z = __half2float(mlp_out[(uint64_t)idx * stride]) + bias;
+            const float sd = expf(z) * dt;
+            a = 1.f - expf(-sd);
+            T = trans[idx];
+            const __half *c3 = rgb + (uint64_t)idx * rgb_stride;
+            const float w = weights[idx];
+            gw = g0 * (__half2float(c3[0]) - b0) + g1 * (__half2float(c3[1]) - b1) + g2 * (__half2float(c3[2]) - b2) +
+                 gop + gdp * ((ts + te) / 2.f);
+            d_rgb[3ull * idx] = w * g0;
+            d_rgb[3ull * idx + 1] = w * g1;
+            d_rgb[3ull * idx + 2] = w * g2;
+            v = gw * a * T;  // gT_i * T_i
+        }
+        const float inc = wave_incl_scan_add(v);
+        if (ok) {
+            const float g_sd = gw * T * (1.f - a) - (carry + (inc - v));
+            d_logit[idx] = g_sd * dt * expf(fminf(z, 15.f));
+        }
+        carry += __shfl(inc, 63, 64);
+    }
+}
+
+// training-ray gather: pixel (index, y, x) -> ray (o, normalised d), ground-truth rgb blended on the background
+__global__ void __launch_bounds__(EW_BLOCK)
+k_gather_train_rays(const float *__restrict__ images, const float *__restrict__ masks,
+                    const float *__restrict__ directions, const float *__restrict__ c2w,
+                    const int64_t *__restrict__ index, const int64_t *__restrict__ px, const int64_t *__restrict__ py,
+                    const float *__restrict__ bg, int H, int W, int apply_mask, float *__restrict__ rays,
+                    float *__restrict__ rgb, float *__restrict__ fg, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t im = index[i], x = px[i], y = py[i];
+    const float *dir = directions + ((size_t)y * W + x) * 3;
+    const float *m = c2w + (size_t)im * 12;  // [3,4] row-major
+    float d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = (dir[0] * m[4 * k] + dir[1] * m[4 * k + 1]) + dir[2] * m[4 * k + 2];
+    const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rays[6ull * i + k] = m[4 * k + 3];
+        rays[6ull * i + 3 + k] = d[k] / nrm;
+    }
+    const size_t pix = ((size_t)im * H + y) * W + x;
+    const float f = masks[pix];
+    fg[i] = f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float c = images[pix * 3 + k];
+        rgb[3ull * i + k] = apply_mask ? c * f + bg[k] * (1.f - f) : c;
+    }
+}
+
+}  // namespace
+
+#define RAY_GRID(n_rays) dim3(nsr_div_up(n_rays, RAYS_PER_BLOCK)), dim3(R_BLOCK), 0, (hipStream_t)stream
+#define EW_GRID(n) dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream
+
+extern "C" int nsr_sample_positions_unit(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                                         const float *t_starts, const float *t_ends, float radius, int contraction,
+                                         float *x01, float *dirs_out, uint32_t n, void *stream)
+{
+    NSR_REQUIRE(contraction == NSR_CONTRACT_AABB || contraction == NSR_CONTRACT_UN_BOUNDED_SPHERE,
+                "nsr_sample_positions_unit: contraction type %d not implemented", contraction);
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && x01, "nsr_sample_positions_unit: NULL pointer");
+    hipLaunchKernelGGL(k_sample_positions_unit, EW_GRID(n), rays_o, rays_d, ray_indices, t_starts, t_ends, radius,
+                       contraction, x01, dirs_out, n);
+    NSR_CHECK_LAUNCH("nsr_sample_positions_unit");
+    return NSR_OK;
+}
+
+extern "C" int nsr_visibility_prefix(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                     const float *t_ends, const int32_t *packed_info, float early_stop_eps,
+                                     int32_t *kept_counts, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && kept_counts, "nsr_visibility_prefix: NULL pointer");
+    hipLaunchKernelGGL(k_visibility_prefix, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
+                       t_ends, packed_info, early_stop_eps, kept_counts, n_rays);
+    NSR_CHECK_LAUNCH("nsr_visibility_prefix");
+    return NSR_OK;
+}
+
+extern "C" int nsr_copy_ray_prefixes(const int32_t *packed_old, const int32_t *packed_new, const float *t_starts,
+                                     const float *t_ends, int64_t *ray_indices_out, float *t_starts_out,
+                                     float *t_ends_out, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_old && packed_new, "nsr_copy_ray_prefixes: NULL pointer");
+    hipLaunchKernelGGL(k_copy_ray_prefixes, RAY_GRID(n_rays), packed_old, packed_new, t_starts, t_ends, ray_indices_out,
+                       t_starts_out, t_ends_out, n_rays);
+    NSR_CHECK_LAUNCH("nsr_copy_ray_prefixes");
+    return NSR_OK;
+}
+
+extern "C" int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in,
+                                 uint32_t n, void *stream)
+{
+    NSR_REQUIRE(stride >= 16 && (stride & 7u) == 0, "nsr_texture_input: feature rows must be >= 16 halfs, 16-B aligned");
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(mlp_out && dirs && tex_in, "nsr_texture_input: NULL pointer");
+    hipLaunchKernelGGL(k_texture_input, EW_GRID(n), (const __half *)mlp_out, stride, dirs, (__half *)tex_in, n);
+    NSR_CHECK_LAUNCH("nsr_texture_input");
+    return NSR_OK;
+}
+
+extern "C" int nsr_composite_forward(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                     const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
+                                     const int32_t *packed_info, const float *background, float *weights, float *trans,
+                                     float *comp_rgb, float *opacity, float *depth, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && comp_rgb && opacity && depth, "nsr_composite_forward: NULL pointer");
+    hipLaunchKernelGGL(k_composite_forward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
+                       t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, comp_rgb,
+                       opacity, depth, n_rays);
+    NSR_CHECK_LAUNCH("nsr_composite_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,
+                                   uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(comp_rgb && opacity && gt_rgb && acc2, "nsr_smooth_l1_valid: NULL pointer");
+    hipLaunchKernelGGL(k_smooth_l1_valid, EW_GRID(n_rays), comp_rgb, opacity, gt_rgb, acc2, n_rays);
+    NSR_CHECK_LAUNCH("nsr_smooth_l1_valid");
+    return NSR_OK;
+}
+
+extern "C" int nsr_smooth_l1_valid_backward(const float *comp_rgb, const float *opacity, const float *gt_rgb,
+                                            const float *acc2, float grad_scale, float *grad_comp_rgb, uint32_t n_rays,
+                                            void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(comp_rgb && opacity && gt_rgb && acc2 && grad_comp_rgb, "nsr_smooth_l1_valid_backward: NULL pointer");
+    hipLaunchKernelGGL(k_smooth_l1_valid_bwd, EW_GRID(n_rays), comp_rgb, opacity, gt_rgb, acc2, grad_scale,
+                       grad_comp_rgb, n_rays);
+    NSR_CHECK_LAUNCH("nsr_smooth_l1_valid_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, float density_bias,
+                                      const float *t_starts, const float *t_ends, const nsr_half *rgb,
+                                      uint32_t rgb_stride, const int32_t *packed_info, const float *background,
+                                      const float *weights, const float *trans, const float *grad_comp_rgb,
+                                      const float *grad_opacity, const float *grad_depth, float *grad_rgb,
+                                      float *grad_logit, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && weights && trans && grad_comp_rgb && grad_rgb && grad_logit,
+                "nsr_composite_backward: NULL pointer");
+    hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
+                       t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb,
+                       grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays);
+    NSR_CHECK_LAUNCH("nsr_composite_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_gather_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,
+                                     const int64_t *index, const int64_t *px, const int64_t *py, const float *background,
+                                     int height, int width, int apply_mask, float *rays, float *rgb, float *fg,
+                                     uint32_t n, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(images && masks && directions && c2w && index && px && py && background && rays && rgb && fg,
+                "nsr_gather_train_rays: NULL pointer");
+    hipLaunchKernelGGL(k_gather_train_rays, EW_GRID(n), images, masks, directions, c2w, index, px, py, background,
+                       height, width, apply_mask, rays, rgb, fg, n);
+    NSR_CHECK_LAUNCH("nsr_gather_train_rays");
+    return NSR_OK;
+}

@@ -247,6 +247,44 @@ k_pack_bricks(const uint8_t *__restrict__ grid, int3 res, unsigned long long *__
     if (lane == 32 && b < n_bricks) any_bits[b >> 5] = (uint32_t)(m >> 32);
 }
 
+// contraction applied to already-computed unit coordinates u = roi_to_unit(p) (same float ops as apply_contraction)
+__device__ __forceinline__ void contract_unit(float *u, int type)
+{
+    if (type == NSR_CONTRACT_UN_BOUNDED_SPHERE) {
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = u[k] * 2.f - 1.f;
+        const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (n > 1.f) {
+            const float s = 2.f - 1.f / n;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = s * (v[k] / n);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = v[k] * 0.25f + 0.5f;
+    } else if (type == NSR_CONTRACT_UN_BOUNDED_TANH) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = tanhf((u[k] - 0.5f) * 1.0986122886681098f) * 0.5f + 0.5f;
+    }
+}
+
+// distance_to_next_voxel on precomputed unit coordinates.  POW2: the grid resolution is a power of two, so the
+// division by it is exactly a multiplication by its reciprocal (identical bits, one instruction instead of ~10).
+template <bool POW2>
+__device__ __forceinline__ float distance_to_next_voxel_u(const float *u, const float *d, const float *inv_d,
+                                                          const Roi &r, const float *rr, const float *inv_rr)
+{
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x = u[k] * rr[k];
+        const float a = (floorf(x + 0.5f + 0.5f * signf(d[k])) - x) * inv_d[k];
+        const float tk = (POW2 ? a * inv_rr[k] : a / rr[k]) * (r.hi[k] - r.lo[k]);
+        t = (k == 0) ? tk : fminf(t, tk);
+    }
+    return fmaxf(t, 0.f);
+}
+
 struct BrickGrid {
     const unsigned long long *bricks;
     const uint32_t *any_lds;  // LDS copy of the any-bits
@@ -256,11 +294,9 @@ struct BrickGrid {
     unsigned long long cur_bits;
 };
 
-__device__ __forceinline__ bool brick_occupied_at(const float *p, const Roi &r, int type, BrickGrid &bg)
+// occupancy test on precomputed unit coordinates `u` (already contracted)
+__device__ __forceinline__ bool brick_occupied_u(const float *u, BrickGrid &bg)
 {
-    if (type == NSR_CONTRACT_AABB && outside_roi(p, r)) return false;
-    float u[3];
-    apply_contraction(p, r, type, u);
     int ix = (int)(u[0] * (float)bg.res.x), iy = (int)(u[1] * (float)bg.res.y), iz = (int)(u[2] * (float)bg.res.z);
     ix = min(max(ix, 0), bg.res.x - 1);
     iy = min(max(iy, 0), bg.res.y - 1);
@@ -274,7 +310,7 @@ __device__ __forceinline__ bool brick_occupied_at(const float *p, const Roi &r, 
 }
 
 // MODE 0: count only (num_steps) ; MODE 1: write at packed_info ; MODE 2: single pass into scratch rows of `cap`
-template <int MODE>
+template <int MODE, bool POW2>
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_ray_march_bricks(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ t_min,
                    const float *__restrict__ t_max, const float *__restrict__ roi,
@@ -307,10 +343,21 @@ k_ray_march_bricks(const float *__restrict__ rays_o, const float *__restrict__ r
     float dt = calc_dt(t0, cone_angle, dt_min, dt_max);
     float t1 = t0 + dt;
     float t_mid = (t0 + t1) * 0.5f;
+    const float rr[3] = {(float)res.x, (float)res.y, (float)res.z};
+    const float inv_rr[3] = {1.f / rr[0], 1.f / rr[1], 1.f / rr[2]};
     while (t_mid < far) {
         const float p[3] = {__builtin_fmaf(t_mid, d[0], o[0]), __builtin_fmaf(t_mid, d[1], o[1]),
                             __builtin_fmaf(t_mid, d[2], o[2])};
-        if (brick_occupied_at(p, r, type, bg)) {
+        // unit coordinates once per visit: shared by the occupancy test and the voxel-exit distance
+        float u[3], uc[3];
+        roi_to_unit(p, r, u);
+        bool occ = false;
+        if (!(type == NSR_CONTRACT_AABB && outside_roi(p, r))) {
+            uc[0] = u[0]; uc[1] = u[1]; uc[2] = u[2];
+            contract_unit(uc, type);
+            occ = brick_occupied_u(uc, bg);
+        }
+        if (occ) {
             if (MODE == 1) {
                 t_starts[base + j] = t0;
                 t_ends[base + j] = t1;
@@ -323,7 +370,7 @@ k_ray_march_bricks(const float *__restrict__ rays_o, const float *__restrict__ r
             t1 = t0 + calc_dt(t0, cone_angle, dt_min, dt_max);
             t_mid = (t0 + t1) * 0.5f;
         } else if (type == NSR_CONTRACT_AABB) {
-            const float t_target = t_mid + distance_to_next_voxel(p, d, inv_d, r, res);
+            const float t_target = t_mid + distance_to_next_voxel_u<POW2>(u, d, inv_d, r, rr, inv_rr);
             do { t_mid += dt_min; } while (t_mid < t_target);
             dt = calc_dt(t_mid, cone_angle, dt_min, dt_max);
             t0 = t_mid - dt * 0.5f;
@@ -609,13 +656,20 @@ static int launch_bricks(int mode, const float *rays_o, const float *rays_d, con
     NSR_REQUIRE(lds <= 64 * 1024, "nsr_ray_march(bricks): grid too large for the LDS any-bit table");
     const dim3 grid(nsr_div_up(n_rays, MARCH_BLOCK)), block(MARCH_BLOCK);
     const int3 res = make_int3(rx, ry, rz);
-#define NSR_LAUNCH_BRICKS(M)                                                                                          \
-    hipLaunchKernelGGL((k_ray_march_bricks<M>), grid, block, lds, (hipStream_t)stream, rays_o, rays_d, t_min, t_max, \
-                       roi, (const unsigned long long *)bricks, any_bits, n_words, res, type, step, cone, packed,     \
+    const bool pow2 = !(rx & (rx - 1)) && !(ry & (ry - 1)) && !(rz & (rz - 1));
+#define NSR_LAUNCH_BRICKS(M, P)                                                                                        \
+    hipLaunchKernelGGL((k_ray_march_bricks<M, P>), grid, block, lds, (hipStream_t)stream, rays_o, rays_d, t_min, t_max, \
+                       roi, (const unsigned long long *)bricks, any_bits, n_words, res, type, step, cone, packed,      \
                        num_steps, ri, t0, t1, (float2 *)scratch, cap, n_rays)
-    if (mode == 0) NSR_LAUNCH_BRICKS(0);
-    else if (mode == 1) NSR_LAUNCH_BRICKS(1);
-    else NSR_LAUNCH_BRICKS(2);
+    if (pow2) {
+        if (mode == 0) NSR_LAUNCH_BRICKS(0, true);
+        else if (mode == 1) NSR_LAUNCH_BRICKS(1, true);
+        else NSR_LAUNCH_BRICKS(2, true);
+    } else {
+        if (mode == 0) NSR_LAUNCH_BRICKS(0, false);
+        else if (mode == 1) NSR_LAUNCH_BRICKS(1, false);
+        else NSR_LAUNCH_BRICKS(2, false);
+    }
 #undef NSR_LAUNCH_BRICKS
     return NSR_OK;
 }

@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(MLP_BLOCK)
 k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, const __half *__restrict__ out,
                const void *__restrict__ x, int x_f32, uint32_t x_stride, const __half *__restrict__ acts,
                const __half *__restrict__ W_, float *__restrict__ dx, uint32_t dx_stride, float *__restrict__ partials,
-               uint32_t n, uint32_t n_in, uint32_t n_out, int out_act, float grad_scale, int need_dw)
+               uint32_t n, uint32_t n_in, uint32_t n_out, int out_act, float grad_scale, int need_dw,
+               const float *__restrict__ dout_extra_col0, uint32_t dx_lm_features)
 {
     constexpr int IN_PAD = KIN * 16;
     constexpr int N_PARAMS = WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH + 16 * WIDTH;
@@ -320,6 +321,7 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
                     const uint64_t off = (uint64_t)s * dout_stride + c;
                     float v = dout_f32 ? reinterpret_cast<const float *>(dout)[off]
                                        : __half2float(reinterpret_cast<const __half *>(dout)[off]);
+                    if (c == 0 && dout_extra_col0) v += dout_extra_col0[s];
                     if (out_act == NSR_ACT_SIGMOID) {
                         const float o = __half2float(out[(uint64_t)s * 16 + c]);
                         v *= o * (1.f - o);
@@ -439,7 +441,12 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const uint32_t col = ib * 16 + 4 * g + r;
-                            if (col < n_in) dx[(uint64_t)s * dx_stride + col] = c[r] * inv_scale;
+                            if (col < n_in) {
+                                const uint64_t off = dx_lm_features
+                                    ? ((uint64_t)(col / dx_lm_features) * n + s) * dx_lm_features + col % dx_lm_features
+                                    : (uint64_t)s * dx_stride + col;
+                                dx[off] = c[r] * inv_scale;
+                            }
                         }
                     }
                 }
@@ -568,17 +575,20 @@ extern "C" uint64_t nsr_mlp_backward_workspace_floats(const NsrMlpDesc *desc, ui
     return (uint64_t)bwd_blocks(n) * n_params_of(desc);
 }
 
-extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, const nsr_half *out,
-                                const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *acts,
-                                const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
-                                float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream)
+extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                                   const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                                   const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx,
+                                   uint32_t dx_stride, uint32_t dx_level_major_features, float *partials, uint32_t n,
+                                   float grad_scale, const NsrMlpDesc *desc, void *stream)
 {
     if (int rc = check_mlp(desc, "nsr_mlp_backward")) return rc;
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(dout && x && acts && weights, "nsr_mlp_backward: NULL pointer");
     NSR_REQUIRE(desc->output_activation == NSR_ACT_NONE || out, "nsr_mlp_backward: sigmoid backward needs `out`");
     NSR_REQUIRE(!grad_weights || partials, "nsr_mlp_backward: grad_weights needs the partials workspace");
-    NSR_REQUIRE(!dx || dx_stride >= desc->n_in, "nsr_mlp_backward: dx_stride < n_in");
+    NSR_REQUIRE(!dx || dx_level_major_features || dx_stride >= desc->n_in, "nsr_mlp_backward: dx_stride < n_in");
+    NSR_REQUIRE(!dx_level_major_features || desc->n_in % dx_level_major_features == 0,
+                "nsr_mlp_backward: level-major dx needs n_in to be a multiple of the feature count");
     NSR_REQUIRE(grad_scale > 0.f, "nsr_mlp_backward: grad_scale must be > 0");
     const uint32_t nb = bwd_blocks(n), np = n_params_of(desc);
     const size_t lds = sizeof(float) * np + WAVES * 2 * 64 * TROW * sizeof(_Float16);
@@ -587,7 +597,8 @@ extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout
         hipLaunchKernelGGL((k_mlp_backward<KIN, NH>), dim3(nb), dim3(MLP_BLOCK), lds, (hipStream_t)stream, dout,
                            dout_is_f32, dout_stride, (const __half *)out, x, x_is_f32, x_stride, (const __half *)acts,
                            (const __half *)weights, dx, dx_stride, partials, n, desc->n_in, desc->n_out,
-                           (int)desc->output_activation, grad_scale, grad_weights ? 1 : 0);
+                           (int)desc->output_activation, grad_scale, grad_weights ? 1 : 0, dout_extra_col0,
+                           dx_level_major_features);
     });
     NSR_CHECK_LAUNCH("nsr_mlp_backward");
     if (grad_weights) {
@@ -596,4 +607,13 @@ extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout
         NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
     }
     return NSR_OK;
+}
+
+extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, const nsr_half *out,
+                                const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *acts,
+                                const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
+                                float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream)
+{
+    return nsr_mlp_backward_ex(dout, dout_is_f32, dout_stride, nullptr, out, x, x_is_f32, x_stride, acts, weights,
+                               grad_weights, dx, dx_stride, 0, partials, n, grad_scale, desc, stream);
 }

@@ -1,0 +1,167 @@
+"""Fused NeRF training step: the same computation as ``NeRFModel.forward_`` + smooth-L1 loss + backward
+(reference models/nerf.py:61-127, systems/nerf.py:87-99), issued as ~25 kernel launches with hand-chained
+backward instead of ~250 launches through autograd.  It reads the parameters of an ordinary ``NeRFModel``
+(same ``state_dict``) and writes the gradients into their ``.grad``; parity with the modular path is tested in
+``tests/test_gpu_fused.py``.
+"""
+import ctypes
+
+import torch
+
+from nerfacc import ContractionType
+from nsr_hip import check, lib, ptr, stream_ptr
+from nsr_hip import ops as _ops
+
+F32, F16 = torch.float32, torch.float16
+_byref = ctypes.byref
+
+
+class FusedNeRFStep:
+    def __init__(self, model, early_stop_eps=1e-4, grad_scale=128.0):
+        cfg = model.config
+        if cfg["learned_background"] or not cfg["grid_prune"]:
+            raise NotImplementedError("FusedNeRFStep covers the bounded (AABB + occupancy grid) nerf-blender path")
+        self.model = model
+        self.ewn = model.geometry.encoding_with_network        # tcnn.NetworkWithInputEncoding
+        self.tex = model.texture.network                       # tcnn.Network (sigmoid output)
+        if not hasattr(self.ewn, "grid_desc") or not hasattr(self.tex, "mlp_desc"):
+            raise NotImplementedError("FusedNeRFStep needs the fused tcnn geometry / texture modules")
+        self.radius = float(cfg["radius"])
+        self.bias = float(cfg["geometry"].get("density_bias", 0.0))
+        assert cfg["geometry"].get("density_activation") == "trunc_exp"
+        self.eps = float(early_stop_eps)
+        self.grad_scale = float(grad_scale)
+
+    # ---- small launch helpers (all on torch's current stream) -------------------------------------------------
+    def _positions(self, rays_o, rays_d, ri, t0, t1, want_dirs):
+        n = ri.shape[0]
+        x01 = torch.empty((n, 3), dtype=F32, device=ri.device)
+        dirs = torch.empty((n, 3), dtype=F32, device=ri.device) if want_dirs else None
+        check(lib.nsr_sample_positions_unit(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), self.radius,
+                                            ContractionType.AABB.value, ptr(x01), ptr(dirs), n, stream_ptr()),
+              "nsr_sample_positions_unit")
+        return x01, dirs
+
+    def march_and_prune(self, rays_o, rays_d):
+        """ray_marching(..., sigma_fn) of models/nerf.py:82-93 -> packed_info, ray_indices, t_starts, t_ends, M"""
+        m = self.model
+        grid = m.occupancy_grid
+        t_min, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
+        if m.randomized:
+            t_min = t_min + torch.rand_like(t_min) * m.render_step_size
+        packed, ri, t0, t1 = _ops.ray_march(rays_o, rays_d, t_min, t_max, grid.roi_aabb, grid.binary,
+                                            ContractionType.AABB.value, m.render_step_size, 0.0,
+                                            roi_host=grid._roi_host)
+        n_rays, M = rays_o.shape[0], ri.shape[0]
+        if M == 0:
+            return packed, ri, t0, t1, 0
+        ewn = self.ewn
+        table, w = ewn.table_half(ewn.params), ewn.weights_half(ewn.params)
+        x01, _ = self._positions(rays_o, rays_d, ri, t0, t1, False)
+        enc = _ops.hashgrid_forward(x01, table, ewn.grid_desc)
+        out, _ = _ops.mlp_forward(enc, w, ewn.mlp_desc, save_acts=False)
+        dev = ri.device
+        kept = torch.empty(n_rays, dtype=torch.int32, device=dev)
+        packed2 = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        s = stream_ptr()
+        check(lib.nsr_visibility_prefix(ptr(out), out.stride(0), self.bias, ptr(t0), ptr(t1), ptr(packed), self.eps,
+                                        ptr(kept), n_rays, s), "nsr_visibility_prefix")
+        check(lib.nsr_pack_from_counts(ptr(kept), ptr(packed2), ptr(total), n_rays, s), "nsr_pack_from_counts")
+        S = int(total.item())  # second (and last) host sync of the step
+        ri2 = torch.empty(S, dtype=torch.int64, device=dev)
+        t0b, t1b = torch.empty((S, 1), dtype=F32, device=dev), torch.empty((S, 1), dtype=F32, device=dev)
+        check(lib.nsr_copy_ray_prefixes(ptr(packed), ptr(packed2), ptr(t0), ptr(t1), ptr(ri2), ptr(t0b), ptr(t1b),
+                                        n_rays, s), "nsr_copy_ray_prefixes")
+        return packed2, ri2, t0b, t1b, M
+
+    def forward_backward(self, rays, gt_rgb, background, compute_grads=True, loss_scale=1.0):
+        """-> dict(loss, comp_rgb, opacity, depth, num_samples, weights, ray_indices, t_starts, t_ends).  Gradients of
+        ``loss_scale * loss`` are ACCUMULATED into ``.grad`` of the MLP slices and OVERWRITE the hash-table slice."""
+        m, ewn, tex = self.model, self.ewn, self.tex
+        dev = rays.device
+        n_rays = rays.shape[0]
+        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+        with torch.no_grad(), torch.cuda.device(dev):
+            with _ops.timed("fused:march_prune"):
+                packed, ri, t0, t1, M = self.march_and_prune(rays_o, rays_d)
+            S = ri.shape[0]
+            s = stream_ptr()
+            table, w1, w2 = ewn.table_half(ewn.params), ewn.weights_half(ewn.params), tex.weights_half(tex.params)
+            with _ops.timed("fused:forward"):
+                x01, dirs = self._positions(rays_o, rays_d, ri, t0, t1, True)
+                enc = _ops.hashgrid_forward(x01, table, ewn.grid_desc)
+                out1, acts1 = _ops.mlp_forward(enc, w1, ewn.mlp_desc, save_acts=compute_grads)
+                tex_in = torch.empty((S, 32), dtype=F16, device=dev)
+                check(lib.nsr_texture_input(ptr(out1), out1.stride(0), ptr(dirs), ptr(tex_in), S, s), "nsr_texture_input")
+                out2, acts2 = _ops.mlp_forward(tex_in, w2, tex.mlp_desc, save_acts=compute_grads)
+                weights, trans = torch.empty(S, dtype=F32, device=dev), torch.empty(S, dtype=F32, device=dev)
+                comp_rgb = torch.empty((n_rays, 3), dtype=F32, device=dev)
+                opacity, depth = torch.empty((n_rays, 1), dtype=F32, device=dev), torch.empty((n_rays, 1), dtype=F32, device=dev)
+                bg = background.to(F32).contiguous()
+                check(lib.nsr_composite_forward(ptr(out1), out1.stride(0), self.bias, ptr(t0), ptr(t1), ptr(out2),
+                                                out2.stride(0), ptr(packed), ptr(bg), ptr(weights), ptr(trans),
+                                                ptr(comp_rgb), ptr(opacity), ptr(depth), n_rays, s), "nsr_composite_forward")
+                acc = torch.zeros(2, dtype=F32, device=dev)
+                gt = gt_rgb.to(F32).contiguous()
+                check(lib.nsr_smooth_l1_valid(ptr(comp_rgb), ptr(opacity), ptr(gt), ptr(acc), n_rays, s), "nsr_smooth_l1_valid")
+            res = {"comp_rgb": comp_rgb, "opacity": opacity, "depth": depth, "rays_valid": opacity > 0,
+                   "num_samples": S, "num_marched": M, "weights": weights, "ray_indices": ri, "t_starts": t0,
+                   "t_ends": t1, "loss_acc": acc}
+            if not compute_grads or S == 0:
+                return res
+            with _ops.timed("fused:backward"):
+                g_comp = torch.empty((n_rays, 3), dtype=F32, device=dev)
+                check(lib.nsr_smooth_l1_valid_backward(ptr(comp_rgb), ptr(opacity), ptr(gt), ptr(acc), float(loss_scale),
+                                                       ptr(g_comp), n_rays, s), "nsr_smooth_l1_valid_backward")
+                d_rgb, d_logit = torch.empty((S, 3), dtype=F32, device=dev), torch.empty(S, dtype=F32, device=dev)
+                check(lib.nsr_composite_backward(ptr(out1), out1.stride(0), self.bias, ptr(t0), ptr(t1), ptr(out2),
+                                                 out2.stride(0), ptr(packed), ptr(bg), ptr(weights), ptr(trans),
+                                                 ptr(g_comp), None, None, ptr(d_rgb), ptr(d_logit), n_rays, s),
+                      "nsr_composite_backward")
+                for p in (ewn.params, tex.params):
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                # colour MLP: dW2 and d(tex_in) (first 16 columns = d feature)
+                d_tex = self._mlp_backward(d_rgb, 3, None, out2, tex_in, acts2, w2, tex.mlp_desc, tex.params.grad, 0)
+                # density MLP: dout = d feature (+ d logit on column 0) -> dW1 and d(enc), level-major
+                d_enc = self._mlp_backward(d_tex, 32, d_logit, out1, enc, acts1, w1, ewn.mlp_desc,
+                                           ewn.mlp_slice(ewn.params.grad), ewn.grid_desc.n_features)
+                _ops.hashgrid_backward_params(x01, d_enc, ewn.grid_slice(ewn.params.grad), ewn.grid_desc,
+                                              accumulate=False, level_major=True)
+            return res
+
+    def _mlp_backward(self, dout, dout_stride, extra, out, x, acts, w, desc, grad_w, dx_lm_f):
+        n = x.shape[0]
+        dx = torch.empty(n * desc.n_in, dtype=F32, device=x.device)
+        nws = lib.nsr_mlp_backward_workspace_floats(_byref(desc), n)
+        partials = torch.empty(int(nws), dtype=F32, device=x.device)
+        with _ops.timed(f"mlp_backward_h{desc.n_hidden}", n):
+            check(lib.nsr_mlp_backward_ex(ptr(dout), 1, dout_stride, ptr(extra), ptr(out), ptr(x), 0, x.stride(0),
+                                          ptr(acts), ptr(w), ptr(grad_w), ptr(dx), desc.n_in, dx_lm_f, ptr(partials), n,
+                                          self.grad_scale, _byref(desc), stream_ptr()), "nsr_mlp_backward_ex")
+        return dx if dx_lm_f else dx.view(n, desc.n_in)
+
+    @staticmethod
+    def loss_value(res):
+        acc = res["loss_acc"]
+        return acc[0] / torch.clamp(3.0 * acc[1], min=1.0)
+
+
+def gather_train_rays(dataset, n_rays, generator, background="random"):
+    """one RNG call + one gather kernel instead of ~15 indexing kernels (reference systems/nerf.py:38-79)"""
+    dev = dataset.all_images.device
+    n_img, H, W = dataset.all_images.shape[0], dataset.h, dataset.w
+    r = torch.rand((4, max(n_rays, 1)), device=dev, generator=generator)
+    index = (r[0] * n_img).long().clamp_(max=n_img - 1)
+    px = (r[1] * W).long().clamp_(max=W - 1)
+    py = (r[2] * H).long().clamp_(max=H - 1)
+    bg = r[3, :3].contiguous() if background == "random" else torch.ones(3, device=dev)
+    rays = torch.empty((n_rays, 6), dtype=F32, device=dev)
+    rgb, fg = torch.empty((n_rays, 3), dtype=F32, device=dev), torch.empty(n_rays, dtype=F32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nsr_gather_train_rays(ptr(dataset.all_images), ptr(dataset.all_fg_masks), ptr(dataset.directions),
+                                        ptr(dataset.all_c2w), ptr(index), ptr(px), ptr(py), ptr(bg), H, W,
+                                        int(dataset.apply_mask), ptr(rays), ptr(rgb), ptr(fg), n_rays, stream_ptr()),
+              "nsr_gather_train_rays")
+    return rays, rgb, fg, bg

@@ -51,7 +51,7 @@ def multistep_lr_scale(step, milestones=(10000, 15000, 18000), gamma=0.33):
 
 
 class Trainer:
-    def __init__(self, model, dataset, config, rank=0, world_size=1, seed=42):
+    def __init__(self, model, dataset, config, rank=0, world_size=1, seed=42, fused=True):
         self.model, self.dataset, self.config = model, dataset, config
         self.rank, self.world_size = rank, world_size
         self.device = next(model.parameters()).device
@@ -68,6 +68,10 @@ class Trainer:
         other = [p for p in model.parameters() if id(p) not in tc_params]
         self.opt = FusedAdamW(tc, other)
         self.last = {}
+        self.fused = None
+        if fused and config["name"] == "nerf":
+            from .fused import FusedNeRFStep
+            self.fused = FusedNeRFStep(model)
 
     def _all_reduce_grads(self):
         if self.world_size == 1:
@@ -81,6 +85,8 @@ class Trainer:
         return F.smooth_l1_loss(out["comp_rgb"][valid], rgb[valid])  # systems/nerf.py:97
 
     def train_step(self):
+        if self.fused is not None:
+            return self._train_step_fused()
         model = self.model
         with _ops.timed("phase:sample_rays"):
             rays, rgb, fg, bg = self.dataset.sample_rays(self.train_num_rays, self.gen, self.config["background_color"])
@@ -103,4 +109,27 @@ class Trainer:
             self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
         self.global_step += 1
         self.last = {"loss": loss.detach(), "n_rays": rays.shape[0], "n_samples": n_samples}
+        return self.last
+
+    def _train_step_fused(self):
+        """same step through nsr.fused.FusedNeRFStep (hand-chained backward, ~25 launches)"""
+        from .fused import FusedNeRFStep, gather_train_rays
+        model = self.model
+        with _ops.timed("phase:sample_rays"):
+            rays, rgb, fg, bg = gather_train_rays(self.dataset, self.train_num_rays, self.gen,
+                                                  self.config["background_color"])
+        model.background_color = bg
+        with _ops.timed("phase:occupancy_update"):
+            model.update_step(0, self.global_step)
+        res = self.fused.forward_backward(rays, rgb, bg)
+        n_samples = res["num_samples"]  # already on the host (the pruning sync): no extra .item()
+        if self.config["dynamic_ray_sampling"] and n_samples > 0:
+            t = int(self.train_num_rays * (self.train_num_samples / n_samples))
+            self.train_num_rays = min(int(self.train_num_rays * 0.9 + t * 0.1), self.config["max_train_num_rays"])
+        with _ops.timed("phase:all_reduce"):
+            self._all_reduce_grads()
+        with _ops.timed("phase:optimizer"):
+            self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
+        self.global_step += 1
+        self.last = {"loss": FusedNeRFStep.loss_value(res), "n_rays": rays.shape[0], "n_samples": n_samples}
         return self.last
