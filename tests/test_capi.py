@@ -1,0 +1,88 @@
+"""The C-ABI library loads and exports every symbol that include/nsr_hip.h declares (no GPU needed: hipcc
+cross-compiles gfx950 and ctypes only resolves symbols), the ctypes binding covers all of them, and the host-only
+entry points behave.  Compute entry points are NOT called here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nsr_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nsr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    import nsr_hip
+    names = _declared()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(nsr_hip.lib, n), f"{n} declared in include/nsr_hip.h but not exported by libnsr_hip.so"
+        assert n in nsr_hip.SIGNATURES, f"{n} has no ctypes signature in nsr_hip/__init__.py"
+    assert sorted(nsr_hip.SIGNATURES) == names, set(nsr_hip.SIGNATURES) ^ set(names)
+    assert nsr_hip.lib.nsr_abi_version() == nsr_hip.ABI_VERSION
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import nsr_hip
+    with pytest.raises(ImportError):
+        nsr_hip.load_library(str(tmp_path / "libnsr_hip.so"))
+
+
+def test_host_side_grid_desc_matches_oracle():
+    import nsr_hip
+    from conftest import NERF_GRID, NEUS_GRID
+    from oracle import tcnn_ref
+    for cfg in (NERF_GRID, NEUS_GRID, dict(NERF_GRID, n_levels=8, log2_hashmap_size=15, per_level_scale=2.0)):
+        od = tcnn_ref.GridDesc.from_config(cfg)
+        hd = nsr_hip.make_grid_desc(cfg["n_levels"], cfg["n_features_per_level"], cfg["log2_hashmap_size"],
+                                    cfg["base_resolution"], cfg["per_level_scale"])
+        assert hd.n_entries == od.n_entries
+        assert [hd.scale[l] for l in range(od.L)] == od.scale
+        assert [hd.resolution[l] for l in range(od.L)] == od.res
+        assert [hd.offset[l] for l in range(od.L + 1)] == od.offset
+
+
+def test_argument_validation_returns_errors_not_crashes():
+    import nsr_hip
+    lib = nsr_hip.lib
+    bad = nsr_hip.NsrGridDesc()
+    assert lib.nsr_hashgrid_make_desc(ctypes.byref(bad), 0, 2, 19, 16, 1.5) < 0      # n_levels = 0
+    assert b"n_levels" in lib.nsr_last_error()
+    assert lib.nsr_hashgrid_make_desc(ctypes.byref(bad), 16, 3, 19, 16, 1.5) < 0     # F = 3 unsupported
+    md = nsr_hip.NsrMlpDesc(32, 32, 40, 48, 2, 0)                                     # out_pad 48 unsupported
+    assert lib.nsr_mlp_backward_workspace_floats(ctypes.byref(md), 1000) == 0
+    with pytest.raises(nsr_hip.NsrError):
+        nsr_hip.check(lib.nsr_mlp_forward(None, 0, 32, None, None, None, 16, ctypes.byref(md), None))
+    assert lib.nsr_grid_bricks_words64(128, 128, 128) == 32768 + 512
+    assert lib.nsr_grid_bricks_words64(30, 32, 32) == 0
+    roi = (ctypes.c_float * 6)(-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
+    assert lib.nsr_ray_march_capacity(roi, 0.00507421875) == 1027
+
+
+def test_product_packages_have_no_cpu_path():
+    import torch
+    import tinycudann as tcnn
+    import nerfacc
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        tcnn.Encoding(3, dict(otype="HashGrid", n_levels=2, n_features_per_level=2, log2_hashmap_size=10,
+                              base_resolution=4, per_level_scale=2.0))
+    with pytest.raises(Exception):
+        nerfacc.ray_marching(torch.zeros(4, 3), torch.ones(4, 3), render_step_size=0.1)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "instant-nsr-pl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle (", "").replace("the oracle", "").replace("oracle/", "ORACLEDOC"), \
+                    f"{f} references the oracle"
