@@ -12,6 +12,8 @@ import torch.nn.functional as F
 import tinycudann as tcnn
 from nsr_hip import ops as _ops
 
+from .parallel import all_reduce_gradients, broadcast_parameters, shard_seed
+
 
 class FusedAdamW:
     """AdamW over the flat fp32 parameters with ONE kernel per tensor that also unscales, refreshes the fp16 shadow
@@ -59,7 +61,9 @@ class Trainer:
         self.train_num_rays = config["train_num_rays"]
         self.global_step = 0
         self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(seed + 1000 * rank)  # per-rank ray batches (see module docstring)
+        self.gen.manual_seed(shard_seed(seed, rank))  # per-rank ray batches (see module docstring)
+        if world_size > 1:
+            broadcast_parameters(model)
         for m in model.modules():  # grads leave the fused modules in fp32: no GradScaler, no fp16 underflow
             if isinstance(m, tcnn.Module):
                 m.dtype = torch.float32
@@ -74,11 +78,8 @@ class Trainer:
             self.fused = FusedNeRFStep(model)
 
     def _all_reduce_grads(self):
-        if self.world_size == 1:
-            return
-        for p in self.model.parameters():
-            if p.grad is not None and p.numel() > 0:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG)
+        if self.world_size > 1:
+            all_reduce_gradients(list(self.model.parameters()))
 
     def loss_fn(self, out, rgb, fg):
         valid = out["rays_valid"][..., 0]

@@ -1,0 +1,159 @@
+"""Mint the golden fixtures under tests/golden/ by running the REFERENCE's own glue (``/root/reference/models``,
+imported unchanged) on top of the CPU oracle's tinycudann / nerfacc stand-ins.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/gen_golden.py          (build container only: needs /root/reference)
+
+What the fixtures pin: the reference-owned arithmetic of the hot path -- ``contract_to_unisphere``, ``trunc_exp``,
+``scale_anything``, ``NeuSModel.get_alpha``, ``VolumeDensity/VolumeSDF/VolumeRadiance.forward``,
+``NeRFModel.forward_`` and ``NeuSModel.forward_`` (incl. the analytic-gradient double backward) -- as executed by the
+reference code itself.  tests/test_golden_glue.py checks oracle/glue_ref.py against them on CPU and
+tests/test_gpu_golden.py checks the HIP path (nsr host mirror over the drop-in packages) on the MI355X.
+The third-party arithmetic underneath (hash grid, MLP, marcher) is the ORACLE's here, so these fixtures do not pin
+tcnn / nerfacc themselves (see oracle/__init__.py).
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import refshim  # noqa: E402
+from oracle import nerfacc_ref, tcnn_ref  # noqa: E402
+
+OUT = os.path.join(HERE, "golden")
+SMALL_GRID = dict(n_levels=4, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8, per_level_scale=2.0)
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def _rays(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * 4.0
+    d = torch.nn.functional.normalize(-o + torch.randn(n, 3, generator=g) * 0.35, dim=-1)
+    return torch.cat([o, d], -1)
+
+
+def _sphere_grid(res, radius, r_occ):
+    ii = torch.stack(torch.meshgrid(*[torch.arange(res)] * 3, indexing="ij"), -1).float()
+    c = (ii + 0.5) / res * 2 * radius - radius
+    return c.norm(dim=-1) < r_occ
+
+
+def gen_glue(models):
+    from models.geometry import contract_to_unisphere
+    from models.utils import get_activation, scale_anything, trunc_exp
+    from nerfacc import ContractionType
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(256, 3, generator=g) * 3.0
+    out = {"x": x, "contract_aabb": contract_to_unisphere(x.clone(), 1.5, ContractionType.AABB),
+           "contract_sphere": contract_to_unisphere(x.clone(), 1.5, ContractionType.UN_BOUNDED_SPHERE),
+           "scale_anything": scale_anything(x, (-1.5, 1.5), (0, 1))}
+    z = (torch.randn(512, generator=g) * 6).requires_grad_(True)
+    y = trunc_exp(z)
+    gz = torch.randn(512, generator=g)
+    y.backward(gz)
+    out.update(trunc_exp_in=z, trunc_exp_out=y, trunc_exp_gin=gz, trunc_exp_grad=z.grad)
+    for name in ("sigmoid", "scale2.5", "+1.5", "lin2srgb", "softplus", "none"):
+        out["act_" + name] = get_activation(name)(x)
+    np.savez_compressed(os.path.join(OUT, "glue_elementwise.npz"), **_np(out))
+
+
+def gen_neus_alpha(models):
+    cfg = refshim.load_config("neus-blender.yaml", ["dataset.scene=lego"])
+    cfg.model.geometry.xyz_encoding_config.update(SMALL_GRID)
+    torch.manual_seed(0)
+    m = models.make("neus", cfg.model)
+    g = torch.Generator().manual_seed(1)
+    n = 600
+    sdf = (torch.randn(n, generator=g) * 0.05).requires_grad_(True)
+    normal = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).requires_grad_(True)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    dists = torch.rand(n, 1, generator=g) * 0.01
+    out = {"sdf": sdf, "normal": normal, "dirs": dirs, "dists": dists, "inv_s": m.variance.inv_s}
+    for ratio in (0.0, 0.4, 1.0):
+        m.cos_anneal_ratio = ratio
+        a = m.get_alpha(sdf, normal, dirs, dists)
+        ga = torch.randn(n, generator=torch.Generator().manual_seed(2))
+        gs, gn, gv = torch.autograd.grad(a, [sdf, normal, m.variance.variance], ga)
+        out.update({f"alpha_{ratio}": a, f"g_alpha_{ratio}": ga, f"g_sdf_{ratio}": gs, f"g_normal_{ratio}": gn,
+                    f"g_variance_{ratio}": gv})
+    np.savez_compressed(os.path.join(OUT, "neus_alpha.npz"), **_np(out))
+
+
+def gen_nerf(models):
+    cfg = refshim.load_config("nerf-blender.yaml", ["dataset.scene=lego"])
+    cfg.model.geometry.xyz_encoding_config.update(SMALL_GRID)
+    cfg.model.num_samples_per_ray = 256
+    torch.manual_seed(3)
+    m = models.make("nerf", cfg.model)
+    m.train()
+    with torch.no_grad():
+        p = m.geometry.encoding_with_network.params
+        p[m.geometry.encoding_with_network.desc.n_params:].normal_(0, 0.3)
+    m.occupancy_grid._binary = _sphere_grid(128, 1.5, 1.0)
+    m.background_color = torch.tensor([0.2, 0.5, 0.8])
+    m.randomized = False
+    rays = _rays(48, 7)
+    out = m(rays)
+    loss = torch.nn.functional.smooth_l1_loss(out["comp_rgb"], torch.full_like(out["comp_rgb"], 0.5)) + out["depth"].mean() * 0.1
+    loss.backward()
+    fx = {"rays": rays, "background": m.background_color, "binary_packed": np.packbits(m.occupancy_grid._binary.numpy()),
+          "render_step_size": m.render_step_size, "loss": loss}
+    fx.update({"param/" + k: v for k, v in m.state_dict().items() if "occupancy" not in k})
+    fx.update({"grad/" + k: v.grad for k, v in m.named_parameters() if v.grad is not None and v.numel() > 0})
+    fx.update({"out/" + k: v for k, v in out.items()})
+    # field-level outputs on fixed points (VolumeDensity.forward / VolumeRadiance.forward)
+    pts = (torch.rand(300, 3, generator=torch.Generator().manual_seed(9)) - 0.5) * 2.4
+    dens, feat = m.geometry(pts)
+    dirs = torch.nn.functional.normalize(torch.randn(300, 3, generator=torch.Generator().manual_seed(10)), dim=-1)
+    fx.update({"field/points": pts, "field/dirs": dirs, "field/density": dens, "field/feature": feat,
+               "field/rgb": m.texture(feat, dirs)})
+    np.savez_compressed(os.path.join(OUT, "nerf_forward.npz"), **_np(fx))
+
+
+def gen_neus(models):
+    cfg = refshim.load_config("neus-blender.yaml", ["dataset.scene=lego"])
+    cfg.model.geometry.xyz_encoding_config.update(SMALL_GRID)
+    cfg.model.num_samples_per_ray = 256
+    torch.manual_seed(4)
+    m = models.make("neus", cfg.model)
+    m.train()
+    m.update_step(0, 5000)  # cos_anneal_ratio = 0.25; occupancy refresh is skipped (5000 % 16 != 0)
+    with torch.no_grad():
+        m.geometry.encoding.encoding.params.normal_(0, 0.05)
+    m.occupancy_grid._binary = _sphere_grid(128, 1.5, 0.8)
+    m.background_color = torch.tensor([1.0, 1.0, 1.0])
+    m.randomized = False
+    rays = _rays(24, 11)
+    out = m(rays)
+    eik = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()  # systems/neus.py:106
+    loss = torch.nn.functional.mse_loss(out["comp_rgb_full"], torch.full_like(out["comp_rgb_full"], 0.4)) * 10 + eik * 0.1
+    loss.backward()
+    fx = {"rays": rays, "background": m.background_color, "binary_packed": np.packbits(m.occupancy_grid._binary.numpy()),
+          "cos_anneal_ratio": m.cos_anneal_ratio, "loss": loss, "loss_eikonal": eik}
+    fx.update({"param/" + k: v for k, v in m.state_dict().items() if "occupancy" not in k})
+    fx.update({"grad/" + k: v.grad for k, v in m.named_parameters() if v.grad is not None and v.numel() > 0})
+    fx.update({"out/" + k: v for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "neus_forward.npz"), **_np(fx))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    models = refshim.install(tcnn_ref, nerfacc_ref)
+    gen_glue(models)
+    gen_neus_alpha(models)
+    gen_nerf(models)
+    gen_neus(models)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

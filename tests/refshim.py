@@ -210,9 +210,31 @@ def _install_stubs():
     _mod("omegaconf", OmegaConf=OmegaConf, DictConfig=DictConfig)
 
 
+_SAVED = {}
+
+
+def uninstall():
+    """undo install(): restore sys.modules / sys.path / torch.cuda.device so later tests see the product packages"""
+    if not _SAVED:
+        return
+    for k in [k for k in sys.modules if k.split(".")[0] in _SAVED["names"]]:
+        del sys.modules[k]
+    sys.modules.update(_SAVED["modules"])
+    if REF in sys.path:
+        sys.path.remove(REF)
+    torch.cuda.device, torch.cuda.empty_cache = _SAVED["cuda_device"], _SAVED["empty_cache"]
+    sys.dont_write_bytecode = _SAVED["dwb"]
+    _SAVED.clear()
+
+
 def install(tcnn_module, nerfacc_module, device="cpu"):
     """Make ``import models`` resolve to the reference with the given tcnn / nerfacc backends."""
     assert available(), "/root/reference is not present on this machine"
+    names = {"tinycudann", "nerfacc", "models", "systems", "utils", "datasets", "pytorch_lightning", "omegaconf",
+             "torch_efficient_distloss", "cv2", "imageio", "mcubes"}
+    if not _SAVED:
+        _SAVED.update(names=names, modules={k: v for k, v in sys.modules.items() if k.split(".")[0] in names},
+                      cuda_device=torch.cuda.device, empty_cache=torch.cuda.empty_cache, dwb=sys.dont_write_bytecode)
     sys.dont_write_bytecode = True
     _install_stubs()
     sys.modules["tinycudann"] = tcnn_module

@@ -79,10 +79,10 @@ def test_product_packages_have_no_cpu_path():
 
 
 def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
     pkg = os.path.join(ROOT, "instant-nsr-pl_amd")
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)|oracle/_build|libnsr_oracle", re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".sh")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("oracle (", "").replace("the oracle", "").replace("oracle/", "ORACLEDOC"), \
-                    f"{f} references the oracle"
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f"{f} uses the oracle"
