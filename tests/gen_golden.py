@@ -128,6 +128,9 @@ def gen_neus(models):
     m.update_step(0, 5000)  # cos_anneal_ratio = 0.25; occupancy refresh is skipped (5000 % 16 != 0)
     with torch.no_grad():
         m.geometry.encoding.encoding.params.normal_(0, 0.05)
+        # sphere_init zeroes the first layer's weights on the encoding columns (network_utils.py:121-123); give them
+        # mass so the fixture exercises the hash-grid gradients (first AND second order), as a trained model does
+        m.geometry.network.layers[0].weight_v[:, 3:].normal_(0, 0.05)
     m.occupancy_grid._binary = _sphere_grid(128, 1.5, 0.8)
     m.background_color = torch.tensor([1.0, 1.0, 1.0])
     m.randomized = False
