@@ -273,6 +273,12 @@ int nsr_visibility_prefix(const nsr_half *mlp_out, uint32_t stride, float densit
 int nsr_copy_ray_prefixes(const int32_t *packed_old, const int32_t *packed_new, const float *t_starts,
                           const float *t_ends, int64_t *ray_indices_out, float *t_starts_out, float *t_ends_out,
                           uint32_t n_rays, void *stream);
+/* Same compaction for up to 8 per-sample row arrays (host arrays of device pointers; row_bytes multiples of 4): the
+ * kept prefix of a ray is contiguous before and after pruning, so this is a per-ray memcpy.  Lets the main pass
+ * reuse the encodings / MLP activations the sigma pass already computed.  dirs_out / ray_indices_out may be NULL. */
+int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
+                             const void *const *src, void *const *dst, const uint32_t *row_bytes, const float *rays_d,
+                             float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays, void *stream);
 /* tex_in[n,32] (half) = [mlp_out[:, :16] | SH4((dirs+1)/2)]   (texture.py:24-26) */
 int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in, uint32_t n,
                       void *stream);
@@ -298,6 +304,14 @@ int nsr_gather_train_rays(const float *images, const float *masks, const float *
                           const int64_t *index, const int64_t *px, const int64_t *py, const float *background,
                           int height, int width, int apply_mask, float *rays, float *rgb, float *fg, uint32_t n,
                           void *stream);
+
+/* everything a training ray needs before marching in ONE launch: pixel choice from 4 uniform rows u01[4,n]
+ * (image, x, y, jitter), pixel gather, get_rays + normalise, background blend, slab test against `aabb`
+ * (device[6]) and the stratified jitter t_min += u*jitter_step (0 disables).  rays[n,6] and the split rays_o/rays_d */
+int nsr_prepare_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,
+                           const float *u01, const float *background, int n_images, int height, int width,
+                           int apply_mask, const float *aabb, float jitter_step, float *rays, float *rays_o,
+                           float *rays_d, float *rgb, float *fg, float *t_min, float *t_max, uint32_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:

@@ -114,6 +114,39 @@ k_copy_ray_prefixes(const int32_t *__restrict__ packed_old, const int32_t *__res
     }
 }
 
+// Row-wise variant: the kept prefix of a ray is ONE contiguous block in both the marched and the pruned layout, so
+// carrying per-sample rows (encoded features, MLP activations, MLP outputs, positions) over the pruning step is a
+// per-ray memcpy -- the main pass then reuses what the sigma pass already computed instead of re-encoding.
+struct RowCopy { const uint32_t *src; uint32_t *dst; uint32_t row_dwords; uint32_t pad; };
+struct RowCopies { RowCopy a[8]; uint32_t n; };
+
+__global__ void __launch_bounds__(R_BLOCK)
+k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__restrict__ packed_new, const RowCopies rc,
+                       const float *__restrict__ rays_d, float *__restrict__ dirs_out, int64_t *__restrict__ ri_o,
+                       uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const uint32_t src = (uint32_t)packed_old[2ull * r];
+    const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
+    if (cnt == 0) return;
+    for (uint32_t q = 0; q < rc.n; ++q) {
+        const uint32_t rd = rc.a[q].row_dwords;
+        const uint32_t *s = rc.a[q].src + (uint64_t)src * rd;
+        uint32_t *d = rc.a[q].dst + (uint64_t)dst * rd;
+        const uint32_t nd = cnt * rd;
+        for (uint32_t w = lane; w < nd; w += 64) d[w] = s[w];
+    }
+    if (dirs_out) {
+        const float d0 = rays_d[3ull * r], d1 = rays_d[3ull * r + 1], d2 = rays_d[3ull * r + 2];
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            dirs_out[3ull * (dst + k)] = d0; dirs_out[3ull * (dst + k) + 1] = d1; dirs_out[3ull * (dst + k) + 2] = d2;
+        }
+    }
+    if (ri_o)
+        for (uint32_t k = lane; k < cnt; k += 64) ri_o[dst + k] = (int64_t)r;
+}
+
 // tex_in[n,32] half = [ mlp_out[:, :16] | SH4((d+1)/2) ]  (the fp16 feature IS what .float() then fp16-cast returns)
 __global__ void __launch_bounds__(EW_BLOCK)
 k_texture_input(const __half *__restrict__ mlp_out, uint32_t stride, const float *__restrict__ dirs,
@@ -322,6 +355,67 @@ k_gather_train_rays(const float *__restrict__ images, const float *__restrict__ 
     }
 }
 
+// One kernel for everything a training ray needs before marching (systems/nerf.py:38-79 + the slab test and the
+// stratified jitter at the top of nerfacc.ray_marching): u01 holds 4 uniform rows [image, x, y, jitter].
+__global__ void __launch_bounds__(EW_BLOCK)
+k_prepare_train_rays(const float *__restrict__ images, const float *__restrict__ masks,
+                     const float *__restrict__ directions, const float *__restrict__ c2w, const float *__restrict__ u01,
+                     const float *__restrict__ bg, int n_img, int H, int W, int apply_mask,
+                     const float *__restrict__ aabb, float jitter_step, float *__restrict__ rays,
+                     float *__restrict__ rays_o, float *__restrict__ rays_d, float *__restrict__ rgb,
+                     float *__restrict__ fg, float *__restrict__ t_min, float *__restrict__ t_max, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int im = min((int)(u01[i] * (float)n_img), n_img - 1);
+    const int x = min((int)(u01[n + i] * (float)W), W - 1);
+    const int y = min((int)(u01[2ull * n + i] * (float)H), H - 1);
+    const float *dir = directions + ((size_t)y * W + x) * 3;
+    const float *m = c2w + (size_t)im * 12;
+    float d[3], o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = (dir[0] * m[4 * k] + dir[1] * m[4 * k + 1]) + dir[2] * m[4 * k + 2];
+    const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = m[4 * k + 3];
+        d[k] = d[k] / nrm;
+        rays[6ull * i + k] = o[k];
+        rays[6ull * i + 3 + k] = d[k];
+        rays_o[3ull * i + k] = o[k];
+        rays_d[3ull * i + k] = d[k];
+    }
+    const size_t pix = ((size_t)im * H + y) * W + x;
+    const float f = masks[pix];
+    fg[i] = f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float c = images[pix * 3 + k];
+        rgb[3ull * i + k] = apply_mask ? c * f + bg[k] * (1.f - f) : c;
+    }
+    // slab test: same operation order as csrc/march.hip:aabb_one (bit-exact against the oracle)
+    float tmin = (aabb[0] - o[0]) / d[0], tmax = (aabb[3] - o[0]) / d[0];
+    if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
+    float tymin = (aabb[1] - o[1]) / d[1], tymax = (aabb[4] - o[1]) / d[1];
+    if (tymin > tymax) { const float s = tymin; tymin = tymax; tymax = s; }
+    float near = 1e10f, far = 1e10f;
+    if (!(tmin > tymax || tymin > tmax)) {
+        if (tymin > tmin) tmin = tymin;
+        if (tymax < tmax) tmax = tymax;
+        float tzmin = (aabb[2] - o[2]) / d[2], tzmax = (aabb[5] - o[2]) / d[2];
+        if (tzmin > tzmax) { const float s = tzmin; tzmin = tzmax; tzmax = s; }
+        if (!(tmin > tzmax || tzmin > tmax)) {
+            if (tzmin > tmin) tmin = tzmin;
+            if (tzmax < tmax) tmax = tzmax;
+            near = tmin > 0.f ? tmin : 0.f;
+            far = tmax;
+        }
+    }
+    if (jitter_step > 0.f) near = __fadd_rn(near, __fmul_rn(u01[3ull * n + i], jitter_step));  // t_min + rand * step
+    t_min[i] = near;
+    t_max[i] = far;
+}
+
 }  // namespace
 
 #define RAY_GRID(n_rays) dim3(nsr_div_up(n_rays, RAYS_PER_BLOCK)), dim3(R_BLOCK), 0, (hipStream_t)stream
@@ -440,5 +534,44 @@ extern "C" int nsr_gather_train_rays(const float *images, const float *masks, co
     hipLaunchKernelGGL(k_gather_train_rays, EW_GRID(n), images, masks, directions, c2w, index, px, py, background,
                        height, width, apply_mask, rays, rgb, fg, n);
     NSR_CHECK_LAUNCH("nsr_gather_train_rays");
+    return NSR_OK;
+}
+
+extern "C" int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
+                                        const void *const *src, void *const *dst, const uint32_t *row_bytes,
+                                        const float *rays_d, float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays,
+                                        void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_old && packed_new, "nsr_copy_ray_prefix_rows: NULL packed_info");
+    NSR_REQUIRE(n_arrays <= 8, "nsr_copy_ray_prefix_rows: at most 8 arrays");
+    NSR_REQUIRE(!dirs_out || rays_d, "nsr_copy_ray_prefix_rows: dirs_out needs rays_d");
+    RowCopies rc;
+    rc.n = n_arrays;
+    for (uint32_t q = 0; q < n_arrays; ++q) {
+        NSR_REQUIRE(src[q] && dst[q] && row_bytes[q] % 4 == 0, "nsr_copy_ray_prefix_rows: array %u: NULL or row not a multiple of 4 B", q);
+        rc.a[q].src = (const uint32_t *)src[q];
+        rc.a[q].dst = (uint32_t *)dst[q];
+        rc.a[q].row_dwords = row_bytes[q] / 4;
+        rc.a[q].pad = 0;
+    }
+    hipLaunchKernelGGL(k_copy_ray_prefix_rows, RAY_GRID(n_rays), packed_old, packed_new, rc, rays_d, dirs_out,
+                       ray_indices_out, n_rays);
+    NSR_CHECK_LAUNCH("nsr_copy_ray_prefix_rows");
+    return NSR_OK;
+}
+
+extern "C" int nsr_prepare_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,
+                                      const float *u01, const float *background, int n_images, int height, int width,
+                                      int apply_mask, const float *aabb, float jitter_step, float *rays, float *rays_o,
+                                      float *rays_d, float *rgb, float *fg, float *t_min, float *t_max, uint32_t n,
+                                      void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(images && masks && directions && c2w && u01 && background && aabb && rays && rays_o && rays_d && rgb &&
+                    fg && t_min && t_max, "nsr_prepare_train_rays: NULL pointer");
+    hipLaunchKernelGGL(k_prepare_train_rays, EW_GRID(n), images, masks, directions, c2w, u01, background, n_images,
+                       height, width, apply_mask, aabb, jitter_step, rays, rays_o, rays_d, rgb, fg, t_min, t_max, n);
+    NSR_CHECK_LAUNCH("nsr_prepare_train_rays");
     return NSR_OK;
 }

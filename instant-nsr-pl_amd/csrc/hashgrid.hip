@@ -269,28 +269,43 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
             if (!any) continue;
             const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
             if (pow2) {
+                // which of the 4 (y,z) corner pairs land in this slice?  Expected 4/32 per lane: instead of four mostly
+                // empty divergent branches, every lane pops ITS matches -- the wave loops max-popcount (~1.4) times.
                 const uint32_t hy0 = c.c[1] * PRIME_Y, hz0 = c.c[2] * PRIME_Z;
                 const uint32_t lowmask = (1u << OWN_POW2_LOG2) - 1u, topmask = g.size - 1u;
+                uint32_t hh[4];
+                uint32_t match = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t h = (hy0 + ((k & 1) ? PRIME_Y : 0u)) ^ (hz0 + ((k & 2) ? PRIME_Z : 0u));
-                    if (((h & topmask) >> OWN_POW2_LOG2) == slice) {
-                        const float wyz = ((k & 1) ? c.w[1] : 1.f - c.w[1]) * ((k & 2) ? c.w[2] : 1.f - c.w[2]);
-                        lds_add<F>(acc, (c.c[0] ^ h) & lowmask, (1.f - c.w[0]) * wyz, g_out);
-                        lds_add<F>(acc, ((c.c[0] + 1u) ^ h) & lowmask, c.w[0] * wyz, g_out);
-                    }
+                    hh[k] = (hy0 + ((k & 1) ? PRIME_Y : 0u)) ^ (hz0 + ((k & 2) ? PRIME_Z : 0u));
+                    match |= (((hh[k] & topmask) >> OWN_POW2_LOG2) == slice) ? (1u << k) : 0u;
+                }
+                while (match) {
+                    const int k = __builtin_ctz(match);
+                    match &= match - 1u;
+                    const uint32_t h = (k == 0) ? hh[0] : (k == 1) ? hh[1] : (k == 2) ? hh[2] : hh[3];
+                    const float wyz = ((k & 1) ? c.w[1] : 1.f - c.w[1]) * ((k & 2) ? c.w[2] : 1.f - c.w[2]);
+                    lds_add<F>(acc, (c.c[0] ^ h) & lowmask, (1.f - c.w[0]) * wyz, g_out);
+                    lds_add<F>(acc, ((c.c[0] + 1u) ^ h) & lowmask, c.w[0] * wyz, g_out);
                 }
             } else {
+                uint32_t ee[8];
+                uint32_t match = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const uint32_t e = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1));
-                    const uint32_t rel = e - r0;
-                    if (rel < cnt) {
-                        float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
-                        w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
-                        w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
-                        lds_add<F>(acc, rel, w, g_out);
-                    }
+                    ee[k] = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1)) - r0;
+                    match |= (ee[k] < cnt) ? (1u << k) : 0u;
+                }
+                while (match) {
+                    const int k = __builtin_ctz(match);
+                    match &= match - 1u;
+                    uint32_t rel = ee[0];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) rel = (k == q) ? ee[q] : rel;
+                    float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
+                    w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
+                    w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
+                    lds_add<F>(acc, rel, w, g_out);
                 }
             }
         }

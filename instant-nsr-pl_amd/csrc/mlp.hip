@@ -231,6 +231,15 @@ k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __
 // ------------------------------------------------------------------------------------------------
 constexpr int TROW = 20;  // halfs per row of the transposed [64][16] tile (40 B: conflict-free b16 scatter)
 
+// Order this wave's LDS writes before its LDS reads (the transposed tiles are wave-private).  Only the LDS counter is
+// drained: a workgroup-scope fence would also wait for every outstanding GLOBAL load/store (vmcnt(0)) six times per
+// tile -- measured ~12 us per tile, 4x the rest of the kernel.
+__device__ __forceinline__ void lds_wave_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // scatter a D-layout value set (lane (n,g): cols cb*16+4g+r) into the transposed tile T[col][n]
 __device__ __forceinline__ void lds_scatter(_Float16 *T, int cb, int g, int nl, const f32x4 &v)
 {
@@ -263,11 +272,16 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
     const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
     const uint32_t n_tiles = (n + 15) / 16;
 
-    const _Float16 *W = reinterpret_cast<const _Float16 *>(W_);
-    if (need_dw) {
-        for (int k = threadIdx.x; k < N_PARAMS; k += MLP_BLOCK) lds_dw[k] = 0.f;
+    // stage the whole weight set in LDS with coalesced 16-B loads (the dW area is free until the tile loop): the
+    // transposed dgrad fragments are 2-byte strided gathers, cheap from LDS, a ~100-load latency chain from L2
+    {
+        const _Float16 *Wg = reinterpret_cast<const _Float16 *>(W_);
+        _Float16 *Wl_ = reinterpret_cast<_Float16 *>(smem);
+        for (int k = threadIdx.x * 8; k < N_PARAMS; k += MLP_BLOCK * 8)
+            *reinterpret_cast<uint4 *>(Wl_ + k) = *reinterpret_cast<const uint4 *>(Wg + k);
     }
     __syncthreads();
+    const _Float16 *W = reinterpret_cast<const _Float16 *>(smem);
 
     // ---- transposed weight fragments for dgrad ----
     const _Float16 *Wl = W + WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH;  // [16, 64]
@@ -290,6 +304,11 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) at0[ib][kc] = load_at_sigma(W, IN_PAD, ib * 16 + nl, kc, g);
     }
+    __syncthreads();  // everyone has its fragments: the area becomes the dW accumulator
+    if (need_dw) {
+        for (int k = threadIdx.x; k < N_PARAMS; k += MLP_BLOCK) lds_dw[k] = 0.f;
+    }
+    __syncthreads();
 
     // ---- fp32 weight-gradient accumulators (D layout of dW blocks: lane (c,g): dW[ob*16+4g+r][kb*16+c]) ----
     f32x4 dw0[4][KIN];
@@ -340,13 +359,11 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
             lds_scatter(TP, 0, g, nl, d_o);
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) lds_scatter(TQ, ib, g, nl, hact[ib]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            lds_wave_sync();
             const half4 pa = lds_gather(TP, 0, g, nl);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) dwl[kb] = mfma16(pa, lds_gather(TQ, kb, g, nl), dwl[kb]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            lds_wave_sync();
         }
         // B fragment of dOut^T: k = 8g+j real for k<16 -> lanes g<2 hold cols 8g..8g+7.  We have cols 4g+r
         // (D layout); rebuild the natural fragment through the LDS tile we may have just written, or
@@ -398,8 +415,7 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
 #pragma unroll
                     for (int ib = 0; ib < KIN; ++ib) lds_scatter(TQ, ib, g, nl, inp[ib]);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                lds_wave_sync();
                 half4 pa[4];
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) pa[ob] = lds_gather(TP, ob, g, nl);
@@ -418,8 +434,7 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
                         for (int ob = 0; ob < 4; ++ob) dw0[ob][kb] = mfma16(pa[ob], qb, dw0[ob][kb]);
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                lds_wave_sync();
             }
             // dgrad to the layer below
             const half8 b0 = pack_b(dh[0], dh[1]), b1 = pack_b(dh[2], dh[3]);
@@ -525,7 +540,7 @@ uint32_t n_params_of(const NsrMlpDesc *d) { return WIDTH * d->in_pad + (d->n_hid
 uint32_t bwd_blocks(uint32_t n)
 {
     const uint32_t n_tiles = (n + 15) / 16;
-    uint32_t nb = (n_tiles + WAVES * 8 - 1) / (WAVES * 8);
+    uint32_t nb = (n_tiles + WAVES * 8 - 1) / (WAVES * 8);  // ~8 tiles per wave (4 was measured slower: fixed cost per wave)
     return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
 }
 
@@ -558,8 +573,11 @@ extern "C" int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, c
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(x && weights && out, "nsr_mlp_forward: NULL pointer");
     NSR_REQUIRE(x_stride >= desc->n_in, "nsr_mlp_forward: x_stride < n_in");
+    // the forward is latency-bound per tile (load -> MFMA chain -> store), so parallelism wins over weight reuse: one
+    // 16-sample tile per wavefront until the chip is full (2048 blocks x 4 waves = 8 waves/SIMD), grid-stride beyond.
+    // (measured at 8.8e4 samples: 8 tiles/wave 20 us -> 1 tile/wave)
     const uint32_t n_tiles = (n + 15) / 16;
-    uint32_t blocks = (n_tiles + WAVES * 8 - 1) / (WAVES * 8);
+    uint32_t blocks = (n_tiles + WAVES - 1) / WAVES;
     if (blocks > 2048) blocks = 2048;
     DISPATCH_MLP(desc->in_pad / 16, desc->n_hidden,
                  hipLaunchKernelGGL((k_mlp_forward<KIN, NH>), dim3(blocks), dim3(MLP_BLOCK), 0, (hipStream_t)stream, x,
@@ -593,7 +611,11 @@ extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t d
     const uint32_t nb = bwd_blocks(n), np = n_params_of(desc);
     const size_t lds = sizeof(float) * np + WAVES * 2 * 64 * TROW * sizeof(_Float16);
     DISPATCH_MLP(desc->in_pad / 16, desc->n_hidden, {
-        (void)hipFuncSetAttribute((const void *)k_mlp_backward<KIN, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static bool attr_set = false;  // per instantiation; the call can block on in-flight work of OTHER streams
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)k_mlp_backward<KIN, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
         hipLaunchKernelGGL((k_mlp_backward<KIN, NH>), dim3(nb), dim3(MLP_BLOCK), lds, (hipStream_t)stream, dout,
                            dout_is_f32, dout_stride, (const __half *)out, x, x_is_f32, x_stride, (const __half *)acts,
                            (const __half *)weights, dx, dx_stride, partials, n, desc->n_in, desc->n_out,

@@ -42,24 +42,34 @@ class FusedNeRFStep:
               "nsr_sample_positions_unit")
         return x01, dirs
 
-    def march_and_prune(self, rays_o, rays_d):
-        """ray_marching(..., sigma_fn) of models/nerf.py:82-93 -> packed_info, ray_indices, t_starts, t_ends, M"""
+    def march_begin(self, rays_o, rays_d, t_min=None, t_max=None):
+        """slab test + (stratified jitter) + marching pass, enqueued on the current stream with no host sync"""
         m = self.model
         grid = m.occupancy_grid
-        t_min, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
-        if m.randomized:
-            t_min = t_min + torch.rand_like(t_min) * m.render_step_size
-        packed, ri, t0, t1 = _ops.ray_march(rays_o, rays_d, t_min, t_max, grid.roi_aabb, grid.binary,
-                                            ContractionType.AABB.value, m.render_step_size, 0.0,
-                                            roi_host=grid._roi_host)
+        if t_min is None:
+            t_min, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
+            if m.randomized:
+                t_min = t_min + torch.rand_like(t_min) * m.render_step_size
+        return _ops.ray_march_begin(rays_o, rays_d, t_min, t_max, grid.roi_aabb, grid.binary,
+                                    ContractionType.AABB.value, m.render_step_size, 0.0, roi_host=grid._roi_host)
+
+    def march_and_prune(self, rays_o, rays_d, keep_rows, handle=None, after_prune=None):
+        """ray_marching(..., sigma_fn) of models/nerf.py:82-93.  With ``keep_rows`` the sigma pass saves encodings and
+        activations of ALL marched samples and the pruning copies the kept rows: the main pass re-encodes nothing.
+        -> dict(packed, ri, t0, t1, M, [x01, dirs, enc, out1, acts1])"""
+        if handle is None:
+            handle = self.march_begin(rays_o, rays_d)
+        packed, ri, t0, t1 = _ops.ray_march_finish(handle)
         n_rays, M = rays_o.shape[0], ri.shape[0]
         if M == 0:
-            return packed, ri, t0, t1, 0
+            if after_prune is not None:
+                after_prune(0)
+            return dict(packed=packed, ri=ri, t0=t0, t1=t1, M=0)
         ewn = self.ewn
         table, w = ewn.table_half(ewn.params), ewn.weights_half(ewn.params)
         x01, _ = self._positions(rays_o, rays_d, ri, t0, t1, False)
         enc = _ops.hashgrid_forward(x01, table, ewn.grid_desc)
-        out, _ = _ops.mlp_forward(enc, w, ewn.mlp_desc, save_acts=False)
+        out, acts = _ops.mlp_forward(enc, w, ewn.mlp_desc, save_acts=keep_rows)
         dev = ri.device
         kept = torch.empty(n_rays, dtype=torch.int32, device=dev)
         packed2 = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
@@ -69,39 +79,61 @@ class FusedNeRFStep:
                                         ptr(kept), n_rays, s), "nsr_visibility_prefix")
         check(lib.nsr_pack_from_counts(ptr(kept), ptr(packed2), ptr(total), n_rays, s), "nsr_pack_from_counts")
         S = int(total.item())  # second (and last) host sync of the step
+        if after_prune is not None:
+            after_prune(S)  # e.g. the trainer launches the NEXT step's marching on a side stream right here
         ri2 = torch.empty(S, dtype=torch.int64, device=dev)
         t0b, t1b = torch.empty((S, 1), dtype=F32, device=dev), torch.empty((S, 1), dtype=F32, device=dev)
-        check(lib.nsr_copy_ray_prefixes(ptr(packed), ptr(packed2), ptr(t0), ptr(t1), ptr(ri2), ptr(t0b), ptr(t1b),
-                                        n_rays, s), "nsr_copy_ray_prefixes")
-        return packed2, ri2, t0b, t1b, M
+        res = dict(packed=packed2, ri=ri2, t0=t0b, t1=t1b, M=M)
+        srcs, dsts = [t0, t1], [t0b, t1b]
+        dirs = None
+        if keep_rows:
+            res["x01"] = torch.empty((S, 3), dtype=F32, device=dev)
+            res["enc"] = torch.empty((S, enc.shape[1]), dtype=F16, device=dev)
+            res["out1"] = torch.empty((S, out.shape[1]), dtype=F16, device=dev)
+            res["acts1"] = torch.empty((acts.shape[0], S, 64), dtype=F16, device=dev)
+            dirs = res["dirs"] = torch.empty((S, 3), dtype=F32, device=dev)
+            srcs += [x01, enc, out] + [acts[h] for h in range(acts.shape[0])]
+            dsts += [res["x01"], res["enc"], res["out1"]] + [res["acts1"][h] for h in range(acts.shape[0])]
+        n = len(srcs)
+        sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        dp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts])
+        rb = (ctypes.c_uint32 * n)(*[t.stride(0) * t.element_size() for t in srcs])
+        check(lib.nsr_copy_ray_prefix_rows(ptr(packed), ptr(packed2), n, sp, dp, rb, ptr(rays_d), ptr(dirs), ptr(ri2),
+                                           n_rays, s), "nsr_copy_ray_prefix_rows")
+        return res
 
-    def forward_backward(self, rays, gt_rgb, background, compute_grads=True, loss_scale=1.0):
-        """-> dict(loss, comp_rgb, opacity, depth, num_samples, weights, ray_indices, t_starts, t_ends).  Gradients of
-        ``loss_scale * loss`` are ACCUMULATED into ``.grad`` of the MLP slices and OVERWRITE the hash-table slice."""
+    def forward_backward(self, rays, gt_rgb, background, compute_grads=True, loss_scale=1.0, march_handle=None,
+                         after_prune=None, after_enqueue=None):
+        """-> dict(loss_acc, comp_rgb, opacity, depth, num_samples, weights, ray_indices, t_starts, t_ends).  Gradients
+        of ``loss_scale * loss`` are ACCUMULATED into ``.grad`` of the MLP slices and OVERWRITE the hash-table slice."""
         m, ewn, tex = self.model, self.ewn, self.tex
         dev = rays.device
         n_rays = rays.shape[0]
         rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
         with torch.no_grad(), torch.cuda.device(dev):
             with _ops.timed("fused:march_prune"):
-                packed, ri, t0, t1, M = self.march_and_prune(rays_o, rays_d)
+                mp = self.march_and_prune(rays_o, rays_d, keep_rows=True, handle=march_handle, after_prune=after_prune)
+            packed, ri, t0, t1, M = mp["packed"], mp["ri"], mp["t0"], mp["t1"], mp["M"]
             S = ri.shape[0]
             s = stream_ptr()
-            table, w1, w2 = ewn.table_half(ewn.params), ewn.weights_half(ewn.params), tex.weights_half(tex.params)
+            w1, w2 = ewn.weights_half(ewn.params), tex.weights_half(tex.params)
             with _ops.timed("fused:forward"):
-                x01, dirs = self._positions(rays_o, rays_d, ri, t0, t1, True)
-                enc = _ops.hashgrid_forward(x01, table, ewn.grid_desc)
-                out1, acts1 = _ops.mlp_forward(enc, w1, ewn.mlp_desc, save_acts=compute_grads)
+                if S > 0:
+                    x01, dirs, enc, out1, acts1 = mp["x01"], mp["dirs"], mp["enc"], mp["out1"], mp["acts1"]
+                else:
+                    x01 = dirs = torch.empty((0, 3), dtype=F32, device=dev)
+                    enc, out1 = torch.empty((0, 32), dtype=F16, device=dev), torch.empty((0, 16), dtype=F16, device=dev)
+                    acts1 = torch.empty((1, 0, 64), dtype=F16, device=dev)
                 tex_in = torch.empty((S, 32), dtype=F16, device=dev)
-                check(lib.nsr_texture_input(ptr(out1), out1.stride(0), ptr(dirs), ptr(tex_in), S, s), "nsr_texture_input")
+                check(lib.nsr_texture_input(ptr(out1), 16, ptr(dirs), ptr(tex_in), S, s), "nsr_texture_input")
                 out2, acts2 = _ops.mlp_forward(tex_in, w2, tex.mlp_desc, save_acts=compute_grads)
                 weights, trans = torch.empty(S, dtype=F32, device=dev), torch.empty(S, dtype=F32, device=dev)
                 comp_rgb = torch.empty((n_rays, 3), dtype=F32, device=dev)
                 opacity, depth = torch.empty((n_rays, 1), dtype=F32, device=dev), torch.empty((n_rays, 1), dtype=F32, device=dev)
                 bg = background.to(F32).contiguous()
-                check(lib.nsr_composite_forward(ptr(out1), out1.stride(0), self.bias, ptr(t0), ptr(t1), ptr(out2),
-                                                out2.stride(0), ptr(packed), ptr(bg), ptr(weights), ptr(trans),
-                                                ptr(comp_rgb), ptr(opacity), ptr(depth), n_rays, s), "nsr_composite_forward")
+                check(lib.nsr_composite_forward(ptr(out1), 16, self.bias, ptr(t0), ptr(t1), ptr(out2), out2.stride(0),
+                                                ptr(packed), ptr(bg), ptr(weights), ptr(trans), ptr(comp_rgb),
+                                                ptr(opacity), ptr(depth), n_rays, s), "nsr_composite_forward")
                 acc = torch.zeros(2, dtype=F32, device=dev)
                 gt = gt_rgb.to(F32).contiguous()
                 check(lib.nsr_smooth_l1_valid(ptr(comp_rgb), ptr(opacity), ptr(gt), ptr(acc), n_rays, s), "nsr_smooth_l1_valid")
@@ -109,16 +141,17 @@ class FusedNeRFStep:
                    "num_samples": S, "num_marched": M, "weights": weights, "ray_indices": ri, "t_starts": t0,
                    "t_ends": t1, "loss_acc": acc}
             if not compute_grads or S == 0:
+                if after_enqueue is not None:
+                    after_enqueue()
                 return res
             with _ops.timed("fused:backward"):
                 g_comp = torch.empty((n_rays, 3), dtype=F32, device=dev)
                 check(lib.nsr_smooth_l1_valid_backward(ptr(comp_rgb), ptr(opacity), ptr(gt), ptr(acc), float(loss_scale),
                                                        ptr(g_comp), n_rays, s), "nsr_smooth_l1_valid_backward")
                 d_rgb, d_logit = torch.empty((S, 3), dtype=F32, device=dev), torch.empty(S, dtype=F32, device=dev)
-                check(lib.nsr_composite_backward(ptr(out1), out1.stride(0), self.bias, ptr(t0), ptr(t1), ptr(out2),
-                                                 out2.stride(0), ptr(packed), ptr(bg), ptr(weights), ptr(trans),
-                                                 ptr(g_comp), None, None, ptr(d_rgb), ptr(d_logit), n_rays, s),
-                      "nsr_composite_backward")
+                check(lib.nsr_composite_backward(ptr(out1), 16, self.bias, ptr(t0), ptr(t1), ptr(out2), out2.stride(0),
+                                                 ptr(packed), ptr(bg), ptr(weights), ptr(trans), ptr(g_comp), None, None,
+                                                 ptr(d_rgb), ptr(d_logit), n_rays, s), "nsr_composite_backward")
                 for p in (ewn.params, tex.params):
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
@@ -129,6 +162,8 @@ class FusedNeRFStep:
                                            ewn.mlp_slice(ewn.params.grad), ewn.grid_desc.n_features)
                 _ops.hashgrid_backward_params(x01, d_enc, ewn.grid_slice(ewn.params.grad), ewn.grid_desc,
                                               accumulate=False, level_major=True)
+            if after_enqueue is not None:
+                after_enqueue()  # the whole step is queued: host time spent here overlaps GPU work
             return res
 
     def _mlp_backward(self, dout, dout_stride, extra, out, x, acts, w, desc, grad_w, dx_lm_f):
@@ -165,3 +200,24 @@ def gather_train_rays(dataset, n_rays, generator, background="random"):
                                         int(dataset.apply_mask), ptr(rays), ptr(rgb), ptr(fg), n_rays, stream_ptr()),
               "nsr_gather_train_rays")
     return rays, rgb, fg, bg
+
+
+def prepare_train_rays(dataset, n_rays, generator, model, background="random"):
+    """ONE RNG call + ONE kernel: pixel choice, gather, get_rays, background blend, slab test, stratified jitter.
+    -> rays[n,6], rays_o, rays_d, rgb, fg, bg, t_min, t_max"""
+    dev = dataset.all_images.device
+    n_img, H, W = dataset.all_images.shape[0], dataset.h, dataset.w
+    u = torch.rand((5, max(n_rays, 3)), device=dev, generator=generator)
+    bg = u[4, :3].contiguous() if background == "random" else torch.ones(3, device=dev)
+    buf = torch.empty(n_rays * 18, dtype=F32, device=dev)  # rays(6) o(3) d(3) rgb(3) fg(1) tmin(1) tmax(1)
+    rays, ro, rd = buf[:6 * n_rays].view(n_rays, 6), buf[6 * n_rays:9 * n_rays].view(n_rays, 3), buf[9 * n_rays:12 * n_rays].view(n_rays, 3)
+    rgb, fg = buf[12 * n_rays:15 * n_rays].view(n_rays, 3), buf[15 * n_rays:16 * n_rays]
+    t_min, t_max = buf[16 * n_rays:17 * n_rays], buf[17 * n_rays:18 * n_rays]
+    u4 = u if u.shape[1] == n_rays else u[:, :n_rays].contiguous()
+    jitter = float(model.render_step_size) if model.randomized else 0.0
+    with torch.cuda.device(dev):
+        check(lib.nsr_prepare_train_rays(ptr(dataset.all_images), ptr(dataset.all_fg_masks), ptr(dataset.directions),
+                                         ptr(dataset.all_c2w), ptr(u4), ptr(bg), n_img, H, W, int(dataset.apply_mask),
+                                         ptr(model.scene_aabb), jitter, ptr(rays), ptr(ro), ptr(rd), ptr(rgb), ptr(fg),
+                                         ptr(t_min), ptr(t_max), n_rays, stream_ptr()), "nsr_prepare_train_rays")
+    return rays, ro, rd, rgb, fg, bg, t_min, t_max

@@ -72,7 +72,7 @@ class Trainer:
         other = [p for p in model.parameters() if id(p) not in tc_params]
         self.opt = FusedAdamW(tc, other)
         self.last = {}
-        self.fused = None
+        self.fused, self._pending, self._side, self.pipeline_march = None, None, None, True
         if fused and config["name"] == "nerf":
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
@@ -113,20 +113,52 @@ class Trainer:
         return self.last
 
     def _train_step_fused(self):
-        """same step through nsr.fused.FusedNeRFStep (hand-chained backward, ~25 launches)"""
-        from .fused import FusedNeRFStep, gather_train_rays
-        model = self.model
-        with _ops.timed("phase:sample_rays"):
-            rays, rgb, fg, bg = gather_train_rays(self.dataset, self.train_num_rays, self.gen,
-                                                  self.config["background_color"])
-        model.background_color = bg
+        """same step through nsr.fused.FusedNeRFStep (hand-chained backward, ~25 launches).
+
+        Marching depends only on the rays and the occupancy grid, not on the parameters, and it is a latency-bound
+        kernel that occupies ~3 % of the chip.  So the marching pass of step k+1 is launched on a SIDE STREAM as soon as
+        step k knows its sample count (which fixes the next ray count), and runs underneath step k's forward/backward/
+        optimizer.  Steps that refresh the occupancy grid (every 16th) march in order instead."""
+        from .fused import FusedNeRFStep, prepare_train_rays
+        model, fused = self.model, self.fused
+        pending, self._pending = getattr(self, "_pending", None), None
         with _ops.timed("phase:occupancy_update"):
             model.update_step(0, self.global_step)
-        res = self.fused.forward_backward(rays, rgb, bg)
+        if pending is None:
+            with _ops.timed("phase:sample_rays"):
+                rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(
+                    self.dataset, self.train_num_rays, self.gen, model, self.config["background_color"])
+                handle = fused.march_begin(ro, rd, t_min, t_max)
+        else:
+            rays, rgb, bg, handle = pending
+        model.background_color = bg
+        next_updates_grid = self.config["grid_prune"] and (self.global_step + 1) % 16 == 0
+
+        def after_prune(n_samples):
+            if self.config["dynamic_ray_sampling"] and n_samples > 0:  # systems/nerf.py:93-95
+                t = int(self.train_num_rays * (self.train_num_samples / n_samples))
+                self.train_num_rays = min(int(self.train_num_rays * 0.9 + t * 0.1), self.config["max_train_num_rays"])
+            launch_next_march()  # first thing after the sync: it is the longest pole of the NEXT step
+
+        def launch_next_march():
+            if not self.pipeline_march or next_updates_grid:
+                return
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(main)  # once: dataset + grid tensors exist.  NOT per step: the marching pass
+                # reads only rays and the (unchanged until the next refresh) occupancy bricks, never the parameters,
+                # and waiting on `main` here would serialise it behind this step's backward.
+            with torch.cuda.stream(self._side):
+                nrays, ro, rd, nrgb, _, nbg, t_min, t_max = prepare_train_rays(
+                    self.dataset, self.train_num_rays, self.gen, model, self.config["background_color"])
+                h = fused.march_begin(ro, rd, t_min, t_max)
+            for x in (nrays, nrgb, nbg):
+                x.record_stream(main)
+            self._pending = (nrays, nrgb, nbg, h)
+
+        res = fused.forward_backward(rays, rgb, bg, march_handle=handle, after_prune=after_prune)
         n_samples = res["num_samples"]  # already on the host (the pruning sync): no extra .item()
-        if self.config["dynamic_ray_sampling"] and n_samples > 0:
-            t = int(self.train_num_rays * (self.train_num_samples / n_samples))
-            self.train_num_rays = min(int(self.train_num_rays * 0.9 + t * 0.1), self.config["max_train_num_rays"])
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):

@@ -64,12 +64,14 @@ SIGNATURES = {
     "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P],
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_copy_ray_prefixes": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_copy_ray_prefix_rows": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_texture_input": [_P, _U, _P, _P, _U, _P],
     "nsr_composite_forward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid": [_P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid_backward": [_P, _P, _P, _P, _F, _P, _U, _P],
     "nsr_gather_train_rays": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _U, _P],
+    "nsr_prepare_train_rays": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_ray_aabb_intersect": [_P, _P, _P, _P, _P, _U, _P],
     "nsr_ray_march_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _U, _P],
     "nsr_ray_march_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _U, _P],

@@ -336,6 +336,94 @@ def grid_bricks(binary):
     return bricks
 
 
+_PINNED = []
+
+
+def _pinned_int32():
+    """ring of pinned host words for the sample-count read-back (hipHostMalloc costs ~100 us: never per step)"""
+    if not _PINNED:
+        _PINNED.extend([torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(8)] + [0])
+    _PINNED[-1] = (_PINNED[-1] + 1) % 8
+    return _PINNED[_PINNED[-1]]
+
+
+class MarchHandle:
+    """an in-flight marching pass (count + per-ray scratch rows); ``ray_march_finish`` turns it into packed samples"""
+    __slots__ = ("args", "counts", "packed", "total", "total_host", "scratch", "cap", "bricks", "grid_u8", "event",
+                 "stream", "n")
+
+
+def ray_march_begin(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone_angle, roi_host=None,
+                    method="bricks"):
+    """enqueue the marching pass on the CURRENT stream without any host sync; the sample total is copied to pinned
+    host memory behind it, so a caller can run this on a side stream underneath other work."""
+    h = MarchHandle()
+    n = h.n = rays_o.shape[0]
+    dev = rays_o.device
+    rx, ry, rz = (int(s) for s in binary.shape)
+    h.args = (rays_o, rays_d, t_min, t_max, roi, (rx, ry, rz), int(contraction), float(step), float(cone_angle))
+    h.counts = torch.empty(n, dtype=torch.int32, device=dev)
+    h.packed = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    h.total = torch.zeros(1, dtype=torch.int32, device=dev)
+    h.total_host = _pinned_int32()
+    h.bricks = grid_bricks(binary) if method == "bricks" else None
+    h.grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
+    h.cap, h.scratch = 0, None
+    with torch.cuda.device(dev):
+        s = stream_ptr()
+        with _timed("ray_march_count", n):
+            if h.bricks is None:
+                check(lib.nsr_ray_march_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(h.grid_u8),
+                                              rx, ry, rz, int(contraction), float(step), float(cone_angle),
+                                              ptr(h.counts), n, s), "nsr_ray_march_count")
+            else:
+                if roi_host is not None and int(contraction) == 0:
+                    h.cap = int(lib.nsr_ray_march_capacity((ctypes.c_float * 6)(*[float(v) for v in roi_host]),
+                                                           float(step)))
+                h.scratch = torch.empty(n * h.cap * 2, dtype=F32, device=dev) if h.cap > 0 else None
+                check(lib.nsr_ray_march_bricks_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
+                                                     ptr(h.bricks), rx, ry, rz, int(contraction), float(step),
+                                                     float(cone_angle), ptr(h.counts), ptr(h.scratch), h.cap, n, s),
+                      "nsr_ray_march_bricks_count")
+        check(lib.nsr_pack_from_counts(ptr(h.counts), ptr(h.packed), ptr(h.total), n, s), "nsr_pack_from_counts")
+        h.total_host.copy_(h.total, non_blocking=True)
+        h.stream = torch.cuda.current_stream()
+        h.event = torch.cuda.Event()
+        h.event.record(h.stream)
+    return h
+
+
+def ray_march_finish(h):
+    """wait for the marching pass (only ITS stream), then pack the samples on the current stream.
+    -> packed_info, ray_indices, t_starts, t_ends"""
+    rays_o, rays_d, t_min, t_max, roi, (rx, ry, rz), contraction, step, cone_angle = h.args
+    dev, n = rays_o.device, h.n
+    h.event.synchronize()  # the marcher's one intrinsic host sync
+    m = int(h.total_host[0])
+    cur = torch.cuda.current_stream()
+    if cur != h.stream:  # tensors born on the marching stream are consumed here
+        cur.wait_event(h.event)
+        for t in (h.counts, h.packed, h.total, h.scratch, rays_o, rays_d, t_min, t_max):
+            if t is not None:
+                t.record_stream(cur)
+    ray_indices = torch.empty(m, dtype=torch.int64, device=dev)
+    t_starts = torch.empty((m, 1), dtype=F32, device=dev)
+    t_ends = torch.empty((m, 1), dtype=F32, device=dev)
+    if m > 0:
+        with torch.cuda.device(dev), _timed("ray_march_write", n):
+            s = stream_ptr()
+            if h.bricks is None:
+                check(lib.nsr_ray_march_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(h.grid_u8),
+                                              rx, ry, rz, contraction, step, cone_angle, ptr(h.packed), ptr(ray_indices),
+                                              ptr(t_starts), ptr(t_ends), n, s), "nsr_ray_march_write")
+            else:
+                check(lib.nsr_ray_march_bricks_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
+                                                     ptr(h.bricks), rx, ry, rz, contraction, step, cone_angle,
+                                                     ptr(h.packed), ptr(h.scratch), h.cap, ptr(ray_indices),
+                                                     ptr(t_starts), ptr(t_ends), n, s), "nsr_ray_march_bricks_write")
+    return h.packed, ray_indices, t_starts, t_ends
+
+
 def ray_march(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone_angle, roi_host=None,
               method="bricks"):
     """occupancy-grid marching; ONE host sync (the sample count).  -> packed_info, ray_indices, t_starts, t_ends.
@@ -343,51 +431,8 @@ def ray_march(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone
     method "bricks" (default): bit-packed 4^3 bricks + LDS any-bits, single marching pass into per-ray scratch when
     the sample capacity is provable (AABB contraction with a finite roi: pass ``roi_host`` = 6 python floats);
     method "bytes": the plain two-pass byte-grid kernels.  Both are bit-exact against the oracle."""
-    n = rays_o.shape[0]
-    dev = rays_o.device
-    rx, ry, rz = (int(s) for s in binary.shape)
-    counts = torch.empty(n, dtype=torch.int32, device=dev)
-    packed = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
-    bricks = grid_bricks(binary) if method == "bricks" else None
-    with torch.cuda.device(dev):
-        s = stream_ptr()
-        if bricks is None:
-            grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
-            with _timed("ray_march_count", n):
-                check(lib.nsr_ray_march_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(grid_u8),
-                                              rx, ry, rz, int(contraction), float(step), float(cone_angle), ptr(counts),
-                                              n, s), "nsr_ray_march_count")
-            cap, scratch = 0, None
-        else:
-            cap = 0
-            if roi_host is not None and int(contraction) == 0:
-                cap = int(lib.nsr_ray_march_capacity((ctypes.c_float * 6)(*[float(v) for v in roi_host]), float(step)))
-            scratch = torch.empty(n * cap * 2, dtype=F32, device=dev) if cap > 0 else None
-            with _timed("ray_march_count", n):
-                check(lib.nsr_ray_march_bricks_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
-                                                     ptr(bricks), rx, ry, rz, int(contraction), float(step),
-                                                     float(cone_angle), ptr(counts), ptr(scratch), cap, n, s),
-                      "nsr_ray_march_bricks_count")
-        check(lib.nsr_pack_from_counts(ptr(counts), ptr(packed), ptr(total), n, s), "nsr_pack_from_counts")
-        m = int(total.item())  # the marcher's one intrinsic host sync
-        ray_indices = torch.empty(m, dtype=torch.int64, device=dev)
-        t_starts = torch.empty((m, 1), dtype=F32, device=dev)
-        t_ends = torch.empty((m, 1), dtype=F32, device=dev)
-        if m > 0:
-            with _timed("ray_march_write", n):
-                if bricks is None:
-                    check(lib.nsr_ray_march_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
-                                                  ptr(grid_u8), rx, ry, rz, int(contraction), float(step),
-                                                  float(cone_angle), ptr(packed), ptr(ray_indices), ptr(t_starts),
-                                                  ptr(t_ends), n, s), "nsr_ray_march_write")
-                else:
-                    check(lib.nsr_ray_march_bricks_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
-                                                         ptr(bricks), rx, ry, rz, int(contraction), float(step),
-                                                         float(cone_angle), ptr(packed), ptr(scratch), cap,
-                                                         ptr(ray_indices), ptr(t_starts), ptr(t_ends), n, s),
-                          "nsr_ray_march_bricks_write")
-    return packed, ray_indices, t_starts, t_ends
+    return ray_march_finish(ray_march_begin(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone_angle,
+                                            roi_host=roi_host, method=method))
 
 
 def pack_info(ray_indices, n_rays):

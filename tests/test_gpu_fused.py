@@ -94,3 +94,25 @@ def test_fused_trainer_reduces_loss():
         tr.train_step()
     last = [float(tr.train_step()["loss"]) for _ in range(5)]
     assert sum(last) / 5 < 0.5 * sum(first) / 5, (first, last)
+
+
+def test_pipelined_marching_matches_in_order_marching():
+    """side-stream marching of step k+1 under step k must not change the computation (same RNG order by design)"""
+    import nsr
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
+    hist = []
+    for pipeline in (False, True):
+        torch.manual_seed(0)
+        cfg = nsr.configs.get("nerf-blender")
+        model = nsr.NeRFModel(cfg).cuda().train()
+        tr = Trainer(model, data, cfg, fused=True, seed=7)
+        tr.pipeline_march = pipeline
+        out = [tr.train_step() for _ in range(40)]
+        hist.append(([float(o["loss"]) for o in out], [o["n_rays"] for o in out], [o["n_samples"] for o in out]))
+    # identical at first; LDS-atomic summation order then perturbs the weights in the last bits, which the dynamic ray
+    # controller amplifies by a ray or two -- so: exact early, statistically equal later
+    assert hist[0][1][:10] == hist[1][1][:10] and hist[0][2][:10] == hist[1][2][:10]
+    assert all(abs(a - b) <= 0.02 * a + 2 for a, b in zip(hist[0][1], hist[1][1]))
+    assert all(abs(a - b) < 0.25 * max(a, b) + 1e-3 for a, b in zip(hist[0][0], hist[1][0]))  # chaotic but same regime
