@@ -314,6 +314,48 @@ int nsr_prepare_train_rays(const float *images, const float *masks, const float 
                            float *rays_d, float *rgb, float *fg, float *t_min, float *t_max, uint32_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Native orchestration of the fused NeRF training step (csrc/step.hip): one C call per PHASE issues all of its
+ * launches back to back (from Python the main queue idles ~40 % of the step on interpreter/allocator overhead).
+ * The caller sizes ONE workspace per phase with the *_layout() functions (host-only) and reads results at the
+ * returned byte offsets.  Reference: models/nerf.py:61-127 + systems/nerf.py:97.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct NsrNerfStepDesc {
+    NsrGridDesc grid;
+    NsrMlpDesc mlp_density; /* encoding -> 16 features (column 0 = density logit) */
+    NsrMlpDesc mlp_color;   /* [16 features | 16 SH] -> rgb (sigmoid) */
+    float radius;           /* scene_aabb = [-radius, radius]^3 */
+    int contraction;        /* NSR_CONTRACT_AABB */
+    float density_bias;     /* density = exp(logit + bias), models/geometry.py:127 */
+    float early_stop_eps;   /* nerfacc ray_marching default 1e-4 */
+    float grad_scale;       /* fp16 backward-chain scale inside the MLP kernels (128) */
+    float loss_scale;       /* multiplies dloss/dcomp_rgb (1) */
+} NsrNerfStepDesc;
+
+typedef struct NsrNerfPruneLayout { uint64_t x01, enc, out1, acts1, total_bytes; } NsrNerfPruneLayout;
+typedef struct NsrNerfMainLayout {
+    uint64_t ray_indices, t_starts, t_ends, weights, comp_rgb, opacity, depth, loss_acc; /* results the host reads */
+    uint64_t trans, x01, dirs, enc, out1, acts1, tex_in, out2, acts2, g_comp, d_rgb, d_logit, d_tex, d_enc, partials,
+        grid_ws;                                                                           /* internals */
+    uint64_t total_bytes;
+} NsrNerfMainLayout;
+
+int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marched, NsrNerfPruneLayout *out);
+/* sigma pass over all marched samples -> kept_counts[n_rays], packed_kept[n_rays,2], total_kept[1] (device) */
+int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                        const float *t_starts, const float *t_ends, const int32_t *packed_info, const nsr_half *table,
+                        const nsr_half *w_density, void *workspace, int32_t *kept_counts, int32_t *packed_kept,
+                        int32_t *total_kept, uint32_t n_marched, uint32_t n_rays, void *stream);
+int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, uint32_t n_rays, NsrNerfMainLayout *out);
+/* forward + loss (+ backward when compute_grads): gradients are ADDED to grad_density_mlp / grad_color_mlp and
+ * OVERWRITE grad_table; t_starts/t_ends/packed_marched describe the marched samples, packed_kept the kept ones */
+int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                       const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                       const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
+                       const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp, float *grad_table,
+                       float *grad_color_mlp, void *workspace, uint32_t n_kept, uint32_t n_rays, int compute_grads,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:
  * AdamW lr 0.01 betas (0.9,0.99) eps 1e-15, systems/utils.py:314-325) that also refreshes the fp16
  * shadow the kernels read and zeroes the gradient.

@@ -1,0 +1,176 @@
+// Native orchestration of the fused NeRF training step (host code only: no kernels here).
+//
+// Measured on MI355X (profiles/r01_c_timeline.csv): with every launch issued from Python the main queue idles ~40 %
+// of the step -- ~10-25 us of interpreter + ctypes + allocator work per launch against kernels that take 3-20 us.
+// So each PHASE of the step is one C call that carves its buffers out of one caller-provided workspace and issues
+// all of its launches back to back on the caller's stream:
+//
+//   nsr_nerf_prune_pass : positions -> hash encode -> density MLP -> visibility prefix -> packed_info of the kept
+//                         samples            (= the sigma_fn pass inside ray_marching, reference models/nerf.py:65-93)
+//   nsr_nerf_main_pass  : kept rows copied (no re-encode) -> texture input -> colour MLP -> composite -> loss ->
+//                         composite backward -> colour-MLP backward -> density-MLP backward -> table backward
+//                                             (= models/nerf.py:95-109 + systems/nerf.py:97 + loss.backward())
+//
+// The data-dependent sizes (M marched, S kept samples) stay on the host side of the call: the caller reads them back
+// (the step's two syncs), sizes the workspace with nsr_nerf_*_layout() and passes it in.  Nothing is allocated here.
+#include <string.h>
+
+#include "nsr_common.h"
+
+namespace {
+
+inline uint64_t align_up(uint64_t v) { return (v + 255ull) & ~255ull; }
+
+struct Carver {
+    uint64_t off = 0;
+    uint64_t take(uint64_t bytes)
+    {
+        const uint64_t o = off;
+        off = align_up(off + bytes);
+        return o;
+    }
+};
+
+}  // namespace
+
+#define NSR_TRY(expr)            \
+    do {                         \
+        const int rc_ = (expr);  \
+        if (rc_ != NSR_OK) return rc_; \
+    } while (0)
+
+extern "C" int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marched, NsrNerfPruneLayout *out)
+{
+    NSR_REQUIRE(d && out, "nsr_nerf_prune_layout: NULL pointer");
+    const uint64_t M = n_marched, C = (uint64_t)d->grid.n_levels * d->grid.n_features;
+    Carver c;
+    out->x01 = c.take(M * 3 * 4);
+    out->enc = c.take(M * C * 2);
+    out->out1 = c.take(M * 16 * 2);
+    out->acts1 = c.take(M * 64 * 2 * d->mlp_density.n_hidden);
+    out->total_bytes = c.off;
+    return NSR_OK;
+}
+
+extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
+                                   const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                   const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
+                                   void *workspace, int32_t *kept_counts, int32_t *packed_kept, int32_t *total_kept,
+                                   uint32_t n_marched, uint32_t n_rays, void *stream)
+{
+    NSR_REQUIRE(d && workspace && kept_counts && packed_kept && total_kept, "nsr_nerf_prune_pass: NULL pointer");
+    NsrNerfPruneLayout L;
+    NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &L));
+    char *ws = (char *)workspace;
+    float *x01 = (float *)(ws + L.x01);
+    nsr_half *enc = (nsr_half *)(ws + L.enc), *out1 = (nsr_half *)(ws + L.out1), *acts1 = (nsr_half *)(ws + L.acts1);
+    const uint32_t C = d->grid.n_levels * d->grid.n_features;
+    NSR_TRY(nsr_sample_positions_unit(rays_o, rays_d, ray_indices, t_starts, t_ends, d->radius, d->contraction, x01,
+                                      nullptr, n_marched, stream));
+    NSR_TRY(nsr_hashgrid_forward(x01, table, enc, n_marched, C, d->grid.n_levels, &d->grid, stream));
+    NSR_TRY(nsr_mlp_forward(enc, 0, C, w_density, out1, acts1, n_marched, &d->mlp_density, stream));
+    NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
+                                  kept_counts, n_rays, stream));
+    NSR_TRY(nsr_pack_from_counts(kept_counts, packed_kept, total_kept, n_rays, stream));
+    return NSR_OK;
+}
+
+extern "C" int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, uint32_t n_rays, NsrNerfMainLayout *out)
+{
+    NSR_REQUIRE(d && out, "nsr_nerf_main_layout: NULL pointer");
+    const uint64_t S = n_kept, R = n_rays, C = (uint64_t)d->grid.n_levels * d->grid.n_features;
+    Carver c;
+    out->ray_indices = c.take(S * 8);
+    out->t_starts = c.take(S * 4);
+    out->t_ends = c.take(S * 4);
+    out->weights = c.take(S * 4);
+    out->comp_rgb = c.take(R * 3 * 4);
+    out->opacity = c.take(R * 4);
+    out->depth = c.take(R * 4);
+    out->loss_acc = c.take(2 * 4);
+    out->trans = c.take(S * 4);
+    out->x01 = c.take(S * 3 * 4);
+    out->dirs = c.take(S * 3 * 4);
+    out->enc = c.take(S * C * 2);
+    out->out1 = c.take(S * 16 * 2);
+    out->acts1 = c.take(S * 64 * 2 * d->mlp_density.n_hidden);
+    out->tex_in = c.take(S * 32 * 2);
+    out->out2 = c.take(S * 16 * 2);
+    out->acts2 = c.take(S * 64 * 2 * d->mlp_color.n_hidden);
+    out->g_comp = c.take(R * 3 * 4);
+    out->d_rgb = c.take(S * 3 * 4);
+    out->d_logit = c.take(S * 4);
+    out->d_tex = c.take(S * 32 * 4);
+    out->d_enc = c.take(S * C * 4);
+    out->partials = c.take(4 * (nsr_mlp_backward_workspace_floats(&d->mlp_color, n_kept) +
+                                nsr_mlp_backward_workspace_floats(&d->mlp_density, n_kept)));
+    out->grid_ws = c.take(4 * nsr_hashgrid_backward_params_workspace_floats(&d->grid, 0));  // slabs only (level-major dy)
+    out->total_bytes = c.off;
+    return NSR_OK;
+}
+
+extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                                  const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                                  const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
+                                  const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
+                                  float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
+                                  uint32_t n_rays, int compute_grads, void *stream)
+{
+    NSR_REQUIRE(d && prune_workspace && workspace && packed_marched && packed_kept, "nsr_nerf_main_pass: NULL pointer");
+    NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
+                "[16 features | 16 SH] (reference models/texture.py:26 with feature_dim 16)");
+    NsrNerfPruneLayout P;
+    NsrNerfMainLayout L;
+    NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &P));
+    NSR_TRY(nsr_nerf_main_layout(d, n_kept, n_rays, &L));
+    const char *pw = (const char *)prune_workspace;
+    char *ws = (char *)workspace;
+    const uint32_t C = d->grid.n_levels * d->grid.n_features, S = n_kept;
+    hipStream_t st = (hipStream_t)stream;
+    float *acc = (float *)(ws + L.loss_acc);
+    if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) {
+        nsr_set_error("nsr_nerf_main_pass: hipMemsetAsync failed");
+        return NSR_ERR_LAUNCH;
+    }
+    nsr_half *enc = (nsr_half *)(ws + L.enc), *out1 = (nsr_half *)(ws + L.out1), *acts1 = (nsr_half *)(ws + L.acts1);
+    nsr_half *tex_in = (nsr_half *)(ws + L.tex_in), *out2 = (nsr_half *)(ws + L.out2), *acts2 = (nsr_half *)(ws + L.acts2);
+    float *x01 = (float *)(ws + L.x01), *dirs = (float *)(ws + L.dirs);
+    float *t0 = (float *)(ws + L.t_starts), *t1 = (float *)(ws + L.t_ends);
+    float *weights = (float *)(ws + L.weights), *trans = (float *)(ws + L.trans);
+    float *comp_rgb = (float *)(ws + L.comp_rgb), *opacity = (float *)(ws + L.opacity), *depth = (float *)(ws + L.depth);
+
+    // kept rows of everything the sigma pass computed (a per-ray memcpy; nothing is re-encoded)
+    const uint32_t nh1 = d->mlp_density.n_hidden;
+    const void *src[8] = {t_starts, t_ends, pw + P.x01, pw + P.enc, pw + P.out1, pw + P.acts1, nullptr, nullptr};
+    void *dst[8] = {t0, t1, x01, enc, out1, acts1, nullptr, nullptr};
+    uint32_t rb[8] = {4, 4, 12, C * 2, 32, 128, 0, 0};
+    uint32_t na = 6;
+    for (uint32_t h = 1; h < nh1 && na < 8; ++h, ++na) {  // further hidden layers of the density MLP
+        src[na] = pw + P.acts1 + (uint64_t)h * n_marched * 128;
+        dst[na] = (char *)acts1 + (uint64_t)h * S * 128;
+        rb[na] = 128;
+    }
+    NSR_TRY(nsr_copy_ray_prefix_rows(packed_marched, packed_kept, na, src, dst, rb, rays_d, dirs,
+                                     (int64_t *)(ws + L.ray_indices), n_rays, stream));
+    NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, stream));
+    NSR_TRY(nsr_mlp_forward(tex_in, 0, 32, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color, stream));
+    NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
+                                  comp_rgb, opacity, depth, n_rays, stream));
+    NSR_TRY(nsr_smooth_l1_valid(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
+    if (!compute_grads || S == 0) return NSR_OK;
+    NSR_REQUIRE(grad_density_mlp && grad_table && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
+    float *g_comp = (float *)(ws + L.g_comp), *d_rgb = (float *)(ws + L.d_rgb), *d_logit = (float *)(ws + L.d_logit);
+    float *d_tex = (float *)(ws + L.d_tex), *d_enc = (float *)(ws + L.d_enc);
+    float *part2 = (float *)(ws + L.partials);
+    float *part1 = part2 + nsr_mlp_backward_workspace_floats(&d->mlp_color, S);
+    NSR_TRY(nsr_smooth_l1_valid_backward(comp_rgb, opacity, gt_rgb, acc, d->loss_scale, g_comp, n_rays, stream));
+    NSR_TRY(nsr_composite_backward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
+                                   g_comp, nullptr, nullptr, d_rgb, d_logit, n_rays, stream));
+    NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, acts2, w_color, grad_color_mlp, d_tex, 32, 0,
+                                part2, S, d->grad_scale, &d->mlp_color, stream));
+    NSR_TRY(nsr_mlp_backward_ex(d_tex, 1, 32, d_logit, out1, enc, 0, C, acts1, w_density, grad_density_mlp, d_enc, C,
+                                d->grid.n_features, part1, S, d->grad_scale, &d->mlp_density, stream));
+    NSR_TRY(nsr_hashgrid_backward_params_owner(x01, d_enc, 2, 0, grad_table, (float *)(ws + L.grid_ws), S,
+                                               d->grid.n_levels, 1.0f, 0, &d->grid, stream));
+    return NSR_OK;
+}

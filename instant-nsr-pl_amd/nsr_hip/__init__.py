@@ -42,8 +42,26 @@ class NsrMlpDesc(ctypes.Structure):
     ]
 
 
+class NsrNerfStepDesc(ctypes.Structure):
+    _fields_ = [("grid", NsrGridDesc), ("mlp_density", NsrMlpDesc), ("mlp_color", NsrMlpDesc),
+                ("radius", ctypes.c_float), ("contraction", ctypes.c_int), ("density_bias", ctypes.c_float),
+                ("early_stop_eps", ctypes.c_float), ("grad_scale", ctypes.c_float), ("loss_scale", ctypes.c_float)]
+
+
+class NsrNerfPruneLayout(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint64) for k in ("x01", "enc", "out1", "acts1", "total_bytes")]
+
+
+class NsrNerfMainLayout(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint64) for k in (
+        "ray_indices", "t_starts", "t_ends", "weights", "comp_rgb", "opacity", "depth", "loss_acc", "trans", "x01",
+        "dirs", "enc", "out1", "acts1", "tex_in", "out2", "acts2", "g_comp", "d_rgb", "d_logit", "d_tex", "d_enc",
+        "partials", "grid_ws", "total_bytes")]
+
+
 _P, _I, _U, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_uint64
 _GD, _MD = ctypes.POINTER(NsrGridDesc), ctypes.POINTER(NsrMlpDesc)
+_SD = ctypes.POINTER(NsrNerfStepDesc)
 
 # name -> argtypes  (restype is int unless listed in _RESTYPES); mirrors include/nsr_hip.h one to one
 SIGNATURES = {
@@ -97,6 +115,10 @@ SIGNATURES = {
     "nsr_density_activation_forward": [_P, _U, _U, _F, _P, _P, _U, _P],
     "nsr_neus_alpha_forward": [_P, _P, _P, _P, _P, _F, _P, _U, _P],
     "nsr_neus_alpha_backward": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _U, _P],
+    "nsr_nerf_prune_layout": [_SD, _U, ctypes.POINTER(NsrNerfPruneLayout)],
+    "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P],
+    "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
+    "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P],
     "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,

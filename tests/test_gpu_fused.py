@@ -46,9 +46,18 @@ def test_fused_step_matches_modular_autograd():
     g1 = model.geometry.encoding_with_network.params.grad.clone()
     g2 = model.texture.network.params.grad.clone()
     model.zero_grad(set_to_none=True)
-    # fused path
-    step = FusedNeRFStep(model)
+    # fused path, Python-issued launches, then the native (one C call per phase) orchestration: same numbers
+    step = FusedNeRFStep(model, native=False)
+    res_py = step.forward_backward(rays, gt, bg)
+    f1_py = model.geometry.encoding_with_network.params.grad.clone()
+    f2_py = model.texture.network.params.grad.clone()
+    model.zero_grad(set_to_none=True)
+    step = FusedNeRFStep(model, native=True)
     res = step.forward_backward(rays, gt, bg)
+    for k in ("comp_rgb", "opacity", "depth", "weights", "ray_indices", "t_starts", "t_ends"):
+        assert torch.equal(res[k], res_py[k]), k
+    assert (model.geometry.encoding_with_network.params.grad - f1_py).norm() / f1_py.norm() < 1e-5
+    assert (model.texture.network.params.grad - f2_py).norm() / f2_py.norm() < 1e-5
     assert res["num_samples"] == int(out["num_samples"])
     assert torch.equal(res["ray_indices"], out["ray_indices"])
     assert torch.allclose(res["comp_rgb"], out["comp_rgb"], rtol=1e-4, atol=2e-5)
@@ -116,3 +125,26 @@ def test_pipelined_marching_matches_in_order_marching():
     assert hist[0][1][:10] == hist[1][1][:10] and hist[0][2][:10] == hist[1][2][:10]
     assert all(abs(a - b) <= 0.02 * a + 2 for a, b in zip(hist[0][1], hist[1][1]))
     assert all(abs(a - b) < 0.25 * max(a, b) + 1e-3 for a, b in zip(hist[0][0], hist[1][0]))  # chaotic but same regime
+
+
+def test_prepare_train_rays_matches_separate_ops():
+    """the one-launch ray preparation == pixel gather + get_rays + slab test + jitter done with separate ops"""
+    import nsr
+    from nsr.scene import SyntheticBlender, get_rays
+    from nsr.fused import prepare_train_rays
+    from nsr_hip import ops
+    data = SyntheticBlender(n_images=3, w=64, h=48, device="cuda", seed=0)
+    model = nsr.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(data, 1000, gen, model)
+    gen.manual_seed(5)
+    u = torch.rand((5, 1000), device="cuda", generator=gen)
+    index, px, py = (u[0] * 3).long().clamp(max=2), (u[1] * 64).long().clamp(max=63), (u[2] * 48).long().clamp(max=47)
+    o_ref, d_ref = get_rays(data.directions[py, px], data.all_c2w[index])
+    d_ref = torch.nn.functional.normalize(d_ref, p=2, dim=-1)
+    assert torch.allclose(ro, o_ref) and torch.allclose(rd, d_ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(rays[:, :3], ro) and torch.equal(rays[:, 3:], rd) and torch.equal(bg, u[4, :3])
+    c, f = data.all_images[index, py, px], data.all_fg_masks[index, py, px]
+    assert torch.allclose(rgb, c * f[:, None] + bg * (1 - f[:, None]), atol=1e-6) and torch.equal(fg, f)
+    a, b = ops.ray_aabb_intersect(ro.contiguous(), rd.contiguous(), model.scene_aabb)  # oracle-checked kernel
+    assert torch.equal(t_max, b) and torch.equal(t_min, a + u[3] * model.render_step_size)
