@@ -339,6 +339,17 @@ typedef struct NsrNerfMainLayout {
     uint64_t total_bytes;
 } NsrNerfMainLayout;
 
+/* opt-in HIP-event timing of the heavy launches inside the two passes (events on the launch stream; zero cost when
+ * off).  collect(tag) synchronises on the recorded events and sums them; collect(-1) resets. */
+#define NSR_PROF_GRID_FORWARD 0
+#define NSR_PROF_GRID_BACKWARD 1
+#define NSR_PROF_MLP_FORWARD_DENSITY 2
+#define NSR_PROF_MLP_FORWARD_COLOR 3
+#define NSR_PROF_MLP_BACKWARD_COLOR 4
+#define NSR_PROF_MLP_BACKWARD_DENSITY 5
+void nsr_profile_enable(int on);
+int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches, uint64_t *units);
+
 int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marched, NsrNerfPruneLayout *out);
 /* sigma pass over all marched samples -> kept_counts[n_rays], packed_kept[n_rays,2], total_kept[1] (device) */
 int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d, const int64_t *ray_indices,

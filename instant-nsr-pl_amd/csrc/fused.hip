@@ -135,7 +135,13 @@ k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__
         const uint32_t *s = rc.a[q].src + (uint64_t)src * rd;
         uint32_t *d = rc.a[q].dst + (uint64_t)dst * rd;
         const uint32_t nd = cnt * rd;
-        for (uint32_t w = lane; w < nd; w += 64) d[w] = s[w];
+        if ((rd & 3u) == 0) {  // rows are multiples of 16 B (and the bases 256-B aligned): 16-B copies, 1 KiB per wave-instr
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+            uint4 *d4 = reinterpret_cast<uint4 *>(d);
+            for (uint32_t w = lane; w < (nd >> 2); w += 64) d4[w] = s4[w];
+        } else {
+            for (uint32_t w = lane; w < nd; w += 64) d[w] = s[w];
+        }
     }
     if (dirs_out) {
         const float d0 = rays_d[3ull * r], d1 = rays_d[3ull * r + 1], d2 = rays_d[3ull * r + 2];

@@ -190,6 +190,8 @@ k_grid_backward_params(const float *__restrict__ x, const void *__restrict__ dy,
         w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
         float *gp = grad_table + (uint64_t)(g.offset + e) * F;
 #pragma unroll
+        // (measured: workgroup-scope atomics compile to the same global_atomic_add_f32 and run at the same 22 G/s --
+        //  the memory mapping, not the scope bits, sends them to the memory side; there is no "L2-local" shortcut)
         for (int f = 0; f < F; ++f) unsafeAtomicAdd(gp + f, w * g_out[f]);
     }
 }

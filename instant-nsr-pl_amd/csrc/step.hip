@@ -15,6 +15,8 @@
 // (the step's two syncs), sizes the workspace with nsr_nerf_*_layout() and passes it in.  Nothing is allocated here.
 #include <string.h>
 
+#include <vector>
+
 #include "nsr_common.h"
 
 namespace {
@@ -32,6 +34,61 @@ struct Carver {
 };
 
 }  // namespace
+
+// ---- opt-in HIP-event timing of the heavy launches (bench.py's roofline leg) --------------------------------------
+// Events are recorded on the stream the kernels are launched on; disabled (zero cost) unless nsr_profile_enable(1).
+namespace {
+struct ProfRec { int tag; uint32_t units; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    bool on;
+    ProfRec r;
+    hipStream_t st;
+    ProfScope(int tag, uint32_t units, void *stream) : on(g_prof_on), st((hipStream_t)stream)
+    {
+        if (!on) return;
+        r.tag = tag;
+        r.units = units;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        g_prof.push_back(r);
+    }
+};
+}  // namespace
+
+extern "C" void nsr_profile_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches, uint64_t *units)
+{
+    NSR_REQUIRE(total_ms && launches && units, "nsr_profile_collect: NULL pointer");
+    *total_ms = 0.0;
+    *launches = 0;
+    *units = 0;
+    if (tag < 0) {  // reset
+        for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        g_prof.clear();
+        return NSR_OK;
+    }
+    for (auto &r : g_prof) {
+        if (r.tag != tag) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            *total_ms += ms;
+            *launches += 1;
+            *units += r.units;
+        }
+    }
+    return NSR_OK;
+}
 
 #define NSR_TRY(expr)            \
     do {                         \
@@ -67,8 +124,14 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
     const uint32_t C = d->grid.n_levels * d->grid.n_features;
     NSR_TRY(nsr_sample_positions_unit(rays_o, rays_d, ray_indices, t_starts, t_ends, d->radius, d->contraction, x01,
                                       nullptr, n_marched, stream));
-    NSR_TRY(nsr_hashgrid_forward(x01, table, enc, n_marched, C, d->grid.n_levels, &d->grid, stream));
-    NSR_TRY(nsr_mlp_forward(enc, 0, C, w_density, out1, acts1, n_marched, &d->mlp_density, stream));
+    {
+        ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
+        NSR_TRY(nsr_hashgrid_forward(x01, table, enc, n_marched, C, d->grid.n_levels, &d->grid, stream));
+    }
+    {
+        ProfScope p(NSR_PROF_MLP_FORWARD_DENSITY, n_marched, stream);
+        NSR_TRY(nsr_mlp_forward(enc, 0, C, w_density, out1, acts1, n_marched, &d->mlp_density, stream));
+    }
     NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
                                   kept_counts, n_rays, stream));
     NSR_TRY(nsr_pack_from_counts(kept_counts, packed_kept, total_kept, n_rays, stream));
@@ -153,7 +216,10 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     NSR_TRY(nsr_copy_ray_prefix_rows(packed_marched, packed_kept, na, src, dst, rb, rays_d, dirs,
                                      (int64_t *)(ws + L.ray_indices), n_rays, stream));
     NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, stream));
-    NSR_TRY(nsr_mlp_forward(tex_in, 0, 32, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color, stream));
+    {
+        ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
+        NSR_TRY(nsr_mlp_forward(tex_in, 0, 32, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color, stream));
+    }
     NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                   comp_rgb, opacity, depth, n_rays, stream));
     NSR_TRY(nsr_smooth_l1_valid(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
@@ -166,11 +232,20 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     NSR_TRY(nsr_smooth_l1_valid_backward(comp_rgb, opacity, gt_rgb, acc, d->loss_scale, g_comp, n_rays, stream));
     NSR_TRY(nsr_composite_backward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                    g_comp, nullptr, nullptr, d_rgb, d_logit, n_rays, stream));
-    NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, acts2, w_color, grad_color_mlp, d_tex, 32, 0,
-                                part2, S, d->grad_scale, &d->mlp_color, stream));
-    NSR_TRY(nsr_mlp_backward_ex(d_tex, 1, 32, d_logit, out1, enc, 0, C, acts1, w_density, grad_density_mlp, d_enc, C,
-                                d->grid.n_features, part1, S, d->grad_scale, &d->mlp_density, stream));
-    NSR_TRY(nsr_hashgrid_backward_params_owner(x01, d_enc, 2, 0, grad_table, (float *)(ws + L.grid_ws), S,
-                                               d->grid.n_levels, 1.0f, 0, &d->grid, stream));
+    {
+        ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
+        NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, acts2, w_color, grad_color_mlp, d_tex, 32,
+                                    0, part2, S, d->grad_scale, &d->mlp_color, stream));
+    }
+    {
+        ProfScope p(NSR_PROF_MLP_BACKWARD_DENSITY, S, stream);
+        NSR_TRY(nsr_mlp_backward_ex(d_tex, 1, 32, d_logit, out1, enc, 0, C, acts1, w_density, grad_density_mlp, d_enc, C,
+                                    d->grid.n_features, part1, S, d->grad_scale, &d->mlp_density, stream));
+    }
+    {
+        ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
+        NSR_TRY(nsr_hashgrid_backward_params_owner(x01, d_enc, 2, 0, grad_table, (float *)(ws + L.grid_ws), S,
+                                                   d->grid.n_levels, 1.0f, 0, &d->grid, stream));
+    }
     return NSR_OK;
 }

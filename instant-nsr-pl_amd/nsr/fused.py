@@ -140,10 +140,7 @@ class FusedNeRFStep:
                     check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1),
                                                   ptr(packed), ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2),
                                                   ptr(total), M, n_rays, s), "nsr_nerf_prune_pass")
-                    host = _ops._pinned_int32()
-                    host.copy_(total, non_blocking=True)
-                    torch.cuda.current_stream().synchronize()  # second (and last) host sync of the step
-                    S = int(host[0])
+                    S = _ops.read_count_when_ready(total)  # second (and last) host sync of the step
                 else:
                     meta.zero_()
                     S = 0

@@ -119,11 +119,14 @@ SIGNATURES = {
     "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P],
     "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
     "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P],
+    "nsr_profile_enable": [_I],
+    "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
+                            ctypes.POINTER(ctypes.c_uint64)],
     "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,
-             "nsr_grid_bricks_words64": ctypes.c_uint64, "nsr_ray_march_capacity": ctypes.c_uint32}
+             "nsr_profile_enable": None, "nsr_grid_bricks_words64": ctypes.c_uint64, "nsr_ray_march_capacity": ctypes.c_uint32}
 
 
 class NsrError(RuntimeError):

@@ -19,9 +19,16 @@ F32, F16 = torch.float32, torch.float16
 _PROFILE = None
 
 
+_NATIVE_TAGS = {0: "hashgrid_forward", 1: "hashgrid_backward_params", 2: "mlp_forward_h1", 3: "mlp_forward_h2",
+                4: "mlp_backward_h2", 5: "mlp_backward_h1"}
+
+
 def profile_begin():
     global _PROFILE
     _PROFILE = {}
+    d, a, b = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    lib.nsr_profile_collect(-1, _byref(d), _byref(a), _byref(b))
+    lib.nsr_profile_enable(1)
 
 
 def profile_end():
@@ -29,7 +36,17 @@ def profile_end():
     global _PROFILE
     prof, _PROFILE = _PROFILE or {}, None
     torch.cuda.synchronize()
-    return {k: (sum(a.elapsed_time(b) for a, b, _ in v), len(v), sum(u for _, _, u in v)) for k, v in prof.items()}
+    lib.nsr_profile_enable(0)
+    out = {k: (sum(a.elapsed_time(b) for a, b, _ in v), len(v), sum(u for _, _, u in v)) for k, v in prof.items()}
+    for tag, name in _NATIVE_TAGS.items():  # launches issued by the native phase orchestration (csrc/step.hip)
+        d, n, u = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.nsr_profile_collect(tag, _byref(d), _byref(n), _byref(u)), "nsr_profile_collect")
+        if n.value:
+            key = name + ("" if name not in out else "")
+            t0, n0, u0 = out.get(key, (0.0, 0, 0))
+            out[key] = (t0 + d.value, n0 + n.value, u0 + u.value)
+    lib.nsr_profile_collect(-1, _byref(d), _byref(n), _byref(u))
+    return out
 
 
 class _timed:
@@ -347,6 +364,28 @@ def _pinned_int32():
     return _PINNED[_PINNED[-1]]
 
 
+def _spin_until_changed(host_word, sentinel, fallback_sync):
+    spins = 0
+    while int(host_word[0]) == sentinel:
+        spins += 1
+        if spins > 2000000:  # ~seconds: fall back to the blocking wait so errors surface
+            break
+    # the D2H blit may write the word BYTE-wise (a torn 0x800000DB was observed): the spin only tells us the copy has
+    # started; the (now nearly free) synchronize makes it complete before the value is read
+    fallback_sync()
+    return int(host_word[0])
+
+
+def read_count_when_ready(dev_word):
+    """device int32 -> host int with a low-latency wait: async copy into a pinned word pre-set to a sentinel, spin
+    until it starts changing, then finish with a stream synchronize.  A cold synchronize sleeps on an interrupt (tens of
+    microseconds to wake up) and the step has two such read-backs on its critical path."""
+    host = _pinned_int32()
+    host[0] = -0x7fffffff
+    host.copy_(dev_word, non_blocking=True)
+    return _spin_until_changed(host, -0x7fffffff, torch.cuda.current_stream().synchronize)
+
+
 class MarchHandle:
     """an in-flight marching pass (count + per-ray scratch rows); ``ray_march_finish`` turns it into packed samples"""
     __slots__ = ("args", "counts", "packed", "total", "total_host", "scratch", "cap", "bricks", "grid_u8", "event",
@@ -386,6 +425,7 @@ def ray_march_begin(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step
                                                      float(cone_angle), ptr(h.counts), ptr(h.scratch), h.cap, n, s),
                       "nsr_ray_march_bricks_count")
         check(lib.nsr_pack_from_counts(ptr(h.counts), ptr(h.packed), ptr(h.total), n, s), "nsr_pack_from_counts")
+        h.total_host[0] = -0x7fffffff
         h.total_host.copy_(h.total, non_blocking=True)
         h.stream = torch.cuda.current_stream()
         h.event = torch.cuda.Event()
@@ -398,8 +438,7 @@ def ray_march_finish(h):
     -> packed_info, ray_indices, t_starts, t_ends"""
     rays_o, rays_d, t_min, t_max, roi, (rx, ry, rz), contraction, step, cone_angle = h.args
     dev, n = rays_o.device, h.n
-    h.event.synchronize()  # the marcher's one intrinsic host sync
-    m = int(h.total_host[0])
+    m = _spin_until_changed(h.total_host, -0x7fffffff, h.event.synchronize)  # the marcher's one intrinsic host sync
     cur = torch.cuda.current_stream()
     if cur != h.stream:  # tensors born on the marching stream are consumed here
         cur.wait_event(h.event)
