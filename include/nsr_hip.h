@@ -64,6 +64,11 @@ int nsr_hashgrid_make_desc(NsrGridDesc *out, uint32_t n_levels, uint32_t n_featu
 int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                          uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
 
+/* same with the output optionally LEVEL-MAJOR ([L][n][F] halfs; y_stride ignored): every wavefront then stores 64*F
+ * consecutive halfs instead of 64 scattered F-half pieces (the fused path's layout; nsr_mlp_forward_ex reads it) */
+int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                            int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
+
 /* grad_table[n_entries*F] (fp32, accumulate) += scatter(dy).  dy_is_f32: 0 = half, 1 = float.
  * grad_scale multiplies dy on load (pass 1.0f). */
 int nsr_hashgrid_backward_params(const float *x, const void *dy, int dy_is_f32, uint32_t dy_stride,
@@ -125,6 +130,11 @@ typedef struct NsrMlpDesc {
 int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *weights, nsr_half *out,
                     nsr_half *acts, uint32_t n, const NsrMlpDesc *desc, void *stream);
 
+/* x_level_major_features = F > 0: x is the level-major fp16 encoding [n_in/F][n][F] (x_is_f32 must be 0) */
+int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride, uint32_t x_level_major_features,
+                       const nsr_half *weights, nsr_half *out, nsr_half *acts, uint32_t n, const NsrMlpDesc *desc,
+                       void *stream);
+
 /* dout: [n, dout_stride] half/float grads w.r.t. the (activated) outputs; out: forward outputs (needed
  * for the sigmoid derivative, may be NULL for NSR_ACT_NONE); x/acts as given to / saved by forward.
  * grad_weights (fp32, accumulate, same layout as weights, may be NULL).
@@ -142,7 +152,8 @@ int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, co
  * dx_level_major_features = F > 0, dx is written level-major [n_in/F][n][F] (what the owner-computes hash-grid
  * backward reads) and dx_stride is ignored. */
 int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
-                        const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *acts,
+                        const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                        uint32_t x_level_major_features, const nsr_half *acts,
                         const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                         uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
                         const NsrMlpDesc *desc, void *stream);
@@ -279,6 +290,12 @@ int nsr_copy_ray_prefixes(const int32_t *packed_old, const int32_t *packed_new, 
 int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
                              const void *const *src, void *const *dst, const uint32_t *row_bytes, const float *rays_d,
                              float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays, void *stream);
+/* ... with per-array plane counts for level-major arrays (planes[q] row-arrays spaced src/dst_plane_bytes[q] apart) */
+int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
+                                const void *const *src, void *const *dst, const uint32_t *row_bytes,
+                                const uint32_t *planes, const uint64_t *src_plane_bytes, const uint64_t *dst_plane_bytes,
+                                const float *rays_d, float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays,
+                                void *stream);
 /* tex_in[n,32] (half) = [mlp_out[:, :16] | SH4((dirs+1)/2)]   (texture.py:24-26) */
 int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in, uint32_t n,
                       void *stream);

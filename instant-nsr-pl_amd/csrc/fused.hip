@@ -117,7 +117,7 @@ k_copy_ray_prefixes(const int32_t *__restrict__ packed_old, const int32_t *__res
 // Row-wise variant: the kept prefix of a ray is ONE contiguous block in both the marched and the pruned layout, so
 // carrying per-sample rows (encoded features, MLP activations, MLP outputs, positions) over the pruning step is a
 // per-ray memcpy -- the main pass then reuses what the sigma pass already computed instead of re-encoding.
-struct RowCopy { const uint32_t *src; uint32_t *dst; uint32_t row_dwords; uint32_t pad; };
+struct RowCopy { const uint32_t *src; uint32_t *dst; uint32_t row_dwords; uint32_t planes; uint64_t src_plane, dst_plane; };
 struct RowCopies { RowCopy a[8]; uint32_t n; };
 
 __global__ void __launch_bounds__(R_BLOCK)
@@ -130,12 +130,13 @@ k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__
     const uint32_t src = (uint32_t)packed_old[2ull * r];
     const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
     if (cnt == 0) return;
-    for (uint32_t q = 0; q < rc.n; ++q) {
+    for (uint32_t q = 0; q < rc.n; ++q)
+      for (uint32_t pl = 0; pl < rc.a[q].planes; ++pl) {  // planes > 1: a level-major array = `planes` arrays of rows
         const uint32_t rd = rc.a[q].row_dwords;
-        const uint32_t *s = rc.a[q].src + (uint64_t)src * rd;
-        uint32_t *d = rc.a[q].dst + (uint64_t)dst * rd;
+        const uint32_t *s = rc.a[q].src + pl * rc.a[q].src_plane + (uint64_t)src * rd;
+        uint32_t *d = rc.a[q].dst + pl * rc.a[q].dst_plane + (uint64_t)dst * rd;
         const uint32_t nd = cnt * rd;
-        if ((rd & 3u) == 0) {  // rows are multiples of 16 B (and the bases 256-B aligned): 16-B copies, 1 KiB per wave-instr
+        if ((rd & 3u) == 0 && rc.a[q].planes == 1) {  // rows are multiples of 16 B (and the bases 256-B aligned): 16-B copies, 1 KiB per wave-instr
             const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
             uint4 *d4 = reinterpret_cast<uint4 *>(d);
             for (uint32_t w = lane; w < (nd >> 2); w += 64) d4[w] = s4[w];
@@ -543,10 +544,11 @@ extern "C" int nsr_gather_train_rays(const float *images, const float *masks, co
     return NSR_OK;
 }
 
-extern "C" int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
-                                        const void *const *src, void *const *dst, const uint32_t *row_bytes,
-                                        const float *rays_d, float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays,
-                                        void *stream)
+extern "C" int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
+                                           const void *const *src, void *const *dst, const uint32_t *row_bytes,
+                                           const uint32_t *planes, const uint64_t *src_plane_bytes,
+                                           const uint64_t *dst_plane_bytes, const float *rays_d, float *dirs_out,
+                                           int64_t *ray_indices_out, uint32_t n_rays, void *stream)
 {
     if (n_rays == 0) return NSR_OK;
     NSR_REQUIRE(packed_old && packed_new, "nsr_copy_ray_prefix_rows: NULL packed_info");
@@ -559,12 +561,23 @@ extern "C" int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t
         rc.a[q].src = (const uint32_t *)src[q];
         rc.a[q].dst = (uint32_t *)dst[q];
         rc.a[q].row_dwords = row_bytes[q] / 4;
-        rc.a[q].pad = 0;
+        rc.a[q].planes = planes ? planes[q] : 1;
+        rc.a[q].src_plane = planes ? src_plane_bytes[q] / 4 : 0;
+        rc.a[q].dst_plane = planes ? dst_plane_bytes[q] / 4 : 0;
     }
     hipLaunchKernelGGL(k_copy_ray_prefix_rows, RAY_GRID(n_rays), packed_old, packed_new, rc, rays_d, dirs_out,
                        ray_indices_out, n_rays);
     NSR_CHECK_LAUNCH("nsr_copy_ray_prefix_rows");
     return NSR_OK;
+}
+
+extern "C" int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
+                                        const void *const *src, void *const *dst, const uint32_t *row_bytes,
+                                        const float *rays_d, float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays,
+                                        void *stream)
+{
+    return nsr_copy_ray_prefix_rows_ex(packed_old, packed_new, n_arrays, src, dst, row_bytes, nullptr, nullptr, nullptr,
+                                       rays_d, dirs_out, ray_indices_out, n_rays, stream);
 }
 
 extern "C" int nsr_prepare_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,

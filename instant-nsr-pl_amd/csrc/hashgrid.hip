@@ -121,13 +121,16 @@ __device__ __forceinline__ bool map_block(uint32_t n_levels, uint32_t lpx, uint3
 template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
-               uint32_t y_stride, uint32_t mask_count, uint32_t lpx, const NsrGridDesc d)
+               uint32_t y_stride, uint32_t mask_count, uint32_t lpx, int level_major, const NsrGridDesc d)
 {
     uint32_t level, blk;
     if (!map_block(d.n_levels, lpx, level, blk)) return;
     const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
     if (i >= n) return;
-    __half *yo = y + (uint64_t)i * y_stride + level * F;
+    // row-major [n, y_stride] is what the tcnn API returns; level-major [L][n][F] is what the fused path uses: a wave
+    // then stores 64 x F consecutive halfs (measured: the row-major 4-B stores, issued level by level from different
+    // XCDs, cost 187 MB of fabric writes for a 19 MB output)
+    __half *yo = level_major ? y + ((uint64_t)level * n + i) * F : y + (uint64_t)i * y_stride + level * F;
     float acc[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -578,18 +581,30 @@ extern "C" int nsr_hashgrid_make_desc(NsrGridDesc *out, uint32_t n_levels, uint3
     return check_desc(out, "nsr_hashgrid_make_desc");
 }
 
+extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                                       int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
+                                       void *stream);
+
 extern "C" int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                                     uint32_t level_mask_count, const NsrGridDesc *desc, void *stream)
 {
+    return nsr_hashgrid_forward_ex(x, table, y, n, y_stride, 0, level_mask_count, desc, stream);
+}
+
+extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                                       int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
+                                       void *stream)
+{
     if (int rc = check_desc(desc, "nsr_hashgrid_forward")) return rc;
-    NSR_REQUIRE(y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward: y_stride too small");
+    NSR_REQUIRE(y_level_major || y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward: y_stride too small");
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(x && table && y, "nsr_hashgrid_forward: NULL pointer");
     const uint32_t lpx = (desc->n_levels + 7) / 8;
     const uint32_t grid = 8u * lpx * nsr_div_up(n, GRID_BLOCK);
     DISPATCH_F(desc->n_features,
                hipLaunchKernelGGL((k_grid_forward<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
-                                  (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, *desc));
+                                  (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
+                                  *desc));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward");
     return NSR_OK;
 }

@@ -92,13 +92,36 @@ __device__ __forceinline__ half8 pack_b(const f32x4 &lo, const f32x4 &hi)
 }
 
 // 8 consecutive input columns [c0, c0+8) of one sample row as fp16 (columns >= n_in are the constant 1)
+// element (sample s, column c) of a LEVEL-MAJOR fp16 input [n_in/F][n][F]  (the fused path's encoding layout)
+__device__ __forceinline__ uint64_t lm_off(uint32_t s, int c, uint32_t n, uint32_t f) { return ((uint64_t)(c / f) * n + s) * f + c % f; }
+
 __device__ __forceinline__ half8 load_x8(const void *__restrict__ x, bool x_f32, uint64_t row_off, int c0, int n_in,
-                                         int in_pad, bool valid)
+                                         int in_pad, bool valid, uint32_t s = 0, uint32_t n = 0, uint32_t lmf = 0)
 {
     half8 b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = (_Float16)0;
     if (!valid || c0 >= in_pad) return b;
+    if (lmf) {
+        const _Float16 *xh = reinterpret_cast<const _Float16 *>(x);
+        if (lmf == 2 && c0 + 8 <= n_in) {  // four coalesced 4-B loads, one per level plane
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(xh + ((uint64_t)(c0 / 2 + j) * n + s) * 2);
+                const __half2 hv = *reinterpret_cast<const __half2 *>(&v);
+                b[2 * j] = (_Float16)__low2float(hv);
+                b[2 * j + 1] = (_Float16)__high2float(hv);
+            }
+            return b;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            if (c < n_in) b[j] = xh[lm_off(s, c, n, lmf)];
+            else if (c < in_pad) b[j] = (_Float16)1;
+        }
+        return b;
+    }
     if (!x_f32 && c0 + 8 <= n_in && ((row_off + c0) & 7) == 0) {
         b = *reinterpret_cast<const half8 *>(reinterpret_cast<const __half *>(x) + row_off + c0);
         return b;
@@ -117,10 +140,20 @@ __device__ __forceinline__ half8 load_x8(const void *__restrict__ x, bool x_f32,
 
 // 4 consecutive columns (D layout) as fp32
 __device__ __forceinline__ f32x4 load_x4(const void *__restrict__ x, bool x_f32, uint64_t row_off, int c0, int n_in,
-                                         int in_pad, bool valid)
+                                         int in_pad, bool valid, uint32_t s = 0, uint32_t n = 0, uint32_t lmf = 0)
 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (!valid) return v;
+    if (lmf) {
+        const __half *xh = reinterpret_cast<const __half *>(x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = c0 + r;
+            if (c < n_in) v[r] = __half2float(xh[lm_off(s, c, n, lmf)]);
+            else if (c < in_pad) v[r] = 1.f;
+        }
+        return v;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = c0 + r;
@@ -152,7 +185,8 @@ __device__ __forceinline__ f32x4 load_h4(const __half *p)
 template <int KIN /* in_pad/16 */, int NH>
 __global__ void __launch_bounds__(MLP_BLOCK)
 k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __half *__restrict__ W_,
-              __half *__restrict__ out, __half *__restrict__ acts, uint32_t n, uint32_t n_in, int out_act)
+              __half *__restrict__ out, __half *__restrict__ acts, uint32_t n, uint32_t n_in, int out_act,
+              uint32_t x_lmf)
 {
     constexpr int IN_PAD = KIN * 16;
     constexpr int KC0 = (IN_PAD + 31) / 32;
@@ -191,7 +225,7 @@ k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __
         for (int ob = 0; ob < 4; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < KC0; ++kc) {
-            const half8 b = load_x8(x, x_f32 != 0, row, kc * 32 + 8 * g, (int)n_in, IN_PAD, valid);
+            const half8 b = load_x8(x, x_f32 != 0, row, kc * 32 + 8 * g, (int)n_in, IN_PAD, valid, s, n, x_lmf);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma32(a0[ob][kc], b, acc[ob]);
         }
@@ -258,7 +292,7 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
                const void *__restrict__ x, int x_f32, uint32_t x_stride, const __half *__restrict__ acts,
                const __half *__restrict__ W_, float *__restrict__ dx, uint32_t dx_stride, float *__restrict__ partials,
                uint32_t n, uint32_t n_in, uint32_t n_out, int out_act, float grad_scale, int need_dw,
-               const float *__restrict__ dout_extra_col0, uint32_t dx_lm_features)
+               const float *__restrict__ dout_extra_col0, uint32_t dx_lm_features, uint32_t x_lmf)
 {
     constexpr int IN_PAD = KIN * 16;
     constexpr int N_PARAMS = WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH + 16 * WIDTH;
@@ -403,7 +437,8 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
             } else {
 #pragma unroll
                 for (int ib = 0; ib < KIN; ++ib)
-                    inp[ib] = load_x4(x, x_f32 != 0, (uint64_t)s * x_stride, ib * 16 + 4 * g, (int)n_in, IN_PAD, valid);
+                    inp[ib] = load_x4(x, x_f32 != 0, (uint64_t)s * x_stride, ib * 16 + 4 * g, (int)n_in, IN_PAD, valid, s, n,
+                                      x_lmf);
             }
             if (need_dw) {
 #pragma unroll
@@ -566,13 +601,26 @@ uint32_t bwd_blocks(uint32_t n)
     default: { constexpr int KIN = 4, NH = 4; __VA_ARGS__; } break;                                      \
     }
 
+extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride, uint32_t x_level_major_features,
+                                  const nsr_half *weights, nsr_half *out, nsr_half *acts, uint32_t n,
+                                  const NsrMlpDesc *desc, void *stream);
+
 extern "C" int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *weights, nsr_half *out,
                                nsr_half *acts, uint32_t n, const NsrMlpDesc *desc, void *stream)
+{
+    return nsr_mlp_forward_ex(x, x_is_f32, x_stride, 0, weights, out, acts, n, desc, stream);
+}
+
+extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride, uint32_t x_level_major_features,
+                                  const nsr_half *weights, nsr_half *out, nsr_half *acts, uint32_t n,
+                                  const NsrMlpDesc *desc, void *stream)
 {
     if (int rc = check_mlp(desc, "nsr_mlp_forward")) return rc;
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(x && weights && out, "nsr_mlp_forward: NULL pointer");
-    NSR_REQUIRE(x_stride >= desc->n_in, "nsr_mlp_forward: x_stride < n_in");
+    NSR_REQUIRE(x_level_major_features || x_stride >= desc->n_in, "nsr_mlp_forward: x_stride < n_in");
+    NSR_REQUIRE(!x_level_major_features || (!x_is_f32 && desc->n_in % x_level_major_features == 0),
+                "nsr_mlp_forward: level-major input must be fp16 with n_in a multiple of the feature count");
     // the forward is latency-bound per tile (load -> MFMA chain -> store), so parallelism wins over weight reuse: one
     // 16-sample tile per wavefront until the chip is full (2048 blocks x 4 waves = 8 waves/SIMD), grid-stride beyond.
     // (measured at 8.8e4 samples: 8 tiles/wave 20 us -> 1 tile/wave)
@@ -582,7 +630,7 @@ extern "C" int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, c
     DISPATCH_MLP(desc->in_pad / 16, desc->n_hidden,
                  hipLaunchKernelGGL((k_mlp_forward<KIN, NH>), dim3(blocks), dim3(MLP_BLOCK), 0, (hipStream_t)stream, x,
                                     x_is_f32, x_stride, (const __half *)weights, (__half *)out, (__half *)acts, n,
-                                    desc->n_in, (int)desc->output_activation));
+                                    desc->n_in, (int)desc->output_activation, x_level_major_features));
     NSR_CHECK_LAUNCH("nsr_mlp_forward");
     return NSR_OK;
 }
@@ -595,7 +643,7 @@ extern "C" uint64_t nsr_mlp_backward_workspace_floats(const NsrMlpDesc *desc, ui
 
 extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
                                    const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
-                                   const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx,
+                                   uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx,
                                    uint32_t dx_stride, uint32_t dx_level_major_features, float *partials, uint32_t n,
                                    float grad_scale, const NsrMlpDesc *desc, void *stream)
 {
@@ -620,7 +668,7 @@ extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t d
                            dout_is_f32, dout_stride, (const __half *)out, x, x_is_f32, x_stride, (const __half *)acts,
                            (const __half *)weights, dx, dx_stride, partials, n, desc->n_in, desc->n_out,
                            (int)desc->output_activation, grad_scale, grad_weights ? 1 : 0, dout_extra_col0,
-                           dx_level_major_features);
+                           dx_level_major_features, x_level_major_features);
     });
     NSR_CHECK_LAUNCH("nsr_mlp_backward");
     if (grad_weights) {
@@ -636,6 +684,6 @@ extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout
                                 const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                                 float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream)
 {
-    return nsr_mlp_backward_ex(dout, dout_is_f32, dout_stride, nullptr, out, x, x_is_f32, x_stride, acts, weights,
+    return nsr_mlp_backward_ex(dout, dout_is_f32, dout_stride, nullptr, out, x, x_is_f32, x_stride, 0, acts, weights,
                                grad_weights, dx, dx_stride, 0, partials, n, grad_scale, desc, stream);
 }

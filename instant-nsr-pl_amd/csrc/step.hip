@@ -126,11 +126,12 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
                                       nullptr, n_marched, stream));
     {
         ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
-        NSR_TRY(nsr_hashgrid_forward(x01, table, enc, n_marched, C, d->grid.n_levels, &d->grid, stream));
+        NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, stream));
     }
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_DENSITY, n_marched, stream);
-        NSR_TRY(nsr_mlp_forward(enc, 0, C, w_density, out1, acts1, n_marched, &d->mlp_density, stream));
+        NSR_TRY(nsr_mlp_forward_ex(enc, 0, C, d->grid.n_features, w_density, out1, acts1, n_marched, &d->mlp_density,
+                                   stream));
     }
     NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
                                   kept_counts, n_rays, stream));
@@ -206,15 +207,21 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     const uint32_t nh1 = d->mlp_density.n_hidden;
     const void *src[8] = {t_starts, t_ends, pw + P.x01, pw + P.enc, pw + P.out1, pw + P.acts1, nullptr, nullptr};
     void *dst[8] = {t0, t1, x01, enc, out1, acts1, nullptr, nullptr};
-    uint32_t rb[8] = {4, 4, 12, C * 2, 32, 128, 0, 0};
+    // the encoding is level-major [L][n][F] (fp16): L planes of F*2-byte rows
+    const uint32_t F = d->grid.n_features, Lv = d->grid.n_levels;
+    uint32_t rb[8] = {4, 4, 12, F * 2, 32, 128, 0, 0};
+    uint32_t planes[8] = {1, 1, 1, Lv, 1, 1, 1, 1};
+    uint64_t sp[8] = {0, 0, 0, (uint64_t)n_marched * F * 2, 0, 0, 0, 0};
+    uint64_t dp[8] = {0, 0, 0, (uint64_t)S * F * 2, 0, 0, 0, 0};
     uint32_t na = 6;
     for (uint32_t h = 1; h < nh1 && na < 8; ++h, ++na) {  // further hidden layers of the density MLP
         src[na] = pw + P.acts1 + (uint64_t)h * n_marched * 128;
         dst[na] = (char *)acts1 + (uint64_t)h * S * 128;
         rb[na] = 128;
     }
-    NSR_TRY(nsr_copy_ray_prefix_rows(packed_marched, packed_kept, na, src, dst, rb, rays_d, dirs,
-                                     (int64_t *)(ws + L.ray_indices), n_rays, stream));
+    NSR_REQUIRE(F * 2 % 4 == 0, "nsr_nerf_main_pass: n_features_per_level must be even");
+    NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, dirs,
+                                        (int64_t *)(ws + L.ray_indices), n_rays, stream));
     NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, stream));
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
@@ -234,13 +241,14 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
                                    g_comp, nullptr, nullptr, d_rgb, d_logit, n_rays, stream));
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
-        NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, acts2, w_color, grad_color_mlp, d_tex, 32,
-                                    0, part2, S, d->grad_scale, &d->mlp_color, stream));
+        NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
+                                    32, 0, part2, S, d->grad_scale, &d->mlp_color, stream));
     }
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_DENSITY, S, stream);
-        NSR_TRY(nsr_mlp_backward_ex(d_tex, 1, 32, d_logit, out1, enc, 0, C, acts1, w_density, grad_density_mlp, d_enc, C,
-                                    d->grid.n_features, part1, S, d->grad_scale, &d->mlp_density, stream));
+        NSR_TRY(nsr_mlp_backward_ex(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
+                                    grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
+                                    &d->mlp_density, stream));
     }
     {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);

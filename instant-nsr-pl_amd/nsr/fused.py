@@ -249,7 +249,7 @@ class FusedNeRFStep:
         nws = lib.nsr_mlp_backward_workspace_floats(_byref(desc), n)
         partials = torch.empty(int(nws), dtype=F32, device=x.device)
         with _ops.timed(f"mlp_backward_h{desc.n_hidden}", n):
-            check(lib.nsr_mlp_backward_ex(ptr(dout), 1, dout_stride, ptr(extra), ptr(out), ptr(x), 0, x.stride(0),
+            check(lib.nsr_mlp_backward_ex(ptr(dout), 1, dout_stride, ptr(extra), ptr(out), ptr(x), 0, x.stride(0), 0,
                                           ptr(acts), ptr(w), ptr(grad_w), ptr(dx), desc.n_in, dx_lm_f, ptr(partials), n,
                                           self.grad_scale, _byref(desc), stream_ptr()), "nsr_mlp_backward_ex")
         return dx if dx_lm_f else dx.view(n, desc.n_in)

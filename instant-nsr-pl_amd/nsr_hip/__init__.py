@@ -69,6 +69,7 @@ SIGNATURES = {
     "nsr_abi_version": [],
     "nsr_hashgrid_make_desc": [_GD, _U, _U, _U, _U, _F],
     "nsr_hashgrid_forward": [_P, _P, _P, _U, _U, _U, _GD, _P],
+    "nsr_hashgrid_forward_ex": [_P, _P, _P, _U, _U, _I, _U, _GD, _P],
     "nsr_hashgrid_backward_params": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P],
     "nsr_hashgrid_backward_params_workspace_floats": [_GD, _U],
     "nsr_hashgrid_backward_params_owner": [_P, _P, _I, _U, _P, _P, _U, _U, _F, _I, _GD, _P],
@@ -76,13 +77,15 @@ SIGNATURES = {
     "nsr_hashgrid_backward_backward_input": [_P, _P, _P, _I, _U, _P, _P, _U, _P, _P, _U, _U, _GD, _P],
     "nsr_sh4_forward": [_P, _P, _U, _U, _P],
     "nsr_mlp_forward": [_P, _I, _U, _P, _P, _P, _U, _MD, _P],
+    "nsr_mlp_forward_ex": [_P, _I, _U, _U, _P, _P, _P, _U, _MD, _P],
     "nsr_mlp_backward_workspace_floats": [_MD, _U],
     "nsr_mlp_backward": [_P, _I, _U, _P, _P, _I, _U, _P, _P, _P, _P, _U, _P, _U, _F, _MD, _P],
-    "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P],
+    "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P],
     "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P],
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_copy_ray_prefixes": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_copy_ray_prefix_rows": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_copy_ray_prefix_rows_ex": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_texture_input": [_P, _U, _P, _P, _U, _P],
     "nsr_composite_forward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
