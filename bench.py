@@ -74,10 +74,18 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    # NSR_DIST_BACKEND=gloo NSR_FORCE_DEVICE0=1 lets two ranks share ONE GPU: a smoke test of the multi-rank code path on
+    # a 1-GPU box (the real runs use nccl = RCCL over xGMI, one rank per GPU)
+    backend = os.environ.get("NSR_DIST_BACKEND", "nccl")
+    if os.environ.get("NSR_FORCE_DEVICE0"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import nsr
     from nsr.scene import SyntheticBlender
