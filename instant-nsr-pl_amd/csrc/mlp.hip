@@ -93,6 +93,11 @@ __device__ __forceinline__ half8 pack_b(const f32x4 &lo, const f32x4 &hi)
 
 // 8 consecutive input columns [c0, c0+8) of one sample row as fp16 (columns >= n_in are the constant 1)
 // element (sample s, column c) of a LEVEL-MAJOR fp16 input [n_in/F][n][F]  (the fused path's encoding layout)
+// column-blocked layout of an [n, cols] matrix for the wgrad kernels: per 32-sample tile a [cols][32] block
+__device__ __forceinline__ uint64_t t32_off(uint32_t s, uint32_t col, uint32_t cols)
+{
+    return ((uint64_t)(s >> 5) * cols + col) * 32 + (s & 31);
+}
 __device__ __forceinline__ uint64_t lm_off(uint32_t s, int c, uint32_t n, uint32_t f) { return ((uint64_t)(c / f) * n + s) * f + c % f; }
 
 __device__ __forceinline__ half8 load_x8(const void *__restrict__ x, bool x_f32, uint64_t row_off, int c0, int n_in,
@@ -261,54 +266,42 @@ k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward (dgrad + wgrad)
+// backward = dgrad kernel + one wgrad kernel per weight matrix
+//
+// A single fused dgrad+wgrad kernel needed 252 VGPRs + accumulators (1 wave/SIMD, 171 blocks) and measured
+// 23 % issue / 35 % dependency stalls / 41 % memory waits (profiles/r01_pmc_mlp_backward.txt).  Split:
+//   k_mlp_dgrad : same register-resident transposed chain as the forward (W^T fragments staged through LDS), one
+//                 16-sample tile per wave, no accumulators -> many waves in flight.  Writes dX and, for the wgrad
+//                 kernels, the pre-activation gradients of every layer (fp16, [n,64] rows; [n,16] for the output).
+//   k_mlp_wgrad : dW[o][k] = sum_n G[n][o] A[n][k] as v_mfma_f32_16x16x32_f16 with the SAMPLE index on the MFMA k
+//                 axis: 32-sample tiles are loaded row-major (64 B per lane, coalesced), transposed through a per-wave
+//                 LDS tile (b16 scatter, b128 gather), accumulated in fp32 VGPRs over the wave's tiles, reduced over
+//                 the block with ds_add_f32 and written as one partial per block (summed by k_reduce_partials).
 // ------------------------------------------------------------------------------------------------
-constexpr int TROW = 20;  // halfs per row of the transposed [64][16] tile (40 B: conflict-free b16 scatter)
-
-// Order this wave's LDS writes before its LDS reads (the transposed tiles are wave-private).  Only the LDS counter is
-// drained: a workgroup-scope fence would also wait for every outstanding GLOBAL load/store (vmcnt(0)) six times per
-// tile -- measured ~12 us per tile, 4x the rest of the kernel.
 __device__ __forceinline__ void lds_wave_sync()
 {
+    // order this wave's LDS writes before its LDS reads (tiles are wave-private).  Only the LDS counter is drained:
+    // a workgroup-scope fence would also wait for every outstanding GLOBAL access (vmcnt(0)).
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
-// scatter a D-layout value set (lane (n,g): cols cb*16+4g+r) into the transposed tile T[col][n]
-__device__ __forceinline__ void lds_scatter(_Float16 *T, int cb, int g, int nl, const f32x4 &v)
-{
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T[(cb * 16 + 4 * g + r) * TROW + nl] = (_Float16)v[r];
-}
-// gather the wgrad fragment: lane (c = lane&15, g) <- T[cb*16 + c][4g .. 4g+3]
-__device__ __forceinline__ half4 lds_gather(const _Float16 *T, int cb, int g, int nl)
-{
-    return *reinterpret_cast<const half4 *>(T + (cb * 16 + nl) * TROW + 4 * g);
-}
-
 template <int KIN, int NH>
 __global__ void __launch_bounds__(MLP_BLOCK)
-k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, const __half *__restrict__ out,
-               const void *__restrict__ x, int x_f32, uint32_t x_stride, const __half *__restrict__ acts,
-               const __half *__restrict__ W_, float *__restrict__ dx, uint32_t dx_stride, float *__restrict__ partials,
-               uint32_t n, uint32_t n_in, uint32_t n_out, int out_act, float grad_scale, int need_dw,
-               const float *__restrict__ dout_extra_col0, uint32_t dx_lm_features, uint32_t x_lmf)
+k_mlp_dgrad(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, const float *__restrict__ dout_extra_col0,
+            const __half *__restrict__ out, const __half *__restrict__ acts, const __half *__restrict__ W_,
+            float *__restrict__ dx, uint32_t dx_stride, uint32_t dx_lm_features, __half *__restrict__ gpre,
+            __half *__restrict__ gout, uint32_t ldn, uint32_t n, uint32_t n_in, uint32_t n_out, int out_act,
+            float grad_scale)
 {
     constexpr int IN_PAD = KIN * 16;
     constexpr int N_PARAMS = WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH + 16 * WIDTH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *lds_dw = reinterpret_cast<float *>(smem);                                  // [N_PARAMS]
-    _Float16 *lds_t = reinterpret_cast<_Float16 *>(smem + sizeof(float) * N_PARAMS);  // per wave: 2 tiles
-    const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    _Float16 *TP = lds_t + wv * (2 * 64 * TROW);  // dY^T tile  [64][TROW]
-    _Float16 *TQ = TP + 64 * TROW;                // In^T tile  [64][TROW]
+    const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4;
     const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
     const uint32_t n_tiles = (n + 15) / 16;
-
-    // stage the whole weight set in LDS with coalesced 16-B loads (the dW area is free until the tile loop): the
-    // transposed dgrad fragments are 2-byte strided gathers, cheap from LDS, a ~100-load latency chain from L2
-    {
+    {   // weights -> LDS with coalesced 16-B loads: the transposed fragments below are 2-byte strided gathers
         const _Float16 *Wg = reinterpret_cast<const _Float16 *>(W_);
         _Float16 *Wl_ = reinterpret_cast<_Float16 *>(smem);
         for (int k = threadIdx.x * 8; k < N_PARAMS; k += MLP_BLOCK * 8)
@@ -316,10 +309,8 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
     }
     __syncthreads();
     const _Float16 *W = reinterpret_cast<const _Float16 *>(smem);
-
-    // ---- transposed weight fragments for dgrad ----
     const _Float16 *Wl = W + WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH;  // [16, 64]
-    half8 atl[4];  // dH^T(64 x n) = Wl^T (64 x 16) . dOut^T : K = 16 real (upper half of K=32 is zero)
+    half8 atl[4];  // dH^T (64 x n) = Wl^T (64 x 16) . dOut^T : K = 16 real (upper half of K = 32 is zero)
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib) atl[ib] = load_at_natural(Wl, WIDTH, ib * 16 + nl, g, 16);
     half8 ath[NH > 1 ? NH - 1 : 1][4][2];
@@ -338,33 +329,12 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) at0[ib][kc] = load_at_sigma(W, IN_PAD, ib * 16 + nl, kc, g);
     }
-    __syncthreads();  // everyone has its fragments: the area becomes the dW accumulator
-    if (need_dw) {
-        for (int k = threadIdx.x; k < N_PARAMS; k += MLP_BLOCK) lds_dw[k] = 0.f;
-    }
-    __syncthreads();
-
-    // ---- fp32 weight-gradient accumulators (D layout of dW blocks: lane (c,g): dW[ob*16+4g+r][kb*16+c]) ----
-    f32x4 dw0[4][KIN];
-    f32x4 dwh[NH > 1 ? NH - 1 : 1][4][4];
-    f32x4 dwl[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < KIN; ++b) dw0[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int h = 0; h < NH - 1; ++h)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) dwh[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dwl[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
     const float inv_scale = 1.f / grad_scale;
 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t s = tile * 16 + nl;
         const bool valid = s < n;
-        // ---- dOut (D layout: cols 4g+r), output-activation derivative, scale ----
+        // dOut (D layout: cols 4g+r), output-activation derivative, scale
         f32x4 d_o = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
 #pragma unroll
@@ -382,29 +352,13 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
                     d_o[r] = v * grad_scale;
                 }
             }
+            if (gout) {  // column-blocked, 16 columns
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gout[t32_off(s, 4 * g + r, 16)] = __float2half_rn(d_o[r]);
+            }
         }
-        // ---- last layer: wgrad dWl[o][k] += dOut[n][o] * act_{NH-1}[n][k] ; dgrad dH = Wl^T dOut ----
-        f32x4 hact[4];  // post-ReLU activation of the layer feeding the current matrix (D layout)
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-            hact[ib] = valid ? load_h4(acts + ((uint64_t)(NH - 1) * n + s) * WIDTH + ib * 16 + 4 * g)
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (need_dw) {
-            lds_scatter(TP, 0, g, nl, d_o);
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) lds_scatter(TQ, ib, g, nl, hact[ib]);
-            lds_wave_sync();
-            const half4 pa = lds_gather(TP, 0, g, nl);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dwl[kb] = mfma16(pa, lds_gather(TQ, kb, g, nl), dwl[kb]);
-            lds_wave_sync();
-        }
-        // B fragment of dOut^T: k = 8g+j real for k<16 -> lanes g<2 hold cols 8g..8g+7.  We have cols 4g+r
-        // (D layout); rebuild the natural fragment through the LDS tile we may have just written, or
-        // cheaper: gather with shuffles from lanes (n, 2g') / (n, 2g'+1).
-        half8 bo;
+        half8 bo;  // natural-order B fragment of dOut^T, rebuilt from the D layout with shuffles
         {
-            // lane (n,g) needs cols 8g+j, j<8, g<2: from lane (n, 2g) regs r=j (j<4) and lane (n, 2g+1) regs r=j-4
             const int src_lo = nl + 16 * ((2 * g) & 3), src_hi = nl + 16 * ((2 * g + 1) & 3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -419,59 +373,22 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
             dh[ib] = mfma32(atl[ib], bo, c);
         }
-        // ---- hidden layers, top down ----
 #pragma unroll
         for (int h = NH - 1; h >= 0; --h) {
-            // ReLU backward with the saved post-activation of layer h
+            // ReLU backward with the saved post-activation of layer h; keep the result for the wgrad kernels
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
+            for (int ib = 0; ib < 4; ++ib) {
+                const f32x4 hact = valid ? load_h4(acts + ((uint64_t)h * n + s) * WIDTH + ib * 16 + 4 * g)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dh[ib][r] = hact[ib][r] > 0.f ? dh[ib][r] : 0.f;
-            // input of matrix h: previous activation (h>0) or x (h==0)
-            f32x4 inp[4];
-            if (h > 0) {
+                for (int r = 0; r < 4; ++r) dh[ib][r] = hact[r] > 0.f ? dh[ib][r] : 0.f;
+                if (gpre && valid) {  // column-blocked, 64 columns per layer
 #pragma unroll
-                for (int ib = 0; ib < 4; ++ib)
-                    inp[ib] = valid ? load_h4(acts + ((uint64_t)(h - 1) * n + s) * WIDTH + ib * 16 + 4 * g)
-                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-#pragma unroll
-                for (int ib = 0; ib < KIN; ++ib)
-                    inp[ib] = load_x4(x, x_f32 != 0, (uint64_t)s * x_stride, ib * 16 + 4 * g, (int)n_in, IN_PAD, valid, s, n,
-                                      x_lmf);
-            }
-            if (need_dw) {
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) lds_scatter(TP, ob, g, nl, dh[ob]);
-                if (h > 0) {
-#pragma unroll
-                    for (int ib = 0; ib < 4; ++ib) lds_scatter(TQ, ib, g, nl, inp[ib]);
-                } else {
-#pragma unroll
-                    for (int ib = 0; ib < KIN; ++ib) lds_scatter(TQ, ib, g, nl, inp[ib]);
+                    for (int r = 0; r < 4; ++r)
+                        gpre[(uint64_t)h * WIDTH * ldn + t32_off(s, ib * 16 + 4 * g + r, WIDTH)] =
+                            __float2half_rn(dh[ib][r]);
                 }
-                lds_wave_sync();
-                half4 pa[4];
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) pa[ob] = lds_gather(TP, ob, g, nl);
-                if (h > 0) {
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {
-                        const half4 qb = lds_gather(TQ, kb, g, nl);
-#pragma unroll
-                        for (int ob = 0; ob < 4; ++ob) dwh[h > 0 ? h - 1 : 0][ob][kb] = mfma16(pa[ob], qb, dwh[h > 0 ? h - 1 : 0][ob][kb]);
-                    }
-                } else {
-#pragma unroll
-                    for (int kb = 0; kb < KIN; ++kb) {
-                        const half4 qb = lds_gather(TQ, kb, g, nl);
-#pragma unroll
-                        for (int ob = 0; ob < 4; ++ob) dw0[ob][kb] = mfma16(pa[ob], qb, dw0[ob][kb]);
-                    }
-                }
-                lds_wave_sync();
             }
-            // dgrad to the layer below
             const half8 b0 = pack_b(dh[0], dh[1]), b1 = pack_b(dh[2], dh[3]);
             if (h > 0) {
 #pragma unroll
@@ -479,7 +396,6 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
                     f32x4 c = {0.f, 0.f, 0.f, 0.f};
                     c = mfma32(ath[h > 0 ? h - 1 : 0][ib][0], b0, c);
                     dh[ib] = mfma32(ath[h > 0 ? h - 1 : 0][ib][1], b1, c);
-                    hact[ib] = inp[ib];
                 }
             } else if (dx) {
 #pragma unroll
@@ -503,33 +419,118 @@ k_mlp_backward(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride
             }
         }
     }
+}
 
-    if (!need_dw) return;
-    // ---- block reduction of dW in LDS (ds_add_f32), then one fp32 partial per block ----
-    // D layout of a dW block: lane (c = nl, g) holds dW[ob*16 + 4g + r][kb*16 + c]
+// ---- wgrad ------------------------------------------------------------------------------------------------------
+// dW[o][k] = sum_n G[n][o] A[n][k] with the SAMPLE index on the MFMA k axis (v_mfma_f32_16x16x32_f16, 32 samples per
+// instruction).  The fragment of lane (i = lane&15, g = lane>>4) is 8 CONSECUTIVE samples of ONE column: with the
+// operands stored column-blocked (t32_off: per 32-sample tile a [cols][32] matrix, written that way by k_mlp_dgrad /
+// k_mlp_forward) that is a single 16-B load and the whole wave reads 1 KB contiguous -- no LDS transpose, ~90 VGPRs,
+// many waves in flight.  (Plain feature-major [cols][n] put the 16 columns of a fragment 2n bytes apart: 16 pages per
+// load instruction, and the TLB misses made it slower than the LDS transpose.)  Row-major / level-major / fp32 operands (the first
+// layer's input) fall back to 8 element loads.
+//   a_kind 0: fp16 column-blocked (t32_off, ld = column count)   1: fp16 row-major [n, ld]   2: fp16 level-major [cols/F][n][F]
+//          3: fp32 row-major [n, ld];  columns >= a_cols are the constant 1 (tcnn input padding)
+template <int KIND>
+__device__ __forceinline__ half8 wgrad_frag(const void *__restrict__ p, uint32_t ld, uint32_t lmf, uint32_t col, uint32_t n0,
+                                            uint32_t n, uint32_t n_cols)
+{
+    half8 f;
+    if constexpr (KIND == 0) {  // ld = column count of the blocked buffer; the caller masks the ragged last tile
+        const uint4 raw =
+            *reinterpret_cast<const uint4 *>(reinterpret_cast<const _Float16 *>(p) + t32_off(n0, col, ld));
+        f = *reinterpret_cast<const half8 *>(&raw);
+    } else {
+        const bool pad = col >= n_cols;
+        const uint32_t c = pad ? 0 : col;
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-#pragma unroll
-        for (int kb = 0; kb < KIN; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&lds_dw[(ob * 16 + 4 * g + r) * IN_PAD + kb * 16 + nl], dw0[ob][kb][r]);
-#pragma unroll
-        for (int h = 0; h < NH - 1; ++h)
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    atomicAdd(&lds_dw[WIDTH * IN_PAD + h * WIDTH * WIDTH + (ob * 16 + 4 * g + r) * WIDTH + kb * 16 + nl],
-                              dwh[h][ob][kb][r]);
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t s = n0 + j < n ? n0 + j : n - 1;  // clamped: unconditional loads, masked afterwards
+            _Float16 v;
+            if constexpr (KIND == 1) v = reinterpret_cast<const _Float16 *>(p)[(uint64_t)s * ld + c];
+            else if constexpr (KIND == 2) v = reinterpret_cast<const _Float16 *>(p)[lm_off(s, (int)c, n, lmf)];
+            else v = (_Float16) reinterpret_cast<const float *>(p)[(uint64_t)s * ld + c];
+            f[j] = pad ? (_Float16)1 : v;
+        }
     }
+    return f;
+}
+
+__device__ __forceinline__ half8 wgrad_mask(half8 f, uint32_t n0, uint32_t n)
+{
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int j = 0; j < 8; ++j)
+        if (n0 + j >= n) f[j] = (_Float16)0;
+    return f;
+}
+
+template <int OB /* output blocks of 16 */, int KB /* input blocks of 16 */, int KIND>
+__global__ void __launch_bounds__(MLP_BLOCK)
+k_mlp_wgrad(const __half *__restrict__ GT, const void *__restrict__ A, uint32_t a_ld, uint32_t a_lmf, uint32_t a_cols,
+            float *__restrict__ partials, uint32_t partial_stride, uint32_t partial_offset, uint32_t n)
+{
+    constexpr int OW = OB * 16, KW = KB * 16;
+    static_assert((OB * KB) % 4 == 0, "block reduction assigns OB*KB/4 fragments to each thread");
+    __shared__ f32x4 red[WAVES][OB * KB][64];  // per-wave accumulators in fragment order (LDS float atomics are ~4 clk/lane)
+    const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4;
+    const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
+    const uint32_t n_tiles = (n + 31) / 32;
+    f32x4 acc[OB][KB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            atomicAdd(&lds_dw[WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH + (4 * g + r) * WIDTH + kb * 16 + nl], dwl[kb][r]);
+    for (int a = 0; a < OB; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // software pipeline: the fragments of the wave's next tile are in flight while the current one is multiplied
+    half8 ga[OB], ab[KB];
+    auto load = [&](uint32_t tile, half8 *pg, half8 *pa) {
+        const uint32_t n0 = tile * 32 + 8 * g;
+#pragma unroll
+        for (int a = 0; a < OB; ++a) pg[a] = wgrad_frag<0>(GT, OW, 0, a * 16 + nl, n0, n, OW);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) pa[b] = wgrad_frag<KIND>(A, a_ld, a_lmf, b * 16 + nl, n0, n, a_cols);
+    };
+    uint32_t tile = wave;
+    if (tile < n_tiles) load(tile, ga, ab);
+    while (tile < n_tiles) {
+        const uint32_t next = tile + n_waves;
+        half8 ga2[OB], ab2[KB];
+        if (next < n_tiles) load(next, ga2, ab2);
+        if (tile * 32 + 32 > n) {  // ragged last tile: zero the samples past n on both operands
+            const uint32_t n0 = tile * 32 + 8 * g;
+#pragma unroll
+            for (int a = 0; a < OB; ++a) ga[a] = wgrad_mask(ga[a], n0, n);
+#pragma unroll
+            for (int b = 0; b < KB; ++b) ab[b] = wgrad_mask(ab[b], n0, n);
+        }
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int a = 0; a < OB; ++a) acc[a][b] = mfma32(ga[a], ab[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < OB; ++a) ga[a] = ga2[a];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) ab[b] = ab2[b];
+        tile = next;
+    }
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < OB; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) red[w][a * KB + b][lane] = acc[a][b];
     __syncthreads();
-    float *dst = partials + (uint64_t)blockIdx.x * N_PARAMS;
-    for (int k = threadIdx.x; k < N_PARAMS; k += MLP_BLOCK) dst[k] = lds_dw[k];
+    // D layout of a dW block: lane (c = ln&15, g = ln>>4) of fragment (a,b) holds dW[a*16 + 4g + r][b*16 + c]
+    float *dst = partials + (uint64_t)blockIdx.x * partial_stride + partial_offset;
+#pragma unroll
+    for (int i = 0; i < OB * KB / 4; ++i) {
+        const int e = i * MLP_BLOCK + threadIdx.x, blk = e >> 6, ln = e & 63;
+        f32x4 s = red[0][blk][ln];
+#pragma unroll
+        for (int k = 1; k < WAVES; ++k) s += red[k][blk][ln];
+        const int a = blk / KB, b = blk % KB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(a * 16 + 4 * (ln >> 4) + r) * KW + b * 16 + (ln & 15)] = s[r];
+    }
 }
 
 // grad[k] += inv_scale * sum_b partials[b][k].  2-D grid: x = 256-parameter column blocks, y = row segments; each
@@ -574,9 +575,18 @@ uint32_t n_params_of(const NsrMlpDesc *d) { return WIDTH * d->in_pad + (d->n_hid
 
 uint32_t bwd_blocks(uint32_t n)
 {
-    const uint32_t n_tiles = (n + 15) / 16;
-    uint32_t nb = (n_tiles + WAVES * 8 - 1) / (WAVES * 8);  // ~8 tiles per wave (4 was measured slower: fixed cost per wave)
+    // wgrad: 32-sample tiles, ~2 tiles per wave, at most 512 blocks (one partial row each)
+    const uint32_t n_tiles = (n + 31) / 32;
+    uint32_t nb = (n_tiles + WAVES * 2 - 1) / (WAVES * 2);
     return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+}
+
+// workspace layout (floats): [partials: nb * n_params][gpre^T: n_hidden * 64 * ldn halfs][gout^T: 16 * ldn halfs]
+uint64_t bwd_ws_floats(const NsrMlpDesc *d, uint32_t n)
+{
+    const uint64_t ldn = (n + 31u) & ~31u;
+    const uint64_t part = (uint64_t)bwd_blocks(n) * n_params_of(d);
+    return part + ((uint64_t)d->n_hidden * 64 * ldn + 16 * ldn) / 2 + 64;
 }
 
 }  // namespace
@@ -611,6 +621,8 @@ extern "C" int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, c
     return nsr_mlp_forward_ex(x, x_is_f32, x_stride, 0, weights, out, acts, n, desc, stream);
 }
 
+static inline uint32_t mlp_ldn(uint32_t n) { return (n + 31u) & ~31u; }
+
 extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride, uint32_t x_level_major_features,
                                   const nsr_half *weights, nsr_half *out, nsr_half *acts, uint32_t n,
                                   const NsrMlpDesc *desc, void *stream)
@@ -638,44 +650,90 @@ extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride
 extern "C" uint64_t nsr_mlp_backward_workspace_floats(const NsrMlpDesc *desc, uint32_t n)
 {
     if (!desc || check_mlp(desc, "nsr_mlp_backward_workspace_floats")) return 0;
-    return (uint64_t)bwd_blocks(n) * n_params_of(desc);
+    return bwd_ws_floats(desc, n);
+}
+
+template <int OB, int KB>
+static void launch_wgrad(const __half *GT, const void *A, int a_kind, uint32_t a_ld, uint32_t a_lmf, uint32_t a_cols,
+                         float *partials, uint32_t np, uint32_t off, uint32_t n, uint32_t nb, hipStream_t st)
+{
+#define NSR_WGRAD(KIND)                                                                                                \
+    hipLaunchKernelGGL((k_mlp_wgrad<OB, KB, KIND>), dim3(nb), dim3(MLP_BLOCK), 0, st, GT, A, a_ld, a_lmf, a_cols,     \
+                       partials, np, off, n)
+    switch (a_kind) {
+    case 0: NSR_WGRAD(0); break;
+    case 1: NSR_WGRAD(1); break;
+    case 2: NSR_WGRAD(2); break;
+    default: NSR_WGRAD(3); break;
+    }
+#undef NSR_WGRAD
 }
 
 extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
                                    const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
-                                   uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx,
-                                   uint32_t dx_stride, uint32_t dx_level_major_features, float *partials, uint32_t n,
-                                   float grad_scale, const NsrMlpDesc *desc, void *stream)
+                                   uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
+                                   uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
+                                   const NsrMlpDesc *desc, void *stream)
 {
     if (int rc = check_mlp(desc, "nsr_mlp_backward")) return rc;
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(dout && x && acts && weights, "nsr_mlp_backward: NULL pointer");
     NSR_REQUIRE(desc->output_activation == NSR_ACT_NONE || out, "nsr_mlp_backward: sigmoid backward needs `out`");
-    NSR_REQUIRE(!grad_weights || partials, "nsr_mlp_backward: grad_weights needs the partials workspace");
+    NSR_REQUIRE(!grad_weights || partials, "nsr_mlp_backward: grad_weights needs the workspace");
     NSR_REQUIRE(!dx || dx_level_major_features || dx_stride >= desc->n_in, "nsr_mlp_backward: dx_stride < n_in");
     NSR_REQUIRE(!dx_level_major_features || desc->n_in % dx_level_major_features == 0,
                 "nsr_mlp_backward: level-major dx needs n_in to be a multiple of the feature count");
+    NSR_REQUIRE(!x_level_major_features || !x_is_f32, "nsr_mlp_backward: level-major x must be fp16");
     NSR_REQUIRE(grad_scale > 0.f, "nsr_mlp_backward: grad_scale must be > 0");
-    const uint32_t nb = bwd_blocks(n), np = n_params_of(desc);
-    const size_t lds = sizeof(float) * np + WAVES * 2 * 64 * TROW * sizeof(_Float16);
-    DISPATCH_MLP(desc->in_pad / 16, desc->n_hidden, {
-        static bool attr_set = false;  // per instantiation; the call can block on in-flight work of OTHER streams
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)k_mlp_backward<KIN, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_mlp_backward<KIN, NH>), dim3(nb), dim3(MLP_BLOCK), lds, (hipStream_t)stream, dout,
-                           dout_is_f32, dout_stride, (const __half *)out, x, x_is_f32, x_stride, (const __half *)acts,
-                           (const __half *)weights, dx, dx_stride, partials, n, desc->n_in, desc->n_out,
-                           (int)desc->output_activation, grad_scale, grad_weights ? 1 : 0, dout_extra_col0,
-                           dx_level_major_features, x_level_major_features);
-    });
-    NSR_CHECK_LAUNCH("nsr_mlp_backward");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t nb = bwd_blocks(n), np = n_params_of(desc), nh = desc->n_hidden, in_pad = desc->in_pad;
+    const uint32_t ldn = mlp_ldn(n);
+    __half *gpre = nullptr, *gout = nullptr;
     if (grad_weights) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3(nsr_div_up(np, 256), RED_SEGS), dim3(256), 0, (hipStream_t)stream, partials,
-                           grad_weights, np, nb, 1.f / grad_scale);
-        NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
+        gpre = reinterpret_cast<__half *>(partials + (uint64_t)nb * np);  // [nh][64][ldn]
+        gout = gpre + (uint64_t)nh * 64 * ldn;                             // [16][ldn]
     }
+    const uint32_t n_tiles = (n + 15) / 16;
+    uint32_t blocks = (n_tiles + WAVES - 1) / WAVES;
+    if (blocks > 2048) blocks = 2048;
+    DISPATCH_MLP(in_pad / 16, nh, {
+        constexpr int NP = WIDTH * KIN * 16 + (NH - 1) * WIDTH * WIDTH + 16 * WIDTH;
+        const size_t lds = NP * sizeof(_Float16);
+        hipLaunchKernelGGL((k_mlp_dgrad<KIN, NH>), dim3(blocks), dim3(MLP_BLOCK), lds, st, dout, dout_is_f32, dout_stride,
+                           dout_extra_col0, (const __half *)out, (const __half *)acts, (const __half *)weights, dx,
+                           dx_stride, dx_level_major_features, gpre, gout, ldn, n, desc->n_in, desc->n_out,
+                           (int)desc->output_activation, grad_scale);
+    });
+    NSR_CHECK_LAUNCH("nsr_mlp_backward(dgrad)");
+    if (!grad_weights) return NSR_OK;
+    const int x_kind = x_level_major_features ? 2 : (x_is_f32 ? 3 : 1);
+    // first matrix W0 [64, in_pad]: G = gpre[0], A = x
+    switch (in_pad / 16) {
+    case 1: launch_wgrad<4, 1>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
+    case 2: launch_wgrad<4, 2>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
+    case 3: launch_wgrad<4, 3>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
+    default: launch_wgrad<4, 4>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
+    }
+    // activations feeding matrix l >= 1: the forward's row-major [n,64] copy (element loads; measured as fast as a
+    // column-blocked copy, so the forward does not write one)
+    auto act_of = [&](uint32_t h, const void *&p, int &kind, uint32_t &ld) {
+        p = (const __half *)acts + (uint64_t)h * n * 64; kind = 1; ld = 64;
+    };
+    for (uint32_t l = 1; l < nh; ++l) {  // hidden matrices W_l [64,64]: G = gpre[l], A = acts[l-1]
+        const void *p; int kind; uint32_t ld;
+        act_of(l - 1, p, kind, ld);
+        launch_wgrad<4, 4>(gpre + (uint64_t)l * 64 * ldn, p, kind, ld, 0, 64, partials, np,
+                           WIDTH * in_pad + (l - 1) * WIDTH * WIDTH, n, nb, st);
+    }
+    {   // last matrix [16, 64]: G = gout, A = acts[nh-1]
+        const void *p; int kind; uint32_t ld;
+        act_of(nh - 1, p, kind, ld);
+        launch_wgrad<1, 4>(gout, p, kind, ld, 0, 64, partials, np, WIDTH * in_pad + (nh - 1) * WIDTH * WIDTH, n, nb, st);
+    }
+    NSR_CHECK_LAUNCH("nsr_mlp_backward(wgrad)");
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nsr_div_up(np, 256), RED_SEGS), dim3(256), 0, st, partials, grad_weights, np,
+                       nb, 1.f / grad_scale);
+    NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
     return NSR_OK;
 }
 
@@ -684,6 +742,5 @@ extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout
                                 const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                                 float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream)
 {
-    return nsr_mlp_backward_ex(dout, dout_is_f32, dout_stride, nullptr, out, x, x_is_f32, x_stride, 0, acts, weights,
-                               grad_weights, dx, dx_stride, 0, partials, n, grad_scale, desc, stream);
+    return nsr_mlp_backward_ex(dout, dout_is_f32, dout_stride, nullptr, out, x, x_is_f32, x_stride, 0, acts, weights, grad_weights, dx, dx_stride, 0, partials, n, grad_scale, desc, stream);
 }
