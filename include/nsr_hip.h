@@ -324,11 +324,19 @@ int nsr_gather_train_rays(const float *images, const float *masks, const float *
 
 /* everything a training ray needs before marching in ONE launch: pixel choice from 4 uniform rows u01[4,n]
  * (image, x, y, jitter), pixel gather, get_rays + normalise, background blend, slab test against `aabb`
- * (device[6]) and the stratified jitter t_min += u*jitter_step (0 disables).  rays[n,6] and the split rays_o/rays_d */
+ * (device[6]) and the stratified jitter t_min += u*jitter_step (0 disables).  rays[n,6] and the split rays_o/rays_d
+ * (systems/nerf.py:38-79, models/ray_utils.py:23-43, nerfacc ray_aabb_intersect + ray_marching stratified) */
 int nsr_prepare_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,
                            const float *u01, const float *background, int n_images, int height, int width,
                            int apply_mask, const float *aabb, float jitter_step, float *rays, float *rays_o,
-                           float *rays_d, float *rgb, float *fg, float *t_min, float *t_max, uint32_t n, void *stream);
+                           float *rays_d, float *rgb, float *fg, float *t_min, float *t_max, uint32_t n,
+                           const int32_t *n_active, void *stream);
+/* n_active (device, may be NULL = all n): slots >= *n_active become DEAD rays (t_min = t_max = 1e10: no samples,
+ * opacity 0, outside the loss), so the dynamic batch size of systems/nerf.py:93-95 can live on the device:
+ *   t = int(n_rays * (target_samples / n_samples)); n_rays = min(int(n_rays * 0.9 + t * 0.1), max_rays)
+ * in double precision (Python's arithmetic); n_samples <= 0 leaves n_rays unchanged. */
+int nsr_update_ray_count(const int32_t *n_samples, int32_t *n_rays, int32_t target_samples, int32_t max_rays,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native orchestration of the fused NeRF training step (csrc/step.hip): one C call per PHASE issues all of its

@@ -370,10 +370,27 @@ k_prepare_train_rays(const float *__restrict__ images, const float *__restrict__
                      const float *__restrict__ bg, int n_img, int H, int W, int apply_mask,
                      const float *__restrict__ aabb, float jitter_step, float *__restrict__ rays,
                      float *__restrict__ rays_o, float *__restrict__ rays_d, float *__restrict__ rgb,
-                     float *__restrict__ fg, float *__restrict__ t_min, float *__restrict__ t_max, uint32_t n)
+                     float *__restrict__ fg, float *__restrict__ t_min, float *__restrict__ t_max, uint32_t n,
+                     const int32_t *__restrict__ n_active)
 {
     const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (n_active && i >= (uint32_t)*n_active) {
+        // slot beyond the current dynamic batch: a DEAD ray (misses the box -> no samples, opacity 0, outside the loss).
+        // Keeping the arrays at their maximum size makes the batch size a device-side value: the next marching pass
+        // can be queued before the host has seen this step's sample count.
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float dk = k == 2 ? 1.f : 0.f;
+            rays[6ull * i + k] = 0.f; rays[6ull * i + 3 + k] = dk;
+            rays_o[3ull * i + k] = 0.f; rays_d[3ull * i + k] = dk;
+            rgb[3ull * i + k] = 0.f;
+        }
+        fg[i] = 0.f;
+        t_min[i] = 1e10f;
+        t_max[i] = 1e10f;
+        return;
+    }
     const int im = min((int)(u01[i] * (float)n_img), n_img - 1);
     const int x = min((int)(u01[n + i] * (float)W), W - 1);
     const int y = min((int)(u01[2ull * n + i] * (float)H), H - 1);
@@ -421,6 +438,20 @@ k_prepare_train_rays(const float *__restrict__ images, const float *__restrict__
     if (jitter_step > 0.f) near = __fadd_rn(near, __fmul_rn(u01[3ull * n + i], jitter_step));  // t_min + rand * step
     t_min[i] = near;
     t_max[i] = far;
+}
+
+// systems/nerf.py:93-95 on the device, in the double arithmetic Python uses:
+//   t = int(n * (target / S));  n = min(int(n * 0.9 + t * 0.1), max)
+__global__ void k_update_ray_count(const int32_t *__restrict__ n_samples, int32_t *__restrict__ n_rays,
+                                   int32_t target_samples, int32_t max_rays)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int32_t s = *n_samples;
+    if (s <= 0) return;
+    const double n = (double)*n_rays;
+    const double t = (double)(long long)(n * ((double)target_samples / (double)s));
+    const long long v = (long long)(n * 0.9 + t * 0.1);
+    *n_rays = (int32_t)(v < (long long)max_rays ? v : (long long)max_rays);
 }
 
 }  // namespace
@@ -584,13 +615,25 @@ extern "C" int nsr_prepare_train_rays(const float *images, const float *masks, c
                                       const float *u01, const float *background, int n_images, int height, int width,
                                       int apply_mask, const float *aabb, float jitter_step, float *rays, float *rays_o,
                                       float *rays_d, float *rgb, float *fg, float *t_min, float *t_max, uint32_t n,
-                                      void *stream)
+                                      const int32_t *n_active, void *stream)
 {
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(images && masks && directions && c2w && u01 && background && aabb && rays && rays_o && rays_d && rgb &&
                     fg && t_min && t_max, "nsr_prepare_train_rays: NULL pointer");
     hipLaunchKernelGGL(k_prepare_train_rays, EW_GRID(n), images, masks, directions, c2w, u01, background, n_images,
-                       height, width, apply_mask, aabb, jitter_step, rays, rays_o, rays_d, rgb, fg, t_min, t_max, n);
+                       height, width, apply_mask, aabb, jitter_step, rays, rays_o, rays_d, rgb, fg, t_min, t_max, n,
+                       n_active);
     NSR_CHECK_LAUNCH("nsr_prepare_train_rays");
+    return NSR_OK;
+}
+
+extern "C" int nsr_update_ray_count(const int32_t *n_samples, int32_t *n_rays, int32_t target_samples, int32_t max_rays,
+                                    void *stream)
+{
+    NSR_REQUIRE(n_samples && n_rays, "nsr_update_ray_count: NULL pointer");
+    NSR_REQUIRE(target_samples > 0 && max_rays > 0, "nsr_update_ray_count: target_samples and max_rays must be > 0");
+    hipLaunchKernelGGL(k_update_ray_count, dim3(1), dim3(64), 0, (hipStream_t)stream, n_samples, n_rays, target_samples,
+                       max_rays);
+    NSR_CHECK_LAUNCH("nsr_update_ray_count");
     return NSR_OK;
 }

@@ -207,124 +207,241 @@ k_grid_backward_params(const float *__restrict__ x, const void *__restrict__ dy,
 // that the 8 non-coherent XCD L2s stay consistent) -- 1.13 ms for one 98 k-sample step, 3x everything else.
 // Rays of a batch are i.i.d., so fine-level entries are touched ~once per step: there is no reuse to cache,
 // only the atomic *rate* hurts.  So instead every workgroup OWNS a contiguous slice of one level's gradient
-// that fits the CU's 160 KiB LDS (20480 fp32 pairs), scans ALL samples of that level, recomputes the 8
+// that fits the CU's 160 KiB LDS (10240 64-bit pairs), scans ALL samples of that level, recomputes the 8
 // corner indices (a few dozen VALU ops -- the chip has ~100x more VALU than atomic throughput), accumulates
-// the corners that fall into its slice with LDS atomics (ds_add_f32) and finally stores the slice with plain
-// coalesced 16-B stores.  314 workgroups cover L=16,T=2^19,F=2; each grad entry is written exactly once, so the
+// the corners that fall into its slice with 64-bit fixed-point LDS atomics (ds_add_u64) and finally stores the slice
+// as fp32 with plain coalesced 16-B stores.  ~750 workgroups cover L=16,T=2^19,F=2; each grad entry is written exactly once, so the
 // 50 MB gradient needs no memset either (accumulate=0).  dy is read level-major ([L][N][F], 8-B coalesced).
 // ------------------------------------------------------------------------------------------------
 constexpr int OWN_BLOCK = 1024;
-constexpr int OWN_LDS_FLOATS = 40960;   // 160 KiB: the whole LDS of a CU
-constexpr int OWN_POW2_LOG2 = 14;       // hashed levels: 16384-entry slices (128 KiB at F=2) -> owner = hash bits
+constexpr int OWN_LDS_WORDS = 20480;    // 64-bit accumulators in 160 KiB: the whole LDS of a CU
+constexpr int OWN_POW2_LOG2 = 13;       // hashed levels: 8192-entry slices (128 KiB at F=2) -> owner = hash bits
 constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decomposition aims for
+constexpr int OWN_MAX_SLICES = 2048;    // per level (T = 2^24 at 8192-entry slices)
+constexpr int OWN_BIN_BLOCK = 256;      // samples per block of the two binning passes
+constexpr float OWN_FIX_SCALE = 68719476736.f;          // 2^36: accumulators are Q27.36 fixed point
+constexpr float OWN_FIX_INV = 1.f / 68719476736.f;
 
-// Decomposition of one level: R slices of its gradient x C sample chunks.  C > 1 (small dense levels, where one
-// slice would see every sample and serialise on same-address LDS atomics) writes per-chunk slabs that a second
-// tiny kernel sums; C == 1 stores straight into the gradient.
+// Decomposition of one level: R slices of its gradient x C item chunks.  C > 1 (small dense levels, where one slice
+// would take every sample and serialise on same-address LDS atomics) writes per-chunk slabs that a second tiny kernel
+// sums; C == 1 stores straight into the gradient.
 struct OwnerMap {
-    uint32_t block_start[NSR_MAX_LEVELS + 1];
+    // XCD-aware placement: block b runs on XCD b % 8 (round-robin dispatch); all workgroups of one level sit on ONE XCD
+    // so that its private L2 serves the level's dy and the shared x to every slice after the first.
+    uint32_t xcd_of_level[NSR_MAX_LEVELS];
+    uint32_t level_start[NSR_MAX_LEVELS];  // first block index (b / 8) of the level within its XCD
     uint32_t n_slices[NSR_MAX_LEVELS];
     uint32_t n_chunks[NSR_MAX_LEVELS];
     uint32_t slab_offset[NSR_MAX_LEVELS];  // floats, into the slab workspace (levels with n_chunks > 1)
     uint32_t entries_per_slice[NSR_MAX_LEVELS];
+    uint32_t bin_offset[NSR_MAX_LEVELS];   // first (level, slice) bin of the level in the counter arrays
 };
 
-template <int F>
-__device__ __forceinline__ void lds_add(float *acc, uint32_t rel, float w, const float (&g)[F])
+// LDS float atomics retire at ~0.33 lane-ops/clk/CU on gfx950, 64-bit INTEGER ones at ~5 (tools/lds_atomics_bench.hip),
+// so the slices accumulate in Q27.36 fixed point: 15x the rate, 1.5e-11 resolution (the reference's tcnn accumulates
+// this gradient in fp16), and -- integer addition being associative -- a bit-reproducible gradient.
+// t = value * 2^36 (|t| < 2^62) -> two's complement int64, built from exact fp32 pieces of |t|.
+__device__ __forceinline__ unsigned long long own_to_fixed(float t)
 {
+    const float a = fabsf(t);
+    const float th = floorf(a * 2.3283064365386963e-10f);  // floor(|t| / 2^32): the high word
+    const float tl = rintf(fmaf(th, -4294967296.f, a));     // |t| - th * 2^32 in [0, 2^32): exact before the rint
+    const unsigned long long v = ((unsigned long long)(uint32_t)th << 32) | (uint32_t)tl;
+    return t < 0.f ? 0ull - v : v;
+}
+
+__device__ __forceinline__ float own_from_fixed(unsigned long long v) { return (float)(long long)v * OWN_FIX_INV; }
+
+// An ITEM is one (y,z) corner pair of one sample on one level: the two x-neighbours share every hash/stride term and
+// nearly always the owning slice.  word = sample << 4 | pair << 2 | mode, mode 0: both corners, 1: only x0, 2: only
+// x0+1 (the pair straddles two slices: dense levels at a slice border or at the wrap-around of the last entries).
+struct PairSlices { uint32_t s0, s1; };
+
+__device__ __forceinline__ PairSlices pair_slices(const LevelGeom &g, const Cell &c, int k, uint32_t epb, bool pow2)
+{
+    const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
+    PairSlices p;
+    if (pow2) {  // x never reaches the slice bits of a hashed level cut into 2^OWN_POW2_LOG2-entry slices
+        const uint32_t h = (cy * PRIME_Y) ^ (cz * PRIME_Z);
+        p.s0 = p.s1 = (h & (g.size - 1u)) >> OWN_POW2_LOG2;
+    } else {
+        p.s0 = corner_index(g, c.c[0], cy, cz) / epb;
+        p.s1 = corner_index(g, c.c[0] + 1u, cy, cz) / epb;
+    }
+    return p;
+}
+
+__device__ __forceinline__ bool own_is_pow2(const LevelGeom &g, uint32_t epb)
+{
+    return !g.dense && epb == (1u << OWN_POW2_LOG2) && (g.size & (g.size - 1u)) == 0u && g.res < (1u << OWN_POW2_LOG2);
+}
+
+// pass 1 (FILL = false): counts[bin] = number of items per (level, slice).
+// pass 2 (FILL = true):  items[level][bin_start + ...] = item words; a block reserves one contiguous range per bin.
+// grid (ceil(n / OWN_BIN_BLOCK), L)
+template <bool FILL>
+__global__ void __launch_bounds__(OWN_BIN_BLOCK)
+k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t *__restrict__ counts,
+          const uint32_t *__restrict__ bin_start, uint32_t *__restrict__ cursors, uint32_t *__restrict__ items,
+          const OwnerMap om, const NsrGridDesc d)
+{
+    __shared__ uint32_t hist[OWN_MAX_SLICES];
+    const uint32_t level = blockIdx.y;
+    if (level >= mask_count) return;
+    const uint32_t R = om.n_slices[level], epb = om.entries_per_slice[level], bin0 = om.bin_offset[level];
+    const LevelGeom g = load_level(d, level);
+    const bool pow2 = own_is_pow2(g, epb);
+    for (uint32_t s = threadIdx.x; s < R; s += OWN_BIN_BLOCK) hist[s] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * OWN_BIN_BLOCK + threadIdx.x;
+    uint32_t slice[8], rank[8];
+    int n_items = 0;
+    if (i < n) {
+        const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
 #pragma unroll
-    for (int f = 0; f < F; ++f) atomicAdd(&acc[rel * F + f], w * g[f]);
+        for (int k = 0; k < 4; ++k) {
+            const PairSlices p = pair_slices(g, c, k, epb, pow2);
+            // slot 2k: the pair (or its x0 half), slot 2k+1: the x0+1 half of a straddling pair
+            slice[2 * k] = p.s0;
+            rank[2 * k] = atomicAdd(&hist[p.s0], 1u);
+            slice[2 * k + 1] = p.s1 != p.s0 ? p.s1 : 0xffffffffu;
+            if (p.s1 != p.s0) rank[2 * k + 1] = atomicAdd(&hist[p.s1], 1u);
+        }
+        n_items = 8;
+    }
+    __syncthreads();
+    if constexpr (!FILL) {
+        for (uint32_t s = threadIdx.x; s < R; s += OWN_BIN_BLOCK)
+            if (hist[s]) atomicAdd(&counts[bin0 + s], hist[s]);
+    } else {
+        // reserve this block's range in every bin it touches; hist[s] becomes the range's first item index
+        for (uint32_t s = threadIdx.x; s < R; s += OWN_BIN_BLOCK)
+            if (hist[s]) hist[s] = bin_start[bin0 + s] + atomicAdd(&cursors[bin0 + s], hist[s]);
+        __syncthreads();
+        uint32_t *dst = items + (uint64_t)level * n * 8ull;
+        for (int q = 0; q < n_items; ++q) {
+            if (slice[q] == 0xffffffffu) continue;
+            const bool straddle = slice[q | 1] != 0xffffffffu;
+            const uint32_t mode = !straddle ? 0u : ((q & 1) ? 2u : 1u);
+            dst[hist[slice[q]] + rank[q]] = (i << 4) | ((uint32_t)(q >> 1) << 2) | mode;
+        }
+    }
+}
+
+// per level: exclusive prefix of the bin counts -> bin_start; clears the fill cursors.  grid (L), block 256
+__global__ void __launch_bounds__(256)
+k_own_bin_scan(const uint32_t *__restrict__ counts, uint32_t *__restrict__ bin_start, uint32_t *__restrict__ cursors,
+               const OwnerMap om)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t level = blockIdx.x, R = om.n_slices[level], bin0 = om.bin_offset[level];
+    const uint32_t per = (R + 255u) / 256u, b = threadIdx.x * per, e = min(R, b + per);
+    uint32_t sum = 0;
+    for (uint32_t s = b; s < e; ++s) sum += counts[bin0 + s];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t s = b; s < e; ++s) {
+        bin_start[bin0 + s] = run;
+        run += counts[bin0 + s];
+        cursors[bin0 + s] = 0u;
+    }
 }
 
 template <int F>
+__device__ __forceinline__ void lds_add(unsigned long long *acc, uint32_t rel, float w, const float (&g)[F])
+{
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(&acc[rel * F + f], own_to_fixed(w * g[f]));
+}
+
+// Workgroup (level, slice, chunk): accumulates ITS items -- every lane busy, no scan over foreign samples.
+template <int F>
 __global__ void __launch_bounds__(OWN_BLOCK)
 k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_lm /* [L][n][F] */,
-                      float *__restrict__ grad_table, float *__restrict__ slabs, uint32_t n, uint32_t mask_count,
-                      float grad_scale, int accumulate, const OwnerMap om, const NsrGridDesc d)
+                      const uint32_t *__restrict__ items, const uint32_t *__restrict__ counts,
+                      const uint32_t *__restrict__ bin_start, float *__restrict__ grad_table,
+                      float *__restrict__ slabs, uint32_t n, uint32_t mask_count, float grad_scale, int accumulate,
+                      const OwnerMap om, const NsrGridDesc d)
 {
-    extern __shared__ __attribute__((aligned(16))) float acc[];
-    uint32_t level = 0;
-    while (level + 1 < d.n_levels && blockIdx.x >= om.block_start[level + 1]) ++level;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    uint32_t level = d.n_levels;
+    for (uint32_t l = 0; l < d.n_levels; ++l)
+        if (om.xcd_of_level[l] == xcd && j >= om.level_start[l] && j < om.level_start[l] + om.n_slices[l] * om.n_chunks[l])
+            level = l;
+    if (level == d.n_levels) return;  // padding block of a lighter XCD
     const uint32_t C = om.n_chunks[level], epb = om.entries_per_slice[level];
-    const uint32_t local = blockIdx.x - om.block_start[level];
+    const uint32_t local = j - om.level_start[level];
     const uint32_t slice = local / C, chunk = local % C;
     const uint32_t r0 = slice * epb;
     const LevelGeom g = load_level(d, level);
     const uint32_t cnt = min(epb, g.size - r0);
-    for (uint32_t k = threadIdx.x; k < cnt * F; k += OWN_BLOCK) acc[k] = 0.f;
+    for (uint32_t k = threadIdx.x; k < cnt * F; k += OWN_BLOCK) acc[k] = 0ull;
     __syncthreads();
     if (level < mask_count) {
-        const uint32_t per = ((n + C - 1) / C + 63u) & ~63u;  // samples per chunk, wave aligned
-        const uint32_t i_end = min(n, (chunk + 1) * per);
+        const uint32_t bin = om.bin_offset[level] + slice;
+        const uint32_t m = counts[bin];
+        const uint32_t per = (m + C - 1) / C;
+        const uint32_t i_beg = min(m, chunk * per), i_end = min(m, (chunk + 1) * per);
+        const uint32_t *it = items + (uint64_t)level * n * 8ull + bin_start[bin];
         const float *dyl = dy_lm + (uint64_t)level * n * F;
-        // hashed level cut into power-of-two slices: x never reaches the slice bits, so ownership is decided once
-        // per (y,z) corner pair instead of once per corner
-        const bool pow2 = !g.dense && epb == (1u << OWN_POW2_LOG2) && g.res < (1u << OWN_POW2_LOG2);
-        for (uint32_t i = chunk * per + threadIdx.x; i < i_end; i += OWN_BLOCK) {
-            float g_out[F];
-            bool any = false;
-            if constexpr (F == 2) {
-                const float2 v = *reinterpret_cast<const float2 *>(dyl + 2ull * i);
-                g_out[0] = v.x * grad_scale; g_out[1] = v.y * grad_scale;
-                any = (v.x != 0.f) | (v.y != 0.f);
-            } else {
+        const float fix = grad_scale * OWN_FIX_SCALE;
+        constexpr int OWN_BATCH = 2;  // items in flight per lane: item -> (x, dy) is a dependent load chain
+        for (uint32_t i0 = i_beg + threadIdx.x; i0 < i_end; i0 += OWN_BLOCK * OWN_BATCH) {
+            uint32_t word[OWN_BATCH];
+            float gb[OWN_BATCH][F], xb[OWN_BATCH][3];
 #pragma unroll
-                for (int f = 0; f < F; ++f) { g_out[f] = dyl[(uint64_t)i * F + f] * grad_scale; any |= g_out[f] != 0.f; }
+            for (int u = 0; u < OWN_BATCH; ++u) {
+                const uint32_t i = i0 + u * OWN_BLOCK;
+                word[u] = i < i_end ? it[i] : 0xffffffffu;
             }
-            if (!any) continue;
-            const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
-            if (pow2) {
-                // which of the 4 (y,z) corner pairs land in this slice?  Expected 4/32 per lane: instead of four mostly
-                // empty divergent branches, every lane pops ITS matches -- the wave loops max-popcount (~1.4) times.
-                const uint32_t hy0 = c.c[1] * PRIME_Y, hz0 = c.c[2] * PRIME_Z;
-                const uint32_t lowmask = (1u << OWN_POW2_LOG2) - 1u, topmask = g.size - 1u;
-                uint32_t hh[4];
-                uint32_t match = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    hh[k] = (hy0 + ((k & 1) ? PRIME_Y : 0u)) ^ (hz0 + ((k & 2) ? PRIME_Z : 0u));
-                    match |= (((hh[k] & topmask) >> OWN_POW2_LOG2) == slice) ? (1u << k) : 0u;
-                }
-                while (match) {
-                    const int k = __builtin_ctz(match);
-                    match &= match - 1u;
-                    const uint32_t h = (k == 0) ? hh[0] : (k == 1) ? hh[1] : (k == 2) ? hh[2] : hh[3];
-                    const float wyz = ((k & 1) ? c.w[1] : 1.f - c.w[1]) * ((k & 2) ? c.w[2] : 1.f - c.w[2]);
-                    lds_add<F>(acc, (c.c[0] ^ h) & lowmask, (1.f - c.w[0]) * wyz, g_out);
-                    lds_add<F>(acc, ((c.c[0] + 1u) ^ h) & lowmask, c.w[0] * wyz, g_out);
-                }
-            } else {
-                uint32_t ee[8];
-                uint32_t match = 0;
+            for (int u = 0; u < OWN_BATCH; ++u) {
+                const uint32_t s = word[u] != 0xffffffffu ? word[u] >> 4 : 0u;
+                if constexpr (F == 2) {
+                    const float2 v = *reinterpret_cast<const float2 *>(dyl + 2ull * s);
+                    gb[u][0] = v.x; gb[u][1] = v.y;
+                } else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    ee[k] = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1)) - r0;
-                    match |= (ee[k] < cnt) ? (1u << k) : 0u;
+                    for (int f = 0; f < F; ++f) gb[u][f] = dyl[(uint64_t)s * F + f];
                 }
-                while (match) {
-                    const int k = __builtin_ctz(match);
-                    match &= match - 1u;
-                    uint32_t rel = ee[0];
+                xb[u][0] = x[3ull * s]; xb[u][1] = x[3ull * s + 1]; xb[u][2] = x[3ull * s + 2];
+            }
 #pragma unroll
-                    for (int q = 1; q < 8; ++q) rel = (k == q) ? ee[q] : rel;
-                    float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
-                    w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
-                    w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
-                    lds_add<F>(acc, rel, w, g_out);
-                }
+            for (int u = 0; u < OWN_BATCH; ++u) {
+                if (word[u] == 0xffffffffu) continue;
+                const int k = (word[u] >> 2) & 3;
+                const uint32_t mode = word[u] & 3u;
+                float g_out[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f)  // to fixed-point units, saturating far beyond anything fp16 dy can produce
+                    g_out[f] = fminf(fmaxf(gb[u][f] * fix, -4.6e18f), 4.6e18f);
+                const Cell c = locate(g, xb[u][0], xb[u][1], xb[u][2]);
+                const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
+                const float wyz = ((k & 1) ? c.w[1] : 1.f - c.w[1]) * ((k & 2) ? c.w[2] : 1.f - c.w[2]);
+                if (mode != 2u) lds_add<F>(acc, corner_index(g, c.c[0], cy, cz) - r0, (1.f - c.w[0]) * wyz, g_out);
+                if (mode != 1u) lds_add<F>(acc, corner_index(g, c.c[0] + 1u, cy, cz) - r0, c.w[0] * wyz, g_out);
             }
         }
     }
     __syncthreads();
-    const uint32_t nf = cnt * F;  // multiple of 8 floats: level sizes are multiples of 8 entries
+    const uint32_t nf = cnt * F;  // multiple of 8: level sizes are multiples of 8 entries
     if (C > 1) {
         float *dst = slabs + om.slab_offset[level] + ((uint64_t)chunk * g.size + r0) * F;
         for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4)
-            *reinterpret_cast<float4 *>(dst + k) = *reinterpret_cast<const float4 *>(acc + k);
+            *reinterpret_cast<float4 *>(dst + k) = make_float4(own_from_fixed(acc[k]), own_from_fixed(acc[k + 1]),
+                                                               own_from_fixed(acc[k + 2]), own_from_fixed(acc[k + 3]));
     } else {
         float *dst = grad_table + (uint64_t)(g.offset + r0) * F;
         for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4) {
-            float4 v = *reinterpret_cast<const float4 *>(acc + k);
+            float4 v = make_float4(own_from_fixed(acc[k]), own_from_fixed(acc[k + 1]), own_from_fixed(acc[k + 2]),
+                                   own_from_fixed(acc[k + 3]));
             if (accumulate) {
                 const float4 o = *reinterpret_cast<const float4 *>(dst + k);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -356,34 +473,55 @@ k_grid_reduce_slabs(const float *__restrict__ slabs, float *__restrict__ grad_ta
     }
 }
 
-// host: build the decomposition; returns the number of blocks, *slab_floats the slab workspace size
-static uint32_t make_owner_map(const NsrGridDesc *desc, OwnerMap *om, uint64_t *slab_floats)
+// host: build the decomposition; returns the number of blocks, *slab_floats the slab workspace size, *n_bins the number
+// of (level, slice) bins
+static uint32_t make_owner_map(const NsrGridDesc *desc, OwnerMap *om, uint64_t *slab_floats, uint32_t *n_bins)
 {
     const uint32_t F = desc->n_features, L = desc->n_levels;
-    uint32_t nb = 0;
     uint64_t slab = 0;
+    uint32_t wgs[NSR_MAX_LEVELS], bins = 0;
+    for (uint32_t l = 0; l < NSR_MAX_LEVELS; ++l)
+        om->xcd_of_level[l] = om->level_start[l] = om->n_slices[l] = om->n_chunks[l] = om->slab_offset[l] =
+            om->entries_per_slice[l] = om->bin_offset[l] = wgs[l] = 0;
     for (uint32_t l = 0; l < L; ++l) {
         const uint32_t size = desc->size[l], res = desc->resolution[l];
         const bool dense = (uint64_t)res * res * res <= (uint64_t)size;
-        const uint32_t max_epb = OWN_LDS_FLOATS / F;
+        const uint32_t max_epb = OWN_LDS_WORDS / F;
         uint32_t epb = max_epb;
         const uint32_t p2 = 1u << OWN_POW2_LOG2;
         if (!dense && (size & (size - 1)) == 0 && size >= p2 && p2 <= max_epb && res < p2) epb = p2;
         const uint32_t R = nsr_div_up(size, epb);
         uint32_t C = 1;
-        if (R < OWN_TARGET_WGS) C = (OWN_TARGET_WGS + R - 1) / R;  // few slices: split the samples instead
-        om->block_start[l] = nb;
+        if (R < OWN_TARGET_WGS) C = (OWN_TARGET_WGS + R - 1) / R;  // few slices: split the items instead
         om->n_slices[l] = R;
         om->n_chunks[l] = C;
         om->entries_per_slice[l] = epb;
         om->slab_offset[l] = (uint32_t)slab;
+        om->bin_offset[l] = bins;
+        bins += R;
         if (C > 1) slab += (uint64_t)C * size * F;
-        nb += R * C;
+        wgs[l] = R * C;
     }
-    for (uint32_t l = L; l <= NSR_MAX_LEVELS; ++l) om->block_start[l] = nb;
-    for (uint32_t l = L; l < NSR_MAX_LEVELS; ++l) om->n_slices[l] = om->n_chunks[l] = om->slab_offset[l] = om->entries_per_slice[l] = 0;
+    // longest-processing-time placement of whole levels onto the 8 XCDs
+    uint32_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool placed[NSR_MAX_LEVELS] = {};
+    for (uint32_t it = 0; it < L; ++it) {
+        uint32_t best = L;
+        for (uint32_t l = 0; l < L; ++l)
+            if (!placed[l] && (best == L || wgs[l] > wgs[best])) best = l;
+        uint32_t x = 0;
+        for (uint32_t k = 1; k < 8; ++k)
+            if (load[k] < load[x]) x = k;
+        placed[best] = true;
+        om->xcd_of_level[best] = x;
+        om->level_start[best] = load[x];
+        load[x] += wgs[best];
+    }
+    uint32_t per_xcd = 0;
+    for (uint32_t k = 0; k < 8; ++k) per_xcd = load[k] > per_xcd ? load[k] : per_xcd;
     *slab_floats = slab;
-    return nb;
+    *n_bins = bins;
+    return per_xcd * 8;
 }
 
 // row-major dy [n, stride] (half or float) -> level-major fp32 [L][n][F]; 64 samples x all columns per block
@@ -632,13 +770,15 @@ extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int 
 }
 
 
+// workspace (4-byte words): [slabs][level-major dy: L*F*n][counts | bin_start | cursors: n_bins each][items: L*8n]
 extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n)
 {
     if (!desc || check_desc(desc, "nsr_hashgrid_backward_params_workspace_floats")) return 0;
     OwnerMap om;
     uint64_t slab = 0;
-    make_owner_map(desc, &om, &slab);
-    return slab + (uint64_t)desc->n_levels * desc->n_features * n;  // [slabs | level-major dy]
+    uint32_t n_bins = 0;
+    make_owner_map(desc, &om, &slab, &n_bins);
+    return slab + (uint64_t)desc->n_levels * desc->n_features * n + 3ull * n_bins + (uint64_t)desc->n_levels * 8ull * n;
 }
 
 extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
@@ -649,40 +789,59 @@ extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy
     if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
     NSR_REQUIRE(grad_table && workspace, "nsr_hashgrid_backward_params_owner: grad_table / workspace is NULL");
     NSR_REQUIRE(n == 0 || (x && dy), "nsr_hashgrid_backward_params_owner: NULL pointer");
+    NSR_REQUIRE(n < (1u << 28), "nsr_hashgrid_backward_params_owner: at most 2^28 - 1 samples per call");
     NSR_REQUIRE(dy_layout >= 0 && dy_layout <= 2, "nsr_hashgrid_backward_params_owner: dy_layout must be 0 (half "
                 "row-major), 1 (float row-major) or 2 (float level-major)");
     const uint32_t F = desc->n_features, L = desc->n_levels;
+    hipStream_t st = (hipStream_t)stream;
     OwnerMap om;
     uint64_t slab_floats = 0;
-    const uint32_t nb = make_owner_map(desc, &om, &slab_floats);
+    uint32_t n_bins = 0;
+    const uint32_t nb = make_owner_map(desc, &om, &slab_floats, &n_bins);
+    for (uint32_t l = 0; l < L; ++l)
+        NSR_REQUIRE(om.n_slices[l] <= (uint32_t)OWN_MAX_SLICES, "nsr_hashgrid_backward_params_owner: level too large");
+    float *lm = workspace + slab_floats;
+    uint32_t *counts = reinterpret_cast<uint32_t *>(lm + (uint64_t)L * F * n);
+    uint32_t *bin_start = counts + n_bins, *cursors = bin_start + n_bins, *items = cursors + n_bins;
     const float *dy_lm = (const float *)dy;
     if (dy_layout != 2 && n > 0) {
-        float *lm = workspace + slab_floats;
         const uint32_t C = L * F;
         const size_t lds = 64 * (C + 1) * sizeof(float);
         DISPATCH_F(F, {
             if (dy_layout == 1)
-                hipLaunchKernelGGL((k_dy_to_level_major<F, true>), dim3(nsr_div_up(n, 64)), dim3(256), lds,
-                                   (hipStream_t)stream, dy, dy_stride, lm, n, L);
+                hipLaunchKernelGGL((k_dy_to_level_major<F, true>), dim3(nsr_div_up(n, 64)), dim3(256), lds, st, dy,
+                                   dy_stride, lm, n, L);
             else
-                hipLaunchKernelGGL((k_dy_to_level_major<F, false>), dim3(nsr_div_up(n, 64)), dim3(256), lds,
-                                   (hipStream_t)stream, dy, dy_stride, lm, n, L);
+                hipLaunchKernelGGL((k_dy_to_level_major<F, false>), dim3(nsr_div_up(n, 64)), dim3(256), lds, st, dy,
+                                   dy_stride, lm, n, L);
         });
         NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(transpose)");
         dy_lm = lm;
     }
-    const size_t lds = OWN_LDS_FLOATS * sizeof(float);
+    // bin the (sample, corner pair) items by owning slice: count, scan, fill
+    NSR_REQUIRE(hipMemsetAsync(counts, 0, n_bins * sizeof(uint32_t), st) == hipSuccess,
+                "nsr_hashgrid_backward_params_owner: hipMemsetAsync failed");
+    if (n > 0) {
+        const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK), L);
+        hipLaunchKernelGGL((k_own_bin<false>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
+                           bin_start, cursors, items, om, *desc);
+        hipLaunchKernelGGL(k_own_bin_scan, dim3(L), dim3(256), 0, st, counts, bin_start, cursors, om);
+        hipLaunchKernelGGL((k_own_bin<true>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
+                           bin_start, cursors, items, om, *desc);
+        NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(bin)");
+    }
+    const size_t lds = OWN_LDS_WORDS * sizeof(unsigned long long);
     DISPATCH_F(F, {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_grid_backward_owner<F>), dim3(nb), dim3(OWN_BLOCK), lds, (hipStream_t)stream, x, dy_lm,
-                           grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc);
+        hipLaunchKernelGGL((k_grid_backward_owner<F>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
+                           bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc);
         if (slab_floats > 0)
-            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(32, L), dim3(256), 0, (hipStream_t)stream, workspace,
-                               grad_table, accumulate, om, *desc);
+            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(32, L), dim3(256), 0, st, workspace, grad_table,
+                               accumulate, om, *desc);
     });
     NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner");
     return NSR_OK;

@@ -168,7 +168,7 @@ extern "C" int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, u
     out->d_enc = c.take(S * C * 4);
     out->partials = c.take(4 * (nsr_mlp_backward_workspace_floats(&d->mlp_color, n_kept) +
                                 nsr_mlp_backward_workspace_floats(&d->mlp_density, n_kept)));
-    out->grid_ws = c.take(4 * nsr_hashgrid_backward_params_workspace_floats(&d->grid, 0));  // slabs only (level-major dy)
+    out->grid_ws = c.take(4 * nsr_hashgrid_backward_params_workspace_floats(&d->grid, n_kept));
     out->total_bytes = c.off;
     return NSR_OK;
 }
@@ -220,8 +220,9 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
         rb[na] = 128;
     }
     NSR_REQUIRE(F * 2 % 4 == 0, "nsr_nerf_main_pass: n_features_per_level must be even");
-    NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, dirs,
-                                        (int64_t *)(ws + L.ray_indices), n_rays, stream));
+    if (S > 0)  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
+        NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, dirs,
+                                            (int64_t *)(ws + L.ray_indices), n_rays, stream));
     NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, stream));
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);

@@ -58,7 +58,7 @@ class FusedNeRFStep:
         return _ops.ray_march_begin(rays_o, rays_d, t_min, t_max, grid.roi_aabb, grid.binary,
                                     ContractionType.AABB.value, m.render_step_size, 0.0, roi_host=grid._roi_host)
 
-    def march_and_prune(self, rays_o, rays_d, keep_rows, handle=None, after_prune=None):
+    def march_and_prune(self, rays_o, rays_d, keep_rows, handle=None, after_prune=None, before_sync=None):
         """ray_marching(..., sigma_fn) of models/nerf.py:82-93.  With ``keep_rows`` the sigma pass saves encodings and
         activations of ALL marched samples and the pruning copies the kept rows: the main pass re-encodes nothing.
         -> dict(packed, ri, t0, t1, M, [x01, dirs, enc, out1, acts1])"""
@@ -67,6 +67,8 @@ class FusedNeRFStep:
         packed, ri, t0, t1 = _ops.ray_march_finish(handle)
         n_rays, M = rays_o.shape[0], ri.shape[0]
         if M == 0:
+            if before_sync is not None:
+                before_sync(None)
             if after_prune is not None:
                 after_prune(0)
             return dict(packed=packed, ri=ri, t0=t0, t1=t1, M=0)
@@ -83,6 +85,8 @@ class FusedNeRFStep:
         check(lib.nsr_visibility_prefix(ptr(out), out.stride(0), self.bias, ptr(t0), ptr(t1), ptr(packed), self.eps,
                                         ptr(kept), n_rays, s), "nsr_visibility_prefix")
         check(lib.nsr_pack_from_counts(ptr(kept), ptr(packed2), ptr(total), n_rays, s), "nsr_pack_from_counts")
+        if before_sync is not None:
+            before_sync(total)
         S = int(total.item())  # second (and last) host sync of the step
         if after_prune is not None:
             after_prune(S)  # e.g. the trainer launches the NEXT step's marching on a side stream right here
@@ -108,14 +112,18 @@ class FusedNeRFStep:
         return res
 
     def forward_backward(self, rays, gt_rgb, background, compute_grads=True, loss_scale=1.0, march_handle=None,
-                         after_prune=None, after_enqueue=None):
+                         after_prune=None, after_enqueue=None, before_sync=None):
+        """hooks: ``before_sync(total)`` runs right after the pruning pass is QUEUED (``total``: int32[1] device tensor
+        that will hold the kept-sample count, or None when nothing was marched) and before the host waits for it;
+        ``after_prune(S)`` runs once the host knows the count."""
         if self.native:
             return self._forward_backward_native(rays, gt_rgb, background, compute_grads, loss_scale, march_handle,
-                                                 after_prune)
+                                                 after_prune, before_sync)
         return self._forward_backward_python(rays, gt_rgb, background, compute_grads, loss_scale, march_handle,
-                                             after_prune, after_enqueue)
+                                             after_prune, after_enqueue, before_sync)
 
-    def _forward_backward_native(self, rays, gt_rgb, background, compute_grads, loss_scale, march_handle, after_prune):
+    def _forward_backward_native(self, rays, gt_rgb, background, compute_grads, loss_scale, march_handle, after_prune,
+                                 before_sync=None):
         """the same step with ONE C call per phase (nsr_nerf_prune_pass / nsr_nerf_main_pass, csrc/step.hip)"""
         m, ewn, tex, d = self.model, self.ewn, self.tex, self.desc
         dev = rays.device
@@ -140,10 +148,16 @@ class FusedNeRFStep:
                     check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1),
                                                   ptr(packed), ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2),
                                                   ptr(total), M, n_rays, s), "nsr_nerf_prune_pass")
+                    if before_sync is not None:
+                        before_sync(total)
                     S = _ops.read_count_when_ready(total)  # second (and last) host sync of the step
                 else:
                     meta.zero_()
+                    if before_sync is not None:
+                        before_sync(None)
                     S = 0
+                if after_prune is not None:
+                    after_prune(S)
             with _ops.timed("fused:main_pass"):
                 check(lib.nsr_nerf_main_layout(_byref(d), S, n_rays, _byref(self._ML)), "nsr_nerf_main_layout")
                 L = self._ML
@@ -162,12 +176,6 @@ class FusedNeRFStep:
                                              ptr(ewn.grid_slice(g1)) if compute_grads else None,
                                              ptr(g2) if compute_grads else None, ptr(ws), S, n_rays,
                                              int(bool(compute_grads)), s), "nsr_nerf_main_pass")
-            if after_prune is not None:
-                # AFTER the main pass is queued: whatever the hook does on the host (the trainer samples the next rays
-                # and launches their marching pass on a side stream) now overlaps ~0.5 ms of queued GPU work instead
-                # of leaving the main queue idle (measured: 220 us per step)
-                after_prune(S)
-
             def view(off, n, dtype, shape):
                 return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
 
@@ -180,7 +188,7 @@ class FusedNeRFStep:
                     "loss_acc": view(L.loss_acc, 2, F32, (2,)), "_workspace": ws}
 
     def _forward_backward_python(self, rays, gt_rgb, background, compute_grads=True, loss_scale=1.0, march_handle=None,
-                                 after_prune=None, after_enqueue=None):
+                                 after_prune=None, after_enqueue=None, before_sync=None):
         """-> dict(loss_acc, comp_rgb, opacity, depth, num_samples, weights, ray_indices, t_starts, t_ends).  Gradients
         of ``loss_scale * loss`` are ACCUMULATED into ``.grad`` of the MLP slices and OVERWRITE the hash-table slice."""
         m, ewn, tex = self.model, self.ewn, self.tex
@@ -189,7 +197,8 @@ class FusedNeRFStep:
         rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
         with torch.no_grad(), torch.cuda.device(dev):
             with _ops.timed("fused:march_prune"):
-                mp = self.march_and_prune(rays_o, rays_d, keep_rows=True, handle=march_handle, after_prune=after_prune)
+                mp = self.march_and_prune(rays_o, rays_d, keep_rows=True, handle=march_handle, after_prune=after_prune,
+                                          before_sync=before_sync)
             packed, ri, t0, t1, M = mp["packed"], mp["ri"], mp["t0"], mp["t1"], mp["M"]
             S = ri.shape[0]
             s = stream_ptr()
@@ -279,9 +288,13 @@ def gather_train_rays(dataset, n_rays, generator, background="random"):
     return rays, rgb, fg, bg
 
 
-def prepare_train_rays(dataset, n_rays, generator, model, background="random"):
+def prepare_train_rays(dataset, n_rays, generator, model, background="random", n_active=None):
     """ONE RNG call + ONE kernel: pixel choice, gather, get_rays, background blend, slab test, stratified jitter.
-    -> rays[n,6], rays_o, rays_d, rgb, fg, bg, t_min, t_max"""
+    -> rays[n,6], rays_o, rays_d, rgb, fg, bg, t_min, t_max
+
+    ``n_active`` (int32[1] on the device): only the first ``n_active[0]`` of the ``n_rays`` slots are live rays, the
+    rest are dead (no samples, outside the loss) -- the batch size is then a device-side value and this call never
+    needs the host to know it."""
     dev = dataset.all_images.device
     n_img, H, W = dataset.all_images.shape[0], dataset.h, dataset.w
     u = torch.rand((5, max(n_rays, 3)), device=dev, generator=generator)
@@ -296,5 +309,6 @@ def prepare_train_rays(dataset, n_rays, generator, model, background="random"):
         check(lib.nsr_prepare_train_rays(ptr(dataset.all_images), ptr(dataset.all_fg_masks), ptr(dataset.directions),
                                          ptr(dataset.all_c2w), ptr(u4), ptr(bg), n_img, H, W, int(dataset.apply_mask),
                                          ptr(model.scene_aabb), jitter, ptr(rays), ptr(ro), ptr(rd), ptr(rgb), ptr(fg),
-                                         ptr(t_min), ptr(t_max), n_rays, stream_ptr()), "nsr_prepare_train_rays")
+                                         ptr(t_min), ptr(t_max), n_rays, ptr(n_active), stream_ptr()),
+              "nsr_prepare_train_rays")
     return rays, ro, rd, rgb, fg, bg, t_min, t_max

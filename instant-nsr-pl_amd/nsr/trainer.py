@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 import tinycudann as tcnn
 from nsr_hip import ops as _ops
+from nsr_hip import check as _check, lib as _lib, ptr as _ptr, stream_ptr as _stream_ptr
 
 from .parallel import all_reduce_gradients, broadcast_parameters, shard_seed
 
@@ -72,7 +73,7 @@ class Trainer:
         other = [p for p in model.parameters() if id(p) not in tc_params]
         self.opt = FusedAdamW(tc, other)
         self.last = {}
-        self.fused, self._pending, self._side, self.pipeline_march = None, None, None, True
+        self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None
         if fused and config["name"] == "nerf":
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
@@ -113,56 +114,70 @@ class Trainer:
         return self.last
 
     def _train_step_fused(self):
-        """same step through nsr.fused.FusedNeRFStep (hand-chained backward, ~25 launches).
+        """same step through nsr.fused.FusedNeRFStep (hand-chained backward, ~40 launches).
 
         Marching depends only on the rays and the occupancy grid, not on the parameters, and it is a latency-bound
-        kernel that occupies ~3 % of the chip.  So the marching pass of step k+1 is launched on a SIDE STREAM as soon as
-        step k knows its sample count (which fixes the next ray count), and runs underneath step k's forward/backward/
-        optimizer.  Steps that refresh the occupancy grid (every 16th) march in order instead."""
+        kernel that occupies ~3 % of the chip.  So the marching pass of step k+1 runs on a SIDE STREAM underneath step
+        k's forward/backward/optimizer.  Its only input from step k is the dynamic ray count (systems/nerf.py:93-95),
+        which therefore lives ON THE DEVICE: the ray arrays always have ``max_train_num_rays`` slots, slots beyond the
+        count are dead rays, and a one-thread kernel behind step k's pruning pass updates the count.  The host can then
+        queue step k+1's marching before it has seen step k's sample count -- the GPU starts it the moment the pruning
+        pass retires.  Steps that refresh the occupancy grid (every 16th) march in order instead."""
         from .fused import FusedNeRFStep, prepare_train_rays
-        model, fused = self.model, self.fused
+        model, fused, cfg = self.model, self.fused, self.config
+        dynamic = bool(cfg["dynamic_ray_sampling"])
+        slots = cfg["max_train_num_rays"] if dynamic else self.train_num_rays
+        if self._n_rays_dev is None:
+            self._n_rays_dev = torch.tensor([self.train_num_rays], dtype=torch.int32, device=self.device)
         pending, self._pending = getattr(self, "_pending", None), None
         with _ops.timed("phase:occupancy_update"):
             model.update_step(0, self.global_step)
         if pending is None:
             with _ops.timed("phase:sample_rays"):
                 rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(
-                    self.dataset, self.train_num_rays, self.gen, model, self.config["background_color"])
+                    self.dataset, slots, self.gen, model, cfg["background_color"], n_active=self._n_rays_dev)
                 handle = fused.march_begin(ro, rd, t_min, t_max)
         else:
             rays, rgb, bg, handle = pending
         model.background_color = bg
-        next_updates_grid = self.config["grid_prune"] and (self.global_step + 1) % 16 == 0
+        n_live = min(self.train_num_rays, slots)  # host mirror of the device-side count for THIS batch
+        next_updates_grid = cfg["grid_prune"] and (self.global_step + 1) % 16 == 0
 
-        def after_prune(n_samples):
-            if self.config["dynamic_ray_sampling"] and n_samples > 0:  # systems/nerf.py:93-95
-                t = int(self.train_num_rays * (self.train_num_samples / n_samples))
-                self.train_num_rays = min(int(self.train_num_rays * 0.9 + t * 0.1), self.config["max_train_num_rays"])
-            launch_next_march()  # first thing after the sync: it is the longest pole of the NEXT step
-
-        def launch_next_march():
+        def before_sync(total):
+            # queued behind the pruning pass, before the host waits for its count
+            if dynamic and total is not None:
+                with torch.cuda.device(self.device):
+                    _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(self._n_rays_dev), int(self.train_num_samples),
+                                                     int(cfg["max_train_num_rays"]), _stream_ptr()),
+                           "nsr_update_ray_count")
             if not self.pipeline_march or next_updates_grid:
                 return
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
-                self._side.wait_stream(main)  # once: dataset + grid tensors exist.  NOT per step: the marching pass
-                # reads only rays and the (unchanged until the next refresh) occupancy bricks, never the parameters,
-                # and waiting on `main` here would serialise it behind this step's backward.
+            ev = torch.cuda.Event()
+            ev.record(main)             # covers everything up to the pruning pass + count update of THIS step --
+            self._side.wait_event(ev)   # not its main pass / backward / optimizer, which are queued later
             with torch.cuda.stream(self._side):
                 nrays, ro, rd, nrgb, _, nbg, t_min, t_max = prepare_train_rays(
-                    self.dataset, self.train_num_rays, self.gen, model, self.config["background_color"])
+                    self.dataset, slots, self.gen, model, cfg["background_color"], n_active=self._n_rays_dev)
                 h = fused.march_begin(ro, rd, t_min, t_max)
             for x in (nrays, nrgb, nbg):
                 x.record_stream(main)
             self._pending = (nrays, nrgb, nbg, h)
 
-        res = fused.forward_backward(rays, rgb, bg, march_handle=handle, after_prune=after_prune)
+        def after_prune(n_samples):
+            if dynamic and n_samples > 0:  # systems/nerf.py:93-95 (the device runs the same arithmetic)
+                t = int(self.train_num_rays * (self.train_num_samples / n_samples))
+                self.train_num_rays = min(int(self.train_num_rays * 0.9 + t * 0.1), cfg["max_train_num_rays"])
+
+        res = fused.forward_backward(rays, rgb, bg, march_handle=handle, after_prune=after_prune,
+                                     before_sync=before_sync)
         n_samples = res["num_samples"]  # already on the host (the pruning sync): no extra .item()
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
             self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
         self.global_step += 1
-        self.last = {"loss": FusedNeRFStep.loss_value(res), "n_rays": rays.shape[0], "n_samples": n_samples}
+        self.last = {"loss": FusedNeRFStep.loss_value(res), "n_rays": n_live, "n_samples": n_samples}
         return self.last

@@ -92,7 +92,8 @@ SIGNATURES = {
     "nsr_smooth_l1_valid": [_P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid_backward": [_P, _P, _P, _P, _F, _P, _U, _P],
     "nsr_gather_train_rays": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _U, _P],
-    "nsr_prepare_train_rays": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_prepare_train_rays": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P, _P, _U, _P, _P],
+    "nsr_update_ray_count": [_P, _P, _I, _I, _P],
     "nsr_ray_aabb_intersect": [_P, _P, _P, _P, _P, _U, _P],
     "nsr_ray_march_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _U, _P],
     "nsr_ray_march_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _U, _P],

@@ -148,3 +148,69 @@ def test_prepare_train_rays_matches_separate_ops():
     assert torch.allclose(rgb, c * f[:, None] + bg * (1 - f[:, None]), atol=1e-6) and torch.equal(fg, f)
     a, b = ops.ray_aabb_intersect(ro.contiguous(), rd.contiguous(), model.scene_aabb)  # oracle-checked kernel
     assert torch.equal(t_max, b) and torch.equal(t_min, a + u[3] * model.render_step_size)
+
+
+def test_dead_ray_slots_do_not_change_the_step():
+    """a batch padded with dead slots (n_active < slots) == the same live rays alone: samples, colours, loss"""
+    import nsr
+    from nsr.scene import SyntheticBlender
+    from nsr.fused import FusedNeRFStep, prepare_train_rays
+    torch.manual_seed(0)
+    data = SyntheticBlender(n_images=4, w=64, h=64, device="cuda", seed=0)
+    model = nsr.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
+    model.update_step(0, 0)  # fills the occupancy grid
+    fused = FusedNeRFStep(model)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    n_active = torch.tensor([600], dtype=torch.int32, device="cuda")
+    rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(data, 1000, gen, model, n_active=n_active)
+    gen.manual_seed(3)
+    rays_all = prepare_train_rays(data, 1000, gen, model)
+    assert torch.equal(rays[:600], rays_all[0][:600]) and torch.equal(t_min[:600], rays_all[6][:600])
+    assert bool((t_min[600:] == 1e10).all()) and bool((t_max[600:] == 1e10).all()) and bool((fg[600:] == 0).all())
+    a = fused.forward_backward(rays, rgb, bg, compute_grads=False,
+                               march_handle=fused.march_begin(ro, rd, t_min, t_max))
+    b = fused.forward_backward(rays[:600].contiguous(), rgb[:600].contiguous(), bg, compute_grads=False,
+                               march_handle=fused.march_begin(ro[:600].contiguous(), rd[:600].contiguous(),
+                                                              t_min[:600].contiguous(), t_max[:600].contiguous()))
+    assert a["num_samples"] == b["num_samples"] and a["num_marched"] == b["num_marched"] and a["num_samples"] > 0
+    assert torch.equal(a["comp_rgb"][:600], b["comp_rgb"]) and bool((a["opacity"][600:] == 0).all())
+    assert torch.equal(a["loss_acc"], b["loss_acc"])
+
+
+def test_device_ray_count_matches_python_arithmetic():
+    """nsr_update_ray_count == systems/nerf.py:93-95 evaluated by Python, bit for bit"""
+    import random
+    from nsr_hip import check, lib, ptr, stream_ptr
+    rnd = random.Random(0)
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(200):
+        n, s = rnd.randint(1, 8192), rnd.choice([0, rnd.randint(1, 2_000_000)])
+        target, mx = rnd.choice([2 ** 18, 256 * 1024, 123457]), rnd.choice([8192, 4096, 100000])
+        n_dev.fill_(n)
+        s_dev.fill_(s)
+        check(lib.nsr_update_ray_count(ptr(s_dev), ptr(n_dev), target, mx, stream_ptr()), "nsr_update_ray_count")
+        want = n
+        if s > 0:
+            t = int(n * (target / s))
+            want = min(int(n * 0.9 + t * 0.1), mx)
+        assert int(n_dev.item()) == want, (n, s, target, mx)
+
+
+def test_trainer_device_ray_count_tracks_host_mirror():
+    import nsr
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    torch.manual_seed(0)
+    cfg = dict(nsr.configs.get("nerf-blender"))
+    cfg["train_num_rays"], cfg["max_train_num_rays"] = 256, 2048  # the controller has to move
+    model = nsr.NeRFModel(cfg).cuda().train()
+    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
+    tr = Trainer(model, data, cfg, fused=True, seed=3)
+    seen = set()
+    for _ in range(40):
+        out = tr.train_step()
+        seen.add(out["n_rays"])
+        torch.cuda.synchronize()
+        assert int(tr._n_rays_dev.item()) == tr.train_num_rays
+    assert len(seen) > 3
