@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: march in order instead of on the side stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,6 +98,7 @@ def main():
     model = nsr.NeRFModel(cfg).to(dev).train()
     data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
     tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42)
+    tr.pipeline_march = not args.no_pipeline
 
     def sync():
         if world > 1:

@@ -213,12 +213,22 @@ k_grid_backward_params(const float *__restrict__ x, const void *__restrict__ dy,
 // as fp32 with plain coalesced 16-B stores.  ~750 workgroups cover L=16,T=2^19,F=2; each grad entry is written exactly once, so the
 // 50 MB gradient needs no memset either (accumulate=0).  dy is read level-major ([L][N][F], 8-B coalesced).
 // ------------------------------------------------------------------------------------------------
-constexpr int OWN_BLOCK = 1024;
-constexpr int OWN_LDS_WORDS = 20480;    // 64-bit accumulators in 160 KiB: the whole LDS of a CU
-constexpr int OWN_POW2_LOG2 = 13;       // hashed levels: 8192-entry slices (128 KiB at F=2) -> owner = hash bits
+#ifndef NSR_OWN_BLOCK
+#define NSR_OWN_BLOCK 1024
+#endif
+#ifndef NSR_OWN_LOG2
+#define NSR_OWN_LOG2 13
+#endif
+#ifndef NSR_OWN_BIN_SPT
+#define NSR_OWN_BIN_SPT 4
+#endif
+constexpr int OWN_BLOCK = NSR_OWN_BLOCK;
+constexpr int OWN_POW2_LOG2 = NSR_OWN_LOG2;            // hashed levels: 8192-entry slices (128 KiB at F=2) -> owner = hash bits
+constexpr int OWN_LDS_WORDS = 2 << NSR_OWN_LOG2;       // 64-bit accumulators (measured: 2^13 119 us, 2^12 133 us, 2^11 124 us)
 constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decomposition aims for
 constexpr int OWN_MAX_SLICES = 2048;    // per level (T = 2^24 at 8192-entry slices)
-constexpr int OWN_BIN_BLOCK = 256;      // samples per block of the two binning passes
+constexpr int OWN_BIN_BLOCK = 256;      // threads per block of the two binning passes
+constexpr int OWN_BIN_SPT = NSR_OWN_BIN_SPT;  // samples per thread: fewer, larger blocks -> fewer global range reservations
 constexpr float OWN_FIX_SCALE = 68719476736.f;          // 2^36: accumulators are Q27.36 fixed point
 constexpr float OWN_FIX_INV = 1.f / 68719476736.f;
 
@@ -278,7 +288,7 @@ __device__ __forceinline__ bool own_is_pow2(const LevelGeom &g, uint32_t epb)
 
 // pass 1 (FILL = false): counts[bin] = number of items per (level, slice).
 // pass 2 (FILL = true):  items[level][bin_start + ...] = item words; a block reserves one contiguous range per bin.
-// grid (ceil(n / OWN_BIN_BLOCK), L)
+// grid (ceil(n / (OWN_BIN_BLOCK * OWN_BIN_SPT)), L)
 template <bool FILL>
 __global__ void __launch_bounds__(OWN_BIN_BLOCK)
 k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t *__restrict__ counts,
@@ -293,21 +303,22 @@ k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t
     const bool pow2 = own_is_pow2(g, epb);
     for (uint32_t s = threadIdx.x; s < R; s += OWN_BIN_BLOCK) hist[s] = 0u;
     __syncthreads();
-    const uint32_t i = blockIdx.x * OWN_BIN_BLOCK + threadIdx.x;
-    uint32_t slice[8], rank[8];
-    int n_items = 0;
-    if (i < n) {
-        const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
+    uint32_t slice[OWN_BIN_SPT][8], rank[OWN_BIN_SPT][8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const PairSlices p = pair_slices(g, c, k, epb, pow2);
-            // slot 2k: the pair (or its x0 half), slot 2k+1: the x0+1 half of a straddling pair
-            slice[2 * k] = p.s0;
-            rank[2 * k] = atomicAdd(&hist[p.s0], 1u);
-            slice[2 * k + 1] = p.s1 != p.s0 ? p.s1 : 0xffffffffu;
-            if (p.s1 != p.s0) rank[2 * k + 1] = atomicAdd(&hist[p.s1], 1u);
+    for (int u = 0; u < OWN_BIN_SPT; ++u) {
+        const uint32_t i = (blockIdx.x * OWN_BIN_SPT + u) * OWN_BIN_BLOCK + threadIdx.x;
+        if (i < n) {
+            const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const PairSlices p = pair_slices(g, c, k, epb, pow2);
+                // slot 2k: the pair (or its x0 half), slot 2k+1: the x0+1 half of a straddling pair
+                slice[u][2 * k] = p.s0;
+                rank[u][2 * k] = atomicAdd(&hist[p.s0], 1u);
+                slice[u][2 * k + 1] = p.s1 != p.s0 ? p.s1 : 0xffffffffu;
+                if (p.s1 != p.s0) rank[u][2 * k + 1] = atomicAdd(&hist[p.s1], 1u);
+            }
         }
-        n_items = 8;
     }
     __syncthreads();
     if constexpr (!FILL) {
@@ -319,11 +330,17 @@ k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t
             if (hist[s]) hist[s] = bin_start[bin0 + s] + atomicAdd(&cursors[bin0 + s], hist[s]);
         __syncthreads();
         uint32_t *dst = items + (uint64_t)level * n * 8ull;
-        for (int q = 0; q < n_items; ++q) {
-            if (slice[q] == 0xffffffffu) continue;
-            const bool straddle = slice[q | 1] != 0xffffffffu;
-            const uint32_t mode = !straddle ? 0u : ((q & 1) ? 2u : 1u);
-            dst[hist[slice[q]] + rank[q]] = (i << 4) | ((uint32_t)(q >> 1) << 2) | mode;
+#pragma unroll
+        for (int u = 0; u < OWN_BIN_SPT; ++u) {
+            const uint32_t i = (blockIdx.x * OWN_BIN_SPT + u) * OWN_BIN_BLOCK + threadIdx.x;
+            if (i >= n) continue;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (slice[u][q] == 0xffffffffu) continue;
+                const bool straddle = slice[u][q | 1] != 0xffffffffu;
+                const uint32_t mode = !straddle ? 0u : ((q & 1) ? 2u : 1u);
+                dst[hist[slice[u][q]] + rank[u][q]] = (i << 4) | ((uint32_t)(q >> 1) << 2) | mode;
+            }
         }
     }
 }
@@ -822,7 +839,7 @@ extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy
     NSR_REQUIRE(hipMemsetAsync(counts, 0, n_bins * sizeof(uint32_t), st) == hipSuccess,
                 "nsr_hashgrid_backward_params_owner: hipMemsetAsync failed");
     if (n > 0) {
-        const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK), L);
+        const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK * OWN_BIN_SPT), L);
         hipLaunchKernelGGL((k_own_bin<false>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
                            bin_start, cursors, items, om, *desc);
         hipLaunchKernelGGL(k_own_bin_scan, dim3(L), dim3(256), 0, st, counts, bin_start, cursors, om);

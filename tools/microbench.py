@@ -80,3 +80,32 @@ if which in ("all", "march"):
             h = ops.ray_march_begin(ro, rd, tmin, tmax, roi, binary, 0, 0.00507421875, 0.0, roi_host=[-1.5] * 3 + [1.5] * 3, method=meth)
             return h
         print(f"march count [{meth}] 8192 rays: {bench(f):.1f} us; samples={int(ops.ray_march_finish(f())[1].shape[0])}")
+if which == "gridreal":
+    # the table backward on the sample distribution of a trained step (surface-concentrated), cumulative over levels
+    import nsr
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    from nsr.fused import prepare_train_rays
+    torch.manual_seed(42)
+    cfg = nsr.configs.get("nerf-blender")
+    model = nsr.NeRFModel(cfg).cuda().train()
+    data = SyntheticBlender(n_images=100, w=800, h=800, device="cuda", seed=0)
+    tr = Trainer(model, data, cfg, seed=42)
+    for _ in range(300): tr.train_step()
+    torch.cuda.synchronize()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(data, 8192, gen, model)
+    with torch.no_grad():
+        mp = tr.fused.march_and_prune(ro, rd, keep_rows=True, handle=tr.fused.march_begin(ro, rd, t_min, t_max))
+    x = mp["x01"].contiguous()
+    n = x.shape[0]
+    print("kept samples", n, "marched", mp["M"])
+    dy = torch.randn(16, n, 2, device="cuda")
+    g = torch.empty(gd.n_entries * 2, device="cuda")
+    prev = 0.0
+    for mc in (0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16):
+        t = bench(lambda: ops.hashgrid_backward_params(x, dy, g, gd, mask_count=mc, accumulate=False, level_major=True))
+        print(f"levels < {mc:2d}: {t:7.1f} us  (+{t - prev:6.1f})")
+        prev = t
+    xr = torch.rand_like(x)
+    print(f"uniform-random x, all levels: {bench(lambda: ops.hashgrid_backward_params(xr, dy, g, gd, accumulate=False, level_major=True)):.1f} us")
