@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: march in order instead of on the side stream")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="diagnostic: the step variant that reads its sample counts back to the host (two syncs/step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +99,7 @@ def main():
     cfg = nsr.configs.get("nerf-blender")
     model = nsr.NeRFModel(cfg).to(dev).train()
     data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
-    tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42)
+    tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42, async_mode=not args.sync_steps)
     tr.pipeline_march = not args.no_pipeline
 
     def sync():
@@ -109,15 +111,28 @@ def main():
         tr.train_step()
     sync()
     ops.profile_begin()  # HIP events around the hash-grid / MLP launches of the timed steps (torch's current stream)
+    c0 = tr.counters() if tr.async_mode else None  # device-side totals (reading them synchronises: outside the clock)
+    sync()
     t0 = time.perf_counter()
-    n_samples = n_rays = 0
+    n_samples = n_rays = n_marched = 0
     for _ in range(args.steps):
         st = tr.train_step()
-        n_samples += st["n_samples"]
-        n_rays += st["n_rays"]
+        if not tr.async_mode:
+            n_samples += st["n_samples"]
+            n_rays += st["n_rays"]
     sync()
     dt = time.perf_counter() - t0
     prof = ops.profile_end()
+    if tr.async_mode:
+        c1 = tr.counters()
+        n_samples, n_rays = c1["samples"] - c0["samples"], c1["rays"] - c0["rays"]
+        n_marched = c1["marched"] - c0["marched"]
+        if c1["truncated"] != c0["truncated"]:
+            raise SystemExit("sample buffers overflowed inside the timed region: the measurement is invalid")
+        # the C orchestration logs buffer CAPACITIES as launch sizes; the live counts are these device-side totals
+        live = {"hashgrid_forward": n_marched, "mlp_forward_h1": n_marched, "hashgrid_backward_params": n_samples,
+                "mlp_forward_h2": n_samples, "mlp_backward_h1": n_samples, "mlp_backward_h2": n_samples}
+        prof = {k: ((v[0], v[1], float(live[k])) if k in live else v) for k, v in prof.items()}
 
     tot = torch.tensor([dt, float(n_samples), float(n_rays)], dtype=torch.float64, device=dev)
     if world > 1:

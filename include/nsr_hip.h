@@ -67,7 +67,12 @@ int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uin
 /* same with the output optionally LEVEL-MAJOR ([L][n][F] halfs; y_stride ignored): every wavefront then stores 64*F
  * consecutive halfs instead of 64 scattered F-half pieces (the fused path's layout; nsr_mlp_forward_ex reads it) */
 int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
-                            int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
+                            int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
+                            const int32_t *n_dev, void *stream);
+
+/* DEVICE-SIDE ROW COUNTS.  Entry points with an (n, n_dev) pair launch for the CAPACITY n and use n for every array
+ * stride; when n_dev (device int32[1]) is not NULL only the first min(*n_dev, n) rows are live.  A whole training step
+ * can then be queued without the host ever reading a sample count (csrc/step.hip, nsr/fused.py). */
 
 /* grad_table[n_entries*F] (fp32, accumulate) += scatter(dy).  dy_is_f32: 0 = half, 1 = float.
  * grad_scale multiplies dy on load (pass 1.0f). */
@@ -84,7 +89,8 @@ int nsr_hashgrid_backward_params(const float *x, const void *dy, int dy_is_f32, 
 uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n);
 int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
                                        float *grad_table, float *workspace, uint32_t n, uint32_t level_mask_count,
-                                       float grad_scale, int accumulate, const NsrGridDesc *desc, void *stream);
+                                       float grad_scale, int accumulate, const NsrGridDesc *desc, const int32_t *n_dev,
+                                       void *stream);
 
 /* dx[n,3] (fp32) = (d y / d x)^T dy  -- the NeuS analytic normal, models/geometry.py:177-180 */
 int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
@@ -133,7 +139,7 @@ int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, const nsr_ha
 /* x_level_major_features = F > 0: x is the level-major fp16 encoding [n_in/F][n][F] (x_is_f32 must be 0) */
 int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride, uint32_t x_level_major_features,
                        const nsr_half *weights, nsr_half *out, nsr_half *acts, uint32_t n, const NsrMlpDesc *desc,
-                       void *stream);
+                       const int32_t *n_dev, void *stream);
 
 /* dout: [n, dout_stride] half/float grads w.r.t. the (activated) outputs; out: forward outputs (needed
  * for the sigmoid derivative, may be NULL for NSR_ACT_NONE); x/acts as given to / saved by forward.
@@ -156,7 +162,7 @@ int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride,
                         uint32_t x_level_major_features, const nsr_half *acts,
                         const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                         uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
-                        const NsrMlpDesc *desc, void *stream);
+                        const NsrMlpDesc *desc, const int32_t *n_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * nerfacc 0.3.3 kernels
@@ -206,6 +212,11 @@ int nsr_ray_march_bricks_write(const float *rays_o, const float *rays_d, const f
 /* exclusive scan of num_steps -> packed_info[n_rays,2]; *total (device int32[1]) <- sum */
 int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
                          void *stream);
+/* ... for fixed-size sample buffers: with capacity > 0 the packed ranges are truncated to `capacity` samples in total
+ * (*total <- min(sum, capacity)); stats (device int32[6], 8-byte aligned, may be NULL): [0] last unclamped sum,
+ * [1] largest sum so far (atomic max), [2] number of truncated launches, [4..5] uint64 running sum of the sums */
+int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
+                                uint32_t capacity, int32_t *stats, void *stream);
 /* packed_info[n_rays,2] from sorted ray_indices[n] (binary search per ray) */
 int nsr_pack_info(const int64_t *ray_indices, int32_t *packed_info, uint32_t n, uint32_t n_rays, void *stream);
 
@@ -275,7 +286,7 @@ int nsr_neus_alpha_backward(const float *sdf, const float *normal, const float *
 /* x01 = contract_to_unisphere(o[r] + d[r]*(t0+t1)/2); dirs_out (may be NULL) = d[r]   (nerf.py:66-69,95-99) */
 int nsr_sample_positions_unit(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
                               const float *t_starts, const float *t_ends, float radius, int contraction, float *x01,
-                              float *dirs_out, uint32_t n, void *stream);
+                              float *dirs_out, uint32_t n, const int32_t *n_dev, void *stream);
 /* kept_counts[r] = number of leading samples of ray r with transmittance >= early_stop_eps, where alpha comes from
  * trunc_exp(mlp_out[:,0] + density_bias) -- nerfacc's render_visibility with alpha_thre == 0 (nerf.py:82-93) */
 int nsr_visibility_prefix(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
@@ -298,7 +309,7 @@ int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed
                                 void *stream);
 /* tex_in[n,32] (half) = [mlp_out[:, :16] | SH4((dirs+1)/2)]   (texture.py:24-26) */
 int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in, uint32_t n,
-                      void *stream);
+                      const int32_t *n_dev, void *stream);
 /* density = exp(mlp_out[:,0] + bias); weights/trans [n]; comp_rgb[R,3] = sum w*rgb + background*(1-opacity)
  * (nerf.py:105-109); rgb: half rows of rgb_stride, first 3 columns */
 int nsr_composite_forward(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
@@ -334,9 +345,10 @@ int nsr_prepare_train_rays(const float *images, const float *masks, const float 
 /* n_active (device, may be NULL = all n): slots >= *n_active become DEAD rays (t_min = t_max = 1e10: no samples,
  * opacity 0, outside the loss), so the dynamic batch size of systems/nerf.py:93-95 can live on the device:
  *   t = int(n_rays * (target_samples / n_samples)); n_rays = min(int(n_rays * 0.9 + t * 0.1), max_rays)
- * in double precision (Python's arithmetic); n_samples <= 0 leaves n_rays unchanged. */
+ * in double precision (Python's arithmetic); n_samples <= 0 or target_samples == 0 leaves n_rays unchanged.
+ * rays_accum (device int64[1], may be NULL) += the ray count of THIS batch (read before the update). */
 int nsr_update_ray_count(const int32_t *n_samples, int32_t *n_rays, int32_t target_samples, int32_t max_rays,
-                         void *stream);
+                         int64_t *rays_accum, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native orchestration of the fused NeRF training step (csrc/step.hip): one C call per PHASE issues all of its
@@ -376,20 +388,24 @@ void nsr_profile_enable(int on);
 int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches, uint64_t *units);
 
 int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marched, NsrNerfPruneLayout *out);
-/* sigma pass over all marched samples -> kept_counts[n_rays], packed_kept[n_rays,2], total_kept[1] (device) */
+/* sigma pass over all marched samples -> kept_counts[n_rays], packed_kept[n_rays,2], total_kept[1] (device).
+ * n_marched_dev (may be NULL): device-side number of marched samples, n_marched then being the buffer capacity;
+ * kept_capacity / kept_stats: see nsr_pack_from_counts_capped (0 / NULL: unlimited, no statistics). */
 int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d, const int64_t *ray_indices,
                         const float *t_starts, const float *t_ends, const int32_t *packed_info, const nsr_half *table,
                         const nsr_half *w_density, void *workspace, int32_t *kept_counts, int32_t *packed_kept,
-                        int32_t *total_kept, uint32_t n_marched, uint32_t n_rays, void *stream);
+                        int32_t *total_kept, uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
+                        uint32_t kept_capacity, int32_t *kept_stats, void *stream);
 int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, uint32_t n_rays, NsrNerfMainLayout *out);
 /* forward + loss (+ backward when compute_grads): gradients are ADDED to grad_density_mlp / grad_color_mlp and
- * OVERWRITE grad_table; t_starts/t_ends/packed_marched describe the marched samples, packed_kept the kept ones */
+ * OVERWRITE grad_table; t_starts/t_ends/packed_marched describe the marched samples, packed_kept the kept ones.
+ * n_kept_dev (may be NULL): device-side number of kept samples, n_kept (and n_marched) then being buffer capacities */
 int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
                        const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
                        const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
                        const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp, float *grad_table,
                        float *grad_color_mlp, void *workspace, uint32_t n_kept, uint32_t n_rays, int compute_grads,
-                       void *stream);
+                       const int32_t *n_kept_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:

@@ -25,10 +25,10 @@ __global__ void __launch_bounds__(EW_BLOCK)
 k_sample_positions_unit(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                         const int64_t *__restrict__ ray_indices, const float *__restrict__ t0,
                         const float *__restrict__ t1, float radius, int type, float *__restrict__ x01,
-                        float *__restrict__ dirs, uint32_t n)
+                        float *__restrict__ dirs, uint32_t n, const int32_t *__restrict__ n_dev)
 {
     const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= live_count(n, n_dev)) return;
     const int64_t r = ray_indices[i];
     const float tm = (t0[i] + t1[i]) / 2.f;
     const float den = radius - (-radius);
@@ -157,10 +157,10 @@ k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__
 // tex_in[n,32] half = [ mlp_out[:, :16] | SH4((d+1)/2) ]  (the fp16 feature IS what .float() then fp16-cast returns)
 __global__ void __launch_bounds__(EW_BLOCK)
 k_texture_input(const __half *__restrict__ mlp_out, uint32_t stride, const float *__restrict__ dirs,
-                __half *__restrict__ tex_in, uint32_t n)
+                __half *__restrict__ tex_in, uint32_t n, const int32_t *__restrict__ n_dev)
 {
     const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= live_count(n, n_dev)) return;
     const uint4 *src = reinterpret_cast<const uint4 *>(mlp_out + (uint64_t)i * stride);
     uint4 *dst = reinterpret_cast<uint4 *>(tex_in + (uint64_t)i * 32);
     dst[0] = src[0];
@@ -443,11 +443,12 @@ k_prepare_train_rays(const float *__restrict__ images, const float *__restrict__
 // systems/nerf.py:93-95 on the device, in the double arithmetic Python uses:
 //   t = int(n * (target / S));  n = min(int(n * 0.9 + t * 0.1), max)
 __global__ void k_update_ray_count(const int32_t *__restrict__ n_samples, int32_t *__restrict__ n_rays,
-                                   int32_t target_samples, int32_t max_rays)
+                                   int32_t target_samples, int32_t max_rays, long long *__restrict__ rays_accum)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (rays_accum) *rays_accum += (long long)*n_rays;  // rays of THIS batch, before the update
     const int32_t s = *n_samples;
-    if (s <= 0) return;
+    if (s <= 0 || target_samples <= 0) return;
     const double n = (double)*n_rays;
     const double t = (double)(long long)(n * ((double)target_samples / (double)s));
     const long long v = (long long)(n * 0.9 + t * 0.1);
@@ -461,14 +462,14 @@ __global__ void k_update_ray_count(const int32_t *__restrict__ n_samples, int32_
 
 extern "C" int nsr_sample_positions_unit(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
                                          const float *t_starts, const float *t_ends, float radius, int contraction,
-                                         float *x01, float *dirs_out, uint32_t n, void *stream)
+                                         float *x01, float *dirs_out, uint32_t n, const int32_t *n_dev, void *stream)
 {
     NSR_REQUIRE(contraction == NSR_CONTRACT_AABB || contraction == NSR_CONTRACT_UN_BOUNDED_SPHERE,
                 "nsr_sample_positions_unit: contraction type %d not implemented", contraction);
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(rays_o && rays_d && ray_indices && t_starts && t_ends && x01, "nsr_sample_positions_unit: NULL pointer");
     hipLaunchKernelGGL(k_sample_positions_unit, EW_GRID(n), rays_o, rays_d, ray_indices, t_starts, t_ends, radius,
-                       contraction, x01, dirs_out, n);
+                       contraction, x01, dirs_out, n, n_dev);
     NSR_CHECK_LAUNCH("nsr_sample_positions_unit");
     return NSR_OK;
 }
@@ -498,12 +499,12 @@ extern "C" int nsr_copy_ray_prefixes(const int32_t *packed_old, const int32_t *p
 }
 
 extern "C" int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in,
-                                 uint32_t n, void *stream)
+                                 uint32_t n, const int32_t *n_dev, void *stream)
 {
     NSR_REQUIRE(stride >= 16 && (stride & 7u) == 0, "nsr_texture_input: feature rows must be >= 16 halfs, 16-B aligned");
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(mlp_out && dirs && tex_in, "nsr_texture_input: NULL pointer");
-    hipLaunchKernelGGL(k_texture_input, EW_GRID(n), (const __half *)mlp_out, stride, dirs, (__half *)tex_in, n);
+    hipLaunchKernelGGL(k_texture_input, EW_GRID(n), (const __half *)mlp_out, stride, dirs, (__half *)tex_in, n, n_dev);
     NSR_CHECK_LAUNCH("nsr_texture_input");
     return NSR_OK;
 }
@@ -628,12 +629,12 @@ extern "C" int nsr_prepare_train_rays(const float *images, const float *masks, c
 }
 
 extern "C" int nsr_update_ray_count(const int32_t *n_samples, int32_t *n_rays, int32_t target_samples, int32_t max_rays,
-                                    void *stream)
+                                    int64_t *rays_accum, void *stream)
 {
     NSR_REQUIRE(n_samples && n_rays, "nsr_update_ray_count: NULL pointer");
-    NSR_REQUIRE(target_samples > 0 && max_rays > 0, "nsr_update_ray_count: target_samples and max_rays must be > 0");
+    NSR_REQUIRE(target_samples >= 0 && max_rays > 0, "nsr_update_ray_count: target_samples must be >= 0, max_rays > 0");
     hipLaunchKernelGGL(k_update_ray_count, dim3(1), dim3(64), 0, (hipStream_t)stream, n_samples, n_rays, target_samples,
-                       max_rays);
+                       max_rays, (long long *)rays_accum);
     NSR_CHECK_LAUNCH("nsr_update_ray_count");
     return NSR_OK;
 }

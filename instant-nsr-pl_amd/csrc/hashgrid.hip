@@ -121,12 +121,13 @@ __device__ __forceinline__ bool map_block(uint32_t n_levels, uint32_t lpx, uint3
 template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
-               uint32_t y_stride, uint32_t mask_count, uint32_t lpx, int level_major, const NsrGridDesc d)
+               uint32_t y_stride, uint32_t mask_count, uint32_t lpx, int level_major, const NsrGridDesc d,
+               const int32_t *__restrict__ n_dev)
 {
     uint32_t level, blk;
     if (!map_block(d.n_levels, lpx, level, blk)) return;
     const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= live_count(n, n_dev)) return;
     // row-major [n, y_stride] is what the tcnn API returns; level-major [L][n][F] is what the fused path uses: a wave
     // then stores 64 x F consecutive halfs (measured: the row-major 4-B stores, issued level by level from different
     // XCDs, cost 187 MB of fabric writes for a 19 MB output)
@@ -293,11 +294,13 @@ template <bool FILL>
 __global__ void __launch_bounds__(OWN_BIN_BLOCK)
 k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t *__restrict__ counts,
           const uint32_t *__restrict__ bin_start, uint32_t *__restrict__ cursors, uint32_t *__restrict__ items,
-          const OwnerMap om, const NsrGridDesc d)
+          const OwnerMap om, const NsrGridDesc d, const int32_t *__restrict__ n_dev)
 {
     __shared__ uint32_t hist[OWN_MAX_SLICES];
     const uint32_t level = blockIdx.y;
     if (level >= mask_count) return;
+    const uint32_t n_live = live_count(n, n_dev);  // n stays the stride of the per-level item regions
+    if (blockIdx.x * OWN_BIN_SPT * OWN_BIN_BLOCK >= n_live) return;
     const uint32_t R = om.n_slices[level], epb = om.entries_per_slice[level], bin0 = om.bin_offset[level];
     const LevelGeom g = load_level(d, level);
     const bool pow2 = own_is_pow2(g, epb);
@@ -307,7 +310,7 @@ k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t
 #pragma unroll
     for (int u = 0; u < OWN_BIN_SPT; ++u) {
         const uint32_t i = (blockIdx.x * OWN_BIN_SPT + u) * OWN_BIN_BLOCK + threadIdx.x;
-        if (i < n) {
+        if (i < n_live) {
             const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -333,7 +336,7 @@ k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t
 #pragma unroll
         for (int u = 0; u < OWN_BIN_SPT; ++u) {
             const uint32_t i = (blockIdx.x * OWN_BIN_SPT + u) * OWN_BIN_BLOCK + threadIdx.x;
-            if (i >= n) continue;
+            if (i >= n_live) continue;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (slice[u][q] == 0xffffffffu) continue;
@@ -738,17 +741,17 @@ extern "C" int nsr_hashgrid_make_desc(NsrGridDesc *out, uint32_t n_levels, uint3
 
 extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                                        int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
-                                       void *stream);
+                                       const int32_t *n_dev, void *stream);
 
 extern "C" int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                                     uint32_t level_mask_count, const NsrGridDesc *desc, void *stream)
 {
-    return nsr_hashgrid_forward_ex(x, table, y, n, y_stride, 0, level_mask_count, desc, stream);
+    return nsr_hashgrid_forward_ex(x, table, y, n, y_stride, 0, level_mask_count, desc, nullptr, stream);
 }
 
 extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                                        int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
-                                       void *stream)
+                                       const int32_t *n_dev, void *stream)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_forward")) return rc;
     NSR_REQUIRE(y_level_major || y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward: y_stride too small");
@@ -759,7 +762,7 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
     DISPATCH_F(desc->n_features,
                hipLaunchKernelGGL((k_grid_forward<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
                                   (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
-                                  *desc));
+                                  *desc, n_dev));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward");
     return NSR_OK;
 }
@@ -801,7 +804,7 @@ extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridD
 extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
                                                   float *grad_table, float *workspace, uint32_t n,
                                                   uint32_t level_mask_count, float grad_scale, int accumulate,
-                                                  const NsrGridDesc *desc, void *stream)
+                                                  const NsrGridDesc *desc, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
     NSR_REQUIRE(grad_table && workspace, "nsr_hashgrid_backward_params_owner: grad_table / workspace is NULL");
@@ -841,10 +844,10 @@ extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy
     if (n > 0) {
         const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK * OWN_BIN_SPT), L);
         hipLaunchKernelGGL((k_own_bin<false>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                           bin_start, cursors, items, om, *desc);
+                           bin_start, cursors, items, om, *desc, n_dev);
         hipLaunchKernelGGL(k_own_bin_scan, dim3(L), dim3(256), 0, st, counts, bin_start, cursors, om);
         hipLaunchKernelGGL((k_own_bin<true>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                           bin_start, cursors, items, om, *desc);
+                           bin_start, cursors, items, om, *desc, n_dev);
         NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(bin)");
     }
     const size_t lds = OWN_LDS_WORDS * sizeof(unsigned long long);

@@ -406,7 +406,7 @@ k_pack_scratch(const float2 *__restrict__ scratch, uint32_t cap, const int32_t *
 // contiguous chunk; wave scan + LDS across the 16 waves.  Removes torch.cumsum + stack from the step.
 __global__ void __launch_bounds__(1024)
 k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ packed, int32_t *__restrict__ total,
-                   uint32_t n)
+                   uint32_t n, uint32_t capacity, int32_t *__restrict__ stats)
 {
     __shared__ int32_t wave_tot[16];
     const uint32_t tid = threadIdx.x, chunk = (n + 1023) / 1024;
@@ -427,12 +427,25 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
     for (int k = 0; k < w; ++k) prefix += wave_tot[k];
     int32_t run = prefix + v - s;  // exclusive prefix of this lane's chunk
     for (uint32_t k = lo; k < hi; ++k) {
-        const int32_t c = counts[k];
-        packed[2ull * k] = run;
-        packed[2ull * k + 1] = c;
+        int32_t c = counts[k], start = run;
         run += c;
+        if (capacity) {  // fixed-size sample buffers: rays past the capacity are truncated (and reported)
+            start = min(start, (int32_t)capacity);
+            c = min(c, (int32_t)capacity - start);
+        }
+        packed[2ull * k] = start;
+        packed[2ull * k + 1] = c;
     }
-    if (tid == 1023) total[0] = prefix + v;
+    if (tid == 1023) {
+        const int32_t t = prefix + v;
+        total[0] = capacity ? min(t, (int32_t)capacity) : t;
+        if (stats) {  // int32[6]: [0] last (unclamped) total, [1] largest, [2] #launches truncated, [4..5] u64 running sum
+            atomicAdd(reinterpret_cast<unsigned long long *>(stats + 4), (unsigned long long)t);
+            atomicMax(&stats[1], t);
+            if (capacity && t > (int32_t)capacity) atomicAdd(&stats[2], 1);
+            stats[0] = t;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(EW_BLOCK)
@@ -717,15 +730,23 @@ extern "C" int nsr_ray_march_bricks_write(const float *rays_o, const float *rays
     return NSR_OK;
 }
 
-extern "C" int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
-                                    void *stream)
+extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *packed_info, int32_t *total,
+                                           uint32_t n_rays, uint32_t capacity, int32_t *stats, void *stream)
 {
     NSR_REQUIRE(total, "nsr_pack_from_counts: total is NULL");
     NSR_REQUIRE(n_rays == 0 || (num_steps && packed_info), "nsr_pack_from_counts: NULL pointer");
+    NSR_REQUIRE(capacity < 0x7fffffffu, "nsr_pack_from_counts: capacity must fit int32");
+    NSR_REQUIRE(!stats || ((uintptr_t)stats & 7u) == 0, "nsr_pack_from_counts: stats must be 8-byte aligned");
     hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, num_steps, packed_info, total,
-                       n_rays);
+                       n_rays, capacity, stats);
     NSR_CHECK_LAUNCH("nsr_pack_from_counts");
     return NSR_OK;
+}
+
+extern "C" int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
+                                    void *stream)
+{
+    return nsr_pack_from_counts_capped(num_steps, packed_info, total, n_rays, 0, nullptr, stream);
 }
 
 extern "C" int nsr_pack_info(const int64_t *ray_indices, int32_t *packed_info, uint32_t n, uint32_t n_rays,

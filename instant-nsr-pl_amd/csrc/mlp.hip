@@ -191,14 +191,15 @@ template <int KIN /* in_pad/16 */, int NH>
 __global__ void __launch_bounds__(MLP_BLOCK)
 k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __half *__restrict__ W_,
               __half *__restrict__ out, __half *__restrict__ acts, uint32_t n, uint32_t n_in, int out_act,
-              uint32_t x_lmf)
+              uint32_t x_lmf, const int32_t *__restrict__ n_dev)
 {
+    const uint32_t n_live = live_count(n, n_dev);  // n stays the row stride of the level-major / per-layer arrays
     constexpr int IN_PAD = KIN * 16;
     constexpr int KC0 = (IN_PAD + 31) / 32;
     const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4;
     const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
-    const uint32_t n_tiles = (n + 15) / 16;
+    const uint32_t n_tiles = (n_live + 15) / 16;
     const _Float16 *W = reinterpret_cast<const _Float16 *>(W_);
 
     // ---- weights -> registers ----
@@ -223,7 +224,7 @@ k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __
 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t s = tile * 16 + nl;
-        const bool valid = s < n;
+        const bool valid = s < n_live;
         const uint64_t row = (uint64_t)s * x_stride;
         f32x4 acc[4];
 #pragma unroll
@@ -292,15 +293,16 @@ k_mlp_dgrad(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, c
             const __half *__restrict__ out, const __half *__restrict__ acts, const __half *__restrict__ W_,
             float *__restrict__ dx, uint32_t dx_stride, uint32_t dx_lm_features, __half *__restrict__ gpre,
             __half *__restrict__ gout, uint32_t ldn, uint32_t n, uint32_t n_in, uint32_t n_out, int out_act,
-            float grad_scale)
+            float grad_scale, const int32_t *__restrict__ n_dev)
 {
+    const uint32_t n_live = live_count(n, n_dev);
     constexpr int IN_PAD = KIN * 16;
     constexpr int N_PARAMS = WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH + 16 * WIDTH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4;
     const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
-    const uint32_t n_tiles = (n + 15) / 16;
+    const uint32_t n_tiles = (n_live + 15) / 16;
     {   // weights -> LDS with coalesced 16-B loads: the transposed fragments below are 2-byte strided gathers
         const _Float16 *Wg = reinterpret_cast<const _Float16 *>(W_);
         _Float16 *Wl_ = reinterpret_cast<_Float16 *>(smem);
@@ -333,7 +335,7 @@ k_mlp_dgrad(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, c
 
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         const uint32_t s = tile * 16 + nl;
-        const bool valid = s < n;
+        const bool valid = s < n_live;
         // dOut (D layout: cols 4g+r), output-activation derivative, scale
         f32x4 d_o = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
@@ -433,7 +435,7 @@ k_mlp_dgrad(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, c
 //          3: fp32 row-major [n, ld];  columns >= a_cols are the constant 1 (tcnn input padding)
 template <int KIND>
 __device__ __forceinline__ half8 wgrad_frag(const void *__restrict__ p, uint32_t ld, uint32_t lmf, uint32_t col, uint32_t n0,
-                                            uint32_t n, uint32_t n_cols)
+                                            uint32_t n, uint32_t n_live, uint32_t n_cols)
 {
     half8 f;
     if constexpr (KIND == 0) {  // ld = column count of the blocked buffer; the caller masks the ragged last tile
@@ -445,7 +447,7 @@ __device__ __forceinline__ half8 wgrad_frag(const void *__restrict__ p, uint32_t
         const uint32_t c = pad ? 0 : col;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t s = n0 + j < n ? n0 + j : n - 1;  // clamped: unconditional loads, masked afterwards
+            const uint32_t s = n0 + j < n_live ? n0 + j : n_live - 1;  // clamped: unconditional loads, masked afterwards
             _Float16 v;
             if constexpr (KIND == 1) v = reinterpret_cast<const _Float16 *>(p)[(uint64_t)s * ld + c];
             else if constexpr (KIND == 2) v = reinterpret_cast<const _Float16 *>(p)[lm_off(s, (int)c, n, lmf)];
@@ -467,15 +469,17 @@ __device__ __forceinline__ half8 wgrad_mask(half8 f, uint32_t n0, uint32_t n)
 template <int OB /* output blocks of 16 */, int KB /* input blocks of 16 */, int KIND>
 __global__ void __launch_bounds__(MLP_BLOCK)
 k_mlp_wgrad(const __half *__restrict__ GT, const void *__restrict__ A, uint32_t a_ld, uint32_t a_lmf, uint32_t a_cols,
-            float *__restrict__ partials, uint32_t partial_stride, uint32_t partial_offset, uint32_t n)
+            float *__restrict__ partials, uint32_t partial_stride, uint32_t partial_offset, uint32_t n,
+            const int32_t *__restrict__ n_dev)
 {
+    const uint32_t n_live = live_count(n, n_dev);  // rows; n is the row stride of level-major / row-major operands
     constexpr int OW = OB * 16, KW = KB * 16;
     static_assert((OB * KB) % 4 == 0, "block reduction assigns OB*KB/4 fragments to each thread");
     __shared__ f32x4 red[WAVES][OB * KB][64];  // per-wave accumulators in fragment order (LDS float atomics are ~4 clk/lane)
     const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4;
     const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
-    const uint32_t n_tiles = (n + 31) / 32;
+    const uint32_t n_tiles = (n_live + 31) / 32;
     f32x4 acc[OB][KB];
 #pragma unroll
     for (int a = 0; a < OB; ++a)
@@ -486,9 +490,9 @@ k_mlp_wgrad(const __half *__restrict__ GT, const void *__restrict__ A, uint32_t 
     auto load = [&](uint32_t tile, half8 *pg, half8 *pa) {
         const uint32_t n0 = tile * 32 + 8 * g;
 #pragma unroll
-        for (int a = 0; a < OB; ++a) pg[a] = wgrad_frag<0>(GT, OW, 0, a * 16 + nl, n0, n, OW);
+        for (int a = 0; a < OB; ++a) pg[a] = wgrad_frag<0>(GT, OW, 0, a * 16 + nl, n0, n, n_live, OW);
 #pragma unroll
-        for (int b = 0; b < KB; ++b) pa[b] = wgrad_frag<KIND>(A, a_ld, a_lmf, b * 16 + nl, n0, n, a_cols);
+        for (int b = 0; b < KB; ++b) pa[b] = wgrad_frag<KIND>(A, a_ld, a_lmf, b * 16 + nl, n0, n, n_live, a_cols);
     };
     uint32_t tile = wave;
     if (tile < n_tiles) load(tile, ga, ab);
@@ -496,12 +500,12 @@ k_mlp_wgrad(const __half *__restrict__ GT, const void *__restrict__ A, uint32_t 
         const uint32_t next = tile + n_waves;
         half8 ga2[OB], ab2[KB];
         if (next < n_tiles) load(next, ga2, ab2);
-        if (tile * 32 + 32 > n) {  // ragged last tile: zero the samples past n on both operands
+        if (tile * 32 + 32 > n_live) {  // ragged last tile: zero the samples past n on both operands
             const uint32_t n0 = tile * 32 + 8 * g;
 #pragma unroll
-            for (int a = 0; a < OB; ++a) ga[a] = wgrad_mask(ga[a], n0, n);
+            for (int a = 0; a < OB; ++a) ga[a] = wgrad_mask(ga[a], n0, n_live);
 #pragma unroll
-            for (int b = 0; b < KB; ++b) ab[b] = wgrad_mask(ab[b], n0, n);
+            for (int b = 0; b < KB; ++b) ab[b] = wgrad_mask(ab[b], n0, n_live);
         }
 #pragma unroll
         for (int b = 0; b < KB; ++b)
@@ -613,19 +617,19 @@ uint64_t bwd_ws_floats(const NsrMlpDesc *d, uint32_t n)
 
 extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride, uint32_t x_level_major_features,
                                   const nsr_half *weights, nsr_half *out, nsr_half *acts, uint32_t n,
-                                  const NsrMlpDesc *desc, void *stream);
+                                  const NsrMlpDesc *desc, const int32_t *n_dev, void *stream);
 
 extern "C" int nsr_mlp_forward(const void *x, int x_is_f32, uint32_t x_stride, const nsr_half *weights, nsr_half *out,
                                nsr_half *acts, uint32_t n, const NsrMlpDesc *desc, void *stream)
 {
-    return nsr_mlp_forward_ex(x, x_is_f32, x_stride, 0, weights, out, acts, n, desc, stream);
+    return nsr_mlp_forward_ex(x, x_is_f32, x_stride, 0, weights, out, acts, n, desc, nullptr, stream);
 }
 
 static inline uint32_t mlp_ldn(uint32_t n) { return (n + 31u) & ~31u; }
 
 extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride, uint32_t x_level_major_features,
                                   const nsr_half *weights, nsr_half *out, nsr_half *acts, uint32_t n,
-                                  const NsrMlpDesc *desc, void *stream)
+                                  const NsrMlpDesc *desc, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_mlp(desc, "nsr_mlp_forward")) return rc;
     if (n == 0) return NSR_OK;
@@ -642,7 +646,7 @@ extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride
     DISPATCH_MLP(desc->in_pad / 16, desc->n_hidden,
                  hipLaunchKernelGGL((k_mlp_forward<KIN, NH>), dim3(blocks), dim3(MLP_BLOCK), 0, (hipStream_t)stream, x,
                                     x_is_f32, x_stride, (const __half *)weights, (__half *)out, (__half *)acts, n,
-                                    desc->n_in, (int)desc->output_activation, x_level_major_features));
+                                    desc->n_in, (int)desc->output_activation, x_level_major_features, n_dev));
     NSR_CHECK_LAUNCH("nsr_mlp_forward");
     return NSR_OK;
 }
@@ -655,11 +659,12 @@ extern "C" uint64_t nsr_mlp_backward_workspace_floats(const NsrMlpDesc *desc, ui
 
 template <int OB, int KB>
 static void launch_wgrad(const __half *GT, const void *A, int a_kind, uint32_t a_ld, uint32_t a_lmf, uint32_t a_cols,
-                         float *partials, uint32_t np, uint32_t off, uint32_t n, uint32_t nb, hipStream_t st)
+                         float *partials, uint32_t np, uint32_t off, uint32_t n, uint32_t nb, const int32_t *n_dev,
+                         hipStream_t st)
 {
 #define NSR_WGRAD(KIND)                                                                                                \
     hipLaunchKernelGGL((k_mlp_wgrad<OB, KB, KIND>), dim3(nb), dim3(MLP_BLOCK), 0, st, GT, A, a_ld, a_lmf, a_cols,     \
-                       partials, np, off, n)
+                       partials, np, off, n, n_dev)
     switch (a_kind) {
     case 0: NSR_WGRAD(0); break;
     case 1: NSR_WGRAD(1); break;
@@ -673,7 +678,7 @@ extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t d
                                    const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
                                    uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                                    uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
-                                   const NsrMlpDesc *desc, void *stream)
+                                   const NsrMlpDesc *desc, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_mlp(desc, "nsr_mlp_backward")) return rc;
     if (n == 0) return NSR_OK;
@@ -702,17 +707,17 @@ extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t d
         hipLaunchKernelGGL((k_mlp_dgrad<KIN, NH>), dim3(blocks), dim3(MLP_BLOCK), lds, st, dout, dout_is_f32, dout_stride,
                            dout_extra_col0, (const __half *)out, (const __half *)acts, (const __half *)weights, dx,
                            dx_stride, dx_level_major_features, gpre, gout, ldn, n, desc->n_in, desc->n_out,
-                           (int)desc->output_activation, grad_scale);
+                           (int)desc->output_activation, grad_scale, n_dev);
     });
     NSR_CHECK_LAUNCH("nsr_mlp_backward(dgrad)");
     if (!grad_weights) return NSR_OK;
     const int x_kind = x_level_major_features ? 2 : (x_is_f32 ? 3 : 1);
     // first matrix W0 [64, in_pad]: G = gpre[0], A = x
     switch (in_pad / 16) {
-    case 1: launch_wgrad<4, 1>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
-    case 2: launch_wgrad<4, 2>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
-    case 3: launch_wgrad<4, 3>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
-    default: launch_wgrad<4, 4>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, st); break;
+    case 1: launch_wgrad<4, 1>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, n_dev, st); break;
+    case 2: launch_wgrad<4, 2>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, n_dev, st); break;
+    case 3: launch_wgrad<4, 3>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, n_dev, st); break;
+    default: launch_wgrad<4, 4>(gpre, x, x_kind, x_stride, x_level_major_features, desc->n_in, partials, np, 0, n, nb, n_dev, st); break;
     }
     // activations feeding matrix l >= 1: the forward's row-major [n,64] copy (element loads; measured as fast as a
     // column-blocked copy, so the forward does not write one)
@@ -723,12 +728,12 @@ extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t d
         const void *p; int kind; uint32_t ld;
         act_of(l - 1, p, kind, ld);
         launch_wgrad<4, 4>(gpre + (uint64_t)l * 64 * ldn, p, kind, ld, 0, 64, partials, np,
-                           WIDTH * in_pad + (l - 1) * WIDTH * WIDTH, n, nb, st);
+                           WIDTH * in_pad + (l - 1) * WIDTH * WIDTH, n, nb, n_dev, st);
     }
     {   // last matrix [16, 64]: G = gout, A = acts[nh-1]
         const void *p; int kind; uint32_t ld;
         act_of(nh - 1, p, kind, ld);
-        launch_wgrad<1, 4>(gout, p, kind, ld, 0, 64, partials, np, WIDTH * in_pad + (nh - 1) * WIDTH * WIDTH, n, nb, st);
+        launch_wgrad<1, 4>(gout, p, kind, ld, 0, 64, partials, np, WIDTH * in_pad + (nh - 1) * WIDTH * WIDTH, n, nb, n_dev, st);
     }
     NSR_CHECK_LAUNCH("nsr_mlp_backward(wgrad)");
     hipLaunchKernelGGL(k_reduce_partials, dim3(nsr_div_up(np, 256), RED_SEGS), dim3(256), 0, st, partials, grad_weights, np,
@@ -742,5 +747,5 @@ extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout
                                 const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                                 float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, void *stream)
 {
-    return nsr_mlp_backward_ex(dout, dout_is_f32, dout_stride, nullptr, out, x, x_is_f32, x_stride, 0, acts, weights, grad_weights, dx, dx_stride, 0, partials, n, grad_scale, desc, stream);
+    return nsr_mlp_backward_ex(dout, dout_is_f32, dout_stride, nullptr, out, x, x_is_f32, x_stride, 0, acts, weights, grad_weights, dx, dx_stride, 0, partials, n, grad_scale, desc, nullptr, stream);
 }

@@ -29,6 +29,16 @@ void nsr_set_error(const char *fmt, ...);
 
 static inline uint32_t nsr_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// Device-side row counts: an entry point that takes (n, n_dev) launches for the CAPACITY n and uses n for array
+// strides; when n_dev != NULL only the first min(*n_dev, n) rows are live.  Lets a whole training step be queued
+// without the host ever reading a sample count.
+__device__ __forceinline__ uint32_t live_count(uint32_t n, const int32_t *__restrict__ n_dev)
+{
+    if (!n_dev) return n;
+    const int32_t v = *n_dev;
+    return v < 0 ? 0u : ((uint32_t)v < n ? (uint32_t)v : n);
+}
+
 // ---- wave-level primitives (wave64) ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
 {

@@ -113,7 +113,8 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
                                    const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                                    const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
                                    void *workspace, int32_t *kept_counts, int32_t *packed_kept, int32_t *total_kept,
-                                   uint32_t n_marched, uint32_t n_rays, void *stream)
+                                   uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
+                                   uint32_t kept_capacity, int32_t *kept_stats, void *stream)
 {
     NSR_REQUIRE(d && workspace && kept_counts && packed_kept && total_kept, "nsr_nerf_prune_pass: NULL pointer");
     NsrNerfPruneLayout L;
@@ -123,19 +124,20 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
     nsr_half *enc = (nsr_half *)(ws + L.enc), *out1 = (nsr_half *)(ws + L.out1), *acts1 = (nsr_half *)(ws + L.acts1);
     const uint32_t C = d->grid.n_levels * d->grid.n_features;
     NSR_TRY(nsr_sample_positions_unit(rays_o, rays_d, ray_indices, t_starts, t_ends, d->radius, d->contraction, x01,
-                                      nullptr, n_marched, stream));
+                                      nullptr, n_marched, n_marched_dev, stream));
     {
         ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
-        NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, stream));
+        NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
+                                        stream));
     }
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_DENSITY, n_marched, stream);
         NSR_TRY(nsr_mlp_forward_ex(enc, 0, C, d->grid.n_features, w_density, out1, acts1, n_marched, &d->mlp_density,
-                                   stream));
+                                   n_marched_dev, stream));
     }
     NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
                                   kept_counts, n_rays, stream));
-    NSR_TRY(nsr_pack_from_counts(kept_counts, packed_kept, total_kept, n_rays, stream));
+    NSR_TRY(nsr_pack_from_counts_capped(kept_counts, packed_kept, total_kept, n_rays, kept_capacity, kept_stats, stream));
     return NSR_OK;
 }
 
@@ -178,7 +180,7 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
                                   const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
                                   const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
                                   float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
-                                  uint32_t n_rays, int compute_grads, void *stream)
+                                  uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev, void *stream)
 {
     NSR_REQUIRE(d && prune_workspace && workspace && packed_marched && packed_kept, "nsr_nerf_main_pass: NULL pointer");
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
@@ -223,10 +225,11 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     if (S > 0)  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
         NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, dirs,
                                             (int64_t *)(ws + L.ray_indices), n_rays, stream));
-    NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, stream));
+    NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, n_kept_dev, stream));
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
-        NSR_TRY(nsr_mlp_forward(tex_in, 0, 32, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color, stream));
+        NSR_TRY(nsr_mlp_forward_ex(tex_in, 0, 32, 0, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color,
+                                   n_kept_dev, stream));
     }
     NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                   comp_rgb, opacity, depth, n_rays, stream));
@@ -243,18 +246,18 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
         NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
-                                    32, 0, part2, S, d->grad_scale, &d->mlp_color, stream));
+                                    32, 0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream));
     }
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_DENSITY, S, stream);
         NSR_TRY(nsr_mlp_backward_ex(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
                                     grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
-                                    &d->mlp_density, stream));
+                                    &d->mlp_density, n_kept_dev, stream));
     }
     {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
         NSR_TRY(nsr_hashgrid_backward_params_owner(x01, d_enc, 2, 0, grad_table, (float *)(ws + L.grid_ws), S,
-                                                   d->grid.n_levels, 1.0f, 0, &d->grid, stream));
+                                                   d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
     }
     return NSR_OK;
 }

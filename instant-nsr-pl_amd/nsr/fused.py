@@ -43,7 +43,7 @@ class FusedNeRFStep:
         x01 = torch.empty((n, 3), dtype=F32, device=ri.device)
         dirs = torch.empty((n, 3), dtype=F32, device=ri.device) if want_dirs else None
         check(lib.nsr_sample_positions_unit(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), self.radius,
-                                            ContractionType.AABB.value, ptr(x01), ptr(dirs), n, stream_ptr()),
+                                            ContractionType.AABB.value, ptr(x01), ptr(dirs), n, None, stream_ptr()),
               "nsr_sample_positions_unit")
         return x01, dirs
 
@@ -147,7 +147,7 @@ class FusedNeRFStep:
                 if M > 0:
                     check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1),
                                                   ptr(packed), ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2),
-                                                  ptr(total), M, n_rays, s), "nsr_nerf_prune_pass")
+                                                  ptr(total), M, n_rays, None, 0, None, s), "nsr_nerf_prune_pass")
                     if before_sync is not None:
                         before_sync(total)
                     S = _ops.read_count_when_ready(total)  # second (and last) host sync of the step
@@ -175,7 +175,7 @@ class FusedNeRFStep:
                                              ptr(ewn.mlp_slice(g1)) if compute_grads else None,
                                              ptr(ewn.grid_slice(g1)) if compute_grads else None,
                                              ptr(g2) if compute_grads else None, ptr(ws), S, n_rays,
-                                             int(bool(compute_grads)), s), "nsr_nerf_main_pass")
+                                             int(bool(compute_grads)), None, s), "nsr_nerf_main_pass")
             def view(off, n, dtype, shape):
                 return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
 
@@ -211,7 +211,7 @@ class FusedNeRFStep:
                     enc, out1 = torch.empty((0, 32), dtype=F16, device=dev), torch.empty((0, 16), dtype=F16, device=dev)
                     acts1 = torch.empty((1, 0, 64), dtype=F16, device=dev)
                 tex_in = torch.empty((S, 32), dtype=F16, device=dev)
-                check(lib.nsr_texture_input(ptr(out1), 16, ptr(dirs), ptr(tex_in), S, s), "nsr_texture_input")
+                check(lib.nsr_texture_input(ptr(out1), 16, ptr(dirs), ptr(tex_in), S, None, s), "nsr_texture_input")
                 out2, acts2 = _ops.mlp_forward(tex_in, w2, tex.mlp_desc, save_acts=compute_grads)
                 weights, trans = torch.empty(S, dtype=F32, device=dev), torch.empty(S, dtype=F32, device=dev)
                 comp_rgb = torch.empty((n_rays, 3), dtype=F32, device=dev)
@@ -252,6 +252,132 @@ class FusedNeRFStep:
                 after_enqueue()  # the whole step is queued: host time spent here overlaps GPU work
             return res
 
+    # ---- fully asynchronous step: every sample count stays on the device ------------------------------------
+    def async_ray_set(self, slots, dataset_like_device):
+        """buffers one marching pass writes (double-buffered by the trainer: the pass of step k+1 runs on a side
+        stream while step k still reads its own set)"""
+        dev = dataset_like_device
+        grid = self.model.occupancy_grid
+        cap = int(lib.nsr_ray_march_capacity((ctypes.c_float * 6)(*[float(v) for v in grid._roi_host]),
+                                             float(self.model.render_step_size)))
+        rs = dict(slots=slots, cap=cap)
+        rs["buf"] = torch.empty(slots * 18, dtype=F32, device=dev)  # rays(6) o(3) d(3) rgb(3) fg(1) tmin(1) tmax(1)
+        b, n = rs["buf"], slots
+        rs["rays"], rs["ro"], rs["rd"] = b[:6 * n].view(n, 6), b[6 * n:9 * n].view(n, 3), b[9 * n:12 * n].view(n, 3)
+        rs["rgb"], rs["fg"] = b[12 * n:15 * n].view(n, 3), b[15 * n:16 * n]
+        rs["t_min"], rs["t_max"] = b[16 * n:17 * n], b[17 * n:18 * n]
+        rs["u"] = torch.empty((5, max(slots, 3)), dtype=F32, device=dev)
+        rs["counts"] = torch.empty(slots, dtype=torch.int32, device=dev)
+        rs["packed"] = torch.empty((slots, 2), dtype=torch.int32, device=dev)
+        rs["total"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        rs["scratch"] = torch.empty(slots * cap * 2, dtype=F32, device=dev)
+        return rs
+
+    def march_async(self, rs, dataset, generator, n_active, m_cap, stats, background="random"):
+        """ray preparation + marching pass + capped packing into ray set ``rs`` on the CURRENT stream; no host sync"""
+        m, grid = self.model, self.model.occupancy_grid
+        slots = rs["slots"]
+        rs["u"].uniform_(generator=generator)
+        rs["bg"] = rs["u"][4, :3] if background == "random" else torch.ones(3, device=rs["u"].device)
+        jitter = float(m.render_step_size) if m.randomized else 0.0
+        bricks = _ops.grid_bricks(grid.binary)
+        if bricks is None:
+            raise NotImplementedError("the asynchronous step needs a brick-able occupancy grid (resolution % 16 == 0)")
+        rx, ry, rz = (int(v) for v in grid.binary.shape)
+        s = stream_ptr()
+        check(lib.nsr_prepare_train_rays(ptr(dataset.all_images), ptr(dataset.all_fg_masks), ptr(dataset.directions),
+                                         ptr(dataset.all_c2w), ptr(rs["u"]), ptr(rs["bg"]),
+                                         dataset.all_images.shape[0], dataset.h, dataset.w, int(dataset.apply_mask),
+                                         ptr(m.scene_aabb), jitter, ptr(rs["rays"]), ptr(rs["ro"]), ptr(rs["rd"]),
+                                         ptr(rs["rgb"]), ptr(rs["fg"]), ptr(rs["t_min"]), ptr(rs["t_max"]), slots,
+                                         ptr(n_active), s), "nsr_prepare_train_rays")
+        with _ops.timed("ray_march_count", slots):
+            check(lib.nsr_ray_march_bricks_count(ptr(rs["ro"]), ptr(rs["rd"]), ptr(rs["t_min"]), ptr(rs["t_max"]),
+                                                 ptr(grid.roi_aabb), ptr(bricks), rx, ry, rz,
+                                                 ContractionType.AABB.value, float(m.render_step_size), 0.0,
+                                                 ptr(rs["counts"]), ptr(rs["scratch"]), rs["cap"], slots, s),
+                  "nsr_ray_march_bricks_count")
+        check(lib.nsr_pack_from_counts_capped(ptr(rs["counts"]), ptr(rs["packed"]), ptr(rs["total"]), slots, int(m_cap),
+                                              ptr(stats), s), "nsr_pack_from_counts_capped")
+        rs["m_cap"] = int(m_cap)
+
+    def _async_buffers(self, slots, m_cap, s_cap, dev):
+        key = (slots, m_cap, s_cap)
+        ab = getattr(self, "_ab", None)
+        if ab is not None and ab["key"] == key:
+            return ab
+        d = self.desc
+        check(lib.nsr_nerf_prune_layout(_byref(d), m_cap, _byref(self._PL)), "nsr_nerf_prune_layout")
+        check(lib.nsr_nerf_main_layout(_byref(d), s_cap, slots, _byref(self._ML)), "nsr_nerf_main_layout")
+        ab = dict(key=key, prev=ab)  # the previous set stays referenced until the next resize: queued work may use it
+        if ab["prev"] is not None:
+            ab["prev"]["prev"] = None
+        ab["pws"] = torch.empty(max(int(self._PL.total_bytes), 256), dtype=torch.uint8, device=dev)
+        ab["ws"] = torch.empty(int(self._ML.total_bytes), dtype=torch.uint8, device=dev)
+        ab["ri"] = torch.empty(m_cap, dtype=torch.int64, device=dev)
+        ab["t0"] = torch.empty((m_cap, 1), dtype=F32, device=dev)
+        ab["t1"] = torch.empty((m_cap, 1), dtype=F32, device=dev)
+        ab["meta"] = torch.zeros(3 * slots + 1, dtype=torch.int32, device=dev)  # kept | packed_kept | total
+        import copy
+        ab["ML"] = copy.copy(self._ML)
+        self._ab = ab
+        return ab
+
+    def forward_backward_async(self, rs, s_cap, kept_stats, loss_scale=1.0, compute_grads=True, after_prune_queued=None):
+        """the training step on ray set ``rs`` (filled by march_async, possibly on another stream -- the caller orders
+        the streams) with NO host synchronisation: the marched / kept sample counts stay on the device, all buffers
+        have fixed capacities (rs['m_cap'], s_cap) and every kernel is launched for the capacity.
+        ``after_prune_queued(total_kept)`` runs once the pruning pass is queued (device int32[1] tensor)."""
+        ewn, tex, d = self.ewn, self.tex, self.desc
+        dev = rs["buf"].device
+        slots, m_cap = rs["slots"], rs["m_cap"]
+        d.loss_scale = float(loss_scale)
+        ab = self._async_buffers(slots, m_cap, int(s_cap), dev)
+        meta = ab["meta"]
+        kept, packed2, total = meta[:slots], meta[slots:3 * slots].view(slots, 2), meta[3 * slots:]
+        with torch.no_grad(), torch.cuda.device(dev):
+            s = stream_ptr()
+            grid = self.model.occupancy_grid
+            rx, ry, rz = (int(v) for v in grid.binary.shape)
+            half = ewn.half_params(ewn.params)
+            table, w1, w2 = half[ewn.n_network_params:], half[:ewn.n_network_params], tex.half_params(tex.params)
+            with _ops.timed("fused:march_prune"):
+                check(lib.nsr_ray_march_bricks_write(ptr(rs["ro"]), ptr(rs["rd"]), ptr(rs["t_min"]), ptr(rs["t_max"]),
+                                                     ptr(grid.roi_aabb), None, rx, ry, rz, ContractionType.AABB.value,
+                                                     float(self.model.render_step_size), 0.0, ptr(rs["packed"]),
+                                                     ptr(rs["scratch"]), rs["cap"], ptr(ab["ri"]), ptr(ab["t0"]),
+                                                     ptr(ab["t1"]), slots, s), "nsr_ray_march_bricks_write")
+                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rs["ro"]), ptr(rs["rd"]), ptr(ab["ri"]), ptr(ab["t0"]),
+                                              ptr(ab["t1"]), ptr(rs["packed"]), ptr(table), ptr(w1), ptr(ab["pws"]),
+                                              ptr(kept), ptr(packed2), ptr(total), m_cap, slots, ptr(rs["total"]),
+                                              int(s_cap), ptr(kept_stats), s), "nsr_nerf_prune_pass")
+            if after_prune_queued is not None:
+                after_prune_queued(total)
+            with _ops.timed("fused:main_pass"):
+                if compute_grads:
+                    for p in (ewn.params, tex.params):
+                        if p.grad is None:
+                            p.grad = torch.zeros_like(p)
+                g1 = ewn.params.grad if compute_grads else None
+                g2 = tex.params.grad if compute_grads else None
+                check(lib.nsr_nerf_main_pass(_byref(d), ptr(ab["pws"]), m_cap, ptr(rs["packed"]), ptr(packed2),
+                                             ptr(ab["t0"]), ptr(ab["t1"]), ptr(rs["rd"]), ptr(rs["bg"]), ptr(rs["rgb"]),
+                                             ptr(w1), ptr(w2),
+                                             ptr(ewn.mlp_slice(g1)) if compute_grads else None,
+                                             ptr(ewn.grid_slice(g1)) if compute_grads else None,
+                                             ptr(g2) if compute_grads else None, ptr(ab["ws"]), int(s_cap), slots,
+                                             int(bool(compute_grads)), ptr(total), s), "nsr_nerf_main_pass")
+            L, ws = ab["ML"], ab["ws"]
+
+            def view(off, n, dtype, shape):
+                return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
+
+            return {"comp_rgb": view(L.comp_rgb, slots * 3, F32, (slots, 3)),
+                    "opacity": view(L.opacity, slots, F32, (slots, 1)), "depth": view(L.depth, slots, F32, (slots, 1)),
+                    "loss_acc": view(L.loss_acc, 2, F32, (2,)), "num_samples": total, "num_marched": rs["total"],
+                    "packed_kept": packed2, "weights": view(L.weights, int(s_cap), F32, (int(s_cap),)),
+                    "ray_indices": view(L.ray_indices, int(s_cap), torch.int64, (int(s_cap),)), "_workspace": ws}
+
     def _mlp_backward(self, dout, dout_stride, extra, out, x, acts, w, desc, grad_w, dx_lm_f):
         n = x.shape[0]
         dx = torch.empty(n * desc.n_in, dtype=F32, device=x.device)
@@ -260,7 +386,7 @@ class FusedNeRFStep:
         with _ops.timed(f"mlp_backward_h{desc.n_hidden}", n):
             check(lib.nsr_mlp_backward_ex(ptr(dout), 1, dout_stride, ptr(extra), ptr(out), ptr(x), 0, x.stride(0), 0,
                                           ptr(acts), ptr(w), ptr(grad_w), ptr(dx), desc.n_in, dx_lm_f, ptr(partials), n,
-                                          self.grad_scale, _byref(desc), stream_ptr()), "nsr_mlp_backward_ex")
+                                          self.grad_scale, _byref(desc), None, stream_ptr()), "nsr_mlp_backward_ex")
         return dx if dx_lm_f else dx.view(n, desc.n_in)
 
     @staticmethod

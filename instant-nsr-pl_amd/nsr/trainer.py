@@ -54,7 +54,7 @@ def multistep_lr_scale(step, milestones=(10000, 15000, 18000), gamma=0.33):
 
 
 class Trainer:
-    def __init__(self, model, dataset, config, rank=0, world_size=1, seed=42, fused=True):
+    def __init__(self, model, dataset, config, rank=0, world_size=1, seed=42, fused=True, async_mode=False):
         self.model, self.dataset, self.config = model, dataset, config
         self.rank, self.world_size = rank, world_size
         self.device = next(model.parameters()).device
@@ -74,6 +74,7 @@ class Trainer:
         self.opt = FusedAdamW(tc, other)
         self.last = {}
         self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None
+        self.async_mode, self._as = bool(async_mode), None
         if fused and config["name"] == "nerf":
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
@@ -88,7 +89,7 @@ class Trainer:
 
     def train_step(self):
         if self.fused is not None:
-            return self._train_step_fused()
+            return self._train_step_async() if self.async_mode else self._train_step_fused()
         model = self.model
         with _ops.timed("phase:sample_rays"):
             rays, rgb, fg, bg = self.dataset.sample_rays(self.train_num_rays, self.gen, self.config["background_color"])
@@ -148,7 +149,7 @@ class Trainer:
             if dynamic and total is not None:
                 with torch.cuda.device(self.device):
                     _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(self._n_rays_dev), int(self.train_num_samples),
-                                                     int(cfg["max_train_num_rays"]), _stream_ptr()),
+                                                     int(cfg["max_train_num_rays"]), None, _stream_ptr()),
                            "nsr_update_ray_count")
             if not self.pipeline_march or next_updates_grid:
                 return
@@ -180,4 +181,107 @@ class Trainer:
             self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
         self.global_step += 1
         self.last = {"loss": FusedNeRFStep.loss_value(res), "n_rays": n_live, "n_samples": n_samples}
+        return self.last
+
+    # ---- asynchronous mode: no host synchronisation inside a step ------------------------------------------------
+    def _async_state(self):
+        if self._as is not None:
+            return self._as
+        cfg, dev = self.config, self.device
+        dynamic = bool(cfg["dynamic_ray_sampling"])
+        slots = cfg["max_train_num_rays"] if dynamic else self.train_num_rays
+        a = dict(slots=slots, pending=False, event=None, check_every=8, last_check=None)
+        a["n_rays"] = torch.tensor([self.train_num_rays], dtype=torch.int32, device=dev)
+        a["sets"] = [self.fused.async_ray_set(slots, dev) for _ in range(2)]
+        a["stats"] = torch.zeros(16, dtype=torch.int32, device=dev)  # [0:6] marched, [8:14] kept (pack_from_counts_capped)
+        a["rays_accum"] = torch.zeros(1, dtype=torch.int64, device=dev)
+        a["host"] = torch.zeros(16, dtype=torch.int32).pin_memory()
+        a["host_event"] = None
+        # generous first capacities; they follow 1.5 x the largest count seen (checked every few steps, never synced)
+        a["m_cap"] = max(1 << 20, 4 * self.train_num_samples)
+        a["s_cap"] = max(1 << 18, (3 * self.train_num_samples) // 2)
+        a["truncated"] = 0
+        self._as = a
+        return a
+
+    def _async_capacities(self, a):
+        """follow the sample counts WITHOUT waiting for them: every ``check_every`` steps the statistics written by
+        the packing kernels are copied to pinned memory behind the step; the copy of the previous round is read here."""
+        if self.global_step % a["check_every"] != 0:
+            return
+        if a["host_event"] is not None and a["host_event"].query():
+            h = a["host"]
+            max_m, max_s, trunc = int(h[1]), int(h[9]), int(h[2]) + int(h[10])
+            for key, mx in (("m_cap", max_m), ("s_cap", max_s)):
+                want = max(-(-int(1.5 * mx) // 16384) * 16384, 65536)
+                if mx > 0.85 * a[key] or (mx > 0 and trunc == a["truncated"] and want < 0.5 * a[key]):
+                    a[key] = want  # grow as soon as the window maximum comes close (or samples were dropped); shrink
+                    #                only when the buffers are more than twice too large
+            a["truncated"] = trunc
+        a["host"].copy_(a["stats"], non_blocking=True)
+        a["host_event"] = torch.cuda.Event()
+        a["host_event"].record(torch.cuda.current_stream())
+        a["stats"][1].zero_()  # the window maxima restart AFTER the copy (stream order)
+        a["stats"][9].zero_()
+
+    def counters(self):
+        """totals since the first asynchronous step (synchronises): marched / kept samples, rays, truncated launches"""
+        a = self._async_state()
+        torch.cuda.synchronize(self.device)
+        st = a["stats"].cpu()
+        u64 = lambda lo, hi: (int(lo) & 0xffffffff) | ((int(hi) & 0xffffffff) << 32)
+        return {"marched": u64(st[4], st[5]), "samples": u64(st[12], st[13]), "rays": int(a["rays_accum"].item()),
+                "truncated": int(st[2]) + int(st[10]), "m_cap": a["m_cap"], "s_cap": a["s_cap"]}
+
+    def _train_step_async(self):
+        """the fused step with every count on the device (FusedNeRFStep.forward_backward_async): the host only queues
+        work -- ~45 launches through two C calls -- and never waits for the GPU.  Returns device tensors; use
+        ``counters()`` for totals."""
+        from .fused import FusedNeRFStep
+        model, fused, cfg = self.model, self.fused, self.config
+        a = self._async_state()
+        dynamic = bool(cfg["dynamic_ray_sampling"])
+        main = torch.cuda.current_stream()
+        with _ops.timed("phase:occupancy_update"):
+            model.update_step(0, self.global_step)
+        k = self.global_step & 1
+        rs = a["sets"][k]
+        stats_m, stats_s = a["stats"][0:8], a["stats"][8:16]
+        if a["pending"]:
+            main.wait_event(a["event"])  # the marching pass of this step ran on the side stream
+        else:
+            with _ops.timed("phase:sample_rays"):
+                fused.march_async(rs, self.dataset, self.gen, a["n_rays"], a["m_cap"], stats_m, cfg["background_color"])
+        model.background_color = rs["bg"]
+        next_updates_grid = cfg["grid_prune"] and (self.global_step + 1) % 16 == 0
+
+        def after_prune_queued(total):
+            with torch.cuda.device(self.device):
+                _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(a["n_rays"]),
+                                                 int(self.train_num_samples) if dynamic else 0,
+                                                 int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), _stream_ptr()),
+                       "nsr_update_ray_count")
+            a["pending"] = False
+            if not self.pipeline_march or next_updates_grid:
+                return
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            ev = torch.cuda.Event()
+            ev.record(main)             # pruning pass + count update of THIS step; its main pass is queued later
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                fused.march_async(a["sets"][1 - k], self.dataset, self.gen, a["n_rays"], a["m_cap"], stats_m,
+                                  cfg["background_color"])
+                a["event"] = torch.cuda.Event()
+                a["event"].record(self._side)
+            a["pending"] = True
+
+        res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued)
+        with _ops.timed("phase:all_reduce"):
+            self._all_reduce_grads()
+        with _ops.timed("phase:optimizer"):
+            self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
+        self.global_step += 1
+        self._async_capacities(a)
+        self.last = {"loss": FusedNeRFStep.loss_value(res), "n_rays": a["n_rays"], "n_samples": res["num_samples"]}
         return self.last

@@ -69,31 +69,31 @@ SIGNATURES = {
     "nsr_abi_version": [],
     "nsr_hashgrid_make_desc": [_GD, _U, _U, _U, _U, _F],
     "nsr_hashgrid_forward": [_P, _P, _P, _U, _U, _U, _GD, _P],
-    "nsr_hashgrid_forward_ex": [_P, _P, _P, _U, _U, _I, _U, _GD, _P],
+    "nsr_hashgrid_forward_ex": [_P, _P, _P, _U, _U, _I, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P],
     "nsr_hashgrid_backward_params_workspace_floats": [_GD, _U],
-    "nsr_hashgrid_backward_params_owner": [_P, _P, _I, _U, _P, _P, _U, _U, _F, _I, _GD, _P],
+    "nsr_hashgrid_backward_params_owner": [_P, _P, _I, _U, _P, _P, _U, _U, _F, _I, _GD, _P, _P],
     "nsr_hashgrid_backward_input": [_P, _P, _P, _I, _U, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_backward_input": [_P, _P, _P, _I, _U, _P, _P, _U, _P, _P, _U, _U, _GD, _P],
     "nsr_sh4_forward": [_P, _P, _U, _U, _P],
     "nsr_mlp_forward": [_P, _I, _U, _P, _P, _P, _U, _MD, _P],
-    "nsr_mlp_forward_ex": [_P, _I, _U, _U, _P, _P, _P, _U, _MD, _P],
+    "nsr_mlp_forward_ex": [_P, _I, _U, _U, _P, _P, _P, _U, _MD, _P, _P],
     "nsr_mlp_backward_workspace_floats": [_MD, _U],
     "nsr_mlp_backward": [_P, _I, _U, _P, _P, _I, _U, _P, _P, _P, _P, _U, _P, _U, _F, _MD, _P],
-    "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P],
-    "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P],
+    "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P],
+    "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P, _P],
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_copy_ray_prefixes": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_copy_ray_prefix_rows": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_copy_ray_prefix_rows_ex": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
-    "nsr_texture_input": [_P, _U, _P, _P, _U, _P],
+    "nsr_texture_input": [_P, _U, _P, _P, _U, _P, _P],
     "nsr_composite_forward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid": [_P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid_backward": [_P, _P, _P, _P, _F, _P, _U, _P],
     "nsr_gather_train_rays": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _U, _P],
     "nsr_prepare_train_rays": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P, _P, _U, _P, _P],
-    "nsr_update_ray_count": [_P, _P, _I, _I, _P],
+    "nsr_update_ray_count": [_P, _P, _I, _I, _P, _P],
     "nsr_ray_aabb_intersect": [_P, _P, _P, _P, _P, _U, _P],
     "nsr_ray_march_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _U, _P],
     "nsr_ray_march_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _U, _P],
@@ -103,6 +103,7 @@ SIGNATURES = {
     "nsr_ray_march_bricks_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _U, _P],
     "nsr_ray_march_bricks_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _P, _P, _P, _U, _P],
     "nsr_pack_from_counts": [_P, _P, _P, _U, _P],
+    "nsr_pack_from_counts_capped": [_P, _P, _P, _U, _U, _P, _P],
     "nsr_pack_info": [_P, _P, _U, _U, _P],
     "nsr_contract": [_P, _P, _I, _P, _U, _P],
     "nsr_contract_inv": [_P, _P, _I, _P, _U, _P],
@@ -120,9 +121,9 @@ SIGNATURES = {
     "nsr_neus_alpha_forward": [_P, _P, _P, _P, _P, _F, _P, _U, _P],
     "nsr_neus_alpha_backward": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _U, _P],
     "nsr_nerf_prune_layout": [_SD, _U, ctypes.POINTER(NsrNerfPruneLayout)],
-    "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P],
+    "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P],
     "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
-    "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P],
+    "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P],
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                             ctypes.POINTER(ctypes.c_uint64)],

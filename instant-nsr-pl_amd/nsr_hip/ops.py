@@ -115,7 +115,7 @@ def hashgrid_backward_params(x, dy, grad_table, desc, mask_count=None, grad_scal
             ws = torch.empty(int(nws), dtype=F32, device=x.device)
             check(lib.nsr_hashgrid_backward_params_owner(ptr(x), ptr(dy), layout, stride, ptr(grad_table), ptr(ws), n, mc,
                                                          float(grad_scale), int(bool(accumulate)), _byref(desc),
-                                                         stream_ptr()), "nsr_hashgrid_backward_params_owner")
+                                                         None, stream_ptr()), "nsr_hashgrid_backward_params_owner")
     return grad_table
 
 

@@ -189,7 +189,7 @@ def test_device_ray_count_matches_python_arithmetic():
         target, mx = rnd.choice([2 ** 18, 256 * 1024, 123457]), rnd.choice([8192, 4096, 100000])
         n_dev.fill_(n)
         s_dev.fill_(s)
-        check(lib.nsr_update_ray_count(ptr(s_dev), ptr(n_dev), target, mx, stream_ptr()), "nsr_update_ray_count")
+        check(lib.nsr_update_ray_count(ptr(s_dev), ptr(n_dev), target, mx, None, stream_ptr()), "nsr_update_ray_count")
         want = n
         if s > 0:
             t = int(n * (target / s))
@@ -214,3 +214,54 @@ def test_trainer_device_ray_count_tracks_host_mirror():
         torch.cuda.synchronize()
         assert int(tr._n_rays_dev.item()) == tr.train_num_rays
     assert len(seen) > 3
+
+
+def test_async_steps_match_synchronous_steps():
+    """device-side counts (no host sync in the step) == the step that reads its counts back, same seeds"""
+    import nsr
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
+    cfg = dict(nsr.configs.get("nerf-blender"))
+    cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
+    out = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        model = nsr.NeRFModel(cfg).cuda().train()
+        tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=mode)
+        steps = [tr.train_step() for _ in range(30)]
+        losses = [float(s["loss"]) for s in steps]
+        if mode:
+            c = tr.counters()
+            assert c["truncated"] == 0
+            out[mode] = (losses, c["samples"], c["rays"])
+        else:
+            out[mode] = (losses, sum(s["n_samples"] for s in steps), sum(s["n_rays"] for s in steps))
+    (l0, s0, r0), (l1, s1, r1) = out[False], out[True]
+    assert abs(l0[0] - l1[0]) < 1e-5 * max(1.0, abs(l0[0])), (l0[0], l1[0])  # identical first batch
+    assert abs(s0 - s1) <= 0.02 * s0 and abs(r0 - r1) <= 0.02 * r0, (s0, s1, r0, r1)
+    assert abs(sum(l0[-5:]) - sum(l1[-5:])) < 0.25 * sum(l0[-5:]) + 1e-3
+
+
+def test_async_capacity_overflow_is_reported_and_recovers():
+    import nsr
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
+    cfg = dict(nsr.configs.get("nerf-blender"))
+    cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
+    torch.manual_seed(0)
+    model = nsr.NeRFModel(cfg).cuda().train()
+    tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
+    a = tr._async_state()
+    a["m_cap"], a["s_cap"] = 16384, 16384  # far too small: samples get dropped, the packing kernels count it
+    for _ in range(40):
+        tr.train_step()
+        torch.cuda.synchronize()  # lets the lagged statistics arrive so the capacities can react
+    c = tr.counters()
+    assert c["truncated"] > 0 and c["m_cap"] > 16384
+    before = c["truncated"]
+    for _ in range(20):
+        tr.train_step()
+        torch.cuda.synchronize()
+    assert tr.counters()["truncated"] == before and bool(torch.isfinite(tr.last["loss"]))

@@ -60,7 +60,7 @@ if which in ("all", "mlp"):
         part = torch.empty(int(lib.nsr_mlp_backward_workspace_floats(ctypes.byref(md), n)), device="cuda")
         def run(gwp, dxp):
             check(lib.nsr_mlp_backward_ex(ptr(dout), 1, nout, None, ptr(out), ptr(x), 0, 32, 0, ptr(acts), ptr(w), ptr(gwp) if gwp is not None else None,
-                                          ptr(dxp) if dxp is not None else None, 32, 0, ptr(part), n, 128.0, ctypes.byref(md), stream_ptr()))
+                                          ptr(dxp) if dxp is not None else None, 32, 0, ptr(part), n, 128.0, ctypes.byref(md), None, stream_ptr()))
         print(f"mlp_backward h{nh} [S] dW+dx: {bench(lambda: run(gw, dx)):.1f} us   dW only: {bench(lambda: run(gw, None)):.1f}   dx only: {bench(lambda: run(None, dx)):.1f}")
 if which in ("all", "march"):
     import nsr
