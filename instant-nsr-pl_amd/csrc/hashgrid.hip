@@ -227,6 +227,9 @@ constexpr int OWN_BLOCK = NSR_OWN_BLOCK;
 constexpr int OWN_POW2_LOG2 = NSR_OWN_LOG2;            // hashed levels: 8192-entry slices (128 KiB at F=2) -> owner = hash bits
 constexpr int OWN_LDS_WORDS = 2 << NSR_OWN_LOG2;       // 64-bit accumulators (measured: 2^13 119 us, 2^12 133 us, 2^11 124 us)
 constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decomposition aims for
+constexpr int OWN_DENSE_TARGET_WGS = 64; // ... for the dense (coarse) levels: every sample lands in few entries and the
+                                         // workgroups serialise on LDS conflicts -- more, smaller item chunks
+                                         // (measured at 1.28e5 surface samples: 32 -> 185 us, 64 -> 177 us, 128 -> 198 us)
 constexpr int OWN_MAX_SLICES = 2048;    // per level (T = 2^24 at 8192-entry slices)
 constexpr int OWN_BIN_BLOCK = 256;      // threads per block of the two binning passes
 constexpr int OWN_BIN_SPT = NSR_OWN_BIN_SPT;  // samples per thread: fewer, larger blocks -> fewer global range reservations
@@ -237,10 +240,10 @@ constexpr float OWN_FIX_INV = 1.f / 68719476736.f;
 // would take every sample and serialise on same-address LDS atomics) writes per-chunk slabs that a second tiny kernel
 // sums; C == 1 stores straight into the gradient.
 struct OwnerMap {
-    // XCD-aware placement: block b runs on XCD b % 8 (round-robin dispatch); all workgroups of one level sit on ONE XCD
-    // so that its private L2 serves the level's dy and the shared x to every slice after the first.
-    uint32_t xcd_of_level[NSR_MAX_LEVELS];
-    uint32_t level_start[NSR_MAX_LEVELS];  // first block index (b / 8) of the level within its XCD
+    // block b runs on XCD b % 8 (round-robin dispatch).  The workgroups of every level are dealt to ALL XCDs: keeping a
+    // level on one XCD (its L2 then serves dy to every slice) was measured slower -- 11 hashed levels do not divide
+    // over 8 XCDs, and the slowest XCD sets the kernel time (1.28e5 samples: 201 us whole-level vs 177 us dealt).
+    uint32_t level_start[NSR_MAX_LEVELS];  // first row (b / 8) of the level; rows [start, start + ceil(wgs / 8))
     uint32_t n_slices[NSR_MAX_LEVELS];
     uint32_t n_chunks[NSR_MAX_LEVELS];
     uint32_t slab_offset[NSR_MAX_LEVELS];  // floats, into the slab workspace (levels with n_chunks > 1)
@@ -392,12 +395,14 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     uint32_t level = d.n_levels;
-    for (uint32_t l = 0; l < d.n_levels; ++l)
-        if (om.xcd_of_level[l] == xcd && j >= om.level_start[l] && j < om.level_start[l] + om.n_slices[l] * om.n_chunks[l])
-            level = l;
+    uint32_t local = 0;
+    for (uint32_t l = 0; l < d.n_levels; ++l) {
+        const uint32_t wgs = om.n_slices[l] * om.n_chunks[l];
+        const uint32_t t = (j - om.level_start[l]) * 8u + xcd;
+        if (j >= om.level_start[l] && t < wgs) { level = l; local = t; }
+    }
     if (level == d.n_levels) return;  // padding block of a lighter XCD
     const uint32_t C = om.n_chunks[level], epb = om.entries_per_slice[level];
-    const uint32_t local = j - om.level_start[level];
     const uint32_t slice = local / C, chunk = local % C;
     const uint32_t r0 = slice * epb;
     const LevelGeom g = load_level(d, level);
@@ -499,10 +504,10 @@ static uint32_t make_owner_map(const NsrGridDesc *desc, OwnerMap *om, uint64_t *
 {
     const uint32_t F = desc->n_features, L = desc->n_levels;
     uint64_t slab = 0;
-    uint32_t wgs[NSR_MAX_LEVELS], bins = 0;
+    uint32_t bins = 0, rows = 0;
     for (uint32_t l = 0; l < NSR_MAX_LEVELS; ++l)
-        om->xcd_of_level[l] = om->level_start[l] = om->n_slices[l] = om->n_chunks[l] = om->slab_offset[l] =
-            om->entries_per_slice[l] = om->bin_offset[l] = wgs[l] = 0;
+        om->level_start[l] = om->n_slices[l] = om->n_chunks[l] = om->slab_offset[l] = om->entries_per_slice[l] =
+            om->bin_offset[l] = 0;
     for (uint32_t l = 0; l < L; ++l) {
         const uint32_t size = desc->size[l], res = desc->resolution[l];
         const bool dense = (uint64_t)res * res * res <= (uint64_t)size;
@@ -511,8 +516,9 @@ static uint32_t make_owner_map(const NsrGridDesc *desc, OwnerMap *om, uint64_t *
         const uint32_t p2 = 1u << OWN_POW2_LOG2;
         if (!dense && (size & (size - 1)) == 0 && size >= p2 && p2 <= max_epb && res < p2) epb = p2;
         const uint32_t R = nsr_div_up(size, epb);
+        const uint32_t target = dense ? OWN_DENSE_TARGET_WGS : OWN_TARGET_WGS;
         uint32_t C = 1;
-        if (R < OWN_TARGET_WGS) C = (OWN_TARGET_WGS + R - 1) / R;  // few slices: split the items instead
+        if (R < target) C = (target + R - 1) / R;  // few slices: split the items instead
         om->n_slices[l] = R;
         om->n_chunks[l] = C;
         om->entries_per_slice[l] = epb;
@@ -520,28 +526,12 @@ static uint32_t make_owner_map(const NsrGridDesc *desc, OwnerMap *om, uint64_t *
         om->bin_offset[l] = bins;
         bins += R;
         if (C > 1) slab += (uint64_t)C * size * F;
-        wgs[l] = R * C;
+        om->level_start[l] = rows;
+        rows += nsr_div_up(R * C, 8);
     }
-    // longest-processing-time placement of whole levels onto the 8 XCDs
-    uint32_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool placed[NSR_MAX_LEVELS] = {};
-    for (uint32_t it = 0; it < L; ++it) {
-        uint32_t best = L;
-        for (uint32_t l = 0; l < L; ++l)
-            if (!placed[l] && (best == L || wgs[l] > wgs[best])) best = l;
-        uint32_t x = 0;
-        for (uint32_t k = 1; k < 8; ++k)
-            if (load[k] < load[x]) x = k;
-        placed[best] = true;
-        om->xcd_of_level[best] = x;
-        om->level_start[best] = load[x];
-        load[x] += wgs[best];
-    }
-    uint32_t per_xcd = 0;
-    for (uint32_t k = 0; k < 8; ++k) per_xcd = load[k] > per_xcd ? load[k] : per_xcd;
     *slab_floats = slab;
     *n_bins = bins;
-    return per_xcd * 8;
+    return rows * 8;
 }
 
 // row-major dy [n, stride] (half or float) -> level-major fp32 [L][n][F]; 64 samples x all columns per block
