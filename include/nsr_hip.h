@@ -92,6 +92,15 @@ int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_la
                                        float grad_scale, int accumulate, const NsrGridDesc *desc, const int32_t *n_dev,
                                        void *stream);
 
+/* The same in two phases, so that a caller can overlap the first with other work: _bin needs only the positions (it
+ * sorts the (sample, corner pair) items by owning slice into `workspace`), _accumulate needs dy and that workspace. */
+int nsr_hashgrid_backward_params_owner_bin(const float *x, float *workspace, uint32_t n, uint32_t level_mask_count,
+                                           const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
+int nsr_hashgrid_backward_params_owner_accumulate(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
+                                                  float *grad_table, float *workspace, uint32_t n,
+                                                  uint32_t level_mask_count, float grad_scale, int accumulate,
+                                                  const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
+
 /* dx[n,3] (fp32) = (d y / d x)^T dy  -- the NeuS analytic normal, models/geometry.py:177-180 */
 int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
                                 uint32_t dy_stride, float *dx, uint32_t n, uint32_t level_mask_count,
@@ -384,6 +393,7 @@ typedef struct NsrNerfMainLayout {
 #define NSR_PROF_MLP_FORWARD_COLOR 3
 #define NSR_PROF_MLP_BACKWARD_COLOR 4
 #define NSR_PROF_MLP_BACKWARD_DENSITY 5
+#define NSR_PROF_GRID_BACKWARD_BIN 6 /* item binning of the table backward, on the main pass's helper stream */
 void nsr_profile_enable(int on);
 int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches, uint64_t *units);
 

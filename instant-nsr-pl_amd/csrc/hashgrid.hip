@@ -791,17 +791,15 @@ extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridD
     return slab + (uint64_t)desc->n_levels * desc->n_features * n + 3ull * n_bins + (uint64_t)desc->n_levels * 8ull * n;
 }
 
-extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
-                                                  float *grad_table, float *workspace, uint32_t n,
-                                                  uint32_t level_mask_count, float grad_scale, int accumulate,
-                                                  const NsrGridDesc *desc, const int32_t *n_dev, void *stream)
+// phases: 1 = bin the items (needs only x), 2 = accumulate (needs dy and the bins), 3 = both
+static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_t dy_stride, float *grad_table,
+                          float *workspace, uint32_t n, uint32_t level_mask_count, float grad_scale, int accumulate,
+                          const NsrGridDesc *desc, const int32_t *n_dev, int phases, void *stream)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
-    NSR_REQUIRE(grad_table && workspace, "nsr_hashgrid_backward_params_owner: grad_table / workspace is NULL");
-    NSR_REQUIRE(n == 0 || (x && dy), "nsr_hashgrid_backward_params_owner: NULL pointer");
+    NSR_REQUIRE(workspace, "nsr_hashgrid_backward_params_owner: workspace is NULL");
+    NSR_REQUIRE(n == 0 || x, "nsr_hashgrid_backward_params_owner: NULL pointer");
     NSR_REQUIRE(n < (1u << 28), "nsr_hashgrid_backward_params_owner: at most 2^28 - 1 samples per call");
-    NSR_REQUIRE(dy_layout >= 0 && dy_layout <= 2, "nsr_hashgrid_backward_params_owner: dy_layout must be 0 (half "
-                "row-major), 1 (float row-major) or 2 (float level-major)");
     const uint32_t F = desc->n_features, L = desc->n_levels;
     hipStream_t st = (hipStream_t)stream;
     OwnerMap om;
@@ -813,6 +811,23 @@ extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy
     float *lm = workspace + slab_floats;
     uint32_t *counts = reinterpret_cast<uint32_t *>(lm + (uint64_t)L * F * n);
     uint32_t *bin_start = counts + n_bins, *cursors = bin_start + n_bins, *items = cursors + n_bins;
+    if (phases & 1) {  // bin the (sample, corner pair) items by owning slice: count, scan, fill
+        NSR_REQUIRE(hipMemsetAsync(counts, 0, n_bins * sizeof(uint32_t), st) == hipSuccess,
+                    "nsr_hashgrid_backward_params_owner: hipMemsetAsync failed");
+        if (n > 0) {
+            const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK * OWN_BIN_SPT), L);
+            hipLaunchKernelGGL((k_own_bin<false>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
+                               bin_start, cursors, items, om, *desc, n_dev);
+            hipLaunchKernelGGL(k_own_bin_scan, dim3(L), dim3(256), 0, st, counts, bin_start, cursors, om);
+            hipLaunchKernelGGL((k_own_bin<true>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
+                               bin_start, cursors, items, om, *desc, n_dev);
+            NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(bin)");
+        }
+    }
+    if (!(phases & 2)) return NSR_OK;
+    NSR_REQUIRE(grad_table && (n == 0 || dy), "nsr_hashgrid_backward_params_owner: NULL pointer");
+    NSR_REQUIRE(dy_layout >= 0 && dy_layout <= 2, "nsr_hashgrid_backward_params_owner: dy_layout must be 0 (half "
+                "row-major), 1 (float row-major) or 2 (float level-major)");
     const float *dy_lm = (const float *)dy;
     if (dy_layout != 2 && n > 0) {
         const uint32_t C = L * F;
@@ -827,18 +842,6 @@ extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy
         });
         NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(transpose)");
         dy_lm = lm;
-    }
-    // bin the (sample, corner pair) items by owning slice: count, scan, fill
-    NSR_REQUIRE(hipMemsetAsync(counts, 0, n_bins * sizeof(uint32_t), st) == hipSuccess,
-                "nsr_hashgrid_backward_params_owner: hipMemsetAsync failed");
-    if (n > 0) {
-        const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK * OWN_BIN_SPT), L);
-        hipLaunchKernelGGL((k_own_bin<false>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                           bin_start, cursors, items, om, *desc, n_dev);
-        hipLaunchKernelGGL(k_own_bin_scan, dim3(L), dim3(256), 0, st, counts, bin_start, cursors, om);
-        hipLaunchKernelGGL((k_own_bin<true>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                           bin_start, cursors, items, om, *desc, n_dev);
-        NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(bin)");
     }
     const size_t lds = OWN_LDS_WORDS * sizeof(unsigned long long);
     DISPATCH_F(F, {
@@ -855,6 +858,32 @@ extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy
     });
     NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner");
     return NSR_OK;
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
+                                                  float *grad_table, float *workspace, uint32_t n,
+                                                  uint32_t level_mask_count, float grad_scale, int accumulate,
+                                                  const NsrGridDesc *desc, const int32_t *n_dev, void *stream)
+{
+    return owner_backward(x, dy, dy_layout, dy_stride, grad_table, workspace, n, level_mask_count, grad_scale, accumulate,
+                          desc, n_dev, 3, stream);
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner_bin(const float *x, float *workspace, uint32_t n,
+                                                      uint32_t level_mask_count, const NsrGridDesc *desc,
+                                                      const int32_t *n_dev, void *stream)
+{
+    return owner_backward(x, nullptr, 2, 0, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, n_dev, 1, stream);
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner_accumulate(const float *x, const void *dy, int dy_layout,
+                                                             uint32_t dy_stride, float *grad_table, float *workspace,
+                                                             uint32_t n, uint32_t level_mask_count, float grad_scale,
+                                                             int accumulate, const NsrGridDesc *desc,
+                                                             const int32_t *n_dev, void *stream)
+{
+    return owner_backward(x, dy, dy_layout, dy_stride, grad_table, workspace, n, level_mask_count, grad_scale, accumulate,
+                          desc, n_dev, 2, stream);
 }
 
 extern "C" int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,

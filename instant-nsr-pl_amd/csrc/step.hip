@@ -41,6 +41,14 @@ namespace {
 struct ProfRec { int tag; uint32_t units; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;  // events are reused: creating one costs the host several microseconds
+inline hipEvent_t prof_event()
+{
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
 
 struct ProfScope {
     bool on;
@@ -51,8 +59,8 @@ struct ProfScope {
         if (!on) return;
         r.tag = tag;
         r.units = units;
-        (void)hipEventCreate(&r.a);
-        (void)hipEventCreate(&r.b);
+        r.a = prof_event();
+        r.b = prof_event();
         (void)hipEventRecord(r.a, st);
     }
     ~ProfScope()
@@ -73,7 +81,7 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
     *launches = 0;
     *units = 0;
     if (tag < 0) {  // reset
-        for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto &r : g_prof) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
         g_prof.clear();
         return NSR_OK;
     }
@@ -95,6 +103,23 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
         const int rc_ = (expr);  \
         if (rc_ != NSR_OK) return rc_; \
     } while (0)
+
+// Helper stream of the main pass: the item binning of the table backward depends only on the sample positions, so it runs
+// beside the colour MLP / compositing / MLP backward chain instead of in front of the accumulation kernel.
+struct HelperStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+    bool init()
+    {
+        if (ok) return true;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        return ok = true;
+    }
+};
+static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
 
 extern "C" int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marched, NsrNerfPruneLayout *out)
 {
@@ -225,6 +250,20 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     if (S > 0)  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
         NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, dirs,
                                             (int64_t *)(ws + L.ray_indices), n_rays, stream));
+    // fork: bin the table-backward items on the helper stream as soon as the kept positions exist
+    const bool overlap_bins = compute_grads && S > 0 && g_helper.init();
+    if (overlap_bins) {
+        NSR_REQUIRE(hipEventRecord(g_helper.fork, st) == hipSuccess &&
+                        hipStreamWaitEvent(g_helper.stream, g_helper.fork, 0) == hipSuccess,
+                    "nsr_nerf_main_pass: helper stream fork failed");
+        {
+            ProfScope p(NSR_PROF_GRID_BACKWARD_BIN, S, g_helper.stream);
+            NSR_TRY(nsr_hashgrid_backward_params_owner_bin(x01, (float *)(ws + L.grid_ws), S, d->grid.n_levels, &d->grid,
+                                                           n_kept_dev, g_helper.stream));
+        }
+        NSR_REQUIRE(hipEventRecord(g_helper.join, g_helper.stream) == hipSuccess,
+                    "nsr_nerf_main_pass: helper stream join failed");
+    }
     NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, n_kept_dev, stream));
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
@@ -256,8 +295,16 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     }
     {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
-        NSR_TRY(nsr_hashgrid_backward_params_owner(x01, d_enc, 2, 0, grad_table, (float *)(ws + L.grid_ws), S,
-                                                   d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
+        if (overlap_bins) {
+            NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess,
+                        "nsr_nerf_main_pass: helper stream join failed");
+            NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate(x01, d_enc, 2, 0, grad_table,
+                                                                  (float *)(ws + L.grid_ws), S, d->grid.n_levels, 1.0f,
+                                                                  0, &d->grid, n_kept_dev, stream));
+        } else {
+            NSR_TRY(nsr_hashgrid_backward_params_owner(x01, d_enc, 2, 0, grad_table, (float *)(ws + L.grid_ws), S,
+                                                       d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
+        }
     }
     return NSR_OK;
 }

@@ -20,12 +20,15 @@ _PROFILE = None
 
 
 _NATIVE_TAGS = {0: "hashgrid_forward", 1: "hashgrid_backward_params", 2: "mlp_forward_h1", 3: "mlp_forward_h2",
-                4: "mlp_backward_h2", 5: "mlp_backward_h1"}
+                4: "mlp_backward_h2", 5: "mlp_backward_h1", 6: "hashgrid_backward_bin"}
 
 
-def profile_begin():
+def profile_begin(native_only=False):
+    """start collecting HIP-event timings.  ``native_only``: only the launches timed inside the C orchestration
+    (pooled events, ~2 us of host time per scope); the Python-side scopes allocate a torch event pair each and are too
+    expensive to leave on inside a measured region."""
     global _PROFILE
-    _PROFILE = {}
+    _PROFILE = None if native_only else {}
     d, a, b = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
     lib.nsr_profile_collect(-1, _byref(d), _byref(a), _byref(b))
     lib.nsr_profile_enable(1)

@@ -174,7 +174,7 @@ def test_dead_ray_slots_do_not_change_the_step():
                                                               t_min[:600].contiguous(), t_max[:600].contiguous()))
     assert a["num_samples"] == b["num_samples"] and a["num_marched"] == b["num_marched"] and a["num_samples"] > 0
     assert torch.equal(a["comp_rgb"][:600], b["comp_rgb"]) and bool((a["opacity"][600:] == 0).all())
-    assert torch.equal(a["loss_acc"], b["loss_acc"])
+    assert torch.allclose(a["loss_acc"], b["loss_acc"], rtol=1e-6)  # atomically summed over the rays
 
 
 def test_device_ray_count_matches_python_arithmetic():
