@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: march in order instead of on the side stream")
+    ap.add_argument("--graphs", action="store_true", help="replay each step from a captured HIP graph (measured slower)")
     ap.add_argument("--sync-steps", action="store_true",
                     help="diagnostic: the step variant that reads its sample counts back to the host (two syncs/step)")
     args = ap.parse_args()
@@ -101,6 +102,7 @@ def main():
     data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
     tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42, async_mode=not args.sync_steps)
     tr.pipeline_march = not args.no_pipeline
+    tr.use_graphs = args.graphs
 
     def sync():
         if world > 1:
@@ -110,9 +112,10 @@ def main():
     for _ in range(args.warmup):
         tr.train_step()
     sync()
-    # HIP events around the hash-grid / MLP launches of the timed steps, recorded by the C orchestration on the stream
-    # each kernel is launched on (pooled events; the Python-side phase scopes run in a separate short pass below)
-    ops.profile_begin(native_only=tr.async_mode)
+    # asynchronous mode replays captured HIP graphs in the timed region (events cannot be recorded into a graph): the
+    # per-kernel HIP-event timings are taken right after it, over further eager steps of the same run
+    if not tr.async_mode:
+        ops.profile_begin()
     c0 = tr.counters() if tr.async_mode else None  # device-side totals (reading them synchronises: outside the clock)
     sync()
     t0 = time.perf_counter()
@@ -125,24 +128,31 @@ def main():
     t_enqueued = time.perf_counter() - t0  # the host has queued every step (it never waits inside one)
     sync()
     dt = time.perf_counter() - t0
-    prof = ops.profile_end()
+    prof = ops.profile_end() if not tr.async_mode else {}
     if tr.async_mode:
         c1 = tr.counters()
         n_samples, n_rays = c1["samples"] - c0["samples"], c1["rays"] - c0["rays"]
         n_marched = c1["marched"] - c0["marched"]
         if c1["truncated"] != c0["truncated"]:
             raise SystemExit("sample buffers overflowed inside the timed region: the measurement is invalid")
-        # the C orchestration logs buffer CAPACITIES as launch sizes; the live counts are these device-side totals
-        live = {"hashgrid_forward": n_marched, "mlp_forward_h1": n_marched, "hashgrid_backward_params": n_samples,
-                "hashgrid_backward_bin": n_samples,
-                "mlp_forward_h2": n_samples, "mlp_backward_h1": n_samples, "mlp_backward_h2": n_samples}
+        # per-kernel durations: 64 further EAGER steps with the pooled HIP events of the C orchestration, recorded on
+        # the stream each kernel is launched on; then 32 steps with the Python-side phase scopes
+        ops.profile_begin(native_only=True)
+        for _ in range(64):
+            tr.train_step()
+        prof = ops.profile_end()
+        c2 = tr.counters()
+        live_m, live_s = c2["marched"] - c1["marched"], c2["samples"] - c1["samples"]
+        live = {"hashgrid_forward": live_m, "mlp_forward_h1": live_m, "hashgrid_backward_params": live_s,
+                "hashgrid_backward_bin": live_s, "mlp_forward_h2": live_s, "mlp_backward_h1": live_s,
+                "mlp_backward_h2": live_s}
         prof = {k: ((v[0], v[1], float(live[k])) if k in live else v) for k, v in prof.items()}
-        ops.profile_begin()  # phases and Python-launched kernels: 32 further steps, outside the clock
+        ops.profile_begin()
         for _ in range(32):
             tr.train_step()
         for k, v2 in ops.profile_end().items():
             if k not in prof:
-                prof[k] = (v2[0] * args.steps / 32.0, int(v2[1] * args.steps / 32.0), v2[2] * args.steps / 32.0)
+                prof[k] = v2
 
     tot = torch.tensor([dt, float(n_samples), float(n_rays)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -156,7 +166,8 @@ def main():
         # dominant kernel: the hash-grid launch class with the largest total time in the timed region
         roof = None
         kern = {}
-        phases = {k[6:]: round(v[0] / args.steps, 4) for k, v in prof.items() if k.startswith("phase:")}
+        phase_steps = 32 if tr.async_mode else args.steps
+        phases = {k[6:]: round(v[0] / phase_steps, 4) for k, v in prof.items() if k.startswith("phase:")}
         for name, (ms_total, launches, units) in prof.items():
             if name.startswith("phase:"):
                 continue

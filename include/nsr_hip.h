@@ -424,8 +424,14 @@ int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, ui
  * ------------------------------------------------------------------------------------------------ */
 int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, nsr_half *shadow_half,
                    uint64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                   float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad,
+                   float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad, const float *hyper,
                    void *stream);
+/* hyper (device float[3], may be NULL): {lr, bias_correction1, bias_correction2} read on the device instead of the scalar
+ * arguments.  nsr_adam_tick advances the device-side step counter (int32[1]) and writes them -- MultiStepLR
+ * (configs nerf-blender.yaml:80-85: up to three milestones, pass INT32_MAX for unused ones) over base_lr, in double
+ * arithmetic -- so that a captured (hipGraph) step needs no per-step host scalar. */
+int nsr_adam_tick(int32_t *step, float *hyper, double base_lr, double beta1, double beta2, double gamma,
+                  int32_t milestone0, int32_t milestone1, int32_t milestone2, void *stream);
 
 #ifdef __cplusplus
 }

@@ -186,8 +186,9 @@ k_neus_alpha_bwd(const float *__restrict__ sdf, const float *__restrict__ normal
 __global__ void __launch_bounds__(EW_BLOCK)
 k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
         __half *__restrict__ shadow, uint64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
-        float bc2, float unscale, int zero_grad)
+        float bc2, float unscale, int zero_grad, const float *__restrict__ hyper)
 {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }  // device-side schedule (nsr_adam_tick): graph-replayable
     const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 4;
     for (uint64_t base = ((uint64_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 4; base < n; base += stride) {
         if (base + 4 <= n) {
@@ -223,6 +224,23 @@ k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, flo
             }
         }
     }
+}
+
+// step counter, MultiStepLR-scaled learning rate and bias corrections on the device, in the double arithmetic the host
+// path uses: a captured step (hipGraph) then needs no per-step host scalar
+__global__ void k_adam_tick(int32_t *__restrict__ step, float *__restrict__ hyper, double base_lr, double b1, double b2,
+                            double gamma, int32_t m0, int32_t m1, int32_t m2)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int32_t done = *step;  // optimizer steps taken so far == the trainer's global_step
+    const int32_t s = done + 1;
+    *step = s;
+    const int k = (done >= m0) + (done >= m1) + (done >= m2);
+    double scale = 1.0;
+    for (int i = 0; i < k; ++i) scale *= gamma;
+    hyper[0] = (float)(base_lr * scale);
+    hyper[1] = (float)(1.0 - pow(b1, (double)s));
+    hyper[2] = (float)(1.0 - pow(b2, (double)s));
 }
 
 }  // namespace
@@ -303,7 +321,7 @@ extern "C" int nsr_neus_alpha_backward(const float *sdf, const float *normal, co
 extern "C" int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, nsr_half *shadow_half,
                               uint64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                               float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad,
-                              void *stream)
+                              const float *hyper, void *stream)
 {
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(params && grad && exp_avg && exp_avg_sq, "nsr_adamw_step: NULL pointer");
@@ -313,7 +331,17 @@ extern "C" int nsr_adamw_step(float *params, float *grad, float *exp_avg, float 
     if (blocks > 2048) blocks = 2048;  // grid-stride: ~8 blocks per CU
     hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, params, grad, exp_avg,
                        exp_avg_sq, (__half *)shadow_half, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
-                       bias_correction2, grad_unscale, zero_grad);
+                       bias_correction2, grad_unscale, zero_grad, hyper);
     NSR_CHECK_LAUNCH("nsr_adamw_step");
+    return NSR_OK;
+}
+
+extern "C" int nsr_adam_tick(int32_t *step, float *hyper, double base_lr, double beta1, double beta2, double gamma,
+                             int32_t milestone0, int32_t milestone1, int32_t milestone2, void *stream)
+{
+    NSR_REQUIRE(step && hyper, "nsr_adam_tick: NULL pointer");
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, (hipStream_t)stream, step, hyper, base_lr, beta1, beta2, gamma,
+                       milestone0, milestone1, milestone2);
+    NSR_CHECK_LAUNCH("nsr_adam_tick");
     return NSR_OK;
 }

@@ -273,14 +273,16 @@ class FusedNeRFStep:
         rs["scratch"] = torch.empty(slots * cap * 2, dtype=F32, device=dev)
         return rs
 
-    def march_async(self, rs, dataset, generator, n_active, m_cap, stats, background="random"):
-        """ray preparation + marching pass + capped packing into ray set ``rs`` on the CURRENT stream; no host sync"""
+    def march_async(self, rs, dataset, generator, n_active, m_cap, stats, background="random", bricks=None):
+        """ray preparation + marching pass + capped packing into ray set ``rs`` on the CURRENT stream; no host sync.
+        ``bricks``: the packed occupancy grid to march through (default: pack / look up the model's current grid)"""
         m, grid = self.model, self.model.occupancy_grid
         slots = rs["slots"]
         rs["u"].uniform_(generator=generator)
         rs["bg"] = rs["u"][4, :3] if background == "random" else torch.ones(3, device=rs["u"].device)
         jitter = float(m.render_step_size) if m.randomized else 0.0
-        bricks = _ops.grid_bricks(grid.binary)
+        if bricks is None:
+            bricks = _ops.grid_bricks(grid.binary)
         if bricks is None:
             raise NotImplementedError("the asynchronous step needs a brick-able occupancy grid (resolution % 16 == 0)")
         rx, ry, rz = (int(v) for v in grid.binary.shape)

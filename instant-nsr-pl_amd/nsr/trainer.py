@@ -47,6 +47,24 @@ class FusedAdamW:
             self.other.step()
             self.other.zero_grad(set_to_none=False)
 
+    def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33):
+        """the same update with the step counter, MultiStepLR scale and bias corrections kept ON THE DEVICE
+        (nsr_adam_tick): no per-step host scalar, so the launches can be replayed from a captured graph"""
+        if self.other is not None:
+            raise NotImplementedError("step_device covers models whose parameters all live in fused tcnn modules")
+        dev = self.tcnn_modules[0].params.device
+        if getattr(self, "_step_dev", None) is None:
+            self._step_dev = torch.tensor([self.step_count], dtype=torch.int32, device=dev)
+            self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        _ops.adam_tick(self._step_dev, self._hyper, self.lr, self.betas[0], self.betas[1], gamma, milestones)
+        self.step_count += 1  # host mirror (not read by the kernels)
+        for m in self.tcnn_modules:
+            p = m.params
+            exp_avg, exp_avg_sq, shadow = self.state[p]
+            _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr, self.betas[0], self.betas[1],
+                            self.eps, self.wd, self.step_count, zero_grad=True, hyper=self._hyper)
+            m._shadow, m._shadow_key = shadow, (p.data_ptr(), p._version, p.device)
+
 
 def multistep_lr_scale(step, milestones=(10000, 15000, 18000), gamma=0.33):
     """configs/nerf-blender.yaml:80-85"""
@@ -74,7 +92,10 @@ class Trainer:
         self.opt = FusedAdamW(tc, other)
         self.last = {}
         self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None
-        self.async_mode, self._as = bool(async_mode), None
+        # use_graphs: replay the queued launches of a step from a captured HIP graph.  Correct (tests/test_gpu_fused.py)
+        # but measured SLOWER on ROCm 7.2 (0.759 vs 0.735 ms/step: hipGraphLaunch re-submits every node from the host),
+        # so it is off by default
+        self.async_mode, self._as, self.use_graphs = bool(async_mode), None, False
         if fused and config["name"] == "nerf":
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
@@ -201,6 +222,10 @@ class Trainer:
         a["m_cap"] = max(1 << 20, 4 * self.train_num_samples)
         a["s_cap"] = max(1 << 18, (3 * self.train_num_samples) // 2)
         a["truncated"] = 0
+        a["graphs"], a["eager_seen"], a["total_kept"] = {}, set(), None
+        g = self.model.occupancy_grid.binary
+        a["bricks"] = torch.empty(int(_lib.nsr_grid_bricks_words64(*[int(v) for v in g.shape])), dtype=torch.int64,
+                                  device=dev)
         self._as = a
         return a
 
@@ -235,25 +260,61 @@ class Trainer:
 
     def _train_step_async(self):
         """the fused step with every count on the device (FusedNeRFStep.forward_backward_async): the host only queues
-        work -- ~45 launches through two C calls -- and never waits for the GPU.  Returns device tensors; use
-        ``counters()`` for totals."""
-        from .fused import FusedNeRFStep
-        model, fused, cfg = self.model, self.fused, self.config
+        work and never waits for the GPU.  With ``use_graphs`` the queued launches of a step are captured once per
+        variant (ray-set parity x in-order marching x launches-next-marching x capacities) as a HIP graph and
+        replayed: ~45 kernel launches become one graph launch.  Returns device tensors; ``counters()`` gives totals."""
+        model, cfg = self.model, self.config
         a = self._async_state()
-        dynamic = bool(cfg["dynamic_ray_sampling"])
-        main = torch.cuda.current_stream()
         with _ops.timed("phase:occupancy_update"):
             model.update_step(0, self.global_step)
+        _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # re-packed in place after a grid refresh
         k = self.global_step & 1
+        inorder = not a["pending"]
+        launch_next = bool(self.pipeline_march and not (cfg["grid_prune"] and (self.global_step + 1) % 16 == 0))
+        key = (k, inorder, launch_next, a["m_cap"], a["s_cap"])
+        graphs_ok = self.use_graphs and self.world_size == 1 and not _ops.profiling()  # events cannot be captured
+        graph = a["graphs"].get(key) if graphs_ok else None
+        if graph is None and graphs_ok and key in a["eager_seen"]:
+            graph = self._capture_async(a, key)
+        if graph is not None:
+            graph[0].replay()
+            a["pending"] = launch_next
+            loss = graph[1]
+        else:
+            loss = self._async_body(a, k, inorder, launch_next)
+            a["eager_seen"].add(key)
+        self.global_step += 1
+        self._async_capacities(a)
+        self.last = {"loss": loss, "n_rays": a["n_rays"], "n_samples": a["total_kept"]}
+        return self.last
+
+    def _capture_async(self, a, key):
+        k, inorder, launch_next = key[:3]
+        if len(a["graphs"]) > 16:  # capacities moved a lot: drop the stale captures
+            a["graphs"].clear()
+        g = torch.cuda.CUDAGraph()
+        if hasattr(g, "register_generator_state"):
+            g.register_generator_state(self.gen)
+        was_pending = a["pending"]
+        with torch.cuda.graph(g):
+            loss = self._async_body(a, k, inorder, launch_next)
+        a["pending"] = was_pending  # capturing queued nothing
+        a["graphs"][key] = (g, loss)
+        return a["graphs"][key]
+
+    def _async_body(self, a, k, inorder, launch_next):
+        """everything of one step that is queued on the GPU (and nothing else): capturable"""
+        from .fused import FusedNeRFStep
+        model, fused, cfg = self.model, self.fused, self.config
+        dynamic = bool(cfg["dynamic_ray_sampling"])
+        main = torch.cuda.current_stream()
         rs = a["sets"][k]
         stats_m, stats_s = a["stats"][0:8], a["stats"][8:16]
-        if a["pending"]:
-            main.wait_event(a["event"])  # the marching pass of this step ran on the side stream
-        else:
+        if inorder:
             with _ops.timed("phase:sample_rays"):
-                fused.march_async(rs, self.dataset, self.gen, a["n_rays"], a["m_cap"], stats_m, cfg["background_color"])
+                fused.march_async(rs, self.dataset, self.gen, a["n_rays"], a["m_cap"], stats_m, cfg["background_color"],
+                                  bricks=a["bricks"])
         model.background_color = rs["bg"]
-        next_updates_grid = cfg["grid_prune"] and (self.global_step + 1) % 16 == 0
 
         def after_prune_queued(total):
             with torch.cuda.device(self.device):
@@ -262,7 +323,7 @@ class Trainer:
                                                  int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), _stream_ptr()),
                        "nsr_update_ray_count")
             a["pending"] = False
-            if not self.pipeline_march or next_updates_grid:
+            if not launch_next:
                 return
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
@@ -271,17 +332,17 @@ class Trainer:
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
                 fused.march_async(a["sets"][1 - k], self.dataset, self.gen, a["n_rays"], a["m_cap"], stats_m,
-                                  cfg["background_color"])
+                                  cfg["background_color"], bricks=a["bricks"])
                 a["event"] = torch.cuda.Event()
                 a["event"].record(self._side)
             a["pending"] = True
 
         res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued)
+        a["total_kept"] = res["num_samples"]
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
-        self.global_step += 1
-        self._async_capacities(a)
-        self.last = {"loss": FusedNeRFStep.loss_value(res), "n_rays": a["n_rays"], "n_samples": res["num_samples"]}
-        return self.last
+            self.opt.step_device()
+        if a["pending"]:
+            main.wait_event(a["event"])  # join: the next step (or the grid refresh before it) starts behind the marching
+        return FusedNeRFStep.loss_value(res)

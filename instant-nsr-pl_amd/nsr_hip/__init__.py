@@ -60,6 +60,7 @@ class NsrNerfMainLayout(ctypes.Structure):
 
 
 _P, _I, _U, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_uint64
+_D = ctypes.c_double
 _GD, _MD = ctypes.POINTER(NsrGridDesc), ctypes.POINTER(NsrMlpDesc)
 _SD = ctypes.POINTER(NsrNerfStepDesc)
 
@@ -129,7 +130,8 @@ SIGNATURES = {
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                             ctypes.POINTER(ctypes.c_uint64)],
-    "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P],
+    "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P, _P],
+    "nsr_adam_tick": [_P, _P, _D, _D, _D, _D, _I, _I, _I, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,

@@ -17,6 +17,7 @@ F32, F16 = torch.float32, torch.float16
 # ---- optional HIP-event timing of the hot kernels (bench.py's roofline leg) -----------------------------------
 # Events are recorded on torch's current stream, which is the stream every kernel here is launched on.
 _PROFILE = None
+_NATIVE_ON = False
 
 
 _NATIVE_TAGS = {0: "hashgrid_forward", 1: "hashgrid_backward_params", 2: "mlp_forward_h1", 3: "mlp_forward_h2",
@@ -27,17 +28,23 @@ def profile_begin(native_only=False):
     """start collecting HIP-event timings.  ``native_only``: only the launches timed inside the C orchestration
     (pooled events, ~2 us of host time per scope); the Python-side scopes allocate a torch event pair each and are too
     expensive to leave on inside a measured region."""
-    global _PROFILE
+    global _PROFILE, _NATIVE_ON
     _PROFILE = None if native_only else {}
+    _NATIVE_ON = True
     d, a, b = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
     lib.nsr_profile_collect(-1, _byref(d), _byref(a), _byref(b))
     lib.nsr_profile_enable(1)
 
 
+def profiling():
+    """True while HIP-event timing is on (events cannot be recorded into a captured graph)"""
+    return _PROFILE is not None or _NATIVE_ON
+
+
 def profile_end():
     """-> {name: (total_ms, launches, units)}; synchronises."""
-    global _PROFILE
-    prof, _PROFILE = _PROFILE or {}, None
+    global _PROFILE, _NATIVE_ON
+    prof, _PROFILE, _NATIVE_ON = _PROFILE or {}, None, False
     torch.cuda.synchronize()
     lib.nsr_profile_enable(0)
     out = {k: (sum(a.elapsed_time(b) for a, b, _ in v), len(v), sum(u for _, _, u in v)) for k, v in prof.items()}
@@ -335,18 +342,19 @@ def ray_aabb_intersect(rays_o, rays_d, aabb):
     return t_min, t_max
 
 
-def grid_bricks(binary):
+def grid_bricks(binary, out=None):
     """4x4x4-brick bit packing of a bool grid, cached on the tensor object (keyed by its version counter).
-    None when the resolution is not brick-able (then the byte-grid kernels are used)."""
+    None when the resolution is not brick-able (then the byte-grid kernels are used).  ``out``: pack into this
+    persistent int64 buffer (a captured step keeps reading the same address after the grid is refreshed)."""
     rx, ry, rz = (int(s) for s in binary.shape)
     words = int(lib.nsr_grid_bricks_words64(rx, ry, rz))
     if words == 0 or ((rx >> 2) * (ry >> 2) * (rz >> 2)) % 64 != 0:
         return None
     tag = getattr(binary, "_nsr_bricks", None)
-    if tag is not None and tag[0] == binary._version and tag[1] == binary.data_ptr():
+    if tag is not None and tag[0] == binary._version and tag[1] == binary.data_ptr() and (out is None or tag[2] is out):
         return tag[2]
     grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
-    bricks = torch.empty(words, dtype=torch.int64, device=binary.device)
+    bricks = out if out is not None else torch.empty(words, dtype=torch.int64, device=binary.device)
     with torch.cuda.device(binary.device):
         check(lib.nsr_grid_pack_bricks(ptr(grid_u8), rx, ry, rz, ptr(bricks), stream_ptr()), "nsr_grid_pack_bricks")
     try:
@@ -675,10 +683,18 @@ def neus_alpha(sdf, normal, dirs, dists, inv_s, cos_anneal_ratio):
 
 
 def adamw_step(params, grad, exp_avg, exp_avg_sq, shadow_half, lr, beta1, beta2, eps, weight_decay, step,
-               grad_unscale=1.0, zero_grad=True):
-    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+               grad_unscale=1.0, zero_grad=True, hyper=None):
+    """``hyper`` (device float[3] written by ``adam_tick``) overrides lr and the bias corrections on the device"""
+    bc1, bc2 = 1.0 - beta1 ** max(step, 1), 1.0 - beta2 ** max(step, 1)
     with torch.cuda.device(params.device):
         check(lib.nsr_adamw_step(ptr(params), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(shadow_half),
                                  params.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                 float(bc1), float(bc2), float(grad_unscale), int(zero_grad), stream_ptr()),
-              "nsr_adamw_step")
+                                 float(bc1), float(bc2), float(grad_unscale), int(zero_grad), ptr(hyper),
+                                 stream_ptr()), "nsr_adamw_step")
+
+
+def adam_tick(step_dev, hyper_dev, base_lr, beta1, beta2, gamma, milestones):
+    ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
+    with torch.cuda.device(step_dev.device):
+        check(lib.nsr_adam_tick(ptr(step_dev), ptr(hyper_dev), float(base_lr), float(beta1), float(beta2), float(gamma),
+                                ms[0], ms[1], ms[2], stream_ptr()), "nsr_adam_tick")
