@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): final bench line, rocprofv3 kernel summary + timeline, PMC traffic passes.
+# Writes small summaries under gpurun_out/$1/ ; copy what should be judged into profiles/.
+set -u
+tag="${1:-r01_final}"; out="/root/repo/gpurun_out/$tag"; mkdir -p "$out"
+cd /root/repo
+python bench.py > "$out/bench.json" 2> "$out/bench.stderr"; tail -c 400 "$out/bench.json"; echo
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o k -- python /root/repo/bench.py --steps 100 --warmup 300 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2>/dev/null
+cp "$(find /tmp/pk -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
+python /root/repo/tools/trace_tail.py "$(find /tmp/pk -name '*kernel_trace.csv' | head -1)" "$out/timeline_tail.csv" 2400
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pc && rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pc -o c -- python /root/repo/bench.py --steps 30 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
+  python /root/repo/tools/pmc_summary.py "$(find /tmp/pc -name '*counter_collection.csv' | head -1)" $c > "$out/pmc_$c.json"
+done
+ls -la "$out"

@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(src)):
     if r.get("Counter_Name") != counter:
         continue
-    m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
+    m = re.search(r"(k_[a-z_0-9]+(?:<[^>(]*>)?)", r["Kernel_Name"])
     if not m:
         continue
     a = acc[m.group(1)]
