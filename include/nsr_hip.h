@@ -426,6 +426,10 @@ int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq
                    uint64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad, const float *hyper,
                    void *stream);
+/* the one collective of the path is the mean all-reduce of the gradients; the 50 MB table
+ * gradient travels as fp16 (dst = half(src * scale) before, dst = float(src) * scale after; nsr/parallel.py) */
+int nsr_scale_to_half(const float *src, nsr_half *dst, uint64_t n, float scale, void *stream);
+int nsr_scale_from_half(const nsr_half *src, float *dst, uint64_t n, float scale, void *stream);
 /* hyper (device float[3], may be NULL): {lr, bias_correction1, bias_correction2} read on the device instead of the scalar
  * arguments.  nsr_adam_tick advances the device-side step counter (int32[1]) and writes them -- MultiStepLR
  * (configs nerf-blender.yaml:80-85: up to three milestones, pass INT32_MAX for unused ones) over base_lr, in double

@@ -226,6 +226,44 @@ k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, flo
     }
 }
 
+// gradient transport in half precision: dst = half(src * scale) and back (dst = float(src) * scale), 8 elements per lane
+__global__ void __launch_bounds__(EW_BLOCK)
+k_scale_to_half(const float *__restrict__ src, __half *__restrict__ dst, uint64_t n, float scale)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 8;
+    for (uint64_t b = ((uint64_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 8; b < n; b += stride) {
+        if (b + 8 <= n) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + b), c = *reinterpret_cast<const float4 *>(src + b + 4);
+            __half2 h[4] = {__floats2half2_rn(a.x * scale, a.y * scale), __floats2half2_rn(a.z * scale, a.w * scale),
+                            __floats2half2_rn(c.x * scale, c.y * scale), __floats2half2_rn(c.z * scale, c.w * scale)};
+            *reinterpret_cast<uint4 *>(dst + b) = *reinterpret_cast<uint4 *>(h);
+        } else {
+            for (uint64_t j = b; j < n; ++j) dst[j] = __float2half_rn(src[j] * scale);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_scale_from_half(const __half *__restrict__ src, float *__restrict__ dst, uint64_t n, float scale)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 8;
+    for (uint64_t b = ((uint64_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 8; b < n; b += stride) {
+        if (b + 8 <= n) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(src + b);
+            const __half2 *h = reinterpret_cast<const __half2 *>(&raw);
+            float4 a, c;
+            a.x = __low2float(h[0]) * scale; a.y = __high2float(h[0]) * scale;
+            a.z = __low2float(h[1]) * scale; a.w = __high2float(h[1]) * scale;
+            c.x = __low2float(h[2]) * scale; c.y = __high2float(h[2]) * scale;
+            c.z = __low2float(h[3]) * scale; c.w = __high2float(h[3]) * scale;
+            *reinterpret_cast<float4 *>(dst + b) = a;
+            *reinterpret_cast<float4 *>(dst + b + 4) = c;
+        } else {
+            for (uint64_t j = b; j < n; ++j) dst[j] = __half2float(src[j]) * scale;
+        }
+    }
+}
+
 // step counter, MultiStepLR-scaled learning rate and bias corrections on the device, in the double arithmetic the host
 // path uses: a captured step (hipGraph) then needs no per-step host scalar
 __global__ void k_adam_tick(int32_t *__restrict__ step, float *__restrict__ hyper, double base_lr, double b1, double b2,
@@ -333,6 +371,32 @@ extern "C" int nsr_adamw_step(float *params, float *grad, float *exp_avg, float 
                        exp_avg_sq, (__half *)shadow_half, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
                        bias_correction2, grad_unscale, zero_grad, hyper);
     NSR_CHECK_LAUNCH("nsr_adamw_step");
+    return NSR_OK;
+}
+
+extern "C" int nsr_scale_to_half(const float *src, nsr_half *dst, uint64_t n, float scale, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(src && dst, "nsr_scale_to_half: NULL pointer");
+    NSR_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "nsr_scale_to_half: buffers must be 16-byte aligned");
+    uint64_t blocks = (n / 8 + EW_BLOCK - 1) / EW_BLOCK + 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_scale_to_half, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, src,
+                       (__half *)dst, n, scale);
+    NSR_CHECK_LAUNCH("nsr_scale_to_half");
+    return NSR_OK;
+}
+
+extern "C" int nsr_scale_from_half(const nsr_half *src, float *dst, uint64_t n, float scale, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(src && dst, "nsr_scale_from_half: NULL pointer");
+    NSR_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "nsr_scale_from_half: buffers must be 16-byte aligned");
+    uint64_t blocks = (n / 8 + EW_BLOCK - 1) / EW_BLOCK + 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_scale_from_half, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const __half *)src, dst, n, scale);
+    NSR_CHECK_LAUNCH("nsr_scale_from_half");
     return NSR_OK;
 }
 

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, half_transport=False):
     for p in (ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -37,7 +37,7 @@ def _worker(rank, world, port, out):
     loss = model["table"](idx).pow(2).mean() + model["mlp"](x).pow(2).mean()
     loss.backward()
     local = [p.grad.clone() for p in model.parameters()]
-    n_bytes = all_reduce_gradients(list(model.parameters()))
+    n_bytes = all_reduce_gradients(list(model.parameters()), half_transport=half_transport)
     torch.save({"w0": w0, "idx": idx, "x": x, "local": local, "avg": [p.grad.clone() for p in model.parameters()],
                 "n_bytes": n_bytes}, os.path.join(out, f"rank{rank}.pt"))
     dist.barrier()
@@ -63,6 +63,20 @@ def test_ray_sharded_gradient_all_reduce(tmp_path):
     idx = torch.cat([r[0]["idx"], r[1]["idx"]])
     model["table"](idx).pow(2).mean().backward()
     assert torch.allclose(model["table"].weight.grad, r[0]["avg"][0], atol=1e-7)
+
+
+def test_gradient_all_reduce_with_half_precision_transport(tmp_path):
+    """the large (table) gradient travels as fp16 x 1024: same mean within fp16 rounding, half the bytes on the wire"""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), True), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
+    mean = (r[0]["local"][0] + r[1]["local"][0]) / 2
+    assert torch.equal(r[0]["avg"][0], r[1]["avg"][0])                       # replicas stay identical
+    assert torch.allclose(r[0]["avg"][0], mean, rtol=2e-3, atol=1e-7)        # 11-bit mantissa on the wire
+    assert bool((r[0]["avg"][0] != 0).sum() == (mean != 0).sum())           # nothing underflowed
+    for k in (1, 2):                                                         # small gradients stay fp32
+        assert torch.allclose(r[0]["avg"][k], (r[0]["local"][k] + r[1]["local"][k]) / 2, atol=1e-7)
+    assert r[0]["n_bytes"] == 70000 * 2 * 2 + (8 * 3 + 3) * 4
 
 
 def test_shard_seed_and_single_process_noop():

@@ -159,3 +159,17 @@ def test_occupancy_grid_update_cells_matches_oracle():
     ggpu.eval()
     with pytest.raises(RuntimeError):
         ggpu.every_n_step(step=0, occ_eval_fn=fn)
+
+
+@pytest.mark.gpu
+def test_half_transport_casts_round_trip():
+    """nsr_scale_to_half / nsr_scale_from_half (gradient transport of nsr/parallel.py)"""
+    from nsr_hip import check, lib, ptr, stream_ptr
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(1_000_003, device="cuda", generator=g) * 1e-3
+    h = torch.empty(x.numel(), dtype=torch.float16, device="cuda")
+    y = torch.empty_like(x)
+    check(lib.nsr_scale_to_half(ptr(x), ptr(h), x.numel(), 1024.0, stream_ptr()), "nsr_scale_to_half")
+    check(lib.nsr_scale_from_half(ptr(h), ptr(y), x.numel(), 1.0 / 2048.0, stream_ptr()), "nsr_scale_from_half")
+    assert torch.equal(h, (x * 1024.0).half())
+    assert torch.equal(y, h.float() / 2048.0)
