@@ -314,8 +314,10 @@ int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t *packed_ne
 int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
                                 const void *const *src, void *const *dst, const uint32_t *row_bytes,
                                 const uint32_t *planes, const uint64_t *src_plane_bytes, const uint64_t *dst_plane_bytes,
-                                const float *rays_d, float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays,
-                                void *stream);
+                                const float *rays_d, float *dirs_out, int64_t *ray_indices_out, const nsr_half *tex_src,
+                                uint32_t tex_src_stride, nsr_half *tex_in, uint32_t n_rays, void *stream);
+/* tex_in (may be NULL): additionally writes the texture network's input rows [n_kept, 32] = [first 16 halfs of the
+ * marched-layout feature row tex_src[sample] | SH4(ray direction)] (what nsr_texture_input computes per sample) */
 /* tex_in[n,32] (half) = [mlp_out[:, :16] | SH4((dirs+1)/2)]   (texture.py:24-26) */
 int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in, uint32_t n,
                       const int32_t *n_dev, void *stream);
@@ -330,6 +332,13 @@ int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, float densi
                            const float *background, const float *weights, const float *trans,
                            const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
                            float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream);
+/* composite backward with the gradient of the masked smooth-L1 loss (nsr_smooth_l1_valid_backward) evaluated inside */
+int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                     const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
+                                     const int32_t *packed_info, const float *background, const float *weights,
+                                     const float *trans, const float *comp_rgb, const float *opacity, const float *gt_rgb,
+                                     const float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
+                                     uint32_t n_rays, void *stream);
 /* acc2[0] += sum of smooth_l1 over valid rays (opacity > 0) x 3 channels, acc2[1] += number of valid rays
  * (loss = acc2[0] / (3*acc2[1]), systems/nerf.py:97); backward writes grad_scale * dloss/dcomp_rgb */
 int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,

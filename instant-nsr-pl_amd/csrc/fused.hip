@@ -114,59 +114,11 @@ k_copy_ray_prefixes(const int32_t *__restrict__ packed_old, const int32_t *__res
     }
 }
 
-// Row-wise variant: the kept prefix of a ray is ONE contiguous block in both the marched and the pruned layout, so
-// carrying per-sample rows (encoded features, MLP activations, MLP outputs, positions) over the pruning step is a
-// per-ray memcpy -- the main pass then reuses what the sigma pass already computed instead of re-encoding.
-struct RowCopy { const uint32_t *src; uint32_t *dst; uint32_t row_dwords; uint32_t planes; uint64_t src_plane, dst_plane; };
-struct RowCopies { RowCopy a[8]; uint32_t n; };
-
-__global__ void __launch_bounds__(R_BLOCK)
-k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__restrict__ packed_new, const RowCopies rc,
-                       const float *__restrict__ rays_d, float *__restrict__ dirs_out, int64_t *__restrict__ ri_o,
-                       uint32_t n_rays)
+// SH degree 4 of a unit direction as the texture network sees it: dirs01 = (d + 1)/2 ; SH maps back 2u - 1 (two
+// roundings each way, exactly as texture.py:24 + tcnn do) -> 16 halfs
+__device__ __forceinline__ void sh4_of_dir(float d0, float d1, float d2, __half2 (&h)[8])
 {
-    const uint32_t r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= n_rays) return;
-    const uint32_t src = (uint32_t)packed_old[2ull * r];
-    const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
-    if (cnt == 0) return;
-    for (uint32_t q = 0; q < rc.n; ++q)
-      for (uint32_t pl = 0; pl < rc.a[q].planes; ++pl) {  // planes > 1: a level-major array = `planes` arrays of rows
-        const uint32_t rd = rc.a[q].row_dwords;
-        const uint32_t *s = rc.a[q].src + pl * rc.a[q].src_plane + (uint64_t)src * rd;
-        uint32_t *d = rc.a[q].dst + pl * rc.a[q].dst_plane + (uint64_t)dst * rd;
-        const uint32_t nd = cnt * rd;
-        if ((rd & 3u) == 0 && rc.a[q].planes == 1) {  // rows are multiples of 16 B (and the bases 256-B aligned): 16-B copies, 1 KiB per wave-instr
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
-            uint4 *d4 = reinterpret_cast<uint4 *>(d);
-            for (uint32_t w = lane; w < (nd >> 2); w += 64) d4[w] = s4[w];
-        } else {
-            for (uint32_t w = lane; w < nd; w += 64) d[w] = s[w];
-        }
-    }
-    if (dirs_out) {
-        const float d0 = rays_d[3ull * r], d1 = rays_d[3ull * r + 1], d2 = rays_d[3ull * r + 2];
-        for (uint32_t k = lane; k < cnt; k += 64) {
-            dirs_out[3ull * (dst + k)] = d0; dirs_out[3ull * (dst + k) + 1] = d1; dirs_out[3ull * (dst + k) + 2] = d2;
-        }
-    }
-    if (ri_o)
-        for (uint32_t k = lane; k < cnt; k += 64) ri_o[dst + k] = (int64_t)r;
-}
-
-// tex_in[n,32] half = [ mlp_out[:, :16] | SH4((d+1)/2) ]  (the fp16 feature IS what .float() then fp16-cast returns)
-__global__ void __launch_bounds__(EW_BLOCK)
-k_texture_input(const __half *__restrict__ mlp_out, uint32_t stride, const float *__restrict__ dirs,
-                __half *__restrict__ tex_in, uint32_t n, const int32_t *__restrict__ n_dev)
-{
-    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
-    if (i >= live_count(n, n_dev)) return;
-    const uint4 *src = reinterpret_cast<const uint4 *>(mlp_out + (uint64_t)i * stride);
-    uint4 *dst = reinterpret_cast<uint4 *>(tex_in + (uint64_t)i * 32);
-    dst[0] = src[0];
-    dst[1] = src[1];
-    // dirs01 = (d + 1)/2 ; SH maps back 2u - 1 (two roundings each way, exactly as texture.py:24 + tcnn do)
-    const float u0 = (dirs[3ull * i] + 1.f) / 2.f, u1 = (dirs[3ull * i + 1] + 1.f) / 2.f, u2 = (dirs[3ull * i + 2] + 1.f) / 2.f;
+    const float u0 = (d0 + 1.f) / 2.f, u1 = (d1 + 1.f) / 2.f, u2 = (d2 + 1.f) / 2.f;
     const float x = u0 * 2.f - 1.f, y = u1 * 2.f - 1.f, z = u2 * 2.f - 1.f;
     const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
     float o[16];
@@ -186,9 +138,89 @@ k_texture_input(const __half *__restrict__ mlp_out, uint32_t stride, const float
     o[13] = 0.45704579946446572f * x * (1.f - 5.f * z2);
     o[14] = 1.4453057213202769f * z * (x2 - y2);
     o[15] = 0.59004358992664352f * x * (-x2 + 3.f * y2);
-    __half2 h[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) h[k] = __floats2half2_rn(o[2 * k], o[2 * k + 1]);
+}
+
+// Row-wise variant: the kept prefix of a ray is ONE contiguous block in both the marched and the pruned layout, so
+// carrying per-sample rows (encoded features, MLP activations, MLP outputs, positions) over the pruning step is a
+// per-ray memcpy -- the main pass then reuses what the sigma pass already computed instead of re-encoding.
+struct RowCopy { const uint32_t *src; uint32_t *dst; uint32_t row_dwords; uint32_t planes; uint64_t src_plane, dst_plane; };
+struct RowCopies { RowCopy a[8]; uint32_t n; };
+
+__global__ void __launch_bounds__(R_BLOCK)
+k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__restrict__ packed_new, const RowCopies rc,
+                       const float *__restrict__ rays_d, float *__restrict__ dirs_out, int64_t *__restrict__ ri_o,
+                       const __half *__restrict__ tex_src, uint32_t tex_src_stride, __half *__restrict__ tex_in,
+                       uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const uint32_t src = (uint32_t)packed_old[2ull * r];
+    const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
+    if (cnt == 0) return;
+    for (uint32_t q = 0; q < rc.n; ++q) {
+        const uint32_t rd = rc.a[q].row_dwords, planes = rc.a[q].planes;
+        const uint32_t nd = cnt * rd;  // dwords of this ray in one plane
+        if (planes == 1) {
+            const uint32_t *s = rc.a[q].src + (uint64_t)src * rd;
+            uint32_t *d = rc.a[q].dst + (uint64_t)dst * rd;
+            if ((rd & 3u) == 0) {  // rows are multiples of 16 B (and the bases 256-B aligned): 1 KiB per wave-instruction
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+                uint4 *d4 = reinterpret_cast<uint4 *>(d);
+                for (uint32_t w = lane; w < (nd >> 2); w += 64) d4[w] = s4[w];
+            } else {
+                for (uint32_t w = lane; w < nd; w += 64) d[w] = s[w];
+            }
+        } else {
+            // level-major array = `planes` arrays of rows: the lanes run over (plane, dword) jointly -- a ray keeps ~13
+            // samples, one loop per plane would leave 50 of 64 lanes idle 16 times over
+            const float inv = 1.f / (float)nd;
+            for (uint32_t w = lane; w < planes * nd; w += 64) {
+                uint32_t pl = (uint32_t)(((float)w + 0.5f) * inv);  // w / nd (w < 2^22: exact up to the fix-up below)
+                uint32_t e = w - pl * nd;
+                if (e >= nd) { e += nd; pl -= 1; }  // e wrapped negative: the estimate was one too high
+                rc.a[q].dst[pl * rc.a[q].dst_plane + (uint64_t)dst * rd + e] =
+                    rc.a[q].src[pl * rc.a[q].src_plane + (uint64_t)src * rd + e];
+            }
+        }
+    }
+    const float d0 = rays_d ? rays_d[3ull * r] : 0.f, d1 = rays_d ? rays_d[3ull * r + 1] : 0.f,
+                d2 = rays_d ? rays_d[3ull * r + 2] : 0.f;
+    if (dirs_out) {
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            dirs_out[3ull * (dst + k)] = d0; dirs_out[3ull * (dst + k) + 1] = d1; dirs_out[3ull * (dst + k) + 2] = d2;
+        }
+    }
+    if (ri_o)
+        for (uint32_t k = lane; k < cnt; k += 64) ri_o[dst + k] = (int64_t)r;
+    if (tex_in) {  // texture-network input [16 features | SH4(dir)]: the direction -- hence the SH half -- is per RAY
+        __half2 h[8];
+        sh4_of_dir(d0, d1, d2, h);
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            const uint4 *f = reinterpret_cast<const uint4 *>(tex_src + (uint64_t)(src + k) * tex_src_stride);
+            uint4 *o = reinterpret_cast<uint4 *>(tex_in + (uint64_t)(dst + k) * 32);
+            o[0] = f[0];
+            o[1] = f[1];
+            o[2] = *reinterpret_cast<uint4 *>(&h[0]);
+            o[3] = *reinterpret_cast<uint4 *>(&h[4]);
+        }
+    }
+}
+
+// tex_in[n,32] half = [ mlp_out[:, :16] | SH4((d+1)/2) ]  (the fp16 feature IS what .float() then fp16-cast returns)
+__global__ void __launch_bounds__(EW_BLOCK)
+k_texture_input(const __half *__restrict__ mlp_out, uint32_t stride, const float *__restrict__ dirs,
+                __half *__restrict__ tex_in, uint32_t n, const int32_t *__restrict__ n_dev)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= live_count(n, n_dev)) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(mlp_out + (uint64_t)i * stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(tex_in + (uint64_t)i * 32);
+    dst[0] = src[0];
+    dst[1] = src[1];
+    __half2 h[8];
+    sh4_of_dir(dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2], h);
     dst[2] = *reinterpret_cast<uint4 *>(&h[0]);
     dst[3] = *reinterpret_cast<uint4 *>(&h[4]);
 }
@@ -291,12 +323,27 @@ k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float 
                      const float *__restrict__ weights, const float *__restrict__ trans,
                      const float *__restrict__ g_comp, const float *__restrict__ g_opacity,
                      const float *__restrict__ g_depth, float *__restrict__ d_rgb, float *__restrict__ d_logit,
-                     uint32_t n_rays)
+                     uint32_t n_rays, const float *__restrict__ l1_comp, const float *__restrict__ l1_opacity,
+                     const float *__restrict__ l1_gt, const float *__restrict__ l1_acc, float l1_scale)
 {
     uint32_t r, start, count;
     if (!wave_ray(packed, n_rays, r, start, count)) return;
     const uint32_t lane = threadIdx.x & 63;
-    const float g0 = g_comp[3ull * r], g1 = g_comp[3ull * r + 1], g2 = g_comp[3ull * r + 2];
+    float g0, g1, g2;
+    if (l1_comp) {  // gradient of the masked smooth-L1 loss evaluated here (k_smooth_l1_valid_bwd without its launch)
+        const bool valid = l1_opacity[r] > 0.f;
+        const float inv = l1_scale / fmaxf(3.f * l1_acc[1], 1.f);
+        float g[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float d = l1_comp[3ull * r + q] - l1_gt[3ull * r + q];
+            const float gq = fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+            g[q] = valid ? gq * inv : 0.f;
+        }
+        g0 = g[0]; g1 = g[1]; g2 = g[2];
+    } else {
+        g0 = g_comp[3ull * r]; g1 = g_comp[3ull * r + 1]; g2 = g_comp[3ull * r + 2];
+    }
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
     const float gop = g_opacity ? g_opacity[r] : 0.f, gdp = g_depth ? g_depth[r] : 0.f;
     float carry = 0.f;  // sum_{i > j} gT_i T_i, walking the ray from its end
@@ -557,8 +604,26 @@ extern "C" int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, 
                 "nsr_composite_backward: NULL pointer");
     hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
                        t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb,
-                       grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays);
+                       grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays, nullptr, nullptr, nullptr, nullptr, 0.f);
     NSR_CHECK_LAUNCH("nsr_composite_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, float density_bias,
+                                                const float *t_starts, const float *t_ends, const nsr_half *rgb,
+                                                uint32_t rgb_stride, const int32_t *packed_info,
+                                                const float *background, const float *weights, const float *trans,
+                                                const float *comp_rgb, const float *opacity, const float *gt_rgb,
+                                                const float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
+                                                uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && weights && trans && comp_rgb && opacity && gt_rgb && acc2 && grad_rgb &&
+                    grad_logit, "nsr_composite_backward_smooth_l1: NULL pointer");
+    hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
+                       t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, nullptr, nullptr,
+                       nullptr, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, acc2, grad_scale);
+    NSR_CHECK_LAUNCH("nsr_composite_backward_smooth_l1");
     return NSR_OK;
 }
 
@@ -580,12 +645,15 @@ extern "C" int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int3
                                            const void *const *src, void *const *dst, const uint32_t *row_bytes,
                                            const uint32_t *planes, const uint64_t *src_plane_bytes,
                                            const uint64_t *dst_plane_bytes, const float *rays_d, float *dirs_out,
-                                           int64_t *ray_indices_out, uint32_t n_rays, void *stream)
+                                           int64_t *ray_indices_out, const nsr_half *tex_src, uint32_t tex_src_stride,
+                                           nsr_half *tex_in, uint32_t n_rays, void *stream)
 {
     if (n_rays == 0) return NSR_OK;
     NSR_REQUIRE(packed_old && packed_new, "nsr_copy_ray_prefix_rows: NULL packed_info");
     NSR_REQUIRE(n_arrays <= 8, "nsr_copy_ray_prefix_rows: at most 8 arrays");
     NSR_REQUIRE(!dirs_out || rays_d, "nsr_copy_ray_prefix_rows: dirs_out needs rays_d");
+    NSR_REQUIRE(!tex_in || (tex_src && rays_d && tex_src_stride >= 16 && (tex_src_stride & 7u) == 0),
+                "nsr_copy_ray_prefix_rows: tex_in needs rays_d and 16-B aligned feature rows of >= 16 halfs");
     RowCopies rc;
     rc.n = n_arrays;
     for (uint32_t q = 0; q < n_arrays; ++q) {
@@ -598,7 +666,7 @@ extern "C" int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int3
         rc.a[q].dst_plane = planes ? dst_plane_bytes[q] / 4 : 0;
     }
     hipLaunchKernelGGL(k_copy_ray_prefix_rows, RAY_GRID(n_rays), packed_old, packed_new, rc, rays_d, dirs_out,
-                       ray_indices_out, n_rays);
+                       ray_indices_out, (const __half *)tex_src, tex_src_stride, (__half *)tex_in, n_rays);
     NSR_CHECK_LAUNCH("nsr_copy_ray_prefix_rows");
     return NSR_OK;
 }
@@ -609,7 +677,7 @@ extern "C" int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t
                                         void *stream)
 {
     return nsr_copy_ray_prefix_rows_ex(packed_old, packed_new, n_arrays, src, dst, row_bytes, nullptr, nullptr, nullptr,
-                                       rays_d, dirs_out, ray_indices_out, n_rays, stream);
+                                       rays_d, dirs_out, ray_indices_out, nullptr, 0, nullptr, n_rays, stream);
 }
 
 extern "C" int nsr_prepare_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,

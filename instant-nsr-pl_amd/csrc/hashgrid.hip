@@ -853,7 +853,7 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
         hipLaunchKernelGGL((k_grid_backward_owner<F>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
                            bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc);
         if (slab_floats > 0)
-            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(32, L), dim3(256), 0, st, workspace, grad_table,
+            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(256, L), dim3(256), 0, st, workspace, grad_table,
                                accumulate, om, *desc);
     });
     NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner");

@@ -225,7 +225,7 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     }
     nsr_half *enc = (nsr_half *)(ws + L.enc), *out1 = (nsr_half *)(ws + L.out1), *acts1 = (nsr_half *)(ws + L.acts1);
     nsr_half *tex_in = (nsr_half *)(ws + L.tex_in), *out2 = (nsr_half *)(ws + L.out2), *acts2 = (nsr_half *)(ws + L.acts2);
-    float *x01 = (float *)(ws + L.x01), *dirs = (float *)(ws + L.dirs);
+    float *x01 = (float *)(ws + L.x01);
     float *t0 = (float *)(ws + L.t_starts), *t1 = (float *)(ws + L.t_ends);
     float *weights = (float *)(ws + L.weights), *trans = (float *)(ws + L.trans);
     float *comp_rgb = (float *)(ws + L.comp_rgb), *opacity = (float *)(ws + L.opacity), *depth = (float *)(ws + L.depth);
@@ -248,8 +248,9 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     }
     NSR_REQUIRE(F * 2 % 4 == 0, "nsr_nerf_main_pass: n_features_per_level must be even");
     if (S > 0)  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
-        NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, dirs,
-                                            (int64_t *)(ws + L.ray_indices), n_rays, stream));
+        NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, nullptr,
+                                            (int64_t *)(ws + L.ray_indices), (const nsr_half *)(pw + P.out1), 16, tex_in,
+                                            n_rays, stream));  // also writes the colour network's input rows
     // fork: bin the table-backward items on the helper stream as soon as the kept positions exist
     const bool overlap_bins = compute_grads && S > 0 && g_helper.init();
     if (overlap_bins) {
@@ -264,7 +265,6 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
         NSR_REQUIRE(hipEventRecord(g_helper.join, g_helper.stream) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream join failed");
     }
-    NSR_TRY(nsr_texture_input(out1, 16, dirs, tex_in, S, n_kept_dev, stream));
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
         NSR_TRY(nsr_mlp_forward_ex(tex_in, 0, 32, 0, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color,
@@ -275,13 +275,13 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     NSR_TRY(nsr_smooth_l1_valid(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
     if (!compute_grads || S == 0) return NSR_OK;
     NSR_REQUIRE(grad_density_mlp && grad_table && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
-    float *g_comp = (float *)(ws + L.g_comp), *d_rgb = (float *)(ws + L.d_rgb), *d_logit = (float *)(ws + L.d_logit);
+    float *d_rgb = (float *)(ws + L.d_rgb), *d_logit = (float *)(ws + L.d_logit);
     float *d_tex = (float *)(ws + L.d_tex), *d_enc = (float *)(ws + L.d_enc);
     float *part2 = (float *)(ws + L.partials);
     float *part1 = part2 + nsr_mlp_backward_workspace_floats(&d->mlp_color, S);
-    NSR_TRY(nsr_smooth_l1_valid_backward(comp_rgb, opacity, gt_rgb, acc, d->loss_scale, g_comp, n_rays, stream));
-    NSR_TRY(nsr_composite_backward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
-                                   g_comp, nullptr, nullptr, d_rgb, d_logit, n_rays, stream));
+    NSR_TRY(nsr_composite_backward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights,
+                                             trans, comp_rgb, opacity, gt_rgb, acc, d->loss_scale, d_rgb, d_logit, n_rays,
+                                             stream));
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
         NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
