@@ -318,6 +318,15 @@ int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed
                                 uint32_t tex_src_stride, nsr_half *tex_in, uint32_t n_rays, void *stream);
 /* tex_in (may be NULL): additionally writes the texture network's input rows [n_kept, 32] = [first 16 halfs of the
  * marched-layout feature row tex_src[sample] | SH4(ray direction)] (what nsr_texture_input computes per sample) */
+/* The fused step's instance of that copy (F = 2 level-major encoding, 16-half feature rows, n_hidden <= 2 saved
+ * activation rows), one lane per kept sample with every row's load issued before the first store; *_capacity are the row
+ * strides of the level-major / per-layer arrays in the marched and the kept layout.  Also writes ray_indices and tex_in */
+int nsr_nerf_copy_kept_rows(const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                            const float *t_ends, const float *x01, const nsr_half *enc, const nsr_half *out1,
+                            const nsr_half *acts1, float *t_starts_out, float *t_ends_out, float *x01_out,
+                            nsr_half *enc_out, nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels,
+                            uint32_t n_hidden, uint32_t marched_capacity, uint32_t kept_capacity, const float *rays_d,
+                            int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays, void *stream);
 /* tex_in[n,32] (half) = [mlp_out[:, :16] | SH4((dirs+1)/2)]   (texture.py:24-26) */
 int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in, uint32_t n,
                       const int32_t *n_dev, void *stream);
@@ -343,6 +352,9 @@ int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, f
  * (loss = acc2[0] / (3*acc2[1]), systems/nerf.py:97); backward writes grad_scale * dloss/dcomp_rgb */
 int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,
                         uint32_t n_rays, void *stream);
+/* the same two sums WRITTEN to acc2 by one workgroup (no same-address atomics, no zeroing by the caller) */
+int nsr_smooth_l1_valid_set(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,
+                            uint32_t n_rays, void *stream);
 int nsr_smooth_l1_valid_backward(const float *comp_rgb, const float *opacity, const float *gt_rgb, const float *acc2,
                                  float grad_scale, float *grad_comp_rgb, uint32_t n_rays, void *stream);
 /* training-ray gather (systems/nerf.py:38-79, models/ray_utils.py:23-43): rays[n,6], rgb[n,3], fg[n] */
@@ -439,8 +451,8 @@ int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq
  * gradient travels as fp16 (dst = half(src * scale) before, dst = float(src) * scale after; nsr/parallel.py) */
 int nsr_scale_to_half(const float *src, nsr_half *dst, uint64_t n, float scale, void *stream);
 int nsr_scale_from_half(const nsr_half *src, float *dst, uint64_t n, float scale, void *stream);
-/* hyper (device float[3], may be NULL): {lr, bias_correction1, bias_correction2} read on the device instead of the scalar
- * arguments.  nsr_adam_tick advances the device-side step counter (int32[1]) and writes them -- MultiStepLR
+/* hyper (device, may be NULL): {lr, bias_correction1, bias_correction2} read on the device instead of the scalar
+ * arguments; nsr_adam_tick needs 8 floats there, 8-byte aligned ([3..7]: its running beta powers).  nsr_adam_tick advances the device-side step counter (int32[1]) and writes them -- MultiStepLR
  * (configs nerf-blender.yaml:80-85: up to three milestones, pass INT32_MAX for unused ones) over base_lr, in double
  * arithmetic -- so that a captured (hipGraph) step needs no per-step host scalar. */
 int nsr_adam_tick(int32_t *step, float *hyper, double base_lr, double beta1, double beta2, double gamma,

@@ -208,6 +208,71 @@ k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__
     }
 }
 
+// The main pass's copy, specialised for its row set (t0, t1: 1 dword; x01: 3; level-major encoding with F = 2: `planes`
+// planes of 1 dword; density-MLP output: 32 B; NH saved activation rows: 128 B each): ONE LANE PER KEPT SAMPLE issues the
+// loads of all its rows before the first store, so a ray costs one memory round trip instead of one per array -- a ray
+// keeps ~13 samples, the copy is latency-, not bandwidth-bound.  Also writes ray_indices and the texture input.
+struct KeptRows {
+    const float *t0_s, *t1_s, *x01_s;
+    const uint32_t *enc_s;
+    const uint4 *out1_s, *acts_s;
+    float *t0_d, *t1_d, *x01_d;
+    uint32_t *enc_d;
+    uint4 *out1_d, *acts_d;
+    uint64_t enc_sp, enc_dp;  // plane strides (dwords)
+    uint64_t acts_sl, acts_dl;  // hidden-layer strides (uint4 units)
+    uint32_t planes;
+};
+
+template <int NH>
+__global__ void __launch_bounds__(R_BLOCK)
+k_copy_kept_rows(const int32_t *__restrict__ packed_old, const int32_t *__restrict__ packed_new, const KeptRows kr,
+                 const float *__restrict__ rays_d, int64_t *__restrict__ ri_o, __half *__restrict__ tex_in,
+                 uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const uint32_t src = (uint32_t)packed_old[2ull * r];
+    const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
+    if (cnt == 0) return;
+    __half2 sh[8];
+    sh4_of_dir(rays_d[3ull * r], rays_d[3ull * r + 1], rays_d[3ull * r + 2], sh);
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint64_t i = src + k, o = dst + k;
+        const float a0 = kr.t0_s[i], a1 = kr.t1_s[i];
+        const float p0 = kr.x01_s[3 * i], p1 = kr.x01_s[3 * i + 1], p2 = kr.x01_s[3 * i + 2];
+        const uint4 f0 = kr.out1_s[2 * i], f1 = kr.out1_s[2 * i + 1];
+        uint4 act[NH][8];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) act[h][j] = kr.acts_s[h * kr.acts_sl + 8 * i + j];
+        for (uint32_t pb = 0; pb < kr.planes; pb += 16) {  // 16 encoding planes in flight per pass
+            uint32_t e[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (pb + j < kr.planes) e[j] = kr.enc_s[(pb + j) * kr.enc_sp + i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (pb + j < kr.planes) kr.enc_d[(pb + j) * kr.enc_dp + o] = e[j];
+        }
+        kr.t0_d[o] = a0;
+        kr.t1_d[o] = a1;
+        kr.x01_d[3 * o] = p0; kr.x01_d[3 * o + 1] = p1; kr.x01_d[3 * o + 2] = p2;
+        kr.out1_d[2 * o] = f0; kr.out1_d[2 * o + 1] = f1;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kr.acts_d[h * kr.acts_dl + 8 * o + j] = act[h][j];
+        ri_o[o] = (int64_t)r;
+        uint4 *t = reinterpret_cast<uint4 *>(tex_in + o * 32);
+        t[0] = f0;
+        t[1] = f1;
+        t[2] = *reinterpret_cast<uint4 *>(&sh[0]);
+        t[3] = *reinterpret_cast<uint4 *>(&sh[4]);
+    }
+}
+
 // tex_in[n,32] half = [ mlp_out[:, :16] | SH4((d+1)/2) ]  (the fp16 feature IS what .float() then fp16-cast returns)
 __global__ void __launch_bounds__(EW_BLOCK)
 k_texture_input(const __half *__restrict__ mlp_out, uint32_t stride, const float *__restrict__ dirs,
@@ -295,6 +360,36 @@ k_smooth_l1_valid(const float *__restrict__ comp_rgb, const float *__restrict__ 
     if ((threadIdx.x & 63) == 0 && c > 0.f) {
         unsafeAtomicAdd(acc, s);
         unsafeAtomicAdd(acc + 1, c);
+    }
+}
+
+// The same sums by ONE workgroup, written (not accumulated): the 2 x (rays / 64) same-address float atomics of the
+// kernel above cost ~17 us at 8192 rays, and the caller no longer has to zero acc first.
+__global__ void __launch_bounds__(1024)
+k_smooth_l1_valid_set(const float *__restrict__ comp_rgb, const float *__restrict__ opacity, const float *__restrict__ gt,
+                      float *__restrict__ acc, uint32_t n_rays)
+{
+    __shared__ float part[2][16];
+    float s = 0.f, c = 0.f;
+    for (uint32_t r = threadIdx.x; r < n_rays; r += 1024) {
+        if (opacity[r] > 0.f) {
+            c += 1.f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float d = fabsf(comp_rgb[3ull * r + q] - gt[3ull * r + q]);
+                s += d < 1.f ? 0.5f * d * d : d - 0.5f;
+            }
+        }
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.f, tc = 0.f;
+        for (int w = 0; w < 16; ++w) { ts += part[0][w]; tc += part[1][w]; }
+        acc[0] = ts;
+        acc[1] = tc;
     }
 }
 
@@ -580,6 +675,16 @@ extern "C" int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, 
     return NSR_OK;
 }
 
+extern "C" int nsr_smooth_l1_valid_set(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,
+                                       uint32_t n_rays, void *stream)
+{
+    NSR_REQUIRE(acc2 && (n_rays == 0 || (comp_rgb && opacity && gt_rgb)), "nsr_smooth_l1_valid_set: NULL pointer");
+    hipLaunchKernelGGL(k_smooth_l1_valid_set, dim3(1), dim3(1024), 0, (hipStream_t)stream, comp_rgb, opacity, gt_rgb,
+                       acc2, n_rays);
+    NSR_CHECK_LAUNCH("nsr_smooth_l1_valid_set");
+    return NSR_OK;
+}
+
 extern "C" int nsr_smooth_l1_valid_backward(const float *comp_rgb, const float *opacity, const float *gt_rgb,
                                             const float *acc2, float grad_scale, float *grad_comp_rgb, uint32_t n_rays,
                                             void *stream)
@@ -668,6 +773,37 @@ extern "C" int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int3
     hipLaunchKernelGGL(k_copy_ray_prefix_rows, RAY_GRID(n_rays), packed_old, packed_new, rc, rays_d, dirs_out,
                        ray_indices_out, (const __half *)tex_src, tex_src_stride, (__half *)tex_in, n_rays);
     NSR_CHECK_LAUNCH("nsr_copy_ray_prefix_rows");
+    return NSR_OK;
+}
+
+extern "C" int nsr_nerf_copy_kept_rows(const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                                       const float *t_ends, const float *x01, const nsr_half *enc, const nsr_half *out1,
+                                       const nsr_half *acts1, float *t_starts_out, float *t_ends_out, float *x01_out,
+                                       nsr_half *enc_out, nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels,
+                                       uint32_t n_hidden, uint32_t marched_capacity, uint32_t kept_capacity,
+                                       const float *rays_d, int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays,
+                                       void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_marched && packed_kept && t_starts && t_ends && x01 && enc && out1 && acts1 && t_starts_out &&
+                    t_ends_out && x01_out && enc_out && out1_out && acts1_out && rays_d && ray_indices_out && tex_in,
+                "nsr_nerf_copy_kept_rows: NULL pointer");
+    NSR_REQUIRE(n_hidden >= 1 && n_hidden <= 2, "nsr_nerf_copy_kept_rows: 1 or 2 hidden layers");
+    KeptRows kr;
+    kr.t0_s = t_starts; kr.t1_s = t_ends; kr.x01_s = x01;
+    kr.enc_s = (const uint32_t *)enc; kr.out1_s = (const uint4 *)out1; kr.acts_s = (const uint4 *)acts1;
+    kr.t0_d = t_starts_out; kr.t1_d = t_ends_out; kr.x01_d = x01_out;
+    kr.enc_d = (uint32_t *)enc_out; kr.out1_d = (uint4 *)out1_out; kr.acts_d = (uint4 *)acts1_out;
+    kr.enc_sp = marched_capacity; kr.enc_dp = kept_capacity;
+    kr.acts_sl = (uint64_t)marched_capacity * 8; kr.acts_dl = (uint64_t)kept_capacity * 8;
+    kr.planes = n_levels;
+    if (n_hidden == 1)
+        hipLaunchKernelGGL((k_copy_kept_rows<1>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
+                           ray_indices_out, (__half *)tex_in, n_rays);
+    else
+        hipLaunchKernelGGL((k_copy_kept_rows<2>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
+                           ray_indices_out, (__half *)tex_in, n_rays);
+    NSR_CHECK_LAUNCH("nsr_nerf_copy_kept_rows");
     return NSR_OK;
 }
 

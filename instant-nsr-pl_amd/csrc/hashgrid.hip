@@ -490,7 +490,8 @@ k_grid_reduce_slabs(const float *__restrict__ slabs, float *__restrict__ grad_ta
     float *dst = grad_table + (uint64_t)d.offset[level] * F;
     for (uint32_t k = (blockIdx.x * 256 + threadIdx.x) * 4; k < nf; k += gridDim.x * 256 * 4) {
         float4 s = accumulate ? *reinterpret_cast<const float4 *>(dst + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t c = 0; c < C; ++c) {
+#pragma unroll 8
+        for (uint32_t c = 0; c < C; ++c) {  // unrolled: 8 independent loads in flight (the sum order stays c = 0..C-1)
             const float4 v = *reinterpret_cast<const float4 *>(src + (uint64_t)c * nf + k);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }

@@ -219,10 +219,6 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     const uint32_t C = d->grid.n_levels * d->grid.n_features, S = n_kept;
     hipStream_t st = (hipStream_t)stream;
     float *acc = (float *)(ws + L.loss_acc);
-    if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) {
-        nsr_set_error("nsr_nerf_main_pass: hipMemsetAsync failed");
-        return NSR_ERR_LAUNCH;
-    }
     nsr_half *enc = (nsr_half *)(ws + L.enc), *out1 = (nsr_half *)(ws + L.out1), *acts1 = (nsr_half *)(ws + L.acts1);
     nsr_half *tex_in = (nsr_half *)(ws + L.tex_in), *out2 = (nsr_half *)(ws + L.out2), *acts2 = (nsr_half *)(ws + L.acts2);
     float *x01 = (float *)(ws + L.x01);
@@ -247,10 +243,18 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
         rb[na] = 128;
     }
     NSR_REQUIRE(F * 2 % 4 == 0, "nsr_nerf_main_pass: n_features_per_level must be even");
-    if (S > 0)  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
-        NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d, nullptr,
-                                            (int64_t *)(ws + L.ray_indices), (const nsr_half *)(pw + P.out1), 16, tex_in,
-                                            n_rays, stream));  // also writes the colour network's input rows
+    if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
+        if (F == 2 && nh1 <= 2)  // the step's usual shape: one lane per kept sample, all its rows in one round trip
+            NSR_TRY(nsr_nerf_copy_kept_rows(packed_marched, packed_kept, t_starts, t_ends, (const float *)(pw + P.x01),
+                                            (const nsr_half *)(pw + P.enc), (const nsr_half *)(pw + P.out1),
+                                            (const nsr_half *)(pw + P.acts1), t0, t1, x01, enc, out1, acts1, Lv, nh1,
+                                            n_marched, S, rays_d, (int64_t *)(ws + L.ray_indices), tex_in, n_rays,
+                                            stream));
+        else
+            NSR_TRY(nsr_copy_ray_prefix_rows_ex(packed_marched, packed_kept, na, src, dst, rb, planes, sp, dp, rays_d,
+                                                nullptr, (int64_t *)(ws + L.ray_indices),
+                                                (const nsr_half *)(pw + P.out1), 16, tex_in, n_rays, stream));
+    }
     // fork: bin the table-backward items on the helper stream as soon as the kept positions exist
     const bool overlap_bins = compute_grads && S > 0 && g_helper.init();
     if (overlap_bins) {
@@ -272,7 +276,7 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     }
     NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                   comp_rgb, opacity, depth, n_rays, stream));
-    NSR_TRY(nsr_smooth_l1_valid(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
+    NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
     if (!compute_grads || S == 0) return NSR_OK;
     NSR_REQUIRE(grad_density_mlp && grad_table && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
     float *d_rgb = (float *)(ws + L.d_rgb), *d_logit = (float *)(ws + L.d_logit);

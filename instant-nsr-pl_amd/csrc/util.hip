@@ -276,9 +276,17 @@ __global__ void k_adam_tick(int32_t *__restrict__ step, float *__restrict__ hype
     const int k = (done >= m0) + (done >= m1) + (done >= m2);
     double scale = 1.0;
     for (int i = 0; i < k; ++i) scale *= gamma;
+    // beta^s as running products kept (as doubles) in hyper[4..7]: a software pow() per step costs this one-thread
+    // kernel ~10 us; restarted with pow() whenever the counter does not continue the stored one (first call, resume)
+    double *pw = reinterpret_cast<double *>(hyper + 4);
+    int32_t *pw_step = reinterpret_cast<int32_t *>(hyper + 3);
+    double p1, p2;
+    if (*pw_step == done && done > 0) { p1 = pw[0] * b1; p2 = pw[1] * b2; }
+    else { p1 = pow(b1, (double)s); p2 = pow(b2, (double)s); }
+    pw[0] = p1; pw[1] = p2; *pw_step = s;
     hyper[0] = (float)(base_lr * scale);
-    hyper[1] = (float)(1.0 - pow(b1, (double)s));
-    hyper[2] = (float)(1.0 - pow(b2, (double)s));
+    hyper[1] = (float)(1.0 - p1);
+    hyper[2] = (float)(1.0 - p2);
 }
 
 }  // namespace

@@ -55,7 +55,7 @@ class FusedAdamW:
         dev = self.tcnn_modules[0].params.device
         if getattr(self, "_step_dev", None) is None:
             self._step_dev = torch.tensor([self.step_count], dtype=torch.int32, device=dev)
-            self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)  # lr, bc1, bc2 | running beta powers
         _ops.adam_tick(self._step_dev, self._hyper, self.lr, self.betas[0], self.betas[1], gamma, milestones)
         self.step_count += 1  # host mirror (not read by the kernels)
         for m in self.tcnn_modules:
@@ -64,6 +64,29 @@ class FusedAdamW:
             _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr, self.betas[0], self.betas[1],
                             self.eps, self.wd, self.step_count, zero_grad=True, hyper=self._hyper)
             m._shadow, m._shadow_key = shadow, (p.data_ptr(), p._version, p.device)
+
+
+class LazyLoss:
+    """the loss of the most recent asynchronous step, formed only when somebody looks: three tiny torch kernels per
+    step (mul, clamp, div) were 4 % of the step.  Reads the step's accumulator, so look before the next step runs."""
+
+    def __init__(self, acc, trainer):
+        self.acc, self.trainer, self.step = acc, trainer, trainer.global_step
+
+    def tensor(self):
+        if self.trainer.global_step != self.step:
+            raise RuntimeError("the loss of an asynchronous step lives in that step's accumulator: read it (float(), "
+                               ".tensor()) before the next train_step()")
+        return self.acc[0] / torch.clamp(3.0 * self.acc[1], min=1.0)
+
+    def __float__(self):
+        return float(self.tensor())
+
+    def item(self):
+        return float(self)
+
+    def isfinite(self):
+        return torch.isfinite(self.tensor())
 
 
 def multistep_lr_scale(step, milestones=(10000, 15000, 18000), gamma=0.33):
@@ -285,7 +308,7 @@ class Trainer:
             a["eager_seen"].add(key)
         self.global_step += 1
         self._async_capacities(a)
-        self.last = {"loss": loss, "n_rays": a["n_rays"], "n_samples": a["total_kept"]}
+        self.last = {"loss": LazyLoss(loss, self), "n_rays": a["n_rays"], "n_samples": a["total_kept"]}
         return self.last
 
     def _capture_async(self, a, key):
@@ -345,4 +368,4 @@ class Trainer:
             self.opt.step_device()
         if a["pending"]:
             main.wait_event(a["event"])  # join: the next step (or the grid refresh before it) starts behind the marching
-        return FusedNeRFStep.loss_value(res)
+        return res["loss_acc"]  # [sum, valid rays]: the loss value itself is formed on demand (LazyLoss)

@@ -88,12 +88,14 @@ SIGNATURES = {
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_copy_ray_prefixes": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_copy_ray_prefix_rows": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_nerf_copy_kept_rows": [_P] * 14 + [_U, _U, _U, _U, _P, _P, _P, _U, _P],
     "nsr_copy_ray_prefix_rows_ex": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P, _U, _P],
     "nsr_texture_input": [_P, _U, _P, _P, _U, _P, _P],
     "nsr_composite_forward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward_smooth_l1": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_smooth_l1_valid": [_P, _P, _P, _P, _U, _P],
+    "nsr_smooth_l1_valid_set": [_P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid_backward": [_P, _P, _P, _P, _F, _P, _U, _P],
     "nsr_gather_train_rays": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _U, _P],
     "nsr_prepare_train_rays": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P, _P, _U, _P, _P],

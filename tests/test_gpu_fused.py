@@ -229,8 +229,10 @@ def test_async_steps_match_synchronous_steps():
         torch.manual_seed(0)
         model = nsr.NeRFModel(cfg).cuda().train()
         tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=mode)
-        steps = [tr.train_step() for _ in range(30)]
-        losses = [float(s["loss"]) for s in steps]
+        steps, losses = [], []
+        for _ in range(30):
+            steps.append(tr.train_step())
+            losses.append(float(steps[-1]["loss"]))  # an asynchronous step's loss must be read before the next step
         if mode:
             c = tr.counters()
             assert c["truncated"] == 0
@@ -264,7 +266,7 @@ def test_async_capacity_overflow_is_reported_and_recovers():
     for _ in range(20):
         tr.train_step()
         torch.cuda.synchronize()
-    assert tr.counters()["truncated"] == before and bool(torch.isfinite(tr.last["loss"]))
+    assert tr.counters()["truncated"] == before and bool(tr.last["loss"].isfinite())
 
 
 def test_captured_graph_steps_match_eager_asynchronous_steps():
@@ -291,3 +293,19 @@ def test_captured_graph_steps_match_eager_asynchronous_steps():
     assert abs(l0[0] - l1[0]) < 1e-5 * max(1.0, abs(l0[0]))
     assert abs(s0 - s1) <= 0.02 * s0 and abs(r0 - r1) <= 0.02 * r0, (s0, s1, r0, r1)
     assert abs(sum(l0[-5:]) - sum(l1[-5:])) < 0.25 * sum(l0[-5:]) + 1e-3
+
+
+def test_device_adam_schedule_matches_host_schedule():
+    """nsr_adam_tick (running beta powers, MultiStepLR on the device) == the host-side scalars, over a milestone"""
+    from nsr_hip import ops
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hyper = torch.zeros(8, dtype=torch.float32, device="cuda")
+    lr, b1, b2, gamma, ms = 0.01, 0.9, 0.99, 0.33, (5, 9, 12)
+    for k in range(1, 16):
+        ops.adam_tick(step, hyper, lr, b1, b2, gamma, ms)
+        done = k - 1
+        want_lr = lr * gamma ** sum(done >= m for m in ms)
+        got = hyper[:3].tolist()
+        assert int(step.item()) == k
+        assert abs(got[0] - want_lr) <= 1e-7 * want_lr
+        assert abs(got[1] - (1 - b1 ** k)) <= 2e-7 and abs(got[2] - (1 - b2 ** k)) <= 2e-7
