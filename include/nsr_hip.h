@@ -225,7 +225,9 @@ int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t
  * (*total <- min(sum, capacity)); stats (device int32[6], 8-byte aligned, may be NULL): [0] last unclamped sum,
  * [1] largest sum so far (atomic max), [2] number of truncated launches, [4..5] uint64 running sum of the sums */
 int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
-                                uint32_t capacity, int32_t *stats, void *stream);
+                                uint32_t capacity, int32_t *stats, const int32_t *n_active, void *stream);
+/* n_active (device int32[1], may be NULL): rays >= *n_active count as empty -- the dead slots of a dynamic ray batch whose
+ * marching pass ran before the batch size was known */
 /* packed_info[n_rays,2] from sorted ray_indices[n] (binary search per ray) */
 int nsr_pack_info(const int64_t *ray_indices, int32_t *packed_info, uint32_t n, uint32_t n_rays, void *stream);
 

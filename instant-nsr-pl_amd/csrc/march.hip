@@ -406,13 +406,15 @@ k_pack_scratch(const float2 *__restrict__ scratch, uint32_t cap, const int32_t *
 // contiguous chunk; wave scan + LDS across the 16 waves.  Removes torch.cumsum + stack from the step.
 __global__ void __launch_bounds__(1024)
 k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ packed, int32_t *__restrict__ total,
-                   uint32_t n, uint32_t capacity, int32_t *__restrict__ stats)
+                   uint32_t n, uint32_t capacity, int32_t *__restrict__ stats, const int32_t *__restrict__ n_active)
 {
     __shared__ int32_t wave_tot[16];
     const uint32_t tid = threadIdx.x, chunk = (n + 1023) / 1024;
     const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    // slots >= *n_active are dead rays: they were marched (the marching pass runs ahead of the ray count) but keep nothing
+    const uint32_t live = n_active ? (uint32_t)max(min(*n_active, (int32_t)n), 0) : n;
     int32_t s = 0;
-    for (uint32_t k = lo; k < hi; ++k) s += counts[k];
+    for (uint32_t k = lo; k < hi; ++k) s += k < live ? counts[k] : 0;
     // inclusive scan of s across the block
     int32_t v = s;
     const int lane = tid & 63, w = tid >> 6;
@@ -427,7 +429,7 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
     for (int k = 0; k < w; ++k) prefix += wave_tot[k];
     int32_t run = prefix + v - s;  // exclusive prefix of this lane's chunk
     for (uint32_t k = lo; k < hi; ++k) {
-        int32_t c = counts[k], start = run;
+        int32_t c = k < live ? counts[k] : 0, start = run;
         run += c;
         if (capacity) {  // fixed-size sample buffers: rays past the capacity are truncated (and reported)
             start = min(start, (int32_t)capacity);
@@ -731,14 +733,15 @@ extern "C" int nsr_ray_march_bricks_write(const float *rays_o, const float *rays
 }
 
 extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *packed_info, int32_t *total,
-                                           uint32_t n_rays, uint32_t capacity, int32_t *stats, void *stream)
+                                           uint32_t n_rays, uint32_t capacity, int32_t *stats, const int32_t *n_active,
+                                           void *stream)
 {
     NSR_REQUIRE(total, "nsr_pack_from_counts: total is NULL");
     NSR_REQUIRE(n_rays == 0 || (num_steps && packed_info), "nsr_pack_from_counts: NULL pointer");
     NSR_REQUIRE(capacity < 0x7fffffffu, "nsr_pack_from_counts: capacity must fit int32");
     NSR_REQUIRE(!stats || ((uintptr_t)stats & 7u) == 0, "nsr_pack_from_counts: stats must be 8-byte aligned");
     hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, num_steps, packed_info, total,
-                       n_rays, capacity, stats);
+                       n_rays, capacity, stats, n_active);
     NSR_CHECK_LAUNCH("nsr_pack_from_counts");
     return NSR_OK;
 }
@@ -746,7 +749,7 @@ extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *pa
 extern "C" int nsr_pack_from_counts(const int32_t *num_steps, int32_t *packed_info, int32_t *total, uint32_t n_rays,
                                     void *stream)
 {
-    return nsr_pack_from_counts_capped(num_steps, packed_info, total, n_rays, 0, nullptr, stream);
+    return nsr_pack_from_counts_capped(num_steps, packed_info, total, n_rays, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int nsr_pack_info(const int64_t *ray_indices, int32_t *packed_info, uint32_t n, uint32_t n_rays,

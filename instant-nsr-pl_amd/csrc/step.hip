@@ -162,7 +162,8 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
     }
     NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
                                   kept_counts, n_rays, stream));
-    NSR_TRY(nsr_pack_from_counts_capped(kept_counts, packed_kept, total_kept, n_rays, kept_capacity, kept_stats, stream));
+    NSR_TRY(nsr_pack_from_counts_capped(kept_counts, packed_kept, total_kept, n_rays, kept_capacity, kept_stats, nullptr,
+                                        stream));
     return NSR_OK;
 }
 

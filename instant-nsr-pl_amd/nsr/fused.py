@@ -273,8 +273,10 @@ class FusedNeRFStep:
         rs["scratch"] = torch.empty(slots * cap * 2, dtype=F32, device=dev)
         return rs
 
-    def march_async(self, rs, dataset, generator, n_active, m_cap, stats, background="random", bricks=None):
-        """ray preparation + marching pass + capped packing into ray set ``rs`` on the CURRENT stream; no host sync.
+    def march_async(self, rs, dataset, generator, n_active, m_cap, stats, background="random", bricks=None,
+                    pack_masks=False):
+        """ray preparation + marching pass (+ capped packing unless ``m_cap`` is None) into ray set ``rs`` on the CURRENT
+        stream; no host sync.  ``n_active`` (device int32[1] or None): dead-slot marking at ray preparation;
         ``bricks``: the packed occupancy grid to march through (default: pack / look up the model's current grid)"""
         m, grid = self.model, self.model.occupancy_grid
         slots = rs["slots"]
@@ -299,8 +301,15 @@ class FusedNeRFStep:
                                                  ContractionType.AABB.value, float(m.render_step_size), 0.0,
                                                  ptr(rs["counts"]), ptr(rs["scratch"]), rs["cap"], slots, s),
                   "nsr_ray_march_bricks_count")
-        check(lib.nsr_pack_from_counts_capped(ptr(rs["counts"]), ptr(rs["packed"]), ptr(rs["total"]), slots, int(m_cap),
-                                              ptr(stats), s), "nsr_pack_from_counts_capped")
+        if m_cap is not None:
+            self.pack_async(rs, n_active if pack_masks else None, m_cap, stats)
+
+    def pack_async(self, rs, n_active, m_cap, stats):
+        """packed_info / total of ray set ``rs`` from its marched counts, clamped to ``m_cap``; slots >= n_active[0]
+        (device) keep nothing.  Separate from the marching pass so that the pass can run before the ray count exists."""
+        check(lib.nsr_pack_from_counts_capped(ptr(rs["counts"]), ptr(rs["packed"]), ptr(rs["total"]), rs["slots"],
+                                              int(m_cap), ptr(stats), ptr(n_active), stream_ptr()),
+              "nsr_pack_from_counts_capped")
         rs["m_cap"] = int(m_cap)
 
     def _async_buffers(self, slots, m_cap, s_cap, dev):

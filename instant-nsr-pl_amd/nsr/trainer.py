@@ -236,7 +236,7 @@ class Trainer:
         slots = cfg["max_train_num_rays"] if dynamic else self.train_num_rays
         a = dict(slots=slots, pending=False, event=None, check_every=8, last_check=None)
         a["n_rays"] = torch.tensor([self.train_num_rays], dtype=torch.int32, device=dev)
-        a["sets"] = [self.fused.async_ray_set(slots, dev) for _ in range(2)]
+        a["sets"] = [self.fused.async_ray_set(slots, dev) for _ in range(2)] if self.use_graphs else None
         a["stats"] = torch.zeros(16, dtype=torch.int32, device=dev)  # [0:6] marched, [8:14] kept (pack_from_counts_capped)
         a["rays_accum"] = torch.zeros(1, dtype=torch.int64, device=dev)
         a["host"] = torch.zeros(16, dtype=torch.int32).pin_memory()
@@ -246,6 +246,8 @@ class Trainer:
         a["s_cap"] = max(1 << 18, (3 * self.train_num_samples) // 2)
         a["truncated"] = 0
         a["graphs"], a["eager_seen"], a["total_kept"] = {}, set(), None
+        a["sets3"] = None if self.use_graphs else [self.fused.async_ray_set(slots, dev) for _ in range(3)]
+        a["events"], a["marched_upto"], a["packed_upto"], a["march_stream"] = {}, -1, -1, {}
         g = self.model.occupancy_grid.binary
         a["bricks"] = torch.empty(int(_lib.nsr_grid_bricks_words64(*[int(v) for v in g.shape])), dtype=torch.int64,
                                   device=dev)
@@ -260,12 +262,15 @@ class Trainer:
         if a["host_event"] is not None and a["host_event"].query():
             h = a["host"]
             max_m, max_s, trunc = int(h[1]), int(h[9]), int(h[2]) + int(h[10])
+            # the sample counts scale with the dynamic ray count: leave room for it to climb to its maximum
+            room = a["slots"] / max(min(int(h[15]), a["slots"]), 1) if int(h[15]) > 0 else 1.0
             for key, mx in (("m_cap", max_m), ("s_cap", max_s)):
-                want = max(-(-int(1.5 * mx) // 16384) * 16384, 65536)
+                want = max(-(-int(1.5 * room * mx) // 16384) * 16384, 65536)
                 if mx > 0.85 * a[key] or (mx > 0 and trunc == a["truncated"] and want < 0.5 * a[key]):
                     a[key] = want  # grow as soon as the window maximum comes close (or samples were dropped); shrink
                     #                only when the buffers are more than twice too large
             a["truncated"] = trunc
+        a["stats"][15:16].copy_(a["n_rays"])
         a["host"].copy_(a["stats"], non_blocking=True)
         a["host_event"] = torch.cuda.Event()
         a["host_event"].record(torch.cuda.current_stream())
@@ -282,6 +287,103 @@ class Trainer:
                 "truncated": int(st[2]) + int(st[10]), "m_cap": a["m_cap"], "s_cap": a["s_cap"]}
 
     def _train_step_async(self):
+        return self._train_step_async_graphable() if self.use_graphs else self._train_step_async_ahead()
+
+    def _train_step_async_ahead(self):
+        """The asynchronous step with the marching passes running AHEAD of the ray count.
+
+        The marching pass (~0.4 ms of latency-bound work on 3 % of the chip) needs rays and occupancy bricks only; what
+        needs the dynamic ray count of the previous step is merely which slots count -- applied by the tiny packing
+        kernel (dead slots keep nothing).  So the side stream marches ALL ``max_train_num_rays`` slots of steps t+1 and
+        t+2 while step t runs, the only work between step t's pruning pass and step t+1's is ``pack(t+1)``, and the
+        marching pass leaves the critical chain entirely (three ray sets rotate).  Steps that refresh the occupancy
+        grid (every 16th) are a pipeline boundary: their rays are marched in order, after the refresh."""
+        model, fused, cfg = self.model, self.fused, self.config
+        a = self._async_state()
+        dynamic = bool(cfg["dynamic_ray_sampling"])
+        t = self.global_step
+        with _ops.timed("phase:occupancy_update"):
+            model.update_step(0, t)
+        _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # re-packed in place after a grid refresh
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        if a.get("bricks_event") is None or (cfg["grid_prune"] and t % 16 == 0):
+            a["bricks_event"] = torch.cuda.Event()
+            a["bricks_event"].record(main)  # marching passes queued from now on read the re-packed bricks
+        sets, ev = a["sets3"], a["events"]
+        stats_m, stats_s = a["stats"][0:8], a["stats"][8:16]
+        refresh = lambda u: bool(cfg["grid_prune"]) and u % 16 == 0  # step u marches through a grid refreshed at its start
+
+        def queue_march(u, stream):
+            with torch.cuda.stream(stream):
+                done = ev.get(("step", u - 3))
+                if done is not None:
+                    stream.wait_event(done)  # ray set u % 3 was last read by step u - 3
+                stream.wait_event(a["bricks_event"])
+                fused.march_async(sets[u % 3], self.dataset, self.gen, None, None, None, cfg["background_color"],
+                                  bricks=a["bricks"])
+            a["marched_upto"], a["march_stream"][u] = u, stream
+
+        def queue_pack(u, stream):
+            with torch.cuda.stream(stream):
+                pruned = ev.get(("prune", u - 1))
+                if pruned is not None:
+                    stream.wait_event(pruned)  # the ray count of step u is final behind step u - 1's pruning pass
+                fused.pack_async(sets[u % 3], a["n_rays"], a["m_cap"], stats_m)
+                e = torch.cuda.Event()
+                e.record(stream)
+                ev[("pack", u)] = e
+            a["packed_upto"] = u
+
+        if a["marched_upto"] < t:     # first step, or the step right after a grid refresh: in order
+            with _ops.timed("phase:sample_rays"):
+                queue_march(t, main)
+        if a["packed_upto"] < t:
+            queue_pack(t, a["march_stream"].get(t, main))
+        main.wait_event(ev[("pack", t)])
+        a["march_stream"].pop(t - 1, None)
+        rs = sets[t % 3]
+        model.background_color = rs["bg"]
+
+        def after_prune_queued(total):
+            with torch.cuda.device(self.device):
+                _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(a["n_rays"]),
+                                                 int(self.train_num_samples) if dynamic else 0,
+                                                 int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), _stream_ptr()),
+                       "nsr_update_ray_count")
+            e = torch.cuda.Event()
+            e.record(main)
+            ev[("prune", t)] = e
+            if not self.pipeline_march:
+                return
+            if a["marched_upto"] >= t + 1 and a["packed_upto"] < t + 1:
+                queue_pack(t + 1, side)           # the only work between this pruning pass and the next one
+            for u in range(a["marched_upto"] + 1, t + 3):
+                if refresh(u):
+                    break                         # marched in order, after the refresh
+                queue_march(u, side)
+                if u == t + 1 and a["packed_upto"] < t + 1:
+                    queue_pack(t + 1, side)       # ahead of march(t + 2) in the side stream's order
+
+        res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued)
+        a["total_kept"] = res["num_samples"]
+        with _ops.timed("phase:all_reduce"):
+            self._all_reduce_grads()
+        with _ops.timed("phase:optimizer"):
+            self.opt.step_device()
+        e = torch.cuda.Event()
+        e.record(main)
+        ev[("step", t)] = e
+        for key in [k for k in ev if k[1] < t - 4]:
+            del ev[key]
+        self.global_step += 1
+        self._async_capacities(a)
+        self.last = {"loss": LazyLoss(res["loss_acc"], self), "n_rays": a["n_rays"], "n_samples": a["total_kept"]}
+        return self.last
+
+    def _train_step_async_graphable(self):
         """the fused step with every count on the device (FusedNeRFStep.forward_backward_async): the host only queues
         work and never waits for the GPU.  With ``use_graphs`` the queued launches of a step are captured once per
         variant (ray-set parity x in-order marching x launches-next-marching x capacities) as a HIP graph and

@@ -109,7 +109,7 @@ SIGNATURES = {
     "nsr_ray_march_bricks_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _U, _P],
     "nsr_ray_march_bricks_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _P, _P, _P, _U, _P],
     "nsr_pack_from_counts": [_P, _P, _P, _U, _P],
-    "nsr_pack_from_counts_capped": [_P, _P, _P, _U, _U, _P, _P],
+    "nsr_pack_from_counts_capped": [_P, _P, _P, _U, _U, _P, _P, _P],
     "nsr_pack_info": [_P, _P, _U, _U, _P],
     "nsr_contract": [_P, _P, _I, _P, _U, _P],
     "nsr_contract_inv": [_P, _P, _I, _P, _U, _P],
