@@ -50,6 +50,22 @@ NEURALANGELO["geometry"].update(
                              include_xyz=True, start_level=4, start_step=0, update_steps=1000))
 
 
+# configs/neus-dtu.yaml:12-110 (C4): NeuS foreground + learned NeRF++ background, fp32 VanillaMLP heads everywhere
+_VANILLA = dict(otype="VanillaMLP", activation="ReLU", output_activation="none", n_neurons=64)
+NEUS_DTU = copy.deepcopy(NEUS_BLENDER)
+NEUS_DTU.update(radius=1.0, ray_chunk=2048, learned_background=True, num_samples_per_ray_bg=64)
+NEUS_DTU["geometry"].update(radius=1.0)
+NEUS_DTU["texture"].update(mlp_network_config=dict(_VANILLA, n_hidden_layers=2))
+NEUS_DTU["geometry_bg"] = dict(
+    name="volume-density", radius=1.0, feature_dim=8, density_activation="trunc_exp", density_bias=-1,
+    xyz_encoding_config=dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+                             base_resolution=32, per_level_scale=1.3195079107728942),
+    mlp_network_config=dict(_VANILLA, n_hidden_layers=1))
+NEUS_DTU["texture_bg"] = dict(
+    name="volume-radiance", input_feature_dim=8, dir_encoding_config=dict(otype="SphericalHarmonics", degree=4),
+    mlp_network_config=dict(_VANILLA, n_hidden_layers=2), color_activation="sigmoid")
+
+
 def get(name):
-    return copy.deepcopy({"nerf-blender": NERF_BLENDER, "neus-blender": NEUS_BLENDER,
-                          "neuralangelo": NEURALANGELO}[name])
+    return copy.deepcopy({"nerf-blender": NERF_BLENDER, "neus-blender": NEUS_BLENDER, "neuralangelo": NEURALANGELO,
+                          "neus-dtu": NEUS_DTU}[name])

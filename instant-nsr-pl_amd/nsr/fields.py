@@ -90,6 +90,37 @@ class ProgressiveBandHashGrid(nn.Module):
         self.current_level = max(level, self.current_level)  # the reference's mask is monotone (:65)
 
 
+class VanillaFrequency(nn.Module):
+    """NeRF positional encoding with an optional coarse-to-fine cosine mask (reference models/network_utils.py:14-37;
+    pure torch there too -- the C1 CPU-plumbing encoder, kept double-differentiable).
+
+    out = cat over k of [sin(2^k x) m_k, cos(2^k x) m_k];  without ``n_masking_step`` every m_k is 1, with it
+    m_k = (1 - cos(pi * clamp(step / n_masking_step * n_freq - k, 0, 1))) / 2, refreshed by ``update_step``."""
+
+    def __init__(self, in_channels, config):
+        super().__init__()
+        self.n_freq = int(config["n_frequencies"])
+        self.n_input_dims = self.in_channels = int(in_channels)
+        self.n_output_dims = self.in_channels * 2 * self.n_freq
+        self.n_masking_step = int(config.get("n_masking_step", 0))
+        self.freq_bands = 2.0 ** torch.linspace(0, self.n_freq - 1, self.n_freq)
+        self.update_step(None, None)
+
+    def forward(self, x):
+        cols = []
+        for k in range(self.n_freq):
+            arg = self.freq_bands[k] * x
+            cols += [torch.sin(arg) * self.mask[k], torch.cos(arg) * self.mask[k]]
+        return torch.cat(cols, dim=-1)
+
+    def update_step(self, epoch, global_step):
+        if self.n_masking_step <= 0 or global_step is None:
+            self.mask = torch.ones(self.n_freq, dtype=torch.float32)
+        else:
+            ramp = (global_step / self.n_masking_step * self.n_freq - torch.arange(0, self.n_freq)).clamp(0, 1)
+            self.mask = (1.0 - torch.cos(math.pi * ramp)) / 2.0
+
+
 class CompositeEncoding(nn.Module):
     """optionally prepends ``x * 2 - 1`` (reference models/network_utils.py:68-79)"""
 
@@ -110,7 +141,9 @@ class CompositeEncoding(nn.Module):
 
 def get_encoding(n_input_dims, config):
     """reference models/network_utils.py:82-92"""
-    if config["otype"] == "ProgressiveBandHashGrid":
+    if config["otype"] == "VanillaFrequency":
+        enc = VanillaFrequency(n_input_dims, config)
+    elif config["otype"] == "ProgressiveBandHashGrid":
         enc = ProgressiveBandHashGrid(n_input_dims, config)
     else:
         enc = tcnn.Encoding(n_input_dims, config)

@@ -65,6 +65,24 @@ def gen_glue(models):
     np.savez_compressed(os.path.join(OUT, "glue_elementwise.npz"), **_np(out))
 
 
+def gen_vanilla_frequency(models):
+    """models/network_utils.py:14-37 -- with and without the coarse-to-fine mask, through get_encoding too"""
+    from models.network_utils import VanillaFrequency, get_encoding
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 3, generator=g)
+    out = {"x": x}
+    enc = VanillaFrequency(3, {"n_frequencies": 6})
+    out["plain"] = enc(x)
+    enc = VanillaFrequency(3, {"n_frequencies": 6, "n_masking_step": 1000})
+    for step in (0, 250, 700, 5000):
+        enc.update_step(0, step)
+        out[f"masked_{step}"] = enc(x)
+        out[f"mask_{step}"] = enc.mask.clone()
+    comp = get_encoding(3, refshim.DictConfig({"otype": "VanillaFrequency", "n_frequencies": 4, "include_xyz": True}))
+    out["composite"] = comp(x)
+    np.savez_compressed(os.path.join(OUT, "vanilla_frequency.npz"), **_np(out))
+
+
 def gen_neus_alpha(models):
     cfg = refshim.load_config("neus-blender.yaml", ["dataset.scene=lego"])
     cfg.model.geometry.xyz_encoding_config.update(SMALL_GRID)
@@ -147,13 +165,49 @@ def gen_neus(models):
     np.savez_compressed(os.path.join(OUT, "neus_forward.npz"), **_np(fx))
 
 
+def gen_neus_bg(models):
+    """configs/neus-dtu.yaml (C4): NeuS foreground + learned NeRF++ background (models/neus.py:141-203, 259-287)"""
+    cfg = refshim.load_config("neus-dtu.yaml", ["dataset.root_dir=unused"])
+    cfg.model.geometry.xyz_encoding_config.update(SMALL_GRID)
+    cfg.model.geometry_bg.xyz_encoding_config.update(SMALL_GRID)
+    cfg.model.num_samples_per_ray = 256
+    torch.manual_seed(5)
+    m = models.make("neus", cfg.model)
+    m.train()
+    m.update_step(0, 5000)  # no occupancy refresh (5000 % 16 != 0)
+    with torch.no_grad():
+        m.geometry.encoding.encoding.params.normal_(0, 0.05)
+        m.geometry.network.layers[0].weight_v[:, 3:].normal_(0, 0.05)
+        m.geometry_bg.encoding_with_network.encoding.encoding.params.normal_(0, 0.3)
+    m.occupancy_grid._binary = _sphere_grid(128, 1.0, 0.6)
+    ii = torch.stack(torch.meshgrid(*[torch.arange(256)] * 3, indexing="ij"), -1)
+    m.occupancy_grid_bg._binary = ((ii.sum(-1) % 3) != 0)  # a deterministic 2/3-full pattern of the contracted space
+    m.background_color = torch.tensor([1.0, 1.0, 1.0])
+    m.randomized = False
+    rays = _rays(16, 12)
+    rays[:, :3] *= 0.6  # cameras at radius 2.4 around the radius-1 foreground box
+    out = m(rays)
+    eik = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    loss = torch.nn.functional.mse_loss(out["comp_rgb_full"], torch.full_like(out["comp_rgb_full"], 0.4)) * 10 + eik * 0.1
+    loss.backward()
+    fx = {"rays": rays, "background": m.background_color, "binary_packed": np.packbits(m.occupancy_grid._binary.numpy()),
+          "binary_bg_packed": np.packbits(m.occupancy_grid_bg._binary.numpy()),
+          "cos_anneal_ratio": m.cos_anneal_ratio, "loss": loss, "loss_eikonal": eik}
+    fx.update({"param/" + k: v for k, v in m.state_dict().items() if "occupancy" not in k})
+    fx.update({"grad/" + k: v.grad for k, v in m.named_parameters() if v.grad is not None and v.numel() > 0})
+    fx.update({"out/" + k: v for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "neus_bg_forward.npz"), **_np(fx))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     models = refshim.install(tcnn_ref, nerfacc_ref)
     gen_glue(models)
+    gen_vanilla_frequency(models)
     gen_neus_alpha(models)
     gen_nerf(models)
     gen_neus(models)
+    gen_neus_bg(models)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

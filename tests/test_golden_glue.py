@@ -154,3 +154,23 @@ def _check_reference_import(refshim):
     m = models.make("nerf", cfg.model)
     assert [n for n, _ in m.named_parameters()] == ["geometry.encoding_with_network.params",
                                                     "texture.encoding.encoding.params", "texture.network.params"]
+
+
+def test_vanilla_frequency_mirror_matches_reference():
+    """nsr.fields.VanillaFrequency == the reference module, masks included, via get_encoding too"""
+    from nsr.fields import VanillaFrequency, get_encoding
+    fx = load("vanilla_frequency.npz")
+    x = fx["x"]
+    assert torch.equal(VanillaFrequency(3, {"n_frequencies": 6})(x), fx["plain"])
+    enc = VanillaFrequency(3, {"n_frequencies": 6, "n_masking_step": 1000})
+    assert enc.n_output_dims == 36 and enc.n_input_dims == 3
+    for step in (0, 250, 700, 5000):
+        enc.update_step(0, step)
+        assert torch.equal(enc.mask, fx[f"mask_{step}"]), step
+        assert torch.equal(enc(x), fx[f"masked_{step}"]), step
+    comp = get_encoding(3, {"otype": "VanillaFrequency", "n_frequencies": 4, "include_xyz": True})
+    assert comp.n_output_dims == 27 and torch.equal(comp(x), fx["composite"])
+    xg = x.clone().requires_grad_(True)  # stays differentiable to second order (eikonal term of the NeuS systems)
+    g1, = torch.autograd.grad(enc(xg).sum(), xg, create_graph=True)
+    g2, = torch.autograd.grad(g1.sum(), xg)
+    assert g2.shape == x.shape and bool(torch.isfinite(g2).all())

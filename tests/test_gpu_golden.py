@@ -3,6 +3,8 @@ REFERENCE's glue produced (tests/gen_golden.py).  Tolerances: segment indices an
 rendered colours 2e-3 (fp16 fields), SDF 1e-3, gradients cosine >= 0.999."""
 import copy
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -83,3 +85,45 @@ def test_neus_model_matches_reference_fixture():
         assert _cos(params[k].grad.cpu(), fx["grad/" + k]) > 0.995, (k, _cos(params[k].grad.cpu(), fx["grad/" + k]))
     assert abs(float(params["variance.variance"].grad) - float(fx["grad/variance.variance"])) < \
         2e-2 * abs(float(fx["grad/variance.variance"])) + 1e-5
+
+
+def test_neus_background_model_matches_reference_fixture():
+    """C4 shapes (configs/neus-dtu.yaml): NeuS foreground + learned NeRF++ background -- forward_bg_ (models/neus.py:141-203:
+    cone-angle marching through the UN_BOUNDED_SPHERE grid from the foreground box's exit, VanillaMLP density/colour heads)
+    and the full composite of models/neus.py:259-287, against the reference's own run of it"""
+    import nsr
+    fx = load("neus_bg_forward.npz")
+    cfg = nsr.configs.get("neus-dtu")
+    for key in ("geometry", "geometry_bg"):
+        cfg[key]["xyz_encoding_config"].update({k: v for k, v in SMALL_GRID.items() if k != "otype"})
+    cfg["num_samples_per_ray"] = 256
+    m = nsr.NeuSModel(cfg).cuda().train()
+    sd = {k[len("param/"):]: v for k, v in fx.items() if k.startswith("param/")}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("occupancy_grid" in k for k in missing), (missing, unexpected)
+    m.update_step(0, 5000)
+    m.occupancy_grid._binary = binary_from(fx).cuda()
+    m.occupancy_grid_bg._binary = torch.from_numpy(np.unpackbits(fx["binary_bg_packed"].numpy())[:256 ** 3]
+                                                   .reshape(256, 256, 256).astype(bool)).cuda()
+    m.background_color = fx["background"].cuda()
+    m.randomized = False
+    out = m(fx["rays"].cuda())
+    assert torch.equal(out["ray_indices"].cpu(), fx["out/ray_indices"])
+    assert torch.equal(out["ray_indices_bg"].cpu(), fx["out/ray_indices_bg"])          # same marcher decisions
+    assert torch.allclose(out["points_bg"].cpu(), fx["out/points_bg"], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(out["intervals_bg"].cpu(), fx["out/intervals_bg"], rtol=1e-5, atol=1e-7)
+    for k in ("comp_rgb_bg", "opacity_bg", "depth_bg", "comp_rgb", "opacity", "comp_rgb_full"):
+        tol = 2e-2 if k == "depth_bg" else 3e-3
+        assert torch.allclose(out[k].cpu(), fx["out/" + k], atol=tol, rtol=1e-2), \
+            (k, (out[k].cpu() - fx["out/" + k]).abs().max())
+    assert torch.equal(out["rays_valid_full"].cpu(), fx["out/rays_valid_full"])
+    assert int(out["num_samples_full"]) == int(fx["out/num_samples_full"])
+    eik = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    loss = torch.nn.functional.mse_loss(out["comp_rgb_full"], torch.full_like(out["comp_rgb_full"], 0.4)) * 10 + eik * 0.1
+    loss.backward()
+    assert abs(float(loss) - float(fx["loss"])) < 2e-3 * max(1.0, float(fx["loss"]))
+    params = dict(m.named_parameters())
+    for k in ("geometry_bg.encoding_with_network.encoding.encoding.params",
+              "geometry_bg.encoding_with_network.network.layers.0.weight", "texture_bg.network.layers.4.weight",
+              "geometry.encoding.encoding.params", "texture.network.layers.0.weight"):
+        assert _cos(params[k].grad.cpu(), fx["grad/" + k]) > 0.995, (k, _cos(params[k].grad.cpu(), fx["grad/" + k]))
