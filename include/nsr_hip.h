@@ -291,6 +291,16 @@ int nsr_neus_alpha_backward(const float *sdf, const float *normal, const float *
                             float *grad_sdf, float *grad_normal, float *grad_inv_s, /* grad_inv_s: device[1], accumulated */
                             uint32_t n, void *stream);
 
+/* the Mip-NeRF 360 distortion loss the reference takes from torch_efficient_distloss
+ * (flatten_eff_distloss(weights, points, intervals, ray_indices), systems/nerf.py:103-106, systems/neus.py:131-139).
+ * forward: ray_loss[r] = sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 dt_i over the samples of ray r (sorted along the
+ * ray); backward: grad_weights[i] = d(sum_r ray_loss[r]) / d w_i.  The mean over rays and the chain factor are the
+ * caller's (torch_efficient_distloss/__init__.py). */
+int nsr_distortion_loss_forward(const int32_t *packed_info, const float *weights, const float *midpoints,
+                                const float *intervals, float *ray_loss, uint32_t n_rays, void *stream);
+int nsr_distortion_loss_backward(const int32_t *packed_info, const float *weights, const float *midpoints,
+                                 const float *intervals, float *grad_weights, uint32_t n_rays, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused training-step glue, see csrc/fused.hip
  * ------------------------------------------------------------------------------------------------ */

@@ -153,6 +153,60 @@ k_accumulate_bwd(const int64_t *__restrict__ ray_indices, const float *__restric
     if (g_w) g_w[i] = gw;
 }
 
+// ---- distortion loss (Mip-NeRF 360; the reference takes torch_efficient_distloss.flatten_eff_distloss,
+// systems/nerf.py:103-106, systems/neus.py:131-139) -------------------------------------------------------------------
+// Per ray, for samples sorted along the ray:  L = sum_i sum_j w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 dt_i
+//                                               = sum_i [ 2 w_i (m_i W_<i - WM_<i) + 1/3 dt_i w_i^2 ]
+// with the exclusive prefix sums W_<i = sum_{j<i} w_j and WM_<i = sum_{j<i} w_j m_j.  One wavefront per ray, wave scans
+// with a running carry, no atomics.  ray_loss[r] <- L of ray r (0 for empty rays).
+__global__ void __launch_bounds__(R_BLOCK)
+k_distortion_fwd(const int32_t *__restrict__ packed, const float *__restrict__ w, const float *__restrict__ m,
+                 const float *__restrict__ dt, float *__restrict__ ray_loss, uint32_t n_rays)
+{
+    const uint32_t r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const uint32_t start = (uint32_t)packed[2ull * r], count = (uint32_t)packed[2ull * r + 1];
+    float cw = 0.f, cwm = 0.f, acc = 0.f;
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        const float wi = ok ? w[start + k] : 0.f, mi = ok ? m[start + k] : 0.f, di = ok ? dt[start + k] : 0.f;
+        const float iw = wave_incl_scan_add(wi), iwm = wave_incl_scan_add(wi * mi);
+        const float w_pre = cw + (iw - wi), wm_pre = cwm + (iwm - wi * mi);
+        acc += 2.f * wi * (mi * w_pre - wm_pre) + (1.f / 3.f) * di * wi * wi;
+        cw += __shfl(iw, 63, 64);
+        cwm += __shfl(iwm, 63, 64);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) ray_loss[r] = acc;
+}
+
+// dL/dw_i = 2 [ m_i (W_<i - W_>i) + (WM_>i - WM_<i) ] + 2/3 dt_i w_i      (suffix = total - prefix - own)
+__global__ void __launch_bounds__(R_BLOCK)
+k_distortion_bwd(const int32_t *__restrict__ packed, const float *__restrict__ w, const float *__restrict__ m,
+                 const float *__restrict__ dt, float *__restrict__ grad_w, uint32_t n_rays)
+{
+    uint32_t start, count;
+    if (!wave_ray(packed, n_rays, start, count)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    float tw = 0.f, twm = 0.f;
+    for (uint32_t k = lane; k < count; k += 64) { tw += w[start + k]; twm += w[start + k] * m[start + k]; }
+    tw = wave_sum(tw);
+    twm = wave_sum(twm);
+    float cw = 0.f, cwm = 0.f;
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        const float wi = ok ? w[start + k] : 0.f, mi = ok ? m[start + k] : 0.f, di = ok ? dt[start + k] : 0.f;
+        const float iw = wave_incl_scan_add(wi), iwm = wave_incl_scan_add(wi * mi);
+        const float w_pre = cw + (iw - wi), wm_pre = cwm + (iwm - wi * mi);
+        const float w_suf = tw - (w_pre + wi), wm_suf = twm - (wm_pre + wi * mi);
+        if (ok) grad_w[start + k] = 2.f * (mi * (w_pre - w_suf) + (wm_suf - wm_pre)) + (2.f / 3.f) * di * wi;
+        cw += __shfl(iw, 63, 64);
+        cwm += __shfl(iwm, 63, 64);
+    }
+}
+
 }  // namespace
 
 #define RAY_GRID(n_rays) dim3(nsr_div_up(n_rays, RAYS_PER_BLOCK)), dim3(R_BLOCK), 0, (hipStream_t)stream
@@ -222,5 +276,26 @@ extern "C" int nsr_accumulate_along_rays_backward(const int64_t *ray_indices, co
     hipLaunchKernelGGL(k_accumulate_bwd, dim3(nsr_div_up(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                        ray_indices, weights, values, dim, grad_out, grad_weights, grad_values, n);
     NSR_CHECK_LAUNCH("nsr_accumulate_along_rays_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_distortion_loss_forward(const int32_t *packed_info, const float *weights, const float *midpoints,
+                                           const float *intervals, float *ray_loss, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && ray_loss, "nsr_distortion_loss_forward: NULL pointer");
+    hipLaunchKernelGGL(k_distortion_fwd, RAY_GRID(n_rays), packed_info, weights, midpoints, intervals, ray_loss, n_rays);
+    NSR_CHECK_LAUNCH("nsr_distortion_loss_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_distortion_loss_backward(const int32_t *packed_info, const float *weights, const float *midpoints,
+                                            const float *intervals, float *grad_weights, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && grad_weights, "nsr_distortion_loss_backward: NULL pointer");
+    hipLaunchKernelGGL(k_distortion_bwd, RAY_GRID(n_rays), packed_info, weights, midpoints, intervals, grad_weights,
+                       n_rays);
+    NSR_CHECK_LAUNCH("nsr_distortion_loss_backward");
     return NSR_OK;
 }

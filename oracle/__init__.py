@@ -23,6 +23,10 @@ arithmetic lives in two third-party CUDA packages that are absent from
   Restated in :mod:`oracle.nerfacc_ref` (+ ``oracle/csrc/nerfacc_ref.c`` for the
   sequential fp32 marcher).
 
+* ``torch_efficient_distloss`` (sunset1995/torch_efficient_distloss, un-pinned; reference ``systems/nerf.py:4,104``,
+  ``systems/neus.py:4``): ``flatten_eff_distloss`` restated in :mod:`oracle.distloss_ref` from the Mip-NeRF 360
+  definition; pinned only by definition-vs-prefix-form KATs (parity unpinned against the package itself).
+
 The reference-owned glue (``contract_to_unisphere``, ``trunc_exp``, ``get_alpha``,
 ``VolumeDensity/VolumeSDF/VolumeRadiance.forward``, ``NeRFModel/NeuSModel.forward_``)
 is restated in :mod:`oracle.glue_ref`.

@@ -217,3 +217,25 @@ def test_occupancy_grid_semantics():
     g.eval()
     with pytest.raises(RuntimeError):
         g.every_n_step(step=32, occ_eval_fn=fn)
+
+
+def test_distortion_loss_prefix_form_equals_definition():
+    """oracle/distloss_ref.py: the O(n) prefix-sum form and its hand-written gradient == the O(n^2) definition + autograd"""
+    import torch
+    from oracle import distloss_ref
+    g = torch.Generator().manual_seed(0)
+    counts = [0, 5, 1, 0, 17, 64, 3]
+    ray_id = torch.cat([torch.full((c,), r, dtype=torch.int64) for r, c in enumerate(counts)])
+    n = ray_id.numel()
+    w = (torch.rand(n, generator=g) * 0.3).double().requires_grad_(True)
+    m = torch.cat([torch.sort(torch.rand(c, generator=g) * 4 + 0.5).values for c in counts if c]).double()
+    interval = (torch.rand(n, generator=g) * 0.05 + 0.01).double()
+    ref = distloss_ref.distortion_definition(w, m, interval, ray_id)
+    gref, = torch.autograd.grad(ref, w)
+    loss, grad = distloss_ref.flatten_eff_distloss(w.detach(), m, interval, ray_id)
+    assert abs(float(loss) - float(ref)) < 1e-12 * max(1.0, abs(float(ref)))
+    assert torch.allclose(grad, gref, rtol=1e-10, atol=1e-13)
+    # one ray, two unit-weight samples a distance d apart, zero-length intervals: L = 2 * d
+    one = distloss_ref.distortion_definition(torch.ones(2).double(), torch.tensor([1.0, 3.5]).double(),
+                                             torch.zeros(2).double(), torch.zeros(2, dtype=torch.int64))
+    assert abs(float(one) - 5.0) < 1e-12
