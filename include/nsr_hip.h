@@ -291,6 +291,23 @@ int nsr_neus_alpha_backward(const float *sdf, const float *normal, const float *
                             float *grad_sdf, float *grad_normal, float *grad_inv_s, /* grad_inv_s: device[1], accumulated */
                             uint32_t n, void *stream);
 
+/* Device-side occupancy refresh (nerfacc 0.3.3 OccupancyGrid._update, reached from models/nerf.py:45-55 every 16th step)
+ * without a host sync; csrc/occupancy.hip.  (1) select_cells: all cells (all_cells != 0, capacity >= res^3) or n_uniform
+ * cells floor(u_cell * res^3) + the occupied cells of the 4^3-brick bitfield (n_uniform of them, picked with replacement by
+ * u_pick, when more than n_uniform are occupied); writes cells[], their jittered positions x_unit[,3] =
+ * (cell coordinate + jitter) / res in grid-unit space and the device count n_cells.  jitter: capacity x 3 uniforms;
+ * brick_offset: one word per brick; occupied_cells: res^3 words.  (2) the caller evaluates the density network on those
+ * positions with n_dev = n_cells.  (3) update: occs_new = occs_old, occs_new[cell] = max(occs_old[cell] * ema_decay,
+ * exp(mlp_out[i, 0] + density_bias) * step_size); threshold[0] = min(mean(occs_new), occ_thre); binary = occs_new > it.
+ * threshold: 8-byte aligned workspace of 2 + 2*256 floats ([0] the value, the rest partial sums). */
+int nsr_occupancy_select_cells(const uint64_t *bricks, int res_x, int res_y, int res_z, const float *u_cell,
+                               const float *u_pick, const float *jitter, uint32_t n_uniform, int all_cells,
+                               uint32_t capacity, uint32_t *brick_offset, uint32_t *occupied_cells, int32_t *n_occupied,
+                               uint32_t *cells, float *x_unit, int32_t *n_cells, void *stream);
+int nsr_occupancy_update(const nsr_half *mlp_out, uint32_t stride, float density_bias, float step_size, float ema_decay,
+                         float occ_thre, const uint32_t *cells, const float *occs_old, float *occs_new, uint8_t *binary,
+                         float *threshold, uint32_t n_total_cells, uint32_t capacity, const int32_t *n_cells, void *stream);
+
 /* the Mip-NeRF 360 distortion loss the reference takes from torch_efficient_distloss
  * (flatten_eff_distloss(weights, points, intervals, ray_indices), systems/nerf.py:103-106, systems/neus.py:131-139).
  * forward: ray_loss[r] = sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 dt_i over the samples of ray r (sorted along the

@@ -389,6 +389,68 @@ class FusedNeRFStep:
                     "packed_kept": packed2, "weights": view(L.weights, int(s_cap), F32, (int(s_cap),)),
                     "ray_indices": view(L.ray_indices, int(s_cap), torch.int64, (int(s_cap),)), "_workspace": ws}
 
+    # ---- occupancy refresh without a host sync --------------------------------------------------------------------
+    def refresh_occupancy_async(self, step, bricks, occ_thre=0.01, ema_decay=0.95, warmup_steps=256):
+        """``OccupancyGrid._update`` (nerfacc 0.3.3, reference models/nerf.py:45-55) queued on the current stream with the
+        selected-cell count kept on the device (csrc/occupancy.hip): no ``torch.nonzero``, ~12 launches.  Updates
+        ``grid.occs`` and ``grid.binary`` IN PLACE and re-packs ``bricks`` (the persistent 4^3-brick bitfield)."""
+        m, grid, ewn, d = self.model, self.model.occupancy_grid, self.ewn, self.desc
+        dev = grid.occs.device
+        rx, ry, rz = grid._res
+        N = grid.num_cells
+        all_cells = step < warmup_steps
+        n_uniform = N // 4
+        cap = N if all_cells else 2 * n_uniform
+        ob = getattr(self, "_occ_buf", None)
+        if ob is None:
+            C = d.grid.n_levels * d.grid.n_features
+            ob = self._occ_buf = dict(
+                cells=torch.empty(N, dtype=torch.int32, device=dev), x_unit=torch.empty(N * 3, dtype=F32, device=dev),
+                world=torch.empty(N * 3, dtype=F32, device=dev), x01=torch.empty(N * 3, dtype=F32, device=dev),
+                enc=torch.empty(N * C, dtype=F16, device=dev), out=torch.empty(N * 16, dtype=F16, device=dev),
+                u=torch.empty(2 * n_uniform, dtype=F32, device=dev), jitter=torch.empty(N * 3, dtype=F32, device=dev),
+                brick_offset=torch.empty(max(bricks.numel(), 1), dtype=torch.int32, device=dev),
+                occupied=torch.empty(N, dtype=torch.int32, device=dev),
+                counts=torch.zeros(4, dtype=torch.int32, device=dev), occs=torch.empty(N, dtype=F32, device=dev),
+                thr=torch.empty(2 + 2 * 256, dtype=F32, device=dev))
+        binary = grid._binary
+        assert binary.is_contiguous() and binary.dtype == torch.bool
+        n_occ, n_cells = ob["counts"][0:1], ob["counts"][1:2]
+        half = ewn.half_params(ewn.params)
+        table, w1 = half[ewn.n_network_params:], half[:ewn.n_network_params]
+        with torch.no_grad(), torch.cuda.device(dev):
+            s = stream_ptr()
+            ob["jitter"][:cap * 3].uniform_()
+            if not all_cells:
+                ob["u"].uniform_()
+            check(lib.nsr_occupancy_select_cells(ptr(bricks), rx, ry, rz, ptr(ob["u"][:n_uniform]),
+                                                 ptr(ob["u"][n_uniform:]), ptr(ob["jitter"]), n_uniform, int(all_cells),
+                                                 cap, ptr(ob["brick_offset"]), ptr(ob["occupied"]), ptr(n_occ),
+                                                 ptr(ob["cells"]), ptr(ob["x_unit"]), ptr(n_cells), s),
+                  "nsr_occupancy_select_cells")
+            # positions exactly as the torch path forms them: grid-unit -> world (contract_inv) -> the geometry's own
+            # contract_to_unisphere (models/geometry.py:122-124)
+            check(lib.nsr_contract_inv(ptr(ob["x_unit"]), ptr(grid.roi_aabb), ContractionType.AABB.value, ptr(ob["world"]),
+                                       cap, s), "nsr_contract_inv")
+            check(lib.nsr_contract_to_unisphere(ptr(ob["world"]), self.radius, ContractionType.AABB.value, ptr(ob["x01"]),
+                                                cap, s), "nsr_contract_to_unisphere")
+            C = d.grid.n_levels * d.grid.n_features
+            check(lib.nsr_hashgrid_forward_ex(ptr(ob["x01"]), ptr(table), ptr(ob["enc"]), cap, C, 1, d.grid.n_levels,
+                                              _byref(d.grid), ptr(n_cells), s), "nsr_hashgrid_forward_ex")
+            check(lib.nsr_mlp_forward_ex(ptr(ob["enc"]), 0, C, d.grid.n_features, ptr(w1), ptr(ob["out"]), None, cap,
+                                         _byref(d.mlp_density), ptr(n_cells), s), "nsr_mlp_forward_ex")
+            check(lib.nsr_occupancy_update(ptr(ob["out"]), 16, self.bias, float(m.render_step_size), float(ema_decay),
+                                           float(occ_thre), ptr(ob["cells"]), ptr(grid.occs), ptr(ob["occs"]),
+                                           ptr(binary.view(torch.uint8)), ptr(ob["thr"]), N, cap, ptr(n_cells), s),
+                  "nsr_occupancy_update")
+            grid.occs.copy_(ob["occs"])
+            check(lib.nsr_grid_pack_bricks(ptr(binary.view(torch.uint8)), rx, ry, rz, ptr(bricks), s),
+                  "nsr_grid_pack_bricks")
+        try:  # the cache of ops.grid_bricks keys on the tensor version, which a raw-pointer write does not bump
+            binary._nsr_bricks = (binary._version, binary.data_ptr(), bricks)
+        except Exception:  # noqa: BLE001
+            pass
+
     def _mlp_backward(self, dout, dout_stride, extra, out, x, acts, w, desc, grad_w, dx_lm_f):
         n = x.shape[0]
         dx = torch.empty(n * desc.n_in, dtype=F32, device=x.device)

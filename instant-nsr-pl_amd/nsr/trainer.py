@@ -119,6 +119,7 @@ class Trainer:
         # but measured SLOWER on ROCm 7.2 (0.759 vs 0.735 ms/step: hipGraphLaunch re-submits every node from the host),
         # so it is off by default
         self.async_mode, self._as, self.use_graphs = bool(async_mode), None, False
+        self.device_occupancy_refresh = True  # asynchronous mode: csrc/occupancy.hip instead of the torch formulation
         if fused and config["name"] == "nerf":
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
@@ -303,7 +304,14 @@ class Trainer:
         dynamic = bool(cfg["dynamic_ray_sampling"])
         t = self.global_step
         with _ops.timed("phase:occupancy_update"):
-            model.update_step(0, t)
+            if self.device_occupancy_refresh and cfg["grid_prune"] and not cfg["learned_background"]:
+                model.geometry.update_step(0, t)  # models/nerf.py:45-55 with the grid refresh kept on the device
+                model.texture.update_step(0, t)
+                _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # first packing (cached afterwards)
+                if t % 16 == 0:
+                    fused.refresh_occupancy_async(t, a["bricks"])
+            else:
+                model.update_step(0, t)
         _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # re-packed in place after a grid refresh
         main = torch.cuda.current_stream()
         if self._side is None:

@@ -108,6 +108,8 @@ SIGNATURES = {
     "nsr_ray_march_capacity": [ctypes.POINTER(ctypes.c_float), _F],
     "nsr_ray_march_bricks_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _U, _P],
     "nsr_ray_march_bricks_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _U, _P, _P, _P, _U, _P],
+    "nsr_occupancy_select_cells": [_P, _I, _I, _I, _P, _P, _P, _U, _I, _U, _P, _P, _P, _P, _P, _P, _P],
+    "nsr_occupancy_update": [_P, _U, _F, _F, _F, _F, _P, _P, _P, _P, _P, _U, _U, _P, _P],
     "nsr_distortion_loss_forward": [_P, _P, _P, _P, _P, _U, _P],
     "nsr_distortion_loss_backward": [_P, _P, _P, _P, _P, _U, _P],
     "nsr_pack_from_counts": [_P, _P, _P, _U, _P],

@@ -1,5 +1,7 @@
 """The fused training step (nsr/fused.py, csrc/fused.hip) against the modular drop-in path (autograd over the
 tinycudann / nerfacc packages) on the same model, rays and targets."""
+import copy
+
 import pytest
 import torch
 
@@ -309,3 +311,63 @@ def test_device_adam_schedule_matches_host_schedule():
         assert int(step.item()) == k
         assert abs(got[0] - want_lr) <= 1e-7 * want_lr
         assert abs(got[1] - (1 - b1 ** k)) <= 2e-7 and abs(got[2] - (1 - b2 ** k)) <= 2e-7
+
+
+def _occupancy_fixture(frac_occupied):
+    import nsr
+    from nsr.fused import FusedNeRFStep
+    torch.manual_seed(0)
+    model = nsr.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
+    grid = model.occupancy_grid
+    g = torch.Generator(device="cuda").manual_seed(1)
+    grid.occs.copy_(torch.rand(grid.num_cells, device="cuda", generator=g) * 0.02)
+    grid._binary = (torch.rand(grid._res, device="cuda", generator=g) < frac_occupied)
+    fused = FusedNeRFStep(model)
+    from nsr_hip import lib, ops
+    bricks = torch.empty(int(lib.nsr_grid_bricks_words64(*grid._res)), dtype=torch.int64, device="cuda")
+    ops.grid_bricks(grid.binary, out=bricks)
+    return model, grid, fused, bricks
+
+
+@pytest.mark.parametrize("step,frac", [(300, 0.03), (300, 0.4), (16, 0.03)])
+def test_device_occupancy_refresh_matches_torch_update(step, frac):
+    """csrc/occupancy.hip == nerfacc's OccupancyGrid._update_cells on the cells / jitter the kernels selected:
+    step 300 / 3 % occupied: uniform + all occupied; 40 % occupied: uniform + n picked with replacement; step 16: warm-up"""
+    model, grid, fused, bricks = _occupancy_fixture(frac)
+    N, nu = grid.num_cells, grid.num_cells // 4
+    occ_before = torch.nonzero(grid._binary.flatten())[:, 0]
+    ref = copy.deepcopy(grid)
+    fused.refresh_occupancy_async(step, bricks)
+    ob = fused._occ_buf
+    n = int(ob["counts"][1])
+    cells = ob["cells"][:n].long()
+    if step < 256:
+        assert n == N and torch.equal(cells, torch.arange(N, device="cuda"))
+    else:
+        n_take = min(occ_before.numel(), nu)
+        assert int(ob["counts"][0]) == occ_before.numel() and n == nu + n_take
+        assert int(cells.min()) >= 0 and int(cells.max()) < N
+        picked = cells[nu:]
+        if occ_before.numel() <= nu:
+            assert torch.equal(torch.sort(picked).values, occ_before)           # every occupied cell, exactly once
+        else:
+            assert bool(grid_was_occupied(ref, picked).all()) and torch.unique(picked).numel() > 0.5 * nu
+        u = ob["u"][:nu]
+        assert torch.equal(cells[:nu], (u * N).long().clamp(max=N - 1))         # floor(u * N)
+
+    def occ_eval_fn(x):
+        density, _ = model.geometry(x)
+        return density[..., None] * model.render_step_size
+
+    jitter = ob["jitter"][:3 * n].view(n, 3)
+    with torch.no_grad():
+        ref._update_cells(cells, jitter, occ_eval_fn, occ_thre=0.01, ema_decay=0.95)
+    once = torch.bincount(cells, minlength=N) <= 1   # duplicated cells: either formulation lets an arbitrary writer win
+    assert torch.allclose(grid.occs[once], ref.occs[once], rtol=2e-3, atol=1e-6)
+    assert float((grid.binary != ref.binary).float().mean()) < 1e-4
+    from nsr_hip import ops
+    assert torch.equal(bricks, ops.grid_bricks(grid.binary.clone()))            # re-packed bitfield == packing from scratch
+
+
+def grid_was_occupied(grid, cells):
+    return grid._binary.flatten()[cells]
