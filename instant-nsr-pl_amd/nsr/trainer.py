@@ -356,14 +356,19 @@ class Trainer:
         model.background_color = rs["bg"]
 
         def after_prune_queued(total):
-            with torch.cuda.device(self.device):
+            e = torch.cuda.Event()
+            e.record(main)
+            # the ray-count update feeds only the NEXT step's packing: it runs on the side stream, off the main queue
+            stream = side if self.pipeline_march else main
+            with torch.cuda.stream(stream), torch.cuda.device(self.device):
+                stream.wait_event(e)
                 _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(a["n_rays"]),
                                                  int(self.train_num_samples) if dynamic else 0,
                                                  int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), _stream_ptr()),
                        "nsr_update_ray_count")
-            e = torch.cuda.Event()
-            e.record(main)
-            ev[("prune", t)] = e
+                e2 = torch.cuda.Event()
+                e2.record(stream)
+            ev[("prune", t)] = e2  # "the ray count of step t + 1 is final"
             if not self.pipeline_march:
                 return
             if a["marched_upto"] >= t + 1 and a["packed_upto"] < t + 1:
