@@ -66,6 +66,20 @@ class FusedAdamW:
             m._shadow, m._shadow_key = shadow, (p.data_ptr(), p._version, p.device)
 
 
+def next_capacity(cap, window_max, n_rays, slots, dropped, granule=16384, floor=65536):
+    """Sample-buffer capacity for the next steps of the asynchronous trainer, from LAGGED statistics (the host never
+    waits for a count): 1.5 x the largest count of the last window, scaled by the room the dynamic ray count still has
+    to climb (counts grow with it), rounded up to ``granule``.  Grows as soon as the window maximum passes 85 % of the
+    current capacity; shrinks only when the buffers are more than twice too large and nothing was dropped."""
+    if window_max <= 0:
+        return cap
+    room = slots / max(min(n_rays, slots), 1) if n_rays > 0 else 1.0
+    want = max(-(-int(1.5 * room * window_max) // granule) * granule, floor)
+    if window_max > 0.85 * cap or (not dropped and want < 0.5 * cap):
+        return want
+    return cap
+
+
 class LazyLoss:
     """the loss of the most recent asynchronous step, formed only when somebody looks: three tiny torch kernels per
     step (mul, clamp, div) were 4 % of the step.  Reads the step's accumulator, so look before the next step runs."""
@@ -263,13 +277,9 @@ class Trainer:
         if a["host_event"] is not None and a["host_event"].query():
             h = a["host"]
             max_m, max_s, trunc = int(h[1]), int(h[9]), int(h[2]) + int(h[10])
-            # the sample counts scale with the dynamic ray count: leave room for it to climb to its maximum
-            room = a["slots"] / max(min(int(h[15]), a["slots"]), 1) if int(h[15]) > 0 else 1.0
-            for key, mx in (("m_cap", max_m), ("s_cap", max_s)):
-                want = max(-(-int(1.5 * room * mx) // 16384) * 16384, 65536)
-                if mx > 0.85 * a[key] or (mx > 0 and trunc == a["truncated"] and want < 0.5 * a[key]):
-                    a[key] = want  # grow as soon as the window maximum comes close (or samples were dropped); shrink
-                    #                only when the buffers are more than twice too large
+            dropped = trunc != a["truncated"]
+            a["m_cap"] = next_capacity(a["m_cap"], max_m, int(h[15]), a["slots"], dropped)
+            a["s_cap"] = next_capacity(a["s_cap"], max_s, int(h[15]), a["slots"], dropped)
             a["truncated"] = trunc
         a["stats"][15:16].copy_(a["n_rays"])
         a["host"].copy_(a["stats"], non_blocking=True)

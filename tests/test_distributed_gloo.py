@@ -88,3 +88,24 @@ def test_shard_seed_and_single_process_noop():
     lin = torch.nn.Linear(2, 2)
     lin(torch.ones(1, 2)).sum().backward()
     assert all_reduce_gradients(list(lin.parameters())) == 0  # not initialised: no collective
+
+
+def test_asynchronous_capacity_policy():
+    """nsr.trainer.next_capacity: the host-side rule that sizes the sample buffers from lagged device statistics"""
+    for p in (ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        from nsr.trainer import next_capacity
+    except ImportError as e:  # the product package refuses to import without its HIP library
+        import pytest
+        pytest.skip(f"nsr not importable here: {e}")
+    assert next_capacity(1 << 20, 0, 8192, 8192, False) == 1 << 20                 # no statistics yet: keep
+    assert next_capacity(1 << 20, 300_000, 8192, 8192, False) == 458752           # > 2x too large: shrink to 1.5x, 16k granule
+    assert next_capacity(458752, 300_000, 8192, 8192, False) == 458752            # comfortable: keep
+    assert next_capacity(458752, 400_000, 8192, 8192, False) == 606208            # > 85 % full: grow
+    assert next_capacity(458752, 900_000, 8192, 8192, True) == 1359872            # samples were dropped: grow to fit
+    assert next_capacity(1 << 20, 300_000, 8192, 8192, True) == 1 << 20           # never shrink right after a drop
+    assert next_capacity(2 << 20, 100_000, 512, 2048, False) == 606208            # ray count at 1/4 of its maximum: 4x room
+    assert next_capacity(1 << 20, 100_000, 512, 2048, False) == 1 << 20           # ... which keeps a 1 Mi buffer
+    assert next_capacity(1 << 20, 1000, 8192, 8192, False) == 65536               # floor
