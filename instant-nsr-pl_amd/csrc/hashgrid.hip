@@ -253,7 +253,8 @@ struct OwnerMap {
 
 // LDS float atomics retire at ~0.33 lane-ops/clk/CU on gfx950, 64-bit INTEGER ones at ~5 (tools/lds_atomics_bench.hip),
 // so the slices accumulate in Q27.36 fixed point: 15x the rate, 1.5e-11 resolution (the reference's tcnn accumulates
-// this gradient in fp16), and -- integer addition being associative -- a bit-reproducible gradient.
+// this gradient in fp16), and -- integer addition being associative -- a bit-reproducible gradient on every level that is
+// not split into chunk slabs (the slabs of the small dense levels are summed in fp32).
 // t = value * 2^36 (|t| < 2^62) -> two's complement int64, built from exact fp32 pieces of |t|.
 __device__ __forceinline__ unsigned long long own_to_fixed(float t)
 {
