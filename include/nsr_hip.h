@@ -475,7 +475,9 @@ int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, ui
 int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, nsr_half *shadow_half,
                    uint64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad, const float *hyper,
-                   void *stream);
+                   uint64_t zero_first_n, void *stream);
+/* zero_first_n (with zero_grad != 0): only grad[0 .. zero_first_n) is zeroed (0 = all of it; a multiple of 4) -- the fused
+ * step OVERWRITES the hash-table part of the gradient every step, zeroing those 50 MB again is wasted bandwidth */
 /* the one collective of the path is the mean all-reduce of the gradients; the 50 MB table
  * gradient travels as fp16 (dst = half(src * scale) before, dst = float(src) * scale after; nsr/parallel.py) */
 int nsr_scale_to_half(const float *src, nsr_half *dst, uint64_t n, float scale, void *stream);

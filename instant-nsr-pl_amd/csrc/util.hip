@@ -186,7 +186,7 @@ k_neus_alpha_bwd(const float *__restrict__ sdf, const float *__restrict__ normal
 __global__ void __launch_bounds__(EW_BLOCK)
 k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
         __half *__restrict__ shadow, uint64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
-        float bc2, float unscale, int zero_grad, const float *__restrict__ hyper)
+        float bc2, float unscale, int zero_grad, const float *__restrict__ hyper, uint64_t zero_first_n)
 {
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }  // device-side schedule (nsr_adam_tick): graph-replayable
     const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 4;
@@ -207,7 +207,7 @@ k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, flo
             *reinterpret_cast<float4 *>(p + base) = pp;
             *reinterpret_cast<float4 *>(m + base) = mm;
             *reinterpret_cast<float4 *>(v + base) = vv;
-            if (zero_grad) *reinterpret_cast<float4 *>(g + base) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zero_grad && base < zero_first_n) *reinterpret_cast<float4 *>(g + base) = make_float4(0.f, 0.f, 0.f, 0.f);
             if (shadow) {
                 __half2 h[2] = {__floats2half2_rn(pa[0], pa[1]), __floats2half2_rn(pa[2], pa[3])};
                 *reinterpret_cast<uint2 *>(shadow + base) = *reinterpret_cast<uint2 *>(h);
@@ -219,7 +219,7 @@ k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, flo
                 const float mj = b1 * m[j] + (1.f - b1) * gr, vj = b2 * v[j] + (1.f - b2) * gr * gr;
                 pj -= (lr / bc1) * (mj / (sqrtf(vj) / sqrtf(bc2) + eps));
                 p[j] = pj; m[j] = mj; v[j] = vj;
-                if (zero_grad) g[j] = 0.f;
+                if (zero_grad && j < zero_first_n) g[j] = 0.f;
                 if (shadow) shadow[j] = __float2half_rn(pj);
             }
         }
@@ -367,9 +367,11 @@ extern "C" int nsr_neus_alpha_backward(const float *sdf, const float *normal, co
 extern "C" int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq, nsr_half *shadow_half,
                               uint64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                               float bias_correction1, float bias_correction2, float grad_unscale, int zero_grad,
-                              const float *hyper, void *stream)
+                              const float *hyper, uint64_t zero_first_n, void *stream)
 {
     if (n == 0) return NSR_OK;
+    if (zero_first_n == 0 || zero_first_n > n) zero_first_n = n;  // 0 = the whole gradient
+    NSR_REQUIRE((zero_first_n & 3) == 0 || zero_first_n == n, "nsr_adamw_step: zero_first_n must be a multiple of 4");
     NSR_REQUIRE(params && grad && exp_avg && exp_avg_sq, "nsr_adamw_step: NULL pointer");
     NSR_REQUIRE((((uintptr_t)params | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                 "nsr_adamw_step: buffers must be 16-byte aligned");
@@ -377,7 +379,7 @@ extern "C" int nsr_adamw_step(float *params, float *grad, float *exp_avg, float 
     if (blocks > 2048) blocks = 2048;  // grid-stride: ~8 blocks per CU
     hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, params, grad, exp_avg,
                        exp_avg_sq, (__half *)shadow_half, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
-                       bias_correction2, grad_unscale, zero_grad, hyper);
+                       bias_correction2, grad_unscale, zero_grad, hyper, zero_first_n);
     NSR_CHECK_LAUNCH("nsr_adamw_step");
     return NSR_OK;
 }

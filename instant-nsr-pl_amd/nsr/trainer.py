@@ -23,6 +23,7 @@ class FusedAdamW:
     def __init__(self, named_modules, other_params, lr=0.01, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.01):
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_count = 0
+        self.table_grad_overwritten = False  # set by the fused trainers: their table backward writes every entry
         self.tcnn_modules = [m for m in named_modules if isinstance(m, tcnn.Module) and m.params.numel() > 0]
         self.state = {}
         for m in self.tcnn_modules:
@@ -61,8 +62,11 @@ class FusedAdamW:
         for m in self.tcnn_modules:
             p = m.params
             exp_avg, exp_avg_sq, shadow = self.state[p]
+            # the fused step overwrites the hash-table slice of the gradient: zero only the MLP slice in front of it
+            n_zero = getattr(m, "n_network_params", 0) if getattr(m, "grid_desc", None) is not None else 0
             _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr, self.betas[0], self.betas[1],
-                            self.eps, self.wd, self.step_count, zero_grad=True, hyper=self._hyper)
+                            self.eps, self.wd, self.step_count, zero_grad=True, hyper=self._hyper,
+                            zero_first_n=n_zero if (n_zero > 0 and n_zero % 4 == 0 and self.table_grad_overwritten) else 0)
             m._shadow, m._shadow_key = shadow, (p.data_ptr(), p._version, p.device)
 
 
@@ -137,6 +141,7 @@ class Trainer:
         if fused and config["name"] == "nerf":
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
+            self.opt.table_grad_overwritten = True
 
     def _all_reduce_grads(self):
         if self.world_size > 1:

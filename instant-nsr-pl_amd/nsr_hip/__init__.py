@@ -137,7 +137,7 @@ SIGNATURES = {
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                             ctypes.POINTER(ctypes.c_uint64)],
-    "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P, _P],
+    "nsr_adamw_step": [_P, _P, _P, _P, _P, _U64, _F, _F, _F, _F, _F, _F, _F, _F, _I, _P, _U64, _P],
     "nsr_scale_to_half": [_P, _P, _U64, _F, _P],
     "nsr_scale_from_half": [_P, _P, _U64, _F, _P],
     "nsr_adam_tick": [_P, _P, _D, _D, _D, _D, _I, _I, _I, _P],

@@ -683,14 +683,14 @@ def neus_alpha(sdf, normal, dirs, dists, inv_s, cos_anneal_ratio):
 
 
 def adamw_step(params, grad, exp_avg, exp_avg_sq, shadow_half, lr, beta1, beta2, eps, weight_decay, step,
-               grad_unscale=1.0, zero_grad=True, hyper=None):
+               grad_unscale=1.0, zero_grad=True, hyper=None, zero_first_n=0):
     """``hyper`` (device float[3] written by ``adam_tick``) overrides lr and the bias corrections on the device"""
     bc1, bc2 = 1.0 - beta1 ** max(step, 1), 1.0 - beta2 ** max(step, 1)
     with torch.cuda.device(params.device):
         check(lib.nsr_adamw_step(ptr(params), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(shadow_half),
                                  params.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                  float(bc1), float(bc2), float(grad_unscale), int(zero_grad), ptr(hyper),
-                                 stream_ptr()), "nsr_adamw_step")
+                                 int(zero_first_n), stream_ptr()), "nsr_adamw_step")
 
 
 def adam_tick(step_dev, hyper_dev, base_lr, beta1, beta2, gamma, milestones):
