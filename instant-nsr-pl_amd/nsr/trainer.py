@@ -335,6 +335,9 @@ class Trainer:
         if a.get("bricks_event") is None or (cfg["grid_prune"] and t % 16 == 0):
             a["bricks_event"] = torch.cuda.Event()
             a["bricks_event"].record(main)  # marching passes queued from now on read the re-packed bricks
+        if a["sets3"] is None:  # use_graphs was switched off after the first step
+            a["sets3"] = [self.fused.async_ray_set(a["slots"], self.device) for _ in range(3)]
+            a["marched_upto"] = a["packed_upto"] = t - 1
         sets, ev = a["sets3"], a["events"]
         stats_m, stats_s = a["stats"][0:8], a["stats"][8:16]
         refresh = lambda u: bool(cfg["grid_prune"]) and u % 16 == 0  # step u marches through a grid refreshed at its start
@@ -418,6 +421,9 @@ class Trainer:
         replayed: ~45 kernel launches become one graph launch.  Returns device tensors; ``counters()`` gives totals."""
         model, cfg = self.model, self.config
         a = self._async_state()
+        if a["sets"] is None:  # use_graphs was switched on after the first step
+            a["sets"] = [self.fused.async_ray_set(a["slots"], self.device) for _ in range(2)]
+            a["pending"] = False
         with _ops.timed("phase:occupancy_update"):
             model.update_step(0, self.global_step)
         _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # re-packed in place after a grid refresh

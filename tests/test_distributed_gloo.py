@@ -109,3 +109,26 @@ def test_asynchronous_capacity_policy():
     assert next_capacity(2 << 20, 100_000, 512, 2048, False) == 606208            # ray count at 1/4 of its maximum: 4x room
     assert next_capacity(1 << 20, 100_000, 512, 2048, False) == 1 << 20           # ... which keeps a 1 Mi buffer
     assert next_capacity(1 << 20, 1000, 8192, 8192, False) == 65536               # floor
+
+
+def test_lazy_loss_refuses_stale_reads():
+    """nsr.trainer.LazyLoss: an asynchronous step's loss lives in that step's accumulator and must be read before the next"""
+    import pytest
+    for p in (ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        from nsr.trainer import LazyLoss
+    except ImportError as e:
+        pytest.skip(f"nsr not importable here: {e}")
+
+    class FakeTrainer:
+        global_step = 7
+
+    tr = FakeTrainer()
+    loss = LazyLoss(torch.tensor([6.0, 4.0]), tr)            # sum of smooth-L1 terms, number of valid rays
+    assert abs(float(loss) - 0.5) < 1e-7 and abs(loss.item() - 0.5) < 1e-7 and bool(loss.isfinite())
+    assert abs(float(LazyLoss(torch.tensor([0.0, 0.0]), tr))) == 0.0   # no valid ray: 0 / max(0, 1)
+    tr.global_step = 8
+    with pytest.raises(RuntimeError):
+        float(loss)
