@@ -1,6 +1,6 @@
 // Native orchestration of the fused NeRF training step (host code only: no kernels here).
 //
-// Measured on MI355X (profiles/r01_c_timeline.csv): with every launch issued from Python the main queue idles ~40 %
+// Measured on MI355X (profiles/r01_c_timeline_tail.csv): with every launch issued from Python the main queue idles ~40 %
 // of the step -- ~10-25 us of interpreter + ctypes + allocator work per launch against kernels that take 3-20 us.
 // So each PHASE of the step is one C call that carves its buffers out of one caller-provided workspace and issues
 // all of its launches back to back on the caller's stream:
@@ -11,8 +11,11 @@
 //                         composite backward -> colour-MLP backward -> density-MLP backward -> table backward
 //                                             (= models/nerf.py:95-109 + systems/nerf.py:97 + loss.backward())
 //
-// The data-dependent sizes (M marched, S kept samples) stay on the host side of the call: the caller reads them back
-// (the step's two syncs), sizes the workspace with nsr_nerf_*_layout() and passes it in.  Nothing is allocated here.
+// Two ways to pass the data-dependent sizes (M marched, S kept samples): as host integers -- the caller reads them back,
+// two syncs per step -- or, with n_marched_dev / n_kept_dev, as DEVICE counts: then M and S are buffer capacities, every
+// launch is made for the capacity and reads the live count itself, and a whole step is queued without a host sync
+// (nsr/fused.py: forward_backward_async).  The caller sizes the workspaces with nsr_nerf_*_layout(); nothing is
+// allocated here.  The item binning of the table backward runs on a helper stream owned by this file.
 #include <string.h>
 
 #include <vector>

@@ -1,8 +1,12 @@
 """Fused NeRF training step: the same computation as ``NeRFModel.forward_`` + smooth-L1 loss + backward
-(reference models/nerf.py:61-127, systems/nerf.py:87-99), issued as ~25 kernel launches with hand-chained
+(reference models/nerf.py:61-127, systems/nerf.py:87-99), issued as ~45 kernel launches with hand-chained
 backward instead of ~250 launches through autograd.  It reads the parameters of an ordinary ``NeRFModel``
 (same ``state_dict``) and writes the gradients into their ``.grad``; parity with the modular path is tested in
 ``tests/test_gpu_fused.py``.
+
+Three entry points: ``forward_backward`` (reads its two sample counts back to the host), ``forward_backward_async`` +
+``march_async`` / ``pack_async`` (every count stays on the device, fixed-capacity buffers: no host sync) and
+``refresh_occupancy_async`` (the occupancy refresh of models/nerf.py:45-55 without ``torch.nonzero``).
 """
 import ctypes
 

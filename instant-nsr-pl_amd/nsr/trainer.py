@@ -4,6 +4,10 @@
 Multi-GPU: rays shard naturally.  Every rank draws its OWN ray batch (rank-offset RNG: the reference seeds all ranks
 identically, launch.py:62-64, so its DDP ranks render duplicate batches), replicates the 50 MB model, and the only
 data-path collective is one mean all-reduce of the gradients per step over RCCL (``torch.distributed`` backend "nccl").
+
+``Trainer(async_mode=True)`` is the measured path: no host synchronisation inside a step (device-side sample and ray
+counts, lagged capacity control), the marching passes two steps ahead on a side stream, the occupancy refresh on the
+device.  ``async_mode=False`` keeps the step that reads its counts back (and ``fused=False`` the modular autograd path).
 """
 import torch
 import torch.distributed as dist
