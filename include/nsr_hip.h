@@ -115,6 +115,12 @@ int nsr_hashgrid_backward_backward_input(const float *x, const nsr_half *table, 
                                          uint32_t dy_stride, const float *g, float *d_dy, uint32_t d_dy_stride,
                                          float *grad_table, float *dx2, uint32_t n, uint32_t level_mask_count,
                                          const NsrGridDesc *desc, void *stream);
+/* ... with the table gradient through the binned owner-computes path (no global float atomics); workspace of
+ * nsr_hashgrid_backward_params_workspace_floats(desc, n) floats; NULL workspace = the atomic kernel above */
+int nsr_hashgrid_backward_backward_input_ws(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
+                                            uint32_t dy_stride, const float *g, float *d_dy, uint32_t d_dy_stride,
+                                            float *grad_table, float *dx2, float *workspace, uint32_t n,
+                                            uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spherical harmonics degree 4 -- replaces tcnn.Encoding(SphericalHarmonics), models/texture.py:25

@@ -146,9 +146,13 @@ def hashgrid_backward_backward_input(x, table_half, dy, g, desc, mask_count=None
     d_dy = torch.empty((n, C), dtype=F32, device=x.device) if want_d_dy else None
     dx2 = torch.empty((n, 3), dtype=F32, device=x.device) if want_dx2 else None
     with torch.cuda.device(x.device):
-        check(lib.nsr_hashgrid_backward_backward_input(
+        ws = None
+        if grad_table is not None and n > 0:  # table part through the binned owner-computes path (no global atomics)
+            nws = lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), n)
+            ws = torch.empty(int(nws), dtype=F32, device=x.device)
+        check(lib.nsr_hashgrid_backward_backward_input_ws(
             ptr(x), ptr(table_half), ptr(dy), _is_f32(dy), dy.stride(0), ptr(g), ptr(d_dy), C, ptr(grad_table),
-            ptr(dx2), n, mc, _byref(desc), stream_ptr()), "nsr_hashgrid_backward_backward_input")
+            ptr(dx2), ptr(ws), n, mc, _byref(desc), stream_ptr()), "nsr_hashgrid_backward_backward_input_ws")
     return d_dy, dx2
 
 
