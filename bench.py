@@ -98,7 +98,7 @@ def main():
 
     torch.manual_seed(42)
     cfg = nsr.configs.get("nerf-blender")
-    model = nsr.NeRFModel(cfg).to(dev).train()
+    model = nsr.build(cfg).to(dev).train()
     data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
     tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42, async_mode=not args.sync_steps)
     tr.pipeline_march = not args.no_pipeline

@@ -414,6 +414,9 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                       const OwnerMap om, const NsrGridDesc d, const float *__restrict__ dir)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
+    __shared__ uint32_t s_nonfinite;  // an inf / NaN gradient reached this slice: it is flushed as NaN (GradScaler's
+                                      // found_inf must fire exactly as it does with tcnn's fp16 atomics), never clamped away
+    if (threadIdx.x == 0) s_nonfinite = 0u;
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     uint32_t level = d.n_levels;
     uint32_t local = 0;
@@ -466,8 +469,10 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                 const uint32_t mode = word[u] & 3u;
                 float g_out[F];
 #pragma unroll
-                for (int f = 0; f < F; ++f)  // to fixed-point units, saturating far beyond anything fp16 dy can produce
+                for (int f = 0; f < F; ++f) {  // to fixed-point units; the clamp only keeps the integer conversion defined
+                    if (!isfinite(gb[u][f])) s_nonfinite = 1u;
                     g_out[f] = fminf(fmaxf(gb[u][f] * fix, -4.6e18f), 4.6e18f);
+                }
                 const Cell c = locate(g, xb[u][0], xb[u][1], xb[u][2]);
                 const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
                 const float a1 = (k & 1) ? c.w[1] : 1.f - c.w[1], a2 = (k & 2) ? c.w[2] : 1.f - c.w[2];
@@ -481,6 +486,7 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                     const float a0l = 1.f - c.w[0], a0h = c.w[0];
                     w_lo = g.scale * (-g0 * a1 * a2 + g1 * s1 * a0l * a2 + g2 * s2 * a0l * a1);
                     w_hi = g.scale * (g0 * a1 * a2 + g1 * s1 * a0h * a2 + g2 * s2 * a0h * a1);
+                    if (!isfinite(w_lo) || !isfinite(w_hi)) { s_nonfinite = 1u; w_lo = w_hi = 0.f; }
                 } else {
                     w_lo = (1.f - c.w[0]) * (a1 * a2);
                     w_hi = c.w[0] * (a1 * a2);
@@ -492,6 +498,13 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
     }
     __syncthreads();
     const uint32_t nf = cnt * F;  // multiple of 8: level sizes are multiples of 8 entries
+    if (s_nonfinite) {
+        const float qnan = __builtin_nanf("");
+        float *dst = C > 1 ? slabs + om.slab_offset[level] + ((uint64_t)chunk * g.size + r0) * F
+                           : grad_table + (uint64_t)(g.offset + r0) * F;
+        for (uint32_t k = threadIdx.x; k < nf; k += OWN_BLOCK) dst[k] = qnan;
+        return;
+    }
     if (C > 1) {
         float *dst = slabs + om.slab_offset[level] + ((uint64_t)chunk * g.size + r0) * F;
         for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4)

@@ -395,7 +395,7 @@ k_pack_scratch(const float2 *__restrict__ scratch, uint32_t cap, const int32_t *
     const uint32_t start = (uint32_t)packed_info[2ull * r], count = (uint32_t)packed_info[2ull * r + 1];
     const float2 *row = scratch + (uint64_t)r * cap;
     for (uint32_t k = lane; k < count; k += 64) {
-        const float2 v = row[k];
+        const float2 v = row[min(k, cap - 1u)];  // (a count beyond the row is the caller's overflow case: stay in bounds)
         t_starts[start + k] = v.x;
         t_ends[start + k] = v.y;
         ray_indices[start + k] = (int64_t)r;

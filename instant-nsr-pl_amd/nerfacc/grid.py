@@ -46,6 +46,12 @@ class OccupancyGrid(Grid):
         self.register_buffer("occs", torch.zeros(self.num_cells))
         self._roi_host = [float(v) for v in roi_aabb.detach().cpu().tolist()]  # host copy: sample-capacity bound
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        key = prefix + "_roi_aabb"
+        if key in state_dict:  # the host copy bounds the marcher's per-ray scratch rows: keep it in step with the buffer
+            self._roi_host = [float(v) for v in state_dict[key].detach().cpu().tolist()]
+
     @property
     def roi_aabb(self):
         return self._roi_aabb

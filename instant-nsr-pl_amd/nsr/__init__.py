@@ -1,11 +1,11 @@
-"""Host-side mirror of the reference's hot-path glue (``models/{geometry,texture,nerf,neus}.py``) on top of the
-drop-in ``tinycudann`` / ``nerfacc`` packages and the fused glue kernels of libnsr_hip.so.
+"""Host side of the MI355X hot path above the drop-in ``tinycudann`` / ``nerfacc`` packages: fused step runners
+(``nsr.fused``: NeRF; ``nsr.fused_neus``: NeuS / neuralangelo), the one-process-per-GPU trainer (``nsr.trainer``,
+``nsr.parallel``), a parameter holder with the reference's state-dict keys (``nsr.state``), the reference YAMLs'
+model sections as dicts (``nsr.configs``) and a procedural dataset (``nsr.scene``).
 
-It exists because ``/root/reference`` cannot travel to the GPU box: the ``-m gpu`` tests, ``smoke()`` and
-``bench.py`` drive the kernels through this mirror, while the reference's own ``models/`` run unchanged on the
-same two packages when a user installs them.  Module / parameter names follow the reference so
-that ``state_dict`` keys match (``geometry.encoding_with_network.params``, ``texture.network.params`` ...).
+The reference's own ``models/`` run unchanged on the two drop-in packages; the runners here take either
+those model objects or an ``nsr.state.HotPathState``.  A line-by-line restatement of the reference's glue exists only
+as test infrastructure (``tests/refmirror``: ``/root/reference`` cannot travel to the GPU box).
 """
 from . import configs  # noqa: F401
-from .fields import VarianceNetwork, VolumeDensity, VolumeRadiance, VolumeSDF  # noqa: F401
-from .renderers import NeRFModel, NeuSModel  # noqa: F401
+from .state import HotPathState, build  # noqa: F401

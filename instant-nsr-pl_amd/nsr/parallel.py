@@ -31,6 +31,9 @@ def broadcast_parameters(module, src=0):
     for t in list(module.parameters()) + list(module.buffers()):
         if t.numel() > 0:
             dist.broadcast(t.data, src=src)
+    for m in module.modules():  # .data writes do not bump the version the fp16 shadow of a tcnn module is keyed on
+        if hasattr(m, "invalidate"):
+            m.invalidate()
 
 
 HALF_TRANSPORT_SCALE = 1024.0
@@ -53,7 +56,7 @@ def _all_reduce_half(g, world):
         g.copy_((h.float() * (1.0 / (HALF_TRANSPORT_SCALE * world))).view_as(g))
 
 
-def all_reduce_gradients(params, small_numel=1 << 16, half_transport=True):
+def all_reduce_gradients(params, small_numel=1 << 16, half_transport=False):
     """mean all-reduce of ``.grad`` over all ranks: large tensors individually (largest first; as fp16 on the wire
     with ``half_transport``), small ones flattened into one fp32 message."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

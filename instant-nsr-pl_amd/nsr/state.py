@@ -1,0 +1,179 @@
+"""Parameter / occupancy holders for the fused step runners (``nsr.fused``, ``nsr.fused_neus``).
+
+The fused runners do not own a model class: they read the hot-path tensors of ANY object that exposes them under the
+reference's attribute paths -- the reference's own ``models.nerf.NeRFModel`` / ``models.neus.NeuSModel`` built on the
+drop-in ``tinycudann`` / ``nerfacc`` packages, or the holder built here when no Lightning system is around
+(``bench.py``, tools).  The holder is a *spec table*: every row is ``(state-dict path, factory)``; the rows are
+instantiated into anonymous ``nn.Module`` containers so that ``state_dict()`` has exactly the reference's key set
+(``geometry.encoding_with_network.params``, ``texture.network.params``, ``occupancy_grid._binary`` ... --
+checkpoints of ``utils/mixins.py``/Lightning load with ``load_reference_checkpoint``) and nothing else of the
+reference's class structure (no ``forward_``: rendering is the runners' job).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+import tinycudann as tcnn
+from nerfacc import ContractionType, OccupancyGrid
+from nsr_hip import ops as _ops
+
+
+def _attach(root, path, module):
+    """root.a.b.c = module, creating anonymous containers on the way"""
+    parts = path.split(".")
+    cur = root
+    for p in parts[:-1]:
+        if not hasattr(cur, p):
+            cur.add_module(p, nn.Module())
+        cur = getattr(cur, p)
+    cur.add_module(parts[-1], module)
+
+
+class _Scalar(nn.Module):
+    def __init__(self, name, value):
+        super().__init__()
+        self.register_parameter(name, nn.Parameter(torch.tensor(float(value))))
+
+
+def _weight_normed_linear(d_in, d_out):
+    return nn.utils.weight_norm(nn.Linear(d_in, d_out, bias=True))
+
+
+def sphere_init_(linear, first, last, radius, d_in, d_out):
+    """geometric initialisation of the SDF network (reference models/network_utils.py:115-127); ``linear`` is the
+    weight-normed layer: the direction parameter is written, then the magnitude is re-derived from it"""
+    with torch.no_grad():
+        w = linear.weight_v if hasattr(linear, "weight_v") else linear.weight
+        if last:
+            linear.bias.fill_(-radius)
+            w.normal_(mean=math.sqrt(math.pi) / math.sqrt(d_in), std=0.0001)
+        else:
+            linear.bias.zero_()
+            w.normal_(0.0, math.sqrt(2) / math.sqrt(d_out))
+            if first:
+                w[:, 3:].zero_()
+        if hasattr(linear, "weight_g"):
+            linear.weight_g.copy_(w.norm(dim=1, keepdim=True))
+
+
+def sphere_init_fused_mlp_(network, n_input_dims, n_output_dims, n_neurons=64):
+    """the same initialisation written into the flat parameter of a fused ``tinycudann.Network`` (what the reference's
+    ``sphere_init_tcnn_network`` does through ``.data``, models/network_utils.py:142-173); invalidates the fp16 shadow"""
+    md = network.mlp_desc
+    mats = []
+    w = torch.zeros(n_neurons, md.in_pad)
+    w[:, :3].normal_(0.0, math.sqrt(2) / math.sqrt(n_neurons))
+    mats.append(w)
+    for _ in range(md.n_hidden - 1):
+        mats.append(torch.empty(n_neurons, n_neurons).normal_(0.0, math.sqrt(2) / math.sqrt(n_neurons)))
+    mats.append(torch.empty(md.out_pad, n_neurons).normal_(math.sqrt(math.pi) / math.sqrt(n_neurons), 0.0001))
+    flat = torch.cat([m.flatten() for m in mats])
+    assert flat.numel() == network.params.numel()
+    with torch.no_grad():
+        network.params.copy_(flat.to(network.params))
+    network.invalidate()
+
+
+class HotPathState(nn.Module):
+    """tensors of one scene: parameters (tcnn modules, the fp32 SDF head, the variance scalar), occupancy grid(s),
+    scene box and the marching constants derived from the config"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = cfg = config
+        kind = cfg["name"]
+        r = float(cfg["radius"])
+        self.register_buffer("scene_aabb", torch.tensor([-r, -r, -r, r, r, r], dtype=torch.float32))
+        rows = []
+        g, t = cfg["geometry"], cfg["texture"]
+        sh = lambda: tcnn.Encoding(3, t["dir_encoding_config"])  # noqa: E731
+        if kind == "nerf":
+            rows += [("geometry.encoding_with_network",
+                      lambda: tcnn.NetworkWithInputEncoding(3, g["feature_dim"], g["xyz_encoding_config"],
+                                                            g["mlp_network_config"])),
+                     ("texture.encoding.encoding", sh),
+                     ("texture.network", lambda: tcnn.Network(t["input_feature_dim"] + 16, 3, t["mlp_network_config"]))]
+        elif kind == "neus":
+            enc_cfg = dict(g["xyz_encoding_config"])
+            progressive = enc_cfg["otype"] == "ProgressiveBandHashGrid"
+            enc_path = "geometry.encoding.encoding" + (".encoding" if progressive else "")
+            n_enc = enc_cfg["n_levels"] * enc_cfg["n_features_per_level"] + (3 if enc_cfg.get("include_xyz") else 0)
+            mc = g["mlp_network_config"]
+            if mc["otype"] != "VanillaMLP" or mc["n_hidden_layers"] != 1 or mc["n_neurons"] != 64:
+                raise NotImplementedError("fused NeuS state: the SDF head is the 1-hidden-layer fp32 VanillaMLP of the "
+                                          "reference's neus-*/neuralangelo-* configs")
+            rows += [(enc_path, lambda: tcnn.Encoding(3, dict(enc_cfg, otype="HashGrid"))),
+                     ("geometry.network.layers.0", lambda: _weight_normed_linear(n_enc, 64)),
+                     ("geometry.network.layers.2", lambda: _weight_normed_linear(64, g["feature_dim"])),
+                     ("texture.encoding.encoding", sh),
+                     ("texture.network", lambda: tcnn.Network(t["input_feature_dim"] + 16, 3, t["mlp_network_config"])),
+                     ("variance", lambda: _Scalar("variance", cfg["variance"]["init_val"]))]
+            self.progressive = dict(enc_cfg) if progressive else None
+            self.current_level = enc_cfg.get("start_level", enc_cfg["n_levels"])
+            self.grad_type = g["grad_type"]
+            self.finite_difference_eps = None
+            self.cos_anneal_ratio = 1.0
+        else:
+            raise ValueError(kind)
+        for path, factory in rows:
+            _attach(self, path, factory())
+        if kind == "neus" and cfg["geometry"]["mlp_network_config"].get("sphere_init", False):
+            rad = cfg["geometry"]["mlp_network_config"].get("sphere_init_radius", 0.5)
+            l0, l2 = getattr(self.geometry.network.layers, "0"), getattr(self.geometry.network.layers, "2")
+            sphere_init_(l0, True, False, rad, l0.in_features, 64)
+            sphere_init_(l2, False, True, rad, 64, l2.out_features)
+        if cfg.get("learned_background", False):
+            raise NotImplementedError("HotPathState holds the bounded foreground scene; the NeRF++ background runs "
+                                      "through the drop-in packages")
+        self.contraction_type = ContractionType.AABB
+        self.render_step_size = 1.732 * 2 * r / cfg["num_samples_per_ray"]  # models/nerf.py:33, models/neus.py:76
+        if cfg["grid_prune"]:
+            self.occupancy_grid = OccupancyGrid(roi_aabb=self.scene_aabb, resolution=128,
+                                                contraction_type=ContractionType.AABB)
+        self.randomized = bool(cfg["randomized"])
+        self.background_color = None
+
+    # -- schedules that live on the reference's model objects (update_step hooks) --------------------------------
+    def update_step(self, epoch, global_step):
+        cfg = self.config
+        if cfg["name"] == "nerf" and self.training and cfg["grid_prune"]:
+            self.occupancy_grid.every_n_step(step=global_step, occ_eval_fn=self.density_of_cells)
+        if cfg["name"] == "neus":
+            end = cfg.get("cos_anneal_end", 0)
+            self.cos_anneal_ratio = 1.0 if end == 0 else min(1.0, global_step / end)  # models/neus.py:86-87
+            pg = self.progressive
+            if pg is not None:  # models/network_utils.py:61-65, models/geometry.py:224-236
+                lvl = min(pg["start_level"] + max(global_step - pg["start_step"], 0) // pg["update_steps"],
+                          pg["n_levels"])
+                self.current_level = max(self.current_level, lvl)
+                if self.config["geometry"].get("finite_difference_eps") == "progressive":
+                    res = pg["base_resolution"] * pg["per_level_scale"] ** (lvl - 1)
+                    self.finite_difference_eps = 2 * float(cfg["radius"]) / res
+            fd = self.config["geometry"].get("finite_difference_eps", 1e-3)
+            if isinstance(fd, float):
+                self.finite_difference_eps = fd
+
+    def density_of_cells(self, x_world):
+        """occupancy statistic of the nerf scene at world points (models/nerf.py:47-52): density x step size"""
+        ewn = self.geometry.encoding_with_network
+        x01 = _ops.contract_to_unisphere(x_world.float().contiguous(), float(self.config["radius"]),
+                                         ContractionType.AABB.value)
+        out = ewn(x01)
+        dens, _ = _ops.density_activation(out.half().contiguous() if out.dtype != torch.float16 else out.contiguous(),
+                                          out.shape[1], float(self.config["geometry"].get("density_bias", 0.0)),
+                                          want_feature=False)
+        return dens[..., None] * self.render_step_size
+
+    def train(self, mode=True):
+        self.randomized = bool(mode and self.config["randomized"])
+        return super().train(mode)
+
+    def load_reference_checkpoint(self, state_dict, strict=True):
+        """a Lightning ``.ckpt`` of the reference stores the model under ``model.``: strip it and load"""
+        sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in state_dict.items()}
+        return self.load_state_dict(sd, strict=strict)
+
+
+def build(config):
+    return HotPathState(config)

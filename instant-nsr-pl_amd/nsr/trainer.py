@@ -45,7 +45,7 @@ class FusedAdamW:
             _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr * lr_scale, self.betas[0],
                             self.betas[1], self.eps, self.wd, self.step_count, grad_unscale=grad_unscale, zero_grad=True)
             # the kernel already wrote the fp16 copy: hand it to the module instead of re-casting 12.6 M floats
-            m._shadow, m._shadow_key = shadow, (p.data_ptr(), p._version, p.device)
+            m.adopt_shadow(shadow)
         if self.other is not None:
             for g in self.other.param_groups:
                 g["lr"] = self.lr * lr_scale
@@ -71,7 +71,7 @@ class FusedAdamW:
             _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr, self.betas[0], self.betas[1],
                             self.eps, self.wd, self.step_count, zero_grad=True, hyper=self._hyper,
                             zero_first_n=n_zero if (n_zero > 0 and n_zero % 4 == 0 and self.table_grad_overwritten) else 0)
-            m._shadow, m._shadow_key = shadow, (p.data_ptr(), p._version, p.device)
+            m.adopt_shadow(shadow)
 
 
 def next_capacity(cap, window_max, n_rays, slots, dropped, granule=16384, floor=65536):
@@ -142,7 +142,10 @@ class Trainer:
         # so it is off by default
         self.async_mode, self._as, self.use_graphs = bool(async_mode), None, False
         self.device_occupancy_refresh = True  # asynchronous mode: csrc/occupancy.hip instead of the torch formulation
-        if fused and config["name"] == "nerf":
+        if config["name"] != "nerf":
+            # systems/neus.py has its own loss set (L1 on comp_rgb_full, eikonal, mask BCE ...): nsr.fused_neus.NeuSTrainer
+            raise NotImplementedError("nsr.trainer.Trainer runs the nerf-system step; use nsr.fused_neus.NeuSTrainer")
+        if fused:
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
             self.opt.table_grad_overwritten = True
@@ -324,8 +327,10 @@ class Trainer:
         t = self.global_step
         with _ops.timed("phase:occupancy_update"):
             if self.device_occupancy_refresh and cfg["grid_prune"] and not cfg["learned_background"]:
-                model.geometry.update_step(0, t)  # models/nerf.py:45-55 with the grid refresh kept on the device
-                model.texture.update_step(0, t)
+                for part in (model.geometry, model.texture):  # models/nerf.py:45-55, grid refresh kept on the device
+                    hook = getattr(part, "update_step", None)
+                    if hook is not None:
+                        hook(0, t)
                 _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # first packing (cached afterwards)
                 if t % 16 == 0:
                     fused.refresh_occupancy_async(t, a["bricks"])

@@ -463,6 +463,11 @@ def ray_march_finish(h):
     ray_indices = torch.empty(m, dtype=torch.int64, device=dev)
     t_starts = torch.empty((m, 1), dtype=F32, device=dev)
     t_ends = torch.empty((m, 1), dtype=F32, device=dev)
+    scratch = h.scratch
+    if m > 0 and scratch is not None and int((h.counts > h.cap).any()):
+        # a ray emitted more samples than its scratch row holds (the diag/step+3 bound assumes unit-length directions
+        # and the roi the capacity was derived from): the counts are still exact, so re-march in two-pass mode
+        scratch = None
     if m > 0:
         with torch.cuda.device(dev), _timed("ray_march_write", n):
             s = stream_ptr()
@@ -473,7 +478,7 @@ def ray_march_finish(h):
             else:
                 check(lib.nsr_ray_march_bricks_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi),
                                                      ptr(h.bricks), rx, ry, rz, contraction, step, cone_angle,
-                                                     ptr(h.packed), ptr(h.scratch), h.cap, ptr(ray_indices),
+                                                     ptr(h.packed), ptr(scratch), h.cap, ptr(ray_indices),
                                                      ptr(t_starts), ptr(t_ends), n, s), "nsr_ray_march_bricks_write")
     return h.packed, ray_indices, t_starts, t_ends
 

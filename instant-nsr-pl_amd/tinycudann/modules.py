@@ -107,19 +107,30 @@ class Module(torch.nn.Module):
         self.loss_scale = 128.0
         dev = _current_device()
         self.params = torch.nn.Parameter(self._initial_params(seed, dev).to(torch.float32), requires_grad=True)
-        self._shadow, self._shadow_key = None, None
+        self._shadow, self._shadow_key, self._shadow_trusted = None, None, False
 
-    # ---- fp16 shadow (tcnn casts params to fp16 on every call; we do it once per parameter version) ----
+    # ---- fp16 shadow (tcnn casts params to fp16 on every call) --------------------------------------------------
     def half_params(self, params):
+        """fp16 copy of the parameters that the kernels read.  Cached per parameter version in inference; while
+        TRAINING with autograd on it is re-cast on every call (75 MB of traffic, ~15 us on MI355X), because writes through
+        ``params.data`` -- the reference's ``sphere_init_tcnn_network`` (models/network_utils.py:172), DDP's initial
+        broadcast -- do not bump the version counter.  A fused optimizer that writes the fp16 copy itself marks it
+        trusted (``adopt_shadow``) and no cast happens at all."""
         key = (params.data_ptr(), params._version, params.device)
-        if key != self._shadow_key or self._shadow is None:
+        stale = key != self._shadow_key or self._shadow is None
+        if stale or (self.training and torch.is_grad_enabled() and not self._shadow_trusted):
             self._shadow = params.detach().to(torch.float16).contiguous()
-            self._shadow_key = key
+            self._shadow_key, self._shadow_trusted = key, False
         return self._shadow
+
+    def adopt_shadow(self, shadow):
+        """``shadow`` IS the current fp16 image of ``params`` (written by the fused AdamW kernel in the same pass)"""
+        p = self.params
+        self._shadow, self._shadow_key, self._shadow_trusted = shadow, (p.data_ptr(), p._version, p.device), True
 
     def invalidate(self):
         """call after writing to ``params.data`` directly (``.data`` writes do not bump the version counter)"""
-        self._shadow_key = None
+        self._shadow_key, self._shadow_trusted = None, False
 
     def _prep(self, x):
         if not x.is_cuda:

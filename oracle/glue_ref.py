@@ -121,9 +121,33 @@ def sdf_with_analytic_grad(points, encoding, sdf_mlp, radius, include_xyz=True):
     return sdf, grad, out
 
 
+def sdf_with_finite_difference(points, encoding, sdf_mlp, radius, eps, level_mask=None, include_xyz=True):
+    """reference models/geometry.py:181-199 (grad_type finite_difference): six +-eps taps clamped to the box, PLAIN AABB
+    scaling of the taps (:194), central differences and the 7-point laplace; ``level_mask`` is the 0/1 column mask of
+    ProgressiveBandHashGrid (models/network_utils.py:56-58).  -> sdf, grad, feature, laplace"""
+    def field(x01):
+        enc = encoding(x01.view(-1, 3))
+        if level_mask is not None:
+            enc = enc * level_mask
+        inp = torch.cat([x01.view(-1, 3) * 2.0 - 1.0, enc], dim=-1) if include_xyz else enc
+        return sdf_mlp(inp).float()
+    x = contract_to_unisphere(points, radius, N.ContractionType.AABB)
+    out = field(x)
+    sdf = out[..., 0]
+    offsets = torch.as_tensor([[eps, 0.0, 0.0], [-eps, 0.0, 0.0], [0.0, eps, 0.0], [0.0, -eps, 0.0],
+                               [0.0, 0.0, eps], [0.0, 0.0, -eps]]).to(points)
+    taps = (points[..., None, :] + offsets).clamp(-radius, radius)
+    taps = scale_anything(taps, (-radius, radius), (0, 1))
+    tap_sdf = field(taps)[..., 0].view(*points.shape[:-1], 6)
+    grad = 0.5 * (tap_sdf[..., 0::2] - tap_sdf[..., 1::2]) / eps
+    laplace = (tap_sdf[..., 0::2] + tap_sdf[..., 1::2] - 2 * sdf[..., None]).sum(-1) / (eps ** 2)
+    return sdf, grad, out, laplace
+
+
 def neus_forward(rays, encoding, sdf_mlp, sh_encoding, color_net, inv_s, grid, scene_aabb, radius, render_step_size,
-                 cos_anneal_ratio, background_color):
-    """reference models/neus.py:205-287 (analytic gradients, no learned background)"""
+                 cos_anneal_ratio, background_color, fd_eps=None, level_mask=None):
+    """reference models/neus.py:205-287 (no learned background); analytic gradients, or finite differences + laplace
+    when ``fd_eps`` is given"""
     n_rays = rays.shape[0]
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
     with torch.no_grad():
@@ -135,7 +159,12 @@ def neus_forward(rays, encoding, sdf_mlp, sh_encoding, color_net, inv_s, grid, s
     midpoints = (t_starts + t_ends) / 2.0
     positions = rays_o[ray_indices] + t_dirs * midpoints
     dists = t_ends - t_starts
-    sdf, sdf_grad, feature = sdf_with_analytic_grad(positions, encoding, sdf_mlp, radius)
+    laplace = None
+    if fd_eps is None:
+        sdf, sdf_grad, feature = sdf_with_analytic_grad(positions, encoding, sdf_mlp, radius)
+    else:
+        sdf, sdf_grad, feature, laplace = sdf_with_finite_difference(positions, encoding, sdf_mlp, radius, fd_eps,
+                                                                     level_mask)
     normal = F.normalize(sdf_grad, p=2, dim=-1)
     alpha = neus_alpha(sdf, normal, t_dirs, dists, inv_s, cos_anneal_ratio)[..., None]
     rgb = volume_radiance(feature, t_dirs, sh_encoding, color_net, "sigmoid", normal)
@@ -145,7 +174,11 @@ def neus_forward(rays, encoding, sdf_mlp, sh_encoding, color_net, inv_s, grid, s
     comp_rgb = N.accumulate_along_rays(weights, ray_indices, values=rgb, n_rays=n_rays)
     comp_normal = F.normalize(N.accumulate_along_rays(weights, ray_indices, values=normal, n_rays=n_rays), p=2, dim=-1)
     comp_rgb_full = comp_rgb + background_color[None, :].expand(*comp_rgb.shape) * (1.0 - opacity)
-    return dict(comp_rgb=comp_rgb, comp_normal=comp_normal, opacity=opacity, depth=depth, rays_valid=opacity > 0,
-                num_samples=torch.as_tensor([len(t_starts)], dtype=torch.int32), sdf_samples=sdf,
-                sdf_grad_samples=sdf_grad, weights=weights.view(-1), points=midpoints.view(-1),
-                intervals=dists.view(-1), ray_indices=ray_indices.view(-1), comp_rgb_full=comp_rgb_full)
+    out = dict(comp_rgb=comp_rgb, comp_normal=comp_normal, opacity=opacity, depth=depth, rays_valid=opacity > 0,
+               num_samples=torch.as_tensor([len(t_starts)], dtype=torch.int32), sdf_samples=sdf,
+               sdf_grad_samples=sdf_grad, weights=weights.view(-1), points=midpoints.view(-1),
+               intervals=dists.view(-1), ray_indices=ray_indices.view(-1), comp_rgb_full=comp_rgb_full,
+               rays_valid_full=opacity > 0)
+    if laplace is not None:
+        out["sdf_laplace_samples"] = laplace
+    return out

@@ -1,0 +1,99 @@
+"""Helpers shared by tests/gen_golden.py (build container) and the parity tests (CPU + GPU box).  TEST INFRASTRUCTURE.
+
+Full-size fixtures (L=16, T=2^19: 12.6-14 M parameters) cannot store their parameters or dense table gradients
+(50-56 MB each), so
+  * parameters are *re-generated* on both sides from a seed with numpy's PCG64 (``seeded_normal`` / ``seeded_uniform``:
+    bit-identical on every machine, unlike torch's device generators), and
+  * a large gradient is pinned by a compact *summary*: its norm, per-chunk norms (chunks = hash levels when offsets are
+    given), eight +-1 projections whose signs come from an integer hash of the index, and the 256 largest entries.
+"""
+import numpy as np
+import torch
+
+
+def seeded_normal(n, seed, std=1.0, mean=0.0):
+    return torch.from_numpy((np.random.default_rng(int(seed)).standard_normal(int(n), dtype=np.float32) * std + mean)
+                            .astype(np.float32))
+
+
+def seeded_uniform(n, seed, lo=0.0, hi=1.0):
+    return torch.from_numpy((np.random.default_rng(int(seed)).random(int(n), dtype=np.float32) * (hi - lo) + lo)
+                            .astype(np.float32))
+
+
+def _signs(n, k, device):
+    i = torch.arange(n, dtype=torch.int64, device=device)
+    h = (i * 2654435761 + (k + 1) * 40503) & 0xFFFFFFFF
+    h = (h ^ (h >> 15)) * 2246822519 & 0xFFFFFFFF
+    h = h ^ (h >> 13)
+    return ((h & 1) * 2 - 1).to(torch.float64)
+
+
+def grad_summary(g, offsets=None, n_proj=8, top=256):
+    """-> dict of small float64/int64 tensors describing the flat gradient ``g``"""
+    g = g.detach().reshape(-1).double().cpu()
+    n = g.numel()
+    if offsets is None:
+        offsets = [round(n * i / 16) for i in range(17)]
+    offsets = [int(o) for o in offsets]
+    chunk = torch.stack([g[a:b].norm() for a, b in zip(offsets[:-1], offsets[1:])])
+    proj = torch.stack([(g * _signs(n, k, g.device)).sum() for k in range(n_proj)])
+    idx = torch.topk(g.abs(), min(top, n)).indices.sort().values
+    return {"norm": g.norm().reshape(1), "chunk_norms": chunk, "offsets": torch.tensor(offsets, dtype=torch.int64),
+            "proj": proj, "top_idx": idx, "top_val": g[idx]}
+
+
+def check_grad_summary(g, s, rel=2e-2, name="grad"):
+    """``g`` (any device) against a summary minted from the reference run.  ``rel`` is relative to the gradient norm
+    (chunk norms: to the chunk's own norm plus 1e-3 of the total)."""
+    g = g.detach().reshape(-1).double().cpu()
+    norm = float(s["norm"])
+    assert abs(float(g.norm()) - norm) <= rel * norm + 1e-12, (name, "norm", float(g.norm()), norm)
+    off = [int(o) for o in s["offsets"]]
+    for c, (a, b) in enumerate(zip(off[:-1], off[1:])):
+        want = float(s["chunk_norms"][c])
+        got = float(g[a:b].norm())
+        if want == 0.0:
+            assert got == 0.0, (name, "chunk", c, "must be exactly zero", got)
+        else:
+            assert abs(got - want) <= rel * want + 1e-3 * rel * norm, (name, "chunk", c, got, want)
+    n = g.numel()
+    for k in range(len(s["proj"])):
+        got = float((g * _signs(n, k, g.device)).sum())
+        # a +-1 projection of an error vector of norm e has magnitude ~e: compare against rel * norm
+        assert abs(got - float(s["proj"][k])) <= 4 * rel * norm + 1e-12, (name, "proj", k, got, float(s["proj"][k]))
+    idx = s["top_idx"].long()
+    err = (g[idx] - s["top_val"].double()).norm() / max(float(s["top_val"].double().norm()), 1e-30)
+    assert err <= rel, (name, "top entries", float(err))
+
+
+def pack_summary(prefix, s):
+    return {f"{prefix}/{k}": v for k, v in s.items()}
+
+
+def unpack_summary(fx, prefix):
+    return {k[len(prefix) + 1:]: v for k, v in fx.items() if k.startswith(prefix + "/")}
+
+
+def neus_system_loss(out, rgb, fg_mask, lam):
+    """the loss terms of the reference's NeuSSystem.training_step (systems/neus.py:96-130) on a model output dict;
+    ``lam``: dict of lambda_* weights (missing = 0).  Used by the generator (on the reference's model) and by the
+    parity tests (on the HIP path) so both sides form the same scalar."""
+    valid = out["rays_valid_full"][..., 0]
+    terms = {}
+    terms["rgb_mse"] = torch.nn.functional.mse_loss(out["comp_rgb_full"][valid], rgb[valid])
+    terms["rgb_l1"] = torch.nn.functional.l1_loss(out["comp_rgb_full"][valid], rgb[valid])
+    terms["eikonal"] = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    opacity = torch.clamp(out["opacity"].squeeze(-1), 1.0e-3, 1.0 - 1.0e-3)
+    fg = fg_mask.float()
+    terms["mask"] = -(fg * torch.log(opacity) + (1 - fg) * torch.log(1 - opacity)).mean()
+    terms["opaque"] = -(opacity * torch.log(opacity) + (1 - opacity) * torch.log(1 - opacity)).mean()
+    terms["sparsity"] = torch.exp(-lam.get("sparsity_scale", 1.0) * out["sdf_samples"].abs()).mean()
+    if "sdf_laplace_samples" in out:
+        terms["curvature"] = out["sdf_laplace_samples"].abs().mean()
+    loss = 0.0
+    for k, v in terms.items():
+        w = float(lam.get("lambda_" + k, 0.0))
+        if w != 0.0:
+            loss = loss + w * v
+    return loss, terms

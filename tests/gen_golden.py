@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 import refshim  # noqa: E402
+import fixture_utils as fu  # noqa: E402
 from oracle import nerfacc_ref, tcnn_ref  # noqa: E402
 
 OUT = os.path.join(HERE, "golden")
@@ -199,6 +200,111 @@ def gen_neus_bg(models):
     np.savez_compressed(os.path.join(OUT, "neus_bg_forward.npz"), **_np(fx))
 
 
+NEURALANGELO_STEPS = {4: 5, 9: 5005, 16: 12005}  # current_level -> a global step that is not an occupancy refresh
+NEURALANGELO_LAMBDAS = {"lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1, "lambda_sparsity": 0.01}
+
+
+def gen_neuralangelo(models):
+    """configs/neuralangelo-dtu-wmask.yaml (C5) at FULL size (L=16, T=2^19, include_xyz): ProgressiveBandHashGrid at
+    current_level 4 / 9 / 16, finite-difference gradients + laplace with the progressive eps
+    (models/geometry.py:181-199,219-238, models/network_utils.py:40-65), fp32 VanillaMLP texture, and the loss terms of
+    systems/neus.py.  The 14 M-entry table is re-generated from a seed on the test side; its gradient is pinned by a
+    summary (tests/fixture_utils.py)."""
+    cfg = refshim.load_config("neuralangelo-dtu-wmask.yaml", ["dataset.root_dir=unused"])
+    cfg.model.num_samples_per_ray = 256
+    torch.manual_seed(6)
+    m = models.make("neus", cfg.model)
+    m.train()
+    table = m.geometry.encoding.encoding.encoding.params
+    desc = m.geometry.encoding.encoding.encoding.desc
+    with torch.no_grad():
+        table.copy_(fu.seeded_normal(table.numel(), 606, std=0.05))
+        m.geometry.network.layers[0].weight_v[:, 3:].copy_(fu.seeded_normal(64 * 32, 607, std=0.05).view(64, 32))
+    m.occupancy_grid._binary = _sphere_grid(128, 1.0, 0.6)
+    m.background_color = torch.tensor([1.0, 1.0, 1.0])
+    m.randomized = False
+    rays = _rays(20, 13)
+    rays[:, :3] *= 0.6
+    g = torch.Generator().manual_seed(14)
+    rgb = torch.rand(20, 3, generator=g)
+    fg_mask = (torch.rand(20, generator=g) > 0.3).float()
+    offsets = [int(o) * desc.F for o in desc.offset]
+    fx = {"rays": rays, "rgb": rgb, "fg_mask": fg_mask, "background": m.background_color,
+          "binary_packed": np.packbits(m.occupancy_grid._binary.numpy()), "table_seed": 606, "table_std": 0.05,
+          "table_numel": table.numel(), "level_offsets": np.asarray(offsets)}
+    fx.update({"param/" + k: v for k, v in m.state_dict().items()
+               if "occupancy" not in k and v.numel() < 100000})
+    for level, step in NEURALANGELO_STEPS.items():
+        m.zero_grad(set_to_none=True)
+        m.update_step(0, step)
+        assert m.geometry.encoding.encoding.current_level == level
+        out = m(rays)
+        lam = dict(NEURALANGELO_LAMBDAS, lambda_curvature=(1e-4 if level < 16 else 0.0))
+        loss, terms = fu.neus_system_loss(out, rgb, fg_mask, lam)
+        loss.backward()
+        p = f"L{level}/"
+        fx.update({p + "global_step": step, p + "eps": m.geometry._finite_difference_eps,
+                   p + "cos_anneal_ratio": m.cos_anneal_ratio, p + "loss": loss,
+                   p + "mask": m.geometry.encoding.encoding.mask.clone()})
+        fx.update({p + "term/" + k: v for k, v in terms.items()})
+        fx.update({p + "out/" + k: v for k, v in out.items()})
+        for k, v in m.named_parameters():
+            if v.grad is None or v.numel() == 0:
+                continue
+            if v.numel() < 100000:
+                fx[p + "grad/" + k] = v.grad.clone()
+            else:
+                fx.update(fu.pack_summary(p + "gradsum/" + k, fu.grad_summary(v.grad, offsets)))
+    np.savez_compressed(os.path.join(OUT, "neuralangelo_forward.npz"), **_np(fx))
+
+
+def gen_boundary_traces():
+    """tests/trace_tools.py: the reference's models from the REAL YAMLs (full-size C2 / C3) on recording wrappers of the
+    oracle packages -> tests/golden/trace_{nerf,neus}.npz"""
+    import trace_tools
+    for name, yaml_name, cli, seed in (("nerf", "nerf-blender.yaml", ["dataset.scene=lego"], 21),
+                                       ("neus", "neus-blender.yaml", ["dataset.scene=lego"], 22)):
+        rec = trace_tools.Recorder()
+        models = refshim.install(rec.wrap_tcnn(tcnn_ref), rec.wrap_nerfacc(nerfacc_ref))
+        try:
+            cfg = refshim.load_config(yaml_name, cli)
+            torch.manual_seed(seed)
+            m = models.make(name, cfg.model)
+            m.train()
+
+            def plan(info, mod):
+                if info["cls"] == "NetworkWithInputEncoding":
+                    n_net = mod.desc.n_params
+                    return [(n_net, seed * 100 + 1, 0.2), (mod.params.numel() - n_net, seed * 100 + 2, 0.3)]
+                if info["cls"] == "Network":
+                    return [(mod.params.numel(), seed * 100 + 3, 0.2)]
+                return [(mod.params.numel(), seed * 100 + 4, 0.05)]
+            rec.seed_parameters(m, plan)
+            if name == "neus":
+                with torch.no_grad():
+                    m.geometry.network.layers[0].weight_v[:, 3:].copy_(fu.seeded_normal(64 * 32, seed * 100 + 5, 0.05).view(64, 32))
+            m.update_step(0, 5)  # not an occupancy-refresh step
+            m.occupancy_grid._binary = _sphere_grid(128, 1.5, 0.5)
+            m.background_color = torch.tensor([0.1, 0.6, 0.9])
+            m.randomized = False
+            rays = _rays(12, seed)
+            out = m(rays)
+            if name == "nerf":
+                valid = out["rays_valid"][..., 0]
+                loss = torch.nn.functional.smooth_l1_loss(out["comp_rgb"][valid], torch.full_like(out["comp_rgb"], 0.5)[valid])
+            else:
+                rgb = torch.full_like(out["comp_rgb_full"], 0.5)
+                loss, _ = fu.neus_system_loss(out, rgb, torch.ones(12), {"lambda_rgb_l1": 1.0, "lambda_eikonal": 0.1,
+                                                                         "lambda_mask": 0.1})
+            loss.backward()
+            fx = rec.finish(m, extra={"model": name, "yaml": yaml_name, "loss": float(loss),
+                                      "num_samples": int(out["num_samples"].sum())})
+            np.savez_compressed(os.path.join(OUT, f"trace_{name}.npz"), **fx)
+            print(name, "calls:", [(c["kind"], c.get("fn", c.get("mod"))) for c in rec.calls])
+        finally:
+            refshim.uninstall()
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     models = refshim.install(tcnn_ref, nerfacc_ref)
@@ -208,6 +314,9 @@ def main():
     gen_nerf(models)
     gen_neus(models)
     gen_neus_bg(models)
+    gen_neuralangelo(models)
+    refshim.uninstall()
+    gen_boundary_traces()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -20,15 +20,34 @@ def _positions(rays_o, rays_d, ray_indices, t_starts, t_ends):
     return _ops.sample_positions(rays_o, rays_d, ray_indices, t_starts.contiguous(), t_ends.contiguous())
 
 
-def chunk_batch(func, chunk_size, *args):
-    """evaluation-time ray chunking (reference models/utils.py:13-50), results moved to the CPU"""
-    out = {}
-    B = args[0].shape[0]
+def chunk_batch(func, chunk_size, move_to_cpu, *args, **kwargs):
+    """evaluation-time chunking (reference models/utils.py:13-50): tensor / tuple / list / dict results, chunks
+    detached when grad mode is off and optionally moved to the CPU; ``None`` chunks are skipped"""
+    B = next(a.shape[0] for a in args if isinstance(a, torch.Tensor))
+    out, out_type, length = {}, None, 0
     for i in range(0, B, chunk_size):
-        o = func(*[a[i:i + chunk_size] if isinstance(a, torch.Tensor) else a for a in args])
+        o = func(*[a[i:i + chunk_size] if isinstance(a, torch.Tensor) else a for a in args], **kwargs)
+        if o is None:
+            continue
+        out_type = type(o)
+        if isinstance(o, torch.Tensor):
+            o = {0: o}
+        elif isinstance(o, (tuple, list)):
+            length = len(o)
+            o = dict(enumerate(o))
+        elif not isinstance(o, dict):
+            raise TypeError(f"chunk_batch: unsupported return type {type(o)}")
         for k, v in o.items():
-            out.setdefault(k, []).append(v.detach().cpu())
-    return {k: torch.cat(v, dim=0) for k, v in out.items()}
+            v = v if torch.is_grad_enabled() else v.detach()
+            out.setdefault(k, []).append(v.cpu() if move_to_cpu else v)
+    if out_type is None:
+        return None
+    out = {k: torch.cat(v, dim=0) for k, v in out.items()}
+    if out_type is torch.Tensor:
+        return out[0]
+    if out_type in (tuple, list):
+        return out_type([out[i] for i in range(length)])
+    return out
 
 
 class NeRFModel(nn.Module):
@@ -104,7 +123,7 @@ class NeRFModel(nn.Module):
     def forward(self, rays):
         if self.training:
             return self.forward_(rays)
-        return chunk_batch(self.forward_, self.config["ray_chunk"], rays)
+        return chunk_batch(self.forward_, self.config["ray_chunk"], True, rays)
 
     def train(self, mode=True):
         self.randomized = mode and self.config["randomized"]
@@ -254,7 +273,7 @@ class NeuSModel(nn.Module):
         return {**out, **{k + "_bg": v for k, v in out_bg.items()}, **{k + "_full": v for k, v in out_full.items()}}
 
     def forward(self, rays):
-        out = self.forward_(rays) if self.training else chunk_batch(self.forward_, self.config["ray_chunk"], rays)
+        out = self.forward_(rays) if self.training else chunk_batch(self.forward_, self.config["ray_chunk"], True, rays)
         return {**out, "inv_s": self.variance.inv_s}
 
     def train(self, mode=True):

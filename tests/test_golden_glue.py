@@ -40,7 +40,7 @@ def test_elementwise_glue():
 
 def test_host_mirror_activations_and_contraction_match_reference():
     from nerfacc import ContractionType
-    from nsr.fields import contract_to_unisphere, get_activation, trunc_exp
+    from refmirror.fields import contract_to_unisphere, get_activation, trunc_exp
     fx = load("glue_elementwise.npz")
     x = fx["x"]
     for name in ("sigmoid", "scale2.5", "+1.5", "softplus", "none"):
@@ -157,8 +157,8 @@ def _check_reference_import(refshim):
 
 
 def test_vanilla_frequency_mirror_matches_reference():
-    """nsr.fields.VanillaFrequency == the reference module, masks included, via get_encoding too"""
-    from nsr.fields import VanillaFrequency, get_encoding
+    """refmirror.fields.VanillaFrequency == the reference module, masks included, via get_encoding too"""
+    from refmirror.fields import VanillaFrequency, get_encoding
     fx = load("vanilla_frequency.npz")
     x = fx["x"]
     assert torch.equal(VanillaFrequency(3, {"n_frequencies": 6})(x), fx["plain"])

@@ -1,0 +1,130 @@
+"""Replay of the recorded boundary traffic (tests/trace_tools.py) against the HIP drop-in packages: every call the
+REFERENCE's own ``models.make('nerf'|'neus', cfg)`` (real YAMLs, full-size L=16 T=2^19) made into ``tinycudann`` /
+``nerfacc`` during one training forward + backward is re-issued with the recorded tensors -- same constructor
+arguments, same call order, same autograd protocol (incl. the ``create_graph=True`` double backward of
+models/geometry.py:177-180) -- and outputs / gradients are compared with what the reference run saw.
+
+Tolerances: marcher outputs and packed indices bit-exact; hash encodings rtol 2e-3 / atol 2e-4 (one fp16 ulp); fused MLP
+outputs rtol 4e-3 / atol 3e-3; fp32 compositing rtol 1e-4; input gradients rel-L2 2e-2 (fp16 backward chain in the
+MLP), 5e-3 for encodings; parameter-gradient summaries 2-3 % of the gradient norm."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_utils as fu
+import trace_tools
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _replay_tcnn(c, call, T, mods):
+    m = mods[call["mod"]]
+    is_grid = getattr(m, "kind", None) == "grid"
+    is_sh = getattr(m, "kind", None) == "sh"
+    x = T[f"c{c}/x"].cuda()
+    want = T[f"c{c}/y"]
+    rtol, atol = (2e-3, 2e-4) if (is_grid or is_sh) else (4e-3, 3e-3)
+    if not call["grad"]:
+        with torch.no_grad():
+            y = m(x)
+        assert y.dtype == torch.float16 and y.shape == want.shape
+        assert torch.allclose(y.float().cpu(), want.float(), rtol=rtol, atol=atol), (c, "y")
+        return
+    x.requires_grad_(call["x_req"])
+    y = m(x)
+    assert y.dtype == torch.float16 and y.shape == want.shape
+    assert torch.allclose(y.float().cpu(), want.float(), rtol=rtol, atol=atol), (c, "y", _rel(y, want))
+    if call["n_gy"] == 0:
+        return
+    gtol = 5e-3 if is_grid else 2e-2
+    if call["n_ggx"] > 0:  # first-order input gradient with a graph, then the backward that differentiates it again
+        gy0 = T[f"c{c}/gy0"].cuda().to(y.dtype).requires_grad_(True)
+        (gx0,) = torch.autograd.grad(y, x, gy0, create_graph=True)
+        assert _rel(gx0, T[f"c{c}/gx0"]) < gtol, (c, "gx0", _rel(gx0, T[f"c{c}/gx0"]))
+        outs, grads = [gx0], [T[f"c{c}/ggx0"].cuda().to(gx0.dtype)]
+        if call["n_gy"] > 1:
+            outs.append(y)
+            grads.append(T[f"c{c}/gy1"].cuda().to(y.dtype))
+        torch.autograd.backward(outs, grads)
+        if call["n_gx"] > 1:
+            assert _rel(x.grad, T[f"c{c}/gx1"]) < 2e-2, (c, "gx1", _rel(x.grad, T[f"c{c}/gx1"]))
+        if call["n_ggy"] > 0:  # J . ggx: what flows on into the SDF network
+            assert _rel(gy0.grad, T[f"c{c}/ggy0"]) < 2e-2, (c, "ggy0", _rel(gy0.grad, T[f"c{c}/ggy0"]))
+    else:
+        torch.autograd.backward([y], [T[f"c{c}/gy0"].cuda().to(y.dtype)])
+        if call["x_req"] and call["n_gx"] > 0:
+            assert _rel(x.grad, T[f"c{c}/gx0"]) < gtol, (c, "gx0", _rel(x.grad, T[f"c{c}/gx0"]))
+
+
+def _replay_nerfacc(c, call, T, nerfacc):
+    def dec(d, slot):
+        if "t" in d:
+            t = T[f"c{c}/{slot}"].cuda()
+            return t.requires_grad_(True) if d["req"] else t
+        if "grid" in d:
+            ct = getattr(nerfacc.ContractionType, d["contraction"])
+            g = nerfacc.OccupancyGrid(roi_aabb=T[f"c{c}/{slot}_roi"], resolution=d["res"], contraction_type=ct).cuda()
+            n = int(np.prod(d["res"]))
+            g._binary = torch.from_numpy(np.unpackbits(T[f"c{c}/{slot}_binary"].numpy())[:n].astype(bool)).view(*d["res"]).cuda()
+            return g
+        if "callback" in d:
+            ret = T[f"c{c}/{slot}_ret"].cuda()
+
+            def cb(t_starts, t_ends, ray_indices):
+                assert t_starts.shape[0] == ret.shape[0] and ray_indices.shape[0] == ret.shape[0]
+                return ret
+            return cb
+        v = d["v"]
+        if isinstance(v, dict) and "enum" in v:
+            return getattr(nerfacc.ContractionType, v["enum"])
+        return v
+    args = [dec(d, f"a{i}") for i, d in enumerate(call["args"])]
+    kw = {k: dec(d, f"k_{k}") for k, d in call["kw"].items()}
+    fn = nerfacc.intersection.ray_aabb_intersect if call["fn"] == "ray_aabb_intersect" else getattr(nerfacc, call["fn"])
+    with torch.set_grad_enabled(call["fn"] != "ray_marching"):
+        out = fn(*args, **kw)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    assert len(outs) == call["n_out"]
+    for j, o in enumerate(outs):
+        want = T[f"c{c}/o{j}"]
+        assert o.shape == want.shape and o.dtype == want.dtype, (c, call["fn"], j, o.shape, want.shape, o.dtype)
+        if call["fn"] in ("ray_marching", "ray_aabb_intersect"):
+            assert torch.equal(o.cpu(), want), (c, call["fn"], j)  # bit-exact segment indices / interval ends
+        else:
+            assert torch.allclose(o.detach().cpu(), want, rtol=1e-4, atol=1e-6), (c, call["fn"], j, _rel(o, want))
+    if call["n_gy"]:
+        gys = [(o, T[f"c{c}/gy_o{j}"].cuda()) for j, o in enumerate(outs) if f"c{c}/gy_o{j}" in T]
+        torch.autograd.backward([o for o, _ in gys], [g for _, g in gys])
+        named = {f"a{i}": a for i, a in enumerate(args)}
+        named.update({f"k_{k}": v for k, v in kw.items()})
+        for slot in call["gx"]:
+            assert _rel(named[slot].grad, T[f"c{c}/gx_{slot}"]) < 1e-4, (c, call["fn"], slot)
+
+
+@pytest.mark.parametrize("name", ["nerf", "neus"])
+def test_reference_call_trace_replays_on_the_hip_packages(name):
+    import nerfacc
+    import tinycudann as tcnn
+    meta, T = trace_tools.load_trace(os.path.join(GOLD, f"trace_{name}.npz"))
+    mods = trace_tools.build_modules(meta, tcnn, torch.device("cuda", 0))
+    kinds = [c["kind"] for c in meta["calls"]]
+    assert kinds.count("tcnn") >= 3 and kinds.count("nerfacc") >= 4
+    for c, call in enumerate(meta["calls"]):
+        if call["kind"] == "tcnn":
+            _replay_tcnn(c, call, T, mods)
+        else:
+            _replay_nerfacc(c, call, T, nerfacc)
+    for tid, m in enumerate(mods):  # what the whole trace accumulated into .grad
+        s = fu.unpack_summary(T, f"m{tid}/gradsum")
+        if not s:
+            continue
+        big = m.params.numel() > 100000
+        fu.check_grad_summary(m.params.grad, s, rel=2e-2 if big else 3e-2, name=f"{name} module {tid}")

@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 
 def _model(seed=0):
     import nsr
+    import refmirror
     torch.manual_seed(seed)
     cfg = nsr.configs.get("nerf-blender")
-    model = nsr.NeRFModel(cfg).cuda().train()
+    model = refmirror.NeRFModel(cfg).cuda().train()
     with torch.no_grad():
         model.geometry.encoding_with_network.params[3072:].normal_(0, 0.08)
     model.randomized = False
@@ -93,11 +94,12 @@ def test_gather_train_rays_matches_reference_formula():
 
 def test_fused_trainer_reduces_loss():
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender
     from nsr.trainer import Trainer
     torch.manual_seed(0)
     cfg = nsr.configs.get("nerf-blender")
-    model = nsr.NeRFModel(cfg).cuda().train()
+    model = refmirror.NeRFModel(cfg).cuda().train()
     data = SyntheticBlender(n_images=8, w=100, h=100, device="cuda", seed=0)
     tr = Trainer(model, data, cfg, fused=True)
     first = [float(tr.train_step()["loss"]) for _ in range(5)]
@@ -110,6 +112,7 @@ def test_fused_trainer_reduces_loss():
 def test_pipelined_marching_matches_in_order_marching():
     """side-stream marching of step k+1 under step k must not change the computation (same RNG order by design)"""
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender
     from nsr.trainer import Trainer
     data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
@@ -117,7 +120,7 @@ def test_pipelined_marching_matches_in_order_marching():
     for pipeline in (False, True):
         torch.manual_seed(0)
         cfg = nsr.configs.get("nerf-blender")
-        model = nsr.NeRFModel(cfg).cuda().train()
+        model = refmirror.NeRFModel(cfg).cuda().train()
         tr = Trainer(model, data, cfg, fused=True, seed=7)
         tr.pipeline_march = pipeline
         out = [tr.train_step() for _ in range(40)]
@@ -132,11 +135,12 @@ def test_pipelined_marching_matches_in_order_marching():
 def test_prepare_train_rays_matches_separate_ops():
     """the one-launch ray preparation == pixel gather + get_rays + slab test + jitter done with separate ops"""
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender, get_rays
     from nsr.fused import prepare_train_rays
     from nsr_hip import ops
     data = SyntheticBlender(n_images=3, w=64, h=48, device="cuda", seed=0)
-    model = nsr.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
+    model = refmirror.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
     gen = torch.Generator(device="cuda").manual_seed(5)
     rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(data, 1000, gen, model)
     gen.manual_seed(5)
@@ -155,11 +159,12 @@ def test_prepare_train_rays_matches_separate_ops():
 def test_dead_ray_slots_do_not_change_the_step():
     """a batch padded with dead slots (n_active < slots) == the same live rays alone: samples, colours, loss"""
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender
     from nsr.fused import FusedNeRFStep, prepare_train_rays
     torch.manual_seed(0)
     data = SyntheticBlender(n_images=4, w=64, h=64, device="cuda", seed=0)
-    model = nsr.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
+    model = refmirror.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
     model.update_step(0, 0)  # fills the occupancy grid
     fused = FusedNeRFStep(model)
     gen = torch.Generator(device="cuda").manual_seed(3)
@@ -201,12 +206,13 @@ def test_device_ray_count_matches_python_arithmetic():
 
 def test_trainer_device_ray_count_tracks_host_mirror():
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender
     from nsr.trainer import Trainer
     torch.manual_seed(0)
     cfg = dict(nsr.configs.get("nerf-blender"))
     cfg["train_num_rays"], cfg["max_train_num_rays"] = 256, 2048  # the controller has to move
-    model = nsr.NeRFModel(cfg).cuda().train()
+    model = refmirror.NeRFModel(cfg).cuda().train()
     data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
     tr = Trainer(model, data, cfg, fused=True, seed=3)
     seen = set()
@@ -221,6 +227,7 @@ def test_trainer_device_ray_count_tracks_host_mirror():
 def test_async_steps_match_synchronous_steps():
     """device-side counts (no host sync in the step) == the step that reads its counts back, same seeds"""
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender
     from nsr.trainer import Trainer
     data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
@@ -229,7 +236,7 @@ def test_async_steps_match_synchronous_steps():
     out = {}
     for mode in (False, True):
         torch.manual_seed(0)
-        model = nsr.NeRFModel(cfg).cuda().train()
+        model = refmirror.NeRFModel(cfg).cuda().train()
         tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=mode)
         steps, losses = [], []
         for _ in range(30):
@@ -249,13 +256,14 @@ def test_async_steps_match_synchronous_steps():
 
 def test_async_capacity_overflow_is_reported_and_recovers():
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender
     from nsr.trainer import Trainer
     data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
     cfg = dict(nsr.configs.get("nerf-blender"))
     cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
     torch.manual_seed(0)
-    model = nsr.NeRFModel(cfg).cuda().train()
+    model = refmirror.NeRFModel(cfg).cuda().train()
     tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
     a = tr._async_state()
     a["m_cap"], a["s_cap"] = 16384, 16384  # far too small: samples get dropped, the packing kernels count it
@@ -274,6 +282,7 @@ def test_async_capacity_overflow_is_reported_and_recovers():
 def test_captured_graph_steps_match_eager_asynchronous_steps():
     """Trainer.use_graphs: the same queued launches replayed from captured HIP graphs"""
     import nsr
+    import refmirror
     from nsr.scene import SyntheticBlender
     from nsr.trainer import Trainer
     data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
@@ -282,7 +291,7 @@ def test_captured_graph_steps_match_eager_asynchronous_steps():
     out = {}
     for graphs in (False, True):
         torch.manual_seed(0)
-        model = nsr.NeRFModel(cfg).cuda().train()
+        model = refmirror.NeRFModel(cfg).cuda().train()
         tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
         tr.use_graphs = graphs
         losses = [float(tr.train_step()["loss"]) for _ in range(40)]
@@ -315,9 +324,10 @@ def test_device_adam_schedule_matches_host_schedule():
 
 def _occupancy_fixture(frac_occupied):
     import nsr
+    import refmirror
     from nsr.fused import FusedNeRFStep
     torch.manual_seed(0)
-    model = nsr.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
+    model = refmirror.NeRFModel(nsr.configs.get("nerf-blender")).cuda().train()
     grid = model.occupancy_grid
     g = torch.Generator(device="cuda").manual_seed(1)
     grid.occs.copy_(torch.rand(grid.num_cells, device="cuda", generator=g) * 0.02)

@@ -19,11 +19,12 @@ def _cos(a, b):
 
 def test_nerf_model_matches_reference_fixture():
     import nsr
+    import refmirror
     fx = load("nerf_forward.npz")
     cfg = nsr.configs.get("nerf-blender")
     cfg["geometry"]["xyz_encoding_config"].update({k: v for k, v in SMALL_GRID.items() if k != "otype"})
     cfg["num_samples_per_ray"] = 256
-    m = nsr.NeRFModel(cfg).cuda().train()
+    m = refmirror.NeRFModel(cfg).cuda().train()
     sd = {k[len("param/"):]: v for k, v in fx.items() if k.startswith("param/")}
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all("occupancy_grid" in k for k in missing), (missing, unexpected)
@@ -55,11 +56,12 @@ def test_nerf_model_matches_reference_fixture():
 
 def test_neus_model_matches_reference_fixture():
     import nsr
+    import refmirror
     fx = load("neus_forward.npz")
     cfg = nsr.configs.get("neus-blender")
     cfg["geometry"]["xyz_encoding_config"].update({k: v for k, v in SMALL_GRID.items() if k != "otype"})
     cfg["num_samples_per_ray"] = 256
-    m = nsr.NeuSModel(cfg).cuda().train()
+    m = refmirror.NeuSModel(cfg).cuda().train()
     sd = {k[len("param/"):]: v for k, v in fx.items() if k.startswith("param/")}
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all("occupancy_grid" in k for k in missing), (missing, unexpected)
@@ -92,12 +94,13 @@ def test_neus_background_model_matches_reference_fixture():
     cone-angle marching through the UN_BOUNDED_SPHERE grid from the foreground box's exit, VanillaMLP density/colour heads)
     and the full composite of models/neus.py:259-287, against the reference's own run of it"""
     import nsr
+    import refmirror
     fx = load("neus_bg_forward.npz")
     cfg = nsr.configs.get("neus-dtu")
     for key in ("geometry", "geometry_bg"):
         cfg[key]["xyz_encoding_config"].update({k: v for k, v in SMALL_GRID.items() if k != "otype"})
     cfg["num_samples_per_ray"] = 256
-    m = nsr.NeuSModel(cfg).cuda().train()
+    m = refmirror.NeuSModel(cfg).cuda().train()
     sd = {k[len("param/"):]: v for k, v in fx.items() if k.startswith("param/")}
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all("occupancy_grid" in k for k in missing), (missing, unexpected)

@@ -129,3 +129,23 @@ def test_grid_query_and_pack_and_compact():
     assert torch.equal(a.cpu(), ri[mask]) and torch.equal(b.cpu(), t0[mask]) and torch.equal(c.cpu(), t1[mask])
     a, b, c = ops.compact_samples(torch.zeros(10000, dtype=torch.bool).cuda(), ri.cuda(), t0.cuda(), t1.cuda())
     assert a.numel() == 0
+
+
+def test_march_scratch_overflow_falls_back_to_two_pass():
+    """nerfacc's public ``ray_marching`` accepts UN-normalised directions: with |d| = 0.3 a ray emits up to 3.3x the
+    samples the single-pass scratch row was sized for (diag/step + 3 assumes unit directions).  The counts stay exact,
+    the write pass must notice and re-march: still bit-exact against the oracle"""
+    from oracle import nerfacc_ref as N
+    from nsr_hip import ops
+    o, d, roi, binary = _scene(600, seed=5)
+    binary[:] = True
+    d = d * 0.3
+    step = 1.732 * 2 * 1.5 / 1024
+    t_min, t_max = N.ray_aabb_intersect(o, d, roi)
+    packed_ref, ri_ref, t0_ref, t1_ref = N.march_rays_packed(o, d, t_min, t_max, roi, binary, N.ContractionType.AABB,
+                                                             step, 0.0)
+    assert int(packed_ref[:, 1].max()) > 1027  # really beyond the scratch capacity
+    packed, ri, t0, t1 = ops.ray_march(o.cuda(), d.cuda(), t_min.cuda(), t_max.cuda(), roi.cuda(), binary.cuda(), 0,
+                                       step, 0.0, roi_host=roi.tolist())
+    assert torch.equal(packed.cpu(), packed_ref) and torch.equal(ri.cpu(), ri_ref)
+    assert torch.equal(t0.cpu(), t0_ref) and torch.equal(t1.cpu(), t1_ref)

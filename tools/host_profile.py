@@ -7,7 +7,7 @@ from nsr.scene import SyntheticBlender
 from nsr.trainer import Trainer
 torch.manual_seed(42)
 cfg = nsr.configs.get("nerf-blender")
-model = nsr.NeRFModel(cfg).cuda().train()
+model = nsr.build(cfg).cuda().train()
 data = SyntheticBlender(n_images=100, w=800, h=800, device="cuda", seed=0)
 tr = Trainer(model, data, cfg, seed=42, async_mode=True)
 for _ in range(300): tr.train_step()

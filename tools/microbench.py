@@ -88,7 +88,7 @@ if which == "gridreal":
     from nsr.fused import prepare_train_rays
     torch.manual_seed(42)
     cfg = nsr.configs.get("nerf-blender")
-    model = nsr.NeRFModel(cfg).cuda().train()
+    model = nsr.build(cfg).cuda().train()
     data = SyntheticBlender(n_images=100, w=800, h=800, device="cuda", seed=0)
     tr = Trainer(model, data, cfg, seed=42)
     for _ in range(300): tr.train_step()

@@ -20,7 +20,7 @@ args = ap.parse_args()
 torch.manual_seed(42)
 dev = "cuda"
 cfg = nsr.configs.get("nerf-blender")
-model = nsr.NeRFModel(cfg).to(dev).train()
+model = nsr.build(cfg).to(dev).train()
 train = SyntheticBlender(n_images=100, w=args.res, h=args.res, device=dev, seed=0)
 test = SyntheticBlender(n_images=args.test_views, w=args.res, h=args.res, device=dev, seed=12345)  # unseen cameras
 tr = Trainer(model, train, cfg, seed=42, async_mode=True)
