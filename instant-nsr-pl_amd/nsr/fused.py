@@ -257,25 +257,71 @@ class FusedNeRFStep:
             return res
 
     # ---- fully asynchronous step: every sample count stays on the device ------------------------------------
-    def async_ray_set(self, slots, dataset_like_device):
-        """buffers one marching pass writes (double-buffered by the trainer: the pass of step k+1 runs on a side
-        stream while step k still reads its own set)"""
-        dev = dataset_like_device
+    def async_ray_sets(self, k_sets, slots, dev):
+        """``k_sets`` ray sets (the buffers one marching pass writes) whose marcher-facing arrays are CONTIGUOUS across
+        sets -- ``ro/rd [K][slots][3]``, ``t_min/t_max/counts [K][slots]``, scratch rows ``[K][slots][cap]`` -- so that any
+        run of consecutive sets is marched by ONE launch over ``n_sets * slots`` rays (``march_async_many``): the grid only
+        changes every 16 steps, nothing forces one marching launch per step"""
         grid = self.model.occupancy_grid
         cap = int(lib.nsr_ray_march_capacity((ctypes.c_float * 6)(*[float(v) for v in grid._roi_host]),
                                              float(self.model.render_step_size)))
-        rs = dict(slots=slots, cap=cap)
-        rs["buf"] = torch.empty(slots * 18, dtype=F32, device=dev)  # rays(6) o(3) d(3) rgb(3) fg(1) tmin(1) tmax(1)
-        b, n = rs["buf"], slots
-        rs["rays"], rs["ro"], rs["rd"] = b[:6 * n].view(n, 6), b[6 * n:9 * n].view(n, 3), b[9 * n:12 * n].view(n, 3)
-        rs["rgb"], rs["fg"] = b[12 * n:15 * n].view(n, 3), b[15 * n:16 * n]
-        rs["t_min"], rs["t_max"] = b[16 * n:17 * n], b[17 * n:18 * n]
-        rs["u"] = torch.empty((5, max(slots, 3)), dtype=F32, device=dev)
-        rs["counts"] = torch.empty(slots, dtype=torch.int32, device=dev)
-        rs["packed"] = torch.empty((slots, 2), dtype=torch.int32, device=dev)
-        rs["total"] = torch.zeros(1, dtype=torch.int32, device=dev)
-        rs["scratch"] = torch.empty(slots * cap * 2, dtype=F32, device=dev)
-        return rs
+        K, n = int(k_sets), int(slots)
+        big = dict(ro=torch.empty((K, n, 3), dtype=F32, device=dev), rd=torch.empty((K, n, 3), dtype=F32, device=dev),
+                   t_min=torch.empty((K, n), dtype=F32, device=dev), t_max=torch.empty((K, n), dtype=F32, device=dev),
+                   counts=torch.empty((K, n), dtype=torch.int32, device=dev),
+                   scratch=torch.empty((K, n * cap * 2), dtype=F32, device=dev))
+        sets = []
+        for k in range(K):
+            rs = dict(slots=n, cap=cap, index=k, big=big)
+            rs["buf"] = torch.empty(n * 10, dtype=F32, device=dev)  # rays(6) rgb(3) fg(1)
+            b = rs["buf"]
+            rs["rays"], rs["rgb"], rs["fg"] = b[:6 * n].view(n, 6), b[6 * n:9 * n].view(n, 3), b[9 * n:10 * n]
+            rs["ro"], rs["rd"], rs["t_min"], rs["t_max"] = big["ro"][k], big["rd"][k], big["t_min"][k], big["t_max"][k]
+            rs["counts"], rs["scratch"] = big["counts"][k], big["scratch"][k]
+            rs["u"] = torch.empty((5, max(n, 3)), dtype=F32, device=dev)
+            rs["packed"] = torch.empty((n, 2), dtype=torch.int32, device=dev)
+            rs["total"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            sets.append(rs)
+        return sets
+
+    def async_ray_set(self, slots, dataset_like_device):
+        return self.async_ray_sets(1, slots, dataset_like_device)[0]
+
+    def prepare_rays_async(self, rs, dataset, generator, n_active, background="random"):
+        """pixel choice -> rays -> slab test -> jitter of ONE ray set, one launch on the current stream"""
+        m = self.model
+        slots = rs["slots"]
+        rs["u"].uniform_(generator=generator)
+        rs["bg"] = rs["u"][4, :3] if background == "random" else torch.ones(3, device=rs["u"].device)
+        jitter = float(m.render_step_size) if m.randomized else 0.0
+        check(lib.nsr_prepare_train_rays(ptr(dataset.all_images), ptr(dataset.all_fg_masks), ptr(dataset.directions),
+                                         ptr(dataset.all_c2w), ptr(rs["u"]), ptr(rs["bg"]),
+                                         dataset.all_images.shape[0], dataset.h, dataset.w, int(dataset.apply_mask),
+                                         ptr(m.scene_aabb), jitter, ptr(rs["rays"]), ptr(rs["ro"]), ptr(rs["rd"]),
+                                         ptr(rs["rgb"]), ptr(rs["fg"]), ptr(rs["t_min"]), ptr(rs["t_max"]), slots,
+                                         ptr(n_active), stream_ptr()), "nsr_prepare_train_rays")
+
+    def march_async_many(self, sets, dataset, generator, background="random", bricks=None):
+        """ray preparation of every set in ``sets`` (consecutive sets of one ``async_ray_sets`` allocation) and ONE marching
+        launch over all their rays, on the current stream; no host sync, no packing (``pack_async`` per set, later)"""
+        m, grid = self.model, self.model.occupancy_grid
+        k0, n_sets, slots = sets[0]["index"], len(sets), sets[0]["slots"]
+        assert [rs["index"] for rs in sets] == list(range(k0, k0 + n_sets)), "sets must be consecutive"
+        for rs in sets:
+            self.prepare_rays_async(rs, dataset, generator, None, background)
+        if bricks is None:
+            bricks = _ops.grid_bricks(grid.binary)
+        if bricks is None:
+            raise NotImplementedError("the asynchronous step needs a brick-able occupancy grid (resolution % 16 == 0)")
+        rx, ry, rz = (int(v) for v in grid.binary.shape)
+        big = sets[0]["big"]
+        sl = slice(k0, k0 + n_sets)
+        with _ops.timed("ray_march_count", n_sets * slots):
+            check(lib.nsr_ray_march_bricks_count(ptr(big["ro"][sl]), ptr(big["rd"][sl]), ptr(big["t_min"][sl]),
+                                                 ptr(big["t_max"][sl]), ptr(grid.roi_aabb), ptr(bricks), rx, ry, rz,
+                                                 ContractionType.AABB.value, float(m.render_step_size), 0.0,
+                                                 ptr(big["counts"][sl]), ptr(big["scratch"][sl]), sets[0]["cap"],
+                                                 n_sets * slots, stream_ptr()), "nsr_ray_march_bricks_count")
 
     def march_async(self, rs, dataset, generator, n_active, m_cap, stats, background="random", bricks=None,
                     pack_masks=False):
@@ -284,21 +330,13 @@ class FusedNeRFStep:
         ``bricks``: the packed occupancy grid to march through (default: pack / look up the model's current grid)"""
         m, grid = self.model, self.model.occupancy_grid
         slots = rs["slots"]
-        rs["u"].uniform_(generator=generator)
-        rs["bg"] = rs["u"][4, :3] if background == "random" else torch.ones(3, device=rs["u"].device)
-        jitter = float(m.render_step_size) if m.randomized else 0.0
+        self.prepare_rays_async(rs, dataset, generator, n_active, background)
         if bricks is None:
             bricks = _ops.grid_bricks(grid.binary)
         if bricks is None:
             raise NotImplementedError("the asynchronous step needs a brick-able occupancy grid (resolution % 16 == 0)")
         rx, ry, rz = (int(v) for v in grid.binary.shape)
         s = stream_ptr()
-        check(lib.nsr_prepare_train_rays(ptr(dataset.all_images), ptr(dataset.all_fg_masks), ptr(dataset.directions),
-                                         ptr(dataset.all_c2w), ptr(rs["u"]), ptr(rs["bg"]),
-                                         dataset.all_images.shape[0], dataset.h, dataset.w, int(dataset.apply_mask),
-                                         ptr(m.scene_aabb), jitter, ptr(rs["rays"]), ptr(rs["ro"]), ptr(rs["rd"]),
-                                         ptr(rs["rgb"]), ptr(rs["fg"]), ptr(rs["t_min"]), ptr(rs["t_max"]), slots,
-                                         ptr(n_active), s), "nsr_prepare_train_rays")
         with _ops.timed("ray_march_count", slots):
             check(lib.nsr_ray_march_bricks_count(ptr(rs["ro"]), ptr(rs["rd"]), ptr(rs["t_min"]), ptr(rs["t_max"]),
                                                  ptr(grid.roi_aabb), ptr(bricks), rx, ry, rz,

@@ -273,7 +273,7 @@ class Trainer:
         a["s_cap"] = max(1 << 18, (3 * self.train_num_samples) // 2)
         a["truncated"] = 0
         a["graphs"], a["eager_seen"], a["total_kept"] = {}, set(), None
-        a["sets3"] = None if self.use_graphs else [self.fused.async_ray_set(slots, dev) for _ in range(3)]
+        a["sets3"], a["window"] = None, 16  # ring of ray sets: one occupancy window (allocated at the first step)
         a["events"], a["marched_upto"], a["packed_upto"], a["march_stream"] = {}, -1, -1, {}
         g = self.model.occupancy_grid.binary
         a["bricks"] = torch.empty(int(_lib.nsr_grid_bricks_words64(*[int(v) for v in g.shape])), dtype=torch.int64,
@@ -313,14 +313,15 @@ class Trainer:
         return self._train_step_async_graphable() if self.use_graphs else self._train_step_async_ahead()
 
     def _train_step_async_ahead(self):
-        """The asynchronous step with the marching passes running AHEAD of the ray count.
+        """The asynchronous step with the marching passes batched over the occupancy WINDOW.
 
-        The marching pass (~0.4 ms of latency-bound work on 3 % of the chip) needs rays and occupancy bricks only; what
-        needs the dynamic ray count of the previous step is merely which slots count -- applied by the tiny packing
-        kernel (dead slots keep nothing).  So the side stream marches ALL ``max_train_num_rays`` slots of steps t+1 and
-        t+2 while step t runs, the only work between step t's pruning pass and step t+1's is ``pack(t+1)``, and the
-        marching pass leaves the critical chain entirely (three ray sets rotate).  Steps that refresh the occupancy
-        grid (every 16th) are a pipeline boundary: their rays are marched in order, after the refresh."""
+        The marching pass (~0.45 ms of latency-bound work: one dependent chain per ray) needs rays and occupancy bricks
+        only, and the bricks change every 16th step.  So right after a refresh (and at the first step) the rays of the
+        whole window -- up to 15 future steps, ``max_train_num_rays`` slots each -- are prepared and marched by ONE launch
+        on the side stream (1,920 wavefronts instead of 15 launches of 128), while the window's first step marches its
+        own set in order.  What needs the dynamic ray count of the previous step is merely which slots count; that is
+        applied by the tiny packing kernel (dead slots keep nothing) queued behind the previous pruning pass.  16 ray
+        sets rotate (set u % 16 was last read by step u - 16)."""
         model, fused, cfg = self.model, self.fused, self.config
         a = self._async_state()
         dynamic = bool(cfg["dynamic_ray_sampling"])
@@ -344,42 +345,60 @@ class Trainer:
         if a.get("bricks_event") is None or (cfg["grid_prune"] and t % 16 == 0):
             a["bricks_event"] = torch.cuda.Event()
             a["bricks_event"].record(main)  # marching passes queued from now on read the re-packed bricks
-        if a["sets3"] is None:  # use_graphs was switched off after the first step
-            a["sets3"] = [self.fused.async_ray_set(a["slots"], self.device) for _ in range(3)]
+        W = a["window"]
+        if a["sets3"] is None:  # first asynchronous step (or use_graphs was switched off)
+            a["sets3"] = self.fused.async_ray_sets(W, a["slots"], self.device)
             a["marched_upto"] = a["packed_upto"] = t - 1
         sets, ev = a["sets3"], a["events"]
         stats_m, stats_s = a["stats"][0:8], a["stats"][8:16]
         refresh = lambda u: bool(cfg["grid_prune"]) and u % 16 == 0  # step u marches through a grid refreshed at its start
 
-        def queue_march(u, stream):
+        def queue_march(u0, u1, stream):
+            """steps u0 .. u1-1 (consecutive ring slots) in one launch"""
             with torch.cuda.stream(stream):
-                done = ev.get(("step", u - 3))
-                if done is not None:
-                    stream.wait_event(done)  # ray set u % 3 was last read by step u - 3
+                done = a.get("last_step_event")
+                if done is not None and stream is not main:
+                    stream.wait_event(done)  # ring slots u % W were last read by steps u - W <= the last queued step
                 stream.wait_event(a["bricks_event"])
-                fused.march_async(sets[u % 3], self.dataset, self.gen, None, None, None, cfg["background_color"],
-                                  bricks=a["bricks"])
-            a["marched_upto"], a["march_stream"][u] = u, stream
+                fused.march_async_many([sets[u % W] for u in range(u0, u1)], self.dataset, self.gen,
+                                       cfg["background_color"], bricks=a["bricks"])
+                e = torch.cuda.Event()
+                e.record(stream)
+            for u in range(u0, u1):
+                ev[("march", u)] = e
+            a["marched_upto"] = u1 - 1
 
         def queue_pack(u, stream):
             with torch.cuda.stream(stream):
                 pruned = ev.get(("prune", u - 1))
                 if pruned is not None:
                     stream.wait_event(pruned)  # the ray count of step u is final behind step u - 1's pruning pass
-                fused.pack_async(sets[u % 3], a["n_rays"], a["m_cap"], stats_m)
+                marched = ev.get(("march", u))
+                if marched is not None:
+                    stream.wait_event(marched)
+                fused.pack_async(sets[u % W], a["n_rays"], a["m_cap"], stats_m)
                 e = torch.cuda.Event()
                 e.record(stream)
                 ev[("pack", u)] = e
             a["packed_upto"] = u
 
-        if a["marched_upto"] < t:     # first step, or the step right after a grid refresh: in order
+        def window_end(u):  # first step after u that marches through a NEW grid (exclusive end of u's window)
+            return (u // 16 + 1) * 16 if cfg["grid_prune"] else u + W
+
+        if a["marched_upto"] < t:     # first step, or the step right after a grid refresh: its own set in order ...
             with _ops.timed("phase:sample_rays"):
-                queue_march(t, main)
+                queue_march(t, t + 1, main)
+            if self.pipeline_march:   # ... and the rest of the window in ONE launch on the side stream
+                u1 = min(window_end(t), t + W)
+                u0 = t + 1
+                while u0 < u1:        # a run of ring slots must not wrap
+                    stop = min(u1, u0 + (W - u0 % W))
+                    queue_march(u0, stop, side)
+                    u0 = stop
         if a["packed_upto"] < t:
-            queue_pack(t, a["march_stream"].get(t, main))
+            queue_pack(t, main)
         main.wait_event(ev[("pack", t)])
-        a["march_stream"].pop(t - 1, None)
-        rs = sets[t % 3]
+        rs = sets[t % W]
         model.background_color = rs["bg"]
 
         def after_prune_queued(total):
@@ -396,16 +415,8 @@ class Trainer:
                 e2 = torch.cuda.Event()
                 e2.record(stream)
             ev[("prune", t)] = e2  # "the ray count of step t + 1 is final"
-            if not self.pipeline_march:
-                return
-            if a["marched_upto"] >= t + 1 and a["packed_upto"] < t + 1:
+            if self.pipeline_march and a["marched_upto"] >= t + 1 and a["packed_upto"] < t + 1:
                 queue_pack(t + 1, side)           # the only work between this pruning pass and the next one
-            for u in range(a["marched_upto"] + 1, t + 3):
-                if refresh(u):
-                    break                         # marched in order, after the refresh
-                queue_march(u, side)
-                if u == t + 1 and a["packed_upto"] < t + 1:
-                    queue_pack(t + 1, side)       # ahead of march(t + 2) in the side stream's order
 
         res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued)
         a["total_kept"] = res["num_samples"]
@@ -413,10 +424,9 @@ class Trainer:
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
             self.opt.step_device()
-        e = torch.cuda.Event()
-        e.record(main)
-        ev[("step", t)] = e
-        for key in [k for k in ev if k[1] < t - 4]:
+        a["last_step_event"] = torch.cuda.Event()
+        a["last_step_event"].record(main)
+        for key in [k for k in ev if k[1] < t - 2]:
             del ev[key]
         self.global_step += 1
         self._async_capacities(a)

@@ -43,8 +43,9 @@ def test_adamw_matches_torch(device_schedule):
             assert float(grad.abs().max()) == 0.0
         assert torch.allclose(p, p_ref.detach(), rtol=2e-5, atol=2e-7), (step, float((p - p_ref.detach()).abs().max()))
         st = opt.state[p_ref]
-        assert torch.allclose(m, st["exp_avg"], rtol=1e-5, atol=1e-12)
-        assert torch.allclose(v, st["exp_avg_sq"], rtol=1e-5, atol=1e-20)
+        # torch forms the moments with lerp / addcmul (different rounding order): compare relative to their scale
+        assert torch.allclose(m, st["exp_avg"], rtol=1e-5, atol=1e-6 * float(m.abs().max()))
+        assert torch.allclose(v, st["exp_avg_sq"], rtol=1e-5, atol=1e-6 * float(v.abs().max()))
         assert torch.equal(shadow, p.half())  # the fp16 image the kernels read is exactly the rounded parameter
 
 
@@ -93,9 +94,15 @@ def test_amp_gradscaler_protocol_matches_fp32_run():
     MLP backward re-scales by its own loss_scale (128) and rounds to fp16 like tcnn, so the first scales may overflow:
     the scaler must SEE that (inf/NaN in .grad -> step skipped, scale halved) and, once a step goes through, the
     unscaled gradients must equal the plain fp32-loss run."""
+    import tinycudann as tcnn
     m, rays, gt = _nerf_model()
+    mods = [x for x in m.modules() if isinstance(x, tcnn.Module)]
+    for x in mods:  # reference gradients: the un-scaled loss with fp32 hand-over between the modules (an un-scaled fp16
+        x.dtype = torch.float32  # hand-over underflows for low-weight samples -- the reason Lightning scales the loss)
     _loss(m, rays, gt).backward()
     ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None and p.numel()}
+    for x in mods:
+        x.dtype = torch.float16  # what tcnn hands out, and what the AMP run below uses
     opt = torch.optim.AdamW(m.parameters(), lr=0.0)  # lr 0: the parameters stay put, only the protocol runs
     scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
     went_through, skipped = 0, 0
