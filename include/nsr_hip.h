@@ -495,6 +495,78 @@ int nsr_scale_from_half(const nsr_half *src, float *dst, uint64_t n, float scale
 int nsr_adam_tick(int32_t *step, float *hyper, double base_lr, double beta1, double beta2, double gamma,
                   int32_t milestone0, int32_t milestone1, int32_t milestone2, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp32 "VanillaMLP" (reference models/network_utils.py:95-139: nn.Linear stack with biases, 64 neurons, ReLU or
+ * Softplus(beta=100); weight norm folded by the caller) on f32 MFMA: the SDF network of models/geometry.py:146-150 and the
+ * fp32 texture / background heads of configs/neus-dtu.yaml, configs/neuralangelo-dtu-wmask.yaml (csrc/vmlp.hip).
+ * Parameter blob (fp32): W0[64][in_pad] b0[64] | (W1[64][64] b1[64]) | Wl[16][64] bl[16]; rows >= n_out of Wl / bl zero.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct NsrVmlpDesc {
+    uint32_t n_in;       /* logical inputs (<= in_pad; the padding columns of W0 must be zero) */
+    uint32_t in_pad;     /* 24, 32, 36 or 40 */
+    uint32_t n_out;      /* <= 16 */
+    uint32_t n_hidden;   /* 1 or 2 hidden layers of width 64 */
+    uint32_t activation; /* 0 = ReLU, 1 = Softplus(beta=100, threshold=20) */
+} NsrVmlpDesc;
+uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *desc);
+uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *desc, uint32_t n);
+/* x: fp32 rows [n][x_stride]; with enc != NULL the input is [2 x - 1 (3 columns of x) | enc (fp16 rows, n_in - 3 columns)]
+ * (CompositeEncoding with include_xyz, models/network_utils.py:75-76).  Rows < n_full write all 16 output columns to
+ * out[n_full][16], rows >= n_full only column 0 to out_col0[n - n_full] (finite-difference taps).  g_in (may be NULL,
+ * one hidden layer): [n][in_pad] = d out[0] / d input (analytic normal, models/geometry.py:176-180). */
+int nsr_vmlp_forward(const NsrVmlpDesc *desc, const float *blob, const float *x, uint32_t x_stride, const nsr_half *enc,
+                     uint32_t enc_stride, float *out, float *out_col0, float *g_in, uint32_t n, uint32_t n_full,
+                     const int32_t *n_dev, void *stream);
+/* d_out [n_full][16] / d_out_col0 [n - n_full]: gradients w.r.t. the outputs written by the forward; p_in (may be NULL):
+ * [n][in_pad] = dL/d g_in (second-order terms of the analytic normal).  d_x (may be NULL): gradient w.r.t. input columns
+ * [dx_first, dx_first + dx_count) (dx_count 0 = all), row-major [n][dx_stride] or, with dx_level_major_features = F,
+ * level-major [dx_count/F][n][F] (what the owner-computes hash-grid backward reads).  grad_blob: blob layout, overwritten
+ * (accumulate = 0) or added to.  partials: nsr_vmlp_backward_workspace_floats() floats. */
+int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, const float *x, uint32_t x_stride, const nsr_half *enc,
+                      uint32_t enc_stride, const float *d_out, const float *d_out_col0, const float *p_in, float *d_x,
+                      uint32_t dx_stride, uint32_t dx_first, uint32_t dx_count, uint32_t dx_level_major_features,
+                      float *grad_blob, int accumulate, float *partials, uint32_t n, uint32_t n_full,
+                      const int32_t *n_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused NeuS step glue (csrc/neus.hip): reference models/neus.py:205-287, models/geometry.py:158-210,
+ * models/neus.py:117-139, models/texture.py:23-30, loss terms of systems/neus.py:96-130.
+ * acc: float[16] loss sums {L1, MSE, valid rays, mask BCE, opaque BCE, eikonal, sparsity, |laplace|, d/d inv_s, rays}
+ * (zeroed by the caller before the forward pass).  loss_weights8: {lambda_rgb_l1, lambda_rgb_mse, lambda_mask,
+ * lambda_opaque, lambda_eikonal, lambda_sparsity, lambda_curvature, sparsity_scale}.
+ * ------------------------------------------------------------------------------------------------ */
+/* x7: [1 + 6*taps][n][3] unit coordinates: the sample itself, then (taps != 0) the +-eps taps of models/geometry.py:182-194 */
+int nsr_neus_points(const float *rays_o, const float *rays_d, const int64_t *ray_indices, const float *t_starts,
+                    const float *t_ends, float radius, float eps, int taps, float *x7, float *dirs, uint32_t n,
+                    const int32_t *n_dev, void *stream);
+/* analytic (tap_sdf == NULL): grad = (2 g_in[:, 0:3] + dx01) / 2r; finite differences: tap_sdf [6][n], laplace out.
+ * tex_in: [n][32] = [feature (n_feat) | SH4(dir) | normal | pad], fp16 (pad 1.0, fused colour MLP) or fp32 (pad 0) */
+int nsr_neus_shade_forward(const float *sdf_out, const float *g_in, uint32_t g_stride, const float *dx01,
+                           const float *tap_sdf, float eps, float radius, const float *dirs, const float *t_starts,
+                           const float *t_ends, const float *inv_s, float cos_anneal_ratio, uint32_t n_feat,
+                           float sparsity_scale, float *grad, float *normal, float *alpha, float *laplace, void *tex_in,
+                           int tex_is_f32, float *acc, uint32_t n, const int32_t *n_dev, void *stream);
+/* rgb_raw: [n][16] colour logits (fp16 or fp32), sigmoid (color_activation) applied here */
+int nsr_neus_composite_forward(const int32_t *packed_info, const float *alpha, const void *rgb_raw, int rgb_is_f32,
+                               const float *normal, const float *t_starts, const float *t_ends, const float *background,
+                               float *weights, float *trans, float *comp_rgb, float *opacity, float *depth,
+                               float *comp_normal, float *comp_rgb_full, uint32_t n_rays, void *stream);
+int nsr_neus_loss_rays(const float *comp_rgb_full, const float *opacity, const float *gt_rgb, const float *fg_mask,
+                       float *acc, uint32_t n_rays, const int32_t *n_active, void *stream);
+int nsr_neus_composite_backward(const int32_t *packed_info, const float *alpha, const void *rgb_raw, int rgb_is_f32,
+                                const float *weights, const float *trans, const float *background,
+                                const float *comp_rgb_full, const float *opacity, const float *gt_rgb,
+                                const float *fg_mask, const float *acc, const float *loss_weights8, float loss_scale,
+                                float *d_alpha, float *d_rgb_raw, uint32_t n_rays, const int32_t *n_active, void *stream);
+/* d_out [n][16]: gradient w.r.t. the SDF network output; analytic: gx [n][3] = dL/d(dx01) (seeds the hash grid's double
+ * backward) and p_in[:, 0:3] = dL/d g_in[:, 0:3]; finite differences: d_taps [6][n] */
+int nsr_neus_shade_backward(const float *sdf_out, const float *grad, const float *normal, const float *dirs,
+                            const float *t_starts, const float *t_ends, const float *inv_s, float cos_anneal_ratio,
+                            const float *laplace, float eps, float radius, const float *d_alpha, const float *d_tex_in,
+                            uint32_t n_feat, const float *loss_weights8, float loss_scale, float n_samples, float *d_out,
+                            float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
+                            const int32_t *n_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

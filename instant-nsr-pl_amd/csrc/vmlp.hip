@@ -1,0 +1,665 @@
+// fp32 "VanillaMLP" (reference models/network_utils.py:95-139: nn.Linear stack WITH biases, 64 neurons, ReLU or
+// Softplus(beta=100), optional weight norm folded by the caller) on gfx950 f32 MFMA -- the SDF network of the NeuS /
+// neuralangelo configs (35 -> 64 -> 13, models/geometry.py:146-150) and the fp32 texture / background heads of
+// configs/neus-dtu.yaml and configs/neuralangelo-dtu-wmask.yaml.  The reference runs these through cuBLAS GEMMs +
+// elementwise kernels with autograd (and torch.autograd.grad(create_graph=True) for the analytic normal); here one
+// wavefront streams 16-sample tiles through the whole net.
+//
+// Everything is computed TRANSPOSED with v_mfma_f32_16x16x4_f32 (exact fp32, 157 TFLOP/s = 2x the plain v_fma rate):
+//   Z^T[neuron][sample] = W[neuron][feature] . X^T[feature][sample]
+//   A operand: lane (c = lane&15, g = lane>>4) holds A[row c][k = g];  B: B[k = g][col c];  D reg r: D[4g + r][c].
+// In the D layout a lane holds neurons {16 b + 4 g + r} of ITS sample c.  The MFMA reduction index is a dummy, so the
+// next layer consumes D register r of block b as the B operand of "k-step (b, r)" and the weight fragment is loaded with
+// the matching column 16 b + 4 g + r (one float4 per (b)): activations never leave registers, no shuffles, no LDS.
+// The same trick runs the data gradient (W^T fragments).  The weight gradient needs the SAMPLE index on the k axis, i.e.
+// both operands transposed: the tile's dZ and inputs go through a wave-private LDS tile ([sample][column]) and are read
+// back in operand layout; dW accumulates in fp32 VGPRs over all tiles of the wave and is written once per wave as a
+// partial (summed by k_vmlp_reduce: deterministic, no float atomics).  Bias gradients are register sums in D layout,
+// reduced over the 16 sample lanes once at the end.
+//
+// SECOND (1 hidden layer, softplus): the analytic-normal protocol of models/geometry.py:177-180.  The forward kernel
+// also emits g = d out[0] / d input = W0^T (s * u)  (s = sigmoid(100 z), u = last-layer row 0); the backward kernel takes
+// P = dL/dg and adds the second-order terms  dW0 += (s*u) P^T,  du += s * (W0 P),  dz += 100 s (1-s) u (W0 P).
+//
+// Parameter blob (fp32): W0[64][in_pad] b0[64] | (W1[64][64] b1[64]) | Wl[16][64] bl[16]   (rows >= n_out of Wl/bl: 0).
+#include "nsr_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int W = 64;        // hidden width
+constexpr int LDT = 68;      // LDS tile row stride for 64-column tiles (floats)
+constexpr int LDX = 52;      // LDS tile row stride for input tiles (<= 48 columns)
+constexpr int LDO = 20;      // LDS tile row stride for the 16-column output-gradient tile
+
+__device__ __forceinline__ void lds_wave_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z)
+{
+    if (ACT == 0) return fmaxf(z, 0.f);
+    const float t = 100.f * z;  // torch.nn.Softplus(beta=100, threshold=20)
+    return t > 20.f ? z : log1pf(expf(t)) * 0.01f;
+}
+// derivative of the activation w.r.t. its pre-activation (softplus: sigmoid(100 z); torch's thresholded branch has slope 1)
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float z)
+{
+    if (ACT == 0) return z > 0.f ? 1.f : 0.f;
+    const float t = 100.f * z;
+    return t > 20.f ? 1.f : 1.f / (1.f + expf(-t));
+}
+
+struct Blob {
+    const float *W0, *b0, *W1, *b1, *Wl, *bl;
+};
+template <int KS, int NH>
+__device__ __forceinline__ Blob split_blob(const float *p)
+{
+    Blob b;
+    b.W0 = p; p += W * KS * 4;
+    b.b0 = p; p += W;
+    b.W1 = b.b1 = nullptr;
+    if (NH == 2) { b.W1 = p; p += W * W; b.b1 = p; p += W; }
+    b.Wl = p; p += 16 * W;
+    b.bl = p;
+    return b;
+}
+
+// input feature k of sample s.  SDF_IN: [2 x01 - 1 (3) | hash encoding (fp16, row-major)] (CompositeEncoding with
+// include_xyz, models/network_utils.py:75-76); otherwise fp32 rows
+template <bool SDF_IN>
+__device__ __forceinline__ float load_feature(const float *__restrict__ x, uint32_t x_stride, const __half *__restrict__ enc,
+                                              uint32_t enc_stride, uint32_t n_in, uint64_t s, uint32_t k)
+{
+    if (k >= n_in) return 0.f;
+    if (SDF_IN) {
+        if (k < 3) return x[s * x_stride + k] * 2.f - 1.f;
+        return __half2float(enc[s * enc_stride + (k - 3)]);
+    }
+    return x[s * x_stride + k];
+}
+
+// chained-layer weight fragment: rows mb*16 + c, columns ib*16 + 4g .. +3 of a row-major [rows][64] matrix
+__device__ __forceinline__ f32x4 load_chain(const float *__restrict__ M, int mb, int ib, int c, int g)
+{
+    return *reinterpret_cast<const f32x4 *>(M + (mb * 16 + c) * W + ib * 16 + 4 * g);
+}
+
+template <int KS, int NH, int ACT, bool SDF_IN, bool GRAD_IN>
+__global__ void __launch_bounds__(64)
+k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint32_t x_stride,
+               const __half *__restrict__ enc, uint32_t enc_stride, uint32_t n_in, uint32_t n_out,
+               float *__restrict__ out /* [n_full][16] */, float *__restrict__ out_col0 /* [n - n_full] */,
+               float *__restrict__ g_in /* [n][KS*4] (GRAD_IN) */, uint32_t n, uint32_t n_full,
+               const int32_t *__restrict__ n_dev)
+{
+    const uint32_t n_live = live_count(n, n_dev);
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const Blob B = split_blob<KS, NH>(blob);
+    constexpr int IN_PAD = KS * 4;
+    constexpr int NB0 = (IN_PAD + 15) / 16;
+    float wf0[4][KS];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + 4 * kk + g];
+    f32x4 b0f[4], b1f[4], blf, wlf[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        b0f[mb] = *reinterpret_cast<const f32x4 *>(B.b0 + mb * 16 + 4 * g);
+        if (NH == 2) b1f[mb] = *reinterpret_cast<const f32x4 *>(B.b1 + mb * 16 + 4 * g);
+        wlf[mb] = load_chain(B.Wl, 0, mb, c, g);
+    }
+    blf = *reinterpret_cast<const f32x4 *>(B.bl + 4 * g);
+    const uint32_t n_tiles = (n_live + 15) / 16;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t s = (uint64_t)tile * 16 + c;
+        const bool valid = s < n_live;
+        float xin[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g) : 0.f;
+        f32x4 z[4], a[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            z[mb] = b0f[mb];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) z[mb] = mfma4(wf0[mb][kk], xin[kk], z[mb]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[mb][r] = act_fwd<ACT>(z[mb][r]);
+        }
+        if (NH == 2) {
+            f32x4 z1[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                z1[mb] = b1f[mb];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    const f32x4 w = load_chain(B.W1, mb, ib, c, g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z1[mb] = mfma4(w[r], a[ib][r], z1[mb]);
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[mb][r] = act_fwd<ACT>(z1[mb][r]);
+        }
+        f32x4 o = blf;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = mfma4(wlf[ib][r], a[ib][r], o);
+        if (valid) {
+            if (s < n_full) {
+                *reinterpret_cast<f32x4 *>(out + s * 16 + 4 * g) = o;
+            } else if (g == 0) {
+                out_col0[s - n_full] = o[0];
+            }
+        }
+        if (GRAD_IN) {  // d out[0] / d input = W0^T (act'(z) * Wl[0][:])   (1 hidden layer)
+            f32x4 q[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(B.Wl + mb * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q[mb][r] = act_bwd<ACT>(z[mb][r]) * u[r];
+            }
+#pragma unroll
+            for (int fb = 0; fb < NB0; ++fb) {
+                f32x4 gh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = fb * 16 + c;
+                        const float wt = col < IN_PAD ? B.W0[(nb * 16 + 4 * g + r) * IN_PAD + col] : 0.f;
+                        gh = mfma4(wt, q[nb][r], gh);
+                    }
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = fb * 16 + 4 * g + r;
+                        if (col < IN_PAD) g_in[s * IN_PAD + col] = gh[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One wave per block: forward recompute + data gradient + weight gradient (+ second-order terms) of its tiles.
+template <int KS, int NH, int ACT, bool SDF_IN, bool SECOND>
+__global__ void __launch_bounds__(64)
+k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uint32_t x_stride,
+                const __half *__restrict__ enc, uint32_t enc_stride, uint32_t n_in,
+                const float *__restrict__ d_out /* [n_full][16] */, const float *__restrict__ d_out_col0,
+                const float *__restrict__ p_in /* [n][KS*4], SECOND */, float *__restrict__ d_x, uint32_t dx_stride,
+                uint32_t dx_first, uint32_t dx_count, uint32_t dx_lm_features, float *__restrict__ partials,
+                uint32_t blob_floats, uint32_t n, uint32_t n_full, const int32_t *__restrict__ n_dev)
+{
+    static_assert(!SECOND || NH == 1, "second-order terms: one hidden layer");
+    const uint32_t n_live = live_count(n, n_dev);
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const Blob B = split_blob<KS, NH>(blob);
+    constexpr int IN_PAD = KS * 4;
+    constexpr int NB0 = (IN_PAD + 15) / 16;
+    __shared__ __attribute__((aligned(16))) float T_a[16 * LDT];   // activations feeding a layer  [sample][neuron]
+    __shared__ __attribute__((aligned(16))) float T_d[16 * LDT];   // pre-activation gradients     [sample][neuron]
+    __shared__ __attribute__((aligned(16))) float T_x[16 * LDX];   // layer-0 inputs               [sample][feature]
+    __shared__ __attribute__((aligned(16))) float T_o[16 * LDO];   // output gradients             [sample][output]
+    for (int k = lane; k < 16 * LDX; k += 64) T_x[k] = 0.f;       // columns >= IN_PAD stay zero
+    float wf0[4][KS];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + 4 * kk + g];
+    f32x4 b0f[4], b1f[4], uf[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        b0f[mb] = *reinterpret_cast<const f32x4 *>(B.b0 + mb * 16 + 4 * g);
+        if (NH == 2) b1f[mb] = *reinterpret_cast<const f32x4 *>(B.b1 + mb * 16 + 4 * g);
+        uf[mb] = *reinterpret_cast<const f32x4 *>(B.Wl + mb * 16 + 4 * g);  // last-layer row 0 in D layout
+    }
+    // accumulators (D layout: rows 4g + r of the block, column c)
+    f32x4 accW0[4][NB0], accW1[NH == 2 ? 4 : 1][4], accWl[4], db0[4], db1[4], du[4];
+    float dbl = 0.f;  // lane (g,c): sum over its tiles of d_out[sample c][4kk + g] per kk -> kept per kk below
+    f32x4 dblv = {0.f, 0.f, 0.f, 0.f};  // dblv[kk] = sum of d_out[.][4kk + g] seen by this lane
+    (void)dbl;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < NB0; ++nb) accW0[mb][nb] = zero4;
+        accWl[mb] = zero4; db0[mb] = zero4; db1[mb] = zero4; du[mb] = zero4;
+    }
+    if constexpr (NH == 2) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) accW1[mb][nb] = zero4;
+    }
+    const uint32_t n_tiles = (n_live + 15) / 16;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t s = (uint64_t)tile * 16 + c;
+        const bool valid = s < n_live;
+        // two hidden layers: ~250 loop-invariant weight fragments would be hoisted into registers and spilled; re-load the
+        // (L1-resident, 37 KB) matrices per tile instead by hiding the pointers' loop invariance from the compiler
+        const float *W0t = B.W0, *W1t = B.W1, *Wlt = B.Wl;
+        if constexpr (NH == 2) {
+            asm volatile("" : "+s"(W0t), "+s"(W1t), "+s"(Wlt));
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = W0t[(mb * 16 + c) * IN_PAD + 4 * kk + g];
+        }
+        // ---- forward recompute ---------------------------------------------------------------------------------
+        float xin[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g) : 0.f;
+        f32x4 z0[4], a0[4], z1[4], a1[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            z0[mb] = b0f[mb];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) z0[mb] = mfma4(wf0[mb][kk], xin[kk], z0[mb]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a0[mb][r] = act_fwd<ACT>(z0[mb][r]);
+        }
+        if constexpr (NH == 2) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                z1[mb] = b1f[mb];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    const f32x4 w = load_chain(W1t, mb, ib, c, g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z1[mb] = mfma4(w[r], a0[ib][r], z1[mb]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a1[mb][r] = act_fwd<ACT>(z1[mb][r]);
+            }
+        }
+        // ---- output gradient in B layout: lane (g,c) holds d_out[sample c][4kk + g] -------------------------------
+        f32x4 dob = zero4;
+        if (valid) {
+            if (s < n_full) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) dob[kk] = d_out[s * 16 + 4 * kk + g];
+            } else if (g == 0) {
+                dob[0] = d_out_col0[s - n_full];
+            }
+        }
+        dblv += dob;
+        // dA_last^T = Wl^T . dOut^T   (A: Wl[4kk + g][fb*16 + c])
+        f32x4 dz_last[4];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            f32x4 acc = zero4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = mfma4(Wlt[(4 * kk + g) * W + fb * 16 + c], dob[kk], acc);
+            const f32x4 &zl = (NH == 2) ? z1[fb] : z0[fb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz_last[fb][r] = acc[r] * act_bwd<ACT>(zl[r]);
+        }
+        // ---- last-layer weight gradient: dWl[o][j] += sum_s dOut[o][s] a_last[j][s] ------------------------------
+        lds_wave_sync();  // previous tile's readers are done
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            *reinterpret_cast<f32x4 *>(&T_a[c * LDT + mb * 16 + 4 * g]) = (NH == 2) ? a1[mb] : a0[mb];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) T_o[c * LDO + 4 * kk + g] = dob[kk];
+        lds_wave_sync();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float ao = T_o[(4 * kk + g) * LDO + c];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) accWl[nb] = mfma4(ao, T_a[(4 * kk + g) * LDT + nb * 16 + c], accWl[nb]);
+        }
+        f32x4 dz0[4];
+        if constexpr (NH == 2) {
+            // dW1[i][j] += sum_s dz1[i][s] a0[j][s] ;  db1 ;  dA0^T = W1^T dz1^T ; dz0 = dA0 * act'(z0)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) db1[mb] += dz_last[mb];
+            lds_wave_sync();
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                *reinterpret_cast<f32x4 *>(&T_d[c * LDT + mb * 16 + 4 * g]) = dz_last[mb];
+                *reinterpret_cast<f32x4 *>(&T_a[c * LDT + mb * 16 + 4 * g]) = a0[mb];
+            }
+            lds_wave_sync();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float bj[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bj[nb] = T_a[(4 * kk + g) * LDT + nb * 16 + c];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const float ai = T_d[(4 * kk + g) * LDT + mb * 16 + c];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) accW1[mb][nb] = mfma4(ai, bj[nb], accW1[mb][nb]);
+                }
+            }
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc = mfma4(W1t[(nb * 16 + 4 * g + r) * W + fb * 16 + c], dz_last[nb][r], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz0[fb][r] = acc[r] * act_bwd<ACT>(z0[fb][r]);
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) dz0[mb] = dz_last[mb];
+        }
+        // ---- second-order terms of the analytic normal -----------------------------------------------------------
+        if (SECOND) {
+            float pb[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) pb[kk] = valid ? p_in[s * IN_PAD + 4 * kk + g] : 0.f;
+            f32x4 q[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x4 dq = zero4;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) dq = mfma4(wf0[mb][kk], pb[kk], dq);  // (W0 P)^T
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sg = act_bwd<ACT>(z0[mb][r]);
+                    q[mb][r] = sg * uf[mb][r];
+                    du[mb][r] += sg * dq[r];
+                    // d/dz of act'(z): softplus -> 100 s (1 - s) (0 on torch's linear branch); relu -> 0
+                    const float curv = (ACT == 1 && 100.f * z0[mb][r] <= 20.f) ? 100.f * sg * (1.f - sg) : 0.f;
+                    dz0[mb][r] += curv * uf[mb][r] * dq[r];
+                }
+            }
+            // dW0 += q P^T
+            lds_wave_sync();
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4 *>(&T_d[c * LDT + mb * 16 + 4 * g]) = q[mb];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) T_x[c * LDX + 4 * kk + g] = pb[kk];
+            lds_wave_sync();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float bj[NB0];
+#pragma unroll
+                for (int nb = 0; nb < NB0; ++nb) bj[nb] = T_x[(4 * kk + g) * LDX + nb * 16 + c];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const float ai = T_d[(4 * kk + g) * LDT + mb * 16 + c];
+#pragma unroll
+                    for (int nb = 0; nb < NB0; ++nb) accW0[mb][nb] = mfma4(ai, bj[nb], accW0[mb][nb]);
+                }
+            }
+        }
+        // ---- first-layer weight gradient: dW0[i][k] += sum_s dz0[i][s] x[k][s] ; db0 ------------------------------
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) db0[mb] += dz0[mb];
+        lds_wave_sync();
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4 *>(&T_d[c * LDT + mb * 16 + 4 * g]) = dz0[mb];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) T_x[c * LDX + 4 * kk + g] = xin[kk];
+        lds_wave_sync();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float bj[NB0];
+#pragma unroll
+            for (int nb = 0; nb < NB0; ++nb) bj[nb] = T_x[(4 * kk + g) * LDX + nb * 16 + c];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float ai = T_d[(4 * kk + g) * LDT + mb * 16 + c];
+#pragma unroll
+                for (int nb = 0; nb < NB0; ++nb) accW0[mb][nb] = mfma4(ai, bj[nb], accW0[mb][nb]);
+            }
+        }
+        // ---- input gradient dX^T = W0^T dz0^T ----------------------------------------------------------------------
+        if (d_x) {
+#pragma unroll
+            for (int fb = 0; fb < NB0; ++fb) {
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = fb * 16 + c;
+                        const float wt = col < IN_PAD ? W0t[(nb * 16 + 4 * g + r) * IN_PAD + col] : 0.f;
+                        acc = mfma4(wt, dz0[nb][r], acc);
+                    }
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t col = fb * 16 + 4 * g + r;  // input feature
+                        if (col < dx_first || col >= dx_first + dx_count) continue;
+                        const uint32_t k = col - dx_first;
+                        const uint64_t off = dx_lm_features
+                            ? ((uint64_t)(k / dx_lm_features) * n + s) * dx_lm_features + k % dx_lm_features
+                            : s * dx_stride + k;
+                        d_x[off] = acc[r];
+                    }
+                }
+            }
+        }
+    }
+    // ---- this wave's partial gradient, in blob layout ---------------------------------------------------------------
+    float *P = partials + (uint64_t)blockIdx.x * blob_floats;
+    float *pW0 = P, *pb0 = pW0 + W * IN_PAD;
+    float *pW1 = pb0 + W, *pb1 = pW1 + (NH == 2 ? W * W : 0);
+    float *pWl = (NH == 2) ? pb1 + W : pW1;
+    float *pbl = pWl + 16 * W;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB0; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = nb * 16 + c;
+                if (col < IN_PAD) pW0[(mb * 16 + 4 * g + r) * IN_PAD + col] = accW0[mb][nb][r];
+            }
+    if constexpr (NH == 2) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pW1[(mb * 16 + 4 * g + r) * W + nb * 16 + c] = accW1[mb][nb][r];
+    }
+    // bias / du sums: reduce the D-layout registers over the 16 sample lanes c (lanes differing in bits 0..3)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v0 = db0[mb][r], v1 = db1[mb][r], v2 = du[mb][r];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                v0 += __shfl_xor(v0, o, 64);
+                if (NH == 2) v1 += __shfl_xor(v1, o, 64);
+                if (SECOND) v2 += __shfl_xor(v2, o, 64);
+            }
+            db0[mb][r] = v0; db1[mb][r] = v1; du[mb][r] = v2;
+        }
+    if (c == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pb0[mb * 16 + 4 * g + r] = db0[mb][r];
+                if (NH == 2) pb1[mb * 16 + 4 * g + r] = db1[mb][r];
+            }
+    }
+    // dWl (rows o = 4g + r, columns nb*16 + c); the second-order du (held per neuron in D layout) joins row 0
+    if (SECOND) {
+        lds_wave_sync();
+        if (c == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T_a[mb * 16 + 4 * g + r] = du[mb][r];
+        }
+        lds_wave_sync();
+        if (g == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) accWl[nb][0] += T_a[nb * 16 + c];
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pWl[(4 * g + r) * W + nb * 16 + c] = accWl[nb][r];
+    // dbl[o]: lane (g,c) holds sums of d_out[.][4kk + g] over ITS sample column c; reduce over c
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        float v = dblv[kk];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (c == 0) pbl[4 * kk + g] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_vmlp_reduce(const float *__restrict__ partials, float *__restrict__ grad, uint32_t blob_floats, uint32_t n_blocks,
+              int accumulate)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= blob_floats) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    uint32_t b = 0;
+    for (; b + 4 <= n_blocks; b += 4) {
+        s0 += partials[(uint64_t)(b + 0) * blob_floats + k];
+        s1 += partials[(uint64_t)(b + 1) * blob_floats + k];
+        s2 += partials[(uint64_t)(b + 2) * blob_floats + k];
+        s3 += partials[(uint64_t)(b + 3) * blob_floats + k];
+    }
+    for (; b < n_blocks; ++b) s0 += partials[(uint64_t)b * blob_floats + k];
+    const float s = (s0 + s1) + (s2 + s3);
+    grad[k] = accumulate ? grad[k] + s : s;
+}
+
+int check_vmlp(const NsrVmlpDesc *d, const char *who)
+{
+    NSR_REQUIRE(d != nullptr, "%s: desc is NULL", who);
+    NSR_REQUIRE(d->in_pad % 4 == 0 && d->in_pad >= 4 && d->in_pad <= 48, "%s: in_pad=%u unsupported (4..48, x4)", who,
+                d->in_pad);
+    NSR_REQUIRE(d->n_in >= 1 && d->n_in <= d->in_pad, "%s: n_in=%u > in_pad=%u", who, d->n_in, d->in_pad);
+    NSR_REQUIRE(d->n_out >= 1 && d->n_out <= 16, "%s: n_out=%u unsupported (1..16)", who, d->n_out);
+    NSR_REQUIRE(d->n_hidden == 1 || d->n_hidden == 2, "%s: n_hidden=%u unsupported (1, 2)", who, d->n_hidden);
+    NSR_REQUIRE(d->activation <= 1, "%s: activation=%u unsupported (0 relu, 1 softplus100)", who, d->activation);
+    NSR_REQUIRE(d->in_pad == 24 || d->in_pad == 32 || d->in_pad == 36 || d->in_pad == 40,
+                "%s: in_pad=%u has no compiled variant (24, 32, 36, 40)", who, d->in_pad);
+    return NSR_OK;
+}
+
+uint32_t vmlp_blocks(uint32_t n)
+{
+    const uint32_t tiles = nsr_div_up(n, 16);
+    return tiles < 1024u ? (tiles ? tiles : 1u) : 1024u;  // one wave per SIMD on 256 CUs
+}
+
+}  // namespace
+
+extern "C" uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *d)
+{
+    if (!d) return 0;
+    return (uint64_t)W * d->in_pad + W + (d->n_hidden == 2 ? (uint64_t)W * W + W : 0) + 16 * W + 16;
+}
+
+extern "C" uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *d, uint32_t n)
+{
+    return d ? (uint64_t)vmlp_blocks(n) * nsr_vmlp_blob_floats(d) : 0;
+}
+
+#define VMLP_DISPATCH(KERNEL, ...)                                                                                      \
+    do {                                                                                                                \
+        bool done_ = false;                                                                                             \
+        VMLP_CASE(KERNEL, 6, __VA_ARGS__) VMLP_CASE(KERNEL, 8, __VA_ARGS__) VMLP_CASE(KERNEL, 9, __VA_ARGS__)           \
+        VMLP_CASE(KERNEL, 10, __VA_ARGS__)                                                                              \
+        if (!done_) { nsr_set_error("vmlp: no variant"); return NSR_ERR_INVALID; }                                      \
+    } while (0)
+
+extern "C" int nsr_vmlp_forward(const NsrVmlpDesc *desc, const float *blob, const float *x, uint32_t x_stride,
+                                const nsr_half *enc, uint32_t enc_stride, float *out, float *out_col0, float *g_in,
+                                uint32_t n, uint32_t n_full, const int32_t *n_dev, void *stream)
+{
+    if (int rc = check_vmlp(desc, "nsr_vmlp_forward")) return rc;
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(blob && x && (out || n_full == 0), "nsr_vmlp_forward: NULL pointer");
+    NSR_REQUIRE(n_full <= n && (n_full == n || out_col0), "nsr_vmlp_forward: rows beyond n_full need out_col0");
+    NSR_REQUIRE(!g_in || desc->n_hidden == 1, "nsr_vmlp_forward: the input gradient is implemented for one hidden layer");
+    const uint32_t blocks = vmlp_blocks(n) * 2 > nsr_div_up(n, 16) ? nsr_div_up(n, 16) : vmlp_blocks(n) * 2;
+    const int ks = desc->in_pad / 4, nh = desc->n_hidden, act = desc->activation;
+    const bool sdf = enc != nullptr, gin = g_in != nullptr;
+    const __half *e = (const __half *)enc;
+#define VMLP_CASE(KERNEL, KSV, ...)                                                                                     \
+    if (!done_ && ks == KSV) {                                                                                          \
+        done_ = true;                                                                                                   \
+        if (nh == 1 && act == 0 && !sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 0, false, false>), __VA_ARGS__);    \
+        else if (nh == 2 && act == 0 && !sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 2, 0, false, false>), __VA_ARGS__); \
+        else if (nh == 1 && act == 1 && sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, false>), __VA_ARGS__); \
+        else if (nh == 1 && act == 1 && sdf && gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, true>), __VA_ARGS__);   \
+        else if (nh == 1 && act == 1 && !sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, false>), __VA_ARGS__); \
+        else if (nh == 1 && act == 1 && !sdf && gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, true>), __VA_ARGS__); \
+        else { nsr_set_error("nsr_vmlp_forward: combination not compiled (n_hidden=%d act=%d sdf=%d grad=%d)", nh, act, \
+                             (int)sdf, (int)gin); return NSR_ERR_INVALID; }                                             \
+    }
+    VMLP_DISPATCH(k_vmlp_forward, dim3(blocks), dim3(64), 0, (hipStream_t)stream, blob, x, x_stride, e, enc_stride,
+                  desc->n_in, desc->n_out, out, out_col0, g_in, n, n_full, n_dev);
+#undef VMLP_CASE
+    NSR_CHECK_LAUNCH("nsr_vmlp_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, const float *x, uint32_t x_stride,
+                                 const nsr_half *enc, uint32_t enc_stride, const float *d_out, const float *d_out_col0,
+                                 const float *p_in, float *d_x, uint32_t dx_stride, uint32_t dx_first, uint32_t dx_count,
+                                 uint32_t dx_level_major_features, float *grad_blob, int accumulate, float *partials,
+                                 uint32_t n, uint32_t n_full, const int32_t *n_dev, void *stream)
+{
+    if (int rc = check_vmlp(desc, "nsr_vmlp_backward")) return rc;
+    NSR_REQUIRE(blob && grad_blob && partials && (n == 0 || x), "nsr_vmlp_backward: NULL pointer");
+    NSR_REQUIRE(n_full <= n && (n_full == 0 || d_out) && (n_full == n || d_out_col0),
+                "nsr_vmlp_backward: d_out / d_out_col0 do not cover the rows");
+    NSR_REQUIRE(!p_in || (desc->n_hidden == 1), "nsr_vmlp_backward: second-order terms need one hidden layer");
+    const uint32_t bf = (uint32_t)nsr_vmlp_blob_floats(desc);
+    const uint32_t blocks = vmlp_blocks(n);
+    const int ks = desc->in_pad / 4, nh = desc->n_hidden, act = desc->activation;
+    const bool sdf = enc != nullptr, second = p_in != nullptr;
+    const __half *e = (const __half *)enc;
+    if (dx_count == 0) { dx_first = 0; dx_count = desc->n_in; }
+#define VMLP_CASE(KERNEL, KSV, ...)                                                                                     \
+    if (!done_ && ks == KSV) {                                                                                          \
+        done_ = true;                                                                                                   \
+        if (nh == 1 && act == 0 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, 0, false, false>), __VA_ARGS__); \
+        else if (nh == 2 && act == 0 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 2, 0, false, false>), __VA_ARGS__); \
+        else if (nh == 1 && act == 1 && sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, false>), __VA_ARGS__); \
+        else if (nh == 1 && act == 1 && sdf && second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, true>), __VA_ARGS__); \
+        else if (nh == 1 && act == 1 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, false>), __VA_ARGS__); \
+        else if (nh == 1 && act == 1 && !sdf && second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, true>), __VA_ARGS__); \
+        else { nsr_set_error("nsr_vmlp_backward: combination not compiled (n_hidden=%d act=%d sdf=%d second=%d)", nh,   \
+                             act, (int)sdf, (int)second); return NSR_ERR_INVALID; }                                     \
+    }
+    VMLP_DISPATCH(k_vmlp_backward, dim3(blocks), dim3(64), 0, (hipStream_t)stream, blob, x, x_stride, e, enc_stride,
+                  desc->n_in, d_out, d_out_col0, p_in, d_x, dx_stride, dx_first, dx_count, dx_level_major_features,
+                  partials, bf, n, n_full, n_dev);
+#undef VMLP_CASE
+    NSR_CHECK_LAUNCH("nsr_vmlp_backward");
+    hipLaunchKernelGGL(k_vmlp_reduce, dim3(nsr_div_up(bf, 256)), dim3(256), 0, (hipStream_t)stream, partials, grad_blob,
+                       bf, blocks, accumulate);
+    NSR_CHECK_LAUNCH("nsr_vmlp_reduce");
+    return NSR_OK;
+}

@@ -1,0 +1,304 @@
+"""Fused NeuS / neuralangelo training step: the computation of ``NeuSModel.forward_`` (reference models/neus.py:205-287)
++ the loss terms of ``NeuSSystem.training_step`` (systems/neus.py:96-130) + backward, issued as ~25 hand-chained kernel
+launches instead of ~250 through autograd (hash encode, fp32 SDF network on f32 MFMA with the analytic-normal double
+backward or the seven-point finite-difference stencil, SDF->alpha, colour network, alpha compositing, losses).
+
+It reads the parameters of ANY object that exposes them under the reference's attribute paths -- the reference's own
+``models.neus.NeuSModel`` on the drop-in packages, ``tests/refmirror`` or an ``nsr.state.HotPathState`` -- and leaves the
+gradients in ``.grad`` (same tensors an optimizer would step).  Weight norm of the SDF network is folded on the host:
+the effective matrices are formed with a handful of tiny torch ops and the kernel's gradient is pushed back through them.
+
+Scope: bounded foreground (AABB + occupancy grid, ``learned_background: false``): configs/neus-blender.yaml (analytic
+normals, fused fp16 colour MLP) and configs/neuralangelo-dtu-wmask.yaml (progressive levels, finite differences, fp32
+colour MLP).  The NeRF++ background of configs/neus-dtu.yaml runs through the drop-in packages.
+"""
+import ctypes
+
+import torch
+
+from nerfacc import ContractionType
+from nsr_hip import NsrVmlpDesc, check, lib, ptr, stream_ptr
+from nsr_hip import ops as _ops
+
+F32, F16 = torch.float32, torch.float16
+_byref = ctypes.byref
+LOSS_KEYS = ("lambda_rgb_l1", "lambda_rgb_mse", "lambda_mask", "lambda_opaque", "lambda_eikonal", "lambda_sparsity",
+             "lambda_curvature", "sparsity_scale")
+ACC = dict(l1=0, mse=1, valid=2, mask=3, opaque=4, eikonal=5, sparsity=6, curvature=7, inv_s_grad=8, rays=9)
+
+
+def _off(t, n_floats):
+    """raw pointer ``n_floats`` fp32 elements into a contiguous tensor (column views of row-major buffers)"""
+    return ctypes.c_void_p(t.data_ptr() + 4 * int(n_floats))
+
+
+def _linear_weight(layer):
+    """effective weight of an ``nn.Linear`` with (old-style) weight norm folded: g * v / |v| per output row"""
+    if hasattr(layer, "weight_g"):
+        v = layer.weight_v
+        return layer.weight_g * v / v.norm(dim=1, keepdim=True)
+    return layer.weight
+
+
+class VanillaBlob:
+    """parameter blob of csrc/vmlp.hip built (differentiably) from the Linear layers of a reference VanillaMLP"""
+
+    def __init__(self, layers, n_in, n_out, activation):
+        self.layers = list(layers)
+        nh = len(self.layers) - 1
+        in_pad = {True: 36, False: (n_in + 3) // 4 * 4}[24 < n_in <= 36]  # 36 for the 32/35-input nets (no register spills)
+        if in_pad not in (24, 32, 36, 40):
+            in_pad = min(p for p in (24, 32, 36, 40) if p >= n_in)
+        self.desc = NsrVmlpDesc(int(n_in), int(in_pad), int(n_out), int(nh), int(activation))
+        self.n_floats = int(lib.nsr_vmlp_blob_floats(_byref(self.desc)))
+        self.blob = None
+
+    def build(self, requires_grad=True):
+        d = self.desc
+        dev = self.layers[0].bias.device
+        parts = []
+        with torch.set_grad_enabled(requires_grad):
+            w0 = _linear_weight(self.layers[0]).float()
+            parts.append(torch.nn.functional.pad(w0, (0, d.in_pad - w0.shape[1])).reshape(-1))
+            parts.append(self.layers[0].bias.float())
+            for layer in self.layers[1:-1]:
+                parts += [_linear_weight(layer).float().reshape(-1), layer.bias.float()]
+            wl = _linear_weight(self.layers[-1]).float()
+            parts.append(torch.nn.functional.pad(wl, (0, 0, 0, 16 - wl.shape[0])).reshape(-1))
+            parts.append(torch.nn.functional.pad(self.layers[-1].bias.float(), (0, 16 - wl.shape[0])))
+            self.blob = torch.cat(parts).contiguous()
+        assert self.blob.numel() == self.n_floats and self.blob.device == dev
+        return self.blob
+
+    def push_gradient(self, grad_blob):
+        """d loss / d blob -> .grad of weight_g / weight_v / weight / bias"""
+        self.blob.backward(grad_blob)
+
+
+def _vanilla_layers(net):
+    """the nn.Linear modules of a reference ``VanillaMLP`` (``net.layers`` = Sequential / container: Linear, act, ...)"""
+    layers = net.layers
+    mods = list(layers.children()) if hasattr(layers, "children") else list(layers)
+    return [m for m in mods if hasattr(m, "bias") and (hasattr(m, "weight") or hasattr(m, "weight_v"))]
+
+
+class FusedNeuSStep:
+    def __init__(self, model, loss_weights=None):
+        cfg = model.config
+        if cfg["learned_background"] or not cfg["grid_prune"]:
+            raise NotImplementedError("FusedNeuSStep covers the bounded foreground (AABB + occupancy grid) NeuS path")
+        self.model = model
+        self.radius = float(cfg["radius"])
+        g = cfg["geometry"]
+        self.fd = g["grad_type"] == "finite_difference"
+        self.n_feat = int(g["feature_dim"])
+        node = model.geometry.encoding.encoding
+        self.enc = node if hasattr(node, "grid_desc") else node.encoding  # tcnn.Encoding (HashGrid)
+        self._pg = None if hasattr(node, "grid_desc") else node           # ProgressiveBandHashGrid-like holder
+        if not g["xyz_encoding_config"].get("include_xyz", False):
+            raise NotImplementedError("fused NeuS: the SDF network input is [xyz | hash encoding] (include_xyz: true)")
+        d = self.enc.grid_desc
+        self.n_enc = int(d.n_levels * d.n_features)
+        if self.n_enc + 3 > 40:
+            raise NotImplementedError("fused NeuS: the SDF network input (3 + levels x features) is limited to 40 columns")
+        sdf_layers = _vanilla_layers(model.geometry.network)
+        if len(sdf_layers) != 2:
+            raise NotImplementedError("fused NeuS: the SDF network has one hidden layer (every reference config)")
+        self.sdf = VanillaBlob(sdf_layers, 3 + self.n_enc, self.n_feat, activation=1)  # softplus(beta=100): sphere_init
+        tex = model.texture.network
+        self.tex_fused = hasattr(tex, "mlp_desc")
+        self.tex = tex if self.tex_fused else VanillaBlob(_vanilla_layers(tex), self.n_feat + 19, 3, activation=0)
+        if cfg["texture"].get("color_activation") != "sigmoid":
+            raise NotImplementedError("fused NeuS: color_activation sigmoid")
+        lw = dict(lambda_rgb_l1=1.0, lambda_eikonal=0.1, lambda_mask=0.1, sparsity_scale=1.0)
+        lw.update(loss_weights or {})
+        self.loss_weights = lw
+
+    # ---- schedules that live on the model object -------------------------------------------------------------------
+    def _mask_count(self):
+        if self._pg is None:
+            return self.enc.grid_desc.n_levels
+        return int(getattr(self._pg, "current_level", getattr(self.model, "current_level", self.enc.grid_desc.n_levels)))
+
+    def _fd_eps(self):
+        geo = self.model.geometry
+        eps = getattr(geo, "_finite_difference_eps", None)
+        if eps is None:
+            eps = getattr(self.model, "finite_difference_eps", None)
+        return float(eps)
+
+    def _inv_s(self):
+        return torch.exp(self.model.variance.variance.detach().float() * 10.0).reshape(1).contiguous()
+
+    def loss_terms(self, acc):
+        """the system's scalar losses from the accumulator (device tensors)"""
+        n_s = max(self._n_samples, 1)
+        valid, rays = torch.clamp(acc[ACC["valid"]], min=1.0), torch.clamp(acc[ACC["rays"]], min=1.0)
+        return {"rgb_l1": acc[ACC["l1"]] / (3.0 * valid), "rgb_mse": acc[ACC["mse"]] / (3.0 * valid),
+                "mask": acc[ACC["mask"]] / rays, "opaque": acc[ACC["opaque"]] / rays,
+                "eikonal": acc[ACC["eikonal"]] / n_s, "sparsity": acc[ACC["sparsity"]] / n_s,
+                "curvature": acc[ACC["curvature"]] / n_s}
+
+    def loss_value(self, acc):
+        t = self.loss_terms(acc)
+        return sum(float(self.loss_weights.get("lambda_" + k, 0.0)) * v for k, v in t.items())
+
+    # ---- the step ----------------------------------------------------------------------------------------------------
+    def forward_backward(self, rays, gt_rgb, fg_mask, background, compute_grads=True, loss_scale=1.0):
+        m, enc, lw = self.model, self.enc, self.loss_weights
+        dev = rays.device
+        n_rays = rays.shape[0]
+        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+        grid = m.occupancy_grid
+        desc = enc.grid_desc
+        with torch.no_grad(), torch.cuda.device(dev):
+            s = stream_ptr()
+            # models/neus.py:209-220: ray_marching(scene_aabb, grid, alpha_fn=None, stratified=randomized)
+            t_min, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
+            if m.randomized:
+                t_min = t_min + torch.rand_like(t_min) * m.render_step_size
+            packed, ri, t0, t1 = _ops.ray_march(rays_o, rays_d, t_min, t_max, grid.roi_aabb, grid.binary,
+                                                ContractionType.AABB.value, m.render_step_size, 0.0,
+                                                roi_host=grid._roi_host)
+            N = ri.shape[0]
+            self._n_samples = N
+            T = 7 if self.fd else 1
+            eps = self._fd_eps() if self.fd else 0.0
+            mc = self._mask_count()
+            x7 = torch.empty((T * N, 3), dtype=F32, device=dev)
+            dirs = torch.empty((N, 3), dtype=F32, device=dev)
+            check(lib.nsr_neus_points(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), self.radius, eps, int(self.fd),
+                                      ptr(x7), ptr(dirs), N, None, s), "nsr_neus_points")
+            table = enc.table_half(enc.params)
+            encd = _ops.hashgrid_forward(x7, table, desc, mc)  # [T*N, 32] fp16; masked levels are zero columns
+        sdf_blob = self.sdf.build(requires_grad=compute_grads)
+        tex_blob = None if self.tex_fused else self.tex.build(requires_grad=compute_grads)
+        with torch.no_grad(), torch.cuda.device(dev):
+            out = torch.empty((N, 16), dtype=F32, device=dev)
+            taps = torch.empty(6 * N, dtype=F32, device=dev) if self.fd else None
+            sd = self.sdf.desc
+            P, C, F = int(sd.in_pad), self.n_enc, int(desc.n_features)
+            g_in = None if self.fd else torch.empty((N, P), dtype=F32, device=dev)
+            check(lib.nsr_vmlp_forward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), C, ptr(out), ptr(taps),
+                                       ptr(g_in), T * N, N, None, s), "nsr_vmlp_forward(sdf)")
+            dx01 = None
+            if not self.fd:  # J^T (d sdf / d encoding): models/geometry.py:176-180 through the encoder
+                dx01 = torch.empty((N, 3), dtype=F32, device=dev)
+                check(lib.nsr_hashgrid_backward_input(ptr(x7), ptr(table), _off(g_in, 3), 1, P, ptr(dx01), N, mc,
+                                                      _byref(desc), s), "nsr_hashgrid_backward_input")
+            acc = torch.zeros(16, dtype=F32, device=dev)
+            inv_s = self._inv_s()
+            anneal = float(getattr(m, "cos_anneal_ratio", 1.0))
+            grad = torch.empty((N, 3), dtype=F32, device=dev)
+            normal = torch.empty((N, 3), dtype=F32, device=dev)
+            alpha = torch.empty(N, dtype=F32, device=dev)
+            laplace = torch.empty(N, dtype=F32, device=dev) if self.fd else None
+            tex_f32 = not self.tex_fused
+            tex_in = torch.empty((N, 32), dtype=F32 if tex_f32 else F16, device=dev)
+            check(lib.nsr_neus_shade_forward(ptr(out), ptr(g_in), P, ptr(dx01), ptr(taps), eps, self.radius, ptr(dirs),
+                                             ptr(t0), ptr(t1), ptr(inv_s), anneal, self.n_feat,
+                                             float(lw.get("sparsity_scale", 1.0)), ptr(grad), ptr(normal), ptr(alpha),
+                                             ptr(laplace), ptr(tex_in), int(tex_f32), ptr(acc), N, None, s),
+                  "nsr_neus_shade_forward")
+            # colour network
+            if self.tex_fused:
+                tex = self.tex
+                w2 = tex.half_params(tex.params)
+                rgb_raw, acts2 = _ops.mlp_forward(tex_in, w2, tex.mlp_desc, save_acts=compute_grads)
+            else:
+                td = self.tex.desc
+                rgb_raw = torch.empty((N, 16), dtype=F32, device=dev)
+                check(lib.nsr_vmlp_forward(_byref(td), ptr(tex_blob.detach()), ptr(tex_in), 32, None, 0, ptr(rgb_raw), None,
+                                           None, N, N, None, s), "nsr_vmlp_forward(texture)")
+            bg = background.to(F32).contiguous()
+            weights, trans = torch.empty(N, dtype=F32, device=dev), torch.empty(N, dtype=F32, device=dev)
+            comp_rgb = torch.empty((n_rays, 3), dtype=F32, device=dev)
+            comp_normal = torch.empty((n_rays, 3), dtype=F32, device=dev)
+            comp_full = torch.empty((n_rays, 3), dtype=F32, device=dev)
+            opacity = torch.empty((n_rays, 1), dtype=F32, device=dev)
+            depth = torch.empty((n_rays, 1), dtype=F32, device=dev)
+            check(lib.nsr_neus_composite_forward(ptr(packed), ptr(alpha), ptr(rgb_raw), int(tex_f32), ptr(normal), ptr(t0),
+                                                 ptr(t1), ptr(bg), ptr(weights), ptr(trans), ptr(comp_rgb), ptr(opacity),
+                                                 ptr(depth), ptr(comp_normal), ptr(comp_full), n_rays, s),
+                  "nsr_neus_composite_forward")
+            gt = gt_rgb.to(F32).contiguous()
+            fg = None if fg_mask is None else fg_mask.to(F32).contiguous()
+            check(lib.nsr_neus_loss_rays(ptr(comp_full), ptr(opacity), ptr(gt), ptr(fg), ptr(acc), n_rays, None, s),
+                  "nsr_neus_loss_rays")
+            res = {"comp_rgb": comp_rgb, "comp_normal": comp_normal, "opacity": opacity, "depth": depth,
+                   "rays_valid": opacity > 0, "comp_rgb_full": comp_full, "rays_valid_full": opacity > 0,
+                   "num_samples": N, "sdf_samples": out[:, 0], "sdf_grad_samples": grad, "weights": weights,
+                   "ray_indices": ri, "t_starts": t0, "t_ends": t1, "alpha": alpha, "loss_acc": acc,
+                   "inv_s": inv_s[0]}
+            if self.fd:
+                res["sdf_laplace_samples"] = laplace
+            if not compute_grads or N == 0:
+                return res
+            lw8 = torch.tensor([float(lw.get(k, 0.0)) for k in LOSS_KEYS], dtype=F32)
+            lw8c = (ctypes.c_float * 8)(*lw8.tolist())
+            d_alpha = torch.empty(N, dtype=F32, device=dev)
+            d_rgb = torch.empty((N, 16), dtype=F32, device=dev)
+            check(lib.nsr_neus_composite_backward(ptr(packed), ptr(alpha), ptr(rgb_raw), int(tex_f32), ptr(weights),
+                                                  ptr(trans), ptr(bg), ptr(comp_full), ptr(opacity), ptr(gt), ptr(fg),
+                                                  ptr(acc), lw8c, float(loss_scale), ptr(d_alpha), ptr(d_rgb), n_rays,
+                                                  None, s), "nsr_neus_composite_backward")
+            # colour network backward -> d tex_in (fp32 [N, 32])
+            if self.tex_fused:
+                tex = self.tex
+                if tex.params.grad is None:
+                    tex.params.grad = torch.zeros_like(tex.params)
+                d_tex = _ops.mlp_backward(d_rgb, rgb_raw, tex_in, acts2, w2, tex.mlp_desc, grad_weights=tex.params.grad,
+                                          want_dx=True, grad_scale=128.0)
+            else:
+                td = self.tex.desc
+                d_tex = torch.empty((N, 32), dtype=F32, device=dev)
+                g_tex = torch.empty(self.tex.n_floats, dtype=F32, device=dev)
+                ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(_byref(td), N)), dtype=F32, device=dev)
+                check(lib.nsr_vmlp_backward(_byref(td), ptr(tex_blob.detach()), ptr(tex_in), 32, None, 0, ptr(d_rgb), None,
+                                            None, ptr(d_tex), 32, 0, 32, 0, ptr(g_tex), 0, ptr(ws), N, N, None, s),
+                      "nsr_vmlp_backward(texture)")
+            d_out = torch.empty((N, 16), dtype=F32, device=dev)
+            gx = p_in = d_taps = None
+            if self.fd:
+                d_taps = torch.empty(6 * N, dtype=F32, device=dev)
+            else:
+                gx = torch.empty((N, 3), dtype=F32, device=dev)
+                p_in = torch.zeros((N, P), dtype=F32, device=dev)
+            check(lib.nsr_neus_shade_backward(ptr(out), ptr(grad), ptr(normal), ptr(dirs), ptr(t0), ptr(t1), ptr(inv_s),
+                                              anneal, ptr(laplace), eps, self.radius, ptr(d_alpha), ptr(d_tex),
+                                              self.n_feat, lw8c, float(loss_scale), float(N), ptr(d_out), ptr(gx),
+                                              ptr(p_in), P, ptr(d_taps), ptr(acc), N, None, s),
+                  "nsr_neus_shade_backward")
+            if enc.params.grad is None:
+                enc.params.grad = torch.zeros_like(enc.params)
+            g_table = enc.params.grad
+            nws = int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), T * N))
+            gws = torch.empty(nws, dtype=F32, device=dev)
+            # analytic normals: the encoder's input gradient is differentiated again -- d_dy = J gx joins p_in (what flows on
+            # into the SDF network), the second-order table gradient is added after the first-order one below
+            # SDF network backward: d enc (level-major, what the owner-computes table backward reads), dW
+            d_enc = torch.empty(C * T * N, dtype=F32, device=dev)
+            g_sdf = torch.empty(self.sdf.n_floats, dtype=F32, device=dev)
+            ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(_byref(sd), T * N)), dtype=F32, device=dev)
+            if not self.fd:
+                check(lib.nsr_hashgrid_backward_backward_input_ws(ptr(x7), ptr(table), _off(g_in, 3), 1, P, ptr(gx),
+                                                                  _off(p_in, 3), P, None, None, None, N, mc, _byref(desc),
+                                                                  s), "nsr_hashgrid_backward_backward_input(d_dy)")
+            check(lib.nsr_vmlp_backward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), C, ptr(d_out),
+                                        ptr(d_taps), ptr(p_in), ptr(d_enc), 0, 3, C, F, ptr(g_sdf), 0, ptr(ws), T * N, N,
+                                        None, s), "nsr_vmlp_backward(sdf)")
+            check(lib.nsr_hashgrid_backward_params_owner(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws), T * N, mc, 1.0, 0,
+                                                         _byref(desc), None, s), "nsr_hashgrid_backward_params_owner")
+            if not self.fd:
+                check(lib.nsr_hashgrid_backward_backward_input_ws(ptr(x7), ptr(table), _off(g_in, 3), 1, P, ptr(gx), None,
+                                                                  0, ptr(g_table), None, ptr(gws), N, mc, _byref(desc), s),
+                      "nsr_hashgrid_backward_backward_input(table)")
+        # weight norm / bias gradients through the host-side fold
+        self.sdf.push_gradient(g_sdf)
+        if not self.tex_fused:
+            self.tex.push_gradient(g_tex)
+        var = m.variance.variance
+        # inv_s = exp(10 v) (models/neus.py:27-32); the clip(1e-6, 1e6) is handled in the kernel
+        g_var = (acc[ACC["inv_s_grad"]] * inv_s[0] * 10.0).reshape(var.shape).to(var.dtype)
+        var.grad = g_var if var.grad is None else var.grad + g_var
+        return res

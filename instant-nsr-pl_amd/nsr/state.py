@@ -75,6 +75,27 @@ def sphere_init_fused_mlp_(network, n_input_dims, n_output_dims, n_neurons=64):
     network.invalidate()
 
 
+def _vanilla_head(n_in, n_out, cfg):
+    """fp32 Linear stack of a reference ``VanillaMLP`` without sphere init (models/network_utils.py:128-131: zero bias,
+    kaiming-uniform weights), as a container whose state-dict keys are ``layers.{0,2,4}.{weight,bias}``"""
+    net, layers = nn.Module(), nn.Module()
+    dims = [n_in] + [int(cfg["n_neurons"])] * int(cfg["n_hidden_layers"]) + [n_out]
+    for i in range(len(dims) - 1):
+        lin = nn.Linear(dims[i], dims[i + 1], bias=True)
+        nn.init.constant_(lin.bias, 0.0)
+        nn.init.kaiming_uniform_(lin.weight, nonlinearity="relu")
+        layers.add_module(str(2 * i), lin)
+    net.add_module("layers", layers)
+    return net
+
+
+def _colour_head(t):
+    n_in = t["input_feature_dim"] + 16
+    if t["mlp_network_config"]["otype"] == "VanillaMLP":
+        return _vanilla_head(n_in, 3, t["mlp_network_config"])
+    return tcnn.Network(n_in, 3, t["mlp_network_config"])
+
+
 class HotPathState(nn.Module):
     """tensors of one scene: parameters (tcnn modules, the fp32 SDF head, the variance scalar), occupancy grid(s),
     scene box and the marching constants derived from the config"""
@@ -93,7 +114,7 @@ class HotPathState(nn.Module):
                       lambda: tcnn.NetworkWithInputEncoding(3, g["feature_dim"], g["xyz_encoding_config"],
                                                             g["mlp_network_config"])),
                      ("texture.encoding.encoding", sh),
-                     ("texture.network", lambda: tcnn.Network(t["input_feature_dim"] + 16, 3, t["mlp_network_config"]))]
+                     ("texture.network", lambda: _colour_head(t))]
         elif kind == "neus":
             enc_cfg = dict(g["xyz_encoding_config"])
             progressive = enc_cfg["otype"] == "ProgressiveBandHashGrid"
@@ -107,7 +128,7 @@ class HotPathState(nn.Module):
                      ("geometry.network.layers.0", lambda: _weight_normed_linear(n_enc, 64)),
                      ("geometry.network.layers.2", lambda: _weight_normed_linear(64, g["feature_dim"])),
                      ("texture.encoding.encoding", sh),
-                     ("texture.network", lambda: tcnn.Network(t["input_feature_dim"] + 16, 3, t["mlp_network_config"])),
+                     ("texture.network", lambda: _colour_head(t)),
                      ("variance", lambda: _Scalar("variance", cfg["variance"]["init_val"]))]
             self.progressive = dict(enc_cfg) if progressive else None
             self.current_level = enc_cfg.get("start_level", enc_cfg["n_levels"])

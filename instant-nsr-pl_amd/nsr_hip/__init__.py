@@ -42,6 +42,11 @@ class NsrMlpDesc(ctypes.Structure):
     ]
 
 
+class NsrVmlpDesc(ctypes.Structure):
+    _fields_ = [("n_in", ctypes.c_uint32), ("in_pad", ctypes.c_uint32), ("n_out", ctypes.c_uint32),
+                ("n_hidden", ctypes.c_uint32), ("activation", ctypes.c_uint32)]
+
+
 class NsrNerfStepDesc(ctypes.Structure):
     _fields_ = [("grid", NsrGridDesc), ("mlp_density", NsrMlpDesc), ("mlp_color", NsrMlpDesc),
                 ("radius", ctypes.c_float), ("contraction", ctypes.c_int), ("density_bias", ctypes.c_float),
@@ -63,6 +68,7 @@ _P, _I, _U, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_
 _D = ctypes.c_double
 _GD, _MD = ctypes.POINTER(NsrGridDesc), ctypes.POINTER(NsrMlpDesc)
 _SD = ctypes.POINTER(NsrNerfStepDesc)
+_VD = ctypes.POINTER(NsrVmlpDesc)
 
 # name -> argtypes  (restype is int unless listed in _RESTYPES); mirrors include/nsr_hip.h one to one
 SIGNATURES = {
@@ -142,8 +148,21 @@ SIGNATURES = {
     "nsr_scale_to_half": [_P, _P, _U64, _F, _P],
     "nsr_scale_from_half": [_P, _P, _U64, _F, _P],
     "nsr_adam_tick": [_P, _P, _D, _D, _D, _D, _I, _I, _I, _P],
+    "nsr_vmlp_blob_floats": [_VD],
+    "nsr_vmlp_backward_workspace_floats": [_VD, _U],
+    "nsr_vmlp_forward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _U, _U, _P, _P],
+    "nsr_vmlp_backward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _P, _U, _U, _U, _U, _P, _I, _P, _U, _U, _P, _P],
+    "nsr_neus_points": [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _U, _P, _P],
+    "nsr_neus_shade_forward": [_P, _P, _U, _P, _P, _F, _F, _P, _P, _P, _P, _F, _U, _F, _P, _P, _P, _P, _P, _I, _P, _U,
+                               _P, _P],
+    "nsr_neus_composite_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_neus_loss_rays": [_P, _P, _P, _P, _P, _U, _P, _P],
+    "nsr_neus_composite_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P, _P],
+    "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
+                                _P, _U, _P, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
+             "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,
              "nsr_profile_enable": None, "nsr_grid_bricks_words64": ctypes.c_uint64, "nsr_ray_march_capacity": ctypes.c_uint32}
 

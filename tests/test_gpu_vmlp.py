@@ -1,0 +1,124 @@
+"""csrc/vmlp.hip (fp32 VanillaMLP on f32 MFMA) against plain PyTorch fp32 autograd of the same nn.Linear stack
+(reference models/network_utils.py:95-139), including the analytic-normal protocol of models/geometry.py:176-180:
+g = d out[0] / d input with create_graph, then a loss on g (double backward).  Tolerances: forward rtol 1e-5,
+gradients rel-L2 1e-4 (fp32 both sides, different summation order)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+
+
+def _net(n_in, n_out, nh, softplus, weight_norm, seed):
+    torch.manual_seed(seed)
+    act = (lambda: torch.nn.Softplus(beta=100)) if softplus else (lambda: torch.nn.ReLU())
+    dims = [n_in] + [64] * nh + [n_out]
+    mods = []
+    for i in range(len(dims) - 1):
+        lin = torch.nn.Linear(dims[i], dims[i + 1])
+        with torch.no_grad():
+            lin.bias.normal_(0, 0.1)
+            if softplus:
+                lin.weight.mul_(0.3)  # keep 100 z inside softplus's curved range for a good share of the units
+        mods.append(torch.nn.utils.weight_norm(lin) if weight_norm else lin)
+        if i < len(dims) - 2:
+            mods.append(act())
+    return torch.nn.Sequential(*mods).cuda()
+
+
+def _linears(net):
+    return [m for m in net if isinstance(m, torch.nn.Linear)]
+
+
+@pytest.mark.parametrize("n", [1, 1000, 4099])
+@pytest.mark.parametrize("n_in,n_out,nh,softplus,wn", [(32, 3, 2, False, False), (35, 13, 1, True, True),
+                                                        (24, 3, 2, False, False), (32, 8, 1, False, False)])
+def test_forward_backward_match_torch(n, n_in, n_out, nh, softplus, wn):
+    from nsr.fused_neus import VanillaBlob
+    from nsr_hip import check, lib, ptr, stream_ptr
+    net = _net(n_in, n_out, nh, softplus, wn, seed=n_in + nh)
+    vb = VanillaBlob(_linears(net), n_in, n_out, activation=int(softplus))
+    blob = vb.build()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, n_in, device="cuda", generator=g)
+    d_out = torch.randn(n, n_out, device="cuda", generator=g)
+    xr = x.clone().requires_grad_(True)
+    want = net(xr)
+    (want * d_out).sum().backward()
+    out = torch.empty(n, 16, device="cuda")
+    d, s = vb.desc, stream_ptr()
+    check(lib.nsr_vmlp_forward(ctypes.byref(d), ptr(blob.detach()), ptr(x), n_in, None, 0, ptr(out), None, None, n, n, None,
+                               s), "fwd")
+    assert torch.allclose(out[:, :n_out], want.detach(), rtol=1e-5, atol=1e-5), float((out[:, :n_out] - want).abs().max())
+    assert float(out[:, n_out:].abs().max() if n_out < 16 else 0.0) == 0.0
+    d16 = torch.zeros(n, 16, device="cuda")
+    d16[:, :n_out] = d_out
+    d_x = torch.empty(n, n_in, device="cuda")
+    gb = torch.empty(vb.n_floats, device="cuda")
+    ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(ctypes.byref(d), n)), device="cuda")
+    check(lib.nsr_vmlp_backward(ctypes.byref(d), ptr(blob.detach()), ptr(x), n_in, None, 0, ptr(d16), None, None, ptr(d_x),
+                                n_in, 0, n_in, 0, ptr(gb), 0, ptr(ws), n, n, None, s), "bwd")
+    assert _rel(d_x, xr.grad) < 1e-4, _rel(d_x, xr.grad)
+    want_grads = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    vb.push_gradient(gb)
+    for (k, p), w in zip(net.named_parameters(), want_grads):
+        assert _rel(p.grad, w) < 2e-4, (k, _rel(p.grad, w))
+
+
+@pytest.mark.parametrize("n,n_taps", [(777, 0), (500, 6)])
+def test_sdf_input_mode_analytic_normal_and_double_backward(n, n_taps):
+    """input = [2 x - 1 | fp16 encoding]; g_in = d sdf / d input; loss = <d_out, out> + <P, g_in> (+ taps: column 0 only)"""
+    from nsr.fused_neus import VanillaBlob
+    from nsr_hip import check, lib, ptr, stream_ptr
+    net = _net(35, 13, 1, True, True, seed=3)
+    vb = VanillaBlob(_linears(net), 35, 13, activation=1)
+    blob = vb.build()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    nt = n * (1 + n_taps)
+    x01 = torch.rand(nt, 3, device="cuda", generator=g)
+    enc = (torch.randn(nt, 32, device="cuda", generator=g) * 0.1).half()
+    d_out = torch.randn(n, 13, device="cuda", generator=g)
+    d_col0 = torch.randn(nt - n, device="cuda", generator=g)
+    P = torch.randn(nt, 36, device="cuda", generator=g) * 0.2
+    P[:, 35] = 0
+    inp = torch.cat([x01 * 2 - 1, enc.float()], -1).requires_grad_(True)
+    want = net(inp)
+    (gin,) = torch.autograd.grad(want[:, 0].sum(), inp, create_graph=True)
+    second = n_taps == 0
+    loss = (want[:n] * d_out).sum() + (want[n:, 0] * d_col0).sum()
+    if second:
+        loss = loss + (gin * P[:, :35]).sum()
+    loss.backward()
+    d, s = vb.desc, stream_ptr()
+    out = torch.empty(n, 16, device="cuda")
+    col0 = torch.empty(max(nt - n, 1), device="cuda")
+    g_in = torch.empty(nt, 36, device="cuda")
+    check(lib.nsr_vmlp_forward(ctypes.byref(d), ptr(blob.detach()), ptr(x01), 3, ptr(enc), 32, ptr(out), ptr(col0),
+                               ptr(g_in) if second else None, nt, n, None, s), "fwd")
+    assert torch.allclose(out[:, :13], want[:n].detach(), rtol=1e-5, atol=1e-5)
+    if n_taps:
+        assert torch.allclose(col0, want[n:, 0].detach(), rtol=1e-5, atol=1e-5)
+    if second:
+        assert _rel(g_in[:, :35], gin.detach()) < 1e-5, _rel(g_in[:, :35], gin.detach())
+    d16 = torch.zeros(n, 16, device="cuda")
+    d16[:, :13] = d_out
+    d_enc = torch.empty(16 * nt * 2, device="cuda")
+    gb = torch.empty(vb.n_floats, device="cuda")
+    ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(ctypes.byref(d), nt)), device="cuda")
+    check(lib.nsr_vmlp_backward(ctypes.byref(d), ptr(blob.detach()), ptr(x01), 3, ptr(enc), 32, ptr(d16), ptr(d_col0),
+                                ptr(P) if second else None, ptr(d_enc), 0, 3, 32, 2, ptr(gb), 0, ptr(ws), nt, n, None, s),
+          "bwd")
+    # level-major [16][nt][2] -> row-major columns 3..34 of d loss / d input
+    got = d_enc.view(16, nt, 2).permute(1, 0, 2).reshape(nt, 32)
+    assert _rel(got, inp.grad[:, 3:]) < 2e-4, _rel(got, inp.grad[:, 3:])
+    want_grads = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    vb.push_gradient(gb)
+    for (k, p), w in zip(net.named_parameters(), want_grads):
+        assert _rel(p.grad, w) < 3e-4, (k, _rel(p.grad, w), second)
