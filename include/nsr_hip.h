@@ -122,6 +122,20 @@ int nsr_hashgrid_backward_backward_input_ws(const float *x, const nsr_half *tabl
                                             float *grad_table, float *dx2, float *workspace, uint32_t n,
                                             uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
 
+/* Encode a sample and its six finite-difference taps in one launch (models/geometry.py:181-197): x7 [7][n][3] as written by
+ * nsr_neus_points (row 0 the sample, rows 1 + 2k / 2 + 2k the +-eps taps along axis k: only that axis may differ from the
+ * sample); y [7 n][y_stride] half, same values as nsr_hashgrid_forward on the 7 n points.  The sample's 8 corners per
+ * level are gathered once and shared by the taps that stay in its cell or cross one face of it. */
+int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                              uint32_t level_mask_count, const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
+
+/* One pass for both table gradients of a NeuS step with analytic normals: grad_table (+)= scatter(dy_first) (first order,
+ * dy_first_lm level-major fp32 [L][n][F]) + d(dx.g)/d table (second order; dy row-major fp32 = d sdf / d encoding) */
+int nsr_hashgrid_backward_params_owner_with_second_order(const float *x, const float *dy_first_lm, const float *dy,
+                                                         uint32_t dy_stride, const float *g, float *grad_table,
+                                                         float *workspace, uint32_t n, uint32_t level_mask_count,
+                                                         int accumulate, const NsrGridDesc *desc, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Spherical harmonics degree 4 -- replaces tcnn.Encoding(SphericalHarmonics), models/texture.py:25
  *   u[n,3] in [0,1] (the reference pre-maps (d+1)/2) -> y[n, y_stride] half, 16 columns

@@ -183,6 +183,98 @@ k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward of a sample AND its six finite-difference taps (reference models/geometry.py:181-197: the neuralangelo
+// configs evaluate the encoder at x and x +- eps e_k, eps = one cell of the finest ACTIVE level).  x7: [7][n][3] unit
+// coordinates, rows 1 + 2k / 2 + 2k = the +eps / -eps tap along axis k; only that axis differs from the sample, and on
+// every active level (cell >= eps) a tap sits in the sample's cell or in the neighbour across ONE face.  So a lane
+// gathers the sample's 8 corners once and per tap only the 4 corners of the far face when the tap crossed it
+// (expected 8 + ~6 gathers per level over 16 active levels instead of 56): one position load, 7 encodes.
+// ------------------------------------------------------------------------------------------------
+template <int F>
+__device__ __forceinline__ void blend8(const Cell &c, const float (&v)[8][F], __half *yo)
+{
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
+        w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
+        w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[k][f], acc[f]);
+    }
+    if constexpr (F == 1) {
+        yo[0] = __float2half_rn(acc[0]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; f += 2) *reinterpret_cast<__half2 *>(yo + f) = __floats2half2_rn(acc[f], acc[f + 1]);
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(GRID_BLOCK)
+k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
+                    uint32_t y_stride, uint32_t mask_count, uint32_t lpx, const NsrGridDesc d,
+                    const int32_t *__restrict__ n_dev)
+{
+    uint32_t level, blk;
+    if (!map_block(d.n_levels, lpx, level, blk)) return;
+    const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
+    if (i >= live_count(n, n_dev)) return;
+    if (level >= mask_count) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+            for (int f = 0; f < F; ++f) y[((uint64_t)t * n + i) * y_stride + level * F + f] = __float2half_rn(0.f);
+        return;
+    }
+    const LevelGeom g = load_level(d, level);
+    const float xb[3] = {x7[3ull * i], x7[3ull * i + 1], x7[3ull * i + 2]};
+    const Cell cb = locate(g, xb[0], xb[1], xb[2]);
+    float vb[8][F];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        load_feat<F>(table, g.offset + corner_index(g, cb.c[0] + (k & 1), cb.c[1] + ((k >> 1) & 1), cb.c[2] + ((k >> 2) & 1)),
+                     vb[k]);
+    blend8<F>(cb, vb, y + (uint64_t)i * y_stride + level * F);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int a = t >> 1;  // the axis this tap moved along
+        float xt[3] = {xb[0], xb[1], xb[2]};
+        xt[a] = x7[((uint64_t)(t + 1) * n + i) * 3 + a];
+        const Cell ct = locate(g, xt[0], xt[1], xt[2]);
+        const int dc = (int)ct.c[a] - (int)cb.c[a];
+        float vt[8][F];
+        if (dc == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int f = 0; f < F; ++f) vt[k][f] = vb[k][f];
+        } else if (dc == 1 || dc == -1) {
+            // corner k of the tap's cell with bit a == (dc < 0) is corner k ^ (1 << a) of the sample's cell (shared face)
+            const int shared_bit = dc < 0 ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (((k >> a) & 1) == shared_bit) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) vt[k][f] = vb[k ^ (1 << a)][f];
+                } else {
+                    load_feat<F>(table, g.offset + corner_index(g, ct.c[0] + (k & 1), ct.c[1] + ((k >> 1) & 1),
+                                                                ct.c[2] + ((k >> 2) & 1)), vt[k]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                load_feat<F>(table, g.offset + corner_index(g, ct.c[0] + (k & 1), ct.c[1] + ((k >> 1) & 1),
+                                                            ct.c[2] + ((k >> 2) & 1)), vt[k]);
+        }
+        blend8<F>(ct, vt, y + ((uint64_t)(t + 1) * n + i) * y_stride + level * F);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward w.r.t. the table: scatter-add with fp32 hardware atomics
 // ------------------------------------------------------------------------------------------------
 template <int F, bool DY_F32>
@@ -404,6 +496,14 @@ __device__ __forceinline__ void lds_add(unsigned long long *acc, uint32_t rel, f
     for (int f = 0; f < F; ++f) atomicAdd(&acc[rel * F + f], own_to_fixed(w * g[f]));
 }
 
+template <int F>
+__device__ __forceinline__ void lds_add2(unsigned long long *acc, uint32_t rel, float w, const float (&g)[F], float w2,
+                                         const float (&g2)[F])
+{
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(&acc[rel * F + f], own_to_fixed(w * g[f] + w2 * g2[f]));
+}
+
 // Workgroup (level, slice, chunk): accumulates ITS items -- every lane busy, no scan over foreign samples.
 template <int F>
 __global__ void __launch_bounds__(OWN_BLOCK)
@@ -411,7 +511,8 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                       const uint32_t *__restrict__ items, const uint32_t *__restrict__ counts,
                       const uint32_t *__restrict__ bin_start, float *__restrict__ grad_table,
                       float *__restrict__ slabs, uint32_t n, uint32_t mask_count, float grad_scale, int accumulate,
-                      const OwnerMap om, const NsrGridDesc d, const float *__restrict__ dir)
+                      const OwnerMap om, const NsrGridDesc d, const float *__restrict__ dir,
+                      const float *__restrict__ dy_first_lm /* with dir: first-order term of the SAME items, or NULL */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
     __shared__ uint32_t s_nonfinite;  // an inf / NaN gradient reached this slice: it is flushed as NaN (GradScaler's
@@ -440,11 +541,12 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         const uint32_t i_beg = min(m, chunk * per), i_end = min(m, (chunk + 1) * per);
         const uint32_t *it = items + (uint64_t)level * n * 8ull + bin_start[bin];
         const float *dyl = dy_lm + (uint64_t)level * n * F;
+        const float *dyf = dy_first_lm ? dy_first_lm + (uint64_t)level * n * F : nullptr;
         const float fix = grad_scale * OWN_FIX_SCALE;
         constexpr int OWN_BATCH = 2;  // items in flight per lane: item -> (x, dy) is a dependent load chain
         for (uint32_t i0 = i_beg + threadIdx.x; i0 < i_end; i0 += OWN_BLOCK * OWN_BATCH) {
             uint32_t word[OWN_BATCH];
-            float gb[OWN_BATCH][F], xb[OWN_BATCH][3];
+            float gb[OWN_BATCH][F], gf[OWN_BATCH][F], xb[OWN_BATCH][3];
 #pragma unroll
             for (int u = 0; u < OWN_BATCH; ++u) {
                 const uint32_t i = i0 + u * OWN_BLOCK;
@@ -461,6 +563,8 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                     for (int f = 0; f < F; ++f) gb[u][f] = dyl[(uint64_t)s * F + f];
                 }
                 xb[u][0] = x[3ull * s]; xb[u][1] = x[3ull * s + 1]; xb[u][2] = x[3ull * s + 2];
+#pragma unroll
+                for (int f = 0; f < F; ++f) gf[u][f] = dyf ? dyf[(uint64_t)s * F + f] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < OWN_BATCH; ++u) {
@@ -490,6 +594,20 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                 } else {
                     w_lo = (1.f - c.w[0]) * (a1 * a2);
                     w_hi = c.w[0] * (a1 * a2);
+                }
+                if (dyf) {
+                    // first-order and second-order terms of one training step share their items (same samples, same
+                    // corners): w_dir * dy_second + w_trilinear * dy_first leaves as ONE fixed-point atomic per entry
+                    float f_out[F];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        if (!isfinite(gf[u][f])) s_nonfinite = 1u;
+                        f_out[f] = fminf(fmaxf(gf[u][f] * fix, -4.6e18f), 4.6e18f);
+                    }
+                    const float f_lo = (1.f - c.w[0]) * (a1 * a2), f_hi = c.w[0] * (a1 * a2);
+                    if (mode != 2u) lds_add2<F>(acc, corner_index(g, c.c[0], cy, cz) - r0, w_lo, g_out, f_lo, f_out);
+                    if (mode != 1u) lds_add2<F>(acc, corner_index(g, c.c[0] + 1u, cy, cz) - r0, w_hi, g_out, f_hi, f_out);
+                    continue;
                 }
                 if (mode != 2u) lds_add<F>(acc, corner_index(g, c.c[0], cy, cz) - r0, w_lo, g_out);
                 if (mode != 1u) lds_add<F>(acc, corner_index(g, c.c[0] + 1u, cy, cz) - r0, w_hi, g_out);
@@ -806,6 +924,23 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
     return NSR_OK;
 }
 
+extern "C" int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n,
+                                         uint32_t y_stride, uint32_t level_mask_count, const NsrGridDesc *desc,
+                                         const int32_t *n_dev, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_forward_taps")) return rc;
+    NSR_REQUIRE(y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward_taps: y_stride too small");
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x7 && table && y, "nsr_hashgrid_forward_taps: NULL pointer");
+    const uint32_t lpx = (desc->n_levels + 7) / 8;
+    const uint32_t grid = 8u * lpx * nsr_div_up(n, GRID_BLOCK);
+    DISPATCH_F(desc->n_features,
+               hipLaunchKernelGGL((k_grid_forward_taps<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x7,
+                                  (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, *desc, n_dev));
+    NSR_CHECK_LAUNCH("nsr_hashgrid_forward_taps");
+    return NSR_OK;
+}
+
 extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int dy_is_f32, uint32_t dy_stride,
                                             float *grad_table, uint32_t n, uint32_t level_mask_count,
                                             float grad_scale, const NsrGridDesc *desc, void *stream)
@@ -844,7 +979,7 @@ extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridD
 static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_t dy_stride, float *grad_table,
                           float *workspace, uint32_t n, uint32_t level_mask_count, float grad_scale, int accumulate,
                           const NsrGridDesc *desc, const int32_t *n_dev, int phases, void *stream,
-                          const float *dir = nullptr)
+                          const float *dir = nullptr, const float *dy_first_lm = nullptr)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
     NSR_REQUIRE(workspace, "nsr_hashgrid_backward_params_owner: workspace is NULL");
@@ -901,7 +1036,8 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
             attr_set = true;
         }
         hipLaunchKernelGGL((k_grid_backward_owner<F>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
-                           bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir);
+                           bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
+                           dy_first_lm);
         if (slab_floats > 0)
             hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(256, L), dim3(256), 0, st, workspace, grad_table,
                                accumulate, om, *desc);
@@ -934,6 +1070,19 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate(const float *x, con
 {
     return owner_backward(x, dy, dy_layout, dy_stride, grad_table, workspace, n, level_mask_count, grad_scale, accumulate,
                           desc, n_dev, 2, stream);
+}
+
+// first-order table gradient (dy_first, level-major fp32) and the second-order one of the analytic normal (dy row-major
+// fp32 with `g` = dL/d(dx)) in ONE binning + accumulation pass
+extern "C" int nsr_hashgrid_backward_params_owner_with_second_order(const float *x, const float *dy_first_lm,
+                                                                    const float *dy, uint32_t dy_stride, const float *g,
+                                                                    float *grad_table, float *workspace, uint32_t n,
+                                                                    uint32_t level_mask_count, int accumulate,
+                                                                    const NsrGridDesc *desc, void *stream)
+{
+    NSR_REQUIRE(n == 0 || (dy_first_lm && dy && g), "nsr_hashgrid_backward_params_owner_with_second_order: NULL pointer");
+    return owner_backward(x, dy, 1, dy_stride, grad_table, workspace, n, level_mask_count, 1.f, accumulate, desc, nullptr,
+                          3, stream, g, dy_first_lm);
 }
 
 extern "C" int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,

@@ -22,6 +22,7 @@ constexpr int EW_BLOCK = 256;
 constexpr int R_BLOCK = 256;
 constexpr int RAYS_PER_BLOCK = R_BLOCK / NSR_WAVE;
 #define EW_GRID(n) dim3(nsr_div_up((n), EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream
+#define EW_GRID_CAPPED(n) dim3(nsr_div_up((n), EW_BLOCK) < 2048u ? nsr_div_up((n), EW_BLOCK) : 2048u), dim3(EW_BLOCK), 0, (hipStream_t)stream
 #define RAY_GRID(n) dim3(nsr_div_up((n), RAYS_PER_BLOCK)), dim3(R_BLOCK), 0, (hipStream_t)stream
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
@@ -122,9 +123,9 @@ k_neus_shade_fwd(const float *__restrict__ sdf_out /* [n][16]: SDF network outpu
                  float *__restrict__ laplace, void *__restrict__ tex_in /* [n][32] half or float */,
                  float *__restrict__ acc, uint32_t n, const int32_t *__restrict__ n_dev)
 {
-    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
     float s_eik = 0.f, s_sp = 0.f, s_curv = 0.f;
-    if (i < live_count(n, n_dev)) {
+    const uint32_t n_live = live_count(n, n_dev);
+    for (uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x; i < n_live; i += gridDim.x * EW_BLOCK) {
         const float sdf = sdf_out[16ull * i];
         float g[3], lap = 0.f;
         if (FD) {
@@ -136,7 +137,7 @@ k_neus_shade_fwd(const float *__restrict__ sdf_out /* [n][16]: SDF network outpu
             }
             lap = lap / (eps * eps);
             laplace[i] = lap;
-            s_curv = fabsf(lap);
+            s_curv += fabsf(lap);
         } else {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -152,8 +153,8 @@ k_neus_shade_fwd(const float *__restrict__ sdf_out /* [n][16]: SDF network outpu
             normal[3ull * i + k] = nv[k];
             dv[k] = dirs[3ull * i + k];
         }
-        s_eik = (nrm2 - 1.f) * (nrm2 - 1.f);
-        s_sp = expf(-sparsity_scale * fabsf(sdf));
+        s_eik += (nrm2 - 1.f) * (nrm2 - 1.f);
+        s_sp += expf(-sparsity_scale * fabsf(sdf));
         alpha[i] = neus_alpha(sdf, nv, dv, t1[i] - t0[i], inv_s_p[0], anneal).alpha;
         // colour-network input: [feature (n_feat) | SH4 of the direction (fp16-rounded, what tcnn hands back) | normal]
         float shv[16];
@@ -179,15 +180,17 @@ k_neus_shade_fwd(const float *__restrict__ sdf_out /* [n][16]: SDF network outpu
             for (uint32_t k = n_feat + 19; k < 32; ++k) row[k] = __float2half_rn(1.f);  // tcnn pads inputs with 1
         }
     }
+    // one atomic per workgroup and quantity (same-address float atomics serialise: ~10 ns each)
+    __shared__ float red[EW_BLOCK / 64][3];
     s_eik = wave_sum(s_eik);
     s_sp = wave_sum(s_sp);
-    if ((threadIdx.x & 63) == 0) {
-        unsafeAtomicAdd(acc + ACC_EIK, s_eik);
-        unsafeAtomicAdd(acc + ACC_SPARSE, s_sp);
-    }
-    if (FD) {
-        s_curv = wave_sum(s_curv);
-        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(acc + ACC_CURV, s_curv);
+    s_curv = FD ? wave_sum(s_curv) : 0.f;
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s_eik; red[threadIdx.x >> 6][1] = s_sp; red[threadIdx.x >> 6][2] = s_curv; }
+    __syncthreads();
+    if (threadIdx.x < 3 && (FD || threadIdx.x < 2)) {
+        float t = 0.f;
+        for (int w = 0; w < EW_BLOCK / 64; ++w) t += red[w][threadIdx.x];
+        unsafeAtomicAdd(acc + (threadIdx.x == 0 ? ACC_EIK : (threadIdx.x == 1 ? ACC_SPARSE : ACC_CURV)), t);
     }
 }
 
@@ -380,9 +383,9 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
                  float *__restrict__ d_taps /* FD: [6][n] */, float *__restrict__ acc, uint32_t n,
                  const int32_t *__restrict__ n_dev)
 {
-    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
     float gs_local = 0.f;
-    if (i < live_count(n, n_dev)) {
+    const uint32_t n_live = live_count(n, n_dev);
+    for (uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x; i < n_live; i += gridDim.x * EW_BLOCK) {
         const float sdf = sdf_out[16ull * i];
         float g[3], nv[3], dv[3];
 #pragma unroll
@@ -396,7 +399,7 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
         float d_sdf = (gp + gn) * e.inv_s;
         const float g_h = (-gp + gn) * e.inv_s;
         const float g_tc = g_h * dist * 0.5f * e.dic_dtc;
-        gs_local = e.s_live ? (gp * e.ep + gn * e.en) : 0.f;
+        gs_local += e.s_live ? (gp * e.ep + gn * e.en) : 0.f;
         // d normal: from alpha (through the cosine) and from the colour network's input columns
         const float *dt = d_tex_in + 32ull * i;
         float dn[3];
@@ -444,8 +447,15 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
         for (uint32_t k = 1; k < n_feat; ++k) row[k] = dt[k];
         for (uint32_t k = n_feat; k < 16; ++k) row[k] = 0.f;
     }
+    __shared__ float red[EW_BLOCK / 64];
     gs_local = wave_sum(gs_local);
-    if ((threadIdx.x & 63) == 0 && gs_local != 0.f) unsafeAtomicAdd(acc + ACC_INV_S_GRAD, gs_local);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs_local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < EW_BLOCK / 64; ++w) t += red[w];
+        if (t != 0.f) unsafeAtomicAdd(acc + ACC_INV_S_GRAD, t);
+    }
 }
 
 }  // namespace
@@ -478,7 +488,7 @@ extern "C" int nsr_neus_shade_forward(const float *sdf_out, const float *g_in, u
                 "nsr_neus_shade_forward: finite differences need tap_sdf/laplace/eps, analytic needs g_in/dx01");
     NSR_REQUIRE(n_feat >= 1 && n_feat + 19 <= 32, "nsr_neus_shade_forward: n_feat=%u unsupported", n_feat);
 #define SHADE(FDV, F32V)                                                                                              \
-    hipLaunchKernelGGL((k_neus_shade_fwd<FDV, F32V>), EW_GRID(n), sdf_out, g_in, g_stride, dx01, tap_sdf, eps, radius,  \
+    hipLaunchKernelGGL((k_neus_shade_fwd<FDV, F32V>), EW_GRID_CAPPED(n), sdf_out, g_in, g_stride, dx01, tap_sdf, eps, radius,  \
                        dirs, t_starts, t_ends, inv_s, cos_anneal_ratio, n_feat, sparsity_scale, grad, normal, alpha,   \
                        laplace, tex_in, acc, n, n_dev)
     if (fd) { if (tex_is_f32) SHADE(true, true); else SHADE(true, false); }
@@ -559,11 +569,11 @@ extern "C" int nsr_neus_shade_backward(const float *sdf_out, const float *grad, 
     NeusLossWeights lw;
     memcpy(&lw, loss_weights8, sizeof(lw));
     if (fd)
-        hipLaunchKernelGGL(k_neus_shade_bwd<true>, EW_GRID(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
+        hipLaunchKernelGGL(k_neus_shade_bwd<true>, EW_GRID_CAPPED(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
                            cos_anneal_ratio, laplace, eps, radius, d_alpha, d_tex_in, n_feat, lw, loss_scale, n_samples,
                            d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev);
     else
-        hipLaunchKernelGGL(k_neus_shade_bwd<false>, EW_GRID(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
+        hipLaunchKernelGGL(k_neus_shade_bwd<false>, EW_GRID_CAPPED(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
                            cos_anneal_ratio, laplace, eps, radius, d_alpha, d_tex_in, n_feat, lw, loss_scale, n_samples,
                            d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev);
     NSR_CHECK_LAUNCH("nsr_neus_shade_backward");

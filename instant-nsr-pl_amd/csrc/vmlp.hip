@@ -44,12 +44,17 @@ __device__ __forceinline__ void lds_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Softplus(beta=100, threshold=20) and its derivative from ONE hardware exponential (v_exp_f32, ~1 ulp): with
+// e = exp(-|t|), t = 100 z:  softplus = max(z, 0) + log(1 + e) / 100,  sigmoid(t) = t >= 0 ? 1 / (1 + e) : e / (1 + e).
+// (libm's expf / log1pf cost ~60 VALU instructions per value and there are 16 values per lane and tile.)
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float z)
 {
     if (ACT == 0) return fmaxf(z, 0.f);
     const float t = 100.f * z;  // torch.nn.Softplus(beta=100, threshold=20)
-    return t > 20.f ? z : log1pf(expf(t)) * 0.01f;
+    if (t > 20.f) return z;
+    const float e = __expf(-fabsf(t));
+    return fmaxf(z, 0.f) + __logf(1.f + e) * 0.01f;
 }
 // derivative of the activation w.r.t. its pre-activation (softplus: sigmoid(100 z); torch's thresholded branch has slope 1)
 template <int ACT>
@@ -57,7 +62,10 @@ __device__ __forceinline__ float act_bwd(float z)
 {
     if (ACT == 0) return z > 0.f ? 1.f : 0.f;
     const float t = 100.f * z;
-    return t > 20.f ? 1.f : 1.f / (1.f + expf(-t));
+    if (t > 20.f) return 1.f;
+    const float e = __expf(-fabsf(t));
+    const float r = __frcp_rn(1.f + e);
+    return t >= 0.f ? r : e * r;
 }
 
 struct Blob {
@@ -269,14 +277,14 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
             xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g) : 0.f;
-        f32x4 z0[4], a0[4], z1[4], a1[4];
+        f32x4 z0[4], a0[4], s0[4], z1[4], a1[4];  // s0 = act'(z0), evaluated once
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             z0[mb] = b0f[mb];
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) z0[mb] = mfma4(wf0[mb][kk], xin[kk], z0[mb]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a0[mb][r] = act_fwd<ACT>(z0[mb][r]);
+            for (int r = 0; r < 4; ++r) { a0[mb][r] = act_fwd<ACT>(z0[mb][r]); s0[mb][r] = act_bwd<ACT>(z0[mb][r]); }
         }
         if constexpr (NH == 2) {
 #pragma unroll
@@ -310,9 +318,8 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             f32x4 acc = zero4;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = mfma4(Wlt[(4 * kk + g) * W + fb * 16 + c], dob[kk], acc);
-            const f32x4 &zl = (NH == 2) ? z1[fb] : z0[fb];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz_last[fb][r] = acc[r] * act_bwd<ACT>(zl[r]);
+            for (int r = 0; r < 4; ++r) dz_last[fb][r] = acc[r] * ((NH == 2) ? act_bwd<ACT>(z1[fb][r]) : s0[fb][r]);
         }
         // ---- last-layer weight gradient: dWl[o][j] += sum_s dOut[o][s] a_last[j][s] ------------------------------
         lds_wave_sync();  // previous tile's readers are done
@@ -361,7 +368,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                     for (int r = 0; r < 4; ++r)
                         acc = mfma4(W1t[(nb * 16 + 4 * g + r) * W + fb * 16 + c], dz_last[nb][r], acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz0[fb][r] = acc[r] * act_bwd<ACT>(z0[fb][r]);
+                for (int r = 0; r < 4; ++r) dz0[fb][r] = acc[r] * s0[fb][r];
             }
         } else {
 #pragma unroll
@@ -380,7 +387,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                 for (int kk = 0; kk < KS; ++kk) dq = mfma4(wf0[mb][kk], pb[kk], dq);  // (W0 P)^T
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float sg = act_bwd<ACT>(z0[mb][r]);
+                    const float sg = s0[mb][r];
                     q[mb][r] = sg * uf[mb][r];
                     du[mb][r] += sg * dq[r];
                     // d/dz of act'(z): softplus -> 100 s (1 - s) (0 on torch's linear branch); relu -> 0

@@ -170,7 +170,12 @@ class FusedNeuSStep:
             check(lib.nsr_neus_points(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), self.radius, eps, int(self.fd),
                                       ptr(x7), ptr(dirs), N, None, s), "nsr_neus_points")
             table = enc.table_half(enc.params)
-            encd = _ops.hashgrid_forward(x7, table, desc, mc)  # [T*N, 32] fp16; masked levels are zero columns
+            if self.fd:  # the sample's corners are gathered once and shared with its six taps
+                encd = torch.empty((T * N, self.n_enc), dtype=F16, device=dev)
+                check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, mc, _byref(desc), None,
+                                                    s), "nsr_hashgrid_forward_taps")
+            else:
+                encd = _ops.hashgrid_forward(x7, table, desc, mc)  # [N, 32] fp16; masked levels are zero columns
         sdf_blob = self.sdf.build(requires_grad=compute_grads)
         tex_blob = None if self.tex_fused else self.tex.build(requires_grad=compute_grads)
         with torch.no_grad(), torch.cuda.device(dev):
@@ -287,12 +292,14 @@ class FusedNeuSStep:
             check(lib.nsr_vmlp_backward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), C, ptr(d_out),
                                         ptr(d_taps), ptr(p_in), ptr(d_enc), 0, 3, C, F, ptr(g_sdf), 0, ptr(ws), T * N, N,
                                         None, s), "nsr_vmlp_backward(sdf)")
-            check(lib.nsr_hashgrid_backward_params_owner(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws), T * N, mc, 1.0, 0,
-                                                         _byref(desc), None, s), "nsr_hashgrid_backward_params_owner")
-            if not self.fd:
-                check(lib.nsr_hashgrid_backward_backward_input_ws(ptr(x7), ptr(table), _off(g_in, 3), 1, P, ptr(gx), None,
-                                                                  0, ptr(g_table), None, ptr(gws), N, mc, _byref(desc), s),
-                      "nsr_hashgrid_backward_backward_input(table)")
+            if self.fd:
+                check(lib.nsr_hashgrid_backward_params_owner(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws), T * N, mc,
+                                                             1.0, 0, _byref(desc), None, s),
+                      "nsr_hashgrid_backward_params_owner")
+            else:  # first- and second-order table gradients share their items: one binning + accumulation pass
+                check(lib.nsr_hashgrid_backward_params_owner_with_second_order(
+                    ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(g_table), ptr(gws), N, mc, 0, _byref(desc), s),
+                    "nsr_hashgrid_backward_params_owner_with_second_order")
         # weight norm / bias gradients through the host-side fold
         self.sdf.push_gradient(g_sdf)
         if not self.tex_fused:

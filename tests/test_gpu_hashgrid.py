@@ -135,3 +135,72 @@ def test_full_size_properties():
     a = (torch.randn(hd.n_entries * 2, device="cuda") * 0.1).half()
     ya, y2a = ops.hashgrid_forward(x, a, hd).float(), ops.hashgrid_forward(x, (a.float() * 2).half(), hd).float()
     assert torch.allclose(y2a, 2 * ya, rtol=2e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("mask_count", [16, 7])
+def test_forward_taps_equals_seven_plain_encodes(mask_count):
+    """nsr_hashgrid_forward_taps (one position load, corners shared between a sample and its six finite-difference taps,
+    models/geometry.py:181-197) == nsr_hashgrid_forward on the 7 n points, bit for bit; eps = one cell of the finest
+    active level (models/geometry.py:231-233), points near the box faces are clamped like the reference clamps them"""
+    import ctypes
+    import tinycudann as tcnn
+    from conftest import NEUS_GRID
+    from nsr_hip import check, lib, ops, ptr, stream_ptr
+    enc = tcnn.Encoding(3, NEUS_GRID).cuda()
+    with torch.no_grad():
+        enc.params.normal_(0, 0.1)
+    n, radius = 20000, 1.0
+    eps = 2 * radius / (32 * 1.3195079107728942 ** (mask_count - 1))
+    g = torch.Generator().manual_seed(mask_count)
+    o = (torch.rand(n, 3, generator=g) * 2 - 1) * radius
+    o[:200] = o[:200].sign() * radius * (1 - 1e-4 * torch.rand(200, 3, generator=g))  # inside eps of the faces
+    rays_o, rays_d = o.cuda(), torch.zeros(n, 3, device="cuda")
+    ri = torch.arange(n, device="cuda")
+    t0 = torch.zeros(n, device="cuda")
+    x7 = torch.empty(7 * n, 3, device="cuda")
+    check(lib.nsr_neus_points(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t0), radius, eps, 1, ptr(x7), None, n, None,
+                              stream_ptr()), "nsr_neus_points")
+    taps = x7.view(7, n, 3)
+    want_pts = ((o[None] + torch.tensor([[0, 0, 0], [eps, 0, 0], [-eps, 0, 0], [0, eps, 0], [0, -eps, 0], [0, 0, eps],
+                                         [0, 0, -eps]])[:, None, :]).clamp(-radius, radius) + radius) / (2 * radius)
+    assert torch.allclose(taps.cpu(), want_pts, atol=1e-6)
+    table = enc.table_half(enc.params)
+    want = ops.hashgrid_forward(x7, table, enc.grid_desc, mask_count)
+    got = torch.empty_like(want)
+    check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(got), n, 32, mask_count, ctypes.byref(enc.grid_desc), None,
+                                        stream_ptr()), "nsr_hashgrid_forward_taps")
+    assert torch.equal(got, want)
+    assert float(got[:, 2 * mask_count:].abs().max() if mask_count < 16 else 0.0) == 0.0
+
+
+def test_owner_backward_with_second_order_equals_two_passes():
+    """first-order (level-major dy) + second-order (directional-derivative weights) table gradient in ONE binning pass
+    == the two separate owner passes added up (hashed levels: bit-identical integer accumulation is not expected because
+    the two terms are summed before the fixed-point conversion; compare to 1e-6 of the norm)"""
+    import ctypes
+    import tinycudann as tcnn
+    from conftest import NEUS_GRID
+    from nsr_hip import check, lib, ptr, stream_ptr
+    enc = tcnn.Encoding(3, NEUS_GRID).cuda()
+    desc = enc.grid_desc
+    n = 30011
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(n, 3, device="cuda", generator=g)
+    dy_first = torch.randn(16, n, 2, device="cuda", generator=g)           # level-major
+    dy_second = torch.randn(n, 36, device="cuda", generator=g)             # row-major, columns 3..34 used
+    gx = torch.randn(n, 3, device="cuda", generator=g) * 1e-3
+    nws = int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(desc), n))
+    ws = torch.empty(nws, device="cuda")
+    a = torch.empty(desc.n_entries * 2, device="cuda")
+    s = stream_ptr()
+    check(lib.nsr_hashgrid_backward_params_owner(ptr(x), ptr(dy_first), 2, 0, ptr(a), ptr(ws), n, 16, 1.0, 0,
+                                                 ctypes.byref(desc), None, s), "first")
+    off = ctypes.c_void_p(dy_second.data_ptr() + 12)
+    table = enc.table_half(enc.params)
+    check(lib.nsr_hashgrid_backward_backward_input_ws(ptr(x), ptr(table), off, 1, 36, ptr(gx), None, 0, ptr(a), None, ptr(ws),
+                                                      n, 16, ctypes.byref(desc), s), "second")
+    b = torch.empty_like(a)
+    check(lib.nsr_hashgrid_backward_params_owner_with_second_order(ptr(x), ptr(dy_first), off, 36, ptr(gx), ptr(b), ptr(ws), n,
+                                                                   16, 0, ctypes.byref(desc), s), "merged")
+    assert float((a - b).norm() / a.norm()) < 1e-6
+    assert float(a.abs().max()) > 0
