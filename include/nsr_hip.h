@@ -122,12 +122,25 @@ int nsr_hashgrid_backward_backward_input_ws(const float *x, const nsr_half *tabl
                                             float *grad_table, float *dx2, float *workspace, uint32_t n,
                                             uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
 
+/* Forward that also stores the Jacobian d y / d x per level (jac: level-major fp32 [L][n][F][3], zero on masked levels) from
+ * the corner values it already holds, and the two dense products the analytic normal needs from it
+ * (models/geometry.py:176-180): dx = J^T dy (first-order input gradient) and d_dy = J g (its double backward) --
+ * instead of gathering the table a second and a third time (nsr_hashgrid_backward_input / _backward_backward_input). */
+int nsr_hashgrid_forward_jac(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                             int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, float *jac,
+                             const int32_t *n_dev, void *stream);
+int nsr_hashgrid_jac_apply(const float *jac, uint32_t n, const NsrGridDesc *desc, const float *dy, uint32_t dy_stride,
+                           float *dx, const float *g, float *d_dy, uint32_t d_dy_stride, const int32_t *n_dev,
+                           void *stream);
+
 /* Encode a sample and its six finite-difference taps in one launch (models/geometry.py:181-197): x7 [7][n][3] as written by
  * nsr_neus_points (row 0 the sample, rows 1 + 2k / 2 + 2k the +-eps taps along axis k: only that axis may differ from the
- * sample); y [7 n][y_stride] half, same values as nsr_hashgrid_forward on the 7 n points.  The sample's 8 corners per
- * level are gathered once and shared by the taps that stay in its cell or cross one face of it. */
+ * sample); y [7 n][y_stride] half (or level-major [L][7 n][F] with y_level_major), same values as nsr_hashgrid_forward on
+ * the 7 n points.  The sample's 8 corners per level are gathered once and shared by the taps that stay in its cell or
+ * cross one face of it. */
 int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
-                              uint32_t level_mask_count, const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
+                              int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, const int32_t *n_dev,
+                              void *stream);
 
 /* One pass for both table gradients of a NeuS step with analytic normals: grad_table (+)= scatter(dy_first) (first order,
  * dy_first_lm level-major fp32 [L][n][F]) + d(dx.g)/d table (second order; dy row-major fp32 = d sdf / d encoding) */
@@ -525,7 +538,8 @@ typedef struct NsrVmlpDesc {
 uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *desc);
 uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *desc, uint32_t n);
 /* x: fp32 rows [n][x_stride]; with enc != NULL the input is [2 x - 1 (3 columns of x) | enc (fp16 rows, n_in - 3 columns)]
- * (CompositeEncoding with include_xyz, models/network_utils.py:75-76).  Rows < n_full write all 16 output columns to
+ * (CompositeEncoding with include_xyz, models/network_utils.py:75-76); enc_stride = 0x80000000 | F selects the level-major
+ * encoding [(n_in - 3) / F][n][F] that the fused encode kernels write.  Rows < n_full write all 16 output columns to
  * out[n_full][16], rows >= n_full only column 0 to out_col0[n - n_full] (finite-difference taps).  g_in (may be NULL,
  * one hidden layer): [n][in_pad] = d out[0] / d input (analytic normal, models/geometry.py:176-180). */
 int nsr_vmlp_forward(const NsrVmlpDesc *desc, const float *blob, const float *x, uint32_t x_stride, const nsr_half *enc,

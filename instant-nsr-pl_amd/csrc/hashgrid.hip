@@ -122,7 +122,7 @@ template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
                uint32_t y_stride, uint32_t mask_count, uint32_t lpx, int level_major, const NsrGridDesc d,
-               const int32_t *__restrict__ n_dev)
+               const int32_t *__restrict__ n_dev, float *__restrict__ jac /* [L][n][F][3] d y / d x, or NULL */)
 {
     uint32_t level, blk;
     if (!map_block(d.n_levels, lpx, level, blk)) return;
@@ -172,6 +172,27 @@ k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __
 #pragma unroll
             for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[k][f], acc[f]);
         }
+        if (jac) {
+            // The Jacobian of this level's F outputs w.r.t. x, from the 8 corner values already in registers: the input
+            // gradient (J^T dy) and its double backward (J g) then need no second / third gather of the table
+            // (what tcnn's dy_dx buffer is for; models/geometry.py:176-180 asks for both every NeuS step)
+            float *jo = jac + ((uint64_t)level * n + i) * (F * 3);
+            const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float d0 = (1.f - w1) * (1.f - w2) * (v[1][f] - v[0][f]) + w1 * (1.f - w2) * (v[3][f] - v[2][f]) +
+                                 (1.f - w1) * w2 * (v[5][f] - v[4][f]) + w1 * w2 * (v[7][f] - v[6][f]);
+                const float d1 = (1.f - w0) * (1.f - w2) * (v[2][f] - v[0][f]) + w0 * (1.f - w2) * (v[3][f] - v[1][f]) +
+                                 (1.f - w0) * w2 * (v[6][f] - v[4][f]) + w0 * w2 * (v[7][f] - v[5][f]);
+                const float d2 = (1.f - w0) * (1.f - w1) * (v[4][f] - v[0][f]) + w0 * (1.f - w1) * (v[5][f] - v[1][f]) +
+                                 (1.f - w0) * w1 * (v[6][f] - v[2][f]) + w0 * w1 * (v[7][f] - v[3][f]);
+                jo[f * 3] = g.scale * d0; jo[f * 3 + 1] = g.scale * d1; jo[f * 3 + 2] = g.scale * d2;
+            }
+        }
+    } else if (jac) {
+        float *jo = jac + ((uint64_t)level * n + i) * (F * 3);
+#pragma unroll
+        for (int q = 0; q < F * 3; ++q) jo[q] = 0.f;
     }
     if constexpr (F == 1) {
         yo[0] = __float2half_rn(acc[0]);
@@ -215,9 +236,12 @@ __device__ __forceinline__ void blend8(const Cell &c, const float (&v)[8][F], __
 template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
-                    uint32_t y_stride, uint32_t mask_count, uint32_t lpx, const NsrGridDesc d,
+                    uint32_t y_stride, uint32_t mask_count, uint32_t lpx, int level_major, const NsrGridDesc d,
                     const int32_t *__restrict__ n_dev)
 {
+    // row pointer of point p (0 .. 7n-1): row-major [7n][y_stride] or level-major [L][7n][F]
+    const uint64_t n7 = 7ull * n;
+#define TAP_ROW(p) (level_major ? y + ((uint64_t)level * n7 + (p)) * F : y + (uint64_t)(p) * y_stride + level * F)
     uint32_t level, blk;
     if (!map_block(d.n_levels, lpx, level, blk)) return;
     const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
@@ -226,7 +250,7 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
-            for (int f = 0; f < F; ++f) y[((uint64_t)t * n + i) * y_stride + level * F + f] = __float2half_rn(0.f);
+            for (int f = 0; f < F; ++f) TAP_ROW((uint64_t)t * n + i)[f] = __float2half_rn(0.f);
         return;
     }
     const LevelGeom g = load_level(d, level);
@@ -237,7 +261,7 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
     for (int k = 0; k < 8; ++k)
         load_feat<F>(table, g.offset + corner_index(g, cb.c[0] + (k & 1), cb.c[1] + ((k >> 1) & 1), cb.c[2] + ((k >> 2) & 1)),
                      vb[k]);
-    blend8<F>(cb, vb, y + (uint64_t)i * y_stride + level * F);
+    blend8<F>(cb, vb, TAP_ROW(i));
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         const int a = t >> 1;  // the axis this tap moved along
@@ -270,8 +294,9 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
                 load_feat<F>(table, g.offset + corner_index(g, ct.c[0] + (k & 1), ct.c[1] + ((k >> 1) & 1),
                                                             ct.c[2] + ((k >> 2) & 1)), vt[k]);
         }
-        blend8<F>(ct, vt, y + ((uint64_t)(t + 1) * n + i) * y_stride + level * F);
+        blend8<F>(ct, vt, TAP_ROW((uint64_t)(t + 1) * n + i));
     }
+#undef TAP_ROW
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -919,24 +944,83 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
     DISPATCH_F(desc->n_features,
                hipLaunchKernelGGL((k_grid_forward<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
                                   (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
-                                  *desc, n_dev));
+                                  *desc, n_dev, (float *)nullptr));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward");
     return NSR_OK;
 }
 
+extern "C" int nsr_hashgrid_forward_jac(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                                        int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, float *jac,
+                                        const int32_t *n_dev, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_forward_jac")) return rc;
+    NSR_REQUIRE(y_level_major || y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward_jac: y_stride too small");
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && table && y && jac, "nsr_hashgrid_forward_jac: NULL pointer");
+    const uint32_t lpx = (desc->n_levels + 7) / 8;
+    const uint32_t grid = 8u * lpx * nsr_div_up(n, GRID_BLOCK);
+    DISPATCH_F(desc->n_features,
+               hipLaunchKernelGGL((k_grid_forward<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
+                                  (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
+                                  *desc, n_dev, jac));
+    NSR_CHECK_LAUNCH("nsr_hashgrid_forward_jac");
+    return NSR_OK;
+}
+
+namespace {
+// dx[i][:] = sum_c dy[i][c] J[c][i][:]   and / or   d_dy[i][c] = J[c][i][:] . g[i][:]     (J level-major [L][n][F][3])
+__global__ void __launch_bounds__(256)
+k_jac_apply(const float *__restrict__ jac, uint32_t n, uint32_t L, uint32_t F, const float *__restrict__ dy,
+            uint32_t dy_stride, float *__restrict__ dx, const float *__restrict__ g, float *__restrict__ d_dy,
+            uint32_t d_dy_stride, const int32_t *__restrict__ n_dev)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= live_count(n, n_dev)) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (g) { g0 = g[3ull * i]; g1 = g[3ull * i + 1]; g2 = g[3ull * i + 2]; }
+    for (uint32_t l = 0; l < L; ++l) {
+        const float *j = jac + ((uint64_t)l * n + i) * (F * 3);
+        for (uint32_t f = 0; f < F; ++f) {
+            const float j0 = j[f * 3], j1 = j[f * 3 + 1], j2 = j[f * 3 + 2];
+            if (dx) {
+                const float w = dy[(uint64_t)i * dy_stride + l * F + f];
+                a0 = fmaf(w, j0, a0); a1 = fmaf(w, j1, a1); a2 = fmaf(w, j2, a2);
+            }
+            if (d_dy) d_dy[(uint64_t)i * d_dy_stride + l * F + f] = j0 * g0 + j1 * g1 + j2 * g2;
+        }
+    }
+    if (dx) { dx[3ull * i] = a0; dx[3ull * i + 1] = a1; dx[3ull * i + 2] = a2; }
+}
+}  // namespace
+
+extern "C" int nsr_hashgrid_jac_apply(const float *jac, uint32_t n, const NsrGridDesc *desc, const float *dy,
+                                      uint32_t dy_stride, float *dx, const float *g, float *d_dy, uint32_t d_dy_stride,
+                                      const int32_t *n_dev, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_jac_apply")) return rc;
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(jac && ((dx && dy) || (d_dy && g)), "nsr_hashgrid_jac_apply: NULL pointer");
+    hipLaunchKernelGGL(k_jac_apply, dim3(nsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, jac, n, desc->n_levels,
+                       desc->n_features, dx ? dy : nullptr, dy_stride, dx, d_dy ? g : nullptr, d_dy, d_dy_stride, n_dev);
+    NSR_CHECK_LAUNCH("nsr_hashgrid_jac_apply");
+    return NSR_OK;
+}
+
 extern "C" int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n,
-                                         uint32_t y_stride, uint32_t level_mask_count, const NsrGridDesc *desc,
-                                         const int32_t *n_dev, void *stream)
+                                         uint32_t y_stride, int y_level_major, uint32_t level_mask_count,
+                                         const NsrGridDesc *desc, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_forward_taps")) return rc;
-    NSR_REQUIRE(y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward_taps: y_stride too small");
+    NSR_REQUIRE(y_level_major || y_stride >= desc->n_levels * desc->n_features,
+                "nsr_hashgrid_forward_taps: y_stride too small");
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(x7 && table && y, "nsr_hashgrid_forward_taps: NULL pointer");
     const uint32_t lpx = (desc->n_levels + 7) / 8;
     const uint32_t grid = 8u * lpx * nsr_div_up(n, GRID_BLOCK);
     DISPATCH_F(desc->n_features,
                hipLaunchKernelGGL((k_grid_forward_taps<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x7,
-                                  (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, *desc, n_dev));
+                                  (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
+                                  *desc, n_dev));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward_taps");
     return NSR_OK;
 }

@@ -86,13 +86,19 @@ __device__ __forceinline__ Blob split_blob(const float *p)
 
 // input feature k of sample s.  SDF_IN: [2 x01 - 1 (3) | hash encoding (fp16, row-major)] (CompositeEncoding with
 // include_xyz, models/network_utils.py:75-76); otherwise fp32 rows
+// enc_stride >= 0x80000000: level-major encoding [C/F][n][F] with F = enc_stride & 0xff and n = the row count (what the
+// fused encode kernels write: a wave stores 64 x F consecutive halfs)
 template <bool SDF_IN>
 __device__ __forceinline__ float load_feature(const float *__restrict__ x, uint32_t x_stride, const __half *__restrict__ enc,
-                                              uint32_t enc_stride, uint32_t n_in, uint64_t s, uint32_t k)
+                                              uint32_t enc_stride, uint32_t n_in, uint64_t s, uint32_t k, uint32_t n)
 {
     if (k >= n_in) return 0.f;
     if (SDF_IN) {
         if (k < 3) return x[s * x_stride + k] * 2.f - 1.f;
+        if (enc_stride & 0x80000000u) {
+            const uint32_t F = enc_stride & 0xffu, c = k - 3;
+            return __half2float(enc[((uint64_t)(c / F) * n + s) * F + c % F]);
+        }
         return __half2float(enc[s * enc_stride + (k - 3)]);
     }
     return x[s * x_stride + k];
@@ -137,7 +143,7 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
         float xin[KS];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g) : 0.f;
+            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g, n) : 0.f;
         f32x4 z[4], a[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -276,7 +282,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
         float xin[KS];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g) : 0.f;
+            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g, n) : 0.f;
         f32x4 z0[4], a0[4], s0[4], z1[4], a1[4];  // s0 = act'(z0), evaluated once
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {

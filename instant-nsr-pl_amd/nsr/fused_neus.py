@@ -170,12 +170,15 @@ class FusedNeuSStep:
             check(lib.nsr_neus_points(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), self.radius, eps, int(self.fd),
                                       ptr(x7), ptr(dirs), N, None, s), "nsr_neus_points")
             table = enc.table_half(enc.params)
+            # level-major encoding [L][T N][F] (masked levels: zero planes): a wave stores 64 x F consecutive halfs
+            encd = torch.empty(T * N * self.n_enc, dtype=F16, device=dev)
             if self.fd:  # the sample's corners are gathered once and shared with its six taps
-                encd = torch.empty((T * N, self.n_enc), dtype=F16, device=dev)
-                check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, mc, _byref(desc), None,
-                                                    s), "nsr_hashgrid_forward_taps")
-            else:
-                encd = _ops.hashgrid_forward(x7, table, desc, mc)  # [N, 32] fp16; masked levels are zero columns
+                check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(encd), N, 0, 1, mc, _byref(desc), None, s),
+                      "nsr_hashgrid_forward_taps")
+            else:  # analytic normals: keep the per-level Jacobian (384 B / sample) instead of two more table gathers
+                jac = torch.empty(N * self.n_enc * 3, dtype=F32, device=dev)
+                check(lib.nsr_hashgrid_forward_jac(ptr(x7), ptr(table), ptr(encd), N, 0, 1, mc, _byref(desc), ptr(jac),
+                                                   None, s), "nsr_hashgrid_forward_jac")
         sdf_blob = self.sdf.build(requires_grad=compute_grads)
         tex_blob = None if self.tex_fused else self.tex.build(requires_grad=compute_grads)
         with torch.no_grad(), torch.cuda.device(dev):
@@ -183,14 +186,15 @@ class FusedNeuSStep:
             taps = torch.empty(6 * N, dtype=F32, device=dev) if self.fd else None
             sd = self.sdf.desc
             P, C, F = int(sd.in_pad), self.n_enc, int(desc.n_features)
+            ENC_LM = 0x80000000 | F  # enc_stride code of the level-major layout
             g_in = None if self.fd else torch.empty((N, P), dtype=F32, device=dev)
-            check(lib.nsr_vmlp_forward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), C, ptr(out), ptr(taps),
+            check(lib.nsr_vmlp_forward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(out), ptr(taps),
                                        ptr(g_in), T * N, N, None, s), "nsr_vmlp_forward(sdf)")
             dx01 = None
             if not self.fd:  # J^T (d sdf / d encoding): models/geometry.py:176-180 through the encoder
                 dx01 = torch.empty((N, 3), dtype=F32, device=dev)
-                check(lib.nsr_hashgrid_backward_input(ptr(x7), ptr(table), _off(g_in, 3), 1, P, ptr(dx01), N, mc,
-                                                      _byref(desc), s), "nsr_hashgrid_backward_input")
+                check(lib.nsr_hashgrid_jac_apply(ptr(jac), N, _byref(desc), _off(g_in, 3), P, ptr(dx01), None, None, 0, None,
+                                                 s), "nsr_hashgrid_jac_apply(J^T dy)")
             acc = torch.zeros(16, dtype=F32, device=dev)
             inv_s = self._inv_s()
             anneal = float(getattr(m, "cos_anneal_ratio", 1.0))
@@ -286,10 +290,9 @@ class FusedNeuSStep:
             g_sdf = torch.empty(self.sdf.n_floats, dtype=F32, device=dev)
             ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(_byref(sd), T * N)), dtype=F32, device=dev)
             if not self.fd:
-                check(lib.nsr_hashgrid_backward_backward_input_ws(ptr(x7), ptr(table), _off(g_in, 3), 1, P, ptr(gx),
-                                                                  _off(p_in, 3), P, None, None, None, N, mc, _byref(desc),
-                                                                  s), "nsr_hashgrid_backward_backward_input(d_dy)")
-            check(lib.nsr_vmlp_backward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), C, ptr(d_out),
+                check(lib.nsr_hashgrid_jac_apply(ptr(jac), N, _byref(desc), None, 0, None, ptr(gx), _off(p_in, 3), P, None,
+                                                 s), "nsr_hashgrid_jac_apply(J g)")
+            check(lib.nsr_vmlp_backward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(d_out),
                                         ptr(d_taps), ptr(p_in), ptr(d_enc), 0, 3, C, F, ptr(g_sdf), 0, ptr(ws), T * N, N,
                                         None, s), "nsr_vmlp_backward(sdf)")
             if self.fd:

@@ -167,9 +167,13 @@ def test_forward_taps_equals_seven_plain_encodes(mask_count):
     table = enc.table_half(enc.params)
     want = ops.hashgrid_forward(x7, table, enc.grid_desc, mask_count)
     got = torch.empty_like(want)
-    check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(got), n, 32, mask_count, ctypes.byref(enc.grid_desc), None,
-                                        stream_ptr()), "nsr_hashgrid_forward_taps")
+    check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(got), n, 32, 0, mask_count, ctypes.byref(enc.grid_desc),
+                                        None, stream_ptr()), "nsr_hashgrid_forward_taps")
     assert torch.equal(got, want)
+    lm = torch.empty(16, 7 * n, 2, dtype=torch.float16, device="cuda")  # level-major variant: same numbers
+    check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(lm), n, 0, 1, mask_count, ctypes.byref(enc.grid_desc),
+                                        None, stream_ptr()), "nsr_hashgrid_forward_taps")
+    assert torch.equal(lm.permute(1, 0, 2).reshape(7 * n, 32), want)
     assert float(got[:, 2 * mask_count:].abs().max() if mask_count < 16 else 0.0) == 0.0
 
 
@@ -204,3 +208,43 @@ def test_owner_backward_with_second_order_equals_two_passes():
                                                                    16, 0, ctypes.byref(desc), s), "merged")
     assert float((a - b).norm() / a.norm()) < 1e-6
     assert float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("mask_count", [16, 9])
+def test_cached_jacobian_reproduces_input_gradient_and_its_double_backward(mask_count):
+    """nsr_hashgrid_forward_jac + nsr_hashgrid_jac_apply == nsr_hashgrid_backward_input (J^T dy) and the d_dy output of
+    nsr_hashgrid_backward_backward_input (J g), which re-gather the table; encodings unchanged (rel 1e-5: fp32 both ways)"""
+    import ctypes
+    import tinycudann as tcnn
+    from conftest import NEUS_GRID
+    from nsr_hip import check, lib, ops, ptr, stream_ptr
+    enc = tcnn.Encoding(3, NEUS_GRID).cuda()
+    with torch.no_grad():
+        enc.params.normal_(0, 0.05)
+    desc, n = enc.grid_desc, 12345
+    g_ = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(n, 3, device="cuda", generator=g_)
+    dy = torch.randn(n, 36, device="cuda", generator=g_)
+    gx = torch.randn(n, 3, device="cuda", generator=g_)
+    table = enc.table_half(enc.params)
+    s = stream_ptr()
+    y = torch.empty(16, n, 2, dtype=torch.float16, device="cuda")
+    jac = torch.empty(16 * n * 6, device="cuda")
+    check(lib.nsr_hashgrid_forward_jac(ptr(x), ptr(table), ptr(y), n, 0, 1, mask_count, ctypes.byref(desc), ptr(jac), None, s),
+          "fwd_jac")
+    want_y = ops.hashgrid_forward(x, table, desc, mask_count)
+    assert torch.equal(y.permute(1, 0, 2).reshape(n, 32), want_y)
+    off = ctypes.c_void_p(dy.data_ptr() + 12)
+    dx = torch.empty(n, 3, device="cuda")
+    d_dy = torch.zeros(n, 36, device="cuda")
+    check(lib.nsr_hashgrid_jac_apply(ptr(jac), n, ctypes.byref(desc), off, 36, ptr(dx), ptr(gx),
+                                     ctypes.c_void_p(d_dy.data_ptr() + 12), 36, None, s), "jac_apply")
+    want_dx = torch.empty(n, 3, device="cuda")
+    check(lib.nsr_hashgrid_backward_input(ptr(x), ptr(table), off, 1, 36, ptr(want_dx), n, mask_count, ctypes.byref(desc), s),
+          "bwd_input")
+    want_ddy = torch.zeros(n, 32, device="cuda")
+    check(lib.nsr_hashgrid_backward_backward_input(ptr(x), ptr(table), off, 1, 36, ptr(gx), ptr(want_ddy), 32, None, None, n,
+                                                   mask_count, ctypes.byref(desc), s), "bwd_bwd")
+    assert float((dx - want_dx).norm() / want_dx.norm()) < 1e-5
+    assert float((d_dy[:, 3:35] - want_ddy).norm() / want_ddy.norm()) < 1e-5
+    assert float(d_dy[:, 3 + 2 * mask_count:35].abs().max() if mask_count < 16 else 0.0) == 0.0
