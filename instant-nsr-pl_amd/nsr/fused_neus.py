@@ -144,23 +144,51 @@ class FusedNeuSStep:
         return sum(float(self.loss_weights.get("lambda_" + k, 0.0)) * v for k, v in t.items())
 
     # ---- the step ----------------------------------------------------------------------------------------------------
-    def forward_backward(self, rays, gt_rgb, fg_mask, background, compute_grads=True, loss_scale=1.0):
+    def march_begin(self, rays_o, rays_d, t_min=None, t_max=None):
+        """models/neus.py:209-220 (ray_marching(scene_aabb, grid, alpha_fn=None, stratified=randomized)) queued on the
+        CURRENT stream without a host sync -- a trainer runs it for the next batch on a side stream"""
+        m, grid = self.model, self.model.occupancy_grid
+        if t_min is None:
+            t_min, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
+            if m.randomized:
+                t_min = t_min + torch.rand_like(t_min) * m.render_step_size
+        return _ops.ray_march_begin(rays_o, rays_d, t_min, t_max, grid.roi_aabb, grid.binary, ContractionType.AABB.value,
+                                    m.render_step_size, 0.0, roi_host=grid._roi_host)
+
+    def occ_eval_fn(self, x):
+        """occupancy statistic of models/neus.py:90-101 (closed-form alpha of one step at a flat SDF) on the kernels"""
+        m, enc = self.model, self.enc
+        n = x.shape[0]
+        with torch.no_grad(), torch.cuda.device(x.device):
+            x01 = _ops.contract_to_unisphere(x.float().contiguous(), self.radius, ContractionType.AABB.value)
+            e = _ops.hashgrid_forward(x01, enc.table_half(enc.params), enc.grid_desc, self._mask_count())
+            blob = self.sdf.build(requires_grad=False)
+            out = torch.empty((n, 16), dtype=F32, device=x.device)
+            check(lib.nsr_vmlp_forward(_byref(self.sdf.desc), ptr(blob), ptr(x01), 3, ptr(e), self.n_enc, ptr(out), None,
+                                       None, n, n, None, stream_ptr()), "nsr_vmlp_forward(occupancy)")
+            sdf = out[:, :1]
+            inv_s = self._inv_s().clip(1e-6, 1e6)
+            h = m.render_step_size * 0.5
+            prev_cdf, next_cdf = torch.sigmoid((sdf + h) * inv_s), torch.sigmoid((sdf - h) * inv_s)
+            return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+
+    def forward_backward(self, rays, gt_rgb, fg_mask, background, compute_grads=True, loss_scale=1.0, march_handle=None,
+                         after_march=None):
         m, enc, lw = self.model, self.enc, self.loss_weights
         dev = rays.device
         n_rays = rays.shape[0]
-        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
         grid = m.occupancy_grid
         desc = enc.grid_desc
         with torch.no_grad(), torch.cuda.device(dev):
             s = stream_ptr()
-            # models/neus.py:209-220: ray_marching(scene_aabb, grid, alpha_fn=None, stratified=randomized)
-            t_min, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
-            if m.randomized:
-                t_min = t_min + torch.rand_like(t_min) * m.render_step_size
-            packed, ri, t0, t1 = _ops.ray_march(rays_o, rays_d, t_min, t_max, grid.roi_aabb, grid.binary,
-                                                ContractionType.AABB.value, m.render_step_size, 0.0,
-                                                roi_host=grid._roi_host)
+            if march_handle is None:
+                rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+                march_handle = self.march_begin(rays_o, rays_d)
+            rays_o, rays_d = march_handle.args[0], march_handle.args[1]
+            packed, ri, t0, t1 = _ops.ray_march_finish(march_handle)
             N = ri.shape[0]
+            if after_march is not None:
+                after_march(N)  # the sample count of this step is known: a trainer queues the next batch's marching here
             self._n_samples = N
             T = 7 if self.fd else 1
             eps = self._fd_eps() if self.fd else 0.0
@@ -312,3 +340,108 @@ class FusedNeuSStep:
         g_var = (acc[ACC["inv_s_grad"]] * inv_s[0] * 10.0).reshape(var.shape).to(var.dtype)
         var.grad = g_var if var.grad is None else var.grad + g_var
         return res
+
+
+def neus_lr_scale(step, config_name, max_steps=20000):
+    """learning-rate factor of the reference's SequentialLR (interval: step) at optimizer step ``step`` (0-based):
+    neus-*.yaml: LinearLR 0.01 -> 1 over 500 steps, then ExponentialLR 0.1^(1 / (max_steps - 500));
+    neuralangelo-*.yaml: constant for 5000 steps, then ExponentialLR 0.1^(1 / (max_steps - 5000))"""
+    if config_name == "neuralangelo":
+        c = 5000
+        return 1.0 if step < c else 0.1 ** ((step - c) / (max_steps - c))
+    w = 500
+    if step < w:
+        return 0.01 + (1.0 - 0.01) * step / w
+    return 0.1 ** ((step - w) / (max_steps - w))
+
+
+class NeuSTrainer:
+    """one-process-per-GPU training step of the reference's NeuSSystem (systems/neus.py:87-152) on the fused runner:
+    sample rays -> schedules / occupancy refresh -> fused forward + losses + backward -> (grad all-reduce) -> AdamW with the
+    per-group learning rates of the YAML (geometry / texture 0.01, variance 0.001).  The marching pass of step t+1 runs
+    on a side stream underneath step t (it needs rays and the occupancy grid only), except across a grid refresh."""
+
+    def __init__(self, model, dataset, config, loss_weights, config_name="neus-blender", rank=0, world_size=1, seed=42,
+                 max_steps=20000):
+        import tinycudann as tcnn
+        from .parallel import broadcast_parameters, shard_seed
+        from .trainer import FusedAdamW
+        self.model, self.dataset, self.config, self.config_name = model, dataset, config, config_name
+        self.rank, self.world_size, self.max_steps = rank, world_size, max_steps
+        self.device = next(model.parameters()).device
+        self.fused = FusedNeuSStep(model, loss_weights)
+        self.train_num_samples = config["train_num_rays"] * config["num_samples_per_ray"]  # systems/neus.py:27
+        self.train_num_rays = config["train_num_rays"]
+        self.global_step = 0
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(shard_seed(seed, rank))
+        if world_size > 1:
+            broadcast_parameters(model)
+        tc = [m for m in model.modules() if isinstance(m, tcnn.Module) and m.params.numel() > 0]
+        tc_ids = {id(m.params) for m in tc}
+        var = [model.variance.variance]
+        rest = [p for p in model.parameters() if id(p) not in tc_ids and p is not var[0] and p.numel() > 0]
+        self.opt = FusedAdamW(tc, [], lr=0.01)
+        self.opt_rest = torch.optim.AdamW([{"params": rest, "lr": 0.01}, {"params": var, "lr": 0.001}], betas=(0.9, 0.99),
+                                          eps=1e-15)
+        self._base_lrs = [0.01, 0.001]
+        self._pending, self._side = None, None
+        self.last = {}
+
+    def _next_batch(self, stream_ctx):
+        from .fused import prepare_train_rays
+        cfg = self.config
+        with stream_ctx:
+            rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(self.dataset, self.train_num_rays, self.gen,
+                                                                         self.model, cfg["background_color"])
+            handle = self.fused.march_begin(ro, rd, t_min, t_max)
+        return rays, rgb, fg, bg, handle
+
+    def train_step(self):
+        import contextlib
+        from .parallel import all_reduce_gradients
+        model, cfg, t = self.model, self.config, self.global_step
+        model.update_step(0, t)  # cos anneal, progressive level / eps (and, on the reference's model, the refresh itself)
+        grid = model.occupancy_grid
+        refreshed = False
+        if type(model).__name__ == "HotPathState" and cfg["grid_prune"] and t % 16 == 0:
+            grid.every_n_step(step=t, occ_eval_fn=self.fused.occ_eval_fn, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
+            refreshed = True
+        if refreshed or (cfg["grid_prune"] and t % 16 == 0):
+            self._pending = None  # marched through the old grid
+        main = torch.cuda.current_stream()
+        if self._pending is None:
+            self._pending = self._next_batch(contextlib.nullcontext())
+        rays, rgb, fg, bg, handle = self._pending
+        self._pending = None
+        model.background_color = bg
+        self.opt_rest.zero_grad(set_to_none=True)
+
+        def after_march(n):
+            if cfg["dynamic_ray_sampling"] and n > 0:  # systems/neus.py:93-95
+                tr = int(self.train_num_rays * (self.train_num_samples / n))
+                self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1), cfg["max_train_num_rays"])
+            # the NEXT batch (its ray count is final now): ray preparation + marching on the side stream, underneath this
+            # step's encode / networks / backward -- unless the next step refreshes the grid first
+            if cfg["grid_prune"] and (t + 1) % 16 != 0:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+                self._pending = self._next_batch(torch.cuda.stream(self._side))
+                for x in self._pending[:4]:
+                    x.record_stream(main)
+
+        res = self.fused.forward_backward(rays, rgb, fg, bg, march_handle=handle, after_march=after_march)
+        n = res["num_samples"]
+        if self.world_size > 1:
+            all_reduce_gradients(list(model.parameters()))
+        scale = neus_lr_scale(t, self.config_name, self.max_steps)
+        self.opt.step(lr_scale=scale)
+        for g, base in zip(self.opt_rest.param_groups, self._base_lrs):
+            g["lr"] = base * scale
+        self.opt_rest.step()
+        self.global_step += 1
+        self.last = {"loss_acc": res["loss_acc"], "n_rays": rays.shape[0], "n_samples": n}
+        return self.last
