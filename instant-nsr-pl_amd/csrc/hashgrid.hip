@@ -969,27 +969,48 @@ extern "C" int nsr_hashgrid_forward_jac(const float *x, const nsr_half *table, n
 
 namespace {
 // dx[i][:] = sum_c dy[i][c] J[c][i][:]   and / or   d_dy[i][c] = J[c][i][:] . g[i][:]     (J level-major [L][n][F][3])
-__global__ void __launch_bounds__(256)
+// dy / d_dy are ROW-major (what the MFMA kernels read and write: 144-B rows): a block moves its 256 x C tile through
+// LDS with coalesced row segments instead of letting every lane walk its own row (64 cache lines per load instruction)
+constexpr int JAC_BLOCK = 256;
+__global__ void __launch_bounds__(JAC_BLOCK)
 k_jac_apply(const float *__restrict__ jac, uint32_t n, uint32_t L, uint32_t F, const float *__restrict__ dy,
             uint32_t dy_stride, float *__restrict__ dx, const float *__restrict__ g, float *__restrict__ d_dy,
             uint32_t d_dy_stride, const int32_t *__restrict__ n_dev)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= live_count(n, n_dev)) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (g) { g0 = g[3ull * i]; g1 = g[3ull * i + 1]; g2 = g[3ull * i + 2]; }
-    for (uint32_t l = 0; l < L; ++l) {
-        const float *j = jac + ((uint64_t)l * n + i) * (F * 3);
-        for (uint32_t f = 0; f < F; ++f) {
-            const float j0 = j[f * 3], j1 = j[f * 3 + 1], j2 = j[f * 3 + 2];
-            if (dx) {
-                const float w = dy[(uint64_t)i * dy_stride + l * F + f];
-                a0 = fmaf(w, j0, a0); a1 = fmaf(w, j1, a1); a2 = fmaf(w, j2, a2);
-            }
-            if (d_dy) d_dy[(uint64_t)i * d_dy_stride + l * F + f] = j0 * g0 + j1 * g1 + j2 * g2;
-        }
+    extern __shared__ float tile[];  // [JAC_BLOCK][C + 1]
+    const uint32_t C = L * F, ld = C + 1;
+    const uint32_t n_live = live_count(n, n_dev);
+    const uint32_t i0 = blockIdx.x * JAC_BLOCK, i = i0 + threadIdx.x;
+    if (i0 >= n_live) return;
+    const uint32_t rows = min((uint32_t)JAC_BLOCK, n_live - i0);
+    if (dx) {
+        for (uint32_t k = threadIdx.x; k < rows * C; k += JAC_BLOCK)
+            tile[(k / C) * ld + k % C] = dy[(uint64_t)(i0 + k / C) * dy_stride + k % C];
+        __syncthreads();
     }
-    if (dx) { dx[3ull * i] = a0; dx[3ull * i + 1] = a1; dx[3ull * i + 2] = a2; }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    const bool live = i < n_live;
+    if (live && g) { g0 = g[3ull * i]; g1 = g[3ull * i + 1]; g2 = g[3ull * i + 2]; }
+    if (live) {
+        for (uint32_t l = 0; l < L; ++l) {
+            const float *j = jac + ((uint64_t)l * n + i) * (F * 3);
+            for (uint32_t f = 0; f < F; ++f) {
+                const float j0 = j[f * 3], j1 = j[f * 3 + 1], j2 = j[f * 3 + 2];
+                float *t = &tile[threadIdx.x * ld + l * F + f];
+                if (dx) {
+                    const float w = *t;
+                    a0 = fmaf(w, j0, a0); a1 = fmaf(w, j1, a1); a2 = fmaf(w, j2, a2);
+                }
+                if (d_dy) *t = j0 * g0 + j1 * g1 + j2 * g2;  // (after the read above: same thread, same slot)
+            }
+        }
+        if (dx) { dx[3ull * i] = a0; dx[3ull * i + 1] = a1; dx[3ull * i + 2] = a2; }
+    }
+    if (d_dy) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < rows * C; k += JAC_BLOCK)
+            d_dy[(uint64_t)(i0 + k / C) * d_dy_stride + k % C] = tile[(k / C) * ld + k % C];
+    }
 }
 }  // namespace
 
@@ -1000,7 +1021,8 @@ extern "C" int nsr_hashgrid_jac_apply(const float *jac, uint32_t n, const NsrGri
     if (int rc = check_desc(desc, "nsr_hashgrid_jac_apply")) return rc;
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(jac && ((dx && dy) || (d_dy && g)), "nsr_hashgrid_jac_apply: NULL pointer");
-    hipLaunchKernelGGL(k_jac_apply, dim3(nsr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, jac, n, desc->n_levels,
+    const size_t lds = (size_t)JAC_BLOCK * (desc->n_levels * desc->n_features + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_jac_apply, dim3(nsr_div_up(n, JAC_BLOCK)), dim3(JAC_BLOCK), lds, (hipStream_t)stream, jac, n, desc->n_levels,
                        desc->n_features, dx ? dy : nullptr, dy_stride, dx, d_dy ? g : nullptr, d_dy, d_dy_stride, n_dev);
     NSR_CHECK_LAUNCH("nsr_hashgrid_jac_apply");
     return NSR_OK;

@@ -137,13 +137,24 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
     }
     blf = *reinterpret_cast<const f32x4 *>(B.bl + 4 * g);
     const uint32_t n_tiles = (n_live + 15) / 16;
+    // software pipeline: the NEXT tile's inputs are requested before this tile's MFMA chain starts (one wave per SIMD: nothing
+    // else hides the ~2 us of a global load)
+    float xnext[KS];
+    auto load_inputs = [&](uint32_t tile, float (&dst)[KS]) {
+        const uint64_t sn = (uint64_t)tile * 16 + c;
+        const bool ok = tile < n_tiles && sn < n_live;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            dst[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, sn, 4 * kk + g, n) : 0.f;
+    };
+    load_inputs(blockIdx.x, xnext);
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t s = (uint64_t)tile * 16 + c;
         const bool valid = s < n_live;
         float xin[KS];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g, n) : 0.f;
+        for (int kk = 0; kk < KS; ++kk) xin[kk] = xnext[kk];
+        load_inputs(tile + gridDim.x, xnext);
         f32x4 z[4], a[4];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -265,6 +276,28 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             for (int nb = 0; nb < 4; ++nb) accW1[mb][nb] = zero4;
     }
     const uint32_t n_tiles = (n_live + 15) / 16;
+    // software pipeline: the NEXT tile's inputs (features, output gradient, P) are requested before this tile's MFMA chain
+    float xnext[KS], pnext[KS];
+    f32x4 donext;
+    auto load_inputs = [&](uint32_t tile, float (&xd)[KS], float (&pd)[KS], f32x4 &dd) {
+        const uint64_t sn = (uint64_t)tile * 16 + c;
+        const bool ok = tile < n_tiles && sn < n_live;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            xd[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, sn, 4 * kk + g, n) : 0.f;
+            if (SECOND) pd[kk] = ok ? p_in[sn * IN_PAD + 4 * kk + g] : 0.f;
+        }
+        dd = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (sn < n_full) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) dd[kk] = d_out[sn * 16 + 4 * kk + g];
+            } else if (g == 0) {
+                dd[0] = d_out_col0[sn - n_full];
+            }
+        }
+    };
+    load_inputs(blockIdx.x, xnext, pnext, donext);
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t s = (uint64_t)tile * 16 + c;
         const bool valid = s < n_live;
@@ -279,10 +312,11 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                 for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = W0t[(mb * 16 + c) * IN_PAD + 4 * kk + g];
         }
         // ---- forward recompute ---------------------------------------------------------------------------------
-        float xin[KS];
+        float xin[KS], pb[KS];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            xin[kk] = valid ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, s, 4 * kk + g, n) : 0.f;
+        for (int kk = 0; kk < KS; ++kk) { xin[kk] = xnext[kk]; pb[kk] = SECOND ? pnext[kk] : 0.f; }
+        f32x4 dob = donext;
+        load_inputs(tile + gridDim.x, xnext, pnext, donext);
         f32x4 z0[4], a0[4], s0[4], z1[4], a1[4];  // s0 = act'(z0), evaluated once
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -307,15 +341,6 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             }
         }
         // ---- output gradient in B layout: lane (g,c) holds d_out[sample c][4kk + g] -------------------------------
-        f32x4 dob = zero4;
-        if (valid) {
-            if (s < n_full) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dob[kk] = d_out[s * 16 + 4 * kk + g];
-            } else if (g == 0) {
-                dob[0] = d_out_col0[s - n_full];
-            }
-        }
         dblv += dob;
         // dA_last^T = Wl^T . dOut^T   (A: Wl[4kk + g][fb*16 + c])
         f32x4 dz_last[4];
@@ -382,9 +407,6 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
         }
         // ---- second-order terms of the analytic normal -----------------------------------------------------------
         if (SECOND) {
-            float pb[KS];
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) pb[kk] = valid ? p_in[s * IN_PAD + 4 * kk + g] : 0.f;
             f32x4 q[4];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {

@@ -122,3 +122,23 @@ def test_sdf_input_mode_analytic_normal_and_double_backward(n, n_taps):
     vb.push_gradient(gb)
     for (k, p), w in zip(net.named_parameters(), want_grads):
         assert _rel(p.grad, w) < 3e-4, (k, _rel(p.grad, w), second)
+
+
+def test_level_major_encoding_input_gives_the_same_output():
+    """enc_stride = 0x80000000 | F: the SDF-input loader reads the level-major encoding [L][n][F] of the fused encoders"""
+    from nsr.fused_neus import VanillaBlob
+    from nsr_hip import check, lib, ptr, stream_ptr
+    net = _net(35, 13, 1, True, True, seed=9)
+    vb = VanillaBlob(_linears(net), 35, 13, activation=1)
+    blob = vb.build(requires_grad=False)
+    n = 1234
+    x01 = torch.rand(n, 3, device="cuda")
+    enc = (torch.randn(n, 32, device="cuda") * 0.1).half()
+    enc_lm = enc.view(n, 16, 2).permute(1, 0, 2).contiguous()
+    outs = []
+    for e, stride in ((enc, 32), (enc_lm, 0x80000000 | 2)):
+        out = torch.empty(n, 16, device="cuda")
+        check(lib.nsr_vmlp_forward(ctypes.byref(vb.desc), ptr(blob), ptr(x01), 3, ptr(e), stride, ptr(out), None, None, n, n,
+                                   None, stream_ptr()), "fwd")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
