@@ -10,7 +10,8 @@ rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 cp "$(find /tmp/pk -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 python /root/repo/tools/trace_tail.py "$(find /tmp/pk -name '*kernel_trace.csv' | head -1)" "$out/timeline_tail.csv" 2400
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pc && rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pc -o c -- python /root/repo/bench.py --steps 30 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
+  rm -rf /tmp/pc && NSR_BENCH_REGIME_OUT="$out/bench_regime.json" rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pc -o c -- python /root/repo/bench.py --steps 30 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
   python /root/repo/tools/pmc_summary.py "$(find /tmp/pc -name '*counter_collection.csv' | head -1)" $c > "$out/pmc_$c.json"
 done
+python /root/repo/tools/pmc_traffic.py "$out" "$out/pmc_traffic.json"
 ls -la "$out"

@@ -1,0 +1,31 @@
+"""Assemble profiles/rNN_pmc_traffic.json from the two PMC passes of tools/collect_profiles.sh (FETCH_SIZE / WRITE_SIZE,
+KiB per dispatch) and the regime bench.py recorded while they ran.  Corrections exactly as MI355X_MICROARCH.md prescribes
+(HBM / rocprofv3 section): units are KiB; FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x -- calibrated in
+the same run on k_adamw (16 B read per parameter).
+
+    python tools/pmc_traffic.py <dir with pmc_FETCH_SIZE.json pmc_WRITE_SIZE.json bench_regime.json> <out.json>
+"""
+import json, os, sys
+d, out = sys.argv[1], sys.argv[2]
+fetch = json.load(open(os.path.join(d, "pmc_FETCH_SIZE.json")))
+write = json.load(open(os.path.join(d, "pmc_WRITE_SIZE.json")))
+regime = json.load(open(os.path.join(d, "bench_regime.json")))
+n_params = 12602992 + 7168
+adam = fetch.get("k_adamw", {}).get("avg")
+# two k_adamw dispatches per step (table+density MLP, colour MLP): avg KiB per dispatch x 2 vs 16 B/param
+fetch_ratio = (adam * 2 * 1024) / (16.0 * n_params) if adam else 0.5
+corr = 1.0 / fetch_ratio if 0.3 < fetch_ratio < 0.8 else 1.0
+ops = {"hashgrid_backward_params": ["k_own_bin<false>", "k_own_bin_scan", "k_own_bin<true>", "k_grid_backward_owner<2>",
+                                    "k_grid_reduce_slabs<2>"],
+       "hashgrid_forward": ["k_grid_forward<2>"]}
+res = {"_unit": "HBM-side bytes per launch = (FETCH_SIZE x correction + WRITE_SIZE) x 1024, separate --pmc passes",
+       "_fetch_calibration": {"kernel": "k_adamw", "measured_over_expected": fetch_ratio, "read_side_multiplier": corr},
+       "_regime": regime}
+for name, kernels in ops.items():
+    b = sum((fetch.get(k, {}).get("avg", 0.0) * corr + write.get(k, {}).get("avg", 0.0)) * 1024 for k in kernels)
+    spl = regime["kept_samples_per_step"] if name == "hashgrid_backward_params" else regime["marched_samples_per_step"]
+    res[name] = {"bytes_per_launch": b, "samples_per_launch": spl, "kernels": kernels}
+res["_raw_KiB_per_dispatch"] = {k: {"FETCH_SIZE": fetch.get(k, {}).get("avg"), "WRITE_SIZE": write.get(k, {}).get("avg"),
+                                   "dispatches": fetch.get(k, {}).get("dispatches")} for k in sorted(set(fetch) | set(write))}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if not k.startswith("_raw")})[:600])
