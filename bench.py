@@ -202,6 +202,28 @@ def main():
             if k not in prof:
                 prof[k] = v2
 
+    comm = None
+    if world > 1 and getattr(tr, "sharded", None) is not None:
+        # the gradient exchange, timed with HIP events on 32 further steps: reduce-scatter (bf16) / AdamW on the shard /
+        # all-gather of the fp16 image, per module; wire bytes per GPU and the per-link rate of the pairwise exchange
+        tr.comm_timings = {}
+        for _ in range(32):
+            tr.train_step()
+        torch.cuda.synchronize()
+        evs = tr.comm_timings.get("events", [])
+        tr.comm_timings = None
+        n_mod = max(len(tr.sharded.modules), 1)
+        steps_c = max(len(evs) // n_mod, 1)
+        rs = sum(e[0].elapsed_time(e[1]) for e in evs) / steps_c
+        ad = sum(e[1].elapsed_time(e[2]) for e in evs) / steps_c
+        ag = sum(e[2].elapsed_time(e[3]) for e in evs) / steps_c
+        wire = tr.sharded.wire_bytes
+        comm = {"reduce_scatter_ms": rs, "sharded_adamw_ms": ad, "all_gather_ms": ag, "algo": tr.sharded.algo,
+                "transport": str(tr.sharded.transport), "wire_bytes_per_gpu_per_step": wire,
+                "per_link_GBps": (wire / max(world - 1, 1)) / max((rs + ag) * 1e-3, 1e-9) / 1e9,
+                "note": "pairwise exchange over the xGMI full mesh: every rank sends chunk j straight to rank j; "
+                        "per_link = bytes one link carries per step / (reduce_scatter + all_gather time)"}
+
     tot = torch.tensor([dt, float(n_samples), float(n_rays)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tot[:1].clone()
@@ -257,7 +279,7 @@ def main():
                        "note": "steady state of the dynamic ray count needs warmup >= ~300 steps (8192-ray cap reached, "
                                "grid pruned); shorter warm-ups time the transient (few rays, dense grid)"},
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
-            "roofline": roof, "kernels": kern, "phase_ms_per_step": phases,
+            "roofline": roof, "kernels": kern, "phase_ms_per_step": phases, "gradient_exchange": comm,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

@@ -17,7 +17,7 @@ import tinycudann as tcnn
 from nsr_hip import ops as _ops
 from nsr_hip import check as _check, lib as _lib, ptr as _ptr, stream_ptr as _stream_ptr
 
-from .parallel import all_reduce_gradients, broadcast_parameters, shard_seed
+from .parallel import ShardedAdamW, all_reduce_gradients, broadcast_parameters, shard_seed
 
 
 class FusedAdamW:
@@ -135,6 +135,9 @@ class Trainer:
         tc_params = {id(m.params) for m in tc}
         other = [p for p in model.parameters() if id(p) not in tc_params]
         self.opt = FusedAdamW(tc, other)
+        # world > 1: reduce-scatter -> AdamW on this rank's 1/P of the table -> all-gather of the fp16 image (nsr/parallel.py)
+        self.sharded = ShardedAdamW(tc) if (world_size > 1 and not other and dist.is_initialized()) else None
+        self.comm_timings = None
         self.last = {}
         self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None
         # use_graphs: replay the queued launches of a step from a captured HIP graph.  Correct (tests/test_gpu_fused.py)
@@ -151,8 +154,16 @@ class Trainer:
             self.opt.table_grad_overwritten = True
 
     def _all_reduce_grads(self):
-        if self.world_size > 1:
+        if self.world_size > 1 and self.sharded is None:
             all_reduce_gradients(list(self.model.parameters()))
+
+    def _optimizer_step(self, device_schedule):
+        if self.sharded is not None:  # the exchange is part of the step
+            self.sharded.step(lr_scale=multistep_lr_scale(self.global_step), timings=self.comm_timings)
+        elif device_schedule:
+            self.opt.step_device()
+        else:
+            self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
 
     def loss_fn(self, out, rgb, fg):
         valid = out["rays_valid"][..., 0]
@@ -180,7 +191,7 @@ class Trainer:
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
+            self._optimizer_step(False)
         self.global_step += 1
         self.last = {"loss": loss.detach(), "n_rays": rays.shape[0], "n_samples": n_samples}
         return self.last
@@ -249,7 +260,7 @@ class Trainer:
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            self.opt.step(lr_scale=multistep_lr_scale(self.global_step))
+            self._optimizer_step(False)
         self.global_step += 1
         self.last = {"loss": FusedNeRFStep.loss_value(res), "n_rays": n_live, "n_samples": n_samples}
         return self.last
@@ -423,7 +434,7 @@ class Trainer:
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            self.opt.step_device()
+            self._optimizer_step(True)
         a["last_step_event"] = torch.cuda.Event()
         a["last_step_event"].record(main)
         for key in [k for k in ev if k[1] < t - 2]:
@@ -520,7 +531,7 @@ class Trainer:
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            self.opt.step_device()
+            self._optimizer_step(True)
         if a["pending"]:
             main.wait_event(a["event"])  # join: the next step (or the grid refresh before it) starts behind the marching
         return res["loss_acc"]  # [sum, valid rays]: the loss value itself is formed on demand (LazyLoss)

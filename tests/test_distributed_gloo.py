@@ -132,3 +132,98 @@ def test_lazy_loss_refuses_stale_reads():
     tr.global_step = 8
     with pytest.raises(RuntimeError):
         float(loss)
+
+
+class _FakeTcnnModule(torch.nn.Module):
+    """what ShardedAdamW needs from a tinycudann module: one flat fp32 ``params`` and ``adopt_shadow``"""
+
+    def __init__(self, n, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.params = torch.nn.Parameter(torch.randn(n, generator=g) * 0.1)
+        self.shadow = None
+
+    def adopt_shadow(self, shadow):
+        self.shadow = shadow
+
+    def invalidate(self):
+        self.shadow = None
+
+
+def _sharded_worker(rank, world, port, out, transport):
+    for p in (ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nsr.parallel import ShardedAdamW
+    mods = [_FakeTcnnModule(70003, 7), _FakeTcnnModule(7168, 8)]  # ragged size: the last shard is short
+    opt = ShardedAdamW(mods, lr=0.01, transport=getattr(torch, transport))
+    grads = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        for m in mods:
+            m.params.grad.copy_(torch.randn(m.params.numel(), generator=g) * 10.0 ** float(torch.randint(-4, 0, (1,), generator=g)))
+        grads.append([m.params.grad.clone() for m in mods])
+        opt.step(lr_scale=0.33 ** (step >= 2))
+    shadows = [m.shadow.clone() for m in mods]
+    own = [m.params.detach().clone() for m in mods]
+    opt.gather_master()
+    torch.save({"grads": grads, "shadows": shadows, "own": own, "master": [m.params.detach().clone() for m in mods],
+                "wire_bytes": opt.wire_bytes}, os.path.join(out, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _reference_adamw(n_list, seeds, mean_grads, lr_scales):
+    ps = [torch.nn.Parameter(_FakeTcnnModule(n, s).params.detach().clone()) for n, s in zip(n_list, seeds)]
+    opt = torch.optim.AdamW(ps, lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+    for step, gs in enumerate(mean_grads):
+        for g_ in opt.param_groups:
+            g_["lr"] = 0.01 * lr_scales[step]
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        opt.step()
+    return [p.detach() for p in ps]
+
+
+def test_sharded_adamw_world4_matches_single_process_adamw_on_the_mean_gradient(tmp_path):
+    """reduce-scatter -> AdamW on each rank's shard -> all-gather of the fp16 image, world_size 4 over gloo: every rank ends
+    with the SAME fp16 image bit for bit, and (fp32 transport) it equals torch.optim.AdamW on the mean gradient"""
+    world, port = 4, _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), "float32"), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
+    for k in range(1, world):
+        for a, b in zip(r[0]["shadows"], r[k]["shadows"]):
+            assert torch.equal(a, b)                                  # replicas stay bit-identical after 3 steps
+        for a, b in zip(r[0]["master"], r[k]["master"]):
+            assert torch.equal(a, b)                                  # ... and so do the gathered fp32 masters
+    mean = [[sum(r[k]["grads"][s][i] for k in range(world)) / world for i in range(2)] for s in range(3)]
+    want = _reference_adamw([70003, 7168], [7, 8], mean, [1.0, 1.0, 0.33])
+    for got, w, sh in zip(r[0]["master"], want, r[0]["shadows"]):
+        assert torch.allclose(got, w, rtol=1e-5, atol=1e-7)
+        assert torch.equal(sh[:w.numel()], got.half())                # the image the kernels read = rounded master
+    # before the gather a rank's fp32 tensor is current only inside its own shard
+    S = -(-70003 // (world * 8)) * 8
+    assert torch.equal(r[1]["own"][0][S:2 * S], r[0]["master"][0][S:2 * S])
+    assert not torch.equal(r[1]["own"][0][:S], r[0]["master"][0][:S])
+    assert r[0]["wire_bytes"] == (S + -(-7168 // (world * 8)) * 8) * (world - 1) * (4 + 2)
+
+
+def test_sharded_adamw_bf16_transport_stays_in_step(tmp_path):
+    """the default wire format: bf16 gradients (fp32 range: no scale, no overflow), fp16 image back"""
+    world, port = 2, _free_port()
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), "bfloat16"), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
+    for a, b in zip(r[0]["shadows"], r[1]["shadows"]):
+        assert torch.equal(a, b)
+    mean = [[sum(r[k]["grads"][s][i] for k in range(world)) / world for i in range(2)] for s in range(3)]
+    want = _reference_adamw([70003, 7168], [7, 8], mean, [1.0, 1.0, 0.33])
+    for got, w in zip(r[0]["master"], want):
+        # Adam normalises the step (eps = 1e-15: the first step is lr * sign(g)): a bf16-rounded gradient moves a parameter
+        # by ~lr * 2^-8 differently per step -- except where the ranks' gradients cancel to within the rounding and the
+        # SIGN of the mean is decided by it (a full lr step, a handful of entries)
+        dev = (got - w).abs()
+        assert float(dev.mean()) < 1e-4 and float(dev.max()) <= 3 * 0.0101
+        assert float((dev > 3 * 0.01 * 2 ** -7).float().mean()) < 5e-3
