@@ -29,13 +29,13 @@ for _ in range(args.steps):
     tr.train_step()
 c = tr.counters(); dt = time.perf_counter() - t0
 model.eval()
-model.background_color = torch.ones(3, device=dev)
+from nsr.export import render_rays
 psnrs = []
 with torch.no_grad():
     for i in range(args.test_views):
         o, d = get_rays(test.directions.view(-1, 3), test.all_c2w[i:i + 1].expand(args.res * args.res, -1, -1))
         rays = torch.cat([o, torch.nn.functional.normalize(d, p=2, dim=-1)], -1)
-        out = model(rays)
+        out = render_rays(tr.fused, rays)  # eval-mode chunked render (ray_chunk pieces, results on the CPU)
         fg = test.all_fg_masks[i].view(-1, 1)
         gt = test.all_images[i].view(-1, 3) * fg + (1 - fg)
         mse = torch.mean((out["comp_rgb"].to(dev).clamp(0, 1) - gt) ** 2)  # chunk_batch offloads to the CPU like the reference
