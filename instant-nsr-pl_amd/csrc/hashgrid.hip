@@ -11,8 +11,13 @@
 //     eight L2s with the whole 24 MiB table.  Placement is a speed assumption only, never correctness.
 //   * level geometry (scale/resolution/size/offset) arrives precomputed in fp32 from the host
 //     (NsrGridDesc) and is read through scalar loads (block-uniform level).
-//   * gradients are accumulated with hardware fp32 atomics (global_atomic_add_f32) straight into the
-//     fp32 gradient of the flat parameter -- no fp16 atomics, no loss-scale hack.
+//   * table gradients: NO global float atomics on the default path.  (sample, corner-pair) items are binned by the
+//     owning slice of a level's gradient; a workgroup accumulates only its own items into a 128 KiB LDS slice in Q27.36
+//     fixed point (64-bit integer LDS atomics) and stores the slice once as fp32 ("owner computes", see below).  The
+//     one-lane-per-(sample, level) kernel with global_atomic_add_f32 is kept for the API without a workspace.
+//   * the forward optionally keeps the per-level Jacobian d y / d x (k_grid_forward with `jac`) so that the analytic
+//     NeuS normal and its double backward are dense products instead of a second and a third table gather, and
+//     k_grid_forward_taps encodes a sample together with its six finite-difference taps from shared corner loads.
 #include <string.h>
 
 #include "nsr_common.h"
@@ -364,7 +369,10 @@ constexpr int OWN_BLOCK = NSR_OWN_BLOCK;
 constexpr int OWN_POW2_LOG2 = NSR_OWN_LOG2;            // hashed levels: 8192-entry slices (128 KiB at F=2) -> owner = hash bits
 constexpr int OWN_LDS_WORDS = 2 << NSR_OWN_LOG2;       // 64-bit accumulators (measured: 2^13 119 us, 2^12 133 us, 2^11 124 us)
 constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decomposition aims for
-constexpr int OWN_DENSE_TARGET_WGS = 64; // ... for the dense (coarse) levels: every sample lands in few entries and the
+#ifndef NSR_OWN_DENSE_WGS
+#define NSR_OWN_DENSE_WGS 64
+#endif
+constexpr int OWN_DENSE_TARGET_WGS = NSR_OWN_DENSE_WGS; // ... for the dense (coarse) levels: every sample lands in few entries and the
                                          // workgroups serialise on LDS conflicts -- more, smaller item chunks
                                          // (measured at 1.28e5 surface samples: 32 -> 185 us, 64 -> 177 us, 128 -> 198 us)
 constexpr int OWN_MAX_SLICES = 2048;    // per level (T = 2^24 at 8192-entry slices)
@@ -569,6 +577,79 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         const float *dyf = dy_first_lm ? dy_first_lm + (uint64_t)level * n * F : nullptr;
         const float fix = grad_scale * OWN_FIX_SCALE;
         constexpr int OWN_BATCH = 2;  // items in flight per lane: item -> (x, dy) is a dependent load chain
+        if (g.dense && !dir) {
+            // Dense (coarse) levels: the binning passes lay the items of a slice down in runs of 64 CONSECUTIVE samples of
+            // one corner pair, and consecutive samples of a ray sit in the same coarse cell for tens of steps -- handing a
+            // wave 64 consecutive items makes its lanes hit the same two LDS words (64-way serialised atomics; DESIGN
+            // section 7.2: levels 0-4 cost half of the kernel).  Here every THREAD walks a contiguous range of items and
+            // keeps a run accumulator per corner in registers: one LDS atomic per (run, feature) instead of one per
+            // (item, feature), and the lanes of a wave work on ranges that are far apart (different cells).
+            const uint32_t m_c = i_end - i_beg, q = (m_c + OWN_BLOCK - 1) / OWN_BLOCK;
+            const uint32_t j0 = min(i_end, i_beg + threadIdx.x * q), j1 = min(i_end, j0 + q);
+            uint32_t key_lo = 0xffffffffu, key_hi = 0xffffffffu;
+            float run_lo[F], run_hi[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) run_lo[f] = run_hi[f] = 0.f;
+            for (uint32_t jb = j0; jb < j1; jb += OWN_BATCH) {
+                uint32_t word[OWN_BATCH];
+                float gb[OWN_BATCH][F], xb[OWN_BATCH][3];
+#pragma unroll
+                for (int u = 0; u < OWN_BATCH; ++u) word[u] = jb + u < j1 ? it[jb + u] : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < OWN_BATCH; ++u) {
+                    const uint32_t s = word[u] != 0xffffffffu ? word[u] >> 4 : 0u;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) gb[u][f] = dyl[(uint64_t)s * F + f];
+                    xb[u][0] = x[3ull * s]; xb[u][1] = x[3ull * s + 1]; xb[u][2] = x[3ull * s + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < OWN_BATCH; ++u) {
+                    if (word[u] == 0xffffffffu) continue;
+                    const int k = (word[u] >> 2) & 3;
+                    const uint32_t mode = word[u] & 3u;
+                    const Cell c = locate(g, xb[u][0], xb[u][1], xb[u][2]);
+                    const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
+                    const float a12 = ((k & 1) ? c.w[1] : 1.f - c.w[1]) * ((k & 2) ? c.w[2] : 1.f - c.w[2]);
+                    const float w_lo = (1.f - c.w[0]) * a12, w_hi = c.w[0] * a12;
+                    const uint32_t e_lo = mode != 2u ? corner_index(g, c.c[0], cy, cz) - r0 : 0xffffffffu;
+                    const uint32_t e_hi = mode != 1u ? corner_index(g, c.c[0] + 1u, cy, cz) - r0 : 0xffffffffu;
+                    float v[F];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        if (!isfinite(gb[u][f])) s_nonfinite = 1u;
+                        v[f] = fminf(fmaxf(gb[u][f] * fix, -4.6e18f), 4.6e18f);
+                    }
+                    if (e_lo != key_lo) {
+                        if (key_lo != 0xffffffffu) {
+#pragma unroll
+                            for (int f = 0; f < F; ++f) atomicAdd(&acc[key_lo * F + f], own_to_fixed(fminf(fmaxf(run_lo[f], -4.6e18f), 4.6e18f)));
+                        }
+                        key_lo = e_lo;
+#pragma unroll
+                        for (int f = 0; f < F; ++f) run_lo[f] = 0.f;
+                    }
+                    if (e_hi != key_hi) {
+                        if (key_hi != 0xffffffffu) {
+#pragma unroll
+                            for (int f = 0; f < F; ++f) atomicAdd(&acc[key_hi * F + f], own_to_fixed(fminf(fmaxf(run_hi[f], -4.6e18f), 4.6e18f)));
+                        }
+                        key_hi = e_hi;
+#pragma unroll
+                        for (int f = 0; f < F; ++f) run_hi[f] = 0.f;
+                    }
+#pragma unroll
+                    for (int f = 0; f < F; ++f) { run_lo[f] += w_lo * v[f]; run_hi[f] += w_hi * v[f]; }
+                }
+            }
+            if (key_lo != 0xffffffffu) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[key_lo * F + f], own_to_fixed(fminf(fmaxf(run_lo[f], -4.6e18f), 4.6e18f)));
+            }
+            if (key_hi != 0xffffffffu) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(&acc[key_hi * F + f], own_to_fixed(fminf(fmaxf(run_hi[f], -4.6e18f), 4.6e18f)));
+            }
+        } else
         for (uint32_t i0 = i_beg + threadIdx.x; i0 < i_end; i0 += OWN_BLOCK * OWN_BATCH) {
             uint32_t word[OWN_BATCH];
             float gb[OWN_BATCH][F], gf[OWN_BATCH][F], xb[OWN_BATCH][3];

@@ -13,12 +13,12 @@
 //   * a wavefront owns all weights of the net in VGPRs (A fragments, permuted by sigma at load time:
 //     72 VGPRs for 32->64->64->16) and streams 16-sample tiles through them (grid-stride).
 //   * fp16 weights/activations, fp32 accumulation (tcnn accumulates in fp16).
-//   * backward: dgrad uses the same trick with W^T fragments; wgrad (dW = dY^T . X, reduction over
-//     samples) needs the sample index on the MFMA k axis, i.e. a 16x16 transpose of what the lanes
-//     hold -- done through a small per-wave LDS tile (b16 scatter, b64 gather), v_mfma_f32_16x16x16_f16
-//     with K = the 16 samples of the tile, dW accumulated in fp32 VGPRs over all tiles of the wave,
-//     reduced across the block with ds_add_f32, written as one fp32 partial per block and summed by a
-//     tiny second kernel (deterministic, no global atomics).
+//   * backward: a dgrad kernel (the same trick with W^T fragments; writes dX and the pre-activation gradients of every
+//     layer column-blocked) and one wgrad kernel per weight matrix: dW = dY^T . X needs the SAMPLE index on the MFMA k
+//     axis, so 32-sample tiles go through v_mfma_f32_16x16x32_f16 with K = the samples (fragments loaded straight from
+//     the column-blocked buffers, 16-B loads); dW accumulates in fp32 VGPRs over all tiles of a wave, the waves of a
+//     block meet through per-wave LDS regions and plain loads (NO LDS float atomics: ds_add_f32 retires 0.33 lane-ops
+//     per clock on gfx950), one fp32 partial per block, summed by k_reduce_partials.
 #include "nsr_common.h"
 
 namespace {
@@ -270,14 +270,16 @@ k_mlp_forward(const void *__restrict__ x, int x_f32, uint32_t x_stride, const __
 // backward = dgrad kernel + one wgrad kernel per weight matrix
 //
 // A single fused dgrad+wgrad kernel needed 252 VGPRs + accumulators (1 wave/SIMD, 171 blocks) and measured
-// 23 % issue / 35 % dependency stalls / 41 % memory waits (profiles/r01_pmc_mlp_backward.txt).  Split:
+// 23 % issue / 35 % dependency stalls / 41 % memory waits in a round-1 PMC pass (SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY /
+// SQ_INSTS_VALU; summarised in DESIGN.md section 4).  Split:
 //   k_mlp_dgrad : same register-resident transposed chain as the forward (W^T fragments staged through LDS), one
 //                 16-sample tile per wave, no accumulators -> many waves in flight.  Writes dX and, for the wgrad
 //                 kernels, the pre-activation gradients of every layer (fp16, [n,64] rows; [n,16] for the output).
 //   k_mlp_wgrad : dW[o][k] = sum_n G[n][o] A[n][k] as v_mfma_f32_16x16x32_f16 with the SAMPLE index on the MFMA k
 //                 axis: 32-sample tiles are loaded row-major (64 B per lane, coalesced), transposed through a per-wave
 //                 LDS tile (b16 scatter, b128 gather), accumulated in fp32 VGPRs over the wave's tiles, reduced over
-//                 the block with ds_add_f32 and written as one partial per block (summed by k_reduce_partials).
+//                 the block through per-wave LDS regions + plain loads (no LDS float atomics) and written as one partial
+//                 per block (summed by k_reduce_partials).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_wave_sync()
 {

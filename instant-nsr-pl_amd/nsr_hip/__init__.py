@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnsr_hip.so")
+# NSR_HIP_LIB: developer switch for A/B runs of differently tuned builds (csrc/build.sh <outdir> with NSR_EXTRA_FLAGS)
+LIB_PATH = os.environ.get("NSR_HIP_LIB") or os.path.join(_HERE, "libnsr_hip.so")
 
 NSR_MAX_LEVELS = 32
 ABI_VERSION = 1
