@@ -49,8 +49,8 @@ def cpu_baseline(seconds_budget=12.0):
     from oracle import tcnn_ref, vanilla_ref
     import nsr
     cfg = nsr.configs.get("nerf-blender")
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
+    cores = int(os.environ.get("NSR_CPU_BASELINE_THREADS", min(os.cpu_count(), 64)))  # measured on the 256-thread GPU box:
+    torch.set_num_threads(cores)  # all 256 threads oversubscribe torch's intra-op pool (1e4 samples/s); see profiles/
     n = 1 << 18
     g = torch.Generator().manual_seed(0)
     x = torch.rand(n, 3, generator=g)
@@ -81,7 +81,7 @@ def cpu_baseline(seconds_budget=12.0):
         (rgb.sum() + feat[:, 0].sum()).backward()
 
     reps_b, dt_b = _time_loop(step_b, seconds_budget, 20)
-    return {"value": n * reps_a / dt_a, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": n * reps_a / dt_a, "unit": "samples/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{reps_a} x 2^18 uniform samples, VanillaFrequency(10)+xyz -> VanillaMLP(64x1) -> 16, SH4, "
                       f"VanillaMLP(64x2) -> rgb, forward + backward, fp32 torch on {cores} host threads "
                       f"(oracle/vanilla_ref.py = models/network_utils.py:14-37,95-139)",
