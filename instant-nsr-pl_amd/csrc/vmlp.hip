@@ -33,6 +33,13 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+#ifndef NSR_VMLP_RELOAD
+#define NSR_VMLP_RELOAD 0
+#endif
+#ifndef NSR_VMLP_WAVES
+#define NSR_VMLP_WAVES 1
+#endif
+constexpr bool VMLP_RELOAD_WEIGHTS = NSR_VMLP_RELOAD != 0;  // backward: re-load the weight fragments per tile (fewer registers)
 constexpr int W = 64;        // hidden width
 constexpr int LDT = 68;      // LDS tile row stride for 64-column tiles (floats)
 constexpr int LDX = 52;      // LDS tile row stride for input tiles (<= 48 columns)
@@ -226,7 +233,7 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 
 // One wave per block: forward recompute + data gradient + weight gradient (+ second-order terms) of its tiles.
 template <int KS, int NH, int ACT, bool SDF_IN, bool SECOND>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, NSR_VMLP_WAVES)
 k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uint32_t x_stride,
                 const __half *__restrict__ enc, uint32_t enc_stride, uint32_t n_in,
                 const float *__restrict__ d_out /* [n_full][16] */, const float *__restrict__ d_out_col0,
@@ -304,7 +311,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
         // two hidden layers: ~250 loop-invariant weight fragments would be hoisted into registers and spilled; re-load the
         // (L1-resident, 37 KB) matrices per tile instead by hiding the pointers' loop invariance from the compiler
         const float *W0t = B.W0, *W1t = B.W1, *Wlt = B.Wl;
-        if constexpr (NH == 2) {
+        if constexpr (NH == 2 || VMLP_RELOAD_WEIGHTS) {
             asm volatile("" : "+s"(W0t), "+s"(W1t), "+s"(Wlt));
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
