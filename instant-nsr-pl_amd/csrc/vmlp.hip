@@ -188,16 +188,31 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[mb][r] = act_fwd<ACT>(z1[mb][r]);
         }
-        f32x4 o = blf;
+        if ((uint64_t)tile * 16 >= n_full) {
+            // a tile of finite-difference taps: only out[0] = u . a + bl[0] is asked for -- 16 FMAs on the lane's own 16
+            // neurons and a 4-lane reduction instead of the 16 MFMAs of the output layer
+            float part = 0.f;
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(B.Wl + mb * 16 + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o = mfma4(wlf[ib][r], a[ib][r], o);
-        if (valid) {
-            if (s < n_full) {
-                *reinterpret_cast<f32x4 *>(out + s * 16 + 4 * g) = o;
-            } else if (g == 0) {
-                out_col0[s - n_full] = o[0];
+                for (int r = 0; r < 4; ++r) part = fmaf(u[r], a[mb][r], part);
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (valid && g == 0) out_col0[s - n_full] = part + B.bl[0];
+        } else {
+            f32x4 o = blf;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = mfma4(wlf[ib][r], a[ib][r], o);
+            if (valid) {
+                if (s < n_full) {
+                    *reinterpret_cast<f32x4 *>(out + s * 16 + 4 * g) = o;
+                } else if (g == 0) {
+                    out_col0[s - n_full] = o[0];
+                }
             }
         }
         if (GRAD_IN) {  // d out[0] / d input = W0^T (act'(z) * Wl[0][:])   (1 hidden layer)
@@ -299,8 +314,9 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             if (sn < n_full) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) dd[kk] = d_out[sn * 16 + 4 * kk + g];
-            } else if (g == 0) {
-                dd[0] = d_out_col0[sn - n_full];
+            } else {
+                dd[3] = d_out_col0[sn - n_full];   // every lane of the sample: the tap fast path reads it from slot 3
+                if (g == 0) dd[0] = dd[3];         // B-layout slot of output column 0
             }
         }
     };
@@ -348,9 +364,23 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             }
         }
         // ---- output gradient in B layout: lane (g,c) holds d_out[sample c][4kk + g] -------------------------------
+        const bool tap_tile = (uint64_t)tile * 16 >= n_full;  // finite-difference taps: only d out[0] is non-zero
+        const float d_tap = tap_tile ? dob[3] : 0.f;
+        if (s >= n_full) dob[3] = 0.f;  // (slot 3 carried the tap's scalar; as an output-gradient slot it is column 12 + g: zero)
         dblv += dob;
         // dA_last^T = Wl^T . dOut^T   (A: Wl[4kk + g][fb*16 + c])
         f32x4 dz_last[4];
+        if (tap_tile) {
+            // rank-1 output gradient: dz = act'(z) * Wl[0][:] * d, and dWl row 0 += d * a -- per-lane products on the D
+            // layout (the row-0 sum joins accWl at the end like the second-order du does): no MFMA, no LDS round trip
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dz_last[fb][r] = d_tap * uf[fb][r] * ((NH == 2) ? act_bwd<ACT>(z1[fb][r]) : s0[fb][r]);
+                    du[fb][r] += d_tap * ((NH == 2) ? a1[fb][r] : a0[fb][r]);
+                }
+        } else {
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
             f32x4 acc = zero4;
@@ -373,6 +403,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) accWl[nb] = mfma4(ao, T_a[(4 * kk + g) * LDT + nb * 16 + c], accWl[nb]);
         }
+        }  // !tap_tile
         f32x4 dz0[4];
         if constexpr (NH == 2) {
             // dW1[i][j] += sum_s dz1[i][s] a0[j][s] ;  db1 ;  dA0^T = W1^T dz1^T ; dz0 = dA0 * act'(z0)
@@ -532,7 +563,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             for (int o = 8; o > 0; o >>= 1) {
                 v0 += __shfl_xor(v0, o, 64);
                 if (NH == 2) v1 += __shfl_xor(v1, o, 64);
-                if (SECOND) v2 += __shfl_xor(v2, o, 64);
+                v2 += __shfl_xor(v2, o, 64);
             }
             db0[mb][r] = v0; db1[mb][r] = v1; du[mb][r] = v2;
         }
@@ -545,8 +576,8 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                 if (NH == 2) pb1[mb * 16 + 4 * g + r] = db1[mb][r];
             }
     }
-    // dWl (rows o = 4g + r, columns nb*16 + c); the second-order du (held per neuron in D layout) joins row 0
-    if (SECOND) {
+    // dWl (rows o = 4g + r, columns nb*16 + c); the per-neuron row-0 sums held in D layout (second-order du, tap tiles) join row 0
+    {
         lds_wave_sync();
         if (c == 0) {
 #pragma unroll
