@@ -122,6 +122,11 @@ int nsr_hashgrid_backward_backward_input_ws(const float *x, const nsr_half *tabl
                                             float *grad_table, float *dx2, float *workspace, uint32_t n,
                                             uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
 
+/* A/B switch of the forward's decomposition (process-wide, for measurements; default (0, 1)): lds_levels = leading small
+ * dense levels (<= 16384 entries) encoded from an LDS copy of their table by persistent workgroups; levels_per_lane = 2:
+ * one lane encodes both levels {l, l + 8} its XCD owns.  Results are identical bit for bit. */
+int nsr_hashgrid_forward_variant(int lds_levels, int levels_per_lane);
+
 /* Forward that also stores the Jacobian d y / d x per level (jac: level-major fp32 [L][n][F][3], zero on masked levels) from
  * the corner values it already holds, and the two dense products the analytic normal needs from it
  * (models/geometry.py:176-180): dx = J^T dy (first-order input gradient) and d_dy = J g (its double backward) --
@@ -147,7 +152,8 @@ int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *
 int nsr_hashgrid_backward_params_owner_with_second_order(const float *x, const float *dy_first_lm, const float *dy,
                                                          uint32_t dy_stride, const float *g, float *grad_table,
                                                          float *workspace, uint32_t n, uint32_t level_mask_count,
-                                                         int accumulate, const NsrGridDesc *desc, void *stream);
+                                                         int accumulate, int binned, const NsrGridDesc *desc, void *stream);
+/* binned != 0: nsr_hashgrid_backward_params_owner_bin already ran on these positions into `workspace` */
 
 /* ------------------------------------------------------------------------------------------------
  * Spherical harmonics degree 4 -- replaces tcnn.Encoding(SphericalHarmonics), models/texture.py:25

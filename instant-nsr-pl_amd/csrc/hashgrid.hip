@@ -127,10 +127,12 @@ template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
                uint32_t y_stride, uint32_t mask_count, uint32_t lpx, int level_major, const NsrGridDesc d,
-               const int32_t *__restrict__ n_dev, float *__restrict__ jac /* [L][n][F][3] d y / d x, or NULL */)
+               const int32_t *__restrict__ n_dev, float *__restrict__ jac /* [L][n][F][3] d y / d x, or NULL */,
+               uint32_t level_begin /* levels below it are produced by k_grid_forward_lds */)
 {
     uint32_t level, blk;
     if (!map_block(d.n_levels, lpx, level, blk)) return;
+    if (level < level_begin) return;
     const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
     if (i >= live_count(n, n_dev)) return;
     // row-major [n, y_stride] is what the tcnn API returns; level-major [L][n][F] is what the fused path uses: a wave
@@ -205,6 +207,135 @@ k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __
 #pragma unroll
         for (int f = 0; f < F; f += 2)
             *reinterpret_cast<__half2 *>(yo + f) = __floats2half2_rn(acc[f], acc[f + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward variants for the A/B the north-star asks for (profiles/r02_forward_ab.json):
+//   * k_grid_forward_lds : the table of a small dense level (<= 16384 entries: 64 KB at F = 2) is staged in LDS by a
+//     persistent workgroup that then encodes a contiguous chunk of samples for that level from LDS;
+//   * k_grid_forward_pair: one lane encodes BOTH levels its XCD owns (l and l + 8): x is loaded once, 16 gathers in flight.
+// Selected at run time by nsr_hashgrid_forward_variant(); the default (0, 1) is the kernel above.
+// ------------------------------------------------------------------------------------------------
+template <int F>
+__device__ __forceinline__ void encode_level_from(const __half *__restrict__ tbl /* level base, global or LDS */,
+                                                  const LevelGeom &g, float x0, float x1, float x2, float (&acc)[F])
+{
+    const Cell c = locate(g, x0, x1, x2);
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t e = corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1));
+        float v[F];
+        load_feat<F>(tbl, e, v);
+        float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
+        w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
+        w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[f], acc[f]);
+    }
+}
+
+template <int F>
+__device__ __forceinline__ void store_enc(__half *yo, const float (&acc)[F])
+{
+    if constexpr (F == 1) {
+        yo[0] = __float2half_rn(acc[0]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; f += 2) *reinterpret_cast<__half2 *>(yo + f) = __floats2half2_rn(acc[f], acc[f + 1]);
+    }
+}
+
+constexpr int LDS_FWD_BLOCK = 1024;
+template <int F>
+__global__ void __launch_bounds__(LDS_FWD_BLOCK)
+k_grid_forward_lds(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
+                   uint32_t y_stride, uint32_t mask_count, int level_major, uint32_t blocks_per_level,
+                   const NsrGridDesc d, const int32_t *__restrict__ n_dev)
+{
+    extern __shared__ __attribute__((aligned(16))) __half lds_table[];
+    const uint32_t level = blockIdx.x / blocks_per_level, part = blockIdx.x % blocks_per_level;
+    const uint32_t n_live = live_count(n, n_dev);
+    const LevelGeom g = load_level(d, level);
+    if (level < mask_count) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(table + (uint64_t)g.offset * F);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_table);
+        const uint32_t n16 = (g.size * F * 2 + 15) / 16;  // level sizes are multiples of 8 entries
+        for (uint32_t k = threadIdx.x; k < n16; k += LDS_FWD_BLOCK) dst[k] = src[k];
+    }
+    __syncthreads();
+    const uint32_t per = (n_live + blocks_per_level - 1) / blocks_per_level;
+    const uint32_t i0 = part * per, i1 = min(n_live, i0 + per);
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += LDS_FWD_BLOCK) {
+        float acc[F];
+        if (level < mask_count) {
+            encode_level_from<F>(lds_table, g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2], acc);
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = 0.f;
+        }
+        store_enc<F>(level_major ? y + ((uint64_t)level * n + i) * F : y + (uint64_t)i * y_stride + level * F, acc);
+    }
+}
+
+// blocks b with (b & 7) = xcd, q = b >> 3: both levels {xcd, xcd + 8} of sample block q (levels < level_begin skipped)
+template <int F>
+__global__ void __launch_bounds__(GRID_BLOCK)
+k_grid_forward_pair(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
+                    uint32_t y_stride, uint32_t mask_count, uint32_t level_begin, int level_major, const NsrGridDesc d,
+                    const int32_t *__restrict__ n_dev)
+{
+    const uint32_t xcd = blockIdx.x & 7u, blk = blockIdx.x >> 3;
+    const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
+    if (i >= live_count(n, n_dev)) return;
+    const float x0 = x[3ull * i], x1 = x[3ull * i + 1], x2 = x[3ull * i + 2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t level = xcd + 8u * h;
+        if (level >= d.n_levels || level < level_begin) continue;
+        float acc[F];
+        if (level < mask_count) {
+            const LevelGeom g = load_level(d, level);
+            const Cell c = locate(g, x0, x1, x2);
+            const __half *tbl = table + (uint64_t)g.offset * F;
+            float v[8][F];
+            bool paired = false;
+            if constexpr (F == 2) {  // same paired 8-B gathers as k_grid_forward
+                paired = !g.dense && !(c.c[0] & 1u);
+                if (paired) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t e0 = corner_index(g, c.c[0], c.c[1] + (j & 1), c.c[2] + (j >> 1));
+                        const uint2 raw = *reinterpret_cast<const uint2 *>(tbl + (uint64_t)(e0 & ~1u) * 2);
+                        const __half2 lo = *reinterpret_cast<const __half2 *>(&raw.x), hi = *reinterpret_cast<const __half2 *>(&raw.y);
+                        const __half2 a = (e0 & 1u) ? hi : lo, b = (e0 & 1u) ? lo : hi;
+                        v[2 * j][0] = __low2float(a); v[2 * j][1] = __high2float(a);
+                        v[2 * j + 1][0] = __low2float(b); v[2 * j + 1][1] = __high2float(b);
+                    }
+                }
+            }
+            if (!paired) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    load_feat<F>(tbl, corner_index(g, c.c[0] + (k & 1), c.c[1] + ((k >> 1) & 1), c.c[2] + ((k >> 2) & 1)), v[k]);
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float w = (k & 1) ? c.w[0] : 1.f - c.w[0];
+                w *= (k & 2) ? c.w[1] : 1.f - c.w[1];
+                w *= (k & 4) ? c.w[2] : 1.f - c.w[2];
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[k][f], acc[f]);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = 0.f;
+        }
+        store_enc<F>(level_major ? y + ((uint64_t)level * n + i) * F : y + (uint64_t)i * y_stride + level * F, acc);
     }
 }
 
@@ -1006,6 +1137,16 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
                                        int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
                                        const int32_t *n_dev, void *stream);
 
+static int g_fwd_lds_levels = 0, g_fwd_levels_per_lane = 1;
+extern "C" int nsr_hashgrid_forward_variant(int lds_levels, int levels_per_lane)
+{
+    NSR_REQUIRE(lds_levels >= 0 && lds_levels <= 4 && (levels_per_lane == 1 || levels_per_lane == 2),
+                "nsr_hashgrid_forward_variant: lds_levels 0..4, levels_per_lane 1 or 2");
+    g_fwd_lds_levels = lds_levels;
+    g_fwd_levels_per_lane = levels_per_lane;
+    return NSR_OK;
+}
+
 extern "C" int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                                     uint32_t level_mask_count, const NsrGridDesc *desc, void *stream)
 {
@@ -1022,10 +1163,38 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
     NSR_REQUIRE(x && table && y, "nsr_hashgrid_forward: NULL pointer");
     const uint32_t lpx = (desc->n_levels + 7) / 8;
     const uint32_t grid = 8u * lpx * nsr_div_up(n, GRID_BLOCK);
+    uint32_t level_begin = 0;
+    if (g_fwd_lds_levels > 0) {  // A/B variant: leading small dense levels from LDS
+        while (level_begin < (uint32_t)g_fwd_lds_levels && level_begin < desc->n_levels &&
+               desc->size[level_begin] <= 16384u &&
+               (uint64_t)desc->resolution[level_begin] * desc->resolution[level_begin] * desc->resolution[level_begin] <=
+                   desc->size[level_begin])
+            ++level_begin;
+        if (level_begin > 0) {
+            const uint32_t bpl = 128;
+            uint32_t max_size = 0;
+            for (uint32_t l = 0; l < level_begin; ++l) max_size = desc->size[l] > max_size ? desc->size[l] : max_size;
+            const size_t lds = (size_t)max_size * desc->n_features * 2;
+            DISPATCH_F(desc->n_features, {
+                (void)hipFuncSetAttribute((const void *)k_grid_forward_lds<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((k_grid_forward_lds<F>), dim3(bpl * level_begin), dim3(LDS_FWD_BLOCK), lds,
+                                   (hipStream_t)stream, x, (const __half *)table, (__half *)y, n, y_stride,
+                                   level_mask_count, y_level_major, bpl, *desc, n_dev);
+            });
+        }
+    }
+    if (g_fwd_levels_per_lane == 2 && desc->n_levels <= 16) {
+        DISPATCH_F(desc->n_features,
+                   hipLaunchKernelGGL((k_grid_forward_pair<F>), dim3(8u * nsr_div_up(n, GRID_BLOCK)), dim3(GRID_BLOCK), 0,
+                                      (hipStream_t)stream, x, (const __half *)table, (__half *)y, n, y_stride,
+                                      level_mask_count, level_begin, y_level_major, *desc, n_dev));
+        NSR_CHECK_LAUNCH("nsr_hashgrid_forward(pair)");
+        return NSR_OK;
+    }
     DISPATCH_F(desc->n_features,
                hipLaunchKernelGGL((k_grid_forward<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
                                   (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
-                                  *desc, n_dev, (float *)nullptr));
+                                  *desc, n_dev, (float *)nullptr, level_begin));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward");
     return NSR_OK;
 }
@@ -1043,7 +1212,7 @@ extern "C" int nsr_hashgrid_forward_jac(const float *x, const nsr_half *table, n
     DISPATCH_F(desc->n_features,
                hipLaunchKernelGGL((k_grid_forward<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x,
                                   (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
-                                  *desc, n_dev, jac));
+                                  *desc, n_dev, jac, 0u));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward_jac");
     return NSR_OK;
 }
@@ -1265,11 +1434,13 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order(const float 
                                                                     const float *dy, uint32_t dy_stride, const float *g,
                                                                     float *grad_table, float *workspace, uint32_t n,
                                                                     uint32_t level_mask_count, int accumulate,
-                                                                    const NsrGridDesc *desc, void *stream)
+                                                                    int binned, const NsrGridDesc *desc, void *stream)
 {
     NSR_REQUIRE(n == 0 || (dy_first_lm && dy && g), "nsr_hashgrid_backward_params_owner_with_second_order: NULL pointer");
+    // binned != 0: the items of these positions are already in `workspace` (nsr_hashgrid_backward_params_owner_bin, e.g.
+    // queued on a helper stream right after the positions were formed)
     return owner_backward(x, dy, 1, dy_stride, grad_table, workspace, n, level_mask_count, 1.f, accumulate, desc, nullptr,
-                          3, stream, g, dy_first_lm);
+                          binned ? 2 : 3, stream, g, dy_first_lm);
 }
 
 extern "C" int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,

@@ -198,6 +198,25 @@ class FusedNeuSStep:
             check(lib.nsr_neus_points(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), self.radius, eps, int(self.fd),
                                       ptr(x7), ptr(dirs), N, None, s), "nsr_neus_points")
             table = enc.table_half(enc.params)
+            gws = bin_event = None
+            if compute_grads and N > 0:
+                # the table backward's binning needs only the positions: it runs on a helper stream underneath the whole
+                # forward pass (count / scan / fill: 0.18 ms at 5e5 points, 0.5 ms at the 7 N points of the C5 stencil)
+                nws = int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), T * N))
+                gws = torch.empty(nws, dtype=F32, device=dev)
+                if getattr(self, "_helper", None) is None:
+                    self._helper = torch.cuda.Stream(device=dev)
+                main = torch.cuda.current_stream()
+                ready = torch.cuda.Event()
+                ready.record(main)
+                self._helper.wait_event(ready)
+                with torch.cuda.stream(self._helper):
+                    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x7), ptr(gws), T * N, mc, _byref(desc), None,
+                                                                     stream_ptr()), "nsr_hashgrid_backward_params_owner_bin")
+                    bin_event = torch.cuda.Event()
+                    bin_event.record(self._helper)
+                gws.record_stream(self._helper)
+                x7.record_stream(self._helper)
             # row-major encoding [T N][C] (masked levels: zero columns).  Measured: the level-major layout saves 36 us (plain) /
             # 131 us (taps) in the encode kernels' stores but costs the MFMA kernels 180 / 660 us -- their per-sample
             # operand loads then touch 16 cache lines instead of one 64-B row
@@ -311,8 +330,6 @@ class FusedNeuSStep:
             if enc.params.grad is None:
                 enc.params.grad = torch.zeros_like(enc.params)
             g_table = enc.params.grad
-            nws = int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), T * N))
-            gws = torch.empty(nws, dtype=F32, device=dev)
             # analytic normals: the encoder's input gradient is differentiated again -- d_dy = J gx joins p_in (what flows on
             # into the SDF network), the second-order table gradient is added after the first-order one below
             # SDF network backward: d enc (level-major, what the owner-computes table backward reads), dW
@@ -325,13 +342,14 @@ class FusedNeuSStep:
             check(lib.nsr_vmlp_backward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(d_out),
                                         ptr(d_taps), ptr(p_in), ptr(d_enc), 0, 3, C, F, ptr(g_sdf), 0, ptr(ws), T * N, N,
                                         None, s), "nsr_vmlp_backward(sdf)")
+            torch.cuda.current_stream().wait_event(bin_event)  # the items are binned (helper stream)
             if self.fd:
-                check(lib.nsr_hashgrid_backward_params_owner(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws), T * N, mc,
-                                                             1.0, 0, _byref(desc), None, s),
-                      "nsr_hashgrid_backward_params_owner")
-            else:  # first- and second-order table gradients share their items: one binning + accumulation pass
+                check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws),
+                                                                        T * N, mc, 1.0, 0, _byref(desc), None, s),
+                      "nsr_hashgrid_backward_params_owner_accumulate")
+            else:  # first- and second-order table gradients share their items: one accumulation pass
                 check(lib.nsr_hashgrid_backward_params_owner_with_second_order(
-                    ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(g_table), ptr(gws), N, mc, 0, _byref(desc), s),
+                    ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(g_table), ptr(gws), N, mc, 0, 1, _byref(desc), s),
                     "nsr_hashgrid_backward_params_owner_with_second_order")
         # weight norm / bias gradients through the host-side fold
         self.sdf.push_gradient(g_sdf)

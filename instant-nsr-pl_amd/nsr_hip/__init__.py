@@ -86,10 +86,11 @@ SIGNATURES = {
     "nsr_hashgrid_backward_input": [_P, _P, _P, _I, _U, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_backward_input": [_P, _P, _P, _I, _U, _P, _P, _U, _P, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_backward_input_ws": [_P, _P, _P, _I, _U, _P, _P, _U, _P, _P, _P, _U, _U, _GD, _P],
+    "nsr_hashgrid_forward_variant": [_I, _I],
     "nsr_hashgrid_forward_jac": [_P, _P, _P, _U, _U, _I, _U, _GD, _P, _P, _P],
     "nsr_hashgrid_jac_apply": [_P, _U, _GD, _P, _U, _P, _P, _P, _U, _P, _P],
     "nsr_hashgrid_forward_taps": [_P, _P, _P, _U, _U, _I, _U, _GD, _P, _P],
-    "nsr_hashgrid_backward_params_owner_with_second_order": [_P, _P, _P, _U, _P, _P, _P, _U, _U, _I, _GD, _P],
+    "nsr_hashgrid_backward_params_owner_with_second_order": [_P, _P, _P, _U, _P, _P, _P, _U, _U, _I, _I, _GD, _P],
     "nsr_sh4_forward": [_P, _P, _U, _U, _P],
     "nsr_mlp_forward": [_P, _I, _U, _P, _P, _P, _U, _MD, _P],
     "nsr_mlp_forward_ex": [_P, _I, _U, _U, _P, _P, _P, _U, _MD, _P, _P],

@@ -205,8 +205,14 @@ def test_owner_backward_with_second_order_equals_two_passes():
                                                       n, 16, ctypes.byref(desc), s), "second")
     b = torch.empty_like(a)
     check(lib.nsr_hashgrid_backward_params_owner_with_second_order(ptr(x), ptr(dy_first), off, 36, ptr(gx), ptr(b), ptr(ws), n,
-                                                                   16, 0, ctypes.byref(desc), s), "merged")
+                                                                   16, 0, 0, ctypes.byref(desc), s), "merged")
     assert float((a - b).norm() / a.norm()) < 1e-6
+    # ... and with the binning done ahead of time (what the fused step queues on a helper stream)
+    c = torch.empty_like(a)
+    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, ctypes.byref(desc), None, s), "bin")
+    check(lib.nsr_hashgrid_backward_params_owner_with_second_order(ptr(x), ptr(dy_first), off, 36, ptr(gx), ptr(c), ptr(ws), n,
+                                                                   16, 0, 1, ctypes.byref(desc), s), "merged, pre-binned")
+    assert float((c - b).norm() / b.norm()) < 1e-6
     assert float(a.abs().max()) > 0
 
 
