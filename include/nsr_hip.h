@@ -122,7 +122,7 @@ int nsr_hashgrid_backward_backward_input_ws(const float *x, const nsr_half *tabl
                                             float *grad_table, float *dx2, float *workspace, uint32_t n,
                                             uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
 
-/* A/B switch of the forward's decomposition (process-wide, for measurements; default (0, 1)): lds_levels = leading small
+/* A/B switch of the forward's decomposition (process-wide, for measurements; default (0, 2)): lds_levels = leading small
  * dense levels (<= 16384 entries) encoded from an LDS copy of their table by persistent workgroups; levels_per_lane = 2:
  * one lane encodes both levels {l, l + 8} its XCD owns.  Results are identical bit for bit. */
 int nsr_hashgrid_forward_variant(int lds_levels, int levels_per_lane);

@@ -215,7 +215,7 @@ k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __
 //   * k_grid_forward_lds : the table of a small dense level (<= 16384 entries: 64 KB at F = 2) is staged in LDS by a
 //     persistent workgroup that then encodes a contiguous chunk of samples for that level from LDS;
 //   * k_grid_forward_pair: one lane encodes BOTH levels its XCD owns (l and l + 8): x is loaded once, 16 gathers in flight.
-// Selected at run time by nsr_hashgrid_forward_variant(); the default (0, 1) is the kernel above.
+// Selected at run time by nsr_hashgrid_forward_variant(); the default is (0, 2) for grids of <= 16 levels.
 // ------------------------------------------------------------------------------------------------
 template <int F>
 __device__ __forceinline__ void encode_level_from(const __half *__restrict__ tbl /* level base, global or LDS */,
@@ -1137,7 +1137,8 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
                                        int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
                                        const int32_t *n_dev, void *stream);
 
-static int g_fwd_lds_levels = 0, g_fwd_levels_per_lane = 1;
+// default (0, 2): measured 22 % faster than (0, 1) on ray-coherent samples, (1..2, *) slower -- profiles/r02_forward_ab.json
+static int g_fwd_lds_levels = 0, g_fwd_levels_per_lane = 2;
 extern "C" int nsr_hashgrid_forward_variant(int lds_levels, int levels_per_lane)
 {
     NSR_REQUIRE(lds_levels >= 0 && lds_levels <= 4 && (levels_per_lane == 1 || levels_per_lane == 2),

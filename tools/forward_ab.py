@@ -18,7 +18,7 @@ table = (torch.randn(gd.n_entries * 2, device="cuda") * 0.1).half()
 VARIANTS = [(0, 1), (1, 1), (2, 1), (0, 2), (2, 2)]
 only = os.environ.get("NSR_AB_VARIANT")
 res = {"shapes": "HashGrid L16 T2^19 F2 (levels 0/1: 4096 / 13824 entries = 16 / 54 KB, the only ones that fit 64 KB of LDS)",
-       "variants": "(lds_levels, levels_per_lane); (0, 1) = shipped kernel", "cases": []}
+       "variants": "(lds_levels, levels_per_lane); (0, 1) = round-1 kernel, (0, 2) = shipped default", "cases": []}
 for n, dist in ((1 << 18, "E2_coherent"), (1 << 18, "E1_uniform"), (280000, "E2_coherent")):
     x = torch.rand(n, 3, device="cuda") if dist == "E1_uniform" else coherent(n - n % 64)
     n = x.shape[0]
@@ -34,5 +34,5 @@ for n, dist in ((1 << 18, "E2_coherent"), (1 << 18, "E1_uniform"), (280000, "E2_
         assert torch.equal(got, want), (lds, lpl)
         row[f"lds{lds}_lpl{lpl}_us"] = median_us(lambda: ops.hashgrid_forward(x, table, gd, out=y), 20, 100 if not only else 300)
     res["cases"].append(row)
-check(lib.nsr_hashgrid_forward_variant(0, 1))
+check(lib.nsr_hashgrid_forward_variant(0, 2))  # the shipped default
 print(json.dumps(res, indent=1))
