@@ -148,8 +148,12 @@ class ShardedAdamW:
     is current only inside its own shard -- ``gather_master()`` completes it (checkpoints)."""
 
     def __init__(self, modules, lr=0.01, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.01, transport=torch.bfloat16,
-                 algo="a2a"):
+                 algo=None):
         assert dist.is_initialized()
+        # default: RCCL's own reduce_scatter_tensor / all_gather_into_tensor ("ring" here; RCCL picks its channels over
+        # the xGMI mesh itself).  The pairwise variant ("a2a") cannot be exercised on the 1-GPU boxes this was developed
+        # on (RCCL refuses two ranks per device), so it is opt-in: NSR_EXCHANGE_ALGO=a2a
+        algo = algo or os.environ.get("NSR_EXCHANGE_ALGO", "ring")
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.lr, self.betas, self.eps, self.wd, self.transport, self.algo = lr, betas, eps, weight_decay, transport, algo
         self.step_count = 0
