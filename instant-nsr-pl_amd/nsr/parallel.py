@@ -123,9 +123,10 @@ def _all_gather_shards(full, shard, world, rank, algo):
     S = shard.numel()
     backend = dist.get_backend()
     if backend == "gloo" or algo == "ring":
-        if backend == "gloo":
-            parts = [torch.empty_like(shard) for _ in range(world)]
-            dist.all_gather(parts, shard)
+        if backend == "gloo":  # (gloo gathers CPU tensors only: the 2-ranks-on-one-GPU smoke run goes through the host)
+            src = shard.cpu() if shard.is_cuda else shard
+            parts = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(parts, src)
             full.copy_(torch.cat(parts))
         else:
             dist.all_gather_into_tensor(full, shard)
