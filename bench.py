@@ -108,6 +108,42 @@ def pmc_traffic(name, samples_per_launch):
     return ent["bytes_per_launch"], f"profiles/r02_pmc_traffic.json ({ent['samples_per_launch']:.0f} samples/launch)"
 
 
+def other_workloads(dev):
+    """the fused NeuS (C3) and neuralangelo (C5) steps at the reference's operating point (dynamic ray count targeting 2^18
+    samples/step), 60 + 60 steps each: reported beside the headline line, never part of `value`"""
+    import nsr
+    from nsr.fused_neus import NeuSTrainer
+    from nsr.scene import SyntheticBlender
+    out = {}
+    lam = {"neus-blender": {"lambda_rgb_mse": 10.0, "lambda_rgb_l1": 0.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1},
+           "neuralangelo": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1}}
+    for name in ("neus-blender", "neuralangelo"):
+        try:
+            torch.manual_seed(7)
+            cfg = nsr.configs.get(name)
+            data = SyntheticBlender(n_images=20, w=400, h=400, device=dev, seed=0)
+            data.all_c2w[:, :, 3] *= float(cfg["radius"]) / 1.5
+            model = nsr.build(cfg).to(dev).train()
+            tr = NeuSTrainer(model, data, cfg, lam[name], config_name=name)
+            if name == "neuralangelo":
+                tr.global_step = 12000  # all 16 levels active (the schedule moves one level per 1000 steps)
+            for _ in range(60):
+                tr.train_step()
+            torch.cuda.synchronize()
+            t0, n = time.perf_counter(), 0
+            for _ in range(60):
+                n += tr.train_step()["n_samples"]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = {"ms_per_step": 1e3 * dt / 60, "samples_per_sec": n / dt, "samples_per_step": n / 60,
+                         "grad_type": cfg["geometry"]["grad_type"], "path": "nsr.fused_neus.NeuSTrainer"}
+            del tr, model, data
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001  (never let a side measurement take the headline line down)
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,8 +257,9 @@ def main():
         comm = {"reduce_scatter_ms": rs, "sharded_adamw_ms": ad, "all_gather_ms": ag, "algo": tr.sharded.algo,
                 "transport": str(tr.sharded.transport), "wire_bytes_per_gpu_per_step": wire,
                 "per_link_GBps": (wire / max(world - 1, 1)) / max((rs + ag) * 1e-3, 1e-9) / 1e9,
-                "note": "pairwise exchange over the xGMI full mesh: every rank sends chunk j straight to rank j; "
-                        "per_link = bytes one link carries per step / (reduce_scatter + all_gather time)"}
+                "note": "algo ring = RCCL reduce_scatter_tensor / all_gather_into_tensor; a2a = pairwise over the xGMI mesh "
+                        "(NSR_EXCHANGE_ALGO); per_link = bytes one of the P-1 links carries per step / (reduce_scatter + "
+                        "all_gather time)"}
 
     tot = torch.tensor([dt, float(n_samples), float(n_rays)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -283,6 +320,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+            res["other_workloads"] = other_workloads(dev)
         if os.environ.get("NSR_BENCH_REGIME_OUT"):  # the PMC passes record the regime they ran in (tools/pmc_traffic.py)
             json.dump(res["regime"], open(os.environ["NSR_BENCH_REGIME_OUT"], "w"))
         print(json.dumps(res))
