@@ -49,8 +49,8 @@ def cpu_baseline(seconds_budget=12.0):
     from oracle import tcnn_ref, vanilla_ref
     import nsr
     cfg = nsr.configs.get("nerf-blender")
-    cores = int(os.environ.get("NSR_CPU_BASELINE_THREADS", min(os.cpu_count(), 64)))  # measured on the 256-thread GPU box:
-    torch.set_num_threads(cores)  # all 256 threads oversubscribe torch's intra-op pool (1e4 samples/s); see profiles/
+    cores = int(os.environ.get("NSR_CPU_BASELINE_THREADS", min(os.cpu_count(), 32)))  # measured on the 256-thread GPU box
+    torch.set_num_threads(cores)  # (profiles/r02_cpu_baseline_thread_sweep.json): 16-32 threads 9.6e5 samples/s, 64: 4.9e5, 256: 1e4
     n = 1 << 18
     g = torch.Generator().manual_seed(0)
     x = torch.rand(n, 3, generator=g)
@@ -322,7 +322,9 @@ def main():
             res["cpu_baseline"] = cpu_baseline()
             res["other_workloads"] = other_workloads(dev)
         if os.environ.get("NSR_BENCH_REGIME_OUT"):  # the PMC passes record the regime they ran in (tools/pmc_traffic.py)
-            json.dump(res["regime"], open(os.environ["NSR_BENCH_REGIME_OUT"], "w"))
+            reg = dict(res["regime"], roofline_units_per_launch={k: v["units_per_launch"] for k, v in kern.items()
+                                                                 if k.startswith("hashgrid")})
+            json.dump(reg, open(os.environ["NSR_BENCH_REGIME_OUT"], "w"))
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

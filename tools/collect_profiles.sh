@@ -10,8 +10,8 @@ rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 cp "$(find /tmp/pk -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 python /root/repo/tools/trace_tail.py "$(find /tmp/pk -name '*kernel_trace.csv' | head -1)" "$out/timeline_tail.csv" 2400
 for c in FETCH_SIZE WRITE_SIZE; do
-  for attempt in 1 2 3; do  # rocprofv3 --pmc occasionally segfaults at exit on this image: retry, the passes are independent
-    rm -rf /tmp/pc && NSR_BENCH_REGIME_OUT="$out/bench_regime.json" rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pc -o c -- python /root/repo/bench.py --steps 30 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
+  for attempt in 1 2 3 4 5; do  # rocprofv3 --pmc occasionally segfaults at exit on this image: retry, the passes are independent
+    rm -rf /tmp/pc && NSR_BENCH_REGIME_OUT="$out/bench_regime.json" rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pc -o c -- python /root/repo/bench.py --steps 200 --warmup 300 --no-cpu-baseline > /dev/null 2>&1
     f="$(find /tmp/pc -name '*counter_collection.csv' 2>/dev/null | head -1)"
     if [ -n "$f" ]; then python /root/repo/tools/pmc_summary.py "$f" $c > "$out/pmc_$c.json" && break; fi
   done

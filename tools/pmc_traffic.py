@@ -13,6 +13,7 @@ regime = json.load(open(os.path.join(d, "bench_regime.json")))
 n_params = 12602992 + 7168
 adam = fetch.get("k_adamw", {}).get("avg")
 # two k_adamw dispatches per step (table+density MLP, colour MLP): avg KiB per dispatch x 2 vs 16 B/param
+# (counters are averaged over the last dispatches of each kernel = the profiling steps bench.py's roofline refers to)
 fetch_ratio = (adam * 2 * 1024) / (16.0 * n_params) if adam else 0.5
 corr = 1.0 / fetch_ratio if 0.3 < fetch_ratio < 0.8 else 1.0
 ops = {"hashgrid_backward_params": ["k_own_bin<false>", "k_own_bin_scan", "k_own_bin<true>", "k_grid_backward_owner<2>",
@@ -23,7 +24,8 @@ res = {"_unit": "HBM-side bytes per launch = (FETCH_SIZE x correction + WRITE_SI
        "_regime": regime}
 for name, kernels in ops.items():
     b = sum((fetch.get(k, {}).get("avg", 0.0) * corr + write.get(k, {}).get("avg", 0.0)) * 1024 for k in kernels)
-    spl = regime["kept_samples_per_step"] if name == "hashgrid_backward_params" else regime["marched_samples_per_step"]
+    spl = regime.get("roofline_units_per_launch", {}).get(name) or (
+        regime["kept_samples_per_step"] if name == "hashgrid_backward_params" else regime["marched_samples_per_step"])
     res[name] = {"bytes_per_launch": b, "samples_per_launch": spl, "kernels": kernels}
 res["_raw_KiB_per_dispatch"] = {k: {"FETCH_SIZE": fetch.get(k, {}).get("avg"), "WRITE_SIZE": write.get(k, {}).get("avg"),
                                    "dispatches": fetch.get(k, {}).get("dispatches")} for k in sorted(set(fetch) | set(write))}
