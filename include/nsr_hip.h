@@ -580,18 +580,23 @@ int nsr_neus_shade_forward(const float *sdf_out, const float *g_in, uint32_t g_s
                            const float *t_ends, const float *inv_s, float cos_anneal_ratio, uint32_t n_feat,
                            float sparsity_scale, float *grad, float *normal, float *alpha, float *laplace, void *tex_in,
                            int tex_is_f32, float *acc, uint32_t n, const int32_t *n_dev, void *stream);
-/* rgb_raw: [n][16] colour logits (fp16 or fp32), sigmoid (color_activation) applied here */
+/* rgb_raw: [n][16] colour logits (fp16 or fp32), sigmoid (color_activation) applied here.  background: one colour
+ * (background_stride 0) or, with the learned background, the per-ray comp_rgb_bg [n_rays][3] (background_stride 3):
+ * comp_rgb_full = comp_rgb + background (1 - opacity)   (models/neus.py:273-283) */
 int nsr_neus_composite_forward(const int32_t *packed_info, const float *alpha, const void *rgb_raw, int rgb_is_f32,
                                const float *normal, const float *t_starts, const float *t_ends, const float *background,
-                               float *weights, float *trans, float *comp_rgb, float *opacity, float *depth,
-                               float *comp_normal, float *comp_rgb_full, uint32_t n_rays, void *stream);
-int nsr_neus_loss_rays(const float *comp_rgb_full, const float *opacity, const float *gt_rgb, const float *fg_mask,
-                       float *acc, uint32_t n_rays, const int32_t *n_active, void *stream);
+                               uint32_t background_stride, float *weights, float *trans, float *comp_rgb, float *opacity,
+                               float *depth, float *comp_normal, float *comp_rgb_full, uint32_t n_rays, void *stream);
+/* opacity_bg (may be NULL): rays_valid_full = opacity > 0 | opacity_bg > 0 */
+int nsr_neus_loss_rays(const float *comp_rgb_full, const float *opacity, const float *opacity_bg, const float *gt_rgb,
+                       const float *fg_mask, float *acc, uint32_t n_rays, const int32_t *n_active, void *stream);
+/* d_background (may be NULL): dL / d comp_rgb_bg [n_rays][3] = dL/d comp_rgb_full (1 - opacity) */
 int nsr_neus_composite_backward(const int32_t *packed_info, const float *alpha, const void *rgb_raw, int rgb_is_f32,
                                 const float *weights, const float *trans, const float *background,
-                                const float *comp_rgb_full, const float *opacity, const float *gt_rgb,
-                                const float *fg_mask, const float *acc, const float *loss_weights8, float loss_scale,
-                                float *d_alpha, float *d_rgb_raw, uint32_t n_rays, const int32_t *n_active, void *stream);
+                                uint32_t background_stride, const float *opacity_bg, const float *comp_rgb_full,
+                                const float *opacity, const float *gt_rgb, const float *fg_mask, const float *acc,
+                                const float *loss_weights8, float loss_scale, float *d_alpha, float *d_rgb_raw,
+                                float *d_background, uint32_t n_rays, const int32_t *n_active, void *stream);
 /* d_out [n][16]: gradient w.r.t. the SDF network output; analytic: gx [n][3] = dL/d(dx01) (seeds the hash grid's double
  * backward) and p_in[:, 0:3] = dL/d g_in[:, 0:3]; finite differences: d_taps [6][n] */
 int nsr_neus_shade_backward(const float *sdf_out, const float *grad, const float *normal, const float *dirs,
@@ -600,6 +605,28 @@ int nsr_neus_shade_backward(const float *sdf_out, const float *grad, const float
                             uint32_t n_feat, const float *loss_weights8, float loss_scale, float n_samples, float *d_out,
                             float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
                             const int32_t *n_dev, void *stream);
+
+/* ---- NeRF++ background of the NeuS model (reference models/neus.py:169-203 `forward_bg_`; VolumeDensity with an fp32
+ * VanillaMLP head models/geometry.py:116-130, trunc_exp models/utils.py:55-66, VolumeRadiance models/texture.py:23-30).
+ * out16: [n][16] fp32 output rows of the density network (csrc/vmlp.hip), column 0 = density logit ---- */
+/* kept_counts[r] = leading samples of ray r with transmittance >= early_stop_eps (ray_marching's sigma_fn pruning) */
+int nsr_bg_visibility_prefix(const float *out16, float density_bias, const float *t_starts, const float *t_ends,
+                             const int32_t *packed_info, float early_stop_eps, int32_t *kept_counts, uint32_t n_rays,
+                             void *stream);
+/* tex_in[i] = [out16[i][0:n_feat] | SH4(rays_d[ray_indices[i]]) rounded to fp16 | 0 ...] (fp32 rows of `stride`) */
+int nsr_bg_texture_input(const float *out16, uint32_t n_feat, const float *rays_d, const int64_t *ray_indices,
+                         float *tex_in, uint32_t stride, uint32_t n, const int32_t *n_dev, void *stream);
+/* render_weight_from_density + accumulate_along_rays; comp_rgb includes background (1 - opacity) */
+int nsr_bg_composite_forward(const int32_t *packed_info, const float *out16, float density_bias, const float *rgb_raw,
+                             const float *t_starts, const float *t_ends, const float *background, float *weights,
+                             float *trans, float *comp_rgb, float *opacity, float *depth, uint32_t n_rays, void *stream);
+int nsr_bg_composite_backward(const int32_t *packed_info, const float *out16, float density_bias, const float *rgb_raw,
+                              const float *weights, const float *trans, const float *t_starts, const float *t_ends,
+                              const float *background, const float *d_comp_rgb, float *d_logit, float *d_rgb_raw,
+                              uint32_t n_rays, void *stream);
+/* d_out16[i] = [d_logit[i] + d_tex_in[i][0] | d_tex_in[i][1:n_feat] | 0] */
+int nsr_bg_join_gradients(const float *d_logit, const float *d_tex_in, uint32_t stride, uint32_t n_feat, float *d_out16,
+                          uint32_t n, const int32_t *n_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(R_BLOCK)
 k_neus_composite_fwd(const int32_t *__restrict__ packed, const float *__restrict__ alpha,
                      const void *__restrict__ rgb_raw /* [n][16]: colour logits (sigmoid applied here) */,
                      const float *__restrict__ normal, const float *__restrict__ t0, const float *__restrict__ t1,
-                     const float *__restrict__ bg, float *__restrict__ weights, float *__restrict__ trans,
+                     const float *__restrict__ bg /* [3] (bg_stride 0) or per ray [n_rays][3] (bg_stride 3) */,
+                     uint32_t bg_stride, float *__restrict__ weights, float *__restrict__ trans,
                      float *__restrict__ comp_rgb, float *__restrict__ opacity, float *__restrict__ depth,
                      float *__restrict__ comp_normal, float *__restrict__ comp_rgb_full, uint32_t n_rays)
 {
@@ -259,14 +260,15 @@ k_neus_composite_fwd(const int32_t *__restrict__ packed, const float *__restrict
         for (int q = 0; q < 3; ++q) {
             comp_rgb[3ull * r + q] = acc[2 + q];
             comp_normal[3ull * r + q] = acc[5 + q] / nn;
-            comp_rgb_full[3ull * r + q] = acc[2 + q] + bg[q] * (1.f - acc[0]);
+            comp_rgb_full[3ull * r + q] = acc[2 + q] + bg[(uint64_t)r * bg_stride + q] * (1.f - acc[0]);
         }
     }
 }
 
-// systems/neus.py:96-117 per-ray terms; valid = opacity > 0 (no learned background here)
+// systems/neus.py:96-117 per-ray terms; valid = rays_valid_full = opacity > 0 | opacity_bg > 0 (models/neus.py:283)
 __global__ void __launch_bounds__(1024)
-k_neus_loss_rays(const float *__restrict__ comp_rgb_full, const float *__restrict__ opacity, const float *__restrict__ gt,
+k_neus_loss_rays(const float *__restrict__ comp_rgb_full, const float *__restrict__ opacity,
+                 const float *__restrict__ opacity_bg /* NULL: no learned background */, const float *__restrict__ gt,
                  const float *__restrict__ fg_mask, float *__restrict__ acc, uint32_t n_rays,
                  const int32_t *__restrict__ n_active)
 {
@@ -275,7 +277,7 @@ k_neus_loss_rays(const float *__restrict__ comp_rgb_full, const float *__restric
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // L1, MSE, valid, mask BCE, opaque BCE
     for (uint32_t r = threadIdx.x; r < live; r += 1024) {
         const float op = opacity[r];
-        if (op > 0.f) {
+        if (op > 0.f || (opacity_bg && opacity_bg[r] > 0.f)) {
             s[2] += 1.f;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -312,11 +314,13 @@ template <bool RGB_F32>
 __global__ void __launch_bounds__(R_BLOCK)
 k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict__ alpha,
                      const void *__restrict__ rgb_raw, const float *__restrict__ weights, const float *__restrict__ trans,
-                     const float *__restrict__ bg, const float *__restrict__ comp_rgb_full, const float *__restrict__ opacity,
+                     const float *__restrict__ bg, uint32_t bg_stride, const float *__restrict__ opacity_bg,
+                     const float *__restrict__ comp_rgb_full, const float *__restrict__ opacity,
                      const float *__restrict__ gt, const float *__restrict__ fg_mask, const float *__restrict__ acc,
                      NeusLossWeights lw, float loss_scale, float *__restrict__ d_alpha,
-                     float *__restrict__ d_rgb_raw /* [n][16] fp32, cols 0..2 (3..15 zeroed) */, uint32_t n_rays,
-                     const int32_t *__restrict__ n_active)
+                     float *__restrict__ d_rgb_raw /* [n][16] fp32, cols 0..2 (3..15 zeroed) */,
+                     float *__restrict__ d_bg /* per-ray background: dL/d comp_rgb_bg [n_rays][3] (may be NULL) */,
+                     uint32_t n_rays, const int32_t *__restrict__ n_active)
 {
     uint32_t r, start, count;
     if (!wave_ray(packed, n_rays, r, start, count)) return;
@@ -326,7 +330,7 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
     const float n_valid = fmaxf(acc[ACC_VALID], 1.f), n_r = fmaxf(acc[ACC_N], 1.f);
     float dC[3] = {0.f, 0.f, 0.f}, dO = 0.f;
     if (r < live) {
-        if (op > 0.f) {
+        if (op > 0.f || (opacity_bg && opacity_bg[r] > 0.f)) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const float d = comp_rgb_full[3ull * r + q] - gt[3ull * r + q];
@@ -340,8 +344,11 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
             dO += loss_scale * lw.opaque * (-(logf(op) - logf(1.f - op))) / n_r;
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) dO -= bg[q] * dC[q];  // comp_rgb_full = comp_rgb + bg (1 - opacity)
+        for (int q = 0; q < 3; ++q) dO -= bg[(uint64_t)r * bg_stride + q] * dC[q];  // comp_rgb_full = comp_rgb + bg (1 - opacity)
     }
+    if (d_bg && (threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) d_bg[3ull * r + q] = dC[q] * (1.f - op);
     // per sample: g_w = dC . rgb + dO ; d alpha_i = g_w_i T_i - (sum_{j>i} g_w_j w_j) / max(1 - alpha_i, 1e-10)
     float carry = 0.f;  // sum of g_w_j w_j over the samples AFTER this chunk (walking backwards)
     for (uint32_t c = 0; c < count; c += 64) {
@@ -458,6 +465,160 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
     }
 }
 
+// ---- NeRF++ background branch (models/neus.py:169-203 `forward_bg_`): VolumeDensity on the contracted space with an fp32
+// VanillaMLP head (models/geometry.py:116-130), trunc_exp density, VolumeRadiance colour head, density compositing ------
+
+// kept[r] = #{ i in ray r : T_i >= eps } from fp32 logits (ray_marching's sigma_fn pruning, alpha_thre == 0)
+__global__ void __launch_bounds__(R_BLOCK)
+k_bg_visibility(const float *__restrict__ out16, float bias, const float *__restrict__ t0, const float *__restrict__ t1,
+                const int32_t *__restrict__ packed, float eps, int32_t *__restrict__ kept, uint32_t n_rays)
+{
+    uint32_t r, start, count;
+    if (!wave_ray(packed, n_rays, r, start, count)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    float carry = 1.f;
+    uint32_t n_kept = 0;
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        float keep = 1.f;
+        if (ok) {
+            const uint64_t i = (uint64_t)start + k;
+            const float sigma = expf(out16[16 * i] + bias);
+            keep = 1.f - (1.f - expf(-sigma * (t1[i] - t0[i])));
+        }
+        const float inc = wave_incl_scan_mul(keep);
+        float exc = __shfl_up(inc, 1, 64);
+        if (lane == 0) exc = 1.f;
+        n_kept += (uint32_t)__popcll(__ballot(ok && carry * exc >= eps));
+        carry *= __shfl(inc, 63, 64);
+        if (carry < eps) break;  // wave-uniform: everything after is invisible
+    }
+    if (lane == 0) kept[r] = (int32_t)n_kept;
+}
+
+// colour-head input of the background: [feature (n_feat, column 0 = the density logit) | SH4(dir), fp16-rounded]
+__global__ void __launch_bounds__(EW_BLOCK)
+k_bg_texture_input(const float *__restrict__ out16, uint32_t n_feat, const float *__restrict__ rays_d,
+                   const int64_t *__restrict__ ri, float *__restrict__ tex_in, uint32_t stride, uint32_t n,
+                   const int32_t *__restrict__ n_dev)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= live_count(n, n_dev)) return;
+    const int64_t r = ri[i];
+    float shv[16];
+    {
+        const float ux = (rays_d[3 * r] + 1.f) / 2.f, uy = (rays_d[3 * r + 1] + 1.f) / 2.f, uz = (rays_d[3 * r + 2] + 1.f) / 2.f;
+        sh4(ux * 2.f - 1.f, uy * 2.f - 1.f, uz * 2.f - 1.f, shv);
+    }
+    float *row = tex_in + (uint64_t)i * stride;
+    for (uint32_t k = 0; k < n_feat; ++k) row[k] = out16[16ull * i + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) row[n_feat + k] = __half2float(__float2half_rn(shv[k]));
+    for (uint32_t k = n_feat + 16; k < stride; ++k) row[k] = 0.f;
+}
+
+// render_weight_from_density + accumulate_along_rays (weights, opacity, depth, colour) + background colour
+__global__ void __launch_bounds__(R_BLOCK)
+k_bg_composite_fwd(const int32_t *__restrict__ packed, const float *__restrict__ out16, float bias,
+                   const float *__restrict__ rgb_raw, const float *__restrict__ t0, const float *__restrict__ t1,
+                   const float *__restrict__ bg, float *__restrict__ weights, float *__restrict__ trans,
+                   float *__restrict__ comp_rgb, float *__restrict__ opacity, float *__restrict__ depth, uint32_t n_rays)
+{
+    uint32_t r, start, count;
+    if (!wave_ray(packed, n_rays, r, start, count)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    float carry = 1.f;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // opacity, depth, rgb
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        const uint64_t i = (uint64_t)start + k;
+        float a = 0.f;
+        if (ok) a = 1.f - expf(-expf(out16[16 * i] + bias) * (t1[i] - t0[i]));
+        const float inc = wave_incl_scan_mul(1.f - a);
+        float excl = __shfl_up(inc, 1, 64);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        const float w = T * a;
+        if (ok) {
+            weights[i] = w;
+            trans[i] = T;
+            acc[0] += w;
+            acc[1] += w * ((t0[i] + t1[i]) / 2.f);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[2 + q] += w * sigmoidf(rgb_raw[16 * i + q]);
+        }
+        carry *= __shfl(inc, 63, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0) {
+        opacity[r] = acc[0];
+        depth[r] = acc[1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) comp_rgb[3ull * r + q] = acc[2 + q] + bg[q] * (1.f - acc[0]);
+    }
+}
+
+// d comp_rgb_bg -> d density logit, d colour logits.  sigma = trunc_exp(logit + bias) (backward: g exp(min(x, 15)),
+// models/utils.py:55-66); alpha = 1 - exp(-sigma dt):  d sigma_i = dt_i [ g_w_i T_i (1 - alpha_i) - sum_{j>i} g_w_j w_j ]
+__global__ void __launch_bounds__(R_BLOCK)
+k_bg_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict__ out16, float bias,
+                   const float *__restrict__ rgb_raw, const float *__restrict__ weights, const float *__restrict__ trans,
+                   const float *__restrict__ t0, const float *__restrict__ t1, const float *__restrict__ bg,
+                   const float *__restrict__ d_comp /* [n_rays][3] */, float *__restrict__ d_logit,
+                   float *__restrict__ d_rgb_raw /* [n][16] */, uint32_t n_rays)
+{
+    uint32_t r, start, count;
+    if (!wave_ray(packed, n_rays, r, start, count)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    float dC[3], dO = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { dC[q] = d_comp[3ull * r + q]; dO -= bg[q] * dC[q]; }
+    float carry = 0.f;
+    for (uint32_t c = 0; c < count; c += 64) {
+        const uint32_t k = c + lane;
+        const bool ok = k < count;
+        const uint64_t i = (uint64_t)start + count - 1 - k;
+        float v = 0.f, gw = 0.f, w = 0.f, rgb[3] = {0.f, 0.f, 0.f};
+        if (ok) {
+            w = weights[i];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rgb[q] = sigmoidf(rgb_raw[16 * i + q]);
+            gw = dC[0] * rgb[0] + dC[1] * rgb[1] + dC[2] * rgb[2] + dO;
+            v = gw * w;
+        }
+        const float inc = wave_incl_scan_add(v);
+        if (ok) {
+            const float after = carry + (inc - v);
+            const float x = out16[16 * i] + bias, dt = t1[i] - t0[i];
+            const float keep = expf(-expf(x) * dt);  // 1 - alpha
+            d_logit[i] = dt * (gw * trans[i] * keep - after) * expf(fminf(x, 15.f));
+            float *row = d_rgb_raw + 16 * i;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) row[q] = w * dC[q] * rgb[q] * (1.f - rgb[q]);
+#pragma unroll
+            for (int q = 3; q < 16; ++q) row[q] = 0.f;
+        }
+        carry += __shfl(inc, 63, 64);
+    }
+}
+
+// d (density network output) [n][16] = [d logit + d feature_0 | d feature_1.. | 0]
+__global__ void __launch_bounds__(EW_BLOCK)
+k_bg_join(const float *__restrict__ d_logit, const float *__restrict__ d_tex, uint32_t stride, uint32_t n_feat,
+          float *__restrict__ d_out16, uint32_t n, const int32_t *__restrict__ n_dev)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= live_count(n, n_dev)) return;
+    const float *dt = d_tex + (uint64_t)i * stride;
+    float *row = d_out16 + 16ull * i;
+    row[0] = d_logit[i] + dt[0];
+    for (uint32_t k = 1; k < n_feat; ++k) row[k] = dt[k];
+    for (uint32_t k = n_feat; k < 16; ++k) row[k] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int nsr_neus_points(const float *rays_o, const float *rays_d, const int64_t *ray_indices, const float *t_starts,
@@ -500,54 +661,60 @@ extern "C" int nsr_neus_shade_forward(const float *sdf_out, const float *g_in, u
 
 extern "C" int nsr_neus_composite_forward(const int32_t *packed_info, const float *alpha, const void *rgb_raw,
                                           int rgb_is_f32, const float *normal, const float *t_starts, const float *t_ends,
-                                          const float *background, float *weights, float *trans, float *comp_rgb,
-                                          float *opacity, float *depth, float *comp_normal, float *comp_rgb_full,
-                                          uint32_t n_rays, void *stream)
+                                          const float *background, uint32_t background_stride, float *weights,
+                                          float *trans, float *comp_rgb, float *opacity, float *depth,
+                                          float *comp_normal, float *comp_rgb_full, uint32_t n_rays, void *stream)
 {
     if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(background_stride == 0 || background_stride == 3, "nsr_neus_composite_forward: background_stride is 0 or 3");
     NSR_REQUIRE(packed_info && background && weights && trans && comp_rgb && opacity && depth && comp_normal && comp_rgb_full,
                 "nsr_neus_composite_forward: NULL pointer");
     if (rgb_is_f32)
         hipLaunchKernelGGL(k_neus_composite_fwd<true>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, normal, t_starts,
-                           t_ends, background, weights, trans, comp_rgb, opacity, depth, comp_normal, comp_rgb_full, n_rays);
+                           t_ends, background, background_stride, weights, trans, comp_rgb, opacity, depth, comp_normal,
+                           comp_rgb_full, n_rays);
     else
         hipLaunchKernelGGL(k_neus_composite_fwd<false>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, normal, t_starts,
-                           t_ends, background, weights, trans, comp_rgb, opacity, depth, comp_normal, comp_rgb_full, n_rays);
+                           t_ends, background, background_stride, weights, trans, comp_rgb, opacity, depth, comp_normal,
+                           comp_rgb_full, n_rays);
     NSR_CHECK_LAUNCH("nsr_neus_composite_forward");
     return NSR_OK;
 }
 
-extern "C" int nsr_neus_loss_rays(const float *comp_rgb_full, const float *opacity, const float *gt_rgb,
-                                  const float *fg_mask, float *acc, uint32_t n_rays, const int32_t *n_active,
-                                  void *stream)
+extern "C" int nsr_neus_loss_rays(const float *comp_rgb_full, const float *opacity, const float *opacity_bg,
+                                  const float *gt_rgb, const float *fg_mask, float *acc, uint32_t n_rays,
+                                  const int32_t *n_active, void *stream)
 {
     NSR_REQUIRE(acc && (n_rays == 0 || (comp_rgb_full && opacity && gt_rgb)), "nsr_neus_loss_rays: NULL pointer");
-    hipLaunchKernelGGL(k_neus_loss_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, comp_rgb_full, opacity, gt_rgb,
-                       fg_mask, acc, n_rays, n_active);
+    hipLaunchKernelGGL(k_neus_loss_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, comp_rgb_full, opacity, opacity_bg,
+                       gt_rgb, fg_mask, acc, n_rays, n_active);
     NSR_CHECK_LAUNCH("nsr_neus_loss_rays");
     return NSR_OK;
 }
 
 extern "C" int nsr_neus_composite_backward(const int32_t *packed_info, const float *alpha, const void *rgb_raw,
                                            int rgb_is_f32, const float *weights, const float *trans,
-                                           const float *background, const float *comp_rgb_full, const float *opacity, const float *gt_rgb,
-                                           const float *fg_mask, const float *acc, const float *loss_weights8,
-                                           float loss_scale, float *d_alpha, float *d_rgb_raw, uint32_t n_rays,
+                                           const float *background, uint32_t background_stride,
+                                           const float *opacity_bg, const float *comp_rgb_full, const float *opacity,
+                                           const float *gt_rgb, const float *fg_mask, const float *acc,
+                                           const float *loss_weights8, float loss_scale, float *d_alpha,
+                                           float *d_rgb_raw, float *d_background, uint32_t n_rays,
                                            const int32_t *n_active, void *stream)
 {
     if (n_rays == 0) return NSR_OK;
     NSR_REQUIRE(packed_info && background && weights && trans && comp_rgb_full && opacity && gt_rgb && acc && loss_weights8 &&
                     d_alpha && d_rgb_raw, "nsr_neus_composite_backward: NULL pointer");
+    NSR_REQUIRE(background_stride == 0 || background_stride == 3, "nsr_neus_composite_backward: background_stride is 0 or 3");
     NeusLossWeights lw;
     memcpy(&lw, loss_weights8, sizeof(lw));
     if (rgb_is_f32)
         hipLaunchKernelGGL(k_neus_composite_bwd<true>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
-                           comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale, d_alpha, d_rgb_raw, n_rays,
-                           n_active);
+                           background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
+                           d_alpha, d_rgb_raw, d_background, n_rays, n_active);
     else
         hipLaunchKernelGGL(k_neus_composite_bwd<false>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
-                           comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale, d_alpha, d_rgb_raw, n_rays,
-                           n_active);
+                           background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
+                           d_alpha, d_rgb_raw, d_background, n_rays, n_active);
     NSR_CHECK_LAUNCH("nsr_neus_composite_backward");
     return NSR_OK;
 }
@@ -577,5 +744,67 @@ extern "C" int nsr_neus_shade_backward(const float *sdf_out, const float *grad, 
                            cos_anneal_ratio, laplace, eps, radius, d_alpha, d_tex_in, n_feat, lw, loss_scale, n_samples,
                            d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev);
     NSR_CHECK_LAUNCH("nsr_neus_shade_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_bg_visibility_prefix(const float *out16, float density_bias, const float *t_starts, const float *t_ends,
+                                        const int32_t *packed_info, float early_stop_eps, int32_t *kept_counts,
+                                        uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && kept_counts, "nsr_bg_visibility_prefix: NULL pointer");
+    hipLaunchKernelGGL(k_bg_visibility, RAY_GRID(n_rays), out16, density_bias, t_starts, t_ends, packed_info,
+                       early_stop_eps, kept_counts, n_rays);
+    NSR_CHECK_LAUNCH("nsr_bg_visibility_prefix");
+    return NSR_OK;
+}
+
+extern "C" int nsr_bg_texture_input(const float *out16, uint32_t n_feat, const float *rays_d, const int64_t *ray_indices,
+                                    float *tex_in, uint32_t stride, uint32_t n, const int32_t *n_dev, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(out16 && rays_d && ray_indices && tex_in, "nsr_bg_texture_input: NULL pointer");
+    NSR_REQUIRE(n_feat >= 1 && n_feat <= 16 && n_feat + 16 <= stride, "nsr_bg_texture_input: n_feat=%u stride=%u", n_feat, stride);
+    hipLaunchKernelGGL(k_bg_texture_input, EW_GRID(n), out16, n_feat, rays_d, ray_indices, tex_in, stride, n, n_dev);
+    NSR_CHECK_LAUNCH("nsr_bg_texture_input");
+    return NSR_OK;
+}
+
+extern "C" int nsr_bg_composite_forward(const int32_t *packed_info, const float *out16, float density_bias,
+                                        const float *rgb_raw, const float *t_starts, const float *t_ends,
+                                        const float *background, float *weights, float *trans, float *comp_rgb,
+                                        float *opacity, float *depth, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && weights && trans && comp_rgb && opacity && depth,
+                "nsr_bg_composite_forward: NULL pointer");
+    hipLaunchKernelGGL(k_bg_composite_fwd, RAY_GRID(n_rays), packed_info, out16, density_bias, rgb_raw, t_starts, t_ends,
+                       background, weights, trans, comp_rgb, opacity, depth, n_rays);
+    NSR_CHECK_LAUNCH("nsr_bg_composite_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_bg_composite_backward(const int32_t *packed_info, const float *out16, float density_bias,
+                                         const float *rgb_raw, const float *weights, const float *trans,
+                                         const float *t_starts, const float *t_ends, const float *background,
+                                         const float *d_comp_rgb, float *d_logit, float *d_rgb_raw, uint32_t n_rays,
+                                         void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && weights && trans && d_comp_rgb, "nsr_bg_composite_backward: NULL pointer");
+    hipLaunchKernelGGL(k_bg_composite_bwd, RAY_GRID(n_rays), packed_info, out16, density_bias, rgb_raw, weights, trans,
+                       t_starts, t_ends, background, d_comp_rgb, d_logit, d_rgb_raw, n_rays);
+    NSR_CHECK_LAUNCH("nsr_bg_composite_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_bg_join_gradients(const float *d_logit, const float *d_tex_in, uint32_t stride, uint32_t n_feat,
+                                     float *d_out16, uint32_t n, const int32_t *n_dev, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(d_logit && d_tex_in && d_out16 && n_feat >= 1 && n_feat <= 16 && stride >= n_feat,
+                "nsr_bg_join_gradients: bad arguments");
+    hipLaunchKernelGGL(k_bg_join, EW_GRID(n), d_logit, d_tex_in, stride, n_feat, d_out16, n, n_dev);
+    NSR_CHECK_LAUNCH("nsr_bg_join_gradients");
     return NSR_OK;
 }

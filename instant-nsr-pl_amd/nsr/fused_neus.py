@@ -8,9 +8,11 @@ It reads the parameters of ANY object that exposes them under the reference's at
 gradients in ``.grad`` (same tensors an optimizer would step).  Weight norm of the SDF network is folded on the host:
 the effective matrices are formed with a handful of tiny torch ops and the kernel's gradient is pushed back through them.
 
-Scope: bounded foreground (AABB + occupancy grid, ``learned_background: false``): configs/neus-blender.yaml (analytic
-normals, fused fp16 colour MLP) and configs/neuralangelo-dtu-wmask.yaml (progressive levels, finite differences, fp32
-colour MLP).  The NeRF++ background of configs/neus-dtu.yaml runs through the drop-in packages.
+Scope: configs/neus-blender.yaml (analytic normals, fused fp16 colour MLP), configs/neuralangelo-dtu-wmask.yaml
+(progressive levels, finite differences, fp32 colour MLP) and configs/neus-dtu.yaml (fp32 colour MLP + the NeRF++
+background of ``forward_bg_``, models/neus.py:169-203: a second hash grid on the contracted space, fp32 density / colour
+heads, cone marching through the 256^3 grid with transmittance pruning, density compositing; joined with the foreground
+as comp_rgb_full = comp_rgb + comp_rgb_bg (1 - opacity)).
 """
 import ctypes
 
@@ -85,9 +87,12 @@ def _vanilla_layers(net):
 class FusedNeuSStep:
     def __init__(self, model, loss_weights=None):
         cfg = model.config
-        if cfg["learned_background"] or not cfg["grid_prune"]:
-            raise NotImplementedError("FusedNeuSStep covers the bounded foreground (AABB + occupancy grid) NeuS path")
+        if not cfg["grid_prune"]:
+            raise NotImplementedError("FusedNeuSStep marches through the occupancy grid(s) (grid_prune: true)")
         self.model = model
+        self.bg = bool(cfg["learned_background"])
+        if self.bg:
+            self._bg_setup(cfg)
         self.radius = float(cfg["radius"])
         g = cfg["geometry"]
         self.fd = g["grad_type"] == "finite_difference"
@@ -172,6 +177,185 @@ class FusedNeuSStep:
             prev_cdf, next_cdf = torch.sigmoid((sdf + h) * inv_s), torch.sigmoid((sdf - h) * inv_s)
             return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
 
+
+    # ---- NeRF++ background (models/neus.py:169-203) -----------------------------------------------------------------
+    def _bg_setup(self, cfg):
+        m, g, t = self.model, cfg["geometry_bg"], cfg["texture_bg"]
+        ewn = m.geometry_bg.encoding_with_network
+        node = ewn.encoding.encoding if hasattr(ewn, "encoding") else None
+        if node is None or not hasattr(node, "grid_desc") or g["xyz_encoding_config"].get("include_xyz", False):
+            raise NotImplementedError("fused NeuS background: HashGrid encoding (no xyz columns) + VanillaMLP density head")
+        if g.get("density_activation") != "trunc_exp" or "feature_activation" in g:
+            raise NotImplementedError("fused NeuS background: density_activation trunc_exp, no feature activation")
+        self.bg_enc = node
+        d = node.grid_desc
+        self.bg_n_enc = int(d.n_levels * d.n_features)
+        self.bg_n_feat = int(g["feature_dim"])
+        self.bg_bias = float(g.get("density_bias", 0.0))
+        layers = _vanilla_layers(ewn.network)
+        if len(layers) != 2 or self.bg_n_enc > 40 or self.bg_n_feat > 16:
+            raise NotImplementedError("fused NeuS background: density head = VanillaMLP with one hidden layer")
+        self.bg_geo = VanillaBlob(layers, self.bg_n_enc, self.bg_n_feat, activation=0)
+        tex = m.texture_bg.network
+        if hasattr(tex, "mlp_desc") or t.get("color_activation") != "sigmoid":
+            raise NotImplementedError("fused NeuS background: fp32 VanillaMLP colour head with sigmoid")
+        self.bg_tex = VanillaBlob(_vanilla_layers(tex), self.bg_n_feat + 16, 3, activation=0)
+        self.bg_tex_stride = int(self.bg_tex.desc.in_pad)
+
+    def bg_march_begin(self, rays_o, rays_d, t_max=None):
+        """ray_marching of forward_bg_ queued without a host sync: near plane = exit of the foreground box (0.1 for rays
+        that miss it), far plane 1e3, cone-angle step growth, 256^3 grid on the contracted space"""
+        m, grid = self.model, self.model.occupancy_grid_bg
+        if t_max is None:
+            _, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
+        near = torch.where(t_max > 1e9, torch.full_like(t_max, float(m.near_plane_bg)), t_max)
+        if m.randomized:
+            near = near + torch.rand_like(near) * float(m.render_step_size_bg)
+        far = torch.full_like(near, float(m.far_plane_bg))
+        return _ops.ray_march_begin(rays_o, rays_d, near.contiguous(), far, grid.roi_aabb, grid.binary,
+                                    grid.contraction_type.value, float(m.render_step_size_bg), float(m.cone_angle_bg),
+                                    roi_host=getattr(grid, "_roi_host", None))
+
+    def bg_occ_eval_fn(self, x):
+        """occupancy statistic of the background grid (models/neus.py:103-106): density x step size"""
+        m, enc = self.model, self.bg_enc
+        n = x.shape[0]
+        with torch.no_grad(), torch.cuda.device(x.device):
+            x01 = _ops.contract_to_unisphere(x.float().contiguous(), self.radius, ContractionType.UN_BOUNDED_SPHERE.value)
+            e = _ops.hashgrid_forward(x01, enc.table_half(enc.params), enc.grid_desc).float()
+            blob = self.bg_geo.build(requires_grad=False)
+            out = torch.empty((n, 16), dtype=F32, device=x.device)
+            check(lib.nsr_vmlp_forward(_byref(self.bg_geo.desc), ptr(blob), ptr(e), self.bg_n_enc, None, 0, ptr(out), None,
+                                       None, n, n, None, stream_ptr()), "nsr_vmlp_forward(bg occupancy)")
+            return torch.exp(out[:, :1] + self.bg_bias) * float(m.render_step_size_bg)
+
+    def _bg_prune(self, handle):
+        """sigma_fn pass of ray_marching: encode + density head on every marched sample, keep each ray's leading samples
+        with transmittance >= 1e-4 -> kept sample count on the host (the branch's second host sync)"""
+        m, enc = self.model, self.bg_enc
+        rays_o, rays_d = handle.args[0], handle.args[1]
+        dev, n_rays = rays_o.device, rays_o.shape[0]
+        pk_m, ri_m, t0_m, t1_m = _ops.ray_march_finish(handle)
+        M = ri_m.shape[0]
+        s = stream_ptr()
+        x01_m = torch.empty((M, 3), dtype=F32, device=dev)
+        check(lib.nsr_sample_positions_unit(ptr(rays_o), ptr(rays_d), ptr(ri_m), ptr(t0_m), ptr(t1_m), self.radius,
+                                            ContractionType.UN_BOUNDED_SPHERE.value, ptr(x01_m), None, M, None, s),
+              "nsr_sample_positions_unit")
+        table = enc.table_half(enc.params)
+        xin_m = _ops.hashgrid_forward(x01_m, table, enc.grid_desc).float() if M else torch.empty((0, self.bg_n_enc), dtype=F32, device=dev)
+        self._bg_blob_g = self.bg_geo.build(requires_grad=self._bg_grads)
+        out_m = torch.empty((M, 16), dtype=F32, device=dev)
+        check(lib.nsr_vmlp_forward(_byref(self.bg_geo.desc), ptr(self._bg_blob_g.detach()), ptr(xin_m), self.bg_n_enc, None, 0,
+                                   ptr(out_m), None, None, M, M, None, s), "nsr_vmlp_forward(bg density, marched)")
+        kept = torch.empty(n_rays, dtype=torch.int32, device=dev)
+        pk = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.nsr_bg_visibility_prefix(ptr(out_m), self.bg_bias, ptr(t0_m), ptr(t1_m), ptr(pk_m), 1e-4, ptr(kept),
+                                           n_rays, s), "nsr_bg_visibility_prefix")
+        check(lib.nsr_pack_from_counts(ptr(kept), ptr(pk), ptr(total), n_rays, s), "nsr_pack_from_counts")
+        S = int(total.item())
+        c = dict(packed=pk, S=S, M=M, rays_d=rays_d, n_rays=n_rays,
+                 ri=torch.empty(S, dtype=torch.int64, device=dev), t0=torch.empty(S, dtype=F32, device=dev),
+                 t1=torch.empty(S, dtype=F32, device=dev), x01=torch.empty((S, 3), dtype=F32, device=dev),
+                 xin=torch.empty((S, self.bg_n_enc), dtype=F32, device=dev), out=torch.empty((S, 16), dtype=F32, device=dev))
+        srcs, dsts = [t0_m, t1_m, x01_m, xin_m, out_m], [c["t0"], c["t1"], c["x01"], c["xin"], c["out"]]
+        k = len(srcs)
+        sp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
+        dp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dsts])
+        rb = (ctypes.c_uint32 * k)(*[(t.stride(0) if t.dim() > 1 else 1) * t.element_size() for t in srcs])
+        check(lib.nsr_copy_ray_prefix_rows(ptr(pk_m), ptr(pk), k, sp, dp, rb, ptr(rays_d), None, ptr(c["ri"]), n_rays, s),
+              "nsr_copy_ray_prefix_rows")
+        return c
+
+    def _bg_forward(self, c, background):
+        """density / colour heads on the kept samples and density compositing -> comp_rgb_bg, opacity_bg"""
+        dev, S, n_rays, s = c["x01"].device, c["S"], c["n_rays"], stream_ptr()
+        st = self.bg_tex_stride
+        if self._bg_grads and S > 0:  # bin the kept samples for the table backward underneath the rest of the forward
+            desc = self.bg_enc.grid_desc
+            c["gws"] = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), S)), dtype=F32, device=dev)
+            c["bin_event"] = self._on_helper(lambda hs: check(lib.nsr_hashgrid_backward_params_owner_bin(
+                ptr(c["x01"]), ptr(c["gws"]), S, desc.n_levels, _byref(desc), None, hs),
+                "nsr_hashgrid_backward_params_owner_bin(bg)"), (c["gws"], c["x01"]))
+        c["tex_in"] = torch.empty((S, st), dtype=F32, device=dev)
+        check(lib.nsr_bg_texture_input(ptr(c["out"]), self.bg_n_feat, ptr(c["rays_d"]), ptr(c["ri"]), ptr(c["tex_in"]), st, S,
+                                       None, s), "nsr_bg_texture_input")
+        c["rgb_raw"] = torch.empty((S, 16), dtype=F32, device=dev)
+        check(lib.nsr_vmlp_forward(_byref(self.bg_tex.desc), ptr(self._bg_blob_t.detach()), ptr(c["tex_in"]), st, None, 0,
+                                   ptr(c["rgb_raw"]), None, None, S, S, None, s), "nsr_vmlp_forward(bg colour)")
+        c["weights"], c["trans"] = torch.empty(S, dtype=F32, device=dev), torch.empty(S, dtype=F32, device=dev)
+        c["comp_rgb"] = torch.empty((n_rays, 3), dtype=F32, device=dev)
+        c["opacity"] = torch.empty((n_rays, 1), dtype=F32, device=dev)
+        c["depth"] = torch.empty((n_rays, 1), dtype=F32, device=dev)
+        c["bg_colour"] = background
+        check(lib.nsr_bg_composite_forward(ptr(c["packed"]), ptr(c["out"]), self.bg_bias, ptr(c["rgb_raw"]), ptr(c["t0"]),
+                                           ptr(c["t1"]), ptr(background), ptr(c["weights"]), ptr(c["trans"]),
+                                           ptr(c["comp_rgb"]), ptr(c["opacity"]), ptr(c["depth"]), n_rays, s),
+              "nsr_bg_composite_forward")
+
+    def _bg_backward(self, c, d_comp):
+        """d comp_rgb_bg [n_rays, 3] -> gradients of the background's table / density head / colour head.
+        -> (g_geo blob gradient, g_tex blob gradient) for the host-side push"""
+        dev, S, n_rays, s = c["x01"].device, c["S"], c["n_rays"], stream_ptr()
+        enc, desc, st = self.bg_enc, self.bg_enc.grid_desc, self.bg_tex_stride
+        gd, td = self.bg_geo.desc, self.bg_tex.desc
+        d_logit = torch.empty(S, dtype=F32, device=dev)
+        d_rgb = torch.empty((S, 16), dtype=F32, device=dev)
+        check(lib.nsr_bg_composite_backward(ptr(c["packed"]), ptr(c["out"]), self.bg_bias, ptr(c["rgb_raw"]),
+                                            ptr(c["weights"]), ptr(c["trans"]), ptr(c["t0"]), ptr(c["t1"]),
+                                            ptr(c["bg_colour"]), ptr(d_comp), ptr(d_logit), ptr(d_rgb), n_rays, s),
+              "nsr_bg_composite_backward")
+        d_tex = torch.empty((S, st), dtype=F32, device=dev)
+        g_tex = torch.empty(self.bg_tex.n_floats, dtype=F32, device=dev)
+        ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(_byref(td), S)), dtype=F32, device=dev)
+        check(lib.nsr_vmlp_backward(_byref(td), ptr(self._bg_blob_t.detach()), ptr(c["tex_in"]), st, None, 0, ptr(d_rgb), None,
+                                    None, ptr(d_tex), st, 0, st, 0, ptr(g_tex), 0, ptr(ws), S, S, None, s),
+              "nsr_vmlp_backward(bg colour)")
+        d_out = torch.empty((S, 16), dtype=F32, device=dev)
+        check(lib.nsr_bg_join_gradients(ptr(d_logit), ptr(d_tex), st, self.bg_n_feat, ptr(d_out), S, None, s),
+              "nsr_bg_join_gradients")
+        C, F = self.bg_n_enc, int(desc.n_features)
+        d_enc = torch.empty(C * S, dtype=F32, device=dev)  # level-major: what the owner-computes table backward reads
+        g_geo = torch.empty(self.bg_geo.n_floats, dtype=F32, device=dev)
+        ws2 = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(_byref(gd), S)), dtype=F32, device=dev)
+        check(lib.nsr_vmlp_backward(_byref(gd), ptr(self._bg_blob_g.detach()), ptr(c["xin"]), C, None, 0, ptr(d_out), None, None,
+                                    ptr(d_enc), 0, 0, C, F, ptr(g_geo), 0, ptr(ws2), S, S, None, s),
+              "nsr_vmlp_backward(bg density)")
+        if enc.params.grad is None:
+            enc.params.grad = torch.zeros_like(enc.params)
+        if S > 0:
+            torch.cuda.current_stream().wait_event(c["bin_event"])
+            check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(c["x01"]), ptr(d_enc), 2, 0, ptr(enc.params.grad),
+                                                                    ptr(c["gws"]), S, desc.n_levels, 1.0, 0, _byref(desc),
+                                                                    None, s),
+                  "nsr_hashgrid_backward_params_owner_accumulate(bg)")
+        else:
+            enc.params.grad.zero_()
+        return g_geo, g_tex
+
+    def _finish_bg_only(self, res, g_bg):
+        with torch.enable_grad():
+            self.bg_geo.push_gradient(g_bg[0])
+            self.bg_tex.push_gradient(g_bg[1])
+        return res
+
+    def _on_helper(self, fn, tensors):
+        """run ``fn(stream_ptr)`` on the helper stream behind everything queued so far; -> completion event"""
+        dev = tensors[0].device
+        if getattr(self, "_helper", None) is None:
+            self._helper = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self._helper.wait_event(ready)
+        with torch.cuda.stream(self._helper):
+            fn(stream_ptr())
+            ev = torch.cuda.Event()
+            ev.record(self._helper)
+        for t in tensors:
+            t.record_stream(self._helper)
+        return ev
+
     def forward_backward(self, rays, gt_rgb, fg_mask, background, compute_grads=True, loss_scale=1.0, march_handle=None,
                          after_march=None):
         m, enc, lw = self.model, self.enc, self.loss_weights
@@ -184,11 +368,21 @@ class FusedNeuSStep:
             if march_handle is None:
                 rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
                 march_handle = self.march_begin(rays_o, rays_d)
+                if self.bg:
+                    march_handle = (march_handle, self.bg_march_begin(rays_o, rays_d))
+            bg_handle = None
+            if self.bg:
+                march_handle, bg_handle = march_handle
             rays_o, rays_d = march_handle.args[0], march_handle.args[1]
             packed, ri, t0, t1 = _ops.ray_march_finish(march_handle)
             N = ri.shape[0]
+            bgc = None
+            if self.bg:  # the background's pruning pass decides its sample count: num_samples_full = N + S
+                self._bg_grads = compute_grads
+                bgc = self._bg_prune(bg_handle)
             if after_march is not None:
-                after_march(N)  # the sample count of this step is known: a trainer queues the next batch's marching here
+                # the sample count of this step is known: a trainer queues the next batch's marching here
+                after_march(N + (bgc["S"] if bgc else 0))
             self._n_samples = N
             T = 7 if self.fd else 1
             eps = self._fd_eps() if self.fd else 0.0
@@ -230,6 +424,8 @@ class FusedNeuSStep:
                                                    ptr(jac), None, s), "nsr_hashgrid_forward_jac")
         sdf_blob = self.sdf.build(requires_grad=compute_grads)
         tex_blob = None if self.tex_fused else self.tex.build(requires_grad=compute_grads)
+        if self.bg:
+            self._bg_blob_t = self.bg_tex.build(requires_grad=compute_grads)
         with torch.no_grad(), torch.cuda.device(dev):
             out = torch.empty((N, 16), dtype=F32, device=dev)
             taps = torch.empty(6 * N, dtype=F32, device=dev) if self.fd else None
@@ -269,37 +465,53 @@ class FusedNeuSStep:
                 check(lib.nsr_vmlp_forward(_byref(td), ptr(tex_blob.detach()), ptr(tex_in), 32, None, 0, ptr(rgb_raw), None,
                                            None, N, N, None, s), "nsr_vmlp_forward(texture)")
             bg = background.to(F32).contiguous()
-            weights, trans = torch.empty(N, dtype=F32, device=dev), torch.empty(N, dtype=F32, device=dev)
+            bg_arg, bg_stride, op_bg = bg, 0, None
+            if bgc is not None:  # per-ray background = the NeRF++ branch's colour (models/neus.py:273-283)
+                self._bg_forward(bgc, bg)
+                bg_arg, bg_stride, op_bg = bgc["comp_rgb"], 3, bgc["opacity"]
+            n1 = max(N, 1)  # the ray kernels run for every ray: no NULL sample arrays when nothing was marched
+            weights, trans = torch.empty(n1, dtype=F32, device=dev), torch.empty(n1, dtype=F32, device=dev)
             comp_rgb = torch.empty((n_rays, 3), dtype=F32, device=dev)
             comp_normal = torch.empty((n_rays, 3), dtype=F32, device=dev)
             comp_full = torch.empty((n_rays, 3), dtype=F32, device=dev)
             opacity = torch.empty((n_rays, 1), dtype=F32, device=dev)
             depth = torch.empty((n_rays, 1), dtype=F32, device=dev)
             check(lib.nsr_neus_composite_forward(ptr(packed), ptr(alpha), ptr(rgb_raw), int(tex_f32), ptr(normal), ptr(t0),
-                                                 ptr(t1), ptr(bg), ptr(weights), ptr(trans), ptr(comp_rgb), ptr(opacity),
-                                                 ptr(depth), ptr(comp_normal), ptr(comp_full), n_rays, s),
+                                                 ptr(t1), ptr(bg_arg), bg_stride, ptr(weights), ptr(trans), ptr(comp_rgb),
+                                                 ptr(opacity), ptr(depth), ptr(comp_normal), ptr(comp_full), n_rays, s),
                   "nsr_neus_composite_forward")
             gt = gt_rgb.to(F32).contiguous()
             fg = None if fg_mask is None else fg_mask.to(F32).contiguous()
-            check(lib.nsr_neus_loss_rays(ptr(comp_full), ptr(opacity), ptr(gt), ptr(fg), ptr(acc), n_rays, None, s),
-                  "nsr_neus_loss_rays")
+            check(lib.nsr_neus_loss_rays(ptr(comp_full), ptr(opacity), ptr(op_bg), ptr(gt), ptr(fg), ptr(acc), n_rays, None,
+                                         s), "nsr_neus_loss_rays")
             res = {"comp_rgb": comp_rgb, "comp_normal": comp_normal, "opacity": opacity, "depth": depth,
                    "rays_valid": opacity > 0, "comp_rgb_full": comp_full, "rays_valid_full": opacity > 0,
-                   "num_samples": N, "sdf_samples": out[:, 0], "sdf_grad_samples": grad, "weights": weights,
+                   "num_samples": N, "sdf_samples": out[:, 0], "sdf_grad_samples": grad, "weights": weights[:N],
                    "ray_indices": ri, "t_starts": t0, "t_ends": t1, "alpha": alpha, "loss_acc": acc,
                    "inv_s": inv_s[0]}
             if self.fd:
                 res["sdf_laplace_samples"] = laplace
-            if not compute_grads or N == 0:
+            if bgc is not None:
+                res.update({"comp_rgb_bg": bgc["comp_rgb"], "opacity_bg": bgc["opacity"], "depth_bg": bgc["depth"],
+                            "rays_valid_bg": bgc["opacity"] > 0, "num_samples_bg": bgc["S"],
+                            "num_samples_full": N + bgc["S"], "rays_valid_full": (opacity > 0) | (bgc["opacity"] > 0),
+                            "weights_bg": bgc["weights"], "ray_indices_bg": bgc["ri"], "t_starts_bg": bgc["t0"],
+                            "t_ends_bg": bgc["t1"]})
+            if not compute_grads or (N == 0 and bgc is None):
                 return res
             lw8 = torch.tensor([float(lw.get(k, 0.0)) for k in LOSS_KEYS], dtype=F32)
             lw8c = (ctypes.c_float * 8)(*lw8.tolist())
-            d_alpha = torch.empty(N, dtype=F32, device=dev)
-            d_rgb = torch.empty((N, 16), dtype=F32, device=dev)
+            d_alpha = torch.empty(n1, dtype=F32, device=dev)
+            d_rgb = torch.empty((n1, 16), dtype=F32, device=dev)
+            d_bg = None if bgc is None else torch.empty((n_rays, 3), dtype=F32, device=dev)
             check(lib.nsr_neus_composite_backward(ptr(packed), ptr(alpha), ptr(rgb_raw), int(tex_f32), ptr(weights),
-                                                  ptr(trans), ptr(bg), ptr(comp_full), ptr(opacity), ptr(gt), ptr(fg),
-                                                  ptr(acc), lw8c, float(loss_scale), ptr(d_alpha), ptr(d_rgb), n_rays,
-                                                  None, s), "nsr_neus_composite_backward")
+                                                  ptr(trans), ptr(bg_arg), bg_stride, ptr(op_bg), ptr(comp_full),
+                                                  ptr(opacity), ptr(gt), ptr(fg), ptr(acc), lw8c, float(loss_scale),
+                                                  ptr(d_alpha), ptr(d_rgb), ptr(d_bg), n_rays, None, s),
+                  "nsr_neus_composite_backward")
+            g_bg = None if bgc is None else self._bg_backward(bgc, d_bg)
+            if N == 0:  # background only: nothing flows into the foreground networks
+                return self._finish_bg_only(res, g_bg)
             # colour network backward -> d tex_in (fp32 [N, 32])
             if self.tex_fused:
                 tex = self.tex
@@ -352,6 +564,9 @@ class FusedNeuSStep:
                     ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(g_table), ptr(gws), N, mc, 0, 1, _byref(desc), s),
                     "nsr_hashgrid_backward_params_owner_with_second_order")
         # weight norm / bias gradients through the host-side fold
+        if g_bg is not None:
+            self.bg_geo.push_gradient(g_bg[0])
+            self.bg_tex.push_gradient(g_bg[1])
         self.sdf.push_gradient(g_sdf)
         if not self.tex_fused:
             self.tex.push_gradient(g_tex)
@@ -364,9 +579,9 @@ class FusedNeuSStep:
 
 def neus_lr_scale(step, config_name, max_steps=20000):
     """learning-rate factor of the reference's SequentialLR (interval: step) at optimizer step ``step`` (0-based):
-    neus-*.yaml: LinearLR 0.01 -> 1 over 500 steps, then ExponentialLR 0.1^(1 / (max_steps - 500));
-    neuralangelo-*.yaml: constant for 5000 steps, then ExponentialLR 0.1^(1 / (max_steps - 5000))"""
-    if config_name == "neuralangelo":
+    neus-blender.yaml: LinearLR 0.01 -> 1 over 500 steps, then ExponentialLR 0.1^(1 / (max_steps - 500));
+    neus-dtu.yaml / neuralangelo-*.yaml: constant for 5000 steps, then ExponentialLR 0.1^(1 / (max_steps - 5000))"""
+    if config_name in ("neuralangelo", "neus-dtu"):
         c = 5000
         return 1.0 if step < c else 0.1 ** ((step - c) / (max_steps - c))
     w = 500
@@ -415,6 +630,8 @@ class NeuSTrainer:
             rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(self.dataset, self.train_num_rays, self.gen,
                                                                          self.model, cfg["background_color"])
             handle = self.fused.march_begin(ro, rd, t_min, t_max)
+            if self.fused.bg:  # the background's cone marching starts at the foreground box exit (t_max)
+                handle = (handle, self.fused.bg_march_begin(ro, rd, t_max))
         return rays, rgb, fg, bg, handle
 
     def train_step(self):
@@ -426,6 +643,9 @@ class NeuSTrainer:
         refreshed = False
         if type(model).__name__ == "HotPathState" and cfg["grid_prune"] and t % 16 == 0:
             grid.every_n_step(step=t, occ_eval_fn=self.fused.occ_eval_fn, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
+            if self.fused.bg:
+                model.occupancy_grid_bg.every_n_step(step=t, occ_eval_fn=self.fused.bg_occ_eval_fn,
+                                                     occ_thre=cfg.get("grid_prune_occ_thre_bg", 0.01))
             refreshed = True
         if refreshed or (cfg["grid_prune"] and t % 16 == 0):
             self._pending = None  # marched through the old grid
@@ -463,5 +683,6 @@ class NeuSTrainer:
             g["lr"] = base * scale
         self.opt_rest.step()
         self.global_step += 1
-        self.last = {"loss_acc": res["loss_acc"], "n_rays": rays.shape[0], "n_samples": n}
+        self.last = {"loss_acc": res["loss_acc"], "n_rays": rays.shape[0], "n_samples": n,
+                     "n_samples_bg": res.get("num_samples_bg", 0)}
         return self.last

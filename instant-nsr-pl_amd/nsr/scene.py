@@ -87,7 +87,10 @@ def render_analytic(rays_o, rays_d):
 class SyntheticBlender:
     """tensors named as in the reference's BlenderDatasetBase (datasets/blender.py:66-71)"""
 
-    def __init__(self, n_images=100, w=800, h=800, device="cuda", seed=0, camera_angle_x=0.6911112070083618):
+    def __init__(self, n_images=100, w=800, h=800, device="cuda", seed=0, camera_angle_x=0.6911112070083618,
+                 environment=False):
+        """``environment``: unmasked captures (configs/neus-dtu.yaml: apply_mask false) -- pixels that miss the object
+        show a smooth direction-dependent backdrop, the target of the learned NeRF++ background"""
         g = torch.Generator().manual_seed(seed)
         self.w, self.h = w, h
         focal = 0.5 * w / math.tan(0.5 * camera_angle_x)
@@ -100,11 +103,15 @@ class SyntheticBlender:
             rd = torch.nn.functional.normalize((dirs[:, None, :] * c2w[None, :3, :3]).sum(-1), dim=-1)
             ro = c2w[:, 3].expand_as(rd)
             rgb, m = render_analytic(ro, rd)
+            if environment:
+                sky = 0.5 + 0.5 * torch.stack([torch.sin(3.0 * rd[:, 0] + 0.5), torch.sin(2.0 * rd[:, 1] + 1.5),
+                                               torch.sin(4.0 * rd[:, 2] + 2.5)], -1)
+                rgb = rgb + sky * (1 - m[:, None])
             imgs.append(rgb.view(h, w, 3))
             masks.append(m.view(h, w))
         self.all_images = torch.stack(imgs).float()
         self.all_fg_masks = torch.stack(masks).float()
-        self.apply_mask = True  # datasets/blender.py:37
+        self.apply_mask = not environment  # datasets/blender.py:37 / datasets/dtu.py with apply_mask: false
 
     def sample_rays(self, n_rays, generator=None, background="random"):
         """training ray batch (reference systems/nerf.py:33-85, batch_image_sampling=True)"""

@@ -135,6 +135,20 @@ class HotPathState(nn.Module):
             self.grad_type = g["grad_type"]
             self.finite_difference_eps = None
             self.cos_anneal_ratio = 1.0
+            if cfg.get("learned_background", False):  # NeRF++ branch: models/neus.py:52-59,69-74
+                gb, tb = cfg["geometry_bg"], cfg["texture_bg"]
+                eb = dict(gb["xyz_encoding_config"])
+                if eb["otype"] != "HashGrid" or gb["mlp_network_config"]["otype"] != "VanillaMLP":
+                    raise NotImplementedError("fused NeuS state: background = HashGrid + VanillaMLP density head")
+                n_bg = eb["n_levels"] * eb["n_features_per_level"]
+                rows += [("geometry_bg.encoding_with_network.encoding.encoding", lambda: tcnn.Encoding(3, eb)),
+                         ("geometry_bg.encoding_with_network.network",
+                          lambda: _vanilla_head(n_bg, gb["feature_dim"], gb["mlp_network_config"])),
+                         ("texture_bg.encoding.encoding", lambda: tcnn.Encoding(3, tb["dir_encoding_config"])),
+                         ("texture_bg.network", lambda: _colour_head(tb))]
+                self.near_plane_bg, self.far_plane_bg = 0.1, 1e3
+                self.cone_angle_bg = 10 ** (math.log10(self.far_plane_bg) / cfg["num_samples_per_ray_bg"]) - 1.0
+                self.render_step_size_bg = 0.01
         else:
             raise ValueError(kind)
         for path, factory in rows:
@@ -144,14 +158,14 @@ class HotPathState(nn.Module):
             l0, l2 = getattr(self.geometry.network.layers, "0"), getattr(self.geometry.network.layers, "2")
             sphere_init_(l0, True, False, rad, l0.in_features, 64)
             sphere_init_(l2, False, True, rad, 64, l2.out_features)
-        if cfg.get("learned_background", False):
-            raise NotImplementedError("HotPathState holds the bounded foreground scene; the NeRF++ background runs "
-                                      "through the drop-in packages")
         self.contraction_type = ContractionType.AABB
         self.render_step_size = 1.732 * 2 * r / cfg["num_samples_per_ray"]  # models/nerf.py:33, models/neus.py:76
         if cfg["grid_prune"]:
             self.occupancy_grid = OccupancyGrid(roi_aabb=self.scene_aabb, resolution=128,
                                                 contraction_type=ContractionType.AABB)
+            if kind == "neus" and cfg.get("learned_background", False):
+                self.occupancy_grid_bg = OccupancyGrid(roi_aabb=self.scene_aabb, resolution=256,
+                                                       contraction_type=ContractionType.UN_BOUNDED_SPHERE)
         self.randomized = bool(cfg["randomized"])
         self.background_color = None
 

@@ -161,9 +161,15 @@ SIGNATURES = {
     "nsr_neus_points": [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _U, _P, _P],
     "nsr_neus_shade_forward": [_P, _P, _U, _P, _P, _F, _F, _P, _P, _P, _P, _F, _U, _F, _P, _P, _P, _P, _P, _I, _P, _U,
                                _P, _P],
-    "nsr_neus_composite_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
-    "nsr_neus_loss_rays": [_P, _P, _P, _P, _P, _U, _P, _P],
-    "nsr_neus_composite_backward": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P, _P],
+    "nsr_neus_composite_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_neus_loss_rays": [_P, _P, _P, _P, _P, _P, _U, _P, _P],
+    "nsr_bg_visibility_prefix": [_P, _F, _P, _P, _P, _F, _P, _U, _P],
+    "nsr_bg_texture_input": [_P, _U, _P, _P, _P, _U, _U, _P, _P],
+    "nsr_bg_composite_forward": [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_bg_composite_backward": [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_bg_join_gradients": [_P, _P, _U, _U, _P, _U, _P, _P],
+    "nsr_neus_composite_backward": [_P, _P, _P, _I, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _U, _P,
+                                    _P],
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }

@@ -1,5 +1,5 @@
 """SURVEY.md 8f row 4 on the MI355X: (a) the product state holder has EXACTLY the reference's state-dict keys and shapes
-(tests/golden/state_dict_keys.json, minted from models.make on the real YAMLs) and round-trips a Lightning-style
+(tests/golden/state_dict_keys.json, minted by tests/gen_state_keys.py from models.make on the real YAMLs) and round-trips a Lightning-style
 checkpoint; (b) eval-mode chunked rendering (models/utils.py:13-50 semantics) equals the one-shot forward; (c) the
 isosurface lattice evaluation (models/geometry.py:83-100) equals the level function called directly."""
 import json
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", ["nerf-blender", "neus-blender", "neuralangelo"])
+@pytest.mark.parametrize("name", ["nerf-blender", "neus-blender", "neus-dtu", "neuralangelo"])
 def test_state_dict_keys_match_reference_and_checkpoint_round_trips(name, tmp_path):
     import nsr
     want = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))[name]

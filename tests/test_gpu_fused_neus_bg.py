@@ -1,0 +1,143 @@
+"""The fused NeuS step with the NeRF++ background (configs/neus-dtu.yaml, BASELINE config C4; reference
+models/neus.py:141-203 `forward_bg_` + 259-287) against (a) the fixture the REFERENCE's own models/ produced
+(neus_bg_forward.npz, tests/gen_golden.py:gen_neus_bg) and (b) the modular drop-in path on the same full-size model
+with every loss term switched on.  Tolerances as in test_gpu_golden.py / test_gpu_fused_neus.py."""
+import numpy as np
+import pytest
+import torch
+
+import fixture_utils as fu
+from test_golden_glue import SMALL_GRID, binary_from, load
+
+pytestmark = pytest.mark.gpu
+
+BG_KEYS = ("geometry_bg.encoding_with_network.encoding.encoding.params",
+           "geometry_bg.encoding_with_network.network.layers.0.weight",
+           "geometry_bg.encoding_with_network.network.layers.0.bias",
+           "geometry_bg.encoding_with_network.network.layers.2.weight",
+           "texture_bg.network.layers.0.weight", "texture_bg.network.layers.2.weight", "texture_bg.network.layers.4.weight",
+           "texture_bg.network.layers.4.bias")
+
+
+def _cos(a, b):
+    return float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
+
+
+def test_fused_neus_background_matches_reference_fixture():
+    import nsr
+    import refmirror
+    from nsr.fused_neus import FusedNeuSStep
+    fx = load("neus_bg_forward.npz")
+    cfg = nsr.configs.get("neus-dtu")
+    for key in ("geometry", "geometry_bg"):
+        cfg[key]["xyz_encoding_config"].update({k: v for k, v in SMALL_GRID.items() if k != "otype"})
+    cfg["num_samples_per_ray"] = 256
+    m = refmirror.NeuSModel(cfg).cuda().train()
+    sd = {k[len("param/"):]: v for k, v in fx.items() if k.startswith("param/")}
+    m.load_state_dict(sd, strict=False)
+    m.update_step(0, 5000)
+    m.occupancy_grid._binary = binary_from(fx).cuda()
+    m.occupancy_grid_bg._binary = torch.from_numpy(np.unpackbits(fx["binary_bg_packed"].numpy())[:256 ** 3]
+                                                   .reshape(256, 256, 256).astype(bool)).cuda()
+    m.background_color = fx["background"].cuda()
+    m.randomized = False
+    rays = fx["rays"].cuda()
+    # the fixture's loss: mse(comp_rgb_full, 0.4) * 10 + eikonal * 0.1 over every ray (all of them are valid here)
+    step = FusedNeuSStep(m, dict(lambda_rgb_l1=0.0, lambda_rgb_mse=10.0, lambda_eikonal=0.1, lambda_mask=0.0))
+    gt = torch.full((rays.shape[0], 3), 0.4, device="cuda")
+    res = step.forward_backward(rays, gt, None, m.background_color)
+    assert torch.equal(res["ray_indices"].cpu(), fx["out/ray_indices"])
+    assert torch.equal(res["ray_indices_bg"].cpu(), fx["out/ray_indices_bg"])  # same marching + pruning decisions
+    mid = (res["t_starts_bg"] + res["t_ends_bg"]) / 2
+    assert torch.allclose(mid.cpu(), fx["out/points_bg"].view(-1), rtol=1e-6, atol=1e-6)
+    for k in ("comp_rgb_bg", "opacity_bg", "depth_bg", "comp_rgb", "opacity", "comp_rgb_full", "weights_bg"):
+        tol = 2e-2 if k == "depth_bg" else 3e-3
+        want = fx["out/" + k]
+        assert torch.allclose(res[k].cpu().view(want.shape), want, atol=tol, rtol=1e-2), \
+            (k, float((res[k].cpu().view(want.shape) - want).abs().max()))
+    assert torch.equal(res["rays_valid_full"].cpu().view(-1), fx["out/rays_valid_full"].view(-1))
+    assert res["num_samples_full"] == int(fx["out/num_samples_full"])
+    assert bool(res["rays_valid_full"].all())
+    assert abs(float(step.loss_value(res["loss_acc"])) - float(fx["loss"])) < 3e-3 * max(1.0, float(fx["loss"]))
+    params = dict(m.named_parameters())
+    for k in BG_KEYS + ("geometry.encoding.encoding.params", "texture.network.layers.0.weight",
+                        "geometry.network.layers.0.weight_v", "geometry.network.layers.2.weight_v"):
+        assert params[k].grad is not None, k
+        assert _cos(params[k].grad.cpu(), fx["grad/" + k]) > 0.995, (k, _cos(params[k].grad.cpu(), fx["grad/" + k]))
+
+
+def test_fused_neus_background_matches_modular_path():
+    """full-size neus-dtu model, same rays: FusedNeuSStep vs autograd over the drop-in packages, all loss terms on"""
+    import nsr
+    import refmirror
+    from nsr.fused_neus import FusedNeuSStep
+    torch.manual_seed(0)
+    cfg = nsr.configs.get("neus-dtu")
+    cfg["num_samples_per_ray"] = 256
+    m = refmirror.NeuSModel(cfg).cuda().train()
+    with torch.no_grad():
+        m.geometry.encoding.encoding.params.normal_(0, 0.05)
+        m.geometry.network.layers[0].weight_v[:, 3:].normal_(0, 0.05)
+        m.geometry_bg.encoding_with_network.encoding.encoding.params.normal_(0, 0.3)
+    m.update_step(0, 7001)
+    ii = torch.stack(torch.meshgrid(*[torch.arange(128)] * 3, indexing="ij"), -1).float().cuda()
+    m.occupancy_grid._binary = (((ii + 0.5) / 128 * 2 - 1.0).norm(dim=-1) < 0.6)
+    jj = torch.stack(torch.meshgrid(*[torch.arange(256)] * 3, indexing="ij"), -1).cuda()
+    m.occupancy_grid_bg._binary = ((jj.sum(-1) % 3) != 0)
+    m.background_color = torch.tensor([0.3, 0.5, 0.7], device="cuda")
+    m.randomized = False
+    g = torch.Generator().manual_seed(1)
+    o = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1) * 2.4
+    d = torch.nn.functional.normalize(-o + torch.randn(300, 3, generator=g) * 0.8, dim=-1)  # some rays miss the box
+    rays = torch.cat([o, d], -1).cuda()
+    gt = torch.rand(300, 3, generator=g).cuda()
+    fg = (torch.rand(300, generator=g) > 0.4).float().cuda()
+    lam = {"lambda_rgb_l1": 1.0, "lambda_rgb_mse": 0.5, "lambda_mask": 0.1, "lambda_opaque": 0.05, "lambda_eikonal": 0.1,
+           "lambda_sparsity": 0.02, "sparsity_scale": 1.0}
+    out = m(rays)
+    loss, terms = fu.neus_system_loss(out, gt, fg, lam)
+    loss.backward()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None and p.numel()}
+    for p in m.parameters():
+        p.grad = None
+    step = FusedNeuSStep(m, lam)
+    res = step.forward_backward(rays, gt, fg, m.background_color)
+    assert res["num_samples"] == int(out["num_samples"])
+    assert res["num_samples_bg"] == int(out["num_samples_bg"]) and res["num_samples_bg"] > 1000
+    assert torch.equal(res["ray_indices_bg"], out["ray_indices_bg"])
+    assert torch.equal(res["rays_valid_full"].view(-1), out["rays_valid_full"].view(-1))
+    for k in ("comp_rgb_bg", "opacity_bg", "comp_rgb_full", "opacity", "weights_bg"):
+        a, b = res[k].reshape(-1), out[k].detach().reshape(-1)
+        bad = float(((a - b).abs() > 2e-3 + 2e-3 * b.abs()).float().mean())
+        assert bad < 5e-3, (k, float((a - b).abs().max()), bad)
+    mine = step.loss_terms(res["loss_acc"])
+    for k in ("rgb_l1", "rgb_mse", "mask", "opaque", "eikonal", "sparsity"):
+        assert abs(float(mine[k]) - float(terms[k])) <= 2e-3 * abs(float(terms[k])) + 1e-5, (k, float(mine[k]), float(terms[k]))
+    assert abs(float(step.loss_value(res["loss_acc"])) - float(loss)) < 2e-3 * abs(float(loss))
+    now = dict(m.named_parameters())
+    for k, w in ref.items():
+        assert now[k].grad is not None, k
+        c = _cos(now[k].grad, w)
+        assert c > 0.998, (k, c, float((now[k].grad - w).norm() / w.norm()))
+
+
+def test_neus_dtu_trainer_steps_with_background():
+    """NeuSTrainer on the product state holder: the background branch trains (its parameters move, its 256^3 grid is
+    refreshed), the sample budget counts both branches (systems/neus.py:93-95)"""
+    import nsr
+    from nsr.fused_neus import NeuSTrainer
+    from nsr.scene import SyntheticBlender
+    torch.manual_seed(0)
+    cfg = nsr.configs.get("neus-dtu")
+    st = nsr.build(cfg).cuda().train()
+    ds = SyntheticBlender(n_images=8, h=64, w=64, device="cuda", environment=True)
+    tr = NeuSTrainer(st, ds, cfg, {"lambda_rgb_l1": 1.0, "lambda_eikonal": 0.1}, config_name="neus-dtu")
+    before = {k: v.detach().clone() for k, v in st.named_parameters() if "_bg" in k and v.numel()}
+    for _ in range(20):
+        last = tr.train_step()
+    assert last["n_samples"] > 0 and last["n_samples_bg"] > 0
+    acc = last["loss_acc"]
+    assert bool(torch.isfinite(acc).all())
+    moved = [k for k, v in st.named_parameters() if k in before and not torch.equal(v.detach(), before[k])]
+    assert len(moved) == len(before), set(before) - set(moved)
+    assert 0 < int(st.occupancy_grid_bg.binary.sum()) <= 256 ** 3
