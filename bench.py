@@ -109,19 +109,21 @@ def pmc_traffic(name, samples_per_launch):
 
 
 def other_workloads(dev):
-    """the fused NeuS (C3) and neuralangelo (C5) steps at the reference's operating point (dynamic ray count targeting 2^18
+    """the fused NeuS (C3), NeuS + NeRF++ background (C4) and neuralangelo (C5) steps at the reference's operating point (dynamic ray count targeting 2^18
     samples/step), 60 + 60 steps each: reported beside the headline line, never part of `value`"""
     import nsr
     from nsr.fused_neus import NeuSTrainer
     from nsr.scene import SyntheticBlender
     out = {}
     lam = {"neus-blender": {"lambda_rgb_mse": 10.0, "lambda_rgb_l1": 0.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1},
+           "neus-dtu": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.0, "lambda_eikonal": 0.1},
            "neuralangelo": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1}}
-    for name in ("neus-blender", "neuralangelo"):
+    for name in ("neus-blender", "neus-dtu", "neuralangelo"):
         try:
             torch.manual_seed(7)
             cfg = nsr.configs.get(name)
-            data = SyntheticBlender(n_images=20, w=400, h=400, device=dev, seed=0)
+            data = SyntheticBlender(n_images=20, w=400, h=400, device=dev, seed=0,
+                                    environment=bool(cfg["learned_background"]))
             data.all_c2w[:, :, 3] *= float(cfg["radius"]) / 1.5
             model = nsr.build(cfg).to(dev).train()
             tr = NeuSTrainer(model, data, cfg, lam[name], config_name=name)
@@ -132,7 +134,8 @@ def other_workloads(dev):
             torch.cuda.synchronize()
             t0, n = time.perf_counter(), 0
             for _ in range(60):
-                n += tr.train_step()["n_samples"]
+                last = tr.train_step()
+                n += last["n_samples"] + last["n_samples_bg"]  # num_samples_full: foreground + NeRF++ background
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out[name] = {"ms_per_step": 1e3 * dt / 60, "samples_per_sec": n / dt, "samples_per_step": n / 60,

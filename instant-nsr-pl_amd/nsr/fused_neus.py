@@ -617,6 +617,15 @@ class NeuSTrainer:
         var = [model.variance.variance]
         rest = [p for p in model.parameters() if id(p) not in tc_ids and p is not var[0] and p.numel() > 0]
         self.opt = FusedAdamW(tc, [], lr=0.01)
+        # multi-GPU: the hash tables' gradients are reduce-scattered in bf16, each rank steps its shard and the fp16
+        # images are all-gathered (nsr.parallel.ShardedAdamW); the small fp32 heads + variance are all-reduced
+        self.sharded, self.comm_timings = None, None
+        if world_size > 1:
+            import torch.distributed as dist
+            from .parallel import ShardedAdamW
+            if dist.is_initialized():
+                self.sharded = ShardedAdamW(tc, lr=0.01)
+        self._rest = rest + var
         self.opt_rest = torch.optim.AdamW([{"params": rest, "lr": 0.01}, {"params": var, "lr": 0.001}], betas=(0.9, 0.99),
                                           eps=1e-15)
         self._base_lrs = [0.01, 0.001]
@@ -675,10 +684,17 @@ class NeuSTrainer:
 
         res = self.fused.forward_backward(rays, rgb, fg, bg, march_handle=handle, after_march=after_march)
         n = res["num_samples"]
-        if self.world_size > 1:
-            all_reduce_gradients(list(model.parameters()))
         scale = neus_lr_scale(t, self.config_name, self.max_steps)
-        self.opt.step(lr_scale=scale)
+        if self.sharded is not None:
+            for p in self._rest:  # every rank contributes the same tensor list (a rank may have marched nothing)
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            all_reduce_gradients(self._rest)
+            self.sharded.step(lr_scale=scale, timings=self.comm_timings)
+        else:
+            if self.world_size > 1:
+                all_reduce_gradients(list(model.parameters()))
+            self.opt.step(lr_scale=scale)
         for g, base in zip(self.opt_rest.param_groups, self._base_lrs):
             g["lr"] = base * scale
         self.opt_rest.step()

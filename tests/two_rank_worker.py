@@ -1,0 +1,79 @@
+"""Worker of tests/test_gpu_two_ranks.py: TWO ranks sharing ONE GPU (gloo rendezvous, both on cuda:0 -- RCCL refuses two
+ranks per device, the 8-GPU runs are the driver's) drive the product trainers' multi-rank code path end to end:
+parameter broadcast, per-rank ray batches, bf16 reduce-scatter -> sharded AdamW -> fp16 all-gather for the hash tables
+(nsr.parallel.ShardedAdamW), all-reduce for the small fp32 heads.  Prints one JSON line from rank 0."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")]
+
+
+def digests(model):
+    """per tensor: (sum, sum of squares) of what the kernels read next step (fp16 image of tcnn tensors, fp32 of the rest)"""
+    import tinycudann as tcnn
+    out, seen = {}, set()
+    for name, mod in model.named_modules():
+        if isinstance(mod, tcnn.Module) and mod.params.numel():
+            h = mod.half_params(mod.params).double()
+            out[name + ".fp16"] = (float(h.sum()), float((h * h).sum()))
+            seen.add(id(mod.params))
+    for name, p in model.named_parameters():
+        if id(p) not in seen and p.numel():
+            d = p.detach().double()
+            out[name] = (float(d.sum()), float((d * d).sum()))
+    return out
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import nsr
+    from nsr.fused_neus import NeuSTrainer
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    report = {}
+    for name in ("nerf-blender", "neus-dtu"):
+        cfg = nsr.configs.get(name)
+        torch.manual_seed(100 + rank)  # different initial weights on purpose: the broadcast has to make them equal
+        model = nsr.build(cfg).to(dev).train()
+        data = SyntheticBlender(n_images=8, w=64, h=64, device=dev, seed=0, environment=bool(cfg.get("learned_background")))
+        data.all_c2w[:, :, 3] *= float(cfg["radius"]) / 1.5
+        if name == "nerf-blender":
+            tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42, async_mode=False)
+        else:
+            tr = NeuSTrainer(model, data, cfg, {"lambda_rgb_l1": 1.0, "lambda_eikonal": 0.1}, config_name=name, rank=rank,
+                             world_size=world, seed=42)
+        assert tr.sharded is not None, "multi-rank trainers exchange the tables through ShardedAdamW"
+        first = digests(model)
+        counts = []
+        for _ in range(6):
+            counts.append(int(tr.train_step()["n_samples"]))
+        torch.cuda.synchronize()
+        mine = digests(model)
+        both = [None] * world
+        dist.all_gather_object(both, {"digest": mine, "counts": counts})
+        if rank == 0:
+            a, b = both[0]["digest"], both[1]["digest"]
+            assert a.keys() == b.keys()
+            worst = max(abs(a[k][0] - b[k][0]) + abs(a[k][1] - b[k][1]) for k in a)
+            moved = sum(1 for k in mine if mine[k] != first[k])
+            report[name] = {"tensors": len(a), "replica_mismatch": worst, "tensors_moved": moved,
+                            "samples_rank0": both[0]["counts"], "samples_rank1": both[1]["counts"],
+                            "finite": all(v[1] == v[1] and abs(v[1]) < 1e30 for v in a.values())}
+        del tr, model, data
+        torch.cuda.empty_cache()
+    if rank == 0:
+        print("TWO_RANK_REPORT " + json.dumps(report), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,7 +3,7 @@
 the FUSED runner (nsr/fused_neus.py) and, for comparison, the modular path through the drop-in packages (autograd over
 ~250 launches, the way the reference's models/neus.py drives them).  One JSON line.
 
-    python tools/neus_step_bench.py [--config neus-blender|neuralangelo] [--rays 4096] [--steps 30] [--modular]
+    python tools/neus_step_bench.py [--config neus-blender|neus-dtu|neuralangelo] [--rays 4096] [--steps 30] [--modular]
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ torch.manual_seed(0)
 dev = "cuda"
 cfg = nsr.configs.get(args.config)
 LAM = {"lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1}
-data = SyntheticBlender(n_images=20, w=400, h=400, device=dev, seed=0)
+data = SyntheticBlender(n_images=20, w=400, h=400, device=dev, seed=0, environment=bool(cfg["learned_background"]))
 scale = float(cfg["radius"]) / 1.5  # the procedural scene lives in radius 1.5: move the cameras with the box
 data.all_c2w[:, :, 3] *= scale
 BASE = (args.level_step // 16) * 16 if args.config == "neuralangelo" else 0
@@ -47,7 +47,7 @@ if args.modular:
         loss, _ = fu.neus_system_loss(out, rgb, fg, LAM)
         loss.backward()
         opt.step()
-        n_samples += int(out["num_samples"].sum())
+        n_samples += int(out["num_samples_full"].sum())
 else:
     from nsr.fused_neus import NeuSTrainer
     model = nsr.build(cfg).to(dev).train()
@@ -57,7 +57,8 @@ else:
 
     def step(i):
         global n_samples
-        n_samples += tr.train_step()["n_samples"]
+        last = tr.train_step()
+        n_samples += last["n_samples"] + last["n_samples_bg"]
 
 for i in range(args.warmup):
     step(i)
