@@ -211,6 +211,14 @@ int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride,
                         const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                         uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
                         const NsrMlpDesc *desc, const int32_t *n_dev, void *stream);
+/* ... with the weight-gradient kernels + reduction queued on `wgrad_stream` behind the dgrad kernel (NULL / == stream: in
+ * line).  The caller joins `wgrad_stream` before anything reads grad_weights. */
+int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                        const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                        uint32_t x_level_major_features, const nsr_half *acts,
+                        const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
+                        uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
+                        const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, void *wgrad_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * nerfacc 0.3.3 kernels
@@ -517,6 +525,15 @@ int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq
                    uint64_t zero_first_n, void *stream);
 /* zero_first_n (with zero_grad != 0): only grad[0 .. zero_first_n) is zeroed (0 = all of it; a multiple of 4) -- the fused
  * step OVERWRITES the hash-table part of the gradient every step, zeroing those 50 MB again is wasted bandwidth */
+/* The optimizer step of the asynchronous trainer in ONE launch: nsr_adam_tick + nsr_adamw_step over up to two tensors
+ * (a: hash table + density MLP with its partial re-zeroing, b: colour MLP; n_b == 0: one tensor).  hyper12: 12 floats, 8-byte
+ * aligned, zero-initialised ([0..7] as for nsr_adam_tick, [8] ticket counter).  Bit-identical to the separate launches. */
+int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, nsr_half *shadow_a,
+                             uint64_t n_a, uint64_t zero_first_n_a, float *params_b, float *grad_b, float *exp_avg_b,
+                             float *exp_avg_sq_b, nsr_half *shadow_b, uint64_t n_b, int32_t *step, float *hyper12,
+                             double base_lr, double beta1, double beta2, double gamma, int32_t milestone0,
+                             int32_t milestone1, int32_t milestone2, float eps, float weight_decay, float grad_unscale,
+                             int zero_grad, void *stream);
 /* the one collective of the path is the mean all-reduce of the gradients; the 50 MB table
  * gradient travels as fp16 (dst = half(src * scale) before, dst = float(src) * scale after; nsr/parallel.py) */
 int nsr_scale_to_half(const float *src, nsr_half *dst, uint64_t n, float scale, void *stream);

@@ -404,17 +404,32 @@ k_pack_scratch(const float2 *__restrict__ scratch, uint32_t cap, const int32_t *
 
 // exclusive scan of per-ray counts by ONE workgroup (n_rays is a few thousand): 1024 lanes, each owns a
 // contiguous chunk; wave scan + LDS across the 16 waves.  Removes torch.cumsum + stack from the step.
+__device__ __forceinline__ int32_t prefix_total(const int32_t *wave_tot)
+{
+    int32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += wave_tot[k];
+    return t;
+}
+
+constexpr uint32_t PACK_LDS = 16384;  // ray counts up to this are staged through LDS (coalesced loads and stores)
 __global__ void __launch_bounds__(1024)
 k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ packed, int32_t *__restrict__ total,
                    uint32_t n, uint32_t capacity, int32_t *__restrict__ stats, const int32_t *__restrict__ n_active)
 {
     __shared__ int32_t wave_tot[16];
+    __shared__ int32_t buf[PACK_LDS];
     const uint32_t tid = threadIdx.x, chunk = (n + 1023) / 1024;
     const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     // slots >= *n_active are dead rays: they were marched (the marching pass runs ahead of the ray count) but keep nothing
     const uint32_t live = n_active ? (uint32_t)max(min(*n_active, (int32_t)n), 0) : n;
+    const bool staged = n <= PACK_LDS;
+    if (staged) {
+        for (uint32_t k = tid; k < n; k += 1024) buf[k] = k < live ? counts[k] : 0;
+        __syncthreads();
+    }
     int32_t s = 0;
-    for (uint32_t k = lo; k < hi; ++k) s += k < live ? counts[k] : 0;
+    for (uint32_t k = lo; k < hi; ++k) s += staged ? buf[k] : (k < live ? counts[k] : 0);
     // inclusive scan of s across the block
     int32_t v = s;
     const int lane = tid & 63, w = tid >> 6;
@@ -429,14 +444,26 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
     for (int k = 0; k < w; ++k) prefix += wave_tot[k];
     int32_t run = prefix + v - s;  // exclusive prefix of this lane's chunk
     for (uint32_t k = lo; k < hi; ++k) {
-        int32_t c = k < live ? counts[k] : 0, start = run;
+        int32_t c = staged ? buf[k] : (k < live ? counts[k] : 0), start = run;
         run += c;
         if (capacity) {  // fixed-size sample buffers: rays past the capacity are truncated (and reported)
             start = min(start, (int32_t)capacity);
             c = min(c, (int32_t)capacity - start);
         }
-        packed[2ull * k] = start;
-        packed[2ull * k + 1] = c;
+        if (staged) {  // only this lane touches buf[lo, hi): the start goes to its own slot, the count is rebuilt below
+            buf[k] = start;
+        } else {
+            packed[2ull * k] = start;
+            packed[2ull * k + 1] = c;
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        const int32_t end_all = capacity ? min(prefix_total(wave_tot), (int32_t)capacity) : prefix_total(wave_tot);
+        for (uint32_t k = tid; k < n; k += 1024) {  // count = next start - start (truncation included)
+            const int32_t a = buf[k], b = k + 1 < n ? buf[k + 1] : end_all;
+            reinterpret_cast<int2 *>(packed)[k] = make_int2(a, b - a);
+        }
     }
     if (tid == 1023) {
         const int32_t t = prefix + v;
@@ -740,6 +767,7 @@ extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *pa
     NSR_REQUIRE(n_rays == 0 || (num_steps && packed_info), "nsr_pack_from_counts: NULL pointer");
     NSR_REQUIRE(capacity < 0x7fffffffu, "nsr_pack_from_counts: capacity must fit int32");
     NSR_REQUIRE(!stats || ((uintptr_t)stats & 7u) == 0, "nsr_pack_from_counts: stats must be 8-byte aligned");
+    NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_pack_from_counts: packed_info must be 8-byte aligned");
     hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, num_steps, packed_info, total,
                        n_rays, capacity, stats, n_active);
     NSR_CHECK_LAUNCH("nsr_pack_from_counts");

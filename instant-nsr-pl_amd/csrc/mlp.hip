@@ -678,11 +678,16 @@ static void launch_wgrad(const __half *GT, const void *A, int a_kind, uint32_t a
 #undef NSR_WGRAD
 }
 
-extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
-                                   const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
-                                   uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
-                                   uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
-                                   const NsrMlpDesc *desc, const int32_t *n_dev, void *stream)
+// dgrad on `stream`; with a distinct `wgrad_stream` the weight-gradient kernels + their reduction are queued THERE behind
+// the dgrad kernel (they read what it saved, nothing downstream of dx reads what they write): a caller that only needs
+// dx to go on -- the next network's backward, the table backward -- keeps them off its critical path and joins
+// `wgrad_stream` before the optimizer.
+extern "C" int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                                      const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                                      uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
+                                      float *grad_weights, float *dx, uint32_t dx_stride,
+                                      uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
+                                      const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, void *wgrad_stream)
 {
     if (int rc = check_mlp(desc, "nsr_mlp_backward")) return rc;
     if (n == 0) return NSR_OK;
@@ -715,6 +720,16 @@ extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t d
     });
     NSR_CHECK_LAUNCH("nsr_mlp_backward(dgrad)");
     if (!grad_weights) return NSR_OK;
+    if (wgrad_stream && wgrad_stream != stream) {
+        static hipEvent_t ring[8] = {};
+        static unsigned next = 0;
+        hipEvent_t &ev = ring[next++ & 7u];
+        if (!ev) NSR_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "nsr_mlp_backward: event");
+        NSR_REQUIRE(hipEventRecord(ev, st) == hipSuccess &&
+                        hipStreamWaitEvent((hipStream_t)wgrad_stream, ev, 0) == hipSuccess,
+                    "nsr_mlp_backward: could not fork the weight-gradient stream");
+        st = (hipStream_t)wgrad_stream;
+    }
     const int x_kind = x_level_major_features ? 2 : (x_is_f32 ? 3 : 1);
     // first matrix W0 [64, in_pad]: G = gpre[0], A = x
     switch (in_pad / 16) {
@@ -744,6 +759,17 @@ extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t d
                        nb, 1.f / grad_scale);
     NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
     return NSR_OK;
+}
+
+extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                                   const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                                   uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
+                                   uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
+                                   const NsrMlpDesc *desc, const int32_t *n_dev, void *stream)
+{
+    return nsr_mlp_backward_split(dout, dout_is_f32, dout_stride, dout_extra_col0, out, x, x_is_f32, x_stride,
+                                  x_level_major_features, acts, weights, grad_weights, dx, dx_stride,
+                                  dx_level_major_features, partials, n, grad_scale, desc, n_dev, stream, nullptr);
 }
 
 extern "C" int nsr_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, const nsr_half *out,

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "nsr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -111,7 +112,7 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
 // beside the colour MLP / compositing / MLP backward chain instead of in front of the accumulation kernel.
 struct HelperStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr;
     bool ok = false;
     bool init()
     {
@@ -119,6 +120,7 @@ struct HelperStream {
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join_wgrad, hipEventDisableTiming) != hipSuccess) return false;
         return ok = true;
     }
 };
@@ -287,19 +289,23 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     float *d_tex = (float *)(ws + L.d_tex), *d_enc = (float *)(ws + L.d_enc);
     float *part2 = (float *)(ws + L.partials);
     float *part1 = part2 + nsr_mlp_backward_workspace_floats(&d->mlp_color, S);
+    // the weight-gradient kernels of both MLPs (8 short launches) run on the helper stream underneath the density MLP's
+    // dgrad and the table backward -- only dx continues down the main chain
+    static const bool wgrad_inline = getenv("NSR_WGRAD_INLINE") != nullptr;  // diagnostic A/B switch
+    void *wg = (overlap_bins && !wgrad_inline) ? (void *)g_helper.stream : nullptr;
     NSR_TRY(nsr_composite_backward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights,
                                              trans, comp_rgb, opacity, gt_rgb, acc, d->loss_scale, d_rgb, d_logit, n_rays,
                                              stream));
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
-        NSR_TRY(nsr_mlp_backward_ex(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
-                                    32, 0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream));
+        NSR_TRY(nsr_mlp_backward_split(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
+                                       32, 0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream, wg));
     }
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_DENSITY, S, stream);
-        NSR_TRY(nsr_mlp_backward_ex(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
-                                    grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
-                                    &d->mlp_density, n_kept_dev, stream));
+        NSR_TRY(nsr_mlp_backward_split(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
+                                       grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
+                                       &d->mlp_density, n_kept_dev, stream, wg));
     }
     {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
@@ -314,5 +320,9 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
                                                        d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
         }
     }
+    if (wg)  // join: the optimizer step that follows on `stream` reads the MLP gradients
+        NSR_REQUIRE(hipEventRecord(g_helper.join_wgrad, g_helper.stream) == hipSuccess &&
+                        hipStreamWaitEvent(st, g_helper.join_wgrad, 0) == hipSuccess,
+                    "nsr_nerf_main_pass: weight-gradient join failed");
     return NSR_OK;
 }

@@ -289,6 +289,100 @@ __global__ void k_adam_tick(int32_t *__restrict__ step, float *__restrict__ hype
     hyper[2] = (float)(1.0 - p2);
 }
 
+// ---- the optimizer step of the asynchronous trainer in ONE launch: nsr_adam_tick + nsr_adamw_step over up to two
+// parameter tensors (hash table + density MLP, colour MLP).  Every workgroup derives (lr, bias corrections) from the
+// device-side step counter itself -- same double arithmetic as k_adam_tick, read-only -- and the LAST workgroup to finish
+// (ticket counter in hyper[8]) publishes the advanced counter / running beta powers.  Bit-identical to the three-launch
+// sequence; removes two dependent launches from the step's critical path.
+struct AdamSeg {
+    float *p, *g, *m, *v;
+    __half *shadow;
+    uint64_t n, zero_first_n;
+};
+
+__device__ __forceinline__ void adamw_span(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                           float *__restrict__ v, __half *__restrict__ shadow, uint64_t n,
+                                           uint64_t zero_first_n, float lr, float b1, float b2, float eps, float wd,
+                                           float bc1, float bc2, float unscale, int zero_grad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 4;
+    for (uint64_t base = ((uint64_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 4; base < n; base += stride) {
+        if (base + 4 <= n) {
+            float4 pp = *reinterpret_cast<float4 *>(p + base), gg = *reinterpret_cast<float4 *>(g + base);
+            float4 mm = *reinterpret_cast<float4 *>(m + base), vv = *reinterpret_cast<float4 *>(v + base);
+            float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gr = ga[k] * unscale;
+                pa[k] *= (1.f - lr * wd);
+                ma[k] = b1 * ma[k] + (1.f - b1) * gr;
+                va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
+                const float denom = sqrtf(va[k]) / sqrtf(bc2) + eps;
+                pa[k] -= (lr / bc1) * (ma[k] / denom);
+            }
+            *reinterpret_cast<float4 *>(p + base) = pp;
+            *reinterpret_cast<float4 *>(m + base) = mm;
+            *reinterpret_cast<float4 *>(v + base) = vv;
+            if (zero_grad && base < zero_first_n) *reinterpret_cast<float4 *>(g + base) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (shadow) {
+                __half2 h[2] = {__floats2half2_rn(pa[0], pa[1]), __floats2half2_rn(pa[2], pa[3])};
+                *reinterpret_cast<uint2 *>(shadow + base) = *reinterpret_cast<uint2 *>(h);
+            }
+        } else {
+            for (uint64_t j = base; j < n; ++j) {
+                const float gr = g[j] * unscale;
+                float pj = p[j] * (1.f - lr * wd);
+                const float mj = b1 * m[j] + (1.f - b1) * gr, vj = b2 * v[j] + (1.f - b2) * gr * gr;
+                pj -= (lr / bc1) * (mj / (sqrtf(vj) / sqrtf(bc2) + eps));
+                p[j] = pj; m[j] = mj; v[j] = vj;
+                if (zero_grad && j < zero_first_n) g[j] = 0.f;
+                if (shadow) shadow[j] = __float2half_rn(pj);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *__restrict__ step, float *__restrict__ hyper /* 12 floats */,
+                  double base_lr, double b1d, double b2d, double gamma, int32_t m0, int32_t m1, int32_t m2, float b1,
+                  float b2, float eps, float wd, float unscale, int zero_grad)
+{
+    __shared__ float hs[3];
+    __shared__ double pws[2];
+    double *pw = reinterpret_cast<double *>(hyper + 4);
+    int32_t *pw_step = reinterpret_cast<int32_t *>(hyper + 3);
+    const int32_t done = *step, s = done + 1;
+    if (threadIdx.x == 0) {
+        const int k = (done >= m0) + (done >= m1) + (done >= m2);
+        double scale = 1.0;
+        for (int i = 0; i < k; ++i) scale *= gamma;
+        double p1, p2;
+        if (*pw_step == done && done > 0) { p1 = pw[0] * b1d; p2 = pw[1] * b2d; }
+        else { p1 = pow(b1d, (double)s); p2 = pow(b2d, (double)s); }
+        pws[0] = p1; pws[1] = p2;
+        hs[0] = (float)(base_lr * scale);
+        hs[1] = (float)(1.0 - p1);
+        hs[2] = (float)(1.0 - p2);
+    }
+    __syncthreads();
+    const float lr = hs[0], bc1 = hs[1], bc2 = hs[2];
+    adamw_span(a.p, a.g, a.m, a.v, a.shadow, a.n, a.zero_first_n, lr, b1, b2, eps, wd, bc1, bc2, unscale, zero_grad);
+    if (b.n) adamw_span(b.p, b.g, b.m, b.v, b.shadow, b.n, b.zero_first_n, lr, b1, b2, eps, wd, bc1, bc2, unscale, zero_grad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // no fence: the only cross-workgroup ordering needed is "every workgroup READ the old schedule state before the
+        // last one overwrites it", and those loads completed long before this point (a release fence here would write
+        // back + invalidate the XCD's L2 once per workgroup -- measured 2x on the whole kernel)
+        uint32_t *ticket = reinterpret_cast<uint32_t *>(hyper + 8);
+        if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            *ticket = 0;
+            *step = s;
+            pw[0] = pws[0]; pw[1] = pws[1]; *pw_step = s;
+            hyper[0] = hs[0]; hyper[1] = hs[1]; hyper[2] = hs[2];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int nsr_sh4_forward(const float *u, nsr_half *y, uint32_t n, uint32_t y_stride, void *stream)
@@ -417,5 +511,32 @@ extern "C" int nsr_adam_tick(int32_t *step, float *hyper, double base_lr, double
     hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, (hipStream_t)stream, step, hyper, base_lr, beta1, beta2, gamma,
                        milestone0, milestone1, milestone2);
     NSR_CHECK_LAUNCH("nsr_adam_tick");
+    return NSR_OK;
+}
+
+extern "C" int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a,
+                                        nsr_half *shadow_a, uint64_t n_a, uint64_t zero_first_n_a, float *params_b,
+                                        float *grad_b, float *exp_avg_b, float *exp_avg_sq_b, nsr_half *shadow_b,
+                                        uint64_t n_b, int32_t *step, float *hyper12, double base_lr, double beta1,
+                                        double beta2, double gamma, int32_t milestone0, int32_t milestone1,
+                                        int32_t milestone2, float eps, float weight_decay, float grad_unscale,
+                                        int zero_grad, void *stream)
+{
+    NSR_REQUIRE(step && hyper12 && ((uintptr_t)hyper12 & 7u) == 0, "nsr_adamw_step_scheduled: step / hyper (8-byte aligned)");
+    NSR_REQUIRE(n_a > 0 && params_a && grad_a && exp_avg_a && exp_avg_sq_a, "nsr_adamw_step_scheduled: NULL pointer");
+    NSR_REQUIRE(n_b == 0 || (params_b && grad_b && exp_avg_b && exp_avg_sq_b), "nsr_adamw_step_scheduled: NULL pointer");
+    NSR_REQUIRE((((uintptr_t)params_a | (uintptr_t)grad_a | (uintptr_t)exp_avg_a | (uintptr_t)exp_avg_sq_a |
+                  (uintptr_t)params_b | (uintptr_t)grad_b | (uintptr_t)exp_avg_b | (uintptr_t)exp_avg_sq_b) & 15) == 0 &&
+                    (((uintptr_t)shadow_a | (uintptr_t)shadow_b) & 7) == 0,
+                "nsr_adamw_step_scheduled: buffers must be 16-byte aligned (fp16 shadow: 8)");
+    NSR_REQUIRE(zero_first_n_a % 4 == 0, "nsr_adamw_step_scheduled: zero_first_n must be a multiple of 4");
+    AdamSeg a{params_a, grad_a, exp_avg_a, exp_avg_sq_a, (__half *)shadow_a, n_a, zero_first_n_a ? zero_first_n_a : n_a};
+    AdamSeg b{params_b, grad_b, exp_avg_b, exp_avg_sq_b, (__half *)shadow_b, n_b, n_b};
+    uint64_t blocks = (n_a / 4 + EW_BLOCK - 1) / EW_BLOCK + 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adamw_scheduled, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, step,
+                       hyper12, base_lr, beta1, beta2, gamma, milestone0, milestone1, milestone2, (float)beta1,
+                       (float)beta2, eps, weight_decay, grad_unscale, zero_grad);
+    NSR_CHECK_LAUNCH("nsr_adamw_step_scheduled");
     return NSR_OK;
 }

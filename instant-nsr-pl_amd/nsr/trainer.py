@@ -9,6 +9,8 @@ data-path collective is one mean all-reduce of the gradients per step over RCCL 
 counts, lagged capacity control), the marching passes two steps ahead on a side stream, the occupancy refresh on the
 device.  ``async_mode=False`` keeps the step that reads its counts back (and ``fused=False`` the modular autograd path).
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -60,18 +62,29 @@ class FusedAdamW:
         dev = self.tcnn_modules[0].params.device
         if getattr(self, "_step_dev", None) is None:
             self._step_dev = torch.tensor([self.step_count], dtype=torch.int32, device=dev)
-            self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)  # lr, bc1, bc2 | running beta powers
-        _ops.adam_tick(self._step_dev, self._hyper, self.lr, self.betas[0], self.betas[1], gamma, milestones)
+            self._hyper = torch.zeros(12, dtype=torch.float32, device=dev)  # lr, bc1, bc2 | running beta powers | ticket
         self.step_count += 1  # host mirror (not read by the kernels)
-        for m in self.tcnn_modules:
-            p = m.params
-            exp_avg, exp_avg_sq, shadow = self.state[p]
-            # the fused step overwrites the hash-table slice of the gradient: zero only the MLP slice in front of it
+
+        def zero_n(m):  # the fused step overwrites the hash-table slice of the gradient: zero only the MLP slice in front
             n_zero = getattr(m, "n_network_params", 0) if getattr(m, "grid_desc", None) is not None else 0
-            _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr, self.betas[0], self.betas[1],
-                            self.eps, self.wd, self.step_count, zero_grad=True, hyper=self._hyper,
-                            zero_first_n=n_zero if (n_zero > 0 and n_zero % 4 == 0 and self.table_grad_overwritten) else 0)
-            m.adopt_shadow(shadow)
+            return n_zero if (n_zero > 0 and n_zero % 4 == 0 and self.table_grad_overwritten) else 0
+
+        mods = self.tcnn_modules
+        if len(mods) <= 2 and not os.environ.get("NSR_ADAM_SEPARATE"):  # schedule tick + every tensor in ONE launch (largest tensor first: it sizes the grid)
+            mods = sorted(mods, key=lambda m: -m.params.numel())
+            _ops.adamw_step_scheduled([(m.params.data, m.params.grad) + tuple(self.state[m.params]) + (zero_n(m),)
+                                       for m in mods], self._step_dev, self._hyper, self.lr, self.betas[0],
+                                      self.betas[1], gamma, milestones, self.eps, self.wd)
+        else:
+            _ops.adam_tick(self._step_dev, self._hyper, self.lr, self.betas[0], self.betas[1], gamma, milestones)
+            for m in mods:
+                p = m.params
+                exp_avg, exp_avg_sq, shadow = self.state[p]
+                _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr, self.betas[0], self.betas[1],
+                                self.eps, self.wd, self.step_count, zero_grad=True, hyper=self._hyper,
+                                zero_first_n=zero_n(m))
+        for m in mods:
+            m.adopt_shadow(self.state[m.params][2])
 
 
 def next_capacity(cap, window_max, n_rays, slots, dropped, granule=16384, floor=65536):

@@ -97,6 +97,7 @@ SIGNATURES = {
     "nsr_mlp_backward_workspace_floats": [_MD, _U],
     "nsr_mlp_backward": [_P, _I, _U, _P, _P, _I, _U, _P, _P, _P, _P, _U, _P, _U, _F, _MD, _P],
     "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P],
+    "nsr_mlp_backward_split": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P, _P],
     "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P, _P],
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_copy_ray_prefixes": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
@@ -154,6 +155,8 @@ SIGNATURES = {
     "nsr_scale_to_half": [_P, _P, _U64, _F, _P],
     "nsr_scale_from_half": [_P, _P, _U64, _F, _P],
     "nsr_adam_tick": [_P, _P, _D, _D, _D, _D, _I, _I, _I, _P],
+    "nsr_adamw_step_scheduled": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _D, _D, _D, _D, _I, _I,
+                                 _I, _F, _F, _F, _I, _P],
     "nsr_vmlp_blob_floats": [_VD],
     "nsr_vmlp_backward_workspace_floats": [_VD, _U],
     "nsr_vmlp_forward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _U, _U, _P, _P],

@@ -152,3 +152,42 @@ def test_nonfinite_gradients_reach_the_table_gradient():
     off = [int(v) * 2 for v in enc.grid_desc.offset[:17]]
     bad_levels = {l for l in range(16) if not bool(torch.isfinite(g[off[l]:off[l + 1]]).all())}
     assert bad_levels == {2, 15}, bad_levels  # columns 5 and 30 belong to levels 2 and 15; the others stay clean
+
+
+def test_scheduled_two_tensor_adamw_is_bit_identical_to_tick_plus_steps():
+    """nsr_adamw_step_scheduled (one launch: device schedule + both tensors) == nsr_adam_tick + two nsr_adamw_step"""
+    from nsr_hip import ops
+    torch.manual_seed(1)
+    sizes = (3072 + 50003, 7168)
+    milestones, gamma = (3, 6, 8), 0.33
+
+    def state():
+        ts = []
+        for n in sizes:
+            p = torch.randn(n, device="cuda") * 0.1
+            ts.append([p, torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p),
+                       torch.empty(n, dtype=torch.float16, device="cuda")])
+        return ts, torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(12, dtype=torch.float32, device="cuda")
+
+    torch.manual_seed(1)
+    a, step_a, hyper_a = state()
+    torch.manual_seed(1)
+    b, step_b, hyper_b = state()
+    for step in range(1, 12):
+        grads = [torch.randn(n, device="cuda") * (10.0 ** torch.randint(-6, 1, (n,), device="cuda").float()) for n in sizes]
+        for t, g in zip(a, grads):
+            t[1].copy_(g)
+        for t, g in zip(b, grads):
+            t[1].copy_(g)
+        ops.adam_tick(step_a, hyper_a, 0.01, 0.9, 0.99, gamma, milestones)
+        ops.adamw_step(a[0][0], a[0][1], a[0][2], a[0][3], a[0][4], 0.01, 0.9, 0.99, 1e-15, 0.01, step, zero_grad=True,
+                       hyper=hyper_a, zero_first_n=3072)
+        ops.adamw_step(a[1][0], a[1][1], a[1][2], a[1][3], a[1][4], 0.01, 0.9, 0.99, 1e-15, 0.01, step, zero_grad=True,
+                       hyper=hyper_a)
+        ops.adamw_step_scheduled([tuple(b[0]) + (3072,), tuple(b[1]) + (0,)], step_b, hyper_b, 0.01, 0.9, 0.99, gamma,
+                                 milestones, 1e-15, 0.01)
+        assert int(step_b) == int(step_a) == step
+        assert torch.equal(hyper_a[:8], hyper_b[:8]) and float(hyper_b[8]) == 0.0
+        for ta, tb in zip(a, b):
+            for x, y in zip(ta, tb):
+                assert torch.equal(x, y), step
