@@ -502,7 +502,9 @@ int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const flo
                         const float *t_starts, const float *t_ends, const int32_t *packed_info, const nsr_half *table,
                         const nsr_half *w_density, void *workspace, int32_t *kept_counts, int32_t *packed_kept,
                         int32_t *total_kept, uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
-                        uint32_t kept_capacity, int32_t *kept_stats, void *stream);
+                        uint32_t kept_capacity, int32_t *kept_stats, const float *x01_marched, void *stream);
+/* x01_marched (may be NULL; both passes): unit-cube positions [n_marched, 3] of the marched samples computed by the caller
+ * ahead of the step (nsr_sample_positions_unit on its marching stream); NULL: formed inside, in the workspace */
 int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, uint32_t n_rays, NsrNerfMainLayout *out);
 /* forward + loss (+ backward when compute_grads): gradients are ADDED to grad_density_mlp / grad_color_mlp and
  * OVERWRITE grad_table; t_starts/t_ends/packed_marched describe the marched samples, packed_kept the kept ones.
@@ -512,7 +514,7 @@ int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, ui
                        const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
                        const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp, float *grad_table,
                        float *grad_color_mlp, void *workspace, uint32_t n_kept, uint32_t n_rays, int compute_grads,
-                       const int32_t *n_kept_dev, void *stream);
+                       const int32_t *n_kept_dev, const float *x01_marched, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:

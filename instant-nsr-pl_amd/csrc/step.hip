@@ -144,17 +144,20 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
                                    const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
                                    void *workspace, int32_t *kept_counts, int32_t *packed_kept, int32_t *total_kept,
                                    uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
-                                   uint32_t kept_capacity, int32_t *kept_stats, void *stream)
+                                   uint32_t kept_capacity, int32_t *kept_stats, const float *x01_marched, void *stream)
 {
     NSR_REQUIRE(d && workspace && kept_counts && packed_kept && total_kept, "nsr_nerf_prune_pass: NULL pointer");
     NsrNerfPruneLayout L;
     NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &L));
     char *ws = (char *)workspace;
-    float *x01 = (float *)(ws + L.x01);
+    // x01_marched: the caller already computed the unit-cube positions of the marched samples (the asynchronous trainer
+    // does it on its marching stream, ahead of the step) -- otherwise they are formed here, into the workspace
+    const float *x01 = x01_marched ? x01_marched : (const float *)(ws + L.x01);
     nsr_half *enc = (nsr_half *)(ws + L.enc), *out1 = (nsr_half *)(ws + L.out1), *acts1 = (nsr_half *)(ws + L.acts1);
     const uint32_t C = d->grid.n_levels * d->grid.n_features;
-    NSR_TRY(nsr_sample_positions_unit(rays_o, rays_d, ray_indices, t_starts, t_ends, d->radius, d->contraction, x01,
-                                      nullptr, n_marched, n_marched_dev, stream));
+    if (!x01_marched)
+        NSR_TRY(nsr_sample_positions_unit(rays_o, rays_d, ray_indices, t_starts, t_ends, d->radius, d->contraction,
+                                          (float *)(ws + L.x01), nullptr, n_marched, n_marched_dev, stream));
     {
         ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
         NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
@@ -211,7 +214,8 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
                                   const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
                                   const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
                                   float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
-                                  uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev, void *stream)
+                                  uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev,
+                                  const float *x01_marched, void *stream)
 {
     NSR_REQUIRE(d && prune_workspace && workspace && packed_marched && packed_kept, "nsr_nerf_main_pass: NULL pointer");
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
@@ -234,7 +238,8 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
 
     // kept rows of everything the sigma pass computed (a per-ray memcpy; nothing is re-encoded)
     const uint32_t nh1 = d->mlp_density.n_hidden;
-    const void *src[8] = {t_starts, t_ends, pw + P.x01, pw + P.enc, pw + P.out1, pw + P.acts1, nullptr, nullptr};
+    const float *x01m = x01_marched ? x01_marched : (const float *)(pw + P.x01);
+    const void *src[8] = {t_starts, t_ends, x01m, pw + P.enc, pw + P.out1, pw + P.acts1, nullptr, nullptr};
     void *dst[8] = {t0, t1, x01, enc, out1, acts1, nullptr, nullptr};
     // the encoding is level-major [L][n][F] (fp16): L planes of F*2-byte rows
     const uint32_t F = d->grid.n_features, Lv = d->grid.n_levels;
@@ -251,7 +256,7 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     NSR_REQUIRE(F * 2 % 4 == 0, "nsr_nerf_main_pass: n_features_per_level must be even");
     if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
         if (F == 2 && nh1 <= 2)  // the step's usual shape: one lane per kept sample, all its rows in one round trip
-            NSR_TRY(nsr_nerf_copy_kept_rows(packed_marched, packed_kept, t_starts, t_ends, (const float *)(pw + P.x01),
+            NSR_TRY(nsr_nerf_copy_kept_rows(packed_marched, packed_kept, t_starts, t_ends, x01m,
                                             (const nsr_half *)(pw + P.enc), (const nsr_half *)(pw + P.out1),
                                             (const nsr_half *)(pw + P.acts1), t0, t1, x01, enc, out1, acts1, Lv, nh1,
                                             n_marched, S, rays_d, (int64_t *)(ws + L.ray_indices), tex_in, n_rays,

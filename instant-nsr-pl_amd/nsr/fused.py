@@ -151,7 +151,7 @@ class FusedNeRFStep:
                 if M > 0:
                     check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1),
                                                   ptr(packed), ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2),
-                                                  ptr(total), M, n_rays, None, 0, None, s), "nsr_nerf_prune_pass")
+                                                  ptr(total), M, n_rays, None, 0, None, None, s), "nsr_nerf_prune_pass")
                     if before_sync is not None:
                         before_sync(total)
                     S = _ops.read_count_when_ready(total)  # second (and last) host sync of the step
@@ -179,7 +179,7 @@ class FusedNeRFStep:
                                              ptr(ewn.mlp_slice(g1)) if compute_grads else None,
                                              ptr(ewn.grid_slice(g1)) if compute_grads else None,
                                              ptr(g2) if compute_grads else None, ptr(ws), S, n_rays,
-                                             int(bool(compute_grads)), None, s), "nsr_nerf_main_pass")
+                                             int(bool(compute_grads)), None, None, s), "nsr_nerf_main_pass")
             def view(off, n, dtype, shape):
                 return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
 
@@ -353,6 +353,38 @@ class FusedNeRFStep:
                                               int(m_cap), ptr(stats), ptr(n_active), stream_ptr()),
               "nsr_pack_from_counts_capped")
         rs["m_cap"] = int(m_cap)
+        if rs.get("marched") is not None:
+            rs["marched"]["valid"] = False  # sample arrays of an earlier packing of this ring slot
+
+    def write_async(self, rs, consumer_stream=None):
+        """sample arrays of ray set ``rs`` (ray index, t_starts, t_ends, unit-cube positions of every marched sample) from
+        its marching scratch + packed_info, into buffers that belong to the ring slot -- queued on the CURRENT stream right
+        behind ``pack_async`` (the marching side stream), so the step itself starts at the hash encode.
+        ``consumer_stream``: the stream the step runs on (allocator bookkeeping for buffers born here)."""
+        m_cap, slots = rs["m_cap"], rs["slots"]
+        dev = rs["buf"].device
+        mb = rs.get("marched")
+        if mb is None or mb["m_cap"] != m_cap:
+            mb = rs["marched"] = dict(m_cap=m_cap, ri=torch.empty(m_cap, dtype=torch.int64, device=dev),
+                                      t0=torch.empty((m_cap, 1), dtype=F32, device=dev),
+                                      t1=torch.empty((m_cap, 1), dtype=F32, device=dev),
+                                      x01=torch.empty((m_cap, 3), dtype=F32, device=dev), valid=False)
+            if consumer_stream is not None:
+                for k in ("ri", "t0", "t1", "x01"):
+                    mb[k].record_stream(consumer_stream)
+        grid, d = self.model.occupancy_grid, self.desc
+        rx, ry, rz = (int(v) for v in grid.binary.shape)
+        with torch.no_grad(), torch.cuda.device(dev):
+            s = stream_ptr()
+            check(lib.nsr_ray_march_bricks_write(ptr(rs["ro"]), ptr(rs["rd"]), ptr(rs["t_min"]), ptr(rs["t_max"]),
+                                                 ptr(grid.roi_aabb), None, rx, ry, rz, ContractionType.AABB.value,
+                                                 float(self.model.render_step_size), 0.0, ptr(rs["packed"]),
+                                                 ptr(rs["scratch"]), rs["cap"], ptr(mb["ri"]), ptr(mb["t0"]),
+                                                 ptr(mb["t1"]), slots, s), "nsr_ray_march_bricks_write")
+            check(lib.nsr_sample_positions_unit(ptr(rs["ro"]), ptr(rs["rd"]), ptr(mb["ri"]), ptr(mb["t0"]), ptr(mb["t1"]),
+                                                float(d.radius), int(d.contraction), ptr(mb["x01"]), None, m_cap,
+                                                ptr(rs["total"]), s), "nsr_sample_positions_unit")
+        mb["valid"] = True
 
     def _async_buffers(self, slots, m_cap, s_cap, dev):
         key = (slots, m_cap, s_cap)
@@ -394,16 +426,23 @@ class FusedNeRFStep:
             rx, ry, rz = (int(v) for v in grid.binary.shape)
             half = ewn.half_params(ewn.params)
             table, w1, w2 = half[ewn.n_network_params:], half[:ewn.n_network_params], tex.half_params(tex.params)
+            mb = rs.get("marched")  # sample arrays already written behind the packing kernel (write_async)?
+            if mb is None or mb["m_cap"] != m_cap or not mb["valid"]:
+                mb, x01m = dict(ri=ab["ri"], t0=ab["t0"], t1=ab["t1"]), None
+                with _ops.timed("fused:march_prune"):
+                    check(lib.nsr_ray_march_bricks_write(ptr(rs["ro"]), ptr(rs["rd"]), ptr(rs["t_min"]), ptr(rs["t_max"]),
+                                                         ptr(grid.roi_aabb), None, rx, ry, rz, ContractionType.AABB.value,
+                                                         float(self.model.render_step_size), 0.0, ptr(rs["packed"]),
+                                                         ptr(rs["scratch"]), rs["cap"], ptr(mb["ri"]), ptr(mb["t0"]),
+                                                         ptr(mb["t1"]), slots, s), "nsr_ray_march_bricks_write")
+            else:
+                x01m = mb["x01"]
+                mb["valid"] = False  # consumed: the ring slot is re-marched before its next use
             with _ops.timed("fused:march_prune"):
-                check(lib.nsr_ray_march_bricks_write(ptr(rs["ro"]), ptr(rs["rd"]), ptr(rs["t_min"]), ptr(rs["t_max"]),
-                                                     ptr(grid.roi_aabb), None, rx, ry, rz, ContractionType.AABB.value,
-                                                     float(self.model.render_step_size), 0.0, ptr(rs["packed"]),
-                                                     ptr(rs["scratch"]), rs["cap"], ptr(ab["ri"]), ptr(ab["t0"]),
-                                                     ptr(ab["t1"]), slots, s), "nsr_ray_march_bricks_write")
-                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rs["ro"]), ptr(rs["rd"]), ptr(ab["ri"]), ptr(ab["t0"]),
-                                              ptr(ab["t1"]), ptr(rs["packed"]), ptr(table), ptr(w1), ptr(ab["pws"]),
+                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rs["ro"]), ptr(rs["rd"]), ptr(mb["ri"]), ptr(mb["t0"]),
+                                              ptr(mb["t1"]), ptr(rs["packed"]), ptr(table), ptr(w1), ptr(ab["pws"]),
                                               ptr(kept), ptr(packed2), ptr(total), m_cap, slots, ptr(rs["total"]),
-                                              int(s_cap), ptr(kept_stats), s), "nsr_nerf_prune_pass")
+                                              int(s_cap), ptr(kept_stats), ptr(x01m), s), "nsr_nerf_prune_pass")
             if after_prune_queued is not None:
                 after_prune_queued(total)
             with _ops.timed("fused:main_pass"):
@@ -414,12 +453,12 @@ class FusedNeRFStep:
                 g1 = ewn.params.grad if compute_grads else None
                 g2 = tex.params.grad if compute_grads else None
                 check(lib.nsr_nerf_main_pass(_byref(d), ptr(ab["pws"]), m_cap, ptr(rs["packed"]), ptr(packed2),
-                                             ptr(ab["t0"]), ptr(ab["t1"]), ptr(rs["rd"]), ptr(rs["bg"]), ptr(rs["rgb"]),
+                                             ptr(mb["t0"]), ptr(mb["t1"]), ptr(rs["rd"]), ptr(rs["bg"]), ptr(rs["rgb"]),
                                              ptr(w1), ptr(w2),
                                              ptr(ewn.mlp_slice(g1)) if compute_grads else None,
                                              ptr(ewn.grid_slice(g1)) if compute_grads else None,
                                              ptr(g2) if compute_grads else None, ptr(ab["ws"]), int(s_cap), slots,
-                                             int(bool(compute_grads)), ptr(total), s), "nsr_nerf_main_pass")
+                                             int(bool(compute_grads)), ptr(total), ptr(x01m), s), "nsr_nerf_main_pass")
             L, ws = ab["ML"], ab["ws"]
 
             def view(off, n, dtype, shape):

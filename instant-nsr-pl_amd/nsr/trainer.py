@@ -401,6 +401,8 @@ class Trainer:
                 if marched is not None:
                     stream.wait_event(marched)
                 fused.pack_async(sets[u % W], a["n_rays"], a["m_cap"], stats_m)
+                if stream is not main and not os.environ.get("NSR_WRITE_INLINE"):  # ... and the sample arrays + positions, off the step's own chain
+                    fused.write_async(sets[u % W], consumer_stream=main)
                 e = torch.cuda.Event()
                 e.record(stream)
                 ev[("pack", u)] = e

@@ -145,9 +145,9 @@ SIGNATURES = {
     "nsr_neus_alpha_forward": [_P, _P, _P, _P, _P, _F, _P, _U, _P],
     "nsr_neus_alpha_backward": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _U, _P],
     "nsr_nerf_prune_layout": [_SD, _U, ctypes.POINTER(NsrNerfPruneLayout)],
-    "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P],
+    "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
-    "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P],
+    "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P],
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                             ctypes.POINTER(ctypes.c_uint64)],
