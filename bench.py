@@ -23,6 +23,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ENC_FWD_BYTES_PER_SAMPLE = 588  # 12 B coords + 16*8*2*2 B gathers + 64 B out (fp16 table)
+ADAM_TABLE_BYTES_PER_PARAM = 26  # fp32 p, m, v read (12) + written (12) + fp16 image written (2)
 ENC_BWD_BYTES_PER_SAMPLE = 2124  # 12 + 64*2(fp32 dy) ... fp32 atomics: 16*8*2*4 B *2 (RMW) + coords + dy
 
 
@@ -216,6 +217,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = ops.profile_end() if not tr.async_mode else {}
+    prof_sep = None
     if tr.async_mode:
         c1 = tr.counters()
         n_samples, n_rays = c1["samples"] - c0["samples"], c1["rays"] - c0["rays"]
@@ -240,6 +242,17 @@ def main():
         for k, v2 in ops.profile_end().items():
             if k not in prof:
                 prof[k] = v2
+        # the table backward WITHOUT the optimizer folded into it (gradient store + separate AdamW kernel): 32 more steps,
+        # so that the roofline line can also be read against the round-1 definition of the operation
+        if world == 1 and tr.fuse_table_update:
+            tr.fuse_table_update = False
+            c3 = tr.counters()
+            ops.profile_begin(native_only=True)
+            for _ in range(32):
+                tr.train_step()
+            prof_sep = ops.profile_end()
+            prof_sep["_samples"] = tr.counters()["samples"] - c3["samples"]
+            tr.fuse_table_update = True
 
     comm = None
     if world > 1 and getattr(tr, "sharded", None) is not None:
@@ -292,15 +305,31 @@ def main():
             name = max(cand, key=lambda k: cand[k][0])
             ms_total, launches, units = cand[name]
             bps = ENC_FWD_BYTES_PER_SAMPLE if name == "hashgrid_forward" else ENC_BWD_BYTES_PER_SAMPLE
-            achieved = bps * units / (ms_total * 1e-3) / 1e9
+            # one GPU: AdamW on the table is applied inside the table backward (csrc/hashgrid.hip OwnerAdam) -- the launch
+            # then also moves the optimizer's bytes: p, m, v read + p, m, v, fp16 image written per table parameter
+            fused_opt = bool(name == "hashgrid_backward_params" and world == 1 and tr.async_mode and tr.fuse_table_update)
+            opt_bytes = ADAM_TABLE_BYTES_PER_PARAM * tr.fused.ewn.grid_desc.n_entries * tr.fused.ewn.grid_desc.n_features \
+                if fused_opt else 0
+            per_launch = bps * units / launches + opt_bytes
+            achieved = per_launch * launches / (ms_total * 1e-3) / 1e9
             traffic, traffic_note = pmc_traffic(name, units / launches)
             frac = achieved / HBM_PEAK_GBS
-            if traffic is not None and traffic < bps * units / launches:
+            if traffic is not None and traffic < per_launch:
                 frac, traffic_note = None, traffic_note + "; measured traffic below the algorithmic bytes: fraction withheld"
-            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": frac, "traffic": traffic, "traffic_source": traffic_note,
+            roof = {"bound": "hbm", "kernel": name + ("+adamw(table)" if fused_opt else ""), "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "traffic": traffic, "traffic_source": traffic_note,
                     "algorithmic_bytes_per_sample": bps, "samples_per_launch": units / launches,
+                    "optimizer_bytes_per_launch": opt_bytes, "algorithmic_bytes_per_launch": per_launch,
                     "avg_launch_us": 1e3 * ms_total / launches}
+            if fused_opt and prof_sep and "hashgrid_backward_params" in prof_sep:
+                ms_b = prof_sep["hashgrid_backward_params"][0] + prof_sep.get("hashgrid_backward_bin", (0.0,))[0]
+                n_l = prof_sep["hashgrid_backward_params"][1]
+                ach_b = ENC_BWD_BYTES_PER_SAMPLE * prof_sep["_samples"] / (ms_b * 1e-3) / 1e9
+                roof["separate_optimizer"] = {
+                    "what": "32 further steps with the gradient stored and AdamW as its own kernel (the round-1 operation: "
+                            "item binning + accumulation only)", "avg_launch_us": 1e3 * ms_b / max(n_l, 1),
+                    "samples_per_launch": prof_sep["_samples"] / max(n_l, 1), "achieved": ach_b,
+                    "frac": ach_b / HBM_PEAK_GBS}
         res = {
             "metric": "hash-encoded MLP samples/sec, full training step (march + encode + MLP + composite, fwd+bwd, "
                       "AdamW), nerf-blender lego config",

@@ -514,7 +514,10 @@ int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, ui
                        const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
                        const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp, float *grad_table,
                        float *grad_color_mlp, void *workspace, uint32_t n_kept, uint32_t n_rays, int compute_grads,
-                       const int32_t *n_kept_dev, const float *x01_marched, void *stream);
+                       const int32_t *n_kept_dev, const float *x01_marched, const struct NsrTableAdam *table_adam,
+                       void *stream);
+/* table_adam (may be NULL): apply AdamW to the hash table inside the table backward (NsrTableAdam below) -- grad_table is
+ * then neither written nor read; with S == 0 kept samples the caller's optimizer still has to decay the table. */
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:
@@ -527,6 +530,25 @@ int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq
                    uint64_t zero_first_n, void *stream);
 /* zero_first_n (with zero_grad != 0): only grad[0 .. zero_first_n) is zeroed (0 = all of it; a multiple of 4) -- the fused
  * step OVERWRITES the hash-table part of the gradient every step, zeroing those 50 MB again is wasted bandwidth */
+/* AdamW fused into the owner-computes table backward: the workgroup that owns a table slice applies the update to it
+ * from the gradient it holds in LDS (no gradient store + separate optimizer read).  params / exp_avg / exp_avg_sq /
+ * shadow point at the TABLE part of the flat parameter vector (entry 0 of level 0 first; 16-byte aligned, shadow 8);
+ * step / hyper: the device schedule state of nsr_adam_tick / nsr_adamw_step_scheduled -- read here, NOT advanced: the
+ * caller advances it afterwards with nsr_adamw_step_scheduled over the remaining (MLP) parameters.  Bit-identical to
+ * nsr_hashgrid_backward_params_owner_accumulate + nsr_adamw_step on the same tensors. */
+typedef struct NsrTableAdam {
+    float *params, *exp_avg, *exp_avg_sq;
+    nsr_half *shadow; /* may be NULL */
+    const int32_t *step;
+    const float *hyper;
+    double base_lr, beta1, beta2, gamma;
+    int32_t milestone0, milestone1, milestone2;
+    float eps, weight_decay;
+} NsrTableAdam;
+int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
+                                                       float *workspace, uint32_t n, uint32_t level_mask_count,
+                                                       float grad_scale, const NsrGridDesc *desc, const int32_t *n_dev,
+                                                       const NsrTableAdam *adam, void *stream);
 /* The optimizer step of the asynchronous trainer in ONE launch: nsr_adam_tick + nsr_adamw_step over up to two tensors
  * (a: hash table + density MLP with its partial re-zeroing, b: colour MLP; n_b == 0: one tensor).  hyper12: 12 floats, 8-byte
  * aligned, zero-initialised ([0..7] as for nsr_adam_tick, [8] ticket counter).  Bit-identical to the separate launches. */

@@ -69,3 +69,36 @@ __device__ __forceinline__ float wave_incl_scan_mul(float v)
     }
     return v;
 }
+
+// ---- AdamW arithmetic shared by every kernel that applies it (csrc/util.hip k_adamw*, the table backward's fused
+// write-out in csrc/hashgrid.hip): torch.optim.AdamW semantics, the library is built with -ffp-contract=off, so the
+// same inputs give the same bits wherever this is inlined ------------------------------------------------------------
+__device__ __forceinline__ void nsr_adamw_elem(float &p, float &m, float &v, float gr, float lr, float b1, float b2,
+                                               float eps, float wd, float bc1, float bc2)
+{
+    p *= (1.f - lr * wd);
+    m = b1 * m + (1.f - b1) * gr;
+    v = b2 * v + (1.f - b2) * gr * gr;
+    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+    p -= (lr / bc1) * (m / denom);
+}
+
+// (lr, bias corrections) of the optimizer step that FOLLOWS the `done` steps counted in *step -- MultiStepLR over base_lr,
+// beta powers as running products kept in hyper[4..7] (doubles) by whoever advances the counter (k_adam_tick /
+// k_adamw_scheduled).  Read-only; p1 / p2 return the new running products for the caller that publishes them.
+__device__ __forceinline__ void nsr_adam_schedule(const int32_t *step, const float *hyper, double base_lr, double b1d,
+                                                  double b2d, double gamma, int32_t m0, int32_t m1, int32_t m2,
+                                                  float &lr, float &bc1, float &bc2, double &p1, double &p2)
+{
+    const int32_t done = *step, s = done + 1;
+    const int k = (done >= m0) + (done >= m1) + (done >= m2);
+    double scale = 1.0;
+    for (int i = 0; i < k; ++i) scale *= gamma;
+    const double *pw = reinterpret_cast<const double *>(hyper + 4);
+    const int32_t pw_step = *reinterpret_cast<const int32_t *>(hyper + 3);
+    if (pw_step == done && done > 0) { p1 = pw[0] * b1d; p2 = pw[1] * b2d; }
+    else { p1 = pow(b1d, (double)s); p2 = pow(b2d, (double)s); }
+    lr = (float)(base_lr * scale);
+    bc1 = (float)(1.0 - p1);
+    bc2 = (float)(1.0 - p2);
+}

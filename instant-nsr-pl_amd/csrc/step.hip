@@ -215,7 +215,7 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
                                   const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
                                   float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
                                   uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev,
-                                  const float *x01_marched, void *stream)
+                                  const float *x01_marched, const NsrTableAdam *table_adam, void *stream)
 {
     NSR_REQUIRE(d && prune_workspace && workspace && packed_marched && packed_kept, "nsr_nerf_main_pass: NULL pointer");
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
@@ -288,8 +288,10 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                   comp_rgb, opacity, depth, n_rays, stream));
     NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
+    NSR_REQUIRE(!(table_adam && compute_grads && S == 0), "nsr_nerf_main_pass: the fused table update needs a non-empty "
+                "sample buffer (the table still decays when nothing was kept)");
     if (!compute_grads || S == 0) return NSR_OK;
-    NSR_REQUIRE(grad_density_mlp && grad_table && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
+    NSR_REQUIRE(grad_density_mlp && (grad_table || table_adam) && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
     float *d_rgb = (float *)(ws + L.d_rgb), *d_logit = (float *)(ws + L.d_logit);
     float *d_tex = (float *)(ws + L.d_tex), *d_enc = (float *)(ws + L.d_enc);
     float *part2 = (float *)(ws + L.partials);
@@ -317,10 +319,16 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
         if (overlap_bins) {
             NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess,
                         "nsr_nerf_main_pass: helper stream join failed");
-            NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate(x01, d_enc, 2, 0, grad_table,
-                                                                  (float *)(ws + L.grid_ws), S, d->grid.n_levels, 1.0f,
-                                                                  0, &d->grid, n_kept_dev, stream));
+            if (table_adam)  // the optimizer's update of the table happens inside the backward (no gradient store)
+                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam(x01, d_enc, 2, 0, (float *)(ws + L.grid_ws), S,
+                                                                           d->grid.n_levels, 1.0f, &d->grid, n_kept_dev,
+                                                                           table_adam, stream));
+            else
+                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate(x01, d_enc, 2, 0, grad_table,
+                                                                      (float *)(ws + L.grid_ws), S, d->grid.n_levels,
+                                                                      1.0f, 0, &d->grid, n_kept_dev, stream));
         } else {
+            NSR_REQUIRE(!table_adam, "nsr_nerf_main_pass: the fused table update needs the helper stream");
             NSR_TRY(nsr_hashgrid_backward_params_owner(x01, d_enc, 2, 0, grad_table, (float *)(ws + L.grid_ws), S,
                                                        d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
         }

@@ -197,12 +197,7 @@ k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, flo
             float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float gr = ga[k] * unscale;
-                pa[k] *= (1.f - lr * wd);
-                ma[k] = b1 * ma[k] + (1.f - b1) * gr;
-                va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
-                const float denom = sqrtf(va[k]) / sqrtf(bc2) + eps;
-                pa[k] -= (lr / bc1) * (ma[k] / denom);
+                nsr_adamw_elem(pa[k], ma[k], va[k], ga[k] * unscale, lr, b1, b2, eps, wd, bc1, bc2);
             }
             *reinterpret_cast<float4 *>(p + base) = pp;
             *reinterpret_cast<float4 *>(m + base) = mm;
@@ -214,10 +209,8 @@ k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, flo
             }
         } else {
             for (uint64_t j = base; j < n; ++j) {
-                const float gr = g[j] * unscale;
-                float pj = p[j] * (1.f - lr * wd);
-                const float mj = b1 * m[j] + (1.f - b1) * gr, vj = b2 * v[j] + (1.f - b2) * gr * gr;
-                pj -= (lr / bc1) * (mj / (sqrtf(vj) / sqrtf(bc2) + eps));
+                float pj = p[j], mj = m[j], vj = v[j];
+                nsr_adamw_elem(pj, mj, vj, g[j] * unscale, lr, b1, b2, eps, wd, bc1, bc2);
                 p[j] = pj; m[j] = mj; v[j] = vj;
                 if (zero_grad && j < zero_first_n) g[j] = 0.f;
                 if (shadow) shadow[j] = __float2half_rn(pj);
@@ -313,12 +306,7 @@ __device__ __forceinline__ void adamw_span(float *__restrict__ p, float *__restr
             float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float gr = ga[k] * unscale;
-                pa[k] *= (1.f - lr * wd);
-                ma[k] = b1 * ma[k] + (1.f - b1) * gr;
-                va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
-                const float denom = sqrtf(va[k]) / sqrtf(bc2) + eps;
-                pa[k] -= (lr / bc1) * (ma[k] / denom);
+                nsr_adamw_elem(pa[k], ma[k], va[k], ga[k] * unscale, lr, b1, b2, eps, wd, bc1, bc2);
             }
             *reinterpret_cast<float4 *>(p + base) = pp;
             *reinterpret_cast<float4 *>(m + base) = mm;
@@ -330,10 +318,8 @@ __device__ __forceinline__ void adamw_span(float *__restrict__ p, float *__restr
             }
         } else {
             for (uint64_t j = base; j < n; ++j) {
-                const float gr = g[j] * unscale;
-                float pj = p[j] * (1.f - lr * wd);
-                const float mj = b1 * m[j] + (1.f - b1) * gr, vj = b2 * v[j] + (1.f - b2) * gr * gr;
-                pj -= (lr / bc1) * (mj / (sqrtf(vj) / sqrtf(bc2) + eps));
+                float pj = p[j], mj = m[j], vj = v[j];
+                nsr_adamw_elem(pj, mj, vj, g[j] * unscale, lr, b1, b2, eps, wd, bc1, bc2);
                 p[j] = pj; m[j] = mj; v[j] = vj;
                 if (zero_grad && j < zero_first_n) g[j] = 0.f;
                 if (shadow) shadow[j] = __float2half_rn(pj);
@@ -351,18 +337,13 @@ k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *__restrict__ step, float *__res
     __shared__ double pws[2];
     double *pw = reinterpret_cast<double *>(hyper + 4);
     int32_t *pw_step = reinterpret_cast<int32_t *>(hyper + 3);
-    const int32_t done = *step, s = done + 1;
+    const int32_t s = *step + 1;
     if (threadIdx.x == 0) {
-        const int k = (done >= m0) + (done >= m1) + (done >= m2);
-        double scale = 1.0;
-        for (int i = 0; i < k; ++i) scale *= gamma;
+        float lr0, c1, c2;
         double p1, p2;
-        if (*pw_step == done && done > 0) { p1 = pw[0] * b1d; p2 = pw[1] * b2d; }
-        else { p1 = pow(b1d, (double)s); p2 = pow(b2d, (double)s); }
+        nsr_adam_schedule(step, hyper, base_lr, b1d, b2d, gamma, m0, m1, m2, lr0, c1, c2, p1, p2);
         pws[0] = p1; pws[1] = p2;
-        hs[0] = (float)(base_lr * scale);
-        hs[1] = (float)(1.0 - p1);
-        hs[2] = (float)(1.0 - p2);
+        hs[0] = lr0; hs[1] = c1; hs[2] = c2;
     }
     __syncthreads();
     const float lr = hs[0], bc1 = hs[1], bc2 = hs[2];

@@ -179,7 +179,7 @@ class FusedNeRFStep:
                                              ptr(ewn.mlp_slice(g1)) if compute_grads else None,
                                              ptr(ewn.grid_slice(g1)) if compute_grads else None,
                                              ptr(g2) if compute_grads else None, ptr(ws), S, n_rays,
-                                             int(bool(compute_grads)), None, None, s), "nsr_nerf_main_pass")
+                                             int(bool(compute_grads)), None, None, None, s), "nsr_nerf_main_pass")
             def view(off, n, dtype, shape):
                 return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
 
@@ -408,7 +408,8 @@ class FusedNeRFStep:
         self._ab = ab
         return ab
 
-    def forward_backward_async(self, rs, s_cap, kept_stats, loss_scale=1.0, compute_grads=True, after_prune_queued=None):
+    def forward_backward_async(self, rs, s_cap, kept_stats, loss_scale=1.0, compute_grads=True, after_prune_queued=None,
+                               table_adam=None):
         """the training step on ray set ``rs`` (filled by march_async, possibly on another stream -- the caller orders
         the streams) with NO host synchronisation: the marched / kept sample counts stay on the device, all buffers
         have fixed capacities (rs['m_cap'], s_cap) and every kernel is launched for the capacity.
@@ -458,7 +459,9 @@ class FusedNeRFStep:
                                              ptr(ewn.mlp_slice(g1)) if compute_grads else None,
                                              ptr(ewn.grid_slice(g1)) if compute_grads else None,
                                              ptr(g2) if compute_grads else None, ptr(ab["ws"]), int(s_cap), slots,
-                                             int(bool(compute_grads)), ptr(total), ptr(x01m), s), "nsr_nerf_main_pass")
+                                             int(bool(compute_grads)), ptr(total), ptr(x01m),
+                                             _byref(table_adam) if (table_adam is not None and compute_grads) else None,
+                                             s), "nsr_nerf_main_pass")
             L, ws = ab["ML"], ab["ws"]
 
             def view(off, n, dtype, shape):

@@ -54,16 +54,52 @@ class FusedAdamW:
             self.other.step()
             self.other.zero_grad(set_to_none=False)
 
-    def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33):
-        """the same update with the step counter, MultiStepLR scale and bias corrections kept ON THE DEVICE
-        (nsr_adam_tick): no per-step host scalar, so the launches can be replayed from a captured graph"""
-        if self.other is not None:
-            raise NotImplementedError("step_device covers models whose parameters all live in fused tcnn modules")
+    def _device_schedule_state(self):
         dev = self.tcnn_modules[0].params.device
         if getattr(self, "_step_dev", None) is None:
             self._step_dev = torch.tensor([self.step_count], dtype=torch.int32, device=dev)
             self._hyper = torch.zeros(12, dtype=torch.float32, device=dev)  # lr, bc1, bc2 | running beta powers | ticket
+        return self._step_dev, self._hyper
+
+    def table_update_desc(self, module, milestones=(10000, 15000, 18000), gamma=0.33):
+        """``NsrTableAdam`` for ``module`` (a NetworkWithInputEncoding): AdamW on its hash table applied INSIDE the table
+        backward of the asynchronous step (csrc/hashgrid.hip OwnerAdam); ``step_device(skip_table_of=module)`` then
+        updates what is left (the MLP weights) and advances the device-side schedule."""
+        from nsr_hip import NsrTableAdam
+        step_dev, hyper = self._device_schedule_state()
+        p = module.params
+        exp_avg, exp_avg_sq, shadow = self.state[p]
+        n0 = int(module.n_network_params)
+        ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
+        d = NsrTableAdam()
+        d.params, d.exp_avg, d.exp_avg_sq = (t.data_ptr() + 4 * n0 for t in (p.data, exp_avg, exp_avg_sq))
+        d.shadow = shadow.data_ptr() + 2 * n0
+        d.step, d.hyper = step_dev.data_ptr(), hyper.data_ptr()
+        d.base_lr, d.beta1, d.beta2, d.gamma = float(self.lr), float(self.betas[0]), float(self.betas[1]), float(gamma)
+        d.milestone0, d.milestone1, d.milestone2 = ms
+        d.eps, d.weight_decay = float(self.eps), float(self.wd)
+        return d
+
+    def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33, skip_table_of=None):
+        """the same update with the step counter, MultiStepLR scale and bias corrections kept ON THE DEVICE
+        (nsr_adam_tick): no per-step host scalar, so the launches can be replayed from a captured graph"""
+        if self.other is not None:
+            raise NotImplementedError("step_device covers models whose parameters all live in fused tcnn modules")
+        self._device_schedule_state()
         self.step_count += 1  # host mirror (not read by the kernels)
+        if skip_table_of is not None:
+            # the table of ``skip_table_of`` was updated inside its backward (table_update_desc): what is left are the MLP
+            # weights in front of it and the other module -- one launch, which also advances the schedule
+            m0, n0 = skip_table_of, int(skip_table_of.n_network_params)
+            rest = [m for m in self.tcnn_modules if m is not m0]
+            assert len(rest) <= 1 and n0 > 0 and n0 % 4 == 0
+            segs = [tuple(t[:n0] for t in (m0.params.data, m0.params.grad) + tuple(self.state[m0.params])) + (0,)]
+            segs += [(m.params.data, m.params.grad) + tuple(self.state[m.params]) + (0,) for m in rest]
+            _ops.adamw_step_scheduled(segs, self._step_dev, self._hyper, self.lr, self.betas[0], self.betas[1], gamma,
+                                      milestones, self.eps, self.wd)
+            for m in self.tcnn_modules:
+                m.adopt_shadow(self.state[m.params][2])
+            return
 
         def zero_n(m):  # the fused step overwrites the hash-table slice of the gradient: zero only the MLP slice in front
             n_zero = getattr(m, "n_network_params", 0) if getattr(m, "grid_desc", None) is not None else 0
@@ -151,6 +187,7 @@ class Trainer:
         # world > 1: reduce-scatter -> AdamW on this rank's 1/P of the table -> all-gather of the fp16 image (nsr/parallel.py)
         self.sharded = ShardedAdamW(tc) if (world_size > 1 and not other and dist.is_initialized()) else None
         self.comm_timings = None
+        self.fuse_table_update = True  # asynchronous single-GPU steps: AdamW on the table inside the table backward
         self.last = {}
         self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None
         # use_graphs: replay the queued launches of a step from a captured HIP graph.  Correct (tests/test_gpu_fused.py)
@@ -444,12 +481,19 @@ class Trainer:
             if self.pipeline_march and a["marched_upto"] >= t + 1 and a["packed_upto"] < t + 1:
                 queue_pack(t + 1, side)           # the only work between this pruning pass and the next one
 
-        res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued)
+        # one GPU: AdamW on the hash table happens inside the table backward (no gradient store / optimizer read-back)
+        fuse_table = (self.world_size == 1 and self.sharded is None and self.fuse_table_update
+                      and not os.environ.get("NSR_TABLE_ADAM_SEPARATE"))
+        res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued,
+                                           table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None)
         a["total_kept"] = res["num_samples"]
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            self._optimizer_step(True)
+            if fuse_table:
+                self.opt.step_device(skip_table_of=fused.ewn)
+            else:
+                self._optimizer_step(True)
         a["last_step_event"] = torch.cuda.Event()
         a["last_step_event"].record(main)
         for key in [k for k in ev if k[1] < t - 2]:
@@ -541,12 +585,19 @@ class Trainer:
                 a["event"].record(self._side)
             a["pending"] = True
 
-        res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued)
+        # one GPU: AdamW on the hash table happens inside the table backward (no gradient store / optimizer read-back)
+        fuse_table = (self.world_size == 1 and self.sharded is None and self.fuse_table_update
+                      and not os.environ.get("NSR_TABLE_ADAM_SEPARATE"))
+        res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued,
+                                           table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None)
         a["total_kept"] = res["num_samples"]
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            self._optimizer_step(True)
+            if fuse_table:
+                self.opt.step_device(skip_table_of=fused.ewn)
+            else:
+                self._optimizer_step(True)
         if a["pending"]:
             main.wait_event(a["event"])  # join: the next step (or the grid refresh before it) starts behind the marching
         return res["loss_acc"]  # [sum, valid rays]: the loss value itself is formed on demand (LazyLoss)

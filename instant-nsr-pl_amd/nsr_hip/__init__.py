@@ -43,6 +43,15 @@ class NsrMlpDesc(ctypes.Structure):
     ]
 
 
+class NsrTableAdam(ctypes.Structure):
+    """include/nsr_hip.h: AdamW applied to the hash table inside the owner-computes table backward"""
+    _fields_ = [("params", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("shadow", ctypes.c_void_p), ("step", ctypes.c_void_p), ("hyper", ctypes.c_void_p),
+                ("base_lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
+                ("gamma", ctypes.c_double), ("milestone0", ctypes.c_int32), ("milestone1", ctypes.c_int32),
+                ("milestone2", ctypes.c_int32), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float)]
+
+
 class NsrVmlpDesc(ctypes.Structure):
     _fields_ = [("n_in", ctypes.c_uint32), ("in_pad", ctypes.c_uint32), ("n_out", ctypes.c_uint32),
                 ("n_hidden", ctypes.c_uint32), ("activation", ctypes.c_uint32)]
@@ -147,7 +156,8 @@ SIGNATURES = {
     "nsr_nerf_prune_layout": [_SD, _U, ctypes.POINTER(NsrNerfPruneLayout)],
     "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
-    "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P],
+    "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P, _P],
+    "nsr_hashgrid_backward_params_owner_accumulate_adam": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P, _P, _P],
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                             ctypes.POINTER(ctypes.c_uint64)],

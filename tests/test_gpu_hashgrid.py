@@ -254,3 +254,51 @@ def test_cached_jacobian_reproduces_input_gradient_and_its_double_backward(mask_
     assert float((dx - want_dx).norm() / want_dx.norm()) < 1e-5
     assert float((d_dy[:, 3:35] - want_ddy).norm() / want_ddy.norm()) < 1e-5
     assert float(d_dy[:, 3 + 2 * mask_count:35].abs().max() if mask_count < 16 else 0.0) == 0.0
+
+
+def test_owner_backward_with_fused_adamw_matches_gradient_plus_optimizer():
+    """nsr_hashgrid_backward_params_owner_accumulate_adam == owner_accumulate -> nsr_adamw_step (device schedule) on the
+    table: parameters, moments and fp16 image bit-identical, over three steps (pow() start + running beta products)"""
+    import ctypes
+    import nsr_hip
+    from nsr_hip import NsrTableAdam, check, lib, ops, ptr, stream_ptr
+    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
+    n, n_tab = 30000, gd.n_entries * 2
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
+
+    def fresh():
+        gg = torch.Generator(device="cuda").manual_seed(5)
+        p = torch.randn(n_tab, device="cuda", generator=gg) * 0.1
+        return dict(p=p, m=torch.zeros_like(p), v=torch.zeros_like(p), h=torch.empty(n_tab, dtype=torch.float16, device="cuda"),
+                    step=torch.zeros(1, dtype=torch.int32, device="cuda"), hyper=torch.zeros(12, device="cuda"))
+
+    a, b = fresh(), fresh()
+    grad = torch.empty(n_tab, device="cuda")
+    ms = (2, 0x7fffffff, 0x7fffffff)
+    for it in range(3):
+        x = torch.rand(n, 3, device="cuda", generator=g)
+        dy = torch.randn(16, n, 2, device="cuda", generator=g) * 1e-3
+        check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, ctypes.byref(gd), None, stream_ptr()), "bin")
+        # (a) gradient, then the optimizer kernel
+        check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x), ptr(dy), 2, 0, ptr(grad), ptr(ws), n, 16, 1.0, 0,
+                                                                ctypes.byref(gd), None, stream_ptr()), "accumulate")
+        ops.adam_tick(a["step"], a["hyper"], 0.01, 0.9, 0.99, 0.33, ms)
+        ops.adamw_step(a["p"], grad, a["m"], a["v"], a["h"], 0.01, 0.9, 0.99, 1e-15, 0.01, it + 1, zero_grad=False,
+                       hyper=a["hyper"])
+        # (b) fused; the schedule is advanced afterwards (here by the tick kernel, in the trainer by the MLP update)
+        d = NsrTableAdam()
+        d.params, d.exp_avg, d.exp_avg_sq, d.shadow = b["p"].data_ptr(), b["m"].data_ptr(), b["v"].data_ptr(), b["h"].data_ptr()
+        d.step, d.hyper = b["step"].data_ptr(), b["hyper"].data_ptr()
+        d.base_lr, d.beta1, d.beta2, d.gamma = 0.01, 0.9, 0.99, 0.33
+        d.milestone0, d.milestone1, d.milestone2 = ms
+        d.eps, d.weight_decay = 1e-15, 0.01
+        check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(x), ptr(dy), 2, 0, ptr(ws), n, 16, 1.0,
+                                                                     ctypes.byref(gd), None, ctypes.byref(d), stream_ptr()),
+              "accumulate_adam")
+        ops.adam_tick(b["step"], b["hyper"], 0.01, 0.9, 0.99, 0.33, ms)
+        off = [int(o) * 2 for o in gd.offset[:17]]
+        for k in ("p", "m", "v", "h"):
+            if not torch.equal(a[k], b[k]):
+                bad = [(lvl, int((a[k][off[lvl]:off[lvl + 1]] != b[k][off[lvl]:off[lvl + 1]]).sum())) for lvl in range(16)]
+                raise AssertionError((it, k, [t for t in bad if t[1]]))
