@@ -187,7 +187,8 @@ class Trainer:
         # world > 1: reduce-scatter -> AdamW on this rank's 1/P of the table -> all-gather of the fp16 image (nsr/parallel.py)
         self.sharded = ShardedAdamW(tc) if (world_size > 1 and not other and dist.is_initialized()) else None
         self.comm_timings = None
-        self.fuse_table_update = True  # asynchronous single-GPU steps: AdamW on the table inside the table backward
+        # asynchronous single-GPU steps: AdamW on the table inside the table backward (NSR_TABLE_ADAM_SEPARATE: A/B switch)
+        self.fuse_table_update = not os.environ.get("NSR_TABLE_ADAM_SEPARATE")
         self.last = {}
         self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None
         # use_graphs: replay the queued launches of a step from a captured HIP graph.  Correct (tests/test_gpu_fused.py)
@@ -482,8 +483,7 @@ class Trainer:
                 queue_pack(t + 1, side)           # the only work between this pruning pass and the next one
 
         # one GPU: AdamW on the hash table happens inside the table backward (no gradient store / optimizer read-back)
-        fuse_table = (self.world_size == 1 and self.sharded is None and self.fuse_table_update
-                      and not os.environ.get("NSR_TABLE_ADAM_SEPARATE"))
+        fuse_table = self.world_size == 1 and self.sharded is None and self.fuse_table_update
         res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued,
                                            table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None)
         a["total_kept"] = res["num_samples"]
@@ -586,8 +586,7 @@ class Trainer:
             a["pending"] = True
 
         # one GPU: AdamW on the hash table happens inside the table backward (no gradient store / optimizer read-back)
-        fuse_table = (self.world_size == 1 and self.sharded is None and self.fuse_table_update
-                      and not os.environ.get("NSR_TABLE_ADAM_SEPARATE"))
+        fuse_table = self.world_size == 1 and self.sharded is None and self.fuse_table_update
         res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued,
                                            table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None)
         a["total_kept"] = res["num_samples"]
