@@ -530,6 +530,15 @@ int nsr_adamw_step(float *params, float *grad, float *exp_avg, float *exp_avg_sq
                    uint64_t zero_first_n, void *stream);
 /* zero_first_n (with zero_grad != 0): only grad[0 .. zero_first_n) is zeroed (0 = all of it; a multiple of 4) -- the fused
  * step OVERWRITES the hash-table part of the gradient every step, zeroing those 50 MB again is wasted bandwidth */
+/* torch.optim.AdamW over up to 32 small tensors in ONE launch, each with its own learning rate (parameter groups of the
+ * NeuS systems: fp32 heads 0.01, variance 0.001 -- configs/neus-*.yaml optimizer.params); zero_grad != 0 clears grad */
+typedef struct NsrAdamSegment {
+    float *params, *grad, *exp_avg, *exp_avg_sq;
+    uint64_t n;
+    float lr;
+} NsrAdamSegment;
+int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segments, float beta1, float beta2, float eps,
+                    float weight_decay, float bias_correction1, float bias_correction2, int zero_grad, void *stream);
 /* AdamW fused into the owner-computes table backward: the workgroup that owns a table slice applies the update to it
  * from the gradient it holds in LDS (no gradient store + separate optimizer read).  params / exp_avg / exp_avg_sq /
  * shadow point at the TABLE part of the flat parameter vector (entry 0 of level 0 first; 16-byte aligned, shadow 8);
@@ -584,6 +593,18 @@ typedef struct NsrVmlpDesc {
 } NsrVmlpDesc;
 uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *desc);
 uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *desc, uint32_t n);
+/* The nn.Linear tensors of a reference VanillaMLP layer (models/network_utils.py:95-139): weight_v [n_out][n_in] with
+ * weight_g [n_out] (old-style torch weight_norm, W[r] = g[r] v[r] / |v[r]|) or the plain weight in weight_v with weight_g
+ * NULL; grad_* receive the gradients (unfold).  nsr_vmlp_fold builds the padded parameter blob from n_hidden + 1 layers,
+ * nsr_vmlp_unfold_gradient turns the blob's gradient into the gradients of those tensors (accumulate != 0: added). */
+typedef struct NsrVanillaLayer {
+    const float *weight_v, *weight_g, *bias;
+    float *grad_v, *grad_g, *grad_bias;
+    uint32_t n_out, n_in;
+} NsrVanillaLayer;
+int nsr_vmlp_fold(const NsrVmlpDesc *desc, const NsrVanillaLayer *layers, uint32_t n_layers, float *blob, void *stream);
+int nsr_vmlp_unfold_gradient(const NsrVmlpDesc *desc, const NsrVanillaLayer *layers, uint32_t n_layers,
+                             const float *grad_blob, int accumulate, void *stream);
 /* x: fp32 rows [n][x_stride]; with enc != NULL the input is [2 x - 1 (3 columns of x) | enc (fp16 rows, n_in - 3 columns)]
  * (CompositeEncoding with include_xyz, models/network_utils.py:75-76); enc_stride = 0x80000000 | F selects the level-major
  * encoding [(n_in - 3) / F][n][F] that the fused encode kernels write.  Rows < n_full write all 16 output columns to
@@ -646,6 +667,10 @@ int nsr_neus_shade_backward(const float *sdf_out, const float *grad, const float
                             uint32_t n_feat, const float *loss_weights8, float loss_scale, float n_samples, float *d_out,
                             float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
                             const int32_t *n_dev, void *stream);
+
+/* inv_s[0] = exp(10 variance[0]) (models/neus.py:27-32); grad_variance (+)= acc[inv_s gradient slot] * inv_s * 10 */
+int nsr_neus_inv_s(const float *variance, float *inv_s, void *stream);
+int nsr_neus_variance_gradient(const float *acc, const float *inv_s, float *grad_variance, int accumulate, void *stream);
 
 /* ---- NeRF++ background of the NeuS model (reference models/neus.py:169-203 `forward_bg_`; VolumeDensity with an fp32
  * VanillaMLP head models/geometry.py:116-130, trunc_exp models/utils.py:55-66, VolumeRadiance models/texture.py:23-30).

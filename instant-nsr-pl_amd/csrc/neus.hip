@@ -808,3 +808,33 @@ extern "C" int nsr_bg_join_gradients(const float *d_logit, const float *d_tex_in
     NSR_CHECK_LAUNCH("nsr_bg_join_gradients");
     return NSR_OK;
 }
+
+// inv_s = exp(10 variance) (models/neus.py:27-32) and d loss / d variance from the accumulator slot the shade backward
+// fills: two one-thread kernels instead of ~8 elementwise launches
+namespace {
+__global__ void k_neus_inv_s(const float *__restrict__ variance, float *__restrict__ inv_s) { inv_s[0] = expf(variance[0] * 10.f); }
+__global__ void k_neus_variance_grad(const float *__restrict__ acc, const float *__restrict__ inv_s,
+                                     float *__restrict__ grad, int accumulate)
+{
+    const float g = acc[ACC_INV_S_GRAD] * inv_s[0] * 10.f;
+    grad[0] = accumulate ? grad[0] + g : g;
+}
+}  // namespace
+
+extern "C" int nsr_neus_inv_s(const float *variance, float *inv_s, void *stream)
+{
+    NSR_REQUIRE(variance && inv_s, "nsr_neus_inv_s: NULL pointer");
+    hipLaunchKernelGGL(k_neus_inv_s, dim3(1), dim3(1), 0, (hipStream_t)stream, variance, inv_s);
+    NSR_CHECK_LAUNCH("nsr_neus_inv_s");
+    return NSR_OK;
+}
+
+extern "C" int nsr_neus_variance_gradient(const float *acc, const float *inv_s, float *grad_variance, int accumulate,
+                                          void *stream)
+{
+    NSR_REQUIRE(acc && inv_s && grad_variance, "nsr_neus_variance_gradient: NULL pointer");
+    hipLaunchKernelGGL(k_neus_variance_grad, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, inv_s, grad_variance,
+                       accumulate);
+    NSR_CHECK_LAUNCH("nsr_neus_variance_gradient");
+    return NSR_OK;
+}

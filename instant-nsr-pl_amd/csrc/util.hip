@@ -364,6 +364,29 @@ k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *__restrict__ step, float *__res
     }
 }
 
+// ---- AdamW over MANY small tensors in one launch (the fp32 heads + variance of the NeuS systems: 7..19 tensors of
+// 1..4096 elements, each with its parameter group's learning rate): blockIdx.y = tensor --------------------------------
+constexpr int ADAM_MULTI_MAX = 32;
+struct AdamMulti {
+    float *p[ADAM_MULTI_MAX], *g[ADAM_MULTI_MAX], *m[ADAM_MULTI_MAX], *v[ADAM_MULTI_MAX];
+    uint32_t n[ADAM_MULTI_MAX];
+    float lr[ADAM_MULTI_MAX];
+};
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_adamw_multi(const AdamMulti t, float b1, float b2, float eps, float wd, float bc1, float bc2, int zero_grad)
+{
+    const uint32_t s = blockIdx.y, n = t.n[s];
+    float *p = t.p[s], *g = t.g[s], *m = t.m[s], *v = t.v[s];
+    const float lr = t.lr[s];
+    for (uint32_t j = blockIdx.x * EW_BLOCK + threadIdx.x; j < n; j += gridDim.x * EW_BLOCK) {
+        float pj = p[j], mj = m[j], vj = v[j];
+        nsr_adamw_elem(pj, mj, vj, g[j], lr, b1, b2, eps, wd, bc1, bc2);
+        p[j] = pj; m[j] = mj; v[j] = vj;
+        if (zero_grad) g[j] = 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int nsr_sh4_forward(const float *u, nsr_half *y, uint32_t n, uint32_t y_stride, void *stream)
@@ -519,5 +542,30 @@ extern "C" int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *e
                        hyper12, base_lr, beta1, beta2, gamma, milestone0, milestone1, milestone2, (float)beta1,
                        (float)beta2, eps, weight_decay, grad_unscale, zero_grad);
     NSR_CHECK_LAUNCH("nsr_adamw_step_scheduled");
+    return NSR_OK;
+}
+
+extern "C" int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segments, float beta1, float beta2, float eps,
+                               float weight_decay, float bias_correction1, float bias_correction2, int zero_grad,
+                               void *stream)
+{
+    if (n_segments == 0) return NSR_OK;
+    NSR_REQUIRE(segments && n_segments <= (uint32_t)ADAM_MULTI_MAX, "nsr_adamw_multi: 1..%d segments", ADAM_MULTI_MAX);
+    AdamMulti t;
+    uint32_t n_max = 0;
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        const NsrAdamSegment &sg = segments[i];
+        NSR_REQUIRE(sg.params && sg.grad && sg.exp_avg && sg.exp_avg_sq && sg.n < (1ull << 32),
+                    "nsr_adamw_multi: segment %u has a NULL pointer or more than 2^32 - 1 elements", i);
+        t.p[i] = sg.params; t.g[i] = sg.grad; t.m[i] = sg.exp_avg; t.v[i] = sg.exp_avg_sq;
+        t.n[i] = (uint32_t)sg.n; t.lr[i] = sg.lr;
+        n_max = sg.n > n_max ? (uint32_t)sg.n : n_max;
+    }
+    uint32_t bx = nsr_div_up(n_max, EW_BLOCK);
+    if (bx > 64) bx = 64;
+    if (bx == 0) bx = 1;
+    hipLaunchKernelGGL(k_adamw_multi, dim3(bx, n_segments), dim3(EW_BLOCK), 0, (hipStream_t)stream, t, beta1, beta2, eps,
+                       weight_decay, bias_correction1, bias_correction2, zero_grad);
+    NSR_CHECK_LAUNCH("nsr_adamw_multi");
     return NSR_OK;
 }

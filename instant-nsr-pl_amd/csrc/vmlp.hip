@@ -23,6 +23,7 @@
 //
 // Parameter blob (fp32): W0[64][in_pad] b0[64] | (W1[64][64] b1[64]) | Wl[16][64] bl[16]   (rows >= n_out of Wl/bl: 0).
 #include "nsr_common.h"
+#include <string.h>
 
 namespace {
 
@@ -646,6 +647,87 @@ uint32_t vmlp_blocks(uint32_t n)
     return tiles < 1024u ? (tiles ? tiles : 1u) : 1024u;  // one wave per SIMD on 256 CUs
 }
 
+// ---- parameter blob <-> the nn.Linear tensors of a reference VanillaMLP (models/network_utils.py:95-139) ---------------
+// The blob is what the MFMA kernels read; the framework side owns weight / (weight_g, weight_v) / bias tensors (old-style
+// torch weight_norm, dim = 0: W[r] = g[r] v[r] / |v[r]|).  One wave per blob row: fold builds the padded blob, unfold turns
+// the blob's gradient into the gradients of those tensors (through the weight-norm fold) -- two launches instead of the
+// ~45 elementwise / reduction launches the same arithmetic costs through torch autograd.
+struct VanillaLayers {
+    const float *v[3];     // weight_v (weight-normed layer) or weight
+    const float *g[3];     // weight_g or NULL
+    const float *bias[3];
+    float *grad_v[3], *grad_g[3], *grad_bias[3];
+    uint32_t n_out[3], n_in[3];   // logical dims of layer l
+    uint32_t rows[3], cols[3];    // padded dims in the blob (64 x in_pad | 64 x 64 | 16 x 64)
+    uint32_t w_off[3], b_off[3];  // float offsets of W_l and b_l in the blob
+    uint32_t n_layers;
+};
+
+__global__ void __launch_bounds__(256)
+k_vmlp_fold(const VanillaLayers L, float *__restrict__ blob)
+{
+    uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t l = 0;
+    while (l < L.n_layers && row >= L.rows[l]) { row -= L.rows[l]; ++l; }
+    if (l >= L.n_layers) return;
+    const uint32_t n_in = L.n_in[l], cols = L.cols[l];
+    float *w = blob + L.w_off[l] + (uint64_t)row * cols;
+    if (row >= L.n_out[l]) {  // padding row of the output layer
+        for (uint32_t c = lane; c < cols; c += 64) w[c] = 0.f;
+        if (lane == 0) blob[L.b_off[l] + row] = 0.f;
+        return;
+    }
+    const float *v = L.v[l] + (uint64_t)row * n_in;
+    float scale = 1.f, inv_norm = 1.f;
+    const bool wn = L.g[l] != nullptr;
+    if (wn) {
+        float ss = 0.f;
+        for (uint32_t c = lane; c < n_in; c += 64) ss += v[c] * v[c];
+        ss = wave_sum(ss);
+        scale = L.g[l][row];
+        inv_norm = sqrtf(ss);
+    }
+    for (uint32_t c = lane; c < cols; c += 64) w[c] = c < n_in ? (wn ? scale * v[c] / inv_norm : v[c]) : 0.f;
+    if (lane == 0) blob[L.b_off[l] + row] = L.bias[l][row];
+}
+
+__global__ void __launch_bounds__(256)
+k_vmlp_unfold(const VanillaLayers L, const float *__restrict__ grad_blob, int accumulate)
+{
+    uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t l = 0;
+    while (l < L.n_layers && row >= L.rows[l]) { row -= L.rows[l]; ++l; }
+    if (l >= L.n_layers || row >= L.n_out[l]) return;
+    const uint32_t n_in = L.n_in[l], cols = L.cols[l];
+    const float *dw = grad_blob + L.w_off[l] + (uint64_t)row * cols;
+    float *gv = L.grad_v[l] + (uint64_t)row * n_in;
+    if (lane == 0) {
+        const float db = grad_blob[L.b_off[l] + row];
+        L.grad_bias[l][row] = accumulate ? L.grad_bias[l][row] + db : db;
+    }
+    if (!L.g[l]) {
+        for (uint32_t c = lane; c < n_in; c += 64) gv[c] = accumulate ? gv[c] + dw[c] : dw[c];
+        return;
+    }
+    // W = g v / |v|:  dL/dg = dW . v / |v| ;  dL/dv = (g / |v|) (dW - v (dW . v) / |v|^2)
+    const float *v = L.v[l] + (uint64_t)row * n_in;
+    float ss = 0.f, dot = 0.f;
+    for (uint32_t c = lane; c < n_in; c += 64) { ss += v[c] * v[c]; dot += dw[c] * v[c]; }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float norm = sqrtf(ss), g = L.g[l][row];
+    if (lane == 0) {
+        const float dg = dot / norm;
+        L.grad_g[l][row] = accumulate ? L.grad_g[l][row] + dg : dg;
+    }
+    for (uint32_t c = lane; c < n_in; c += 64) {
+        const float d = (g / norm) * (dw[c] - v[c] * (dot / (norm * norm)));
+        gv[c] = accumulate ? gv[c] + d : d;
+    }
+}
+
 }  // namespace
 
 extern "C" uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *d)
@@ -739,5 +821,65 @@ extern "C" int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, con
     hipLaunchKernelGGL(k_vmlp_reduce, dim3(nsr_div_up(bf, 256), nsr_div_up(blocks, VRED_SEG)), dim3(256), 0,
                        (hipStream_t)stream, partials, grad_blob, bf, blocks);
     NSR_CHECK_LAUNCH("nsr_vmlp_reduce");
+    return NSR_OK;
+}
+
+static int vanilla_layers(const NsrVmlpDesc *d, const NsrVanillaLayer *layers, uint32_t n_layers, bool want_grads,
+                          VanillaLayers *L, uint32_t *total_rows)
+{
+    NSR_REQUIRE(layers && n_layers == d->n_hidden + 1, "vmlp fold: a network with %u hidden layers has %u Linear layers",
+                d->n_hidden, d->n_hidden + 1);
+    memset(L, 0, sizeof(*L));
+    L->n_layers = n_layers;
+    uint32_t off = 0, rows = 0;
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        const bool last = l + 1 == n_layers;
+        L->rows[l] = last ? 16 : W;
+        L->cols[l] = l == 0 ? d->in_pad : W;
+        L->n_out[l] = last ? d->n_out : W;
+        L->n_in[l] = l == 0 ? d->n_in : W;
+        NSR_REQUIRE(layers[l].n_out == L->n_out[l] && layers[l].n_in == L->n_in[l],
+                    "vmlp fold: layer %u is %u x %u, the descriptor says %u x %u", l, layers[l].n_out, layers[l].n_in,
+                    L->n_out[l], L->n_in[l]);
+        NSR_REQUIRE(layers[l].weight_v && layers[l].bias, "vmlp fold: NULL weight / bias");
+        NSR_REQUIRE(!want_grads || (layers[l].grad_v && layers[l].grad_bias && (!layers[l].weight_g || layers[l].grad_g)),
+                    "vmlp unfold: NULL gradient tensor");
+        L->v[l] = layers[l].weight_v; L->g[l] = layers[l].weight_g; L->bias[l] = layers[l].bias;
+        L->grad_v[l] = layers[l].grad_v; L->grad_g[l] = layers[l].grad_g; L->grad_bias[l] = layers[l].grad_bias;
+        L->w_off[l] = off;
+        off += L->rows[l] * L->cols[l];
+        L->b_off[l] = off;
+        off += L->rows[l];
+        rows += L->rows[l];
+    }
+    NSR_REQUIRE(off == nsr_vmlp_blob_floats(d), "vmlp fold: blob layout mismatch");
+    *total_rows = rows;
+    return NSR_OK;
+}
+
+extern "C" int nsr_vmlp_fold(const NsrVmlpDesc *desc, const NsrVanillaLayer *layers, uint32_t n_layers, float *blob,
+                             void *stream)
+{
+    if (int rc = check_vmlp(desc, "nsr_vmlp_fold")) return rc;
+    NSR_REQUIRE(blob, "nsr_vmlp_fold: NULL blob");
+    VanillaLayers L;
+    uint32_t rows = 0;
+    if (int rc = vanilla_layers(desc, layers, n_layers, false, &L, &rows)) return rc;
+    hipLaunchKernelGGL(k_vmlp_fold, dim3(nsr_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, L, blob);
+    NSR_CHECK_LAUNCH("nsr_vmlp_fold");
+    return NSR_OK;
+}
+
+extern "C" int nsr_vmlp_unfold_gradient(const NsrVmlpDesc *desc, const NsrVanillaLayer *layers, uint32_t n_layers,
+                                        const float *grad_blob, int accumulate, void *stream)
+{
+    if (int rc = check_vmlp(desc, "nsr_vmlp_unfold_gradient")) return rc;
+    NSR_REQUIRE(grad_blob, "nsr_vmlp_unfold_gradient: NULL gradient blob");
+    VanillaLayers L;
+    uint32_t rows = 0;
+    if (int rc = vanilla_layers(desc, layers, n_layers, true, &L, &rows)) return rc;
+    hipLaunchKernelGGL(k_vmlp_unfold, dim3(nsr_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, L, grad_blob,
+                       accumulate);
+    NSR_CHECK_LAUNCH("nsr_vmlp_unfold_gradient");
     return NSR_OK;
 }

@@ -19,7 +19,7 @@ import ctypes
 import torch
 
 from nerfacc import ContractionType
-from nsr_hip import NsrVmlpDesc, check, lib, ptr, stream_ptr
+from nsr_hip import NsrAdamSegment, NsrVanillaLayer, NsrVmlpDesc, check, lib, ptr, stream_ptr
 from nsr_hip import ops as _ops
 
 F32, F16 = torch.float32, torch.float16
@@ -43,7 +43,10 @@ def _linear_weight(layer):
 
 
 class VanillaBlob:
-    """parameter blob of csrc/vmlp.hip built (differentiably) from the Linear layers of a reference VanillaMLP"""
+    """parameter blob of csrc/vmlp.hip for the Linear layers of a reference VanillaMLP: ``build`` folds weight norm and
+    pads in ONE launch (nsr_vmlp_fold), ``push_gradient`` turns the blob's gradient into ``.grad`` of weight_g / weight_v /
+    weight / bias in ONE launch (nsr_vmlp_unfold_gradient) -- the same arithmetic through torch autograd costs ~45
+    elementwise / reduction launches per network and step."""
 
     def __init__(self, layers, n_in, n_out, activation):
         self.layers = list(layers)
@@ -54,27 +57,56 @@ class VanillaBlob:
         self.desc = NsrVmlpDesc(int(n_in), int(in_pad), int(n_out), int(nh), int(activation))
         self.n_floats = int(lib.nsr_vmlp_blob_floats(_byref(self.desc)))
         self.blob = None
+        self._grad_flat = None
+
+    def _tensors(self, layer):
+        wn = hasattr(layer, "weight_g")
+        return (layer.weight_v if wn else layer.weight), (layer.weight_g if wn else None), layer.bias
+
+    def _layer_array(self, grads=None):
+        arr = (NsrVanillaLayer * len(self.layers))()
+        for i, layer in enumerate(self.layers):
+            v, g, b = self._tensors(layer)
+            for t in (v, g, b):
+                if t is not None and (t.dtype != F32 or not t.is_contiguous()):
+                    raise NotImplementedError("fused NeuS: VanillaMLP parameters are contiguous fp32 tensors")
+            a = arr[i]
+            a.weight_v, a.weight_g, a.bias = v.data_ptr(), (None if g is None else g.data_ptr()), b.data_ptr()
+            a.n_out, a.n_in = int(v.shape[0]), int(v.shape[1])
+            if grads is not None:
+                gv, gg, gb = grads[i]
+                a.grad_v, a.grad_g, a.grad_bias = gv.data_ptr(), (None if gg is None else gg.data_ptr()), gb.data_ptr()
+        return arr
 
     def build(self, requires_grad=True):
-        d = self.desc
         dev = self.layers[0].bias.device
-        parts = []
-        with torch.set_grad_enabled(requires_grad):
-            w0 = _linear_weight(self.layers[0]).float()
-            parts.append(torch.nn.functional.pad(w0, (0, d.in_pad - w0.shape[1])).reshape(-1))
-            parts.append(self.layers[0].bias.float())
-            for layer in self.layers[1:-1]:
-                parts += [_linear_weight(layer).float().reshape(-1), layer.bias.float()]
-            wl = _linear_weight(self.layers[-1]).float()
-            parts.append(torch.nn.functional.pad(wl, (0, 0, 0, 16 - wl.shape[0])).reshape(-1))
-            parts.append(torch.nn.functional.pad(self.layers[-1].bias.float(), (0, 16 - wl.shape[0])))
-            self.blob = torch.cat(parts).contiguous()
-        assert self.blob.numel() == self.n_floats and self.blob.device == dev
+        if self.blob is None or self.blob.device != dev:
+            self.blob = torch.empty(self.n_floats, dtype=F32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.nsr_vmlp_fold(_byref(self.desc), self._layer_array(), len(self.layers), ptr(self.blob), stream_ptr()),
+                  "nsr_vmlp_fold")
         return self.blob
 
     def push_gradient(self, grad_blob):
-        """d loss / d blob -> .grad of weight_g / weight_v / weight / bias"""
-        self.blob.backward(grad_blob)
+        """d loss / d blob -> .grad of weight_g / weight_v / weight / bias (added to gradients that already exist)"""
+        params = [t for layer in self.layers for t in self._tensors(layer) if t is not None]
+        fresh = all(p.grad is None for p in params)
+        if fresh:  # views of one persistent buffer, fully overwritten by the kernel: no allocation, no zeroing
+            n = sum(p.numel() for p in params)
+            if self._grad_flat is None or self._grad_flat.numel() != n or self._grad_flat.device != grad_blob.device:
+                self._grad_flat = torch.empty(n, dtype=F32, device=grad_blob.device)
+            off = 0
+            for p in params:
+                p.grad = self._grad_flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        else:
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+        grads = [tuple(None if t is None else t.grad for t in self._tensors(layer)) for layer in self.layers]
+        with torch.cuda.device(grad_blob.device):
+            check(lib.nsr_vmlp_unfold_gradient(_byref(self.desc), self._layer_array(grads), len(self.layers), ptr(grad_blob),
+                                               0 if fresh else 1, stream_ptr()), "nsr_vmlp_unfold_gradient")
 
 
 def _vanilla_layers(net):
@@ -133,7 +165,13 @@ class FusedNeuSStep:
         return float(eps)
 
     def _inv_s(self):
-        return torch.exp(self.model.variance.variance.detach().float() * 10.0).reshape(1).contiguous()
+        """exp(10 variance) (models/neus.py:27-32) into a persistent one-float buffer"""
+        var = self.model.variance.variance
+        if getattr(self, "_inv_s_buf", None) is None or self._inv_s_buf.device != var.device:
+            self._inv_s_buf = torch.empty(1, dtype=F32, device=var.device)
+        with torch.cuda.device(var.device):
+            check(lib.nsr_neus_inv_s(ptr(var.detach()), ptr(self._inv_s_buf), stream_ptr()), "nsr_neus_inv_s")
+        return self._inv_s_buf
 
     def loss_terms(self, acc):
         """the system's scalar losses from the accumulator (device tensors)"""
@@ -484,8 +522,10 @@ class FusedNeuSStep:
             fg = None if fg_mask is None else fg_mask.to(F32).contiguous()
             check(lib.nsr_neus_loss_rays(ptr(comp_full), ptr(opacity), ptr(op_bg), ptr(gt), ptr(fg), ptr(acc), n_rays, None,
                                          s), "nsr_neus_loss_rays")
+            lean = getattr(self, "lean_outputs", False) and compute_grads  # a trainer does not read the validity masks
             res = {"comp_rgb": comp_rgb, "comp_normal": comp_normal, "opacity": opacity, "depth": depth,
-                   "rays_valid": opacity > 0, "comp_rgb_full": comp_full, "rays_valid_full": opacity > 0,
+                   "rays_valid": None if lean else opacity > 0, "comp_rgb_full": comp_full,
+                   "rays_valid_full": None if lean else opacity > 0,
                    "num_samples": N, "sdf_samples": out[:, 0], "sdf_grad_samples": grad, "weights": weights[:N],
                    "ray_indices": ri, "t_starts": t0, "t_ends": t1, "alpha": alpha, "loss_acc": acc,
                    "inv_s": inv_s[0]}
@@ -493,14 +533,14 @@ class FusedNeuSStep:
                 res["sdf_laplace_samples"] = laplace
             if bgc is not None:
                 res.update({"comp_rgb_bg": bgc["comp_rgb"], "opacity_bg": bgc["opacity"], "depth_bg": bgc["depth"],
-                            "rays_valid_bg": bgc["opacity"] > 0, "num_samples_bg": bgc["S"],
-                            "num_samples_full": N + bgc["S"], "rays_valid_full": (opacity > 0) | (bgc["opacity"] > 0),
+                            "rays_valid_bg": None if lean else bgc["opacity"] > 0, "num_samples_bg": bgc["S"],
+                            "num_samples_full": N + bgc["S"],
+                            "rays_valid_full": None if lean else (opacity > 0) | (bgc["opacity"] > 0),
                             "weights_bg": bgc["weights"], "ray_indices_bg": bgc["ri"], "t_starts_bg": bgc["t0"],
                             "t_ends_bg": bgc["t1"]})
             if not compute_grads or (N == 0 and bgc is None):
                 return res
-            lw8 = torch.tensor([float(lw.get(k, 0.0)) for k in LOSS_KEYS], dtype=F32)
-            lw8c = (ctypes.c_float * 8)(*lw8.tolist())
+            lw8c = (ctypes.c_float * 8)(*[float(lw.get(k, 0.0)) for k in LOSS_KEYS])
             d_alpha = torch.empty(n1, dtype=F32, device=dev)
             d_rgb = torch.empty((n1, 16), dtype=F32, device=dev)
             d_bg = None if bgc is None else torch.empty((n_rays, 3), dtype=F32, device=dev)
@@ -572,8 +612,12 @@ class FusedNeuSStep:
             self.tex.push_gradient(g_tex)
         var = m.variance.variance
         # inv_s = exp(10 v) (models/neus.py:27-32); the clip(1e-6, 1e6) is handled in the kernel
-        g_var = (acc[ACC["inv_s_grad"]] * inv_s[0] * 10.0).reshape(var.shape).to(var.dtype)
-        var.grad = g_var if var.grad is None else var.grad + g_var
+        fresh = var.grad is None
+        if fresh:
+            var.grad = torch.empty_like(var)
+        with torch.cuda.device(dev):
+            check(lib.nsr_neus_variance_gradient(ptr(acc), ptr(inv_s), ptr(var.grad), 0 if fresh else 1, stream_ptr()),
+                  "nsr_neus_variance_gradient")
         return res
 
 
@@ -588,6 +632,48 @@ def neus_lr_scale(step, config_name, max_steps=20000):
     if step < w:
         return 0.01 + (1.0 - 0.01) * step / w
     return 0.1 ** ((step - w) / (max_steps - w))
+
+
+class SmallAdamW:
+    """torch.optim.AdamW (lr per tensor, betas (0.9, 0.99), eps 1e-15, weight decay 0.01: systems/utils.py:314-325 with
+    the YAML's optimizer.params groups) over the handful of small fp32 tensors of a NeuS model -- fp32 heads, variance --
+    as ONE launch (nsr_adamw_multi) instead of the ~16 foreach launches + their host time.  Tensors whose ``.grad`` is
+    None are skipped, like torch does; ``step`` leaves the gradients set to None."""
+
+    def __init__(self, params_and_lrs, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.01):
+        self.items = [(p, float(lr)) for p, lr in params_and_lrs if p.numel() > 0]
+        if len(self.items) > 32:
+            raise NotImplementedError("SmallAdamW: at most 32 tensors")
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.step_count = 0
+        n = sum(p.numel() for p, _ in self.items)
+        dev = self.items[0][0].device if self.items else None
+        self._m = torch.zeros(n, dtype=F32, device=dev) if self.items else None
+        self._v = torch.zeros(n, dtype=F32, device=dev) if self.items else None
+        self.state, off = {}, 0
+        for p, _ in self.items:
+            if p.dtype != F32 or not p.is_contiguous():
+                raise NotImplementedError("SmallAdamW: contiguous fp32 parameters")
+            self.state[p] = (self._m[off:off + p.numel()], self._v[off:off + p.numel()])
+            off += p.numel()
+
+    def step(self, lr_scale=1.0):
+        live = [(p, lr) for p, lr in self.items if p.grad is not None]
+        self.step_count += 1
+        if not live:
+            return
+        segs = (NsrAdamSegment * len(live))()
+        for sg, (p, lr) in zip(segs, live):
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            m, v = self.state[p]
+            sg.params, sg.grad, sg.exp_avg, sg.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            sg.n, sg.lr = p.numel(), lr * lr_scale
+        bc1, bc2 = 1.0 - self.betas[0] ** self.step_count, 1.0 - self.betas[1] ** self.step_count
+        with torch.cuda.device(live[0][0].device):
+            check(lib.nsr_adamw_multi(segs, len(live), self.betas[0], self.betas[1], self.eps, self.wd, bc1, bc2, 0,
+                                      stream_ptr()), "nsr_adamw_multi")
+        for p, _ in live:
+            p.grad = None
 
 
 class NeuSTrainer:
@@ -626,9 +712,8 @@ class NeuSTrainer:
             if dist.is_initialized():
                 self.sharded = ShardedAdamW(tc, lr=0.01)
         self._rest = rest + var
-        self.opt_rest = torch.optim.AdamW([{"params": rest, "lr": 0.01}, {"params": var, "lr": 0.001}], betas=(0.9, 0.99),
-                                          eps=1e-15)
-        self._base_lrs = [0.01, 0.001]
+        self.opt_rest = SmallAdamW([(p, 0.01) for p in rest] + [(p, 0.001) for p in var])
+        self.fused.lean_outputs = True  # no per-ray validity masks etc. in the step's result dict
         self._pending, self._side = None, None
         self.last = {}
 
@@ -650,7 +735,7 @@ class NeuSTrainer:
         model.update_step(0, t)  # cos anneal, progressive level / eps (and, on the reference's model, the refresh itself)
         grid = model.occupancy_grid
         refreshed = False
-        if type(model).__name__ == "HotPathState" and cfg["grid_prune"] and t % 16 == 0:
+        if getattr(model, "refresh_owned_by_trainer", False) and cfg["grid_prune"] and t % 16 == 0:
             grid.every_n_step(step=t, occ_eval_fn=self.fused.occ_eval_fn, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
             if self.fused.bg:
                 model.occupancy_grid_bg.every_n_step(step=t, occ_eval_fn=self.fused.bg_occ_eval_fn,
@@ -664,7 +749,6 @@ class NeuSTrainer:
         rays, rgb, fg, bg, handle = self._pending
         self._pending = None
         model.background_color = bg
-        self.opt_rest.zero_grad(set_to_none=True)
 
         def after_march(n):
             if cfg["dynamic_ray_sampling"] and n > 0:  # systems/neus.py:93-95
@@ -695,9 +779,7 @@ class NeuSTrainer:
             if self.world_size > 1:
                 all_reduce_gradients(list(model.parameters()))
             self.opt.step(lr_scale=scale)
-        for g, base in zip(self.opt_rest.param_groups, self._base_lrs):
-            g["lr"] = base * scale
-        self.opt_rest.step()
+        self.opt_rest.step(lr_scale=scale)
         self.global_step += 1
         self.last = {"loss_acc": res["loss_acc"], "n_rays": rays.shape[0], "n_samples": n,
                      "n_samples_bg": res.get("num_samples_bg", 0)}

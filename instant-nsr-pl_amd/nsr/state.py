@@ -168,6 +168,9 @@ class HotPathState(nn.Module):
                                                        contraction_type=ContractionType.UN_BOUNDED_SPHERE)
         self.randomized = bool(cfg["randomized"])
         self.background_color = None
+        # the reference's NeuSModel refreshes its occupancy grid(s) inside update_step (models/neus.py:79-111); this holder
+        # has no field code of its own, so the trainer drives the refresh through the fused runner's occ_eval_fn
+        self.refresh_owned_by_trainer = kind == "neus"
 
     # -- schedules that live on the reference's model objects (update_step hooks) --------------------------------
     def update_step(self, epoch, global_step):

@@ -52,6 +52,18 @@ class NsrTableAdam(ctypes.Structure):
                 ("milestone2", ctypes.c_int32), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float)]
 
 
+class NsrVanillaLayer(ctypes.Structure):
+    """include/nsr_hip.h: the nn.Linear tensors of one VanillaMLP layer (weight_g NULL: plain weight)"""
+    _fields_ = [("weight_v", ctypes.c_void_p), ("weight_g", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("grad_v", ctypes.c_void_p), ("grad_g", ctypes.c_void_p), ("grad_bias", ctypes.c_void_p),
+                ("n_out", ctypes.c_uint32), ("n_in", ctypes.c_uint32)]
+
+
+class NsrAdamSegment(ctypes.Structure):
+    _fields_ = [("params", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_uint64), ("lr", ctypes.c_float)]
+
+
 class NsrVmlpDesc(ctypes.Structure):
     _fields_ = [("n_in", ctypes.c_uint32), ("in_pad", ctypes.c_uint32), ("n_out", ctypes.c_uint32),
                 ("n_hidden", ctypes.c_uint32), ("activation", ctypes.c_uint32)]
@@ -176,6 +188,11 @@ SIGNATURES = {
                                _P, _P],
     "nsr_neus_composite_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_neus_loss_rays": [_P, _P, _P, _P, _P, _P, _U, _P, _P],
+    "nsr_vmlp_fold": [_VD, _P, _U, _P, _P],
+    "nsr_vmlp_unfold_gradient": [_VD, _P, _U, _P, _I, _P],
+    "nsr_adamw_multi": [_P, _U, _F, _F, _F, _F, _F, _F, _I, _P],
+    "nsr_neus_inv_s": [_P, _P, _P],
+    "nsr_neus_variance_gradient": [_P, _P, _P, _I, _P],
     "nsr_bg_visibility_prefix": [_P, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_bg_texture_input": [_P, _U, _P, _P, _P, _U, _U, _P, _P],
     "nsr_bg_composite_forward": [_P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],

@@ -142,3 +142,51 @@ def test_level_major_encoding_input_gives_the_same_output():
                                    None, stream_ptr()), "fwd")
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n_in,n_out,n_hidden,weight_norm", [(35, 13, 1, True), (32, 3, 2, False), (11, 13, 1, True),
+                                                            (24, 3, 2, False), (32, 8, 1, False)])
+def test_blob_fold_and_gradient_unfold_match_torch(n_in, n_out, n_hidden, weight_norm):
+    """nsr_vmlp_fold / nsr_vmlp_unfold_gradient (one launch each) == the torch formulation of the same arithmetic:
+    W = g v / |v| per row (old-style weight_norm, models/network_utils.py:133-137), padded blob, and its autograd"""
+    import torch.nn as nn
+    from nsr.fused_neus import VanillaBlob, _linear_weight
+    torch.manual_seed(0)
+    dims = [n_in] + [64] * n_hidden + [n_out]
+    layers = []
+    for i in range(len(dims) - 1):
+        lin = nn.Linear(dims[i], dims[i + 1]).cuda()
+        with torch.no_grad():
+            lin.bias.normal_(0, 0.3)
+        layers.append(nn.utils.weight_norm(lin) if weight_norm else lin)
+    if weight_norm:
+        with torch.no_grad():
+            for lin in layers:
+                lin.weight_g.mul_(1.7)
+    vb = VanillaBlob(layers, n_in, n_out, activation=0)
+    blob = vb.build().clone()
+    d = vb.desc
+    # torch formulation of the blob
+    parts = []
+    w0 = _linear_weight(layers[0]).float()
+    parts += [torch.nn.functional.pad(w0, (0, d.in_pad - w0.shape[1])).reshape(-1), layers[0].bias]
+    for lin in layers[1:-1]:
+        parts += [_linear_weight(lin).float().reshape(-1), lin.bias]
+    wl = _linear_weight(layers[-1]).float()
+    parts += [torch.nn.functional.pad(wl, (0, 0, 0, 16 - wl.shape[0])).reshape(-1),
+              torch.nn.functional.pad(layers[-1].bias, (0, 16 - wl.shape[0]))]
+    ref = torch.cat(parts)
+    assert ref.numel() == blob.numel()
+    assert torch.allclose(blob, ref.detach(), rtol=2e-6, atol=1e-7), float((blob - ref.detach()).abs().max())
+    gb = torch.randn_like(ref)
+    ref.backward(gb)
+    names = [(lin, k) for lin in layers for k, _ in lin.named_parameters()]
+    want = [dict(lin.named_parameters())[k].grad.clone() for lin, k in names]
+    for lin in layers:
+        for p in lin.parameters():
+            p.grad = None
+    vb.push_gradient(gb)   # fresh gradients: written
+    vb.push_gradient(gb)   # existing gradients: accumulated
+    for (lin, k), ref_g in zip(names, want):
+        g = dict(lin.named_parameters())[k].grad
+        assert torch.allclose(g, 2 * ref_g, rtol=2e-5, atol=2e-6), (k, float((g - 2 * ref_g).abs().max()))
