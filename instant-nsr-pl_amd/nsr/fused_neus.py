@@ -418,9 +418,6 @@ class FusedNeuSStep:
             if self.bg:  # the background's pruning pass decides its sample count: num_samples_full = N + S
                 self._bg_grads = compute_grads
                 bgc = self._bg_prune(bg_handle)
-            if after_march is not None:
-                # the sample count of this step is known: a trainer queues the next batch's marching here
-                after_march(N + (bgc["S"] if bgc else 0))
             self._n_samples = N
             T = 7 if self.fd else 1
             eps = self._fd_eps() if self.fd else 0.0
@@ -430,25 +427,8 @@ class FusedNeuSStep:
             check(lib.nsr_neus_points(ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), self.radius, eps, int(self.fd),
                                       ptr(x7), ptr(dirs), N, None, s), "nsr_neus_points")
             table = enc.table_half(enc.params)
-            gws = bin_event = None
-            if compute_grads and N > 0:
-                # the table backward's binning needs only the positions: it runs on a helper stream underneath the whole
-                # forward pass (count / scan / fill: 0.18 ms at 5e5 points, 0.5 ms at the 7 N points of the C5 stencil)
-                nws = int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), T * N))
-                gws = torch.empty(nws, dtype=F32, device=dev)
-                if getattr(self, "_helper", None) is None:
-                    self._helper = torch.cuda.Stream(device=dev)
-                main = torch.cuda.current_stream()
-                ready = torch.cuda.Event()
-                ready.record(main)
-                self._helper.wait_event(ready)
-                with torch.cuda.stream(self._helper):
-                    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x7), ptr(gws), T * N, mc, _byref(desc), None,
-                                                                     stream_ptr()), "nsr_hashgrid_backward_params_owner_bin")
-                    bin_event = torch.cuda.Event()
-                    bin_event.record(self._helper)
-                gws.record_stream(self._helper)
-                x7.record_stream(self._helper)
+            positions_ready = torch.cuda.Event()
+            positions_ready.record(torch.cuda.current_stream())
             # row-major encoding [T N][C] (masked levels: zero columns).  Measured: the level-major layout saves 36 us (plain) /
             # 131 us (taps) in the encode kernels' stores but costs the MFMA kernels 180 / 660 us -- their per-sample
             # operand loads then touch 16 cache lines instead of one 64-B row
@@ -460,6 +440,23 @@ class FusedNeuSStep:
                 jac = torch.empty(N * self.n_enc * 3, dtype=F32, device=dev)
                 check(lib.nsr_hashgrid_forward_jac(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, 0, mc, _byref(desc),
                                                    ptr(jac), None, s), "nsr_hashgrid_forward_jac")
+            gws = bin_event = None
+            if compute_grads and N > 0:
+                # the table backward's binning needs only the positions: it runs on a helper stream underneath the whole
+                # forward pass (count / scan / fill: 0.18 ms at 5e5 points, 0.5 ms at the 7 N points of the C5 stencil);
+                # queued AFTER the encode so that its host-side setup does not hold the main stream's first big kernel back
+                nws = int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), T * N))
+                gws = torch.empty(nws, dtype=F32, device=dev)
+                if getattr(self, "_helper", None) is None:
+                    self._helper = torch.cuda.Stream(device=dev)
+                self._helper.wait_event(positions_ready)
+                with torch.cuda.stream(self._helper):
+                    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x7), ptr(gws), T * N, mc, _byref(desc), None,
+                                                                     stream_ptr()), "nsr_hashgrid_backward_params_owner_bin")
+                    bin_event = torch.cuda.Event()
+                    bin_event.record(self._helper)
+                gws.record_stream(self._helper)
+                x7.record_stream(self._helper)
         sdf_blob = self.sdf.build(requires_grad=compute_grads)
         tex_blob = None if self.tex_fused else self.tex.build(requires_grad=compute_grads)
         if self.bg:
@@ -473,6 +470,11 @@ class FusedNeuSStep:
             g_in = None if self.fd else torch.empty((N, P), dtype=F32, device=dev)
             check(lib.nsr_vmlp_forward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(out), ptr(taps),
                                        ptr(g_in), T * N, N, None, s), "nsr_vmlp_forward(sdf)")
+            if after_march is not None:
+                # the sample count of this step is known: a trainer queues the next batch's ray preparation + marching
+                # (side stream) here -- AFTER the first ~0.6 ms of this step's kernels are in the queue, so that the host
+                # time it takes does not leave the main stream idle
+                after_march(N + (bgc["S"] if bgc else 0))
             dx01 = None
             if not self.fd:  # J^T (d sdf / d encoding): models/geometry.py:176-180 through the encoder
                 dx01 = torch.empty((N, 3), dtype=F32, device=dev)

@@ -374,7 +374,7 @@ _PINNED = []
 def _pinned_int32():
     """ring of pinned host words for the sample-count read-back (hipHostMalloc costs ~100 us: never per step)"""
     if not _PINNED:
-        _PINNED.extend([torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(8)] + [0])
+        _PINNED.extend([torch.empty(2, dtype=torch.int32, pin_memory=True) for _ in range(8)] + [0])
     _PINNED[-1] = (_PINNED[-1] + 1) % 8
     return _PINNED[_PINNED[-1]]
 
@@ -404,7 +404,7 @@ def read_count_when_ready(dev_word):
 class MarchHandle:
     """an in-flight marching pass (count + per-ray scratch rows); ``ray_march_finish`` turns it into packed samples"""
     __slots__ = ("args", "counts", "packed", "total", "total_host", "scratch", "cap", "bricks", "grid_u8", "event",
-                 "stream", "n")
+                 "stream", "n", "host_words")
 
 
 def ray_march_begin(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone_angle, roi_host=None,
@@ -419,7 +419,8 @@ def ray_march_begin(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step
     h.counts = torch.empty(n, dtype=torch.int32, device=dev)
     h.packed = torch.empty((n, 2), dtype=torch.int32, device=dev)
     h.total = torch.zeros(1, dtype=torch.int32, device=dev)
-    h.total_host = _pinned_int32()
+    h.host_words = _pinned_int32()  # [0] sample total, [1] "a ray overflowed its scratch row"
+    h.total_host = h.host_words[0:1]
     h.bricks = grid_bricks(binary) if method == "bricks" else None
     h.grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
     h.cap, h.scratch = 0, None
@@ -441,7 +442,12 @@ def ray_march_begin(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step
                       "nsr_ray_march_bricks_count")
         check(lib.nsr_pack_from_counts(ptr(h.counts), ptr(h.packed), ptr(h.total), n, s), "nsr_pack_from_counts")
         h.total_host[0] = -0x7fffffff
-        h.total_host.copy_(h.total, non_blocking=True)
+        h.host_words[1] = 0
+        if h.scratch is not None:
+            # the overflow test of the single-pass scratch (see ray_march_finish) rides along with the count: reading it on
+            # the consumer's stream would make the host wait for everything queued there
+            h.host_words[1:2].copy_((h.counts > h.cap).any().to(torch.int32).reshape(1), non_blocking=True)
+        h.total_host.copy_(h.total, non_blocking=True)  # last: the spin in ray_march_finish watches this word
         h.stream = torch.cuda.current_stream()
         h.event = torch.cuda.Event()
         h.event.record(h.stream)
@@ -464,7 +470,7 @@ def ray_march_finish(h):
     t_starts = torch.empty((m, 1), dtype=F32, device=dev)
     t_ends = torch.empty((m, 1), dtype=F32, device=dev)
     scratch = h.scratch
-    if m > 0 and scratch is not None and int((h.counts > h.cap).any()):
+    if m > 0 and scratch is not None and int(h.host_words[1]):
         # a ray emitted more samples than its scratch row holds (the diag/step+3 bound assumes unit-length directions
         # and the roi the capacity was derived from): the counts are still exact, so re-march in two-pass mode
         scratch = None
