@@ -460,9 +460,11 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
     if (staged) {
         __syncthreads();
         const int32_t end_all = capacity ? min(prefix_total(wave_tot), (int32_t)capacity) : prefix_total(wave_tot);
+        const bool vec = (reinterpret_cast<uintptr_t>(packed) & 7u) == 0;  // (a caller may hand in a 4-byte aligned view)
         for (uint32_t k = tid; k < n; k += 1024) {  // count = next start - start (truncation included)
             const int32_t a = buf[k], b = k + 1 < n ? buf[k + 1] : end_all;
-            reinterpret_cast<int2 *>(packed)[k] = make_int2(a, b - a);
+            if (vec) reinterpret_cast<int2 *>(packed)[k] = make_int2(a, b - a);
+            else { packed[2ull * k] = a; packed[2ull * k + 1] = b - a; }
         }
     }
     if (tid == 1023) {
@@ -767,7 +769,6 @@ extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *pa
     NSR_REQUIRE(n_rays == 0 || (num_steps && packed_info), "nsr_pack_from_counts: NULL pointer");
     NSR_REQUIRE(capacity < 0x7fffffffu, "nsr_pack_from_counts: capacity must fit int32");
     NSR_REQUIRE(!stats || ((uintptr_t)stats & 7u) == 0, "nsr_pack_from_counts: stats must be 8-byte aligned");
-    NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_pack_from_counts: packed_info must be 8-byte aligned");
     hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, num_steps, packed_info, total,
                        n_rays, capacity, stats, n_active);
     NSR_CHECK_LAUNCH("nsr_pack_from_counts");
