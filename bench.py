@@ -24,6 +24,10 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ENC_FWD_BYTES_PER_SAMPLE = 588  # 12 B coords + 16*8*2*2 B gathers + 64 B out (fp16 table)
 ADAM_TABLE_BYTES_PER_PARAM = 26  # fp32 p, m, v read (12) + written (12) + fp16 image written (2)
+# table backward with AdamW applied inside it: the table gradient never reaches HBM (it lives in the LDS of the workgroup
+# that owns the slice), so SURVEY 8(d)'s 2 x 2048 B/sample of gradient read-modify-write do not exist for this launch --
+# what it must move is each sample's position (12 B) + level-major dy (16 levels x 2 x 4 B) and the optimizer's bytes
+ENC_BWD_FUSED_INPUT_BYTES_PER_SAMPLE = 12 + 16 * 2 * 4
 ENC_BWD_BYTES_PER_SAMPLE = 2124  # 12 + 64*2(fp32 dy) ... fp32 atomics: 16*8*2*4 B *2 (RMW) + coords + dy
 
 
@@ -310,6 +314,8 @@ def main():
             fused_opt = bool(name == "hashgrid_backward_params" and world == 1 and tr.async_mode and tr.fuse_table_update)
             opt_bytes = ADAM_TABLE_BYTES_PER_PARAM * tr.fused.ewn.grid_desc.n_entries * tr.fused.ewn.grid_desc.n_features \
                 if fused_opt else 0
+            if fused_opt:
+                bps = ENC_BWD_FUSED_INPUT_BYTES_PER_SAMPLE
             per_launch = bps * units / launches + opt_bytes
             achieved = per_launch * launches / (ms_total * 1e-3) / 1e9
             traffic, traffic_note = pmc_traffic(name, units / launches)
