@@ -2,7 +2,7 @@
 schedule of the YAML, dynamic ray count, occupancy refresh every 16 steps, cos-anneal, progressive levels) for --steps
 steps, then PSNR of unseen views rendered in eval mode through nsr.export.render_rays.  One JSON line.
 
-    python tools/train_neus.py --config neus-blender --steps 4000
+    python tools/train_neus.py --config neus-blender|neus-dtu|neuralangelo --steps 4000
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,10 +23,12 @@ torch.manual_seed(42)
 dev = "cuda"
 cfg = nsr.configs.get(args.config)
 LAM = {"neus-blender": {"lambda_rgb_mse": 10.0, "lambda_rgb_l1": 0.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1},
+       "neus-dtu": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.0, "lambda_eikonal": 0.1},
        "neuralangelo": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1}}[args.config]
 scale = float(cfg["radius"]) / 1.5
-train = SyntheticBlender(n_images=100, w=args.res, h=args.res, device=dev, seed=0)
-test = SyntheticBlender(n_images=args.test_views, w=args.res, h=args.res, device=dev, seed=12345)
+env = bool(cfg["learned_background"])  # unmasked captures with a backdrop: the target of the NeRF++ background branch
+train = SyntheticBlender(n_images=100, w=args.res, h=args.res, device=dev, seed=0, environment=env)
+test = SyntheticBlender(n_images=args.test_views, w=args.res, h=args.res, device=dev, seed=12345, environment=env)
 for d in (train, test):
     d.all_c2w[:, :, 3] *= scale  # the procedural object lives in radius 1.5: shrink the camera orbit with the box ...
 model = nsr.build(cfg).to(dev).train()
@@ -38,7 +40,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n_samples, hist = 0, []
 for i in range(args.steps):
     st = tr.train_step()
-    n_samples += st["n_samples"]
+    n_samples += st["n_samples"] + st["n_samples_bg"]
     if (i + 1) % max(args.steps // 8, 1) == 0:
         terms = tr.fused.loss_terms(st["loss_acc"])
         hist.append({"step": i + 1, "rays": st["n_rays"], "samples": st["n_samples"],
@@ -51,7 +53,7 @@ for i in range(args.test_views):
     rays = torch.cat([o, torch.nn.functional.normalize(d, p=2, dim=-1)], -1)
     out = render_rays(tr.fused, rays, chunk=16384)
     fg = test.all_fg_masks[i].view(-1, 1).cpu()
-    gt = test.all_images[i].view(-1, 3).cpu() * fg + (1 - fg)
+    gt = test.all_images[i].view(-1, 3).cpu() if env else test.all_images[i].view(-1, 3).cpu() * fg + (1 - fg)
     mse = torch.mean((out["comp_rgb_full"].clamp(0, 1) - gt) ** 2)
     psnrs.append(float(-10.0 * torch.log10(mse)))
 print(json.dumps({"config": args.config, "steps": args.steps, "train_seconds": dt, "ms_per_step": 1e3 * dt / args.steps,
