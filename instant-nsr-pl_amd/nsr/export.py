@@ -9,6 +9,8 @@
     [vmin, vmax], evaluated in ``chunk``-point pieces (configs: 512^3 in 2,097,152-point chunks), returned on the CPU as the
     [res, res, res] volume ``mcubes.marching_cubes`` takes.  Marching cubes itself (a CPU library call in the reference) and
     the .obj writer are outside the hot path.
+  * ``vertex_colors`` -- the per-vertex colour query of ``export()`` (models/nerf.py:152-161: viewing direction -z;
+    models/neus.py:313-323: viewing direction = -normal, the "albedo"), in ``chunk_size`` pieces.
   * checkpoints: ``nsr.state.HotPathState`` has the reference's state-dict keys; ``load_reference_checkpoint`` strips the
     ``model.`` prefix Lightning adds (utils/mixins.py:211-222 saves meshes, Lightning's ModelCheckpoint the weights).
 """
@@ -122,3 +124,36 @@ def isosurface_levels(state, resolution, vmin=None, vmax=None, chunk=2097152):
         lv = forward_level(state, pts)
         out[i0 * resolution * resolution:(i0 + xs.numel()) * resolution * resolution] = lv.float().cpu()
     return out.view(resolution, resolution, resolution)
+
+
+@torch.no_grad()
+def vertex_colors(state, v_pos, chunk=2097152):
+    """``export_vertex_color`` of the reference's ``export()``: colours of mesh vertices ``v_pos`` [n, 3] (world), on the
+    CPU.  nerf: ``texture(feature, (0, 0, -1))`` clamped to [0, 1] (models/nerf.py:155-159); neus: ``texture(feature,
+    -normal, normal)`` with the normal of the SDF at the vertex (models/neus.py:316-321)."""
+    cfg = state.config
+    dev = state.scene_aabb.device
+    if cfg["name"] == "nerf":
+        radius = float(cfg["radius"])
+        bias = float(cfg["geometry"].get("density_bias", 0.0))
+        sh, net = state.texture.encoding.encoding, state.texture.network
+
+        def one(p):
+            x01 = _ops.contract_to_unisphere(p.float().contiguous(), radius, ContractionType.AABB.value)
+            out = state.geometry.encoding_with_network(x01)
+            _, feature = _ops.density_activation(out.contiguous(), out.shape[1], bias, want_feature=True)
+            dirs = torch.zeros((p.shape[0], 3), device=p.device)
+            dirs[:, 2] = -1.0
+            emb = sh((dirs + 1.0) / 2.0)
+            rgb = net(torch.cat([feature.to(emb.dtype), emb], dim=-1)).float()[:, :3]  # (output_activation inside the MLP)
+            if cfg["texture"].get("color_activation") == "sigmoid":  # models/texture.py:28-29
+                rgb = torch.sigmoid(rgb)
+            elif "color_activation" in cfg["texture"]:
+                raise NotImplementedError("vertex_colors: color_activation " + str(cfg["texture"]["color_activation"]))
+            return rgb.clamp(0.0, 1.0)
+        return chunk_batch(one, chunk, True, v_pos.to(dev))
+    from .fused_neus import FusedNeuSStep
+    runner = getattr(state, "_level_runner", None)
+    if runner is None:
+        runner = state._level_runner = FusedNeuSStep(state)
+    return chunk_batch(lambda p: runner.surface_attributes(p)["rgb"], chunk, True, v_pos.to(dev))

@@ -394,6 +394,71 @@ class FusedNeuSStep:
             t.record_stream(self._helper)
         return ev
 
+    @torch.no_grad()
+    def surface_attributes(self, points):
+        """``VolumeSDF.forward(points, with_grad=True, with_feature=True)`` + the "albedo" query of ``NeuSModel.export``
+        (models/neus.py:313-323: colour network with viewing direction = -normal) on world points [n, 3], gradients off.
+        -> dict(sdf [n], sdf_grad [n, 3], normal [n, 3], feature [n, feature_dim], rgb [n, 3])"""
+        enc, desc, dev = self.enc, self.enc.grid_desc, points.device
+        n = points.shape[0]
+        T = 7 if self.fd else 1
+        eps = self._fd_eps() if self.fd else 0.0
+        mc = self._mask_count()
+        with torch.cuda.device(dev):
+            s = stream_ptr()
+            pts = points.float().contiguous()
+            zeros3, zeros1 = torch.zeros((n, 3), dtype=F32, device=dev), torch.zeros(n, dtype=F32, device=dev)
+            ri = torch.arange(n, dtype=torch.int64, device=dev)
+            x7 = torch.empty((T * n, 3), dtype=F32, device=dev)
+            # positions (+ the six clamped taps) through the same kernel as the training step: origin = point, t = 0
+            check(lib.nsr_neus_points(ptr(pts), ptr(zeros3), ptr(ri), ptr(zeros1), ptr(zeros1), self.radius, eps,
+                                      int(self.fd), ptr(x7), None, n, None, s), "nsr_neus_points")
+            table = enc.table_half(enc.params)
+            encd = torch.empty((T * n, self.n_enc), dtype=F16, device=dev)
+            sd = self.sdf.desc
+            P = int(sd.in_pad)
+            out = torch.empty((n, 16), dtype=F32, device=dev)
+            blob = self.sdf.build(requires_grad=False)
+            taps = g_in = dx01 = laplace = None
+            if self.fd:
+                check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(encd), n, self.n_enc, 0, mc, _byref(desc), None,
+                                                    s), "nsr_hashgrid_forward_taps")
+                taps = torch.empty(6 * n, dtype=F32, device=dev)
+                laplace = torch.empty(n, dtype=F32, device=dev)
+            else:
+                jac = torch.empty(n * self.n_enc * 3, dtype=F32, device=dev)
+                check(lib.nsr_hashgrid_forward_jac(ptr(x7), ptr(table), ptr(encd), n, self.n_enc, 0, mc, _byref(desc),
+                                                   ptr(jac), None, s), "nsr_hashgrid_forward_jac")
+                g_in = torch.empty((n, P), dtype=F32, device=dev)
+            check(lib.nsr_vmlp_forward(_byref(sd), ptr(blob), ptr(x7), 3, ptr(encd), self.n_enc, ptr(out), ptr(taps), ptr(g_in),
+                                       T * n, n, None, s), "nsr_vmlp_forward(sdf)")
+            if not self.fd:
+                dx01 = torch.empty((n, 3), dtype=F32, device=dev)
+                check(lib.nsr_hashgrid_jac_apply(ptr(jac), n, _byref(desc), _off(g_in, 3), P, ptr(dx01), None, None, 0, None,
+                                                 s), "nsr_hashgrid_jac_apply(J^T dy)")
+            acc = torch.zeros(16, dtype=F32, device=dev)
+            inv_s = self._inv_s()
+            grad, normal = torch.empty((n, 3), dtype=F32, device=dev), torch.empty((n, 3), dtype=F32, device=dev)
+            alpha = torch.empty(n, dtype=F32, device=dev)
+            tex_f32 = not self.tex_fused
+            tex_in = torch.empty((n, 32), dtype=F32 if tex_f32 else F16, device=dev)
+            dirs = zeros3
+            for _ in range(2):  # pass 1: the normal; pass 2: the colour-network input with viewing direction = -normal
+                check(lib.nsr_neus_shade_forward(ptr(out), ptr(g_in), P, ptr(dx01), ptr(taps), eps, self.radius, ptr(dirs),
+                                                 ptr(zeros1), ptr(zeros1), ptr(inv_s), 1.0, self.n_feat, 1.0, ptr(grad),
+                                                 ptr(normal), ptr(alpha), ptr(laplace), ptr(tex_in), int(tex_f32), ptr(acc),
+                                                 n, None, s), "nsr_neus_shade_forward")
+                dirs = (-normal).contiguous()
+            if self.tex_fused:
+                rgb_raw, _ = _ops.mlp_forward(tex_in, self.tex.half_params(self.tex.params), self.tex.mlp_desc, save_acts=False)
+            else:
+                rgb_raw = torch.empty((n, 16), dtype=F32, device=dev)
+                tb = self.tex.build(requires_grad=False)
+                check(lib.nsr_vmlp_forward(_byref(self.tex.desc), ptr(tb), ptr(tex_in), 32, None, 0, ptr(rgb_raw), None, None,
+                                           n, n, None, s), "nsr_vmlp_forward(texture)")
+            rgb = torch.sigmoid(rgb_raw[:, :3].float())
+        return {"sdf": out[:, 0], "sdf_grad": grad, "normal": normal, "feature": out[:, :self.n_feat], "rgb": rgb}
+
     def forward_backward(self, rays, gt_rgb, fg_mask, background, compute_grads=True, loss_scale=1.0, march_handle=None,
                          after_march=None):
         m, enc, lw = self.model, self.enc, self.loss_weights

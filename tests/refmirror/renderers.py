@@ -276,6 +276,10 @@ class NeuSModel(nn.Module):
         out = self.forward_(rays) if self.training else chunk_batch(self.forward_, self.config["ray_chunk"], True, rays)
         return {**out, "inv_s": self.variance.inv_s}
 
+    def regularizations(self, out):
+        """models/neus.py:307-311: geometry + texture regularizers (both empty in the reference: models/base.py:27-28)"""
+        return {}
+
     def train(self, mode=True):
         self.randomized = mode and self.config["randomized"]
         return super().train(mode=mode)

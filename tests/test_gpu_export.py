@@ -99,3 +99,49 @@ def test_isosurface_lattice_matches_direct_level_evaluation():
         if name == "neus-blender":  # sphere initialisation: the level set is (about) the sphere of radius 0.5
             c = res // 2
             assert float(vol[c, c, c]) < 0 < float(vol[0, 0, 0])
+
+
+def test_vertex_colors_match_the_reference_export_queries():
+    """nsr.export.vertex_colors == the colour queries of the reference's export() (models/nerf.py:152-161: viewing direction
+    -z; models/neus.py:313-323: texture(feature, -normal, normal)) evaluated through the reference-shaped modules"""
+    import nsr
+    import refmirror
+    from nsr.export import vertex_colors
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(3)
+    # NeRF
+    m = refmirror.NeRFModel(nsr.configs.get("nerf-blender")).cuda().eval()
+    with torch.no_grad():
+        m.geometry.encoding_with_network.params[3072:].normal_(0, 0.1)
+    pts = ((torch.rand(5000, 3, generator=g) * 2 - 1) * 1.4).cuda()
+    with torch.no_grad():
+        _, feature = m.geometry(pts)
+        dirs = torch.zeros_like(pts)
+        dirs[:, 2] = -1.0
+        want = m.texture(feature, dirs).clamp(0, 1)
+    got = vertex_colors(m, pts, chunk=1777)
+    assert not got.is_cuda and got.shape == (5000, 3)
+    assert torch.allclose(got, want.cpu(), atol=3e-3), float((got - want.cpu()).abs().max())
+    # NeuS (analytic normals, fused colour MLP) and neuralangelo (finite differences, fp32 colour MLP)
+    for name, step in (("neus-blender", 1000), ("neuralangelo", 12005)):
+        cfg = nsr.configs.get(name)
+        m = refmirror.NeuSModel(cfg).cuda().eval()
+        with torch.no_grad():
+            enc = m.geometry.encoding.encoding
+            (enc.encoding if hasattr(enc, "encoding") else enc).params.normal_(0, 0.05)
+            m.geometry.network.layers[0].weight_v[:, 3:].normal_(0, 0.05)
+        m.update_step(0, step)
+        r = float(cfg["radius"])
+        pts = ((torch.rand(4000, 3, generator=g) * 2 - 1) * 0.95 * r).cuda()
+        fd = cfg["geometry"]["grad_type"] == "finite_difference"
+        with torch.enable_grad():
+            outs = m.geometry(pts, with_grad=True, with_feature=True, **({"with_laplace": True} if fd else {}))
+        sdf, sdf_grad, feature = outs[0], outs[1], outs[2]
+        normal = torch.nn.functional.normalize(sdf_grad.detach(), p=2, dim=-1)
+        with torch.no_grad():
+            want = m.texture(feature.detach(), -normal, normal)
+        got = vertex_colors(m, pts, chunk=1500)
+        bad = float(((got - want.cpu()).abs() > 5e-3).float().mean())  # (samples on a fine-level cell boundary: see DESIGN 2)
+        assert bad < 5e-3, (name, bad, float((got - want.cpu()).abs().max()))
+        at = m._level_runner.surface_attributes(pts[:1000])
+        assert torch.allclose(at["sdf"], sdf[:1000].detach().view(-1), atol=1e-3)
