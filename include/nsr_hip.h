@@ -539,6 +539,18 @@ typedef struct NsrAdamSegment {
 } NsrAdamSegment;
 int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segments, float beta1, float beta2, float eps,
                     float weight_decay, float bias_correction1, float bias_correction2, int zero_grad, void *stream);
+/* Stencil mode of the owner-computes table backward (finite-difference normals, reference models/geometry.py:181-199):
+ * x7 = positions [7][n_centre][3] (sample, then the six +-eps taps), dy_level_major = [L][7 n_centre][F] fp32.  A tap that
+ * stays in its sample's cell moves one coordinate inside a trilinear cell, so it is folded exactly into the sample's items
+ * (w G0 + sum_a dw/dx_a D_a); only taps that cross into a neighbouring cell keep items of their own.  workspace as for the
+ * plain call over 7 n_centre points, tap_workspace: nsr_hashgrid_backward_params_taps_workspace_floats floats. */
+uint64_t nsr_hashgrid_backward_params_taps_workspace_floats(const NsrGridDesc *desc, uint32_t n_centre);
+int nsr_hashgrid_backward_params_owner_bin_taps(const float *x7, float *workspace, float *tap_workspace, uint32_t n_centre,
+                                                uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
+int nsr_hashgrid_backward_params_owner_accumulate_taps(const float *x7, const float *dy_level_major, float *grad_table,
+                                                       float *workspace, float *tap_workspace, uint32_t n_centre,
+                                                       uint32_t level_mask_count, int accumulate,
+                                                       const NsrGridDesc *desc, void *stream);
 /* AdamW fused into the owner-computes table backward: the workgroup that owns a table slice applies the update to it
  * from the gradient it holds in LDS (no gradient store + separate optimizer read).  params / exp_avg / exp_avg_sq /
  * shadow point at the TABLE part of the flat parameter vector (entry 0 of level 0 first; 16-byte aligned, shadow 8);

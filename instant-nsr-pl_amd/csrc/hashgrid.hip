@@ -567,6 +567,70 @@ __device__ __forceinline__ bool own_is_pow2(const LevelGeom &g, uint32_t epb)
     return !g.dense && epb == (1u << OWN_POW2_LOG2) && (g.size & (g.size - 1u)) == 0u && g.res < (1u << OWN_POW2_LOG2);
 }
 
+
+// ---- finite-difference stencils (neuralangelo, models/geometry.py:181-199): the table gradient of N samples x 7 points --
+// The points of a sample are its position and six +-eps taps (layout [7][N][3], taps clamped to the box).  A tap that stays
+// in the sample's cell of a level moves ONE coordinate inside a trilinear cell, so its corner weights are
+// w(x) + delta * d w / d x_a exactly: everything those taps and the centre contribute to the cell's 8 corners is
+//      w_c * G0  +  sum_a (d w_c / d x_a) * D_a ,    G0 = sum of their dy,  D_a = sum of delta * dy over the taps of axis a
+// (delta in grid units, signed, the clamped taps' actual offsets).  Only taps that CROSS into a neighbouring cell keep
+// items of their own.  At level 16 that is 16 merged + ~24 crossing point-items per sample instead of 112.
+// cross[l][s]: bit t-1 set = tap t is in another cell than the centre on level l.
+__global__ void __launch_bounds__(256)
+k_tap_cross(const float *__restrict__ x7, uint32_t n_c, uint32_t mask_count, uint8_t *__restrict__ cross,
+            const NsrGridDesc d)
+{
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x, level = blockIdx.y;
+    if (s >= n_c || level >= mask_count) return;
+    const LevelGeom g = load_level(d, level);
+    const Cell c0 = locate(g, x7[3ull * s], x7[3ull * s + 1], x7[3ull * s + 2]);
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 1; t < 7; ++t) {
+        const uint64_t i = (uint64_t)t * n_c + s;
+        const Cell ct = locate(g, x7[3 * i], x7[3 * i + 1], x7[3 * i + 2]);
+        if (ct.c[0] != c0.c[0] || ct.c[1] != c0.c[1] || ct.c[2] != c0.c[2]) m |= 1u << (t - 1);
+    }
+    cross[(uint64_t)level * n_c + s] = (uint8_t)m;
+}
+
+// G0 [L][N][F] and D [L][N][3][F] from the level-major dy of all 7N points ([L][7N][F])
+template <int F>
+__global__ void __launch_bounds__(256)
+k_tap_reduce(const float *__restrict__ x7, const float *__restrict__ dy_lm, const uint8_t *__restrict__ cross,
+             uint32_t n_c, uint32_t mask_count, float *__restrict__ g0, float *__restrict__ dd, const NsrGridDesc d)
+{
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x, level = blockIdx.y;
+    if (s >= n_c || level >= mask_count) return;
+    const float scale = d.scale[level];
+    const uint32_t m = cross[(uint64_t)level * n_c + s];
+    const float *dyl = dy_lm + (uint64_t)level * 7ull * n_c * F;
+    float G[F], D[3][F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { G[f] = dyl[(uint64_t)s * F + f]; D[0][f] = D[1][f] = D[2][f] = 0.f; }
+#pragma unroll
+    for (int t = 1; t < 7; ++t) {
+        if (m & (1u << (t - 1))) continue;
+        const int a = (t - 1) >> 1;
+        const uint64_t i = (uint64_t)t * n_c + s;
+        // same arithmetic as locate(): the offset of the tap inside the cell, in grid units
+        const float delta = fmaf(scale, x7[3 * i + a], 0.5f) - fmaf(scale, x7[3ull * s + a], 0.5f);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float gv = dyl[i * F + f];
+            G[f] += gv;
+            D[a][f] = fmaf(delta, gv, D[a][f]);
+        }
+    }
+    const uint64_t o = (uint64_t)level * n_c + s;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        g0[o * F + f] = G[f];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dd[(o * 3 + a) * F + f] = D[a][f];
+    }
+}
+
 // pass 1 (FILL = false): counts[bin] = number of items per (level, slice).
 // pass 2 (FILL = true):  items[level][bin_start + ...] = item words; a block reserves one contiguous range per bin.
 // grid (ceil(n / (OWN_BIN_BLOCK * OWN_BIN_SPT)), L)
@@ -574,7 +638,9 @@ template <bool FILL>
 __global__ void __launch_bounds__(OWN_BIN_BLOCK)
 k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t *__restrict__ counts,
           const uint32_t *__restrict__ bin_start, uint32_t *__restrict__ cursors, uint32_t *__restrict__ items,
-          const OwnerMap om, const NsrGridDesc d, const int32_t *__restrict__ n_dev)
+          const OwnerMap om, const NsrGridDesc d, const int32_t *__restrict__ n_dev,
+          const uint8_t *__restrict__ cross /* stencil mode: tap points that stay in their sample's cell emit no items */,
+          uint32_t n_c)
 {
     __shared__ uint32_t hist[OWN_MAX_SLICES];
     const uint32_t level = blockIdx.y;
@@ -590,7 +656,14 @@ k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t
 #pragma unroll
     for (int u = 0; u < OWN_BIN_SPT; ++u) {
         const uint32_t i = (blockIdx.x * OWN_BIN_SPT + u) * OWN_BIN_BLOCK + threadIdx.x;
-        if (i < n_live) {
+        bool emit = i < n_live;
+        if (emit && cross && i >= n_c) {
+            const uint32_t t = i / n_c, sc = i - t * n_c;
+            emit = (cross[(uint64_t)level * n_c + sc] >> (t - 1)) & 1u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) slice[u][q] = 0xffffffffu;
+        if (emit) {
             const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -619,7 +692,7 @@ k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t
             if (i >= n_live) continue;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (slice[u][q] == 0xffffffffu) continue;
+                if (slice[u][q] == 0xffffffffu) continue;  // (also: a tap point that emits nothing)
                 const bool straddle = slice[u][q | 1] != 0xffffffffu;
                 const uint32_t mode = !straddle ? 0u : ((q & 1) ? 2u : 1u);
                 dst[hist[slice[u][q]] + rank[u][q]] = (i << 4) | ((uint32_t)(q >> 1) << 2) | mode;
@@ -701,7 +774,8 @@ __device__ __forceinline__ void owner_adam4(const OwnerAdam &ad, uint64_t idx, c
 }
 
 // Workgroup (level, slice, chunk): accumulates ITS items -- every lane busy, no scan over foreign samples.
-template <int F>
+// TAPS: stencil mode (see k_tap_cross / k_tap_reduce): items of points < taps_nc carry the merged centre + in-cell taps.
+template <int F, bool TAPS>
 __global__ void __launch_bounds__(OWN_BLOCK)
 k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_lm /* [L][n][F] */,
                       const uint32_t *__restrict__ items, const uint32_t *__restrict__ counts,
@@ -709,7 +783,8 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                       float *__restrict__ slabs, uint32_t n, uint32_t mask_count, float grad_scale, int accumulate,
                       const OwnerMap om, const NsrGridDesc d, const float *__restrict__ dir,
                       const float *__restrict__ dy_first_lm /* with dir: first-order term of the SAME items, or NULL */,
-                      const OwnerAdam ad)
+                      const OwnerAdam ad, uint32_t taps_nc /* stencil mode: points < taps_nc are merged centre items */,
+                      const float *__restrict__ tap_g0 /* [L][taps_nc][F] */, const float *__restrict__ tap_dd /* [L][taps_nc][3][F] */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
     __shared__ float s_hyper[3];
@@ -747,6 +822,8 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         const float *dyf = dy_first_lm ? dy_first_lm + (uint64_t)level * n * F : nullptr;
         const float fix = grad_scale * OWN_FIX_SCALE;
         constexpr int OWN_BATCH = 2;  // items in flight per lane: item -> (x, dy) is a dependent load chain
+        const float *g0l = TAPS ? tap_g0 + (uint64_t)level * taps_nc * F : nullptr;
+        const float *ddl = TAPS ? tap_dd + (uint64_t)level * taps_nc * 3 * F : nullptr;
         if (g.dense && !dir) {
             // Dense (coarse) levels: the binning passes lay the items of a slice down in runs of 64 CONSECUTIVE samples of
             // one corner pair, and consecutive samples of a ray sit in the same coarse cell for tens of steps -- handing a
@@ -762,14 +839,19 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
             for (int f = 0; f < F; ++f) run_lo[f] = run_hi[f] = 0.f;
             for (uint32_t jb = j0; jb < j1; jb += OWN_BATCH) {
                 uint32_t word[OWN_BATCH];
-                float gb[OWN_BATCH][F], xb[OWN_BATCH][3];
+                float gb[OWN_BATCH][F], xb[OWN_BATCH][3], db[OWN_BATCH][3][F];
 #pragma unroll
                 for (int u = 0; u < OWN_BATCH; ++u) word[u] = jb + u < j1 ? it[jb + u] : 0xffffffffu;
 #pragma unroll
                 for (int u = 0; u < OWN_BATCH; ++u) {
                     const uint32_t s = word[u] != 0xffffffffu ? word[u] >> 4 : 0u;
+                    const bool merged = TAPS && s < taps_nc;
 #pragma unroll
-                    for (int f = 0; f < F; ++f) gb[u][f] = dyl[(uint64_t)s * F + f];
+                    for (int f = 0; f < F; ++f) {
+                        gb[u][f] = merged ? g0l[(uint64_t)s * F + f] : dyl[(uint64_t)s * F + f];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) db[u][a][f] = merged ? ddl[((uint64_t)s * 3 + a) * F + f] : 0.f;
+                    }
                     xb[u][0] = x[3ull * s]; xb[u][1] = x[3ull * s + 1]; xb[u][2] = x[3ull * s + 2];
                 }
 #pragma unroll
@@ -779,15 +861,30 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                     const uint32_t mode = word[u] & 3u;
                     const Cell c = locate(g, xb[u][0], xb[u][1], xb[u][2]);
                     const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
-                    const float a12 = ((k & 1) ? c.w[1] : 1.f - c.w[1]) * ((k & 2) ? c.w[2] : 1.f - c.w[2]);
+                    const float a1 = (k & 1) ? c.w[1] : 1.f - c.w[1], a2 = (k & 2) ? c.w[2] : 1.f - c.w[2];
+                    const float a12 = a1 * a2;
                     const float w_lo = (1.f - c.w[0]) * a12, w_hi = c.w[0] * a12;
                     const uint32_t e_lo = mode != 2u ? corner_index(g, c.c[0], cy, cz) - r0 : 0xffffffffu;
                     const uint32_t e_hi = mode != 1u ? corner_index(g, c.c[0] + 1u, cy, cz) - r0 : 0xffffffffu;
-                    float v[F];
+                    // stencil mode, merged centre item: + sum_a (d w / d x_a) D_a  (zero D for plain items)
+                    const float s1 = (k & 1) ? 1.f : -1.f, s2 = (k & 2) ? 1.f : -1.f;
+                    const float dy_lo = (1.f - c.w[0]) * s1 * a2, dy_hi = c.w[0] * s1 * a2;
+                    const float dz_lo = (1.f - c.w[0]) * a1 * s2, dz_hi = c.w[0] * a1 * s2;
+                    float v_lo[F], v_hi[F];
 #pragma unroll
                     for (int f = 0; f < F; ++f) {
                         if (!isfinite(gb[u][f])) s_nonfinite = 1u;
-                        v[f] = fminf(fmaxf(gb[u][f] * fix, -4.6e18f), 4.6e18f);
+                        if constexpr (TAPS) {
+                            if (!isfinite(db[u][0][f]) || !isfinite(db[u][1][f]) || !isfinite(db[u][2][f])) s_nonfinite = 1u;
+                            const float t_lo = w_lo * gb[u][f] - a12 * db[u][0][f] + dy_lo * db[u][1][f] + dz_lo * db[u][2][f];
+                            const float t_hi = w_hi * gb[u][f] + a12 * db[u][0][f] + dy_hi * db[u][1][f] + dz_hi * db[u][2][f];
+                            v_lo[f] = fminf(fmaxf(t_lo * fix, -4.6e18f), 4.6e18f);
+                            v_hi[f] = fminf(fmaxf(t_hi * fix, -4.6e18f), 4.6e18f);
+                        } else {  // (the order of operations of the plain kernel: clamp(g * fix), then the weights)
+                            const float v = fminf(fmaxf(gb[u][f] * fix, -4.6e18f), 4.6e18f);
+                            v_lo[f] = w_lo * v;
+                            v_hi[f] = w_hi * v;
+                        }
                     }
                     if (e_lo != key_lo) {
                         if (key_lo != 0xffffffffu) {
@@ -808,7 +905,7 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                         for (int f = 0; f < F; ++f) run_hi[f] = 0.f;
                     }
 #pragma unroll
-                    for (int f = 0; f < F; ++f) { run_lo[f] += w_lo * v[f]; run_hi[f] += w_hi * v[f]; }
+                    for (int f = 0; f < F; ++f) { run_lo[f] += v_lo[f]; run_hi[f] += v_hi[f]; }
                 }
             }
             if (key_lo != 0xffffffffu) {
@@ -831,12 +928,13 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
 #pragma unroll
             for (int u = 0; u < OWN_BATCH; ++u) {
                 const uint32_t s = word[u] != 0xffffffffu ? word[u] >> 4 : 0u;
+                const float *src = (TAPS && s < taps_nc) ? g0l : dyl;
                 if constexpr (F == 2) {
-                    const float2 v = *reinterpret_cast<const float2 *>(dyl + 2ull * s);
+                    const float2 v = *reinterpret_cast<const float2 *>(src + 2ull * s);
                     gb[u][0] = v.x; gb[u][1] = v.y;
                 } else {
 #pragma unroll
-                    for (int f = 0; f < F; ++f) gb[u][f] = dyl[(uint64_t)s * F + f];
+                    for (int f = 0; f < F; ++f) gb[u][f] = src[(uint64_t)s * F + f];
                 }
                 xb[u][0] = x[3ull * s]; xb[u][1] = x[3ull * s + 1]; xb[u][2] = x[3ull * s + 2];
 #pragma unroll
@@ -870,6 +968,26 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                 } else {
                     w_lo = (1.f - c.w[0]) * (a1 * a2);
                     w_hi = c.w[0] * (a1 * a2);
+                }
+                if constexpr (TAPS) {
+                    const uint32_t smp = word[u] >> 4;
+                    if (smp < taps_nc) {  // merged centre item: w G0 + sum_a (d w / d x_a) D_a, G0 was loaded as gb
+                        const float s1 = (k & 1) ? 1.f : -1.f, s2 = (k & 2) ? 1.f : -1.f;
+                        const float a12 = a1 * a2, a0l = 1.f - c.w[0], a0h = c.w[0];
+                        float t_lo[F], t_hi[F];
+#pragma unroll
+                        for (int f = 0; f < F; ++f) {
+                            const float dx = ddl[((uint64_t)smp * 3 + 0) * F + f], dyv = ddl[((uint64_t)smp * 3 + 1) * F + f],
+                                        dz = ddl[((uint64_t)smp * 3 + 2) * F + f];
+                            if (!isfinite(dx) || !isfinite(dyv) || !isfinite(dz)) s_nonfinite = 1u;
+                            const float g_ = gb[u][f];
+                            t_lo[f] = fminf(fmaxf((a0l * a12 * g_ - a12 * dx + a0l * s1 * a2 * dyv + a0l * a1 * s2 * dz) * fix, -4.6e18f), 4.6e18f);
+                            t_hi[f] = fminf(fmaxf((a0h * a12 * g_ + a12 * dx + a0h * s1 * a2 * dyv + a0h * a1 * s2 * dz) * fix, -4.6e18f), 4.6e18f);
+                        }
+                        if (mode != 2u) lds_add<F>(acc, corner_index(g, c.c[0], cy, cz) - r0, 1.f, t_lo);
+                        if (mode != 1u) lds_add<F>(acc, corner_index(g, c.c[0] + 1u, cy, cz) - r0, 1.f, t_hi);
+                        continue;
+                    }
                 }
                 if (dyf) {
                     // first-order and second-order terms of one training step share their items (same samples, same
@@ -1403,7 +1521,7 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
                           float *workspace, uint32_t n, uint32_t level_mask_count, float grad_scale, int accumulate,
                           const NsrGridDesc *desc, const int32_t *n_dev, int phases, void *stream,
                           const float *dir = nullptr, const float *dy_first_lm = nullptr,
-                          const NsrTableAdam *adam = nullptr)
+                          const NsrTableAdam *adam = nullptr, uint32_t taps_nc = 0, float *tap_ws = nullptr)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
     NSR_REQUIRE(workspace, "nsr_hashgrid_backward_params_owner: workspace is NULL");
@@ -1420,16 +1538,26 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
     float *lm = workspace + slab_floats;
     uint32_t *counts = reinterpret_cast<uint32_t *>(lm + (uint64_t)L * F * n);
     uint32_t *bin_start = counts + n_bins, *cursors = bin_start + n_bins, *items = cursors + n_bins;
+    // stencil mode (n = 7 taps_nc points, layout [7][taps_nc]): crossing masks | G0 | D in the tap workspace
+    NSR_REQUIRE(taps_nc == 0 || (tap_ws && n == 7u * taps_nc && !dir && !adam),
+                "nsr_hashgrid_backward_params_owner: the stencil mode takes 7 n_centre points and a tap workspace");
+    uint8_t *cross = reinterpret_cast<uint8_t *>(tap_ws);
+    float *tap_g0 = tap_ws ? tap_ws + ((uint64_t)L * taps_nc + 15) / 16 * 4 : nullptr;  // (16-byte aligned behind the masks)
+    float *tap_dd = tap_ws ? tap_g0 + (uint64_t)L * taps_nc * F : nullptr;
     if (phases & 1) {  // bin the (sample, corner pair) items by owning slice: count, scan, fill
         NSR_REQUIRE(hipMemsetAsync(counts, 0, n_bins * sizeof(uint32_t), st) == hipSuccess,
                     "nsr_hashgrid_backward_params_owner: hipMemsetAsync failed");
         if (n > 0) {
+            const uint8_t *cr = taps_nc ? cross : nullptr;
+            if (taps_nc)
+                hipLaunchKernelGGL(k_tap_cross, dim3(nsr_div_up(taps_nc, 256), L), dim3(256), 0, st, x, taps_nc,
+                                   level_mask_count, cross, *desc);
             const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK * OWN_BIN_SPT), L);
             hipLaunchKernelGGL((k_own_bin<false>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                               bin_start, cursors, items, om, *desc, n_dev);
+                               bin_start, cursors, items, om, *desc, n_dev, cr, taps_nc);
             hipLaunchKernelGGL(k_own_bin_scan, dim3(L), dim3(256), 0, st, counts, bin_start, cursors, om);
             hipLaunchKernelGGL((k_own_bin<true>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                               bin_start, cursors, items, om, *desc, n_dev);
+                               bin_start, cursors, items, om, *desc, n_dev, cr, taps_nc);
             NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(bin)");
         }
     }
@@ -1471,12 +1599,22 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
     DISPATCH_F(F, {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_grid_backward_owner<F>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
+        if (taps_nc) {
+            NSR_REQUIRE(n_dev == nullptr, "nsr_hashgrid_backward_params_owner: the stencil mode takes a host-side count");
+            if (n > 0)
+                hipLaunchKernelGGL((k_tap_reduce<F>), dim3(nsr_div_up(taps_nc, 256), L), dim3(256), 0, st, x, dy_lm, cross,
+                                   taps_nc, level_mask_count, tap_g0, tap_dd, *desc);
+            hipLaunchKernelGGL((k_grid_backward_owner<F, true>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
+                               bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
+                               dy_first_lm, ad, taps_nc, tap_g0, tap_dd);
+        } else
+        hipLaunchKernelGGL((k_grid_backward_owner<F, false>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
                            bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
-                           dy_first_lm, ad);
+                           dy_first_lm, ad, 0u, nullptr, nullptr);
         if (slab_floats > 0)
             hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(256, L), dim3(256), 0, st, workspace, grad_table,
                                accumulate, om, *desc, ad);
@@ -1521,6 +1659,36 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x
     NSR_REQUIRE(adam, "nsr_hashgrid_backward_params_owner_accumulate_adam: adam is NULL");
     return owner_backward(x, dy, dy_layout, dy_stride, nullptr, workspace, n, level_mask_count, grad_scale, 0, desc, n_dev,
                           2, stream, nullptr, nullptr, adam);
+}
+
+// ---- stencil mode: the 7 n_centre points of a finite-difference step (positions [7][n_centre][3]: sample, then the six
+// +-eps taps; dy level-major [L][7 n_centre][F]).  Taps that stay in their sample's cell are folded into the sample's items
+// (see k_tap_cross / k_tap_reduce); the result equals the plain call over all 7 n_centre points up to fp32 rounding.
+extern "C" uint64_t nsr_hashgrid_backward_params_taps_workspace_floats(const NsrGridDesc *desc, uint32_t n_centre)
+{
+    if (!desc || check_desc(desc, "nsr_hashgrid_backward_params_taps_workspace_floats")) return 0;
+    const uint64_t L = desc->n_levels, F = desc->n_features;
+    return (L * n_centre + 15) / 16 * 4 + L * n_centre * F * 4;
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner_bin_taps(const float *x7, float *workspace, float *tap_workspace,
+                                                           uint32_t n_centre, uint32_t level_mask_count,
+                                                           const NsrGridDesc *desc, void *stream)
+{
+    NSR_REQUIRE(n_centre > 0 && tap_workspace, "nsr_hashgrid_backward_params_owner_bin_taps: empty input / NULL workspace");
+    return owner_backward(x7, nullptr, 2, 0, nullptr, workspace, 7u * n_centre, level_mask_count, 1.f, 0, desc, nullptr, 1,
+                          stream, nullptr, nullptr, nullptr, n_centre, tap_workspace);
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner_accumulate_taps(const float *x7, const float *dy_level_major,
+                                                                  float *grad_table, float *workspace,
+                                                                  float *tap_workspace, uint32_t n_centre,
+                                                                  uint32_t level_mask_count, int accumulate,
+                                                                  const NsrGridDesc *desc, void *stream)
+{
+    NSR_REQUIRE(n_centre > 0 && tap_workspace, "nsr_hashgrid_backward_params_owner_accumulate_taps: empty input / NULL workspace");
+    return owner_backward(x7, dy_level_major, 2, 0, grad_table, workspace, 7u * n_centre, level_mask_count, 1.f, accumulate,
+                          desc, nullptr, 2, stream, nullptr, nullptr, nullptr, n_centre, tap_workspace);
 }
 
 // first-order table gradient (dy_first, level-major fp32) and the second-order one of the analytic normal (dy row-major

@@ -15,6 +15,7 @@ heads, cone marching through the 256^3 grid with transmittance pruning, density 
 as comp_rgb_full = comp_rgb + comp_rgb_bg (1 - opacity)).
 """
 import ctypes
+import os
 
 import torch
 
@@ -125,6 +126,8 @@ class FusedNeuSStep:
         self.bg = bool(cfg["learned_background"])
         if self.bg:
             self._bg_setup(cfg)
+        # finite differences: fold the taps that stay in their sample's cell into the sample's table-backward items
+        self.fold_taps = not os.environ.get("NSR_FD_PLAIN_TAPS")
         self.radius = float(cfg["radius"])
         g = cfg["geometry"]
         self.fd = g["grad_type"] == "finite_difference"
@@ -505,7 +508,7 @@ class FusedNeuSStep:
                 jac = torch.empty(N * self.n_enc * 3, dtype=F32, device=dev)
                 check(lib.nsr_hashgrid_forward_jac(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, 0, mc, _byref(desc),
                                                    ptr(jac), None, s), "nsr_hashgrid_forward_jac")
-            gws = bin_event = None
+            gws = bin_event = tws = None
             if compute_grads and N > 0:
                 # the table backward's binning needs only the positions: it runs on a helper stream underneath the whole
                 # forward pass (count / scan / fill: 0.18 ms at 5e5 points, 0.5 ms at the 7 N points of the C5 stencil);
@@ -514,10 +517,20 @@ class FusedNeuSStep:
                 gws = torch.empty(nws, dtype=F32, device=dev)
                 if getattr(self, "_helper", None) is None:
                     self._helper = torch.cuda.Stream(device=dev)
+                if self.fd and self.fold_taps:  # in-cell taps are folded into their sample's items (stencil mode)
+                    tws = torch.empty(int(lib.nsr_hashgrid_backward_params_taps_workspace_floats(_byref(desc), N)), dtype=F32,
+                                      device=dev)
                 self._helper.wait_event(positions_ready)
                 with torch.cuda.stream(self._helper):
-                    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x7), ptr(gws), T * N, mc, _byref(desc), None,
-                                                                     stream_ptr()), "nsr_hashgrid_backward_params_owner_bin")
+                    if tws is not None:
+                        check(lib.nsr_hashgrid_backward_params_owner_bin_taps(ptr(x7), ptr(gws), ptr(tws), N, mc, _byref(desc),
+                                                                              stream_ptr()),
+                              "nsr_hashgrid_backward_params_owner_bin_taps")
+                        tws.record_stream(self._helper)
+                    else:
+                        check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x7), ptr(gws), T * N, mc, _byref(desc), None,
+                                                                         stream_ptr()),
+                              "nsr_hashgrid_backward_params_owner_bin")
                     bin_event = torch.cuda.Event()
                     bin_event.record(self._helper)
                 gws.record_stream(self._helper)
@@ -662,7 +675,11 @@ class FusedNeuSStep:
                                         ptr(d_taps), ptr(p_in), ptr(d_enc), 0, 3, C, F, ptr(g_sdf), 0, ptr(ws), T * N, N,
                                         None, s), "nsr_vmlp_backward(sdf)")
             torch.cuda.current_stream().wait_event(bin_event)  # the items are binned (helper stream)
-            if self.fd:
+            if self.fd and tws is not None:
+                check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps(ptr(x7), ptr(d_enc), ptr(g_table), ptr(gws),
+                                                                             ptr(tws), N, mc, 0, _byref(desc), s),
+                      "nsr_hashgrid_backward_params_owner_accumulate_taps")
+            elif self.fd:
                 check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws),
                                                                         T * N, mc, 1.0, 0, _byref(desc), None, s),
                       "nsr_hashgrid_backward_params_owner_accumulate")

@@ -302,3 +302,46 @@ def test_owner_backward_with_fused_adamw_matches_gradient_plus_optimizer():
             if not torch.equal(a[k], b[k]):
                 bad = [(lvl, int((a[k][off[lvl]:off[lvl + 1]] != b[k][off[lvl]:off[lvl + 1]]).sum())) for lvl in range(16)]
                 raise AssertionError((it, k, [t for t in bad if t[1]]))
+
+
+@pytest.mark.parametrize("mask_count,eps_level", [(16, 15), (9, 8), (4, 3)])
+def test_owner_backward_stencil_mode_matches_plain_backward_over_all_taps(mask_count, eps_level):
+    """nsr_hashgrid_backward_params_owner_{bin,accumulate}_taps (in-cell taps folded into their sample's items) == the plain
+    owner backward over all 7 N points; eps = one cell of the finest active level (models/geometry.py:224-236), taps clamped
+    to the box like k_neus_points does, some samples ON the box faces"""
+    import ctypes
+    import nsr_hip
+    from nsr_hip import check, lib, ptr, stream_ptr
+    gd = nsr_hip.make_grid_desc(16, 2, 19, 32, 1.3195079107728942)  # neuralangelo's grid
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n_c = 20011
+    x = torch.rand(n_c, 3, device="cuda", generator=g)
+    x[:500] = torch.round(x[:500])          # corners / faces of the box: clamped taps
+    x[500:900, 0] = 1.0
+    res = 32 * 1.3195079107728942 ** eps_level
+    eps = 1.0 / res                          # unit-cube eps = 2 r / res / (2 r)
+    x7 = x.repeat(7, 1).view(7, n_c, 3).clone()
+    for t in range(6):
+        x7[t + 1, :, t // 2] += eps if t % 2 == 0 else -eps
+    x7 = x7.clamp_(0.0, 1.0).view(-1, 3).contiguous()
+    dy = torch.randn(16, 7 * n_c, 2, device="cuda", generator=g)
+    dy[:, n_c:] *= 0.3
+    n = 7 * n_c
+    ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
+    tws = torch.empty(int(lib.nsr_hashgrid_backward_params_taps_workspace_floats(ctypes.byref(gd), n_c)), device="cuda")
+    want = torch.empty(gd.n_entries * 2, device="cuda")
+    got = torch.full_like(want, 7.0)
+    check(lib.nsr_hashgrid_backward_params_owner(ptr(x7), ptr(dy), 2, 0, ptr(want), ptr(ws), n, mask_count, 1.0, 0,
+                                                 ctypes.byref(gd), None, stream_ptr()), "plain")
+    check(lib.nsr_hashgrid_backward_params_owner_bin_taps(ptr(x7), ptr(ws), ptr(tws), n_c, mask_count, ctypes.byref(gd),
+                                                          stream_ptr()), "bin_taps")
+    check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps(ptr(x7), ptr(dy), ptr(got), ptr(ws), ptr(tws), n_c,
+                                                                 mask_count, 0, ctypes.byref(gd), stream_ptr()), "acc_taps")
+    off = [int(o) * 2 for o in gd.offset[:17]]
+    for lvl in range(16):
+        a, b = got[off[lvl]:off[lvl + 1]], want[off[lvl]:off[lvl + 1]]
+        if lvl >= mask_count:
+            assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+            continue
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 2e-5, (lvl, rel, float((a - b).abs().max()))
