@@ -16,10 +16,10 @@ adam = fetch.get("k_adamw", {}).get("avg")
 # (counters are averaged over the last dispatches of each kernel = the profiling steps bench.py's roofline refers to)
 fetch_ratio = (adam * 2 * 1024) / (16.0 * n_params) if adam else 0.5
 corr = 1.0 / fetch_ratio if 0.3 < fetch_ratio < 0.8 else 1.0
-ops = {"hashgrid_backward_params": ["k_own_bin<false>", "k_own_bin_scan", "k_own_bin<true>", "k_grid_backward_owner<2>",
-                                    "k_grid_reduce_slabs<2>"],
+names = sorted(set(fetch) | set(write))
+ops = {"hashgrid_backward_params": [k for k in names if k.startswith(("k_own_bin", "k_grid_backward_owner", "k_grid_reduce_slabs"))],
        # whichever forward variant the library dispatched (plain / two-levels-per-lane / LDS-staged)
-       "hashgrid_forward": sorted(k for k in set(fetch) | set(write) if k.startswith("k_grid_forward"))}
+       "hashgrid_forward": [k for k in names if k.startswith("k_grid_forward")]}
 res = {"_unit": "HBM-side bytes per launch = (FETCH_SIZE x correction + WRITE_SIZE) x 1024, separate --pmc passes",
        "_fetch_calibration": {"kernel": "k_adamw", "measured_over_expected": fetch_ratio, "read_side_multiplier": corr},
        "_regime": regime}
