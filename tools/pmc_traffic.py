@@ -21,7 +21,11 @@ ops = {"hashgrid_backward_params": [k for k in names if k.startswith(("k_own_bin
        # whichever forward variant the library dispatched (plain / two-levels-per-lane / LDS-staged)
        "hashgrid_forward": [k for k in names if k.startswith("k_grid_forward")]}
 res = {"_unit": "HBM-side bytes per launch = (FETCH_SIZE x correction + WRITE_SIZE) x 1024, separate --pmc passes",
-       "_fetch_calibration": {"kernel": "k_adamw", "measured_over_expected": fetch_ratio, "read_side_multiplier": corr},
+       "_fetch_calibration": {"kernel": "k_adamw" if adam else None, "measured_over_expected": fetch_ratio,
+                              "read_side_multiplier": corr,
+                              "note": None if adam else "no stand-alone k_adamw sweep in this run (AdamW on the table runs inside "
+                                      "the table backward): the guide's x2 read-side correction is applied as is; the "
+                                      "same-box calibration of an earlier pass measured 0.5003"},
        "_regime": regime}
 for name, kernels in ops.items():
     b = sum((fetch.get(k, {}).get("avg", 0.0) * corr + write.get(k, {}).get("avg", 0.0)) * 1024 for k in kernels)
