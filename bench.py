@@ -95,14 +95,22 @@ def cpu_baseline(seconds_budget=12.0):
                                         f"restatement (oracle/tcnn_ref.py), forward + backward, fp32"}}
 
 
-def pmc_traffic(name, samples_per_launch):
+def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
     """HBM-side bytes per launch of the dominant operation from the PMC passes of THIS round (tools/collect_profiles.sh ->
-    profiles/r02_pmc_traffic.json, assembled by tools/pmc_traffic.py) -- used only when those passes ran in the same
-    regime (their recorded samples per launch within 15 % of this run's); otherwise the field is null"""
+    profiles/r02_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
+    run in) -- used only when a pass ran in the same regime (same warmup / steps, or its recorded samples per launch
+    within 15 % of this run's); otherwise the field is null"""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None, "no PMC file for this round"
     pmc = json.load(open(path))
+    regimes = pmc.get("regimes")
+    if regimes:  # pick the pass that ran with this command line, else the closest one by samples per launch
+        key = f"w{warmup}_s{steps}"
+        cands = [regimes[key]] if key in regimes else []
+        cands += sorted((r for k, r in regimes.items() if k != key and isinstance(r.get(name), dict)),
+                        key=lambda r: abs(r[name].get("samples_per_launch", 0) - samples_per_launch))
+        pmc = cands[0] if cands else {}
     ent = pmc.get(name)
     if not isinstance(ent, dict) or not ent.get("samples_per_launch"):
         return None, "PMC file has no entry / regime for " + name
@@ -318,7 +326,7 @@ def main():
                 bps = ENC_BWD_FUSED_INPUT_BYTES_PER_SAMPLE
             per_launch = bps * units / launches + opt_bytes
             achieved = per_launch * launches / (ms_total * 1e-3) / 1e9
-            traffic, traffic_note = pmc_traffic(name, units / launches)
+            traffic, traffic_note = pmc_traffic(name, units / launches, args.warmup, args.steps)
             frac = achieved / HBM_PEAK_GBS
             if traffic is not None and traffic < per_launch:
                 frac, traffic_note = None, traffic_note + "; measured traffic below the algorithmic bytes: fraction withheld"
@@ -361,7 +369,9 @@ def main():
             res["other_workloads"] = other_workloads(dev)
         if os.environ.get("NSR_BENCH_REGIME_OUT"):  # the PMC passes record the regime they ran in (tools/pmc_traffic.py)
             reg = dict(res["regime"], roofline_units_per_launch={k: v["units_per_launch"] for k, v in kern.items()
-                                                                 if k.startswith("hashgrid")})
+                                                                 if k.startswith("hashgrid")},
+                       # per-step kernels: the dispatch ordinals of the 64 steps the per-kernel durations are taken on
+                       roofline_dispatch_window=[args.warmup + args.steps, args.warmup + args.steps + 64])
             json.dump(reg, open(os.environ["NSR_BENCH_REGIME_OUT"], "w"))
         print(json.dumps(res))
     if world > 1:
