@@ -313,12 +313,6 @@ class FusedNeuSStep:
         """density / colour heads on the kept samples and density compositing -> comp_rgb_bg, opacity_bg"""
         dev, S, n_rays, s = c["x01"].device, c["S"], c["n_rays"], stream_ptr()
         st = self.bg_tex_stride
-        if self._bg_grads and S > 0:  # bin the kept samples for the table backward underneath the rest of the forward
-            desc = self.bg_enc.grid_desc
-            c["gws"] = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), S)), dtype=F32, device=dev)
-            c["bin_event"] = self._on_helper(lambda hs: check(lib.nsr_hashgrid_backward_params_owner_bin(
-                ptr(c["x01"]), ptr(c["gws"]), S, desc.n_levels, _byref(desc), None, hs),
-                "nsr_hashgrid_backward_params_owner_bin(bg)"), (c["gws"], c["x01"]))
         c["tex_in"] = torch.empty((S, st), dtype=F32, device=dev)
         check(lib.nsr_bg_texture_input(ptr(c["out"]), self.bg_n_feat, ptr(c["rays_d"]), ptr(c["ri"]), ptr(c["tex_in"]), st, S,
                                        None, s), "nsr_bg_texture_input")
@@ -334,6 +328,14 @@ class FusedNeuSStep:
                                            ptr(c["t1"]), ptr(background), ptr(c["weights"]), ptr(c["trans"]),
                                            ptr(c["comp_rgb"]), ptr(c["opacity"]), ptr(c["depth"]), n_rays, s),
               "nsr_bg_composite_forward")
+        # bin the kept samples for the table backward underneath the foreground's compositing / backward (queued after the
+        # branch's own forward kernels: its host-side setup must not hold those back)
+        if self._bg_grads and S > 0:
+            desc = self.bg_enc.grid_desc
+            c["gws"] = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), S)), dtype=F32, device=dev)
+            c["bin_event"] = self._on_helper(lambda hs: check(lib.nsr_hashgrid_backward_params_owner_bin(
+                ptr(c["x01"]), ptr(c["gws"]), S, desc.n_levels, _byref(desc), None, hs),
+                "nsr_hashgrid_backward_params_owner_bin(bg)"), (c["gws"], c["x01"]))
 
     def _bg_backward(self, c, d_comp):
         """d comp_rgb_bg [n_rays, 3] -> gradients of the background's table / density head / colour head.
@@ -551,7 +553,8 @@ class FusedNeuSStep:
             if after_march is not None:
                 # the sample count of this step is known: a trainer queues the next batch's ray preparation + marching
                 # (side stream) here -- AFTER the first ~0.6 ms of this step's kernels are in the queue, so that the host
-                # time it takes does not leave the main stream idle
+                # time it takes does not leave the main stream idle.  (Later is worse: measured, the marching pass then
+                # runs next to the backward kernels, and the table backward is sensitive to co-runners.)
                 after_march(N + (bgc["S"] if bgc else 0))
             dx01 = None
             if not self.fd:  # J^T (d sdf / d encoding): models/geometry.py:176-180 through the encoder
