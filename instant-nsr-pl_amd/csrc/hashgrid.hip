@@ -774,8 +774,11 @@ __device__ __forceinline__ void owner_adam4(const OwnerAdam &ad, uint64_t idx, c
 }
 
 // Workgroup (level, slice, chunk): accumulates ITS items -- every lane busy, no scan over foreign samples.
-// TAPS: stencil mode (see k_tap_cross / k_tap_reduce): items of points < taps_nc carry the merged centre + in-cell taps.
-template <int F, bool TAPS>
+// MODE 0: plain.  MODE 1: stencil mode (see k_tap_cross / k_tap_reduce): items of points < taps_nc carry the merged centre +
+// in-cell taps.  MODE 2: second-order use (`dir` != NULL, optionally with the first-order term dy_first_lm of the same items).
+// (Both are of the form  w_c G0 + sum_a (d w_c / d x_a) D_a  per corner -- mode 2 with G0 = dy_first, D_a = scale dir_a dy --
+// but giving mode 2 the dense levels' run-length walk was measured slower: C3 2.96 -> 3.28 ms.)
+template <int F, int MODE>
 __global__ void __launch_bounds__(OWN_BLOCK)
 k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_lm /* [L][n][F] */,
                       const uint32_t *__restrict__ items, const uint32_t *__restrict__ counts,
@@ -786,6 +789,7 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                       const OwnerAdam ad, uint32_t taps_nc /* stencil mode: points < taps_nc are merged centre items */,
                       const float *__restrict__ tap_g0 /* [L][taps_nc][F] */, const float *__restrict__ tap_dd /* [L][taps_nc][3][F] */)
 {
+    constexpr bool TAPS = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
     __shared__ float s_hyper[3];
     if (ad.p && threadIdx.x == 64) {  // a lane of the second wave: the schedule arithmetic (doubles) runs beside the LDS clear
@@ -824,7 +828,7 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         constexpr int OWN_BATCH = 2;  // items in flight per lane: item -> (x, dy) is a dependent load chain
         const float *g0l = TAPS ? tap_g0 + (uint64_t)level * taps_nc * F : nullptr;
         const float *ddl = TAPS ? tap_dd + (uint64_t)level * taps_nc * 3 * F : nullptr;
-        if (g.dense && !dir) {
+        if (g.dense && MODE != 2) {  // (measured: the run-length walk is slower for the second-order mode's heavier items)
             // Dense (coarse) levels: the binning passes lay the items of a slice down in runs of 64 CONSECUTIVE samples of
             // one corner pair, and consecutive samples of a ray sit in the same coarse cell for tens of steps -- handing a
             // wave 64 consecutive items makes its lanes hit the same two LDS words (64-way serialised atomics; DESIGN
@@ -874,7 +878,7 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
 #pragma unroll
                     for (int f = 0; f < F; ++f) {
                         if (!isfinite(gb[u][f])) s_nonfinite = 1u;
-                        if constexpr (TAPS) {
+                        if constexpr (MODE == 1) {
                             if (!isfinite(db[u][0][f]) || !isfinite(db[u][1][f]) || !isfinite(db[u][2][f])) s_nonfinite = 1u;
                             const float t_lo = w_lo * gb[u][f] - a12 * db[u][0][f] + dy_lo * db[u][1][f] + dz_lo * db[u][2][f];
                             const float t_hi = w_hi * gb[u][f] + a12 * db[u][0][f] + dy_hi * db[u][1][f] + dz_hi * db[u][2][f];
@@ -1599,8 +1603,9 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
     DISPATCH_F(F, {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
         if (taps_nc) {
@@ -1608,11 +1613,15 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
             if (n > 0)
                 hipLaunchKernelGGL((k_tap_reduce<F>), dim3(nsr_div_up(taps_nc, 256), L), dim3(256), 0, st, x, dy_lm, cross,
                                    taps_nc, level_mask_count, tap_g0, tap_dd, *desc);
-            hipLaunchKernelGGL((k_grid_backward_owner<F, true>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
+            hipLaunchKernelGGL((k_grid_backward_owner<F, 1>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
                                bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
                                dy_first_lm, ad, taps_nc, tap_g0, tap_dd);
+        } else if (dir) {
+            hipLaunchKernelGGL((k_grid_backward_owner<F, 2>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
+                               bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
+                               dy_first_lm, ad, 0u, nullptr, nullptr);
         } else
-        hipLaunchKernelGGL((k_grid_backward_owner<F, false>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
+        hipLaunchKernelGGL((k_grid_backward_owner<F, 0>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
                            bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
                            dy_first_lm, ad, 0u, nullptr, nullptr);
         if (slab_floats > 0)
