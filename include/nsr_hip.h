@@ -355,6 +355,12 @@ int nsr_occupancy_update(const nsr_half *mlp_out, uint32_t stride, float density
                          float occ_thre, const uint32_t *cells, const float *occs_old, float *occs_new, uint8_t *binary,
                          float *threshold, uint32_t n_total_cells, uint32_t capacity, const int32_t *n_cells, void *stream);
 
+/* ... with the occupancy statistic of the selected cells evaluated by the caller (occ_values [capacity] fp32; NeuS:
+ * nsr_neus_occupancy_values) instead of derived from a density logit */
+int nsr_occupancy_update_values(const float *occ_values, float ema_decay, float occ_thre, const uint32_t *cells,
+                                const float *occs_old, float *occs_new, uint8_t *binary, float *threshold,
+                                uint32_t n_total_cells, uint32_t capacity, const int32_t *n_cells, void *stream);
+
 /* the Mip-NeRF 360 distortion loss the reference takes from torch_efficient_distloss
  * (flatten_eff_distloss(weights, points, intervals, ray_indices), systems/nerf.py:103-106, systems/neus.py:131-139).
  * forward: ray_loss[r] = sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 dt_i over the samples of ray r (sorted along the
@@ -680,6 +686,10 @@ int nsr_neus_shade_backward(const float *sdf_out, const float *grad, const float
                             float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
                             const int32_t *n_dev, void *stream);
 
+/* occ[i] = clip((sigmoid((sdf + h) inv_s) - sigmoid((sdf - h) inv_s) + 1e-5) / (sigmoid((sdf + h) inv_s) + 1e-5), 0, 1),
+ * h = step_size / 2, sdf = sdf_out[i][0] (rows of 16 floats), inv_s clipped to [1e-6, 1e6]   (models/neus.py:90-101) */
+int nsr_neus_occupancy_values(const float *sdf_out, const float *inv_s, float step_size, float *occ, uint32_t n,
+                              const int32_t *n_dev, void *stream);
 /* inv_s[0] = exp(10 variance[0]) (models/neus.py:27-32); grad_variance (+)= acc[inv_s gradient slot] * inv_s * 10 */
 int nsr_neus_inv_s(const float *variance, float *inv_s, void *stream);
 int nsr_neus_variance_gradient(const float *acc, const float *inv_s, float *grad_variance, int accumulate, void *stream);

@@ -812,6 +812,17 @@ extern "C" int nsr_bg_join_gradients(const float *d_logit, const float *d_tex_in
 // inv_s = exp(10 variance) (models/neus.py:27-32) and d loss / d variance from the accumulator slot the shade backward
 // fills: two one-thread kernels instead of ~8 elementwise launches
 namespace {
+// occupancy statistic of the NeuS grid refresh (models/neus.py:90-101): the alpha one marching step would get at a flat SDF
+__global__ void __launch_bounds__(EW_BLOCK)
+k_neus_occupancy(const float *__restrict__ sdf16, const float *__restrict__ inv_s_p, float step, float *__restrict__ occ,
+                 uint32_t n, const int32_t *__restrict__ n_dev)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= live_count(n, n_dev)) return;
+    const float inv_s = fminf(fmaxf(inv_s_p[0], 1e-6f), 1e6f), sdf = sdf16[16ull * i], h = step * 0.5f;
+    const float prev = sigmoidf((sdf + h) * inv_s), next = sigmoidf((sdf - h) * inv_s);
+    occ[i] = fminf(fmaxf(((prev - next) + 1e-5f) / (prev + 1e-5f), 0.f), 1.f);
+}
 __global__ void k_neus_inv_s(const float *__restrict__ variance, float *__restrict__ inv_s) { inv_s[0] = expf(variance[0] * 10.f); }
 __global__ void k_neus_variance_grad(const float *__restrict__ acc, const float *__restrict__ inv_s,
                                      float *__restrict__ grad, int accumulate)
@@ -836,5 +847,15 @@ extern "C" int nsr_neus_variance_gradient(const float *acc, const float *inv_s, 
     hipLaunchKernelGGL(k_neus_variance_grad, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, inv_s, grad_variance,
                        accumulate);
     NSR_CHECK_LAUNCH("nsr_neus_variance_gradient");
+    return NSR_OK;
+}
+
+extern "C" int nsr_neus_occupancy_values(const float *sdf_out, const float *inv_s, float step_size, float *occ, uint32_t n,
+                                         const int32_t *n_dev, void *stream)
+{
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(sdf_out && inv_s && occ, "nsr_neus_occupancy_values: NULL pointer");
+    hipLaunchKernelGGL(k_neus_occupancy, EW_GRID(n), sdf_out, inv_s, step_size, occ, n, n_dev);
+    NSR_CHECK_LAUNCH("nsr_neus_occupancy_values");
     return NSR_OK;
 }

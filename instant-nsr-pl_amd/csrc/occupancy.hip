@@ -104,6 +104,18 @@ k_occ_ema(const __half *__restrict__ mlp_out, uint32_t stride, float bias, float
     occs_new[c] = fmaxf(occs_old[c] * decay, occ);  // duplicates: one of them wins, all computed from the OLD value
 }
 
+// ... with the per-cell occupancy statistic already evaluated by the caller (NeuS: the closed-form alpha of one step)
+__global__ void __launch_bounds__(EW_BLOCK)
+k_occ_ema_values(const float *__restrict__ occ, float decay, const uint32_t *__restrict__ cells,
+                 const float *__restrict__ occs_old, float *__restrict__ occs_new, uint32_t capacity,
+                 const int32_t *__restrict__ n_cells)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= live_count(capacity, n_cells)) return;
+    const uint32_t c = cells[i];
+    occs_new[c] = fmaxf(occs_old[c] * decay, occ[i]);
+}
+
 constexpr int OCC_PARTS = 256;
 
 // mean(occs) in two steps: OCC_PARTS partial sums (a single workgroup walking 8 MB serially took ~1 ms) ...
@@ -195,5 +207,26 @@ extern "C" int nsr_occupancy_update(const nsr_half *mlp_out, uint32_t stride, fl
     hipLaunchKernelGGL(k_occ_binarize, dim3(nsr_div_up(n_total_cells, EW_BLOCK)), dim3(EW_BLOCK), 0, st, occs_new,
                        partial, occ_thre, threshold, binary, n_total_cells);
     NSR_CHECK_LAUNCH("nsr_occupancy_update");
+    return NSR_OK;
+}
+
+extern "C" int nsr_occupancy_update_values(const float *occ_values, float ema_decay, float occ_thre, const uint32_t *cells,
+                                           const float *occs_old, float *occs_new, uint8_t *binary, float *threshold,
+                                           uint32_t n_total_cells, uint32_t capacity, const int32_t *n_cells, void *stream)
+{
+    NSR_REQUIRE(occ_values && cells && occs_old && occs_new && binary && threshold && n_cells,
+                "nsr_occupancy_update_values: NULL pointer");
+    NSR_REQUIRE(((uintptr_t)threshold & 7u) == 0, "nsr_occupancy_update_values: threshold must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    NSR_REQUIRE(hipMemcpyAsync(occs_new, occs_old, (size_t)n_total_cells * sizeof(float), hipMemcpyDeviceToDevice, st) ==
+                    hipSuccess, "nsr_occupancy_update_values: copy failed");
+    if (capacity > 0)
+        hipLaunchKernelGGL(k_occ_ema_values, dim3(nsr_div_up(capacity, EW_BLOCK)), dim3(EW_BLOCK), 0, st, occ_values,
+                           ema_decay, cells, occs_old, occs_new, capacity, n_cells);
+    double *partial = reinterpret_cast<double *>(threshold + 2);
+    hipLaunchKernelGGL(k_occ_partial_sums, dim3(OCC_PARTS), dim3(EW_BLOCK), 0, st, occs_new, n_total_cells, partial);
+    hipLaunchKernelGGL(k_occ_binarize, dim3(nsr_div_up(n_total_cells, EW_BLOCK)), dim3(EW_BLOCK), 0, st, occs_new,
+                       partial, occ_thre, threshold, binary, n_total_cells);
+    NSR_CHECK_LAUNCH("nsr_occupancy_update_values");
     return NSR_OK;
 }

@@ -400,6 +400,70 @@ class FusedNeuSStep:
         return ev
 
     @torch.no_grad()
+    def refresh_occupancy_async(self, step, occ_thre=0.01, ema_decay=0.95, warmup_steps=256):
+        """``OccupancyGrid._update`` of the FOREGROUND grid (nerfacc 0.3.3; reference models/neus.py:79-109) queued on the
+        current stream with the selected-cell count kept on the device (csrc/occupancy.hip): cell selection, positions,
+        encode, SDF network, closed-form alpha, EMA / threshold / binarise, brick re-packing -- ~14 launches and no host
+        synchronisation instead of the ~250 launches + ``torch.nonzero`` of the torch formulation."""
+        m, grid, enc, desc = self.model, self.model.occupancy_grid, self.enc, self.enc.grid_desc
+        dev = grid.occs.device
+        rx, ry, rz = grid._res
+        N = grid.num_cells
+        all_cells = step < warmup_steps
+        n_uniform = N // 4
+        cap = N if all_cells else 2 * n_uniform
+        ob = getattr(self, "_occ_buf", None)
+        binary = grid._binary
+        assert binary.is_contiguous() and binary.dtype == torch.bool
+        if ob is None:
+            bricks = torch.empty(int(lib.nsr_grid_bricks_words64(rx, ry, rz)), dtype=torch.int64, device=dev)
+            ob = self._occ_buf = dict(
+                bricks=bricks, cells=torch.empty(N, dtype=torch.int32, device=dev),
+                x_unit=torch.empty(N * 3, dtype=F32, device=dev), world=torch.empty(N * 3, dtype=F32, device=dev),
+                x01=torch.empty(N * 3, dtype=F32, device=dev), enc=torch.empty(N * self.n_enc, dtype=F16, device=dev),
+                out=torch.empty(N * 16, dtype=F32, device=dev), occ=torch.empty(N, dtype=F32, device=dev),
+                u=torch.empty(2 * n_uniform, dtype=F32, device=dev), jitter=torch.empty(N * 3, dtype=F32, device=dev),
+                brick_offset=torch.empty(max(bricks.numel(), 1), dtype=torch.int32, device=dev),
+                occupied=torch.empty(N, dtype=torch.int32, device=dev), counts=torch.zeros(4, dtype=torch.int32, device=dev),
+                occs=torch.empty(N, dtype=F32, device=dev), thr=torch.empty(2 + 2 * 256, dtype=F32, device=dev))
+        bricks = ob["bricks"]
+        _ops.grid_bricks(binary, out=bricks)  # the bitfield of the CURRENT grid (cached per tensor version)
+        n_occ, n_cells = ob["counts"][0:1], ob["counts"][1:2]
+        table = enc.table_half(enc.params)
+        blob = self.sdf.build(requires_grad=False)
+        inv_s = self._inv_s()
+        with torch.cuda.device(dev):
+            s = stream_ptr()
+            ob["jitter"][:cap * 3].uniform_()
+            if not all_cells:
+                ob["u"].uniform_()
+            check(lib.nsr_occupancy_select_cells(ptr(bricks), rx, ry, rz, ptr(ob["u"][:n_uniform]),
+                                                 ptr(ob["u"][n_uniform:]), ptr(ob["jitter"]), n_uniform, int(all_cells),
+                                                 cap, ptr(ob["brick_offset"]), ptr(ob["occupied"]), ptr(n_occ),
+                                                 ptr(ob["cells"]), ptr(ob["x_unit"]), ptr(n_cells), s),
+                  "nsr_occupancy_select_cells")
+            check(lib.nsr_contract_inv(ptr(ob["x_unit"]), ptr(grid.roi_aabb), ContractionType.AABB.value, ptr(ob["world"]),
+                                       cap, s), "nsr_contract_inv")
+            check(lib.nsr_contract_to_unisphere(ptr(ob["world"]), self.radius, ContractionType.AABB.value, ptr(ob["x01"]),
+                                                cap, s), "nsr_contract_to_unisphere")
+            check(lib.nsr_hashgrid_forward_ex(ptr(ob["x01"]), ptr(table), ptr(ob["enc"]), cap, self.n_enc, 0,
+                                              self._mask_count(), _byref(desc), ptr(n_cells), s), "nsr_hashgrid_forward_ex")
+            check(lib.nsr_vmlp_forward(_byref(self.sdf.desc), ptr(blob), ptr(ob["x01"]), 3, ptr(ob["enc"]), self.n_enc,
+                                       ptr(ob["out"]), None, None, cap, cap, ptr(n_cells), s), "nsr_vmlp_forward(occupancy)")
+            check(lib.nsr_neus_occupancy_values(ptr(ob["out"]), ptr(inv_s), float(m.render_step_size), ptr(ob["occ"]), cap,
+                                                ptr(n_cells), s), "nsr_neus_occupancy_values")
+            check(lib.nsr_occupancy_update_values(ptr(ob["occ"]), float(ema_decay), float(occ_thre), ptr(ob["cells"]),
+                                                  ptr(grid.occs), ptr(ob["occs"]), ptr(binary.view(torch.uint8)),
+                                                  ptr(ob["thr"]), N, cap, ptr(n_cells), s), "nsr_occupancy_update_values")
+            grid.occs.copy_(ob["occs"])
+            check(lib.nsr_grid_pack_bricks(ptr(binary.view(torch.uint8)), rx, ry, rz, ptr(bricks), s),
+                  "nsr_grid_pack_bricks")
+        try:  # the cache of ops.grid_bricks keys on the tensor version, which a raw-pointer write does not bump
+            binary._nsr_bricks = (binary._version, binary.data_ptr(), bricks)
+        except Exception:  # noqa: BLE001
+            pass
+
+    @torch.no_grad()
     def surface_attributes(self, points):
         """``VolumeSDF.forward(points, with_grad=True, with_feature=True)`` + the "albedo" query of ``NeuSModel.export``
         (models/neus.py:313-323: colour network with viewing direction = -normal) on world points [n, 3], gradients off.
@@ -801,6 +865,7 @@ class NeuSTrainer:
         self._rest = rest + var
         self.opt_rest = SmallAdamW([(p, 0.01) for p in rest] + [(p, 0.001) for p in var])
         self.fused.lean_outputs = True  # no per-ray validity masks etc. in the step's result dict
+        self.device_occupancy_refresh = not os.environ.get("NSR_NEUS_TORCH_REFRESH")  # foreground grid (A/B switch)
         self._pending, self._side = None, None
         self.last = {}
 
@@ -823,7 +888,10 @@ class NeuSTrainer:
         grid = model.occupancy_grid
         refreshed = False
         if getattr(model, "refresh_owned_by_trainer", False) and cfg["grid_prune"] and t % 16 == 0:
-            grid.every_n_step(step=t, occ_eval_fn=self.fused.occ_eval_fn, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
+            if self.device_occupancy_refresh:  # csrc/occupancy.hip: no host synchronisation, ~14 launches
+                self.fused.refresh_occupancy_async(t, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
+            else:
+                grid.every_n_step(step=t, occ_eval_fn=self.fused.occ_eval_fn, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
             if self.fused.bg:
                 model.occupancy_grid_bg.every_n_step(step=t, occ_eval_fn=self.fused.bg_occ_eval_fn,
                                                      occ_thre=cfg.get("grid_prune_occ_thre_bg", 0.01))

@@ -174,3 +174,39 @@ def test_fused_neus_runs_on_the_product_state_holder():
                 assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), k
         keys = set(st.state_dict().keys())
         assert "variance.variance" in keys and "geometry.network.layers.0.weight_g" in keys
+
+
+@pytest.mark.parametrize("step,config", [(16, "neus-blender"), (304, "neus-blender"), (304, "neuralangelo")])
+def test_neus_device_occupancy_refresh_matches_torch_update(step, config):
+    """FusedNeuSStep.refresh_occupancy_async (csrc/occupancy.hip + the SDF network + nsr_neus_occupancy_values) == nerfacc's
+    OccupancyGrid._update_cells with the reference's occ_eval_fn (models/neus.py:90-101) on the cells / jitter the kernels
+    selected; brick bitfield re-packed"""
+    import copy
+    import nsr
+    from nsr.fused_neus import FusedNeuSStep
+    from nsr_hip import ops
+    torch.manual_seed(0)
+    cfg = nsr.configs.get(config)
+    st = nsr.build(cfg).cuda().train()
+    st.update_step(0, 12005 if config == "neuralangelo" else step)
+    grid = st.occupancy_grid
+    g = torch.Generator(device="cuda").manual_seed(1)
+    grid.occs.copy_(torch.rand(grid.num_cells, device="cuda", generator=g) * 0.02)
+    grid._binary = (torch.rand(grid._res, device="cuda", generator=g) < 0.05)
+    run = FusedNeuSStep(st)
+    ref = copy.deepcopy(grid)
+    thre = cfg.get("grid_prune_occ_thre", 0.01)
+    run.refresh_occupancy_async(step, occ_thre=thre)
+    ob = run._occ_buf
+    n = int(ob["counts"][1])
+    N = grid.num_cells
+    assert n == (N if step < 256 else N // 4 + min(int(ref._binary.sum()), N // 4))
+    cells = ob["cells"][:n].long()
+    jitter = ob["jitter"][:3 * n].view(n, 3)
+    with torch.no_grad():
+        ref._update_cells(cells, jitter, run.occ_eval_fn, occ_thre=thre, ema_decay=0.95)
+    once = torch.bincount(cells, minlength=N) <= 1
+    assert torch.allclose(grid.occs[once], ref.occs[once], rtol=2e-3, atol=2e-6), \
+        float((grid.occs[once] - ref.occs[once]).abs().max())
+    assert float((grid.binary != ref.binary).float().mean()) < 1e-4
+    assert torch.equal(ob["bricks"], ops.grid_bricks(grid.binary.clone()))
