@@ -315,7 +315,11 @@ k_composite_forward(const __half *__restrict__ mlp_out, uint32_t stride, float b
             mid = (ts + te) / 2.f;
         }
         const float inc = wave_incl_scan_add(sd);
-        const float T = expf(-(carry + (inc - sd)));
+        // exclusive prefix by shuffle, not as `inc - sd`: an overflowed density (exp(logit) = inf) would give inf - inf = NaN,
+        // where nerfacc's sequential loop gives T = 0 behind the sample (seen as a NaN pixel in an eval render)
+        float exc = __shfl_up(inc, 1, 64);
+        if (lane == 0) exc = 0.f;
+        const float T = expf(-(carry + exc));
         const float w = T * a;
         if (ok) {
             weights[start + k] = w;

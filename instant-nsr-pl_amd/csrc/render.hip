@@ -40,7 +40,11 @@ k_trans_sigma_fwd(const int32_t *__restrict__ packed, const float *__restrict__ 
         const bool ok = k < count;
         const float v = ok ? sigma[start + k] * (t1[start + k] - t0[start + k]) : 0.f;
         const float inc = wave_incl_scan_add(v);
-        if (ok) trans[start + k] = expf(-(carry + (inc - v)));
+        // exclusive prefix by shuffle, not as `inc - v`: an overflowed density (sigma = inf) would give inf - inf = NaN here,
+        // where nerfacc's sequential loop gives T = 0 behind it
+        float exc = __shfl_up(inc, 1, 64);
+        if (lane == 0) exc = 0.f;
+        if (ok) trans[start + k] = expf(-(carry + exc));
         carry += __shfl(inc, 63, 64);
     }
 }

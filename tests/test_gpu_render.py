@@ -103,3 +103,39 @@ def test_neus_alpha_fwd_bwd():
         assert torch.allclose(b[0].grad.cpu(), a[0].grad, rtol=2e-3, atol=1e-4)
         assert torch.allclose(b[1].grad.cpu(), a[1].grad, rtol=2e-3, atol=1e-5)
         assert torch.allclose(b[2].grad.cpu(), a[2].grad, rtol=2e-3, atol=1e-4)
+
+
+def test_overflowed_density_does_not_poison_the_ray():
+    """sigma = inf (trunc_exp of a large logit overflows fp32) on consecutive samples: nerfacc's sequential loop gives
+    alpha = 1, T = 0 behind the sample and finite weights; a scan written as `inclusive - own` would produce inf - inf = NaN
+    for every later sample of the ray (seen once as a NaN pixel in an eval render)"""
+    import nerfacc as A
+    n_rays, per = 3, 70
+    ri = torch.repeat_interleave(torch.arange(n_rays), per).cuda()
+    t0 = (torch.arange(per).float() * 0.01).repeat(n_rays).view(-1, 1).cuda()
+    t1 = t0 + 0.01
+    sig = torch.full((n_rays * per, 1), 2.0).cuda()
+    sig[per + 10] = float("inf")
+    sig[per + 11] = float("inf")          # two in a row, inside one wavefront
+    sig[2 * per + 63] = float("inf")
+    sig[2 * per + 64] = float("inf")      # across the 64-sample chunk boundary
+    w = A.render_weight_from_density(t0, t1, sig, ray_indices=ri, n_rays=n_rays)
+    assert bool(torch.isfinite(w).all())
+    w = w.view(n_rays, per)
+    assert float(w[1, 11:].abs().max()) == 0.0 and float(w[2, 64:].abs().max()) == 0.0   # nothing behind an opaque sample
+    assert abs(float(w[1].sum()) - 1.0) < 1e-5 and abs(float(w[2].sum()) - 1.0) < 1e-5     # the ray is fully absorbed
+    assert torch.allclose(w[0], w[1].new_tensor([(1 - torch.exp(torch.tensor(-0.02))) * torch.exp(torch.tensor(-0.02 * k))
+                                                 for k in range(per)]), rtol=1e-4)
+    # the fused NeRF compositing kernel (logits; exp(logit) overflows above 88.7)
+    from nsr_hip import check, lib, ptr, stream_ptr
+    out1 = torch.zeros((n_rays * per, 16), dtype=torch.float16, device="cuda")
+    out1[per + 10, 0] = 100.0
+    out1[per + 11, 0] = 100.0
+    rgb = torch.full((n_rays * per, 16), 0.5, dtype=torch.float16, device="cuda")
+    packed = torch.tensor([[k * per, per] for k in range(n_rays)], dtype=torch.int32, device="cuda")
+    bg = torch.ones(3, device="cuda")
+    wts, tr = torch.empty(n_rays * per, device="cuda"), torch.empty(n_rays * per, device="cuda")
+    comp, op, dp = torch.empty((n_rays, 3), device="cuda"), torch.empty(n_rays, device="cuda"), torch.empty(n_rays, device="cuda")
+    check(lib.nsr_composite_forward(ptr(out1), 16, 0.0, ptr(t0), ptr(t1), ptr(rgb), 16, ptr(packed), ptr(bg), ptr(wts), ptr(tr),
+                                    ptr(comp), ptr(op), ptr(dp), n_rays, stream_ptr()), "nsr_composite_forward")
+    assert bool(torch.isfinite(wts).all()) and bool(torch.isfinite(comp).all()) and abs(float(op[1]) - 1.0) < 1e-5

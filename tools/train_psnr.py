@@ -28,6 +28,8 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(args.steps):
     tr.train_step()
 c = tr.counters(); dt = time.perf_counter() - t0
+final_loss = float(tr.last["loss"])
+params_finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())
 model.eval()
 from nsr.export import render_rays
 psnrs = []
@@ -42,4 +44,5 @@ with torch.no_grad():
         psnrs.append(float(-10.0 * torch.log10(mse)))
 print(json.dumps({"steps": args.steps, "train_seconds": dt, "ms_per_step": 1e3 * dt / args.steps,
                   "samples_per_sec": c["samples"] / dt, "rays_per_sec": c["rays"] / dt, "truncated_launches": c["truncated"],
+                  "final_train_loss": final_loss, "parameters_finite": params_finite,
                   "test_psnr": sum(psnrs) / len(psnrs), "test_psnr_per_view": psnrs, "test_res": args.res}))
