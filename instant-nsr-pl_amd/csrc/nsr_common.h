@@ -73,9 +73,13 @@ __device__ __forceinline__ float wave_incl_scan_mul(float v)
 // ---- AdamW arithmetic shared by every kernel that applies it (csrc/util.hip k_adamw*, the table backward's fused
 // write-out in csrc/hashgrid.hip): torch.optim.AdamW semantics, the library is built with -ffp-contract=off, so the
 // same inputs give the same bits wherever this is inlined ------------------------------------------------------------
+// A non-finite gradient leaves the parameter and its moments untouched: the fused trainers run without a GradScaler
+// (gradients leave the kernels in fp32), this is its "skip the step on overflow" at element granularity -- one overflowed
+// sample must not turn a table entry into NaN for the rest of the run.  (torch.optim.AdamW would propagate the NaN.)
 __device__ __forceinline__ void nsr_adamw_elem(float &p, float &m, float &v, float gr, float lr, float b1, float b2,
                                                float eps, float wd, float bc1, float bc2)
 {
+    if (!(fabsf(gr) <= 3.4028234e38f)) return;
     p *= (1.f - lr * wd);
     m = b1 * m + (1.f - b1) * gr;
     v = b2 * v + (1.f - b2) * gr * gr;

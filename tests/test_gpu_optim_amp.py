@@ -221,3 +221,24 @@ def test_small_adamw_matches_torch_param_groups():
             if i == 1 and step >= 3:
                 continue  # bias correction of the skipped tensor lags one step in torch: compared up to the skip only
             assert torch.allclose(p, r, rtol=3e-5, atol=3e-7), (step, i, float((p - r).abs().max()))
+
+
+def test_adamw_kernels_skip_nonfinite_gradient_elements():
+    """the fused trainers have no GradScaler: an inf / NaN gradient element leaves its parameter and moments untouched
+    (skip-on-overflow at element granularity) instead of poisoning it; finite elements update as usual"""
+    from nsr_hip import ops
+    torch.manual_seed(0)
+    n = 4099
+    p = torch.randn(n, device="cuda")
+    m, v = torch.rand(n, device="cuda") * 0.1, torch.rand(n, device="cuda") * 0.01
+    g = torch.randn(n, device="cuda")
+    g[5], g[77], g[4098] = float("inf"), float("nan"), float("-inf")
+    bad = torch.tensor([5, 77, 4098], device="cuda")
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    shadow = torch.empty(n, dtype=torch.float16, device="cuda")
+    ops.adamw_step(p, g.clone(), m, v, shadow, 0.01, 0.9, 0.99, 1e-15, 0.01, 3, zero_grad=True)
+    assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(m).all()) and bool(torch.isfinite(v).all())
+    assert torch.equal(p[bad], p0[bad]) and torch.equal(m[bad], m0[bad]) and torch.equal(v[bad], v0[bad])
+    good = torch.ones(n, dtype=torch.bool, device="cuda")
+    good[bad] = False
+    assert bool((p[good] != p0[good]).all())
