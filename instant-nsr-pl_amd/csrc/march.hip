@@ -418,7 +418,8 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
                    uint32_t n, uint32_t capacity, int32_t *__restrict__ stats, const int32_t *__restrict__ n_active)
 {
     __shared__ int32_t wave_tot[16];
-    __shared__ int32_t buf[PACK_LDS];
+    extern __shared__ int32_t buf[];  // n words when staged (sized by the launch: a fixed 64 KiB would keep this one-workgroup
+                                      // kernel waiting for a CU with that much free LDS next to the step's big kernels)
     const uint32_t tid = threadIdx.x, chunk = (n + 1023) / 1024;
     const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     // slots >= *n_active are dead rays: they were marched (the marching pass runs ahead of the ray count) but keep nothing
@@ -769,7 +770,8 @@ extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *pa
     NSR_REQUIRE(n_rays == 0 || (num_steps && packed_info), "nsr_pack_from_counts: NULL pointer");
     NSR_REQUIRE(capacity < 0x7fffffffu, "nsr_pack_from_counts: capacity must fit int32");
     NSR_REQUIRE(!stats || ((uintptr_t)stats & 7u) == 0, "nsr_pack_from_counts: stats must be 8-byte aligned");
-    hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, num_steps, packed_info, total,
+    const size_t lds = n_rays <= PACK_LDS ? (size_t)n_rays * sizeof(int32_t) : 0;
+    hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), lds, (hipStream_t)stream, num_steps, packed_info, total,
                        n_rays, capacity, stats, n_active);
     NSR_CHECK_LAUNCH("nsr_pack_from_counts");
     return NSR_OK;
