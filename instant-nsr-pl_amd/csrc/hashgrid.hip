@@ -1074,12 +1074,26 @@ k_grid_reduce_slabs(const float *__restrict__ slabs, float *__restrict__ grad_ta
     const uint32_t nf = d.size[level] * F;
     const float *src = slabs + om.slab_offset[level];
     float *dst = grad_table + (uint64_t)d.offset[level] * F;
-    for (uint32_t k = (blockIdx.x * 256 + threadIdx.x) * 4; k < nf; k += gridDim.x * 256 * 4) {
-        float4 s = accumulate ? *reinterpret_cast<const float4 *>(dst + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // levels split into many chunks are small (level 0: 8 K floats x 64 slabs): one thread per float4 would leave 2,048
+    // threads walking 64 slabs each.  S lanes share a float4, each sums every S-th slab, a shuffle tree joins them
+    // (fixed order: the result does not depend on the launch).
+    const uint32_t S = C >= 32 ? 8u : (C >= 8 ? 4u : 1u);
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x, sub = t % S, q0 = t / S, qs = gridDim.x * 256 / S;
+    for (uint32_t k = q0 * 4; k < nf; k += qs * 4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-        for (uint32_t c = 0; c < C; ++c) {  // unrolled: 8 independent loads in flight (the sum order stays c = 0..C-1)
+        for (uint32_t c = sub; c < C; c += S) {  // unrolled: independent loads in flight
             const float4 v = *reinterpret_cast<const float4 *>(src + (uint64_t)c * nf + k);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        for (uint32_t o = S >> 1; o > 0; o >>= 1) {
+            s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+            s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        }
+        if (sub != 0) continue;
+        if (accumulate) {
+            const float4 o4 = *reinterpret_cast<const float4 *>(dst + k);
+            s.x += o4.x; s.y += o4.y; s.z += o4.z; s.w += o4.w;
         }
         if (ad.p) {  // the summed gradient of a dense level goes straight into AdamW (see OwnerAdam)
             const float gr[4] = {s.x, s.y, s.z, s.w};
