@@ -500,6 +500,9 @@ constexpr int OWN_BLOCK = NSR_OWN_BLOCK;
 constexpr int OWN_POW2_LOG2 = NSR_OWN_LOG2;            // hashed levels: 8192-entry slices (128 KiB at F=2) -> owner = hash bits
 constexpr int OWN_LDS_WORDS = 2 << NSR_OWN_LOG2;       // 64-bit accumulators (measured: 2^13 119 us, 2^12 133 us, 2^11 124 us)
 constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decomposition aims for
+#ifndef NSR_OWN_RL_MAX
+#define NSR_OWN_RL_MAX 10
+#endif
 #ifndef NSR_OWN_DENSE_WGS
 #define NSR_OWN_DENSE_WGS 64
 #endif
@@ -828,7 +831,11 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         constexpr int OWN_BATCH = 2;  // items in flight per lane: item -> (x, dy) is a dependent load chain
         const float *g0l = TAPS ? tap_g0 + (uint64_t)level * taps_nc * F : nullptr;
         const float *ddl = TAPS ? tap_dd + (uint64_t)level * taps_nc * 3 * F : nullptr;
-        if (g.dense && MODE != 2) {  // (measured: the run-length walk is slower for the second-order mode's heavier items)
+        // the run-length walk below hands every thread a CONTIGUOUS item range: with many items per thread the lanes of a
+        // wave then read 64 different cache lines per load (measured: 1 M uniform samples 1.28 -> 1.90 ms), so it is used
+        // up to NSR_OWN_RL_MAX items per thread only (the NeRF step has ~6); and not for the second-order mode's heavier items
+        const uint32_t rl_q = (i_end - i_beg + OWN_BLOCK - 1) / OWN_BLOCK;
+        if (g.dense && MODE != 2 && rl_q <= NSR_OWN_RL_MAX) {
             // Dense (coarse) levels: the binning passes lay the items of a slice down in runs of 64 CONSECUTIVE samples of
             // one corner pair, and consecutive samples of a ray sit in the same coarse cell for tens of steps -- handing a
             // wave 64 consecutive items makes its lanes hit the same two LDS words (64-way serialised atomics; DESIGN
