@@ -3,13 +3,20 @@
 (HashGrid L16 T2^19 F2 + fused 64-wide MLPs, <= 8192 rays/step) = sample rays -> occupancy refresh -> march ->
 hash-encode + MLP -> composite -> loss -> backward -> (RCCL grad all-reduce) -> AdamW.   Synthetic scene.
 
-    python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`` (RANK / WORLD_SIZE in the environment) or, from a bare ``python bench.py --gpus N``, this script re-launches
+itself that way (the reference's launch.py:93-107 spawns its own ranks too).  With fewer GPUs than ranks (a 1-GPU
+development box) the ranks share device 0 over a gloo rendezvous: a smoke run of the multi-rank code path, not a measurement.
 
 Prints ONE JSON line (rank 0).  value = live hash-encoded MLP samples/s over the whole job (all ranks).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,7 +49,7 @@ def _time_loop(step, seconds_budget, max_reps):
     return reps, time.time() - t0
 
 
-def cpu_baseline(seconds_budget=12.0):
+def cpu_baseline(seconds_budget=8.0):
     """The reference's CPU formulation of the path, timed on this box's host cores (fp32, all cores, N = 2^18 = one
     training step's sample budget, forward + backward):
       (a) "reference": VanillaFrequency(10) + VanillaMLP density head + SH + VanillaMLP colour head -- the reference's own
@@ -86,13 +93,98 @@ def cpu_baseline(seconds_budget=12.0):
         (rgb.sum() + feat[:, 0].sum()).backward()
 
     reps_b, dt_b = _time_loop(step_b, seconds_budget, 20)
-    return {"value": n * reps_a / dt_a, "unit": "samples/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
+    b3, b4 = cpu_marcher_compositor(cores), cpu_config0_step(cores)
+    return {"marcher_compositor": b3, "config0_end_to_end": b4, "value": n * reps_a / dt_a, "unit": "samples/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{reps_a} x 2^18 uniform samples, VanillaFrequency(10)+xyz -> VanillaMLP(64x1) -> 16, SH4, "
                       f"VanillaMLP(64x2) -> rgb, forward + backward, fp32 torch on {cores} host threads "
                       f"(oracle/vanilla_ref.py = models/network_utils.py:14-37,95-139)",
             "hashgrid_port": {"value": nb * reps_b / dt_b, "unit": "samples/s", "cores": torch.get_num_threads(),
                               "sample": f"{reps_b} x 2^16 uniform samples, hash-encode (L16 T2^19 F2) + fused-MLP "
                                         f"restatement (oracle/tcnn_ref.py), forward + backward, fp32"}}
+
+
+def _cpu_rays(n_rays, seed=0):
+    """camera rays of the Blender setup (origins on the r = 4.03 sphere, looking at the scene of radius 1.5)"""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1) * 4.03
+    target = (torch.rand(n_rays, 3, generator=g) * 2 - 1) * 0.8
+    return o, torch.nn.functional.normalize(target - o, dim=-1)
+
+
+def _cpu_ball_grid():
+    from oracle import nerfacc_ref
+    grid = nerfacc_ref.OccupancyGrid(torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), 128)
+    c = (torch.arange(128) + 0.5) / 128 * 3.0 - 1.5
+    zz, yy, xx = torch.meshgrid(c, c, c, indexing="ij")
+    grid._binary[:] = ((xx * xx + yy * yy + zz * zz) < 1.0).reshape(grid._binary.shape)  # a ball: ~15 % of the cells
+    return grid
+
+
+def cpu_marcher_compositor(cores, seconds_budget=3.0):
+    """BASELINE.md section 3, leg B3: the CPU oracle's ray marcher (scalar C, oracle/csrc/nerfacc_ref.c, 1 thread) +
+    render_weight_from_density + 3 x accumulate_along_rays (torch, `cores` threads) at 1,024 and 8,192 rays through a
+    128^3 occupancy grid, step 0.00507 (nerfacc==0.3.3 call sites models/nerf.py:83,105-108)"""
+    from oracle import nerfacc_ref as N
+    torch.set_num_threads(cores)
+    grid = _cpu_ball_grid()
+    aabb = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    out = {}
+    for n_rays in (1024, 8192):
+        o, d = _cpu_rays(n_rays)
+        box = {}
+
+        def step():
+            ri, t0, t1 = N.ray_marching(o, d, scene_aabb=aabb, grid=grid, render_step_size=0.00507421875)
+            sig = torch.full_like(t0, 20.0)
+            w = N.render_weight_from_density(t0, t1, sig, ray_indices=ri, n_rays=n_rays)
+            N.accumulate_along_rays(w, ri, values=None, n_rays=n_rays)
+            N.accumulate_along_rays(w, ri, values=(t0 + t1) / 2, n_rays=n_rays)
+            N.accumulate_along_rays(w, ri, values=torch.ones(len(ri), 3), n_rays=n_rays)
+            box["n"] = len(ri)
+
+        reps, dt = _time_loop(step, seconds_budget, 200)
+        out[str(n_rays)] = {"rays_per_sec": n_rays * reps / dt, "samples_per_sec": box["n"] * reps / dt,
+                            "samples_per_call": box["n"], "calls": reps}
+    out["what"] = "oracle marcher (C, 1 thread) + render_weight_from_density + 3 accumulate_along_rays (torch), forward"
+    return out
+
+
+def cpu_config0_step(cores, seconds_budget=5.0):
+    """BASELINE.md section 3, leg B4 = BASELINE.json configs[0]: one training step (march with sigma_fn pruning -> fields
+    -> composite -> smooth-L1 -> backward -> AdamW) of the NeRF model at 1,024 rays with the reference's pure-PyTorch
+    encoding + MLPs (VanillaFrequency + VanillaMLP, oracle/vanilla_ref.py) on the CPU oracle backend
+    (oracle/glue_ref.py:nerf_forward = models/nerf.py:61-127)"""
+    from oracle import glue_ref, tcnn_ref, vanilla_ref
+    import nsr
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    cfg = nsr.configs.get("nerf-blender")
+    grid = _cpu_ball_grid()
+    aabb = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    freq = vanilla_ref.VanillaFrequency(3, {"n_frequencies": 10})
+    dens = vanilla_ref.VanillaMLP(3 + freq.n_output_dims, 16, 64, 1)
+    col = vanilla_ref.VanillaMLP(16 + 16, 3, 64, 2)
+    sh = tcnn_ref.Encoding(3, cfg["texture"]["dir_encoding_config"])
+    opt = torch.optim.AdamW(list(dens.parameters()) + list(col.parameters()), lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+    o, d = _cpu_rays(1024)
+    rays, gt = torch.cat([o, d], -1), torch.rand(1024, 3)
+    box = {}
+
+    def step():
+        out = glue_ref.nerf_forward(rays, lambda x: dens(vanilla_ref.include_xyz(freq, x)), lambda u: sh(u).float(), col,
+                                    grid, aabb, 1.5, 0.00507421875, torch.ones(3))
+        valid = out["rays_valid"][..., 0]
+        loss = torch.nn.functional.smooth_l1_loss(out["comp_rgb"][valid], gt[valid])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        box["n"] = int(out["num_samples"])
+
+    reps, dt = _time_loop(step, seconds_budget, 50)
+    return {"rays_per_sec": 1024 * reps / dt, "samples_per_sec": box["n"] * reps / dt, "ms_per_step": 1e3 * dt / reps,
+            "kept_samples_per_step": box["n"], "steps": reps,
+            "what": "1,024 rays/step, VanillaFrequency(10)+xyz -> VanillaMLP density, SH4 -> VanillaMLP colour, CPU marcher + "
+                    "compositor, smooth-L1, backward, AdamW"}
 
 
 def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
@@ -121,9 +213,10 @@ def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
     return ent["bytes_per_launch"], f"profiles/r02_pmc_traffic.json ({ent['samples_per_launch']:.0f} samples/launch)"
 
 
-def other_workloads(dev):
+def other_workloads(dev, rank=0, world=1, sync=None, n_steps=60):
     """the fused NeuS (C3), NeuS + NeRF++ background (C4) and neuralangelo (C5) steps at the reference's operating point (dynamic ray count targeting 2^18
-    samples/step), 60 + 60 steps each: reported beside the headline line, never part of `value`"""
+    samples/step), 60 + 60 steps each: reported beside the headline line, never part of `value`.  world > 1: ray-sharded
+    over all ranks (BASELINE.json names C4 / C5 as the 8-GPU configs), same barrier + max-over-ranks timing as the headline"""
     import nsr
     from nsr.fused_neus import NeuSTrainer
     from nsr.scene import SyntheticBlender
@@ -139,25 +232,90 @@ def other_workloads(dev):
                                     environment=bool(cfg["learned_background"]))
             data.all_c2w[:, :, 3] *= float(cfg["radius"]) / 1.5
             model = nsr.build(cfg).to(dev).train()
-            tr = NeuSTrainer(model, data, cfg, lam[name], config_name=name)
+            tr = NeuSTrainer(model, data, cfg, lam[name], config_name=name, rank=rank, world_size=world)
             if name == "neuralangelo":
                 tr.global_step = 12000  # all 16 levels active (the schedule moves one level per 1000 steps)
-            for _ in range(60):
+            for _ in range(n_steps):
                 tr.train_step()
-            torch.cuda.synchronize()
+            (sync or torch.cuda.synchronize)()
             t0, n = time.perf_counter(), 0
-            for _ in range(60):
+            for _ in range(n_steps):
                 last = tr.train_step()
                 n += last["n_samples"] + last["n_samples_bg"]  # num_samples_full: foreground + NeRF++ background
-            torch.cuda.synchronize()
+            (sync or torch.cuda.synchronize)()
             dt = time.perf_counter() - t0
-            out[name] = {"ms_per_step": 1e3 * dt / 60, "samples_per_sec": n / dt, "samples_per_step": n / 60,
-                         "grad_type": cfg["geometry"]["grad_type"], "path": "nsr.fused_neus.NeuSTrainer"}
+            if world > 1:
+                t = torch.tensor([dt, float(n)], dtype=torch.float64, device=dev)
+                tm = t[:1].clone()
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+                dt, n = float(tm[0]), float(t[1])
+            out[name] = {"ms_per_step": 1e3 * dt / n_steps, "samples_per_sec": n / dt, "samples_per_step": n / n_steps,
+                         "n_gpus": world, "grad_type": cfg["geometry"]["grad_type"], "path": "nsr.fused_neus.NeuSTrainer"}
             del tr, model, data
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001  (never let a side measurement take the headline line down)
+            if world > 1:
+                raise  # ... except in a multi-rank run, where a rank that skips ahead would desynchronise the collectives
             out[name] = {"error": repr(e)[:300]}
     return out
+
+
+def exchange_report(tr, world, n_steps=32):
+    """the gradient exchange of 32 further steps, timed with HIP events on the communication stream: the small fp32
+    all-reduce, then per table range reduce-scatter (bf16) / AdamW on the shard / all-gather of the fp16 image; plus how
+    long the step's own stream waits for the exchange after its last table-backward launch (the exposed part)"""
+    sh = tr.sharded
+    tr.comm_timings = {}
+    exposed = []
+    for _ in range(n_steps):
+        tr.train_step()
+        x = getattr(tr, "_xchg", None)
+        if x is not None and getattr(sh, "_done_timed", None) is not None:
+            torch.cuda.synchronize()
+            exposed.append(x["events"][len(x["groups"]) - 1].elapsed_time(sh._done_timed))
+    torch.cuda.synchronize()
+    evs, small = tr.comm_timings.get("events", []), tr.comm_timings.get("small", [])
+    tr.comm_timings = None
+    rs = sum(e[0].elapsed_time(e[1]) for e in evs) / n_steps
+    ad = sum(e[1].elapsed_time(e[2]) for e in evs) / n_steps
+    ag = sum(e[2].elapsed_time(e[3]) for e in evs) / n_steps
+    sm = sum(e[0].elapsed_time(e[1]) for e in small) / n_steps
+    wire = sh.wire_bytes
+    return {"small_all_reduce_ms": sm, "reduce_scatter_ms": rs, "sharded_adamw_ms": ad, "all_gather_ms": ag,
+            "exposed_after_last_backward_launch_ms": (sum(exposed) / len(exposed)) if exposed else None,
+            "ranges_per_step": len(evs) / n_steps, "table_ranges": {str(i): sh.ranges(m) for i, m in enumerate(sh.modules)
+                                                                    if sh.ranges(m)},
+            "level_groups": getattr(tr, "_xchg", None) and tr._xchg["groups"], "algo": sh.algo,
+            "transport": str(sh.transport), "backend": dist.get_backend(), "wire_bytes_per_gpu_per_step": wire,
+            "per_link_GBps": (wire / max(world - 1, 1)) / max((rs + ag) * 1e-3, 1e-9) / 1e9,
+            "note": "algo ring = RCCL reduce_scatter_tensor / all_gather_into_tensor; a2a = pairwise over the xGMI mesh "
+                    "(NSR_EXCHANGE_ALGO); per_link = bytes one of the P-1 links carries per step / (reduce_scatter + all_gather "
+                    "time); the table backward writes bf16 straight into the send buffer, finest levels first, and the "
+                    "exchange of a range starts behind its level group's event (nsr/parallel.py, csrc/step.hip)"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_spawn(n_ranks):
+    """`python bench.py --gpus N` from a bare interpreter: re-launch under torch.distributed.run, one rank per GPU
+    (reference launch.py:93-107 lets Lightning spawn its DDP ranks the same way)"""
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: no GPU visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_ranks, 1))))
+    if n_dev < n_ranks:  # e.g. a 1-GPU box: RCCL refuses two ranks per device -- gloo rendezvous, every rank on device 0
+        env.update(NSR_DIST_BACKEND="gloo", NSR_FORCE_DEVICE0="1")
+        print(f"bench.py: {n_ranks} ranks requested, {n_dev} GPU(s) visible: the ranks share device 0 over gloo (a smoke run "
+              "of the multi-rank path, not a scaling measurement)", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -166,6 +324,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the C3 / C4 / C5 side measurements")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: march in order instead of on the side stream")
     ap.add_argument("--graphs", action="store_true", help="replay each step from a captured HIP graph (measured slower)")
     ap.add_argument("--sync-steps", action="store_true",
@@ -175,13 +334,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args.gpus)
     # NSR_DIST_BACKEND=gloo NSR_FORCE_DEVICE0=1 lets two ranks share ONE GPU: a smoke test of the multi-rank code path on
     # a 1-GPU box (the real runs use nccl = RCCL over xGMI, one rank per GPU)
     backend = os.environ.get("NSR_DIST_BACKEND", "nccl")
-    if os.environ.get("NSR_FORCE_DEVICE0"):
+    shared_device = bool(os.environ.get("NSR_FORCE_DEVICE0"))
+    if shared_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -238,8 +397,9 @@ def main():
             raise SystemExit("sample buffers overflowed inside the timed region: the measurement is invalid")
         # per-kernel durations: 64 further EAGER steps with the pooled HIP events of the C orchestration, recorded on
         # the stream each kernel is launched on; then 32 steps with the Python-side phase scopes
+        n_prof = 8 if shared_device else 64  # (two ranks sharing a GPU over gloo stage every exchange through the host)
         ops.profile_begin(native_only=True)
-        for _ in range(64):
+        for _ in range(n_prof):
             tr.train_step()
         prof = ops.profile_end()
         c2 = tr.counters()
@@ -249,7 +409,7 @@ def main():
                 "mlp_backward_h2": live_s}
         prof = {k: ((v[0], v[1], float(live[k])) if k in live else v) for k, v in prof.items()}
         ops.profile_begin()
-        for _ in range(32):
+        for _ in range(n_prof // 2):
             tr.train_step()
         for k, v2 in ops.profile_end().items():
             if k not in prof:
@@ -268,26 +428,36 @@ def main():
 
     comm = None
     if world > 1 and getattr(tr, "sharded", None) is not None:
-        # the gradient exchange, timed with HIP events on 32 further steps: reduce-scatter (bf16) / AdamW on the shard /
-        # all-gather of the fp16 image, per module; wire bytes per GPU and the per-link rate of the pairwise exchange
-        tr.comm_timings = {}
-        for _ in range(32):
+        comm = exchange_report(tr, world, 4 if shared_device else 32)
+
+    # steady state of the dynamic ray count (8192-ray cap reached, grid pruned): whatever --warmup / --steps were, run on
+    # until >= 300 steps are behind and time 200 more -- OUTSIDE the driver-controlled region, reported beside `value`
+    steady = None
+    if tr.async_mode and not shared_device and not os.environ.get("NSR_BENCH_NO_STEADY"):
+        while tr.global_step < 300:
             tr.train_step()
-        torch.cuda.synchronize()
-        evs = tr.comm_timings.get("events", [])
-        tr.comm_timings = None
-        n_mod = max(len(tr.sharded.modules), 1)
-        steps_c = max(len(evs) // n_mod, 1)
-        rs = sum(e[0].elapsed_time(e[1]) for e in evs) / steps_c
-        ad = sum(e[1].elapsed_time(e[2]) for e in evs) / steps_c
-        ag = sum(e[2].elapsed_time(e[3]) for e in evs) / steps_c
-        wire = tr.sharded.wire_bytes
-        comm = {"reduce_scatter_ms": rs, "sharded_adamw_ms": ad, "all_gather_ms": ag, "algo": tr.sharded.algo,
-                "transport": str(tr.sharded.transport), "wire_bytes_per_gpu_per_step": wire,
-                "per_link_GBps": (wire / max(world - 1, 1)) / max((rs + ag) * 1e-3, 1e-9) / 1e9,
-                "note": "algo ring = RCCL reduce_scatter_tensor / all_gather_into_tensor; a2a = pairwise over the xGMI mesh "
-                        "(NSR_EXCHANGE_ALGO); per_link = bytes one of the P-1 links carries per step / (reduce_scatter + "
-                        "all_gather time)"}
+        sync()
+        s0 = tr.counters()
+        sync()
+        ts = time.perf_counter()
+        for _ in range(200):
+            tr.train_step()
+        sync()
+        dts = time.perf_counter() - ts
+        s1 = tr.counters()
+        st = torch.tensor([dts, float(s1["samples"] - s0["samples"]), float(s1["rays"] - s0["rays"]),
+                           float(s1["marched"] - s0["marched"])], dtype=torch.float64, device=dev)
+        if world > 1:
+            tm = st[:1].clone()
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dist.all_reduce(st[1:], op=dist.ReduceOp.SUM)
+            st[0] = tm[0]
+        dts, ss, sr, sm = (float(v) for v in st.tolist())
+        steady = {"steps_before": int(tr.global_step) - 200, "timed_steps": 200, "ms_per_step": 1e3 * dts / 200,
+                  "samples_per_sec": ss / dts, "train_rays_per_sec": sr / dts, "kept_samples_per_step_per_gpu": ss / 200 / world,
+                  "marched_samples_per_step_per_gpu": sm / 200 / world, "rays_per_step_per_gpu": sr / 200 / world,
+                  "note": "same run, same trainer, after the driver-timed region: >= 300 steps behind, 200 steps timed with the "
+                          "same barrier + synchronize bracket (max over ranks)"}
 
     tot = torch.tensor([dt, float(n_samples), float(n_rays)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -297,11 +467,20 @@ def main():
         tot[0] = tmax[0]
     dt, n_samples, n_rays = (float(v) for v in tot.tolist())
 
+    async_mode, fuse_table_update = tr.async_mode, tr.fuse_table_update
+    n_table_params = tr.fused.ewn.grid_desc.n_entries * tr.fused.ewn.grid_desc.n_features
+    final_loss = float(tr.last["loss"])  # (a LazyLoss of the most recent step: read before anything else runs)
+    others = None
+    if not args.no_other_workloads:
+        del tr, model  # (the NeuS trainers allocate their own tables)
+        torch.cuda.empty_cache()
+        others = other_workloads(dev, rank, world, sync, 4 if shared_device else 60)
+
     if rank == 0:
         # dominant kernel: the hash-grid launch class with the largest total time in the timed region
         roof = None
         kern = {}
-        phase_steps = 32 if tr.async_mode else args.steps
+        phase_steps = (4 if shared_device else 32) if async_mode else args.steps
         phases = {k[6:]: round(v[0] / phase_steps, 4) for k, v in prof.items() if k.startswith("phase:")}
         for name, (ms_total, launches, units) in prof.items():
             if name.startswith("phase:"):
@@ -319,9 +498,8 @@ def main():
             bps = ENC_FWD_BYTES_PER_SAMPLE if name == "hashgrid_forward" else ENC_BWD_BYTES_PER_SAMPLE
             # one GPU: AdamW on the table is applied inside the table backward (csrc/hashgrid.hip OwnerAdam) -- the launch
             # then also moves the optimizer's bytes: p, m, v read + p, m, v, fp16 image written per table parameter
-            fused_opt = bool(name == "hashgrid_backward_params" and world == 1 and tr.async_mode and tr.fuse_table_update)
-            opt_bytes = ADAM_TABLE_BYTES_PER_PARAM * tr.fused.ewn.grid_desc.n_entries * tr.fused.ewn.grid_desc.n_features \
-                if fused_opt else 0
+            fused_opt = bool(name == "hashgrid_backward_params" and world == 1 and async_mode and fuse_table_update)
+            opt_bytes = ADAM_TABLE_BYTES_PER_PARAM * n_table_params if fused_opt else 0
             if fused_opt:
                 bps = ENC_BWD_FUSED_INPUT_BYTES_PER_SAMPLE
             per_launch = bps * units / launches + opt_bytes
@@ -354,7 +532,7 @@ def main():
                                    "64-wide MLPs (1+2 hidden), dynamic <=8192 rays/step targeting 2^18 samples/step, "
                                    "100x800x800 views", "parallelism": f"ray-sharded dp{world}"},
             "train_rays_per_sec": n_rays / dt, "samples_per_step_per_gpu": n_samples / args.steps / world,
-            "rays_per_step_per_gpu": n_rays / args.steps / world, "final_loss": float(tr.last["loss"]),
+            "rays_per_step_per_gpu": n_rays / args.steps / world, "final_loss": final_loss,
             "regime": {"warmup_steps": args.warmup, "timed_steps": args.steps,
                        "kept_samples_per_step": n_samples / args.steps / world,
                        "marched_samples_per_step": (n_marched / args.steps) if n_marched else None,
@@ -362,11 +540,15 @@ def main():
                        "note": "steady state of the dynamic ray count needs warmup >= ~300 steps (8192-ray cap reached, "
                                "grid pruned); shorter warm-ups time the transient (few rays, dense grid)"},
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
+            "steady_state": steady,
             "roofline": roof, "kernels": kern, "phase_ms_per_step": phases, "gradient_exchange": comm,
         }
+        if shared_device:
+            res["note"] = (f"{world} ranks SHARE one GPU over gloo (fewer GPUs than ranks on this box): a smoke run of the "
+                           "multi-rank path, not a scaling measurement")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-            res["other_workloads"] = other_workloads(dev)
+        res["other_workloads"] = others
         if os.environ.get("NSR_BENCH_REGIME_OUT"):  # the PMC passes record the regime they ran in (tools/pmc_traffic.py)
             reg = dict(res["regime"], roofline_units_per_launch={k: v["units_per_launch"] for k, v in kern.items()
                                                                  if k.startswith("hashgrid")},

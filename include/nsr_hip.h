@@ -101,6 +101,17 @@ int nsr_hashgrid_backward_params_owner_accumulate(const float *x, const void *dy
                                                   uint32_t level_mask_count, float grad_scale, int accumulate,
                                                   const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
 
+/* _accumulate over the run of levels [level_begin, level_end) only (items binned beforehand, dy level-major fp32
+ * [L][n][F]), the gradient written either as fp32 into grad_table or as bf16 (round to nearest even) into grad_bf16 --
+ * exactly one of the two is non-NULL; both are indexed like the table (entry 0 of level 0 first) and OVERWRITTEN.
+ * bf16 is the transport format of the multi-GPU gradient exchange (nsr/parallel.py): a ray-sharded step
+ * launches the finest levels first and starts their reduce-scatter while the coarse levels are still accumulating. */
+int nsr_hashgrid_backward_params_owner_accumulate_range(const float *x, const float *dy_level_major, float *grad_table,
+                                                        void *grad_bf16, float *workspace, uint32_t n,
+                                                        uint32_t level_mask_count, float grad_scale, uint32_t level_begin,
+                                                        uint32_t level_end, const NsrGridDesc *desc, const int32_t *n_dev,
+                                                        void *stream);
+
 /* dx[n,3] (fp32) = (d y / d x)^T dy  -- the NeuS analytic normal, models/geometry.py:177-180 */
 int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,
                                 uint32_t dy_stride, float *dx, uint32_t n, uint32_t level_mask_count,
@@ -524,6 +535,31 @@ int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, ui
                        void *stream);
 /* table_adam (may be NULL): apply AdamW to the hash table inside the table backward (NsrTableAdam below) -- grad_table is
  * then neither written nor read; with S == 0 kept samples the caller's optimizer still has to decay the table. */
+
+/* The ray-sharded (multi-GPU) form of the main pass -- the reference gets its gradient exchange from Lightning DDP
+ * (launch.py:93-107); here the step itself hands the gradients to the exchange in pieces, as they become final:
+ *   * the table gradient leaves as bf16 in grad_bf16 (indexed like the table), in n_groups launches over the level runs
+ *     [level_begin[g], level_end[g]) in the order given (finest levels first); event_group[g] (a hipEvent_t of the caller,
+ *     may be NULL) is recorded on `stream` behind group g, so that a communication stream can reduce-scatter group g
+ *     while group g + 1 is still accumulating;
+ *   * event_small (may be NULL) is recorded behind the weight-gradient kernels of both MLPs (which finish before the
+ *     table backward starts): the small fp32 gradients can be all-reduced underneath the table backward.
+ * grad_table / table_adam must be NULL.  With S == 0 kept samples grad_bf16 is zero-filled and every event recorded. */
+typedef struct NsrTableExchange {
+    void *grad_bf16;
+    uint64_t grad_bf16_elems; /* capacity of grad_bf16 (>= table parameters; the tail is padding of the exchange) */
+    uint32_t n_groups;        /* 1..4 */
+    uint32_t level_begin[4], level_end[4];
+    void *event_group[4];
+    void *event_small;
+} NsrTableExchange;
+int nsr_nerf_main_pass_exchange(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                                const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                                const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
+                                const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
+                                float *grad_color_mlp, void *workspace, uint32_t n_kept, uint32_t n_rays,
+                                const int32_t *n_kept_dev, const float *x01_marched, const NsrTableExchange *exchange,
+                                void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f "next" row 1: fused AdamW over the flat fp32 params (configs/<name>.yaml optimizer:

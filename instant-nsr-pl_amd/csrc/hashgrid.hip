@@ -506,6 +506,9 @@ constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decompositio
 #ifndef NSR_OWN_DENSE_WGS
 #define NSR_OWN_DENSE_WGS 64
 #endif
+#ifndef NSR_OWN_BATCH
+#define NSR_OWN_BATCH 2
+#endif
 constexpr int OWN_DENSE_TARGET_WGS = NSR_OWN_DENSE_WGS; // ... for the dense (coarse) levels: every sample lands in few entries and the
                                          // workgroups serialise on LDS conflicts -- more, smaller item chunks
                                          // (measured at 1.28e5 surface samples: 32 -> 185 us, 64 -> 177 us, 128 -> 198 us)
@@ -790,7 +793,9 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
                       const OwnerMap om, const NsrGridDesc d, const float *__restrict__ dir,
                       const float *__restrict__ dy_first_lm /* with dir: first-order term of the SAME items, or NULL */,
                       const OwnerAdam ad, uint32_t taps_nc /* stencil mode: points < taps_nc are merged centre items */,
-                      const float *__restrict__ tap_g0 /* [L][taps_nc][F] */, const float *__restrict__ tap_dd /* [L][taps_nc][3][F] */)
+                      const float *__restrict__ tap_g0 /* [L][taps_nc][F] */, const float *__restrict__ tap_dd /* [L][taps_nc][3][F] */,
+                      uint16_t *__restrict__ grad_bf16 /* non-NULL: the gradient leaves as bf16 (the multi-GPU transport buffer) */,
+                      uint32_t row_base /* first block row of this launch: a launch may cover a run of levels only */)
 {
     constexpr bool TAPS = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
@@ -803,7 +808,7 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
     __shared__ uint32_t s_nonfinite;  // an inf / NaN gradient reached this slice: it is flushed as NaN (GradScaler's
                                       // found_inf must fire exactly as it does with tcnn's fp16 atomics), never clamped away
     if (threadIdx.x == 0) s_nonfinite = 0u;
-    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t xcd = blockIdx.x & 7u, j = (blockIdx.x >> 3) + row_base;
     uint32_t level = d.n_levels;
     uint32_t local = 0;
     for (uint32_t l = 0; l < d.n_levels; ++l) {
@@ -828,7 +833,7 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         const float *dyl = dy_lm + (uint64_t)level * n * F;
         const float *dyf = dy_first_lm ? dy_first_lm + (uint64_t)level * n * F : nullptr;
         const float fix = grad_scale * OWN_FIX_SCALE;
-        constexpr int OWN_BATCH = 2;  // items in flight per lane: item -> (x, dy) is a dependent load chain
+        constexpr int OWN_BATCH = NSR_OWN_BATCH;  // items in flight per lane: item -> (x, dy) is a dependent load chain
         const float *g0l = TAPS ? tap_g0 + (uint64_t)level * taps_nc * F : nullptr;
         const float *ddl = TAPS ? tap_dd + (uint64_t)level * taps_nc * 3 * F : nullptr;
         // the run-length walk below hands every thread a CONTIGUOUS item range: with many items per thread the lanes of a
@@ -1026,16 +1031,45 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         const uint64_t base = (uint64_t)(g.offset + r0) * F;
         const bool bad = s_nonfinite != 0u;
         const float qnan = __builtin_nanf("");
-        for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4) {
-            float gr[4];
+        // every load of the slice's p / m / v is issued before the first store: the pointers may alias as far as the
+        // compiler knows, so a load / compute / store loop would pay one memory round trip per iteration
+        constexpr int ADAM_IT = (OWN_LDS_WORDS + OWN_BLOCK * 4 - 1) / (OWN_BLOCK * 4);
+        float4 pp[ADAM_IT], mm[ADAM_IT], vv[ADAM_IT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gr[q] = bad ? qnan : own_from_fixed(acc[k + q]);
-            owner_adam4<F>(ad, base + k, gr, lr, bc1, bc2);
+        for (int it = 0; it < ADAM_IT; ++it) {
+            const uint32_t k = (it * OWN_BLOCK + threadIdx.x) * 4;
+            if (k < nf) {
+                pp[it] = *reinterpret_cast<const float4 *>(ad.p + base + k);
+                mm[it] = *reinterpret_cast<const float4 *>(ad.m + base + k);
+                vv[it] = *reinterpret_cast<const float4 *>(ad.v + base + k);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ADAM_IT; ++it) {
+            const uint32_t k = (it * OWN_BLOCK + threadIdx.x) * 4;
+            if (k >= nf) continue;
+            float *pa = &pp[it].x, *ma = &mm[it].x, *va = &vv[it].x;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                nsr_adamw_elem(pa[q], ma[q], va[q], bad ? qnan : own_from_fixed(acc[k + q]), lr, ad.b1, ad.b2, ad.eps, ad.wd,
+                               bc1, bc2);
+            *reinterpret_cast<float4 *>(ad.p + base + k) = pp[it];
+            *reinterpret_cast<float4 *>(ad.m + base + k) = mm[it];
+            *reinterpret_cast<float4 *>(ad.v + base + k) = vv[it];
+            if (ad.shadow) {
+                __half2 h[2] = {__floats2half2_rn(pa[0], pa[1]), __floats2half2_rn(pa[2], pa[3])};
+                *reinterpret_cast<uint2 *>(ad.shadow + base + k) = *reinterpret_cast<uint2 *>(h);
+            }
         }
         return;
     }
     if (s_nonfinite) {
         const float qnan = __builtin_nanf("");
+        if (grad_bf16 && C == 1) {
+            uint16_t *dst = grad_bf16 + (uint64_t)(g.offset + r0) * F;
+            for (uint32_t k = threadIdx.x; k < nf; k += OWN_BLOCK) dst[k] = 0x7fc0u;
+            return;
+        }
         float *dst = C > 1 ? slabs + om.slab_offset[level] + ((uint64_t)chunk * g.size + r0) * F
                            : grad_table + (uint64_t)(g.offset + r0) * F;
         for (uint32_t k = threadIdx.x; k < nf; k += OWN_BLOCK) dst[k] = qnan;
@@ -1046,6 +1080,14 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
         for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4)
             *reinterpret_cast<float4 *>(dst + k) = make_float4(own_from_fixed(acc[k]), own_from_fixed(acc[k + 1]),
                                                                own_from_fixed(acc[k + 2]), own_from_fixed(acc[k + 3]));
+    } else if (grad_bf16) {  // transport format of the multi-GPU exchange: written once, never accumulated into
+        uint16_t *dst = grad_bf16 + (uint64_t)(g.offset + r0) * F;
+        for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4) {
+            uint2 o;
+            o.x = nsr_pack_bf16x2(own_from_fixed(acc[k]), own_from_fixed(acc[k + 1]));
+            o.y = nsr_pack_bf16x2(own_from_fixed(acc[k + 2]), own_from_fixed(acc[k + 3]));
+            *reinterpret_cast<uint2 *>(dst + k) = o;
+        }
     } else {
         float *dst = grad_table + (uint64_t)(g.offset + r0) * F;
         for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4) {
@@ -1064,9 +1106,9 @@ k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_
 template <int F>
 __global__ void __launch_bounds__(256)
 k_grid_reduce_slabs(const float *__restrict__ slabs, float *__restrict__ grad_table, int accumulate, const OwnerMap om,
-                    const NsrGridDesc d, const OwnerAdam ad)
+                    const NsrGridDesc d, const OwnerAdam ad, uint16_t *__restrict__ grad_bf16, uint32_t level_base)
 {
-    const uint32_t level = blockIdx.y;
+    const uint32_t level = blockIdx.y + level_base;
     const uint32_t C = om.n_chunks[level];
     if (C <= 1) return;
     __shared__ float s_hyper[3];
@@ -1105,6 +1147,11 @@ k_grid_reduce_slabs(const float *__restrict__ slabs, float *__restrict__ grad_ta
         if (ad.p) {  // the summed gradient of a dense level goes straight into AdamW (see OwnerAdam)
             const float gr[4] = {s.x, s.y, s.z, s.w};
             owner_adam4<F>(ad, (uint64_t)d.offset[level] * F + k, gr, s_hyper[0], s_hyper[1], s_hyper[2]);
+        } else if (grad_bf16) {
+            uint2 o;
+            o.x = nsr_pack_bf16x2(s.x, s.y);
+            o.y = nsr_pack_bf16x2(s.z, s.w);
+            *reinterpret_cast<uint2 *>(grad_bf16 + (uint64_t)d.offset[level] * F + k) = o;
         } else {
             *reinterpret_cast<float4 *>(dst + k) = s;
         }
@@ -1546,7 +1593,8 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
                           float *workspace, uint32_t n, uint32_t level_mask_count, float grad_scale, int accumulate,
                           const NsrGridDesc *desc, const int32_t *n_dev, int phases, void *stream,
                           const float *dir = nullptr, const float *dy_first_lm = nullptr,
-                          const NsrTableAdam *adam = nullptr, uint32_t taps_nc = 0, float *tap_ws = nullptr)
+                          const NsrTableAdam *adam = nullptr, uint32_t taps_nc = 0, float *tap_ws = nullptr,
+                          uint16_t *grad_bf16 = nullptr, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
     NSR_REQUIRE(workspace, "nsr_hashgrid_backward_params_owner: workspace is NULL");
@@ -1557,9 +1605,18 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
     OwnerMap om;
     uint64_t slab_floats = 0;
     uint32_t n_bins = 0;
-    const uint32_t nb = make_owner_map(desc, &om, &slab_floats, &n_bins);
+    uint32_t nb = make_owner_map(desc, &om, &slab_floats, &n_bins);
     for (uint32_t l = 0; l < L; ++l)
         NSR_REQUIRE(om.n_slices[l] <= (uint32_t)OWN_MAX_SLICES, "nsr_hashgrid_backward_params_owner: level too large");
+    // a launch may cover the run of levels [level_begin, level_end) only (the multi-GPU step exchanges the finest levels'
+    // gradient while the coarse ones are still being accumulated)
+    if (level_end > L) level_end = L;
+    NSR_REQUIRE(level_begin < level_end, "nsr_hashgrid_backward_params_owner: empty level range");
+    const bool partial = level_begin > 0 || level_end < L;
+    NSR_REQUIRE(!partial || (dy_layout == 2 && !adam && taps_nc == 0 && !dir && (phases & 1) == 0),
+                "nsr_hashgrid_backward_params_owner: a level range takes level-major dy, binned items and plain mode");
+    const uint32_t row_base = om.level_start[level_begin];
+    nb = ((level_end < L ? om.level_start[level_end] : nb / 8u) - row_base) * 8u;
     float *lm = workspace + slab_floats;
     uint32_t *counts = reinterpret_cast<uint32_t *>(lm + (uint64_t)L * F * n);
     uint32_t *bin_start = counts + n_bins, *cursors = bin_start + n_bins, *items = cursors + n_bins;
@@ -1587,7 +1644,10 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
         }
     }
     if (!(phases & 2)) return NSR_OK;
-    NSR_REQUIRE((grad_table || adam) && (n == 0 || dy), "nsr_hashgrid_backward_params_owner: NULL pointer");
+    NSR_REQUIRE((grad_table || adam || grad_bf16) && (n == 0 || dy), "nsr_hashgrid_backward_params_owner: NULL pointer");
+    NSR_REQUIRE(!grad_bf16 || (!adam && !accumulate && ((uintptr_t)grad_bf16 & 7) == 0),
+                "nsr_hashgrid_backward_params_owner: the bf16 gradient is written once (no accumulate, no fused AdamW) "
+                "into an 8-byte aligned buffer");
     OwnerAdam ad;
     memset(&ad, 0, sizeof(ad));
     if (adam) {
@@ -1636,18 +1696,20 @@ static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_
                                    taps_nc, level_mask_count, tap_g0, tap_dd, *desc);
             hipLaunchKernelGGL((k_grid_backward_owner<F, 1>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
                                bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
-                               dy_first_lm, ad, taps_nc, tap_g0, tap_dd);
+                               dy_first_lm, ad, taps_nc, tap_g0, tap_dd, grad_bf16, row_base);
         } else if (dir) {
             hipLaunchKernelGGL((k_grid_backward_owner<F, 2>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
                                bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
-                               dy_first_lm, ad, 0u, nullptr, nullptr);
+                               dy_first_lm, ad, 0u, nullptr, nullptr, grad_bf16, row_base);
         } else
         hipLaunchKernelGGL((k_grid_backward_owner<F, 0>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
                            bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
-                           dy_first_lm, ad, 0u, nullptr, nullptr);
-        if (slab_floats > 0)
-            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(256, L), dim3(256), 0, st, workspace, grad_table,
-                               accumulate, om, *desc, ad);
+                           dy_first_lm, ad, 0u, nullptr, nullptr, grad_bf16, row_base);
+        bool slabs_in_range = false;
+        for (uint32_t l = level_begin; l < level_end; ++l) slabs_in_range |= om.n_chunks[l] > 1;
+        if (slabs_in_range)
+            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(256, level_end - level_begin), dim3(256), 0, st, workspace,
+                               grad_table, accumulate, om, *desc, ad, grad_bf16, level_begin);
     });
     NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner");
     return NSR_OK;
@@ -1677,6 +1739,21 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate(const float *x, con
 {
     return owner_backward(x, dy, dy_layout, dy_stride, grad_table, workspace, n, level_mask_count, grad_scale, accumulate,
                           desc, n_dev, 2, stream);
+}
+
+// ... over the levels [level_begin, level_end) only, the gradient either as fp32 (grad_table) or as bf16 (grad_bf16: the
+// transport format of the multi-GPU exchange, nsr/parallel.py); items binned beforehand, dy level-major fp32
+extern "C" int nsr_hashgrid_backward_params_owner_accumulate_range(const float *x, const float *dy_level_major,
+                                                                   float *grad_table, void *grad_bf16, float *workspace,
+                                                                   uint32_t n, uint32_t level_mask_count, float grad_scale,
+                                                                   uint32_t level_begin, uint32_t level_end,
+                                                                   const NsrGridDesc *desc, const int32_t *n_dev,
+                                                                   void *stream)
+{
+    NSR_REQUIRE((grad_table != nullptr) != (grad_bf16 != nullptr),
+                "nsr_hashgrid_backward_params_owner_accumulate_range: exactly one of grad_table / grad_bf16");
+    return owner_backward(x, dy_level_major, 2, 0, grad_table, workspace, n, level_mask_count, grad_scale, 0, desc, n_dev, 2,
+                          stream, nullptr, nullptr, nullptr, 0, nullptr, (uint16_t *)grad_bf16, level_begin, level_end);
 }
 
 // ... with AdamW applied to the table by the workgroups that own the slices (see OwnerAdam): no gradient is written

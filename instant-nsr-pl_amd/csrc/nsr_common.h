@@ -39,6 +39,15 @@ __device__ __forceinline__ uint32_t live_count(uint32_t n, const int32_t *__rest
     return v < 0 ? 0u : ((uint32_t)v < n ? (uint32_t)v : n);
 }
 
+// fp32 -> bf16, round to nearest even (NaN stays NaN); two values packed low | high << 16
+__device__ __forceinline__ uint32_t nsr_to_bf16(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t nsr_pack_bf16x2(float lo, float hi) { return nsr_to_bf16(lo) | (nsr_to_bf16(hi) << 16); }
+
 // ---- wave-level primitives (wave64) ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v)
 {

@@ -209,13 +209,13 @@ extern "C" int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, u
     return NSR_OK;
 }
 
-extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
-                                  const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
-                                  const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
-                                  const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
-                                  float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
-                                  uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev,
-                                  const float *x01_marched, const NsrTableAdam *table_adam, void *stream)
+static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                     const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                     const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
+                     const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
+                     float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
+                     uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev,
+                     const float *x01_marched, const NsrTableAdam *table_adam, const NsrTableExchange *xchg, void *stream)
 {
     NSR_REQUIRE(d && prune_workspace && workspace && packed_marched && packed_kept, "nsr_nerf_main_pass: NULL pointer");
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
@@ -290,8 +290,25 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
     NSR_REQUIRE(!(table_adam && compute_grads && S == 0), "nsr_nerf_main_pass: the fused table update needs a non-empty "
                 "sample buffer (the table still decays when nothing was kept)");
+    if (xchg) {
+        NSR_REQUIRE(compute_grads && !grad_table && !table_adam && xchg->grad_bf16 && xchg->n_groups >= 1 &&
+                        xchg->n_groups <= 4 &&
+                        xchg->grad_bf16_elems >= (uint64_t)d->grid.n_entries * d->grid.n_features,
+                    "nsr_nerf_main_pass_exchange: needs a bf16 gradient buffer for the whole table, 1..4 level groups, and "
+                    "neither grad_table nor table_adam");
+        if (S == 0) {  // nothing kept on this rank: it still contributes (zeros) to every collective
+            NSR_REQUIRE(hipMemsetAsync(xchg->grad_bf16, 0, xchg->grad_bf16_elems * 2, st) == hipSuccess,
+                        "nsr_nerf_main_pass_exchange: hipMemsetAsync failed");
+            if (xchg->event_small)
+                NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_small, st) == hipSuccess, "hipEventRecord failed");
+            for (uint32_t g = 0; g < xchg->n_groups; ++g)
+                if (xchg->event_group[g])
+                    NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_group[g], st) == hipSuccess, "hipEventRecord failed");
+            return NSR_OK;
+        }
+    }
     if (!compute_grads || S == 0) return NSR_OK;
-    NSR_REQUIRE(grad_density_mlp && (grad_table || table_adam) && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
+    NSR_REQUIRE(grad_density_mlp && (grad_table || table_adam || xchg) && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
     float *d_rgb = (float *)(ws + L.d_rgb), *d_logit = (float *)(ws + L.d_logit);
     float *d_tex = (float *)(ws + L.d_tex), *d_enc = (float *)(ws + L.d_enc);
     float *part2 = (float *)(ws + L.partials);
@@ -314,7 +331,23 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
                                        grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
                                        &d->mlp_density, n_kept_dev, stream, wg));
     }
-    {
+    if (xchg && xchg->event_small)  // the MLP weight gradients are final behind what is queued on their stream by now
+        NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_small, wg ? g_helper.stream : st) == hipSuccess,
+                    "nsr_nerf_main_pass_exchange: hipEventRecord failed");
+    if (xchg) {
+        NSR_REQUIRE(overlap_bins, "nsr_nerf_main_pass_exchange: the helper stream is not available");
+        NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess, "nsr_nerf_main_pass: helper stream join failed");
+        ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);  // (all groups: one operation)
+        for (uint32_t g = 0; g < xchg->n_groups; ++g) {
+            NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_range(x01, d_enc, nullptr, xchg->grad_bf16,
+                                                                        (float *)(ws + L.grid_ws), S, d->grid.n_levels,
+                                                                        1.0f, xchg->level_begin[g], xchg->level_end[g],
+                                                                        &d->grid, n_kept_dev, stream));
+            if (xchg->event_group[g])
+                NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_group[g], st) == hipSuccess,
+                            "nsr_nerf_main_pass_exchange: hipEventRecord failed");
+        }
+    } else {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
         if (overlap_bins) {
             NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess,
@@ -338,4 +371,31 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
                         hipStreamWaitEvent(st, g_helper.join_wgrad, 0) == hipSuccess,
                     "nsr_nerf_main_pass: weight-gradient join failed");
     return NSR_OK;
+}
+
+extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                                  const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                                  const float *t_ends, const float *rays_d, const float *background, const float *gt_rgb,
+                                  const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
+                                  float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
+                                  uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev,
+                                  const float *x01_marched, const NsrTableAdam *table_adam, void *stream)
+{
+    return main_pass(d, prune_workspace, n_marched, packed_marched, packed_kept, t_starts, t_ends, rays_d, background,
+                     gt_rgb, w_density, w_color, grad_density_mlp, grad_table, grad_color_mlp, workspace, n_kept, n_rays,
+                     compute_grads, n_kept_dev, x01_marched, table_adam, nullptr, stream);
+}
+
+extern "C" int nsr_nerf_main_pass_exchange(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                                           const int32_t *packed_marched, const int32_t *packed_kept,
+                                           const float *t_starts, const float *t_ends, const float *rays_d,
+                                           const float *background, const float *gt_rgb, const nsr_half *w_density,
+                                           const nsr_half *w_color, float *grad_density_mlp, float *grad_color_mlp,
+                                           void *workspace, uint32_t n_kept, uint32_t n_rays, const int32_t *n_kept_dev,
+                                           const float *x01_marched, const NsrTableExchange *exchange, void *stream)
+{
+    NSR_REQUIRE(exchange, "nsr_nerf_main_pass_exchange: exchange is NULL");
+    return main_pass(d, prune_workspace, n_marched, packed_marched, packed_kept, t_starts, t_ends, rays_d, background,
+                     gt_rgb, w_density, w_color, grad_density_mlp, nullptr, grad_color_mlp, workspace, n_kept, n_rays, 1,
+                     n_kept_dev, x01_marched, nullptr, exchange, stream);
 }

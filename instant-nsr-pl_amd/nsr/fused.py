@@ -409,11 +409,14 @@ class FusedNeRFStep:
         return ab
 
     def forward_backward_async(self, rs, s_cap, kept_stats, loss_scale=1.0, compute_grads=True, after_prune_queued=None,
-                               table_adam=None):
+                               table_adam=None, exchange=None):
         """the training step on ray set ``rs`` (filled by march_async, possibly on another stream -- the caller orders
         the streams) with NO host synchronisation: the marched / kept sample counts stay on the device, all buffers
         have fixed capacities (rs['m_cap'], s_cap) and every kernel is launched for the capacity.
-        ``after_prune_queued(total_kept)`` runs once the pruning pass is queued (device int32[1] tensor)."""
+        ``after_prune_queued(total_kept)`` runs once the pruning pass is queued (device int32[1] tensor).
+        ``exchange`` = (NsrTableExchange, grad_density_mlp, grad_color_mlp): the ray-sharded form of the main pass -- the table
+        gradient leaves as bf16 in level groups with an event behind each, the MLP gradients go into the given fp32 views
+        (nsr/parallel.py ShardedAdamW); ``.grad`` of the parameters is not touched."""
         ewn, tex, d = self.ewn, self.tex, self.desc
         dev = rs["buf"].device
         slots, m_cap = rs["slots"], rs["m_cap"]
@@ -446,7 +449,16 @@ class FusedNeRFStep:
                                               int(s_cap), ptr(kept_stats), ptr(x01m), s), "nsr_nerf_prune_pass")
             if after_prune_queued is not None:
                 after_prune_queued(total)
-            with _ops.timed("fused:main_pass"):
+            if exchange is not None:
+                xd, g_density, g_color = exchange
+                with _ops.timed("fused:main_pass"):
+                    check(lib.nsr_nerf_main_pass_exchange(_byref(d), ptr(ab["pws"]), m_cap, ptr(rs["packed"]), ptr(packed2),
+                                                          ptr(mb["t0"]), ptr(mb["t1"]), ptr(rs["rd"]), ptr(rs["bg"]),
+                                                          ptr(rs["rgb"]), ptr(w1), ptr(w2), ptr(g_density), ptr(g_color),
+                                                          ptr(ab["ws"]), int(s_cap), slots, ptr(total), ptr(x01m),
+                                                          _byref(xd), s), "nsr_nerf_main_pass_exchange")
+            else:
+              with _ops.timed("fused:main_pass"):
                 if compute_grads:
                     for p in (ewn.params, tex.params):
                         if p.grad is None:

@@ -842,7 +842,9 @@ class NeuSTrainer:
         self.rank, self.world_size, self.max_steps = rank, world_size, max_steps
         self.device = next(model.parameters()).device
         self.fused = FusedNeuSStep(model, loss_weights)
-        self.train_num_samples = config["train_num_rays"] * config["num_samples_per_ray"]  # systems/neus.py:27
+        # systems/neus.py:28: the dynamic ray count targets rays x (foreground + background samples per ray)
+        self.train_num_samples = config["train_num_rays"] * (config["num_samples_per_ray"] +
+                                                             config.get("num_samples_per_ray_bg", 0))
         self.train_num_rays = config["train_num_rays"]
         self.global_step = 0
         self.gen = torch.Generator(device=self.device)
@@ -861,13 +863,27 @@ class NeuSTrainer:
             import torch.distributed as dist
             from .parallel import ShardedAdamW
             if dist.is_initialized():
+                from .trainer import guard_stale_state_dict
                 self.sharded = ShardedAdamW(tc, lr=0.01)
+                guard_stale_state_dict(model, self.sharded)
+        self._tables = tuple(m for m in tc if getattr(m, "grid_desc", None) is not None)  # their backward OVERWRITES .grad
         self._rest = rest + var
         self.opt_rest = SmallAdamW([(p, 0.01) for p in rest] + [(p, 0.001) for p in var])
         self.fused.lean_outputs = True  # no per-ray validity masks etc. in the step's result dict
         self.device_occupancy_refresh = not os.environ.get("NSR_NEUS_TORCH_REFRESH")  # foreground grid (A/B switch)
         self._pending, self._side = None, None
         self.last = {}
+
+    def state_dict(self):
+        """``model.state_dict()`` with every fp32 parameter current; at world > 1 a COLLECTIVE (every rank calls it): the
+        tables' master values are gathered from the owners' optimizer shards first (nsr.parallel.ShardedAdamW)"""
+        from .trainer import checkpoint_state_dict
+        return checkpoint_state_dict(self.model, self.sharded)
+
+    def save(self, path):
+        sd = self.state_dict()
+        if self.rank == 0:
+            torch.save({"state_dict": sd, "global_step": self.global_step}, path)
 
     def _next_batch(self, stream_ctx):
         from .fused import prepare_train_rays
@@ -929,7 +945,7 @@ class NeuSTrainer:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             all_reduce_gradients(self._rest)
-            self.sharded.step(lr_scale=scale, timings=self.comm_timings)
+            self.sharded.step(lr_scale=scale, timings=self.comm_timings, overwritten=self._tables)
         else:
             if self.world_size > 1:
                 all_reduce_gradients(list(model.parameters()))

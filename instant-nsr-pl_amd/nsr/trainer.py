@@ -123,6 +123,23 @@ class FusedAdamW:
             m.adopt_shadow(self.state[m.params][2])
 
 
+def checkpoint_state_dict(model, sharded):
+    if sharded is not None:
+        sharded.gather_master()
+    return model.state_dict()
+
+
+def guard_stale_state_dict(model, sharded):
+    """a plain ``model.state_dict()`` in the middle of a multi-GPU run would silently hold stale table values on every
+    rank: refuse it, ``Trainer.state_dict()`` gathers first"""
+    def hook(module, prefix, keep_vars):
+        if not sharded.master_current:
+            raise RuntimeError("the fp32 hash tables of a multi-GPU run live in the ranks' optimizer shards: call "
+                               "trainer.state_dict() / trainer.save() (a collective: on every rank) instead of "
+                               "model.state_dict()")
+    model.register_state_dict_pre_hook(hook)
+
+
 def next_capacity(cap, window_max, n_rays, slots, dropped, granule=16384, floor=65536):
     """Sample-buffer capacity for the next steps of the asynchronous trainer, from LAGGED statistics (the host never
     waits for a count): 1.5 x the largest count of the last window, scaled by the room the dynamic ray count still has
@@ -185,7 +202,18 @@ class Trainer:
         other = [p for p in model.parameters() if id(p) not in tc_params]
         self.opt = FusedAdamW(tc, other)
         # world > 1: reduce-scatter -> AdamW on this rank's 1/P of the table -> all-gather of the fp16 image (nsr/parallel.py)
-        self.sharded = ShardedAdamW(tc) if (world_size > 1 and not other and dist.is_initialized()) else None
+        self.sharded, self._xchg = None, None
+        if world_size > 1 and not other and dist.is_initialized():
+            # the table is exchanged in NSR_EXCHANGE_GROUPS ranges cut at level boundaries (default 2: the five finest levels,
+            # launched first by the fused step, travel while the other eleven are still being accumulated)
+            splits = {}
+            for m in tc:
+                gd = getattr(m, "grid_desc", None)
+                if gd is not None and int(os.environ.get("NSR_EXCHANGE_GROUPS", "2")) > 1:
+                    lv = min(int(os.environ.get("NSR_EXCHANGE_SPLIT_LEVEL", "11")), gd.n_levels - 1)
+                    splits[m] = [int(gd.offset[lv]) * int(gd.n_features)]
+            self.sharded = ShardedAdamW(tc, splits=splits)
+            guard_stale_state_dict(model, self.sharded)
         self.comm_timings = None
         # asynchronous single-GPU steps: AdamW on the table inside the table backward (NSR_TABLE_ADAM_SEPARATE: A/B switch)
         self.fuse_table_update = not os.environ.get("NSR_TABLE_ADAM_SEPARATE")
@@ -204,13 +232,65 @@ class Trainer:
             self.fused = FusedNeRFStep(model)
             self.opt.table_grad_overwritten = True
 
+    # ---- checkpoints -------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """``model.state_dict()`` (reference key set, tests/golden/state_dict_keys.json) with every fp32 parameter current.
+        Multi-GPU: the tables' fp32 master values live in the owners' shards (nsr.parallel.ShardedAdamW), so this is a
+        COLLECTIVE -- every rank calls it (rank 0 alone then writes the file: ``save``)."""
+        return checkpoint_state_dict(self.model, self.sharded)
+
+    def save(self, path):
+        sd = self.state_dict()
+        if self.rank == 0:
+            torch.save({"state_dict": sd, "global_step": self.global_step}, path)
+
     def _all_reduce_grads(self):
         if self.world_size > 1 and self.sharded is None:
             all_reduce_gradients(list(self.model.parameters()))
 
-    def _optimizer_step(self, device_schedule):
+    def _exchange(self):
+        """(NsrTableExchange, density-MLP gradient view, colour-MLP gradient view) + the events behind each level group:
+        the fused asynchronous step hands its gradients to nsr.parallel.ShardedAdamW in pieces, as they become final"""
+        if self._xchg is not None:
+            return self._xchg
+        from nsr_hip import NsrTableExchange
+        ewn, tex, sh = self.fused.ewn, self.fused.tex, self.sharded
+        gd = ewn.grid_desc
+        F, L = int(gd.n_features), int(gd.n_levels)
+        send = sh.send_buffer(ewn)
+        assert send.dtype == torch.bfloat16, "the table backward writes bf16 (ShardedAdamW transport)"
+        # level run of every exchange range (highest offsets first): a range is final once the levels that reach into it are
+        offs = [int(gd.offset[l]) * F for l in range(L + 1)]
+        groups, hi = [], L
+        for a, _ in sh.ranges(ewn)[:-1]:
+            lo = max(l for l in range(L) if offs[l] <= a)  # the level a (rounded-up) cut falls into is launched with the
+            # EARLIER group: its tail lies in this range, its head in the next one, which is exchanged after both groups
+            groups.append((lo, hi))
+            hi = lo
+        groups.append((0, hi))
+        groups = [g for g in groups if g[1] > g[0]]
+        assert 1 <= len(groups) <= 4 and len(groups) == len(sh.ranges(ewn))
+        xd = NsrTableExchange()
+        xd.grad_bf16, xd.grad_bf16_elems, xd.n_groups = send.data_ptr(), send.numel(), len(groups)
+        events = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
+        for e in events:
+            e.record()  # (materialises the HIP event: the C side records it from now on)
+        for k, (lo, hi) in enumerate(groups):
+            xd.level_begin[k], xd.level_end[k], xd.event_group[k] = lo, hi, events[k].cuda_event
+        xd.event_small = events[-1].cuda_event
+        self._xchg = dict(desc=xd, g_density=sh.small_grad_view(ewn), g_color=sh.small_grad_view(tex),
+                          ready={"small": events[-1], ewn: events[:-1]}, groups=groups, events=events)
+        return self._xchg
+
+    def _optimizer_step(self, device_schedule, exchanged=False):
         if self.sharded is not None:  # the exchange is part of the step
-            self.sharded.step(lr_scale=multistep_lr_scale(self.global_step), timings=self.comm_timings)
+            kw = {}
+            if exchanged:  # the fused step already wrote bf16 table gradients / flattened MLP gradients (see _exchange)
+                x = self._xchg
+                kw = dict(ready=x["ready"], prefilled=(self.fused.ewn,), direct_small=(self.fused.ewn, self.fused.tex))
+            elif self.fused is not None:
+                kw = dict(overwritten=(self.fused.ewn,))
+            self.sharded.step(lr_scale=multistep_lr_scale(self.global_step), timings=self.comm_timings, **kw)
         elif device_schedule:
             self.opt.step_device()
         else:
@@ -484,8 +564,10 @@ class Trainer:
 
         # one GPU: AdamW on the hash table happens inside the table backward (no gradient store / optimizer read-back)
         fuse_table = self.world_size == 1 and self.sharded is None and self.fuse_table_update
+        xchg = self._exchange() if (self.sharded is not None and not os.environ.get("NSR_EXCHANGE_UNFUSED")) else None
         res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued,
-                                           table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None)
+                                           table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None,
+                                           exchange=(xchg["desc"], xchg["g_density"], xchg["g_color"]) if xchg else None)
         a["total_kept"] = res["num_samples"]
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
@@ -493,7 +575,7 @@ class Trainer:
             if fuse_table:
                 self.opt.step_device(skip_table_of=fused.ewn)
             else:
-                self._optimizer_step(True)
+                self._optimizer_step(True, exchanged=xchg is not None)
         a["last_step_event"] = torch.cuda.Event()
         a["last_step_event"].record(main)
         for key in [k for k in ev if k[1] < t - 2]:

@@ -52,6 +52,13 @@ class NsrTableAdam(ctypes.Structure):
                 ("milestone2", ctypes.c_int32), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float)]
 
 
+class NsrTableExchange(ctypes.Structure):
+    """include/nsr_hip.h: the ray-sharded main pass hands the table gradient to the exchange as bf16, in level groups"""
+    _fields_ = [("grad_bf16", ctypes.c_void_p), ("grad_bf16_elems", ctypes.c_uint64), ("n_groups", ctypes.c_uint32),
+                ("level_begin", ctypes.c_uint32 * 4), ("level_end", ctypes.c_uint32 * 4),
+                ("event_group", ctypes.c_void_p * 4), ("event_small", ctypes.c_void_p)]
+
+
 class NsrVanillaLayer(ctypes.Structure):
     """include/nsr_hip.h: the nn.Linear tensors of one VanillaMLP layer (weight_g NULL: plain weight)"""
     _fields_ = [("weight_v", ctypes.c_void_p), ("weight_g", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -169,6 +176,8 @@ SIGNATURES = {
     "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
     "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P, _P],
+    "nsr_nerf_main_pass_exchange": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _P],
+    "nsr_hashgrid_backward_params_owner_accumulate_range": [_P, _P, _P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_taps_workspace_floats": [_GD, _U],
     "nsr_hashgrid_backward_params_owner_bin_taps": [_P, _P, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_taps": [_P, _P, _P, _P, _P, _U, _U, _I, _GD, _P],

@@ -137,10 +137,12 @@ def test_lazy_loss_refuses_stale_reads():
 class _FakeTcnnModule(torch.nn.Module):
     """what ShardedAdamW needs from a tinycudann module: one flat fp32 ``params`` and ``adopt_shadow``"""
 
-    def __init__(self, n, seed):
+    def __init__(self, n, seed, n_network_params=0):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
         self.params = torch.nn.Parameter(torch.randn(n, generator=g) * 0.1)
+        self.params.grad = torch.zeros(n)
+        self.n_network_params = n_network_params  # MLP weights in front of the table (NetworkWithInputEncoding)
         self.shadow = None
 
     def adopt_shadow(self, shadow):
@@ -158,8 +160,11 @@ def _sharded_worker(rank, world, port, out, transport):
                       LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nsr.parallel import ShardedAdamW
-    mods = [_FakeTcnnModule(70003, 7), _FakeTcnnModule(7168, 8)]  # ragged size: the last shard is short
-    opt = ShardedAdamW(mods, lr=0.01, transport=getattr(torch, transport))
+    # [3072 MLP weights | ragged 70003-element table] (the last shard is short) + a small module (replicated, not sharded)
+    mods = [_FakeTcnnModule(3072 + 70003, 7, n_network_params=3072), _FakeTcnnModule(7168, 8)]
+    # the table is exchanged in three ranges (cut points rounded up to world x 8 elements), highest offsets first
+    opt = ShardedAdamW(mods, lr=0.01, transport=getattr(torch, transport), small_numel=1 << 14,
+                       splits={mods[0]: [20000, 50001]})
     grads = []
     for step in range(3):
         g = torch.Generator().manual_seed(1000 * step + rank)
@@ -171,7 +176,7 @@ def _sharded_worker(rank, world, port, out, transport):
     own = [m.params.detach().clone() for m in mods]
     opt.gather_master()
     torch.save({"grads": grads, "shadows": shadows, "own": own, "master": [m.params.detach().clone() for m in mods],
-                "wire_bytes": opt.wire_bytes}, os.path.join(out, f"rank{rank}.pt"))
+                "wire_bytes": opt.wire_bytes, "ranges": opt.ranges(mods[0])}, os.path.join(out, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -200,15 +205,19 @@ def test_sharded_adamw_world4_matches_single_process_adamw_on_the_mean_gradient(
         for a, b in zip(r[0]["master"], r[k]["master"]):
             assert torch.equal(a, b)                                  # ... and so do the gathered fp32 masters
     mean = [[sum(r[k]["grads"][s][i] for k in range(world)) / world for i in range(2)] for s in range(3)]
-    want = _reference_adamw([70003, 7168], [7, 8], mean, [1.0, 1.0, 0.33])
+    want = _reference_adamw([3072 + 70003, 7168], [7, 8], mean, [1.0, 1.0, 0.33])
     for got, w, sh in zip(r[0]["master"], want, r[0]["shadows"]):
         assert torch.allclose(got, w, rtol=1e-5, atol=1e-7)
         assert torch.equal(sh[:w.numel()], got.half())                # the image the kernels read = rounded master
-    # before the gather a rank's fp32 tensor is current only inside its own shard
-    S = -(-70003 // (world * 8)) * 8
-    assert torch.equal(r[1]["own"][0][S:2 * S], r[0]["master"][0][S:2 * S])
-    assert not torch.equal(r[1]["own"][0][:S], r[0]["master"][0][:S])
-    assert r[0]["wire_bytes"] == (S + -(-7168 // (world * 8)) * 8) * (world - 1) * (4 + 2)
+    # before the gather a rank's fp32 tensor is current in the replicated parts only (MLP head, small module); the
+    # table's master values live in the owners' shards
+    assert torch.equal(r[1]["own"][0][:3072], r[0]["master"][0][:3072]) and torch.equal(r[1]["own"][1], r[0]["master"][1])
+    assert not torch.equal(r[1]["own"][0][3072:], r[0]["master"][0][3072:])
+    G = world * 8
+    pad = -(-70003 // G) * G
+    assert r[0]["ranges"] == [(-(-50001 // G) * G, pad), (-(-20000 // G) * G, -(-50001 // G) * G), (0, -(-20000 // G) * G)]
+    n_small = 3072 + 7168
+    assert r[0]["wire_bytes"] == pad // world * (world - 1) * (4 + 2) + 2 * n_small * 4 * (world - 1) // world
 
 
 def test_sharded_adamw_bf16_transport_stays_in_step(tmp_path):
@@ -219,7 +228,7 @@ def test_sharded_adamw_bf16_transport_stays_in_step(tmp_path):
     for a, b in zip(r[0]["shadows"], r[1]["shadows"]):
         assert torch.equal(a, b)
     mean = [[sum(r[k]["grads"][s][i] for k in range(world)) / world for i in range(2)] for s in range(3)]
-    want = _reference_adamw([70003, 7168], [7, 8], mean, [1.0, 1.0, 0.33])
+    want = _reference_adamw([3072 + 70003, 7168], [7, 8], mean, [1.0, 1.0, 0.33])
     for got, w in zip(r[0]["master"], want):
         # Adam normalises the step (eps = 1e-15: the first step is lr * sign(g)): a bf16-rounded gradient moves a parameter
         # by ~lr * 2^-8 differently per step -- except where the ranks' gradients cancel to within the rounding and the

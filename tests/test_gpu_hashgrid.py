@@ -345,3 +345,48 @@ def test_owner_backward_stencil_mode_matches_plain_backward_over_all_taps(mask_c
             continue
         rel = float((a - b).norm() / b.norm())
         assert rel < 2e-5, (lvl, rel, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("groups", [[(0, 16)], [(11, 16), (0, 11)], [(13, 16), (5, 13), (2, 5), (0, 2)]],
+                         ids=["one", "two", "four"])
+def test_owner_backward_level_ranges_and_bf16_transport(groups):
+    """nsr_hashgrid_backward_params_owner_accumulate_range: the table gradient launched as runs of levels (finest first, what
+    the ray-sharded step does so that the exchange of the finest levels overlaps the rest of the backward) equals the one
+    launch bit for bit as fp32, and as bf16 it is the round-to-nearest-even image of that gradient -- incl. NaN flushing of a
+    slice that saw a non-finite dy"""
+    import ctypes
+    import nsr_hip
+    from nsr_hip import check, lib, ptr, stream_ptr
+    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
+    n, n_tab = 40000, gd.n_entries * 2
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand(n, 3, device="cuda", generator=g)
+    dy = torch.randn(16, n, 2, device="cuda", generator=g) * 1e-3
+    ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
+    D = ctypes.byref(gd)
+    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, D, None, stream_ptr()), "bin")
+    want = torch.empty(n_tab, device="cuda")
+    check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x), ptr(dy), 2, 0, ptr(want), ptr(ws), n, 16, 1.0, 0, D, None,
+                                                            stream_ptr()), "accumulate")
+    got = torch.full((n_tab,), float("nan"), device="cuda")
+    got16 = torch.full((n_tab + 64,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    for lo, hi in groups:
+        check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), ptr(got), None, ptr(ws), n, 16, 1.0, lo,
+                                                                      hi, D, None, stream_ptr()), "range fp32")
+        check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), None, ptr(got16), ptr(ws), n, 16, 1.0,
+                                                                      lo, hi, D, None, stream_ptr()), "range bf16")
+    assert torch.equal(got, want)
+    assert torch.equal(got16[:n_tab], want.to(torch.bfloat16))          # torch rounds to nearest even too
+    assert bool(torch.isnan(got16[n_tab:].float()).all())                # the padding of the exchange is not touched
+    assert float(want.abs().sum()) > 0
+    # exactly one of the two outputs
+    rc = lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), ptr(got), ptr(got16), ptr(ws), n, 16, 1.0, 0, 16,
+                                                                 D, None, stream_ptr())
+    assert rc != 0
+    # a non-finite dy flushes the slices it reaches as NaN in the transport format as well (GradScaler's found_inf)
+    dy2 = dy.clone()
+    dy2[15, 7, 0] = float("inf")
+    check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy2), None, ptr(got16), ptr(ws), n, 16, 1.0, 11, 16,
+                                                                  D, None, stream_ptr()), "range bf16 inf")
+    off = [int(o) * 2 for o in gd.offset[:17]]
+    assert bool(torch.isnan(got16[off[15]:off[16]].float()).any()) and not bool(torch.isnan(got16[off[11]:off[15]].float()).any())

@@ -39,14 +39,16 @@ def main():
     from nsr.scene import SyntheticBlender
     from nsr.trainer import Trainer
     report = {}
-    for name in ("nerf-blender", "neus-dtu"):
-        cfg = nsr.configs.get(name)
+    for name in ("nerf-blender", "nerf-blender-async", "neus-dtu"):
+        cfg = nsr.configs.get(name.replace("-async", ""))
         torch.manual_seed(100 + rank)  # different initial weights on purpose: the broadcast has to make them equal
         model = nsr.build(cfg).to(dev).train()
         data = SyntheticBlender(n_images=8, w=64, h=64, device=dev, seed=0, environment=bool(cfg.get("learned_background")))
         data.all_c2w[:, :, 3] *= float(cfg["radius"]) / 1.5
-        if name == "nerf-blender":
-            tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42, async_mode=False)
+        if name.startswith("nerf-blender"):
+            # "-async": the measured path of bench.py -- no host sync, the table backward writes bf16 into the exchange's send
+            # buffer in two level groups, the MLP gradients go into the flattened small message (nsr_nerf_main_pass_exchange)
+            tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42, async_mode=name.endswith("-async"))
         else:
             tr = NeuSTrainer(model, data, cfg, {"lambda_rgb_l1": 1.0, "lambda_eikonal": 0.1}, config_name=name, rank=rank,
                              world_size=world, seed=42)
@@ -57,6 +59,15 @@ def main():
             counts.append(int(tr.train_step()["n_samples"]))
         torch.cuda.synchronize()
         mine = digests(model)
+        groups = None
+        if name.endswith("-async"):
+            assert tr._xchg is not None and len(tr._xchg["groups"]) == 2, "the asynchronous step exchanges in two level groups"
+            groups = tr._xchg["groups"]
+            # a checkpoint of a multi-rank run: the fp32 table lives in the owners' shards until state_dict() gathers it
+            sd = tr.state_dict()
+            full = sd["geometry.encoding_with_network.params"].float()
+            img = model.geometry.encoding_with_network.half_params(model.geometry.encoding_with_network.params)
+            assert torch.equal(full.half(), img), "gathered fp32 master != the fp16 image the kernels read"
         both = [None] * world
         dist.all_gather_object(both, {"digest": mine, "counts": counts})
         if rank == 0:
@@ -64,7 +75,7 @@ def main():
             assert a.keys() == b.keys()
             worst = max(abs(a[k][0] - b[k][0]) + abs(a[k][1] - b[k][1]) for k in a)
             moved = sum(1 for k in mine if mine[k] != first[k])
-            report[name] = {"tensors": len(a), "replica_mismatch": worst, "tensors_moved": moved,
+            report[name] = {"tensors": len(a), "replica_mismatch": worst, "tensors_moved": moved, "groups": groups,
                             "samples_rank0": both[0]["counts"], "samples_rank1": both[1]["counts"],
                             "finite": all(v[1] == v[1] and abs(v[1]) < 1e30 for v in a.values())}
         del tr, model, data
