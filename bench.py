@@ -261,6 +261,63 @@ def other_workloads(dev, rank=0, world=1, sync=None, n_steps=60):
     return out
 
 
+def boundary_path(dev, warmup=300, steps=200):
+    """The same training step driven THROUGH THE DROP-IN BOUNDARY the way the reference's system drives its model
+    (systems/nerf.py:33-99, systems/base.py:54-57): torch ray sampling -> model.update_step -> out = model(rays) ->
+    dynamic ray count from out['num_samples'] -> smooth-L1 on the valid rays in torch -> loss.backward() ->
+    torch.optim.AdamW + MultiStepLR.  The model is nsr.models.FusedNeRFModel = what `models.make('nerf', cfg)` builds once the
+    registry is pointed at it: forward and backward are one autograd.Function over the fused C passes.
+    Reported beside the headline (whose trainer also owns loss / optimizer / ray sampling); never part of `value`."""
+    import nsr
+    import nsr.models
+    from nsr.scene import SyntheticBlender
+    torch.manual_seed(42)
+    cfg = nsr.configs.get("nerf-blender")
+    model = nsr.models.FusedNeRFModel(cfg).to(dev).train()
+    data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    try:
+        opt = torch.optim.AdamW(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-15, fused=True)
+        opt_kind = "torch.optim.AdamW(fused=True)"
+    except Exception:  # noqa: BLE001
+        opt = torch.optim.AdamW(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+        opt_kind = "torch.optim.AdamW"
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10000, 15000, 18000], gamma=0.33)
+    train_num_rays = cfg["train_num_rays"]
+    target = cfg["train_num_rays"] * cfg["num_samples_per_ray"]
+    n_samples = n_rays = 0
+    t0 = None
+    for step in range(warmup + steps):
+        if step == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        rays, rgb, fg, bg = data.sample_rays(train_num_rays, gen, cfg["background_color"])  # preprocess_data
+        model.background_color = bg
+        model.update_step(0, step)                                                           # on_train_batch_start
+        out = model(rays)                                                                    # training_step ...
+        n = int(out["num_samples"].sum().item())
+        if cfg["dynamic_ray_sampling"] and n > 0:
+            t = int(train_num_rays * (target / n))
+            train_num_rays = min(int(train_num_rays * 0.9 + t * 0.1), cfg["max_train_num_rays"])
+        valid = out["rays_valid"][..., 0]
+        loss = torch.nn.functional.smooth_l1_loss(out["comp_rgb"][valid], rgb[valid])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        sched.step()
+        if step >= warmup:
+            n_samples += n
+            n_rays += rays.shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"samples_per_sec": n_samples / dt, "ms_per_step": 1e3 * dt / steps, "train_rays_per_sec": n_rays / dt,
+            "kept_samples_per_step": n_samples / steps, "rays_per_step": n_rays / steps, "final_loss": float(loss),
+            "warmup": warmup, "steps": steps, "optimizer": opt_kind, "model": "nsr.models.FusedNeRFModel",
+            "what": "reference-style step through the model interface: torch ray sampling, model.update_step, model(rays), "
+                    ".item() on num_samples, torch smooth-L1 on boolean-masked rays, loss.backward(), torch AdamW, MultiStepLR"}
+
+
 def exchange_report(tr, world, n_steps=32):
     """the gradient exchange of 32 further steps, timed with HIP events on the communication stream: the small fp32
     all-reduce, then per table range reduce-scatter (bf16) / AdamW on the shard / all-gather of the fp16 image; plus how
@@ -325,6 +382,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the C3 / C4 / C5 side measurements")
+    ap.add_argument("--no-boundary-path", action="store_true", help="skip the step through nsr.models.FusedNeRFModel")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: march in order instead of on the side stream")
     ap.add_argument("--graphs", action="store_true", help="replay each step from a captured HIP graph (measured slower)")
     ap.add_argument("--sync-steps", action="store_true",
@@ -546,6 +604,11 @@ def main():
         if shared_device:
             res["note"] = (f"{world} ranks SHARE one GPU over gloo (fewer GPUs than ranks on this box): a smoke run of the "
                            "multi-rank path, not a scaling measurement")
+        if world == 1 and not args.no_boundary_path:
+            try:
+                res["boundary_path"] = boundary_path(dev)
+            except Exception as e:  # noqa: BLE001  (a side measurement must not take the headline line down)
+                res["boundary_path"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         res["other_workloads"] = others

@@ -434,6 +434,13 @@ int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, float densi
                            const float *background, const float *weights, const float *trans,
                            const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
                            float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream);
+/* ... and with dL/d weights[n] of the caller's own loss terms on the per-sample weights (grad_weights may be NULL; e.g. the
+ * distortion loss of systems/nerf.py:103-106 when it is formed outside) */
+int nsr_composite_backward_ex(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                              const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
+                              const float *background, const float *weights, const float *trans,
+                              const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
+                              const float *grad_weights, float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream);
 /* composite backward with the gradient of the masked smooth-L1 loss (nsr_smooth_l1_valid_backward) evaluated inside */
 int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
                                      const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
@@ -535,6 +542,28 @@ int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, ui
                        void *stream);
 /* table_adam (may be NULL): apply AdamW to the hash table inside the table backward (NsrTableAdam below) -- grad_table is
  * then neither written nor read; with S == 0 kept samples the caller's optimizer still has to decay the table. */
+
+/* The main pass split AT THE LOSS, for callers that own it: the reference's system computes its loss in torch on the
+ * model's output dict and calls backward() (systems/nerf.py:87-99) -- nsr.models.FusedNeRFModel wraps these two in one
+ * torch.autograd.Function.  _forward = everything of nsr_nerf_main_pass up to the composite (outputs and every saved
+ * activation at the nsr_nerf_main_layout offsets of `workspace`; with prepare_backward != 0 the table-backward items are
+ * binned on the helper stream meanwhile).  _backward = the rest, from the upstream gradients: comp_rgb[n_rays,3]
+ * (required), opacity[n_rays], depth[n_rays], weights[n_kept] (each may be NULL = zero); gradients are ADDED to
+ * grad_density_mlp / grad_color_mlp and OVERWRITE grad_table.  Same n_kept / n_rays / workspace in both calls, nothing else
+ * may use the helper stream's bins in between (a no-grad forward passes prepare_backward = 0). */
+typedef struct NsrRenderGrads {
+    const float *comp_rgb, *opacity, *depth, *weights;
+} NsrRenderGrads;
+int nsr_nerf_render_forward(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                            const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                            const float *t_ends, const float *rays_d, const float *background, const nsr_half *w_density,
+                            const nsr_half *w_color, void *workspace, uint32_t n_kept, uint32_t n_rays,
+                            int prepare_backward, const int32_t *n_kept_dev, const float *x01_marched, void *stream);
+int nsr_nerf_render_backward(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                             const int32_t *packed_marched, const int32_t *packed_kept, const float *rays_d,
+                             const float *background, const NsrRenderGrads *upstream, const nsr_half *w_density,
+                             const nsr_half *w_color, float *grad_density_mlp, float *grad_table, float *grad_color_mlp,
+                             void *workspace, uint32_t n_kept, uint32_t n_rays, const int32_t *n_kept_dev, void *stream);
 
 /* The ray-sharded (multi-GPU) form of the main pass -- the reference gets its gradient exchange from Lightning DDP
  * (launch.py:93-107); here the step itself hands the gradients to the exchange in pieces, as they become final:

@@ -423,7 +423,8 @@ k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float 
                      const float *__restrict__ g_comp, const float *__restrict__ g_opacity,
                      const float *__restrict__ g_depth, float *__restrict__ d_rgb, float *__restrict__ d_logit,
                      uint32_t n_rays, const float *__restrict__ l1_comp, const float *__restrict__ l1_opacity,
-                     const float *__restrict__ l1_gt, const float *__restrict__ l1_acc, float l1_scale)
+                     const float *__restrict__ l1_gt, const float *__restrict__ l1_acc, float l1_scale,
+                     const float *__restrict__ g_weights /* dL/d weights[n] of the caller's own loss terms, or NULL */)
 {
     uint32_t r, start, count;
     if (!wave_ray(packed, n_rays, r, start, count)) return;
@@ -461,7 +462,7 @@ k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float 
             const __half *c3 = rgb + (uint64_t)idx * rgb_stride;
             const float w = weights[idx];
             gw = g0 * (__half2float(c3[0]) - b0) + g1 * (__half2float(c3[1]) - b1) + g2 * (__half2float(c3[2]) - b2) +
-                 gop + gdp * ((ts + te) / 2.f);
+                 gop + gdp * ((ts + te) / 2.f) + (g_weights ? g_weights[idx] : 0.f);
             d_rgb[3ull * idx] = w * g0;
             d_rgb[3ull * idx + 1] = w * g1;
             d_rgb[3ull * idx + 2] = w * g2;
@@ -713,8 +714,27 @@ extern "C" int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, 
                 "nsr_composite_backward: NULL pointer");
     hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
                        t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb,
-                       grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays, nullptr, nullptr, nullptr, nullptr, 0.f);
+                       grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays, nullptr, nullptr, nullptr, nullptr, 0.f,
+                       nullptr);
     NSR_CHECK_LAUNCH("nsr_composite_backward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_composite_backward_ex(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                         const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
+                                         const int32_t *packed_info, const float *background, const float *weights,
+                                         const float *trans, const float *grad_comp_rgb, const float *grad_opacity,
+                                         const float *grad_depth, const float *grad_weights, float *grad_rgb,
+                                         float *grad_logit, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && weights && trans && grad_comp_rgb && grad_rgb && grad_logit,
+                "nsr_composite_backward_ex: NULL pointer");
+    hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
+                       t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb,
+                       grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays, nullptr, nullptr, nullptr, nullptr, 0.f,
+                       grad_weights);
+    NSR_CHECK_LAUNCH("nsr_composite_backward_ex");
     return NSR_OK;
 }
 
@@ -731,7 +751,7 @@ extern "C" int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_
                     grad_logit, "nsr_composite_backward_smooth_l1: NULL pointer");
     hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
                        t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, nullptr, nullptr,
-                       nullptr, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, acc2, grad_scale);
+                       nullptr, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, acc2, grad_scale, nullptr);
     NSR_CHECK_LAUNCH("nsr_composite_backward_smooth_l1");
     return NSR_OK;
 }

@@ -487,11 +487,15 @@ k_grid_backward_params(const float *__restrict__ x, const void *__restrict__ dy,
 // as fp32 with plain coalesced 16-B stores.  ~750 workgroups cover L=16,T=2^19,F=2; each grad entry is written exactly once, so the
 // 50 MB gradient needs no memset either (accumulate=0).  dy is read level-major ([L][N][F], 8-B coalesced).
 // ------------------------------------------------------------------------------------------------
+// slice size / workgroup size, measured at the NeRF step's operating point (tools/table_backward_variants.py, 9.6e4 coherent
+// samples, accumulate / accumulate + AdamW): 2^13 entries x 1024 threads (one workgroup per CU) 87 / 122 us, 2^12 x 512
+// 77 / 111 us, 2^11 x 256 72 / 105 us -- several small workgroups per CU overlap one's item phase (LDS atomics, latency
+// bound) with another's write-out / AdamW phase (HBM streaming).  More items in flight per lane (batch 4, 8) changed nothing.
 #ifndef NSR_OWN_BLOCK
-#define NSR_OWN_BLOCK 1024
+#define NSR_OWN_BLOCK 256
 #endif
 #ifndef NSR_OWN_LOG2
-#define NSR_OWN_LOG2 13
+#define NSR_OWN_LOG2 11
 #endif
 #ifndef NSR_OWN_BIN_SPT
 #define NSR_OWN_BIN_SPT 4

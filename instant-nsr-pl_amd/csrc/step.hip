@@ -215,7 +215,9 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                      const nsr_half *w_density, const nsr_half *w_color, float *grad_density_mlp,
                      float *grad_table, float *grad_color_mlp, void *workspace, uint32_t n_kept,
                      uint32_t n_rays, int compute_grads, const int32_t *n_kept_dev,
-                     const float *x01_marched, const NsrTableAdam *table_adam, const NsrTableExchange *xchg, void *stream)
+                     const float *x01_marched, const NsrTableAdam *table_adam, const NsrTableExchange *xchg, void *stream,
+                     int phases = 3 /* 1: forward (+ item binning when compute_grads), 2: backward, 3: both */,
+                     const NsrRenderGrads *up = nullptr /* upstream gradients; NULL: the masked smooth-L1 loss on gt_rgb */)
 {
     NSR_REQUIRE(d && prune_workspace && workspace && packed_marched && packed_kept, "nsr_nerf_main_pass: NULL pointer");
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
@@ -254,6 +256,8 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         rb[na] = 128;
     }
     NSR_REQUIRE(F * 2 % 4 == 0, "nsr_nerf_main_pass: n_features_per_level must be even");
+    const bool overlap_bins = compute_grads && S > 0 && g_helper.init();
+    if (phases & 1) {
     if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
         if (F == 2 && nh1 <= 2)  // the step's usual shape: one lane per kept sample, all its rows in one round trip
             NSR_TRY(nsr_nerf_copy_kept_rows(packed_marched, packed_kept, t_starts, t_ends, x01m,
@@ -267,7 +271,6 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                 (const nsr_half *)(pw + P.out1), 16, tex_in, n_rays, stream));
     }
     // fork: bin the table-backward items on the helper stream as soon as the kept positions exist
-    const bool overlap_bins = compute_grads && S > 0 && g_helper.init();
     if (overlap_bins) {
         NSR_REQUIRE(hipEventRecord(g_helper.fork, st) == hipSuccess &&
                         hipStreamWaitEvent(g_helper.stream, g_helper.fork, 0) == hipSuccess,
@@ -287,7 +290,11 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     }
     NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                   comp_rgb, opacity, depth, n_rays, stream));
-    NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
+    if (gt_rgb)
+        NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
+    }  // phases & 1
+    if (!(phases & 2)) return NSR_OK;
+    NSR_REQUIRE(!compute_grads || up || gt_rgb, "nsr_nerf_main_pass: no loss (gt_rgb) and no upstream gradients");
     NSR_REQUIRE(!(table_adam && compute_grads && S == 0), "nsr_nerf_main_pass: the fused table update needs a non-empty "
                 "sample buffer (the table still decays when nothing was kept)");
     if (xchg) {
@@ -317,9 +324,13 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // dgrad and the table backward -- only dx continues down the main chain
     static const bool wgrad_inline = getenv("NSR_WGRAD_INLINE") != nullptr;  // diagnostic A/B switch
     void *wg = (overlap_bins && !wgrad_inline) ? (void *)g_helper.stream : nullptr;
-    NSR_TRY(nsr_composite_backward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights,
-                                             trans, comp_rgb, opacity, gt_rgb, acc, d->loss_scale, d_rgb, d_logit, n_rays,
-                                             stream));
+    if (up)  // the caller's loss: arbitrary dL/d comp_rgb, dL/d opacity, dL/d depth (+ dL/d weights: distortion loss)
+        NSR_TRY(nsr_composite_backward_ex(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
+                                          up->comp_rgb, up->opacity, up->depth, up->weights, d_rgb, d_logit, n_rays, stream));
+    else
+        NSR_TRY(nsr_composite_backward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background,
+                                                 weights, trans, comp_rgb, opacity, gt_rgb, acc, d->loss_scale, d_rgb,
+                                                 d_logit, n_rays, stream));
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
         NSR_TRY(nsr_mlp_backward_split(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
@@ -384,6 +395,34 @@ extern "C" int nsr_nerf_main_pass(const NsrNerfStepDesc *d, const void *prune_wo
     return main_pass(d, prune_workspace, n_marched, packed_marched, packed_kept, t_starts, t_ends, rays_d, background,
                      gt_rgb, w_density, w_color, grad_density_mlp, grad_table, grad_color_mlp, workspace, n_kept, n_rays,
                      compute_grads, n_kept_dev, x01_marched, table_adam, nullptr, stream);
+}
+
+// ---- the same pass split at the loss, for callers that own it (the reference's systems/nerf.py:87-99 computes the loss in
+// torch on the model's output dict and calls backward()): forward keeps every activation in `workspace` and -- when
+// prepare_backward -- bins the table-backward items on the helper stream; backward takes the upstream gradients.
+extern "C" int nsr_nerf_render_forward(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                                       const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                                       const float *t_ends, const float *rays_d, const float *background,
+                                       const nsr_half *w_density, const nsr_half *w_color, void *workspace,
+                                       uint32_t n_kept, uint32_t n_rays, int prepare_backward, const int32_t *n_kept_dev,
+                                       const float *x01_marched, void *stream)
+{
+    return main_pass(d, prune_workspace, n_marched, packed_marched, packed_kept, t_starts, t_ends, rays_d, background,
+                     nullptr, w_density, w_color, nullptr, nullptr, nullptr, workspace, n_kept, n_rays, prepare_backward,
+                     n_kept_dev, x01_marched, nullptr, nullptr, stream, 1, nullptr);
+}
+
+extern "C" int nsr_nerf_render_backward(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,
+                                        const int32_t *packed_marched, const int32_t *packed_kept, const float *rays_d,
+                                        const float *background, const NsrRenderGrads *upstream, const nsr_half *w_density,
+                                        const nsr_half *w_color, float *grad_density_mlp, float *grad_table,
+                                        float *grad_color_mlp, void *workspace, uint32_t n_kept, uint32_t n_rays,
+                                        const int32_t *n_kept_dev, void *stream)
+{
+    NSR_REQUIRE(upstream && upstream->comp_rgb, "nsr_nerf_render_backward: upstream gradient of comp_rgb is NULL");
+    return main_pass(d, prune_workspace, n_marched, packed_marched, packed_kept, nullptr, nullptr, rays_d, background,
+                     nullptr, w_density, w_color, grad_density_mlp, grad_table, grad_color_mlp, workspace, n_kept, n_rays, 1,
+                     n_kept_dev, nullptr, nullptr, nullptr, stream, 2, upstream);
 }
 
 extern "C" int nsr_nerf_main_pass_exchange(const NsrNerfStepDesc *d, const void *prune_workspace, uint32_t n_marched,

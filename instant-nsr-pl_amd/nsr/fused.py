@@ -191,6 +191,83 @@ class FusedNeRFStep:
                     "t_starts": view(L.t_starts, S, F32, (S, 1)), "t_ends": view(L.t_ends, S, F32, (S, 1)),
                     "loss_acc": view(L.loss_acc, 2, F32, (2,)), "_workspace": ws}
 
+    # ---- the step split at the loss (nsr.models.FusedNeRFModel: the reference's system owns loss and backward()) ---------
+    def render_forward(self, rays, background, prepare_backward):
+        """march + sigma pass + main forward of ``NeRFModel.forward_`` (models/nerf.py:61-127) as three C calls; returns the
+        reference's output tensors plus the state ``render_backward`` needs (everything lives in two workspaces)."""
+        m, ewn, tex, d = self.model, self.ewn, self.tex, self.desc
+        dev = rays.device
+        n_rays = rays.shape[0]
+        with torch.no_grad(), torch.cuda.device(dev):
+            rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+            handle = self.march_begin(rays_o, rays_d)
+            rays_o, rays_d = handle.args[0], handle.args[1]
+            packed, ri, t0, t1 = _ops.ray_march_finish(handle)  # host sync 1: the marched count
+            M = ri.shape[0]
+            s = stream_ptr()
+            half = ewn.half_params(ewn.params)
+            table, w1, w2 = half[ewn.n_network_params:], half[:ewn.n_network_params], tex.half_params(tex.params)
+            check(lib.nsr_nerf_prune_layout(_byref(d), M, _byref(self._PL)), "nsr_nerf_prune_layout")
+            pws = torch.empty(max(int(self._PL.total_bytes), 256), dtype=torch.uint8, device=dev)
+            meta = torch.empty(3 * n_rays + 1, dtype=torch.int32, device=dev)  # kept | packed_kept | total
+            kept, packed2, total = meta[:n_rays], meta[n_rays:3 * n_rays].view(n_rays, 2), meta[3 * n_rays:]
+            if M > 0:
+                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), ptr(packed),
+                                              ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2), ptr(total), M, n_rays,
+                                              None, 0, None, None, s), "nsr_nerf_prune_pass")
+                S = _ops.read_count_when_ready(total)  # host sync 2: the kept count
+            else:
+                meta.zero_()
+                S = 0
+            check(lib.nsr_nerf_main_layout(_byref(d), S, n_rays, _byref(self._ML)), "nsr_nerf_main_layout")
+            import copy
+            L = copy.copy(self._ML)
+            ws = torch.empty(int(L.total_bytes), dtype=torch.uint8, device=dev)
+            bg = background.to(F32).contiguous()
+            check(lib.nsr_nerf_render_forward(_byref(d), ptr(pws), M, ptr(packed), ptr(packed2), ptr(t0), ptr(t1), ptr(rays_d),
+                                              ptr(bg), ptr(w1), ptr(w2), ptr(ws), S, n_rays, int(bool(prepare_backward)), None,
+                                              None, s), "nsr_nerf_render_forward")
+
+        def view(off, n, dtype, shape):
+            return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
+
+        out = {"comp_rgb": view(L.comp_rgb, n_rays * 3, F32, (n_rays, 3)), "opacity": view(L.opacity, n_rays, F32, (n_rays, 1)),
+               "depth": view(L.depth, n_rays, F32, (n_rays, 1)), "weights": view(L.weights, S, F32, (S,)),
+               "ray_indices": view(L.ray_indices, S, torch.int64, (S,)), "t_starts": view(L.t_starts, S, F32, (S,)),
+               "t_ends": view(L.t_ends, S, F32, (S,)), "num_samples": S, "num_marched": M}
+        state = dict(pws=pws, ws=ws, packed=packed, packed2=packed2, rays_d=rays_d, bg=bg, M=M, S=S, n_rays=n_rays,
+                     w1=w1, w2=w2, keep=(meta, half))
+        return out, state
+
+    def render_backward(self, state, g_comp_rgb, g_opacity=None, g_depth=None, g_weights=None, grad_scale=1.0):
+        """gradients of the flat parameters (geometry.encoding_with_network.params [MLP | table], texture.network.params) from
+        the upstream gradients of comp_rgb [R,3], opacity [R,1], depth [R,1], weights [S]; fresh fp32 tensors"""
+        import nsr_hip
+        ewn, tex, d = self.ewn, self.tex, self.desc
+        dev = state["ws"].device
+        g1 = torch.empty_like(ewn.params)
+        g1[:ewn.n_network_params].zero_()  # the MLP slices are accumulated into, the table slice is overwritten
+        g2 = torch.zeros_like(tex.params)
+        if state["S"] == 0:
+            g1.zero_()
+            return g1, g2
+        up = nsr_hip.NsrRenderGrads()
+        keep = []
+        for name, g in (("comp_rgb", g_comp_rgb), ("opacity", g_opacity), ("depth", g_depth), ("weights", g_weights)):
+            if g is not None:
+                g = g.to(F32).contiguous()
+                keep.append(g)
+                setattr(up, name, g.data_ptr())
+        old = d.grad_scale
+        with torch.no_grad(), torch.cuda.device(dev):
+            check(lib.nsr_nerf_render_backward(_byref(d), ptr(state["pws"]), state["M"], ptr(state["packed"]),
+                                               ptr(state["packed2"]), ptr(state["rays_d"]), ptr(state["bg"]), _byref(up),
+                                               ptr(state["w1"]), ptr(state["w2"]), ptr(ewn.mlp_slice(g1)), ptr(ewn.grid_slice(g1)),
+                                               ptr(g2), ptr(state["ws"]), state["S"], state["n_rays"], None, stream_ptr()),
+                  "nsr_nerf_render_backward")
+        d.grad_scale = old
+        return g1, g2
+
     def _forward_backward_python(self, rays, gt_rgb, background, compute_grads=True, loss_scale=1.0, march_handle=None,
                                  after_prune=None, after_enqueue=None, before_sync=None):
         """-> dict(loss_acc, comp_rgb, opacity, depth, num_samples, weights, ray_indices, t_starts, t_ends).  Gradients

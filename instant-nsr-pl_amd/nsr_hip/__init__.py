@@ -59,6 +59,12 @@ class NsrTableExchange(ctypes.Structure):
                 ("event_group", ctypes.c_void_p * 4), ("event_small", ctypes.c_void_p)]
 
 
+class NsrRenderGrads(ctypes.Structure):
+    """include/nsr_hip.h: upstream gradients of nsr_nerf_render_backward (NULL = zero)"""
+    _fields_ = [("comp_rgb", ctypes.c_void_p), ("opacity", ctypes.c_void_p), ("depth", ctypes.c_void_p),
+                ("weights", ctypes.c_void_p)]
+
+
 class NsrVanillaLayer(ctypes.Structure):
     """include/nsr_hip.h: the nn.Linear tensors of one VanillaMLP layer (weight_g NULL: plain weight)"""
     _fields_ = [("weight_v", ctypes.c_void_p), ("weight_g", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -176,6 +182,9 @@ SIGNATURES = {
     "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
     "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P, _P],
+    "nsr_composite_backward_ex": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_nerf_render_forward": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P],
+    "nsr_nerf_render_backward": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P],
     "nsr_nerf_main_pass_exchange": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_range": [_P, _P, _P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_taps_workspace_floats": [_GD, _U],
