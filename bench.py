@@ -318,6 +318,22 @@ def boundary_path(dev, warmup=300, steps=200):
                     ".item() on num_samples, torch smooth-L1 on boolean-masked rays, loss.backward(), torch AdamW, MultiStepLR"}
 
 
+def side_measurement(name, timeout=600):
+    """run bench.<name>(cuda:0) in a child process and return its JSON: a side measurement must not be able to take the
+    headline line down (a GPU fault kills the process it happens in)"""
+    code = (f"import json, sys, torch; sys.argv = ['bench.py']; import bench; "
+            f"print('SIDE_JSON ' + json.dumps(bench.{name}(torch.device('cuda', 0))))")
+    try:
+        p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                           env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("SIDE_JSON ")]
+        if p.returncode != 0 or not line:
+            return {"error": f"rc={p.returncode}: " + (p.stderr or p.stdout)[-300:]}
+        return json.loads(line[-1][len("SIDE_JSON "):])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 def exchange_report(tr, world, n_steps=32):
     """the gradient exchange of 32 further steps, timed with HIP events on the communication stream: the small fp32
     all-reduce, then per table range reduce-scatter (bf16) / AdamW on the shard / all-gather of the fp16 image; plus how
@@ -605,10 +621,7 @@ def main():
             res["note"] = (f"{world} ranks SHARE one GPU over gloo (fewer GPUs than ranks on this box): a smoke run of the "
                            "multi-rank path, not a scaling measurement")
         if world == 1 and not args.no_boundary_path:
-            try:
-                res["boundary_path"] = boundary_path(dev)
-            except Exception as e:  # noqa: BLE001  (a side measurement must not take the headline line down)
-                res["boundary_path"] = {"error": repr(e)[:300]}
+            res["boundary_path"] = side_measurement("boundary_path")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         res["other_workloads"] = others

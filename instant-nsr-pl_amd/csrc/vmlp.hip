@@ -341,27 +341,37 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
         for (int kk = 0; kk < KS; ++kk) { xin[kk] = xnext[kk]; pb[kk] = SECOND ? pnext[kk] : 0.f; }
         f32x4 dob = donext;
         load_inputs(tile + gridDim.x, xnext, pnext, donext);
-        f32x4 z0[4], a0[4], s0[4], z1[4], a1[4];  // s0 = act'(z0), evaluated once
+        // ReLU: act'(z) = (a > 0), so neither the pre-activations nor a separate derivative array stay live (the two-hidden-
+        // layer colour heads otherwise spill); softplus keeps z0 (curvature term) and s0 = sigmoid(100 z0), evaluated once
+        f32x4 z0[ACT == 1 ? 4 : 1], a0[4], s0[ACT == 1 ? 4 : 1], a1[4], s1[(NH == 2 && ACT == 1) ? 4 : 1];
+#define NSR_S0(mb, r) (ACT == 1 ? s0[ACT == 1 ? (mb) : 0][r] : (a0[mb][r] > 0.f ? 1.f : 0.f))
+#define NSR_S1(mb, r) (ACT == 1 ? s1[(NH == 2 && ACT == 1) ? (mb) : 0][r] : (a1[mb][r] > 0.f ? 1.f : 0.f))
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            z0[mb] = b0f[mb];
+            f32x4 z = b0f[mb];
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) z0[mb] = mfma4(wf0[mb][kk], xin[kk], z0[mb]);
+            for (int kk = 0; kk < KS; ++kk) z = mfma4(wf0[mb][kk], xin[kk], z);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a0[mb][r] = act_fwd<ACT>(z0[mb][r]); s0[mb][r] = act_bwd<ACT>(z0[mb][r]); }
+            for (int r = 0; r < 4; ++r) {
+                a0[mb][r] = act_fwd<ACT>(z[r]);
+                if constexpr (ACT == 1) { z0[mb][r] = z[r]; s0[mb][r] = act_bwd<ACT>(z[r]); }
+            }
         }
         if constexpr (NH == 2) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                z1[mb] = b1f[mb];
+                f32x4 z = b1f[mb];
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) {
                     const f32x4 w = load_chain(W1t, mb, ib, c, g);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) z1[mb] = mfma4(w[r], a0[ib][r], z1[mb]);
+                    for (int r = 0; r < 4; ++r) z = mfma4(w[r], a0[ib][r], z);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a1[mb][r] = act_fwd<ACT>(z1[mb][r]);
+                for (int r = 0; r < 4; ++r) {
+                    a1[mb][r] = act_fwd<ACT>(z[r]);
+                    if constexpr (ACT == 1) s1[mb][r] = act_bwd<ACT>(z[r]);
+                }
             }
         }
         // ---- output gradient in B layout: lane (g,c) holds d_out[sample c][4kk + g] -------------------------------
@@ -378,7 +388,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    dz_last[fb][r] = d_tap * uf[fb][r] * ((NH == 2) ? act_bwd<ACT>(z1[fb][r]) : s0[fb][r]);
+                    dz_last[fb][r] = d_tap * uf[fb][r] * ((NH == 2) ? NSR_S1(fb, r) : NSR_S0(fb, r));
                     du[fb][r] += d_tap * ((NH == 2) ? a1[fb][r] : a0[fb][r]);
                 }
         } else {
@@ -388,7 +398,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = mfma4(Wlt[(4 * kk + g) * W + fb * 16 + c], dob[kk], acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dz_last[fb][r] = acc[r] * ((NH == 2) ? act_bwd<ACT>(z1[fb][r]) : s0[fb][r]);
+            for (int r = 0; r < 4; ++r) dz_last[fb][r] = acc[r] * ((NH == 2) ? NSR_S1(fb, r) : NSR_S0(fb, r));
         }
         // ---- last-layer weight gradient: dWl[o][j] += sum_s dOut[o][s] a_last[j][s] ------------------------------
         lds_wave_sync();  // previous tile's readers are done
@@ -438,7 +448,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                     for (int r = 0; r < 4; ++r)
                         acc = mfma4(W1t[(nb * 16 + 4 * g + r) * W + fb * 16 + c], dz_last[nb][r], acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz0[fb][r] = acc[r] * s0[fb][r];
+                for (int r = 0; r < 4; ++r) dz0[fb][r] = acc[r] * NSR_S0(fb, r);
             }
         } else {
 #pragma unroll
@@ -454,11 +464,11 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                 for (int kk = 0; kk < KS; ++kk) dq = mfma4(wf0[mb][kk], pb[kk], dq);  // (W0 P)^T
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float sg = s0[mb][r];
+                    const float sg = NSR_S0(mb, r);
                     q[mb][r] = sg * uf[mb][r];
                     du[mb][r] += sg * dq[r];
                     // d/dz of act'(z): softplus -> 100 s (1 - s) (0 on torch's linear branch); relu -> 0
-                    const float curv = (ACT == 1 && 100.f * z0[mb][r] <= 20.f) ? 100.f * sg * (1.f - sg) : 0.f;
+                    const float curv = (ACT == 1 && 100.f * z0[ACT == 1 ? mb : 0][r] <= 20.f) ? 100.f * sg * (1.f - sg) : 0.f;
                     dz0[mb][r] += curv * uf[mb][r] * dq[r];
                 }
             }
@@ -531,6 +541,8 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             }
         }
     }
+#undef NSR_S0
+#undef NSR_S1
     // ---- this wave's partial gradient, in blob layout ---------------------------------------------------------------
     float *P = partials + (uint64_t)blockIdx.x * blob_floats;
     float *pW0 = P, *pb0 = pW0 + W * IN_PAD;

@@ -44,10 +44,11 @@ class _RenderNeRF(torch.autograd.Function):
     """comp_rgb, opacity, depth, weights = render(rays, background; geometry params, texture params)"""
 
     @staticmethod
-    def forward(ctx, model, rays, background, p_geometry, p_texture):
+    def forward(ctx, model, need_grad, rays, background, p_geometry, p_texture):
+        # (need_grad is decided by the caller: grad mode is always off inside Function.forward)
         step = model._runner()
-        need_grad = torch.is_grad_enabled() and (p_geometry.requires_grad or p_texture.requires_grad)
         out, state = step.render_forward(rays.detach(), background.detach(), prepare_backward=need_grad)
+        ctx.prepared = bool(need_grad)
         ctx.step, ctx.state = step, state
         model._last = out  # the non-differentiable outputs (ray_indices, t_starts, t_ends, counts) for forward_()
         ctx.mark_non_differentiable(out["ray_indices"])
@@ -55,11 +56,13 @@ class _RenderNeRF(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_comp, g_opacity, g_depth, g_weights, _g_ri):
+        if not ctx.prepared:
+            raise RuntimeError("FusedNeRFModel: backward through a forward that ran without gradients enabled")
         if g_comp is None:  # the loss did not touch the colours: their upstream gradient is zero
             g_comp = torch.zeros((ctx.state["n_rays"], 3), device=ctx.state["ws"].device)
         g1, g2 = ctx.step.render_backward(ctx.state, g_comp, g_opacity, g_depth, g_weights)
         ctx.state = None  # the workspaces go back to the allocator
-        return None, None, None, g1, g2
+        return None, None, None, None, g1, g2
 
 
 class FusedNeRFModel(HotPathState):
@@ -101,7 +104,8 @@ class FusedNeRFModel(HotPathState):
     def forward_(self, rays):
         bg = self.background_color if self.background_color is not None else torch.ones(3, device=rays.device)
         ewn, tex = self.geometry.encoding_with_network, self.texture.network
-        comp_rgb, opacity, depth, weights, ray_indices = _RenderNeRF.apply(self, rays, bg, ewn.params, tex.params)
+        need_grad = torch.is_grad_enabled() and (ewn.params.requires_grad or tex.params.requires_grad)
+        comp_rgb, opacity, depth, weights, ray_indices = _RenderNeRF.apply(self, need_grad, rays, bg, ewn.params, tex.params)
         last = self._last
         out = {"comp_rgb": comp_rgb, "opacity": opacity, "depth": depth, "rays_valid": opacity > 0,
                "num_samples": torch.as_tensor([last["num_samples"]], dtype=torch.int32)}

@@ -21,6 +21,13 @@ def seeded_uniform(n, seed, lo=0.0, hi=1.0):
                             .astype(np.float32))
 
 
+def rel_l2(got, want):
+    """|got - want| / |want| in float64: the gradient-parity measure of the -m gpu tests (a cosine > 0.995 would still admit
+    ~10 % relative error; rel-L2 <= 2e-2 does not)"""
+    a, b = got.detach().reshape(-1).double().cpu(), want.detach().reshape(-1).double().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
 def _signs(n, k, device):
     i = torch.arange(n, dtype=torch.int64, device=device)
     h = (i * 2654435761 + (k + 1) * 40503) & 0xFFFFFFFF

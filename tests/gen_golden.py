@@ -41,6 +41,17 @@ def _rays(n, seed):
     return torch.cat([o, d], -1)
 
 
+def _valid_rays(m, rays, n_keep, key="rays_valid_full"):
+    """the first n_keep of `rays` that the reference's own model renders as VALID (opacity > 0): rays are independent, so
+    the selection stays valid when rendered alone -- the parity tests then compare loss and EVERY gradient
+    unconditionally (the system's losses are taken over the valid rays, systems/neus.py:96-104)"""
+    with torch.no_grad():
+        out = m(rays)
+    idx = torch.nonzero(out[key][..., 0]).flatten()[:n_keep]
+    assert idx.numel() == n_keep, (idx.numel(), n_keep)
+    return rays[idx].clone()
+
+
 def _sphere_grid(res, radius, r_occ):
     ii = torch.stack(torch.meshgrid(*[torch.arange(res)] * 3, indexing="ij"), -1).float()
     c = (ii + 0.5) / res * 2 * radius - radius
@@ -153,8 +164,9 @@ def gen_neus(models):
     m.occupancy_grid._binary = _sphere_grid(128, 1.5, 0.8)
     m.background_color = torch.tensor([1.0, 1.0, 1.0])
     m.randomized = False
-    rays = _rays(24, 11)
+    rays = _valid_rays(m, _rays(48, 11), 24)
     out = m(rays)
+    assert bool(out["rays_valid_full"].all())
     eik = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()  # systems/neus.py:106
     loss = torch.nn.functional.mse_loss(out["comp_rgb_full"], torch.full_like(out["comp_rgb_full"], 0.4)) * 10 + eik * 0.1
     loss.backward()
@@ -185,9 +197,11 @@ def gen_neus_bg(models):
     m.occupancy_grid_bg._binary = ((ii.sum(-1) % 3) != 0)  # a deterministic 2/3-full pattern of the contracted space
     m.background_color = torch.tensor([1.0, 1.0, 1.0])
     m.randomized = False
-    rays = _rays(16, 12)
+    rays = _rays(32, 12)
     rays[:, :3] *= 0.6  # cameras at radius 2.4 around the radius-1 foreground box
+    rays = _valid_rays(m, rays, 16)
     out = m(rays)
+    assert bool(out["rays_valid_full"].all())
     eik = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()
     loss = torch.nn.functional.mse_loss(out["comp_rgb_full"], torch.full_like(out["comp_rgb_full"], 0.4)) * 10 + eik * 0.1
     loss.backward()
@@ -258,6 +272,77 @@ def gen_neuralangelo(models):
     np.savez_compressed(os.path.join(OUT, "neuralangelo_forward.npz"), **_np(fx))
 
 
+from gen_golden_constants import FULL_LAMBDAS  # noqa: E402
+
+
+def _gen_full(models, yaml, overrides, out_name, seed, with_bg):
+    """configs/neus-blender.yaml (C3) / configs/neus-dtu.yaml (C4) at FULL size (L=16, T=2^19): analytic normals with the
+    double backward, the system's loss terms on the valid rays (systems/neus.py:96-130 via fixture_utils.neus_system_loss);
+    tables re-generated from seeds on the test side, their 14 M-entry gradients pinned by summaries (the scheme of
+    gen_neuralangelo)"""
+    cfg = refshim.load_config(yaml, overrides)
+    cfg.model.num_samples_per_ray = 256
+    torch.manual_seed(seed)
+    m = models.make("neus", cfg.model)
+    m.train()
+    m.update_step(0, 5000)  # cos_anneal_ratio = 0.25; no occupancy refresh (5000 % 16 != 0)
+    enc = m.geometry.encoding.encoding
+    seeds = {"geometry.encoding.encoding.params": (seed * 100 + 1, 0.05)}
+    with torch.no_grad():
+        enc.params.copy_(fu.seeded_normal(enc.params.numel(), seed * 100 + 1, std=0.05))
+        m.geometry.network.layers[0].weight_v[:, 3:].copy_(fu.seeded_normal(64 * 32, seed * 100 + 2, std=0.05).view(64, 32))
+        if with_bg:
+            eb = m.geometry_bg.encoding_with_network.encoding.encoding
+            eb.params.copy_(fu.seeded_normal(eb.params.numel(), seed * 100 + 3, std=0.3))
+            seeds["geometry_bg.encoding_with_network.encoding.encoding.params"] = (seed * 100 + 3, 0.3)
+    r = float(cfg.model.radius)
+    m.occupancy_grid._binary = _sphere_grid(128, r, 0.6 * r / 1.0 if with_bg else 0.8)
+    if with_bg:
+        ii = torch.stack(torch.meshgrid(*[torch.arange(256)] * 3, indexing="ij"), -1)
+        m.occupancy_grid_bg._binary = ((ii.sum(-1) % 3) != 0)
+    m.background_color = torch.tensor([1.0, 1.0, 1.0])
+    m.randomized = False
+    rays = _rays(40, seed + 20)
+    if with_bg:
+        rays[:, :3] *= 0.6
+    rays = _valid_rays(m, rays, 20)
+    g = torch.Generator().manual_seed(seed + 30)
+    rgb = torch.rand(20, 3, generator=g)
+    fg_mask = (torch.rand(20, generator=g) > 0.3).float()
+    out = m(rays)
+    assert bool(out["rays_valid_full"].all())
+    loss, terms = fu.neus_system_loss(out, rgb, fg_mask, FULL_LAMBDAS)
+    loss.backward()
+    desc = enc.desc
+    offsets = [int(o) * desc.F for o in desc.offset]
+    fx = {"rays": rays, "rgb": rgb, "fg_mask": fg_mask, "background": m.background_color,
+          "binary_packed": np.packbits(m.occupancy_grid._binary.numpy()), "level_offsets": np.asarray(offsets),
+          "cos_anneal_ratio": m.cos_anneal_ratio, "loss": loss}
+    if with_bg:
+        fx["binary_bg_packed"] = np.packbits(m.occupancy_grid_bg._binary.numpy())
+    for k, (sd, std) in seeds.items():
+        fx.update({"seed/" + k: sd, "std/" + k: std, "numel/" + k: dict(m.named_parameters())[k].numel()})
+    fx.update({"param/" + k: v for k, v in m.state_dict().items() if "occupancy" not in k and v.numel() < 100000})
+    fx.update({"term/" + k: v for k, v in terms.items()})
+    fx.update({"out/" + k: v for k, v in out.items()})
+    for k, v in m.named_parameters():
+        if v.grad is None or v.numel() == 0:
+            continue
+        if v.numel() < 100000:
+            fx["grad/" + k] = v.grad.clone()
+        else:
+            fx.update(fu.pack_summary("gradsum/" + k, fu.grad_summary(v.grad, offsets)))
+    np.savez_compressed(os.path.join(OUT, out_name), **_np(fx))
+
+
+def gen_neus_full(models):
+    _gen_full(models, "neus-blender.yaml", ["dataset.scene=lego"], "neus_full_forward.npz", 8, False)
+
+
+def gen_neus_bg_full(models):
+    _gen_full(models, "neus-dtu.yaml", ["dataset.root_dir=unused"], "neus_bg_full_forward.npz", 9, True)
+
+
 def gen_boundary_traces():
     """tests/trace_tools.py: the reference's models from the REAL YAMLs (full-size C2 / C3) on recording wrappers of the
     oracle packages -> tests/golden/trace_{nerf,neus}.npz"""
@@ -315,6 +400,8 @@ def main():
     gen_neus(models)
     gen_neus_bg(models)
     gen_neuralangelo(models)
+    gen_neus_full(models)
+    gen_neus_bg_full(models)
     refshim.uninstall()
     gen_boundary_traces()
     for f in sorted(os.listdir(OUT)):
@@ -322,4 +409,11 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # only the named generators, e.g.  python tests/gen_golden.py gen_neus gen_neus_full
+        os.makedirs(OUT, exist_ok=True)
+        models_ = refshim.install(tcnn_ref, nerfacc_ref)
+        for name in sys.argv[1:]:
+            globals()[name](models_)
+        refshim.uninstall()
+    else:
+        main()

@@ -49,14 +49,17 @@ def test_fused_neus_analytic_matches_reference_fixture():
             (k, float((res[k].cpu().view(fx["out/" + k].shape) - fx["out/" + k]).abs().max()))
     terms = step.loss_terms(res["loss_acc"])
     assert abs(float(terms["eikonal"]) - float(fx["loss_eikonal"])) < 2e-3 * max(1.0, float(fx["loss_eikonal"]))
-    if bool(res["rays_valid_full"].all()):
-        assert abs(float(step.loss_value(res["loss_acc"])) - float(fx["loss"])) < 3e-3 * max(1.0, float(fx["loss"]))
-        params = dict(m.named_parameters())
-        for k in ("geometry.encoding.encoding.params", "texture.network.params", "geometry.network.layers.0.weight_v",
-                  "geometry.network.layers.2.weight_v", "geometry.network.layers.0.weight_g", "geometry.network.layers.0.bias"):
-            assert _cos(params[k].grad.cpu(), fx["grad/" + k]) > 0.995, (k, _cos(params[k].grad.cpu(), fx["grad/" + k]))
-        gv, wv = float(params["variance.variance"].grad), float(fx["grad/variance.variance"])
-        assert abs(gv - wv) < 2e-2 * abs(wv) + 1e-5, (gv, wv)
+    # every ray of the fixture is valid (tests/gen_golden.py:_valid_rays), so the fixture's mean over all rays IS the system's
+    # masked mean and loss + every gradient are compared unconditionally
+    assert bool(fx["out/rays_valid_full"].all()) and bool(res["rays_valid_full"].all())
+    assert abs(float(step.loss_value(res["loss_acc"])) - float(fx["loss"])) < 3e-3 * max(1.0, float(fx["loss"]))
+    params = dict(m.named_parameters())
+    for k in ("geometry.encoding.encoding.params", "texture.network.params", "geometry.network.layers.0.weight_v",
+              "geometry.network.layers.2.weight_v", "geometry.network.layers.0.weight_g", "geometry.network.layers.0.bias",
+              "geometry.network.layers.2.weight_g", "geometry.network.layers.2.bias"):
+        assert fu.rel_l2(params[k].grad.cpu(), fx["grad/" + k]) < 2e-2, (k, fu.rel_l2(params[k].grad.cpu(), fx["grad/" + k]))
+    gv, wv = float(params["variance.variance"].grad), float(fx["grad/variance.variance"])
+    assert abs(gv - wv) < 2e-2 * abs(wv) + 1e-5, (gv, wv)
 
 
 def test_fused_neus_matches_modular_path_on_all_loss_terms():
@@ -108,8 +111,7 @@ def test_fused_neus_matches_modular_path_on_all_loss_terms():
     for k, w in ref.items():
         gk = dict(m.named_parameters())[k].grad
         assert gk is not None, k
-        c = _cos(gk, w)
-        assert c > 0.998, (k, c, float((gk - w).norm() / w.norm()))
+        assert fu.rel_l2(gk, w) < 2e-2, (k, fu.rel_l2(gk, w), _cos(gk, w))
 
 
 @pytest.mark.parametrize("level", [4, 16])
@@ -144,8 +146,8 @@ def test_fused_neuralangelo_matches_reference_fixture(level):
     for k in ("geometry.network.layers.0.weight_v", "geometry.network.layers.0.weight_g", "geometry.network.layers.2.weight_v",
               "geometry.network.layers.0.bias", "texture.network.layers.0.weight", "texture.network.layers.4.weight",
               "texture.network.layers.2.bias"):
-        c = _cos(params[k].grad.cpu(), fx[p + "grad/" + k])
-        assert c > 0.995, (level, k, c)
+        e = fu.rel_l2(params[k].grad.cpu(), fx[p + "grad/" + k])
+        assert e < 2e-2, (level, k, e)
     gv, wv = float(params["variance.variance"].grad), float(fx[p + "grad/variance.variance"])
     assert abs(gv - wv) < 2e-2 * abs(wv) + 1e-5, (gv, wv)
 
