@@ -80,6 +80,17 @@ def render_rays(runner, rays, background=None, chunk=None, move_to_cpu=True):
         model.randomized = was
 
 
+def _require_schedules(state):
+    """a progressive / finite-difference model straight out of ``load_state_dict`` has no current level and no eps yet (they
+    are functions of the global step, restored by the reference's batch-start hooks): refuse to export with a guess"""
+    progressive = getattr(state, "progressive", None) is not None
+    fd = getattr(state, "grad_type", None) == "finite_difference"
+    if (progressive or fd) and not getattr(state, "schedules_restored", True):
+        raise RuntimeError("export from a freshly loaded progressive / finite-difference model: call "
+                           "state.restore_schedules(global_step) (or load_reference_checkpoint(ckpt, global_step=...)) first "
+                           "-- the active level count and the finite-difference eps depend on the training step")
+
+
 @torch.no_grad()
 def forward_level(state, points):
     """models/geometry.py:132-136 (-density) / :212-217 (sdf) on world points [n, 3]"""
@@ -92,6 +103,7 @@ def forward_level(state, points):
                                           want_feature=False)
         return -dens
     from .fused_neus import FusedNeuSStep
+    _require_schedules(state)
     runner = getattr(state, "_level_runner", None)
     if runner is None:
         runner = state._level_runner = FusedNeuSStep(state)
@@ -132,6 +144,7 @@ def vertex_colors(state, v_pos, chunk=2097152):
     CPU.  nerf: ``texture(feature, (0, 0, -1))`` clamped to [0, 1] (models/nerf.py:155-159); neus: ``texture(feature,
     -normal, normal)`` with the normal of the SDF at the vertex (models/neus.py:316-321)."""
     cfg = state.config
+    _require_schedules(state)
     dev = state.scene_aabb.device
     if cfg["name"] == "nerf":
         radius = float(cfg["radius"])

@@ -144,6 +144,18 @@ class FusedNeuSStep:
         sdf_layers = _vanilla_layers(model.geometry.network)
         if len(sdf_layers) != 2:
             raise NotImplementedError("fused NeuS: the SDF network has one hidden layer (every reference config)")
+        # options of the reference's modules that no shipped YAML switches on are REFUSED, not silently ignored: a model
+        # configured that way would train / render something else (models/neus.py:27-44, models/geometry.py:171-174,
+        # models/network_utils.py:133-139)
+        if (cfg.get("variance") or {}).get("modulate", False):
+            raise NotImplementedError("fused NeuS: variance.modulate (the clamp schedule on inv_s, models/neus.py:27-44) is "
+                                      "not implemented -- every reference config sets modulate: false")
+        if not g["mlp_network_config"].get("sphere_init", False):
+            raise NotImplementedError("fused NeuS: the SDF network is the sphere-initialised Softplus(beta=100) MLP "
+                                      "(mlp_network_config.sphere_init: true); the ReLU variant is not compiled")
+        for key in ("sdf_activation", "feature_activation"):
+            if g.get(key) not in (None, "none", "None"):
+                raise NotImplementedError(f"fused NeuS: geometry.{key} is not implemented (no reference config sets it)")
         self.sdf = VanillaBlob(sdf_layers, 3 + self.n_enc, self.n_feat, activation=1)  # softplus(beta=100): sphere_init
         tex = model.texture.network
         self.tex_fused = hasattr(tex, "mlp_desc")

@@ -36,8 +36,10 @@ class _Scalar(nn.Module):
         self.register_parameter(name, nn.Parameter(torch.tensor(float(value))))
 
 
-def _weight_normed_linear(d_in, d_out):
-    return nn.utils.weight_norm(nn.Linear(d_in, d_out, bias=True))
+def _weight_normed_linear(d_in, d_out, weight_norm=True):
+    """models/network_utils.py:131-139: the layer is wrapped in weight_norm only when the config asks for it"""
+    lin = nn.Linear(d_in, d_out, bias=True)
+    return nn.utils.weight_norm(lin) if weight_norm else lin
 
 
 def sphere_init_(linear, first, last, radius, d_in, d_out):
@@ -55,24 +57,6 @@ def sphere_init_(linear, first, last, radius, d_in, d_out):
                 w[:, 3:].zero_()
         if hasattr(linear, "weight_g"):
             linear.weight_g.copy_(w.norm(dim=1, keepdim=True))
-
-
-def sphere_init_fused_mlp_(network, n_input_dims, n_output_dims, n_neurons=64):
-    """the same initialisation written into the flat parameter of a fused ``tinycudann.Network`` (what the reference's
-    ``sphere_init_tcnn_network`` does through ``.data``, models/network_utils.py:142-173); invalidates the fp16 shadow"""
-    md = network.mlp_desc
-    mats = []
-    w = torch.zeros(n_neurons, md.in_pad)
-    w[:, :3].normal_(0.0, math.sqrt(2) / math.sqrt(n_neurons))
-    mats.append(w)
-    for _ in range(md.n_hidden - 1):
-        mats.append(torch.empty(n_neurons, n_neurons).normal_(0.0, math.sqrt(2) / math.sqrt(n_neurons)))
-    mats.append(torch.empty(md.out_pad, n_neurons).normal_(math.sqrt(math.pi) / math.sqrt(n_neurons), 0.0001))
-    flat = torch.cat([m.flatten() for m in mats])
-    assert flat.numel() == network.params.numel()
-    with torch.no_grad():
-        network.params.copy_(flat.to(network.params))
-    network.invalidate()
 
 
 def _vanilla_head(n_in, n_out, cfg):
@@ -124,9 +108,10 @@ class HotPathState(nn.Module):
             if mc["otype"] != "VanillaMLP" or mc["n_hidden_layers"] != 1 or mc["n_neurons"] != 64:
                 raise NotImplementedError("fused NeuS state: the SDF head is the 1-hidden-layer fp32 VanillaMLP of the "
                                           "reference's neus-*/neuralangelo-* configs")
+            wn = bool(mc.get("weight_norm", False))
             rows += [(enc_path, lambda: tcnn.Encoding(3, dict(enc_cfg, otype="HashGrid"))),
-                     ("geometry.network.layers.0", lambda: _weight_normed_linear(n_enc, 64)),
-                     ("geometry.network.layers.2", lambda: _weight_normed_linear(64, g["feature_dim"])),
+                     ("geometry.network.layers.0", lambda: _weight_normed_linear(n_enc, 64, wn)),
+                     ("geometry.network.layers.2", lambda: _weight_normed_linear(64, g["feature_dim"], wn)),
                      ("texture.encoding.encoding", sh),
                      ("texture.network", lambda: _colour_head(t)),
                      ("variance", lambda: _Scalar("variance", cfg["variance"]["init_val"]))]
@@ -168,6 +153,7 @@ class HotPathState(nn.Module):
                                                        contraction_type=ContractionType.UN_BOUNDED_SPHERE)
         self.randomized = bool(cfg["randomized"])
         self.background_color = None
+        self.schedules_restored = False  # set by update_step / restore_schedules (nsr.export refuses to guess the schedule)
         # the reference's NeuSModel refreshes its occupancy grid(s) inside update_step (models/neus.py:79-111); this holder
         # has no field code of its own, so the trainer drives the refresh through the fused runner's occ_eval_fn
         self.refresh_owned_by_trainer = kind == "neus"
@@ -177,6 +163,15 @@ class HotPathState(nn.Module):
         cfg = self.config
         if cfg["name"] == "nerf" and self.training and cfg["grid_prune"]:
             self.occupancy_grid.every_n_step(step=global_step, occ_eval_fn=self.density_of_cells)
+        self.restore_schedules(global_step)
+
+    def restore_schedules(self, global_step):
+        """the step-dependent state that lives on the reference's model objects and is NOT in the state dict -- cos-anneal
+        ratio, progressive level, finite-difference eps (models/neus.py:86-87, models/network_utils.py:61-65,
+        models/geometry.py:224-236).  The reference restores it through its batch-start hooks from the checkpoint's
+        global_step; call this (or ``load_reference_checkpoint(..., global_step=...)``) before exporting from a loaded model."""
+        cfg = self.config
+        self.schedules_restored = True
         if cfg["name"] == "neus":
             end = cfg.get("cos_anneal_end", 0)
             self.cos_anneal_ratio = 1.0 if end == 0 else min(1.0, global_step / end)  # models/neus.py:86-87
@@ -207,10 +202,18 @@ class HotPathState(nn.Module):
         self.randomized = bool(mode and self.config["randomized"])
         return super().train(mode)
 
-    def load_reference_checkpoint(self, state_dict, strict=True):
-        """a Lightning ``.ckpt`` of the reference stores the model under ``model.``: strip it and load"""
+    def load_reference_checkpoint(self, state_dict, strict=True, global_step=None):
+        """a Lightning ``.ckpt`` of the reference stores the model under ``model.``: strip it and load.  ``state_dict`` may be
+        the whole checkpoint (its ``state_dict`` / ``global_step`` entries are then used); ``global_step`` restores the
+        step-dependent schedules (``restore_schedules``) the way the reference's hooks do after a resume."""
+        if "state_dict" in state_dict and not any(torch.is_tensor(v) for v in state_dict.values()):
+            global_step = state_dict.get("global_step", global_step) if global_step is None else global_step
+            state_dict = state_dict["state_dict"]
         sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in state_dict.items()}
-        return self.load_state_dict(sd, strict=strict)
+        res = self.load_state_dict(sd, strict=strict)
+        if global_step is not None:
+            self.restore_schedules(int(global_step))
+        return res
 
 
 def build(config):

@@ -111,14 +111,14 @@ class Module(torch.nn.Module):
 
     # ---- fp16 shadow (tcnn casts params to fp16 on every call) --------------------------------------------------
     def half_params(self, params):
-        """fp16 copy of the parameters that the kernels read.  Cached per parameter version in inference; while
-        TRAINING with autograd on it is re-cast on every call (75 MB of traffic, ~15 us on MI355X), because writes through
-        ``params.data`` -- the reference's ``sphere_init_tcnn_network`` (models/network_utils.py:172), DDP's initial
-        broadcast -- do not bump the version counter.  A fused optimizer that writes the fp16 copy itself marks it
-        trusted (``adopt_shadow``) and no cast happens at all."""
+        """fp16 copy of the parameters that the kernels read (tcnn casts its fp32 params on every call as well).  It is
+        re-cast on EVERY call (75 MB of traffic, ~15 us on MI355X for the 12.6 M-parameter table) because writes through
+        ``params.data`` -- the reference's ``sphere_init_tcnn_network`` (models/network_utils.py:155,172), DDP's initial
+        broadcast -- bump no version counter and would otherwise be invisible.  The exception: a fused optimizer that writes
+        the fp16 image itself in the pass that updates the parameters hands it over (``adopt_shadow``); it is then used as
+        is until the parameter tensor is replaced or modified in place (version counter), or ``invalidate()`` is called."""
         key = (params.data_ptr(), params._version, params.device)
-        stale = key != self._shadow_key or self._shadow is None
-        if stale or (self.training and torch.is_grad_enabled() and not self._shadow_trusted):
+        if self._shadow is None or key != self._shadow_key or not self._shadow_trusted:
             self._shadow = params.detach().to(torch.float16).contiguous()
             self._shadow_key, self._shadow_trusted = key, False
         return self._shadow

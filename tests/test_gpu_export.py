@@ -145,3 +145,26 @@ def test_vertex_colors_match_the_reference_export_queries():
         assert bad < 5e-3, (name, bad, float((got - want.cpu()).abs().max()))
         at = m._level_runner.surface_attributes(pts[:1000])
         assert torch.allclose(at["sdf"], sdf[:1000].detach().view(-1), atol=1e-3)
+
+
+def test_export_after_checkpoint_load_needs_the_schedules_of_its_global_step():
+    """a progressive / finite-difference model restored from a checkpoint has no active level count and no eps until the
+    step-dependent schedules are restored (the reference does it in its batch-start hooks from the checkpoint's
+    global_step): exporting without them is refused, `load_reference_checkpoint(ckpt)` with the Lightning checkpoint's
+    `global_step` restores them"""
+    import nsr
+    from nsr.export import isosurface_levels
+    cfg = nsr.configs.get("neuralangelo")
+    src = nsr.build(cfg).cuda().train()
+    src.update_step(0, 9005)                      # level 4 + 9 = 13 active
+    ckpt = {"state_dict": {"model." + k: v for k, v in src.state_dict().items()}, "global_step": 9005, "epoch": 0}
+    dst = nsr.build(cfg).cuda().eval()
+    dst.load_reference_checkpoint(ckpt["state_dict"])
+    with pytest.raises(RuntimeError, match="restore_schedules"):
+        isosurface_levels(dst, 16)
+    dst2 = nsr.build(cfg).cuda().eval()
+    dst2.load_reference_checkpoint(ckpt)          # the whole Lightning checkpoint: state_dict + global_step
+    assert dst2.current_level == src.current_level == 13
+    assert abs(dst2.finite_difference_eps - src.finite_difference_eps) < 1e-12
+    a, b = isosurface_levels(dst2, 16), isosurface_levels(src.eval(), 16)
+    assert torch.equal(a, b)

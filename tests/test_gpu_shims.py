@@ -173,3 +173,71 @@ def test_half_transport_casts_round_trip():
     check(lib.nsr_scale_from_half(ptr(h), ptr(y), x.numel(), 1.0 / 2048.0, stream_ptr()), "nsr_scale_from_half")
     assert torch.equal(h, (x * 1024.0).half())
     assert torch.equal(y, h.float() / 2048.0)
+
+
+def _reference_sphere_init(n_input_dims, n_output_dims, config, network):
+    """the body of the reference's sphere_init_tcnn_network (models/network_utils.py:142-173): the flat parameter is
+    re-written THROUGH ``.data`` (no version bump) after asserting its length -- the layout contract of a tcnn.Network"""
+    import math
+    padto = 16 if config["otype"] == "FullyFusedMLP" else 8
+    n_input_dims = n_input_dims + (padto - n_input_dims % padto) % padto
+    n_output_dims = n_output_dims + (padto - n_output_dims % padto) % padto
+    data = list(network.parameters())[0].data
+    assert data.shape[0] == (n_input_dims + n_output_dims) * config["n_neurons"] + (config["n_hidden_layers"] - 1) * config["n_neurons"] ** 2
+    new_data = []
+    weight = torch.zeros((config["n_neurons"], n_input_dims)).to(data)
+    torch.nn.init.constant_(weight[:, 3:], 0.0)
+    torch.nn.init.normal_(weight[:, :3], 0.0, math.sqrt(2) / math.sqrt(config["n_neurons"]))
+    new_data.append(weight.flatten())
+    for _ in range(config["n_hidden_layers"] - 1):
+        weight = torch.zeros((config["n_neurons"], config["n_neurons"])).to(data)
+        torch.nn.init.normal_(weight, 0.0, math.sqrt(2) / math.sqrt(config["n_neurons"]))
+        new_data.append(weight.flatten())
+    weight = torch.zeros((n_output_dims, config["n_neurons"])).to(data)
+    torch.nn.init.normal_(weight, mean=math.sqrt(math.pi) / math.sqrt(config["n_neurons"]), std=0.0001)
+    new_data.append(weight.flatten())
+    new_data = torch.cat(new_data)
+    data.copy_(new_data)
+    return new_data
+
+
+@pytest.mark.parametrize("warm", ["fresh", "after_no_grad_forward", "after_training_forward"])
+def test_sphere_init_through_params_data_is_seen_and_trains(warm):
+    """get_mlp(..., sphere_init=True) of the reference (models/network_utils.py:176-184) on the HIP tcnn.Network: the
+    ``.data`` write must reach the fp16 image the kernels read -- also when a forward already cached one -- the network then
+    represents the sphere |x| - r, and one optimizer step trains it"""
+    import tinycudann as tcnn
+    from oracle import tcnn_ref
+    cfg = dict(otype="FullyFusedMLP", activation="ReLU", output_activation="none", n_neurons=64, n_hidden_layers=2,
+               sphere_init=True)  # (unknown keys are ignored, like tcnn does)
+    torch.manual_seed(3)
+    net = tcnn.Network(3, 13, cfg).train()
+    x = (torch.rand(2048, 3, device="cuda") - 0.5) * 2
+    if warm == "after_no_grad_forward":
+        with torch.no_grad():
+            net(x)
+    elif warm == "after_training_forward":
+        net(x).float().sum().backward()
+        net.params.grad = None
+    new_data = _reference_sphere_init(3, 13, cfg, net)
+    assert torch.equal(net.params.data, new_data)
+    want = tcnn_ref.mlp_forward(x.cpu(), new_data.cpu(), tcnn_ref.MLPDesc(3, 13, cfg))
+    for grad_mode in (False, True):
+        with torch.set_grad_enabled(grad_mode):
+            y = net(x)
+        assert torch.allclose(y.float().cpu(), want.float(), rtol=1e-2, atol=3e-3), (warm, grad_mode)
+    # the geometric init: output 0 grows ~linearly with |x| (a sphere's signed distance up to scale and offset)
+    r = x.norm(dim=-1)
+    corr = torch.corrcoef(torch.stack([y[:, 0].float(), r]))[0, 1]
+    assert float(corr) > 0.98, float(corr)
+    # ... and it trains: one AdamW step on the eikonal-free target  out[:, 0] -> |x| - 0.5
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(30):
+        loss = ((net(x)[:, 0].float() - (r - 0.5)) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.5 * losses[0], losses[::6]
+    assert not torch.equal(net.params.data, new_data)
