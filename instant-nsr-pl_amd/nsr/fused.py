@@ -284,7 +284,7 @@ class FusedNeRFStep:
                      n_kept_dev=total_s, n_rays=n_rays, w1=w1, w2=w2, keep=(meta, half, smp))
         return out, state
 
-    def render_backward(self, state, g_comp_rgb, g_opacity=None, g_depth=None, g_weights=None, grad_scale=1.0):
+    def render_backward(self, state, g_comp_rgb, g_opacity=None, g_depth=None, g_weights=None):
         """gradients of the flat parameters (geometry.encoding_with_network.params [MLP | table], texture.network.params) from
         the upstream gradients of comp_rgb [R,3], opacity [R,1], depth [R,1], weights [S]; fresh fp32 tensors"""
         import nsr_hip
@@ -309,7 +309,6 @@ class FusedNeRFStep:
                                                ptr(state["w1"]), ptr(state["w2"]), ptr(ewn.mlp_slice(g1)), ptr(ewn.grid_slice(g1)),
                                                ptr(g2), ptr(state["ws"]), state["S"], state["n_rays"], ptr(state["n_kept_dev"]),
                                                stream_ptr()), "nsr_nerf_render_backward")
-        d.grad_scale = old
         return g1, g2
 
     def _forward_backward_python(self, rays, gt_rgb, background, compute_grads=True, loss_scale=1.0, march_handle=None,
