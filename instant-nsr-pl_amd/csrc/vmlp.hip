@@ -249,6 +249,14 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 }
 
 // One wave per block: forward recompute + data gradient + weight gradient (+ second-order terms) of its tiles.
+// Register budget: 304-468 (arch + acc), one wave per SIMD, no spills -- after two fixes found in the ISA: the per-column
+// offsets of the d_x stores and of the final partial stores are functions of the lane only, so the compiler computed them
+// BEFORE the tile loop and kept ~70 + ~100 registers alive across it (spilling 57-152 of them in the two-hidden-layer
+// variants); the lane coordinates are now made opaque (empty asm) right where those addresses are needed.
+// Measured alternative (round 3): a 128-thread workgroup with a "data" wave (forward / dgrad / d_x) feeding a "weight" wave
+// (all dW accumulators) through the LDS tiles -- <= 248 registers, two waves per SIMD, no spills, all parity tests green --
+// was SLOWER: C5 SDF backward 1.69 ms vs 1.32 ms, colour head 0.49 vs 0.50 ms, C3 step +4 %.  Two barriers per 16-sample
+// tile and re-reading the weight fragments per tile cost more than the second wave hides; not adopted.
 template <int KS, int NH, int ACT, bool SDF_IN, bool SECOND>
 __global__ void __launch_bounds__(64, NSR_VMLP_WAVES)
 k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uint32_t x_stride,
@@ -300,6 +308,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
             for (int nb = 0; nb < 4; ++nb) accW1[mb][nb] = zero4;
     }
     const uint32_t n_tiles = (n_live + 15) / 16;
+    const uint32_t lm_shift = dx_lm_features ? 31u - (uint32_t)__clz((int)dx_lm_features) : 0u;
     // software pipeline: the NEXT tile's inputs (features, output gradient, P) are requested before this tile's MFMA chain
     float xnext[KS], pnext[KS];
     f32x4 donext;
@@ -516,6 +525,11 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
         }
         // ---- input gradient dX^T = W0^T dz0^T ----------------------------------------------------------------------
         if (d_x) {
+            // (lane coordinates made opaque per tile: the per-column store offsets are otherwise hoisted out of the tile loop
+            // as ~70 loop-invariant registers; re-deriving them costs ~30 VALU per tile)
+            int cx = c, gx = g;
+            asm volatile("" : "+v"(cx), "+v"(gx));
+            const uint64_t sx = (uint64_t)tile * 16 + cx;
 #pragma unroll
             for (int fb = 0; fb < NB0; ++fb) {
                 f32x4 acc = zero4;
@@ -523,19 +537,20 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int col = fb * 16 + c;
-                        const float wt = col < IN_PAD ? W0t[(nb * 16 + 4 * g + r) * IN_PAD + col] : 0.f;
+                        const int col = fb * 16 + cx;
+                        const float wt = col < IN_PAD ? W0t[(nb * 16 + 4 * gx + r) * IN_PAD + col] : 0.f;
                         acc = mfma4(wt, dz0[nb][r], acc);
                     }
-                if (valid) {
+                if (sx < n_live) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const uint32_t col = fb * 16 + 4 * g + r;  // input feature
+                        const uint32_t col = fb * 16 + 4 * gx + r;  // input feature
                         if (col < dx_first || col >= dx_first + dx_count) continue;
                         const uint32_t k = col - dx_first;
+                        // level-major [k / F][n][F] with F a power of two
                         const uint64_t off = dx_lm_features
-                            ? ((uint64_t)(k / dx_lm_features) * n + s) * dx_lm_features + k % dx_lm_features
-                            : s * dx_stride + k;
+                            ? ((((uint64_t)(k >> lm_shift) * n + sx) << lm_shift) | (k & (dx_lm_features - 1u)))
+                            : sx * dx_stride + k;
                         d_x[off] = acc[r];
                     }
                 }
@@ -545,416 +560,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #undef NSR_S0
 #undef NSR_S1
     // ---- this wave's partial gradient, in blob layout ---------------------------------------------------------------
-    float *P = partials + (uint64_t)blockIdx.x * blob_floats;
-    float *pW0 = P, *pb0 = pW0 + W * IN_PAD;
-    float *pW1 = pb0 + W, *pb1 = pW1 + (NH == 2 ? W * W : 0);
-    float *pWl = (NH == 2) ? pb1 + W : pW1;
-    float *pbl = pWl + 16 * W;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB0; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = nb * 16 + c;
-                if (col < IN_PAD) pW0[(mb * 16 + 4 * g + r) * IN_PAD + col] = accW0[mb][nb][r];
-            }
-    if constexpr (NH == 2) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pW1[(mb * 16 + 4 * g + r) * W + nb * 16 + c] = accW1[mb][nb][r];
-    }
-    // bias / du sums: reduce the D-layout registers over the 16 sample lanes c (lanes differing in bits 0..3)
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v0 = db0[mb][r], v1 = db1[mb][r], v2 = du[mb][r];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                v0 += __shfl_xor(v0, o, 64);
-                if (NH == 2) v1 += __shfl_xor(v1, o, 64);
-                v2 += __shfl_xor(v2, o, 64);
-            }
-            db0[mb][r] = v0; db1[mb][r] = v1; du[mb][r] = v2;
-        }
-    if (c == 0) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pb0[mb * 16 + 4 * g + r] = db0[mb][r];
-                if (NH == 2) pb1[mb * 16 + 4 * g + r] = db1[mb][r];
-            }
-    }
-    // dWl (rows o = 4g + r, columns nb*16 + c); the per-neuron row-0 sums held in D layout (second-order du, tap tiles) join row 0
-    {
-        lds_wave_sync();
-        if (c == 0) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T_a[mb * 16 + 4 * g + r] = du[mb][r];
-        }
-        lds_wave_sync();
-        if (g == 0) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) accWl[nb][0] += T_a[nb * 16 + c];
-        }
-    }
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pWl[(4 * g + r) * W + nb * 16 + c] = accWl[nb][r];
-    // dbl[o]: lane (g,c) holds sums of d_out[.][4kk + g] over ITS sample column c; reduce over c
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        float v = dblv[kk];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (c == 0) pbl[4 * kk + g] = v;
-    }
-}
-
-// ---- backward, two waves per workgroup -------------------------------------------------------------------------------
-// The one-wave kernel above keeps ~50 activation registers AND ~130-200 weight-gradient accumulators live in one wave:
-// 430-512 registers, one wave per SIMD, 25 % MFMA busy (its dependent MFMA / activation / LDS chains have nothing to
-// overlap with), and the two-hidden-layer variants spill.  Here the work of a tile is split between the two waves of a
-// 128-thread workgroup:
-//   wave 0 ("data"):   forward recompute, pre-activation gradients, second-order terms, input gradient -> global memory;
-//                      leaves the tile's operands of the weight gradient in LDS ([sample][column] tiles, as before);
-//   wave 1 ("weight"): reads them back in MFMA operand layout and owns every accumulator (dW0, dW1, dWl; the bias / row-0
-//                      sums as plain adds on the operand values it loads anyway).
-// Each wave stays under 256 registers, so two workgroups' waves share a SIMD and one's MFMA chain runs under the other's
-// activation math / LDS traffic.  Two barriers per tile (tile written / tile consumed): wave 0 computes tile t + 1 while
-// wave 1 accumulates tile t.  Same arithmetic per product as the one-wave kernel; summation order of the bias sums differs.
-template <int KS, int NH, int ACT, bool SDF_IN, bool SECOND>
-__global__ void __launch_bounds__(128, 2)
-k_vmlp_backward2(const float *__restrict__ blob, const float *__restrict__ x, uint32_t x_stride,
-                 const __half *__restrict__ enc, uint32_t enc_stride, uint32_t n_in,
-                 const float *__restrict__ d_out /* [n_full][16] */, const float *__restrict__ d_out_col0,
-                 const float *__restrict__ p_in /* [n][KS*4], SECOND */, float *__restrict__ d_x, uint32_t dx_stride,
-                 uint32_t dx_first, uint32_t dx_count, uint32_t dx_lm_features, float *__restrict__ partials,
-                 uint32_t blob_floats, uint32_t n, uint32_t n_full, const int32_t *__restrict__ n_dev)
-{
-    static_assert(!SECOND || NH == 1, "second-order terms: one hidden layer");
-    const uint32_t n_live = live_count(n, n_dev);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const Blob B = split_blob<KS, NH>(blob);
-    constexpr int IN_PAD = KS * 4;
-    constexpr int NB0 = (IN_PAD + 15) / 16;
-    __shared__ __attribute__((aligned(16))) float T_a[16 * LDT];                     // a_last  [sample][neuron]
-    __shared__ __attribute__((aligned(16))) float T_d[16 * LDT];                     // dz0     [sample][neuron]
-    __shared__ __attribute__((aligned(16))) float T_x[16 * LDX];                     // x       [sample][feature]
-    __shared__ __attribute__((aligned(16))) float T_o[16 * LDO];                     // d_out   [sample][output]
-    __shared__ __attribute__((aligned(16))) float T_u[16 * LDT];                     // row-0 terms of dWl [sample][neuron]
-    __shared__ __attribute__((aligned(16))) float T_a0[(NH == 2 ? 16 : 1) * LDT];    // a0 (two hidden layers)
-    __shared__ __attribute__((aligned(16))) float T_d1[(NH == 2 ? 16 : 1) * LDT];    // dz1
-    __shared__ __attribute__((aligned(16))) float T_q[(SECOND ? 16 : 1) * LDT];      // q = act'(z0) * u
-    __shared__ __attribute__((aligned(16))) float T_p[(SECOND ? 16 : 1) * LDX];      // P = dL/dg
-    for (int k = threadIdx.x; k < 16 * LDX; k += 128) { T_x[k] = 0.f; if (SECOND) T_p[k] = 0.f; }  // columns >= IN_PAD stay 0
-    const uint32_t n_tiles = (n_live + 15) / 16;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const uint32_t lm_shift = dx_lm_features ? 31u - (uint32_t)__clz((int)dx_lm_features) : 0u;
-    __syncthreads();
-    if (wave == 0) {
-        // =============================== data wave ===============================
-        // (biases and the last layer's row 0 are re-read from L1 where they are used: 48 registers less than keeping them)
-#define NSR_B0F(mb) (*reinterpret_cast<const f32x4 *>(b0t + (mb) * 16 + 4 * g))
-#define NSR_B1F(mb) (*reinterpret_cast<const f32x4 *>(b1t + (mb) * 16 + 4 * g))
-#define NSR_UF(mb) (*reinterpret_cast<const f32x4 *>(Wlt + (mb) * 16 + 4 * g))
-        float xnext[KS], pnext[KS];
-        f32x4 donext;
-        auto load_inputs = [&](uint32_t tile, float (&xd)[KS], float (&pd)[KS], f32x4 &dd) {
-            const uint64_t sn = (uint64_t)tile * 16 + c;
-            const bool ok = tile < n_tiles && sn < n_live;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                xd[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, sn, 4 * kk + g, n) : 0.f;
-                if (SECOND) pd[kk] = ok ? p_in[sn * IN_PAD + 4 * kk + g] : 0.f;
-            }
-            dd = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                if (sn < n_full) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) dd[kk] = d_out[sn * 16 + 4 * kk + g];
-                } else {
-                    dd[3] = d_out_col0[sn - n_full];
-                    if (g == 0) dd[0] = dd[3];
-                }
-            }
-        };
-        load_inputs(blockIdx.x, xnext, pnext, donext);
-        for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            const uint64_t s = (uint64_t)tile * 16 + c;
-            const bool valid = s < n_live;
-            // the (L1-resident, <= 37 KB) weight matrices are re-read per tile: hoisted fragments would cost ~100 registers
-            const float *W0t = B.W0, *W1t = B.W1, *Wlt = B.Wl, *b0t = B.b0, *b1t = B.b1;
-            asm volatile("" : "+s"(W0t), "+s"(W1t), "+s"(Wlt), "+s"(b0t), "+s"(b1t));
-            float xin[KS], pb[KS];
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) { xin[kk] = xnext[kk]; pb[kk] = SECOND ? pnext[kk] : 0.f; }
-            f32x4 dob = donext;
-            load_inputs(tile + gridDim.x, xnext, pnext, donext);
-            // ---- forward recompute (ReLU: act'(z) = (a > 0), nothing but the activations stays live) ----
-            f32x4 a0[4], s0[ACT == 1 ? 4 : 1], a1[NH == 2 ? 4 : 1], s1[(NH == 2 && ACT == 1) ? 4 : 1];
-#define NSR_S0(mb, r) (ACT == 1 ? s0[ACT == 1 ? (mb) : 0][r] : (a0[mb][r] > 0.f ? 1.f : 0.f))
-#define NSR_S1(mb, r) (ACT == 1 ? s1[(NH == 2 && ACT == 1) ? (mb) : 0][r] : (a1[NH == 2 ? (mb) : 0][r] > 0.f ? 1.f : 0.f))
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                f32x4 z = NSR_B0F(mb);
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) z = mfma4(W0t[(mb * 16 + c) * IN_PAD + 4 * kk + g], xin[kk], z);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    a0[mb][r] = act_fwd<ACT>(z[r]);
-                    if constexpr (ACT == 1) s0[mb][r] = act_bwd<ACT>(z[r]);
-                }
-            }
-            if constexpr (NH == 2) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    f32x4 z = NSR_B1F(mb);
-#pragma unroll
-                    for (int ib = 0; ib < 4; ++ib) {
-                        const f32x4 w = load_chain(W1t, mb, ib, c, g);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) z = mfma4(w[r], a0[ib][r], z);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        a1[mb][r] = act_fwd<ACT>(z[r]);
-                        if constexpr (ACT == 1) s1[mb][r] = act_bwd<ACT>(z[r]);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- pre-activation gradient of the last hidden layer ----
-            const bool tap_tile = (uint64_t)tile * 16 >= n_full;  // finite-difference taps: only d out[0] is non-zero
-            const float d_tap = tap_tile ? dob[3] : 0.f;
-            if (s >= n_full) dob[3] = 0.f;
-            f32x4 dz_last[4], du_t[4];  // du_t: this tile's per-(sample, neuron) contributions to row 0 of dWl
-            if (tap_tile) {
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) {
-                    const f32x4 uq = NSR_UF(fb);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dz_last[fb][r] = d_tap * uq[r] * ((NH == 2) ? NSR_S1(fb, r) : NSR_S0(fb, r));
-                        du_t[fb][r] = d_tap * ((NH == 2) ? a1[NH == 2 ? fb : 0][r] : a0[fb][r]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) {
-                    f32x4 acc = zero4;
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = mfma4(Wlt[(4 * kk + g) * W + fb * 16 + c], dob[kk], acc);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dz_last[fb][r] = acc[r] * ((NH == 2) ? NSR_S1(fb, r) : NSR_S0(fb, r));
-                        du_t[fb][r] = 0.f;
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 dz0[4];
-            if constexpr (NH == 2) {
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) {
-                    f32x4 acc = zero4;
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc = mfma4(W1t[(nb * 16 + 4 * g + r) * W + fb * 16 + c], dz_last[nb][r], acc);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dz0[fb][r] = acc[r] * NSR_S0(fb, r);
-                }
-            } else {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) dz0[mb] = dz_last[mb];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 q[SECOND ? 4 : 1];
-            if constexpr (SECOND) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    f32x4 dq = zero4;
-#pragma unroll
-                    for (int kk = 0; kk < KS; ++kk) dq = mfma4(W0t[(mb * 16 + c) * IN_PAD + 4 * kk + g], pb[kk], dq);  // (W0 P)^T
-                    const f32x4 uq = NSR_UF(mb);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float sg = NSR_S0(mb, r);
-                        q[mb][r] = sg * uq[r];
-                        du_t[mb][r] += sg * dq[r];
-                        // d/dz of act'(z): softplus 100 s (1 - s) -- on torch's linear branch (100 z > 20) s is exactly 1, so the
-                        // product vanishes there by itself; relu 0
-                        const float curv = (ACT == 1) ? 100.f * sg * (1.f - sg) : 0.f;
-                        dz0[mb][r] += curv * uq[r] * dq[r];
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- hand the tile to the weight wave ----
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // (B) the previous tile has been consumed
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                *reinterpret_cast<f32x4 *>(&T_a[c * LDT + mb * 16 + 4 * g]) = (NH == 2) ? a1[NH == 2 ? mb : 0] : a0[mb];
-                *reinterpret_cast<f32x4 *>(&T_d[c * LDT + mb * 16 + 4 * g]) = dz0[mb];
-                *reinterpret_cast<f32x4 *>(&T_u[c * LDT + mb * 16 + 4 * g]) = du_t[mb];
-                if constexpr (NH == 2) {
-                    *reinterpret_cast<f32x4 *>(&T_a0[c * LDT + mb * 16 + 4 * g]) = a0[mb];
-                    *reinterpret_cast<f32x4 *>(&T_d1[c * LDT + mb * 16 + 4 * g]) = dz_last[mb];
-                }
-                if constexpr (SECOND) *reinterpret_cast<f32x4 *>(&T_q[c * LDT + mb * 16 + 4 * g]) = q[mb];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) T_o[c * LDO + 4 * kk + g] = dob[kk];
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                T_x[c * LDX + 4 * kk + g] = xin[kk];
-                if constexpr (SECOND) T_p[c * LDX + 4 * kk + g] = pb[kk];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // (A) the tile is in LDS
-            // ---- input gradient dX^T = W0^T dz0^T (runs while the weight wave accumulates) ----
-            if (d_x) {
-                // (lane coordinates made opaque per tile: the per-column store offsets are otherwise hoisted out of the tile
-                // loop as ~70 loop-invariant registers and spilled across it; re-deriving them costs ~30 VALU per tile)
-                int cx = c, gx = g;
-                asm volatile("" : "+v"(cx), "+v"(gx));
-                const uint64_t sx = (uint64_t)tile * 16 + cx;
-#pragma unroll
-                for (int fb = 0; fb < NB0; ++fb) {
-                    f32x4 acc = zero4;
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int col = fb * 16 + cx;
-                            const float wt = col < IN_PAD ? W0t[(nb * 16 + 4 * gx + r) * IN_PAD + col] : 0.f;
-                            acc = mfma4(wt, dz0[nb][r], acc);
-                        }
-                    if (sx < n_live) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const uint32_t col = fb * 16 + 4 * gx + r;  // input feature
-                            if (col < dx_first || col >= dx_first + dx_count) continue;
-                            const uint32_t k = col - dx_first;
-                            // level-major [k / F][n][F] with F a power of two
-                            const uint64_t off = dx_lm_features
-                                ? ((((uint64_t)(k >> lm_shift) * n + sx) << lm_shift) | (k & (dx_lm_features - 1u)))
-                                : sx * dx_stride + k;
-                            d_x[off] = acc[r];
-                        }
-                    }
-                }
-            }
-        }
-#undef NSR_S0
-#undef NSR_S1
-#undef NSR_B0F
-#undef NSR_B1F
-#undef NSR_UF
-        return;
-    }
-    // =============================== weight wave ===============================
-    f32x4 accW0[4][NB0], accW1[NH == 2 ? 4 : 1][4], accWl[4];
-    float sb0[4], sb1[4], su[4], sbl = 0.f;  // bias / row-0 sums over the samples {g, 4 + g, 8 + g, 12 + g} of every tile
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-#pragma unroll
-        for (int nb = 0; nb < NB0; ++nb) accW0[mb][nb] = zero4;
-        accWl[mb] = zero4;
-        sb0[mb] = sb1[mb] = su[mb] = 0.f;
-    }
-    if constexpr (NH == 2) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) accW1[mb][nb] = zero4;
-    }
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const bool tap_tile = (uint64_t)tile * 16 >= n_full;
-        __builtin_amdgcn_s_barrier();  // (B) this wave is done with the previous tile
-        __builtin_amdgcn_s_barrier();  // (A) the data wave has written this one
-        // last layer: dWl[o][j] += sum_s dOut[o][s] a_last[j][s] ; dbl ; the row-0 terms
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) su[nb] += T_u[(4 * kk + g) * LDT + nb * 16 + c];
-            if (!tap_tile) {
-                const float ao = T_o[(4 * kk + g) * LDO + c];
-                sbl += ao;
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) accWl[nb] = mfma4(ao, T_a[(4 * kk + g) * LDT + nb * 16 + c], accWl[nb]);
-            }
-        }
-        if (tap_tile) {  // (a tap tile's d_out is the scalar of column 0: dbl[0] += sum over the samples)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) sbl += T_o[(4 * kk + g) * LDO + c];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NH == 2) {
-            // dW1[i][j] += sum_s dz1[i][s] a0[j][s] ; db1
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float bj[4];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) bj[nb] = T_a0[(4 * kk + g) * LDT + nb * 16 + c];
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const float ai = T_d1[(4 * kk + g) * LDT + mb * 16 + c];
-                    sb1[mb] += ai;
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) accW1[mb][nb] = mfma4(ai, bj[nb], accW1[mb][nb]);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SECOND) {
-            // dW0 += q P^T
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float bj[NB0];
-#pragma unroll
-                for (int nb = 0; nb < NB0; ++nb) bj[nb] = T_p[(4 * kk + g) * LDX + nb * 16 + c];
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const float ai = T_q[(4 * kk + g) * LDT + mb * 16 + c];
-#pragma unroll
-                    for (int nb = 0; nb < NB0; ++nb) accW0[mb][nb] = mfma4(ai, bj[nb], accW0[mb][nb]);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // first layer: dW0[i][k] += sum_s dz0[i][s] x[k][s] ; db0
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float bj[NB0];
-#pragma unroll
-            for (int nb = 0; nb < NB0; ++nb) bj[nb] = T_x[(4 * kk + g) * LDX + nb * 16 + c];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const float ai = T_d[(4 * kk + g) * LDT + mb * 16 + c];
-                sb0[mb] += ai;
-#pragma unroll
-                for (int nb = 0; nb < NB0; ++nb) accW0[mb][nb] = mfma4(ai, bj[nb], accW0[mb][nb]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the tile has landed before (B) releases it
-    }
-    // ---- this workgroup's partial gradient, in blob layout ----
-    // (the lane coordinates are made opaque here: otherwise the ~250 store addresses below are computed BEFORE the tile loop
-    // and spilled across it)
-    int c2 = c, g2 = g;
+    int c2 = c, g2 = g;  // (opaque: the ~250 store addresses below must not be computed before the tile loop)
     asm volatile("" : "+v"(c2), "+v"(g2));
     float *P = partials + (uint64_t)blockIdx.x * blob_floats;
     float *pW0 = P, *pb0 = pW0 + W * IN_PAD;
@@ -978,28 +584,56 @@ k_vmlp_backward2(const float *__restrict__ blob, const float *__restrict__ x, ui
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pW1[(mb * 16 + 4 * g2 + r) * W + nb * 16 + c2] = accW1[mb][nb][r];
     }
-    // the sums held per (c2, g2): join the four sample groups g2 (lanes c2, c2 + 16, c2 + 32, c2 + 48)
+    // bias / du sums: reduce the D-layout registers over the 16 sample lanes c2 (lanes differing in bits 0..3)
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        float v0 = sb0[mb], v1 = sb1[mb], v2 = su[mb];
-        v0 += __shfl_xor(v0, 16, 64); v0 += __shfl_xor(v0, 32, 64);
-        if (NH == 2) { v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64); }
-        v2 += __shfl_xor(v2, 16, 64); v2 += __shfl_xor(v2, 32, 64);
-        if (g2 == 0) {
-            pb0[mb * 16 + c2] = v0;
-            if (NH == 2) pb1[mb * 16 + c2] = v1;
-            accWl[mb][0] += v2;  // row o = 4 g2 + r = 0 of dWl, column mb * 16 + c2
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v0 = db0[mb][r], v1 = db1[mb][r], v2 = du[mb][r];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                v0 += __shfl_xor(v0, o, 64);
+                if (NH == 2) v1 += __shfl_xor(v1, o, 64);
+                v2 += __shfl_xor(v2, o, 64);
+            }
+            db0[mb][r] = v0; db1[mb][r] = v1; du[mb][r] = v2;
         }
+    if (c2 == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pb0[mb * 16 + 4 * g2 + r] = db0[mb][r];
+                if (NH == 2) pb1[mb * 16 + 4 * g2 + r] = db1[mb][r];
+            }
     }
+    // dWl (rows o = 4g + r, columns nb*16 + c2); the per-neuron row-0 sums held in D layout (second-order du, tap tiles) join row 0
     {
-        float v = sbl;
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        if (g2 == 0) pbl[c2] = v;
+        lds_wave_sync();
+        if (c2 == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T_a[mb * 16 + 4 * g2 + r] = du[mb][r];
+        }
+        lds_wave_sync();
+        if (g2 == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) accWl[nb][0] += T_a[nb * 16 + c2];
+        }
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) pWl[(4 * g2 + r) * W + nb * 16 + c2] = accWl[nb][r];
+    // dbl[o]: lane (g2,c2) holds sums of d_out[.][4kk + g2] over ITS sample column c2; reduce over c2
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        float v = dblv[kk];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (c2 == 0) pbl[4 * kk + g2] = v;
+    }
 }
 
 // grad[k] (+)= sum over the per-wave partials.  One thread per (parameter, segment of 64 partials): the 14 MB of partials are
@@ -1208,16 +842,9 @@ extern "C" int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, con
         else { nsr_set_error("nsr_vmlp_backward: combination not compiled (n_hidden=%d act=%d sdf=%d second=%d)", nh,   \
                              act, (int)sdf, (int)second); return NSR_ERR_INVALID; }                                     \
     }
-    // NSR_VMLP_BACKWARD_V1: the one-wave kernel (A/B switch; the two-wave workgroup is the default)
-    static const bool one_wave = getenv("NSR_VMLP_BACKWARD_V1") != nullptr;
-    if (one_wave)
-        VMLP_DISPATCH(k_vmlp_backward, dim3(blocks), dim3(64), 0, (hipStream_t)stream, blob, x, x_stride, e, enc_stride,
-                      desc->n_in, d_out, d_out_col0, p_in, d_x, dx_stride, dx_first, dx_count, dx_level_major_features,
-                      partials, bf, n, n_full, n_dev);
-    else
-        VMLP_DISPATCH(k_vmlp_backward2, dim3(blocks), dim3(128), 0, (hipStream_t)stream, blob, x, x_stride, e, enc_stride,
-                      desc->n_in, d_out, d_out_col0, p_in, d_x, dx_stride, dx_first, dx_count, dx_level_major_features,
-                      partials, bf, n, n_full, n_dev);
+    VMLP_DISPATCH(k_vmlp_backward, dim3(blocks), dim3(64), 0, (hipStream_t)stream, blob, x, x_stride, e, enc_stride,
+                  desc->n_in, d_out, d_out_col0, p_in, d_x, dx_stride, dx_first, dx_count, dx_level_major_features,
+                  partials, bf, n, n_full, n_dev);
 #undef VMLP_CASE
     NSR_CHECK_LAUNCH("nsr_vmlp_backward");
     if (!accumulate)

@@ -86,3 +86,23 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".sh")):
                 assert not pat.search(open(os.path.join(dirpath, f)).read()), f"{f} uses the oracle"
+
+
+def test_no_shipped_kernel_spills_registers():
+    """code-object notes of the built library (tools/kernel_meta.py): every gfx950 kernel keeps its live values in registers
+    -- vgpr_spill_count == 0, no scratch memory.  (Round 2 shipped fp32-MLP backward variants with 57-152 spilled VGPRs: the
+    per-column store offsets had been hoisted out of the tile loop.)  Also: the MFMA kernels are really there."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_meta
+    import nsr_hip
+    meta = kernel_meta.kernel_meta(nsr_hip.LIB_PATH)
+    assert len(meta) > 200, len(meta)
+    bad = {k: v for k, v in meta.items() if v["spill"] or v["sgpr_spill"] or v["scratch"]}
+    assert not bad, {k[:80]: v for k, v in bad.items()}
+    names = kernel_meta.demangle(sorted(meta))
+    for must in ("k_vmlp_backward<", "k_vmlp_forward<", "k_mlp_forward", "k_grid_backward_owner<", "k_grid_forward"):
+        assert any(must in n for n in names), must
+    # one workgroup per CU is not a requirement any more: the owner-computes table backward runs 2^11-entry slices / 256 threads
+    owner = [meta[k] for k, n in zip(sorted(meta), names) if "k_grid_backward_owner<2, 0>" in n]
+    assert owner and owner[0]["wg"] == 256 and owner[0]["vgpr"] <= 128

@@ -14,23 +14,26 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def code_objects(path):
-    """paths of the gfx950 code objects bundled in `path` (an object file or shared library built by hipcc)"""
+    """paths of the gfx950 code objects bundled in `path` (an object file or shared library built by hipcc; a linked
+    library holds one clang offload bundle per translation unit, back to back in its .hip_fatbin section)"""
     out = tempfile.mkdtemp(prefix="nsr_co_")
-    co = os.path.join(out, "gfx950.co")
-    r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={path}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True, text=True)
-    if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
-        # a linked .so holds the bundle in a section: extract it first
-        sec = os.path.join(out, "bundle.bin")
-        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={sec}", path],
-                       capture_output=True)
-        if not os.path.exists(sec):
-            raise RuntimeError(f"no gfx950 code object in {path}: {r.stderr[:300]}")
-        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={sec}",
+    sec = os.path.join(out, "fatbin.bin")
+    subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={sec}", path], capture_output=True)
+    if not os.path.exists(sec):
+        return []  # host-only object
+    blob = open(sec, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m for m in range(len(blob)) if blob.startswith(magic, m)]
+    cos = []
+    for k, a in enumerate(starts):
+        piece = os.path.join(out, f"bundle{k}.bin")
+        open(piece, "wb").write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        co = os.path.join(out, f"gfx950_{k}.co")
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={piece}",
                             "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(r.stderr[:300])
-    return [co]
+        if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0:
+            cos.append(co)
+    return cos
 
 
 def kernel_meta(path):
