@@ -98,7 +98,8 @@ def test_no_shipped_kernel_spills_registers():
     import nsr_hip
     meta = kernel_meta.kernel_meta(nsr_hip.LIB_PATH)
     assert len(meta) > 200, len(meta)
-    bad = {k: v for k, v in meta.items() if v["spill"] or v["sgpr_spill"] or v["scratch"]}
+    # (SGPR "spills" go to lanes of a VGPR -- v_writelane, no memory -- and are not counted; what must not exist is scratch)
+    bad = {k: v for k, v in meta.items() if v["spill"] or v["scratch"]}
     assert not bad, {k[:80]: v for k, v in bad.items()}
     names = kernel_meta.demangle(sorted(meta))
     for must in ("k_vmlp_backward<", "k_vmlp_forward<", "k_mlp_forward", "k_grid_backward_owner<", "k_grid_forward"):
