@@ -212,19 +212,24 @@ k_copy_ray_prefix_rows(const int32_t *__restrict__ packed_old, const int32_t *__
 // planes of 1 dword; density-MLP output: 32 B; NH saved activation rows: 128 B each): ONE LANE PER KEPT SAMPLE issues the
 // loads of all its rows before the first store, so a ray costs one memory round trip instead of one per array -- a ray
 // keeps ~13 samples, the copy is latency-, not bandwidth-bound.  Also writes ray_indices and the texture input.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // a NATIVE 16-byte vector: arrays of HIP's uint4 (a struct
+                                                             // around a union) are not promoted to registers
 struct KeptRows {
     const float *t0_s, *t1_s, *x01_s;
     const uint32_t *enc_s;
-    const uint4 *out1_s, *acts_s;
+    const u32x4 *out1_s, *acts_s;
     float *t0_d, *t1_d, *x01_d;
     uint32_t *enc_d;
-    uint4 *out1_d, *acts_d;
+    u32x4 *out1_d, *acts_d;
     uint64_t enc_sp, enc_dp;  // plane strides (dwords)
     uint64_t acts_sl, acts_dl;  // hidden-layer strides (uint4 units)
     uint32_t planes;
 };
 
-template <int NH>
+// PLANES16: exactly 16 encoding planes (every reference config: 16 levels x 2 features) -- the body is then straight-line
+// code and every row stays in registers; with the generic plane loop in between, the compiler kept the activation rows in
+// SCRATCH (an un-promoted 128-byte array per hidden layer: 8 + 8 scratch round trips per sample on the step's critical path)
+template <int NH, bool PLANES16>
 __global__ void __launch_bounds__(R_BLOCK)
 k_copy_kept_rows(const int32_t *__restrict__ packed_old, const int32_t *__restrict__ packed_new, const KeptRows kr,
                  const float *__restrict__ rays_d, int64_t *__restrict__ ri_o, __half *__restrict__ tex_in,
@@ -235,26 +240,42 @@ k_copy_kept_rows(const int32_t *__restrict__ packed_old, const int32_t *__restri
     const uint32_t src = (uint32_t)packed_old[2ull * r];
     const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
     if (cnt == 0) return;
-    __half2 sh[8];
-    sh4_of_dir(rays_d[3ull * r], rays_d[3ull * r + 1], rays_d[3ull * r + 2], sh);
+    u32x4 sh_lo, sh_hi;  // (by value: punning an array of half2 through a pointer would put it -- and the rows below -- in scratch)
+    {
+        __half2 sh[8];
+        sh4_of_dir(rays_d[3ull * r], rays_d[3ull * r + 1], rays_d[3ull * r + 2], sh);
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = __builtin_bit_cast(uint32_t, sh[q]);
+        sh_lo = u32x4{w[0], w[1], w[2], w[3]};
+        sh_hi = u32x4{w[4], w[5], w[6], w[7]};
+    }
     for (uint32_t k = lane; k < cnt; k += 64) {
         const uint64_t i = src + k, o = dst + k;
         const float a0 = kr.t0_s[i], a1 = kr.t1_s[i];
         const float p0 = kr.x01_s[3 * i], p1 = kr.x01_s[3 * i + 1], p2 = kr.x01_s[3 * i + 2];
-        const uint4 f0 = kr.out1_s[2 * i], f1 = kr.out1_s[2 * i + 1];
-        uint4 act[NH][8];
+        const u32x4 f0 = kr.out1_s[2 * i], f1 = kr.out1_s[2 * i + 1];
+        u32x4 act[NH][8];
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int j = 0; j < 8; ++j) act[h][j] = kr.acts_s[h * kr.acts_sl + 8 * i + j];
-        for (uint32_t pb = 0; pb < kr.planes; pb += 16) {  // 16 encoding planes in flight per pass
+        if constexpr (PLANES16) {
             uint32_t e[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (pb + j < kr.planes) e[j] = kr.enc_s[(pb + j) * kr.enc_sp + i];
+            for (int j = 0; j < 16; ++j) e[j] = kr.enc_s[j * kr.enc_sp + i];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (pb + j < kr.planes) kr.enc_d[(pb + j) * kr.enc_dp + o] = e[j];
+            for (int j = 0; j < 16; ++j) kr.enc_d[j * kr.enc_dp + o] = e[j];
+        } else {
+            for (uint32_t pb = 0; pb < kr.planes; pb += 16) {  // 16 encoding planes in flight per pass
+                uint32_t e[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (pb + j < kr.planes) e[j] = kr.enc_s[(pb + j) * kr.enc_sp + i];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (pb + j < kr.planes) kr.enc_d[(pb + j) * kr.enc_dp + o] = e[j];
+            }
         }
         kr.t0_d[o] = a0;
         kr.t1_d[o] = a1;
@@ -265,11 +286,11 @@ k_copy_kept_rows(const int32_t *__restrict__ packed_old, const int32_t *__restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) kr.acts_d[h * kr.acts_dl + 8 * o + j] = act[h][j];
         ri_o[o] = (int64_t)r;
-        uint4 *t = reinterpret_cast<uint4 *>(tex_in + o * 32);
+        u32x4 *t = reinterpret_cast<u32x4 *>(tex_in + o * 32);
         t[0] = f0;
         t[1] = f1;
-        t[2] = *reinterpret_cast<uint4 *>(&sh[0]);
-        t[3] = *reinterpret_cast<uint4 *>(&sh[4]);
+        t[2] = sh_lo;
+        t[3] = sh_hi;
     }
 }
 
@@ -815,17 +836,23 @@ extern "C" int nsr_nerf_copy_kept_rows(const int32_t *packed_marched, const int3
     NSR_REQUIRE(n_hidden >= 1 && n_hidden <= 2, "nsr_nerf_copy_kept_rows: 1 or 2 hidden layers");
     KeptRows kr;
     kr.t0_s = t_starts; kr.t1_s = t_ends; kr.x01_s = x01;
-    kr.enc_s = (const uint32_t *)enc; kr.out1_s = (const uint4 *)out1; kr.acts_s = (const uint4 *)acts1;
+    kr.enc_s = (const uint32_t *)enc; kr.out1_s = (const u32x4 *)out1; kr.acts_s = (const u32x4 *)acts1;
     kr.t0_d = t_starts_out; kr.t1_d = t_ends_out; kr.x01_d = x01_out;
-    kr.enc_d = (uint32_t *)enc_out; kr.out1_d = (uint4 *)out1_out; kr.acts_d = (uint4 *)acts1_out;
+    kr.enc_d = (uint32_t *)enc_out; kr.out1_d = (u32x4 *)out1_out; kr.acts_d = (u32x4 *)acts1_out;
     kr.enc_sp = marched_capacity; kr.enc_dp = kept_capacity;
     kr.acts_sl = (uint64_t)marched_capacity * 8; kr.acts_dl = (uint64_t)kept_capacity * 8;
     kr.planes = n_levels;
-    if (n_hidden == 1)
-        hipLaunchKernelGGL((k_copy_kept_rows<1>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
+    if (n_hidden == 1 && n_levels == 16)
+        hipLaunchKernelGGL((k_copy_kept_rows<1, true>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
+                           ray_indices_out, (__half *)tex_in, n_rays);
+    else if (n_hidden == 2 && n_levels == 16)
+        hipLaunchKernelGGL((k_copy_kept_rows<2, true>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
+                           ray_indices_out, (__half *)tex_in, n_rays);
+    else if (n_hidden == 1)
+        hipLaunchKernelGGL((k_copy_kept_rows<1, false>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
                            ray_indices_out, (__half *)tex_in, n_rays);
     else
-        hipLaunchKernelGGL((k_copy_kept_rows<2>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
+        hipLaunchKernelGGL((k_copy_kept_rows<2, false>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
                            ray_indices_out, (__half *)tex_in, n_rays);
     NSR_CHECK_LAUNCH("nsr_nerf_copy_kept_rows");
     return NSR_OK;
