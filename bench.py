@@ -189,12 +189,13 @@ def cpu_config0_step(cores, seconds_budget=5.0):
 
 def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
     """HBM-side bytes per launch of the dominant operation from the PMC passes of THIS round (tools/collect_profiles.sh ->
-    profiles/r02_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
+    profiles/r03_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
     run in) -- used only when a pass ran in the same regime (same warmup / steps, or its recorded samples per launch
     within 15 % of this run's); otherwise the field is null"""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None, "no PMC file for this round"
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"))
+                 if os.path.exists(q)), None)
+    if path is None:
+        return None, "no PMC file"
     pmc = json.load(open(path))
     regimes = pmc.get("regimes")
     if regimes:  # pick the pass that ran with this command line, else the closest one by samples per launch
@@ -210,7 +211,7 @@ def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
     if not 0.85 <= ratio <= 1.15:
         return None, (f"PMC passes ran at {ent['samples_per_launch']:.0f} samples/launch, this run at "
                       f"{samples_per_launch:.0f}: not comparable")
-    return ent["bytes_per_launch"], f"profiles/r02_pmc_traffic.json ({ent['samples_per_launch']:.0f} samples/launch)"
+    return ent["bytes_per_launch"], f"profiles/{os.path.basename(path)} ({ent['samples_per_launch']:.0f} samples/launch)"
 
 
 def other_workloads(dev, rank=0, world=1, sync=None, n_steps=60):

@@ -1,21 +1,27 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): final bench line, rocprofv3 kernel summary + timeline, PMC traffic passes.
-# Writes small summaries under gpurun_out/$1/ ; copy what should be judged into profiles/.
+# Run ON THE GPU BOX (through gpurun): bench lines in both regimes, rocprofv3 kernel summaries + timeline for both, PMC
+# traffic passes for both, kernel breakdowns of the three NeuS workloads, the boundary-path timeline, micro-benchmarks.
+# Writes small summaries under gpurun_out/$1/ ; copy what should be judged into profiles/ (tools/install_profiles.sh).
 set -u
-tag="${1:-r01_final}"; out="/root/repo/gpurun_out/$tag"; mkdir -p "$out"
+tag="${1:-r03_final}"; out="/root/repo/gpurun_out/$tag"; mkdir -p "$out"
 cd /root/repo
-python bench.py > "$out/bench.json" 2> "$out/bench.stderr"; tail -c 400 "$out/bench.json"; echo
+python bench.py > "$out/bench_w300_s200.json" 2> "$out/bench_w300_s200.stderr"; tail -c 300 "$out/bench_w300_s200.json"; echo
+python bench.py --steps 20 --warmup 5 > "$out/bench_w5_s20.json" 2> "$out/bench_w5_s20.stderr"; tail -c 200 "$out/bench_w5_s20.json"; echo
+LEAN="--no-cpu-baseline --no-other-workloads --no-boundary-path"
+export NSR_BENCH_NO_STEADY=1
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o k -- python /root/repo/bench.py --steps 100 --warmup 300 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2>/dev/null
-cp "$(find /tmp/pk -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
-python /root/repo/tools/trace_tail.py "$(find /tmp/pk -name '*kernel_trace.csv' | head -1)" "$out/timeline_tail.csv" 2400
-# PMC passes (separate --pmc runs, kernel trace only): once in the default regime and once with the short command line the
-# round-end driver has used (--steps 20 --warmup 5), so that bench.py finds measured traffic for either
+for regime in "300 200" "5 20"; do
+  set -- $regime; w=$1; st=$2
+  rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o k -- python /root/repo/bench.py --steps $st --warmup $w $LEAN > "$out/bench_under_rocprof_w${w}_s${st}.json" 2>/dev/null
+  cp "$(find /tmp/pk -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_w${w}_s${st}.csv"
+  python /root/repo/tools/trace_tail.py "$(find /tmp/pk -name '*kernel_trace.csv' | head -1)" "$out/timeline_tail_w${w}_s${st}.csv" 2400
+done
+# PMC passes (separate --pmc runs, kernel trace only), once per command line, so that bench.py finds measured traffic for either
 for regime in "300 200" "5 20"; do
   set -- $regime; w=$1; st=$2; rd="$out/pmc_w${w}_s${st}"; mkdir -p "$rd"
   for c in FETCH_SIZE WRITE_SIZE; do
     for attempt in 1 2 3 4 5; do  # rocprofv3 --pmc occasionally segfaults at exit on this image: retry, the passes are independent
-      rm -rf /tmp/pc && NSR_BENCH_REGIME_OUT="$rd/bench_regime.json" rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pc -o c -- python /root/repo/bench.py --steps $st --warmup $w --no-cpu-baseline > /dev/null 2>&1
+      rm -rf /tmp/pc && NSR_BENCH_REGIME_OUT="$rd/bench_regime.json" rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pc -o c -- python /root/repo/bench.py --steps $st --warmup $w $LEAN > /dev/null 2>&1
       f="$(find /tmp/pc -name '*counter_collection.csv' 2>/dev/null | head -1)"
       if [ -n "$f" ]; then python /root/repo/tools/pmc_summary.py "$f" $c "$rd/bench_regime.json" > "$rd/pmc_$c.json" && break; fi
     done
@@ -34,4 +40,16 @@ json.dump({"_what": "HBM-side traffic per launch from rocprofv3 --pmc FETCH_SIZE
                     "(warmup, steps) command line; see tools/pmc_traffic.py", "regimes": regimes},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 PY
+unset NSR_BENCH_NO_STEADY
+# the three NeuS workloads at the reference's operating point: kernel breakdown of the fused step
+for c in neus-blender neus-dtu neuralangelo; do
+  rm -rf /tmp/pn && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pn -o k -- python /root/repo/tools/neus_step_bench.py --config $c --dynamic --steps 60 --warmup 60 > "$out/neus_step_$c.json" 2>/dev/null
+  cp "$(find /tmp/pn -name '*kernel_stats.csv' | head -1)" "$out/fused_${c}_kernel_stats.csv"
+done
+# the step through the model interface (bench.py boundary_path): phases and kernel timeline
+cd /root/repo
+python tools/boundary_profile.py > "$out/boundary_phases.json" 2>/dev/null
+NSR_BP_NOSYNC=1 tools/timeline_tail.sh "$out/boundary_timeline_tail.csv" 3000 -- python /root/repo/tools/boundary_profile.py > "$out/boundary_timeline_summary.txt" 2>&1
+python tools/kernel_microbench.py > "$out/microbench.json" 2>/dev/null
+python tools/table_backward_variants.py instant-nsr-pl_amd/nsr_hip/libnsr_hip.so > "$out/table_backward_isolated.json" 2>/dev/null
 ls -la "$out"

@@ -7,7 +7,7 @@ f="$(find /tmp/tt -name '*kernel_trace.csv' | head -1)"
 python /root/repo/tools/trace_tail.py "$f" "$out" "$n"
 python - "$out" <<'PY'
 import csv, sys, collections
-rows = [r for r in csv.reader(open(sys.argv[1]))]
+rows = [(r[0], r[1], r[2], ",".join(r[3:])) for r in csv.reader(open(sys.argv[1]))]
 tot = collections.defaultdict(lambda: [0.0, 0])
 for s, e, q, k in rows:
     tot[k][0] += float(e) - float(s); tot[k][1] += 1
