@@ -101,6 +101,12 @@ int nsr_hashgrid_backward_params_owner_accumulate(const float *x, const void *dy
                                                   uint32_t level_mask_count, float grad_scale, int accumulate,
                                                   const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
 
+/* The owner-computes backward is compiled in two configurations -- 2^11-entry slices x 256 threads (the NeRF step's ~1e5
+ * samples per launch) and 2^13 x 1024 (~1e6-point launches of the NeuS steps) -- and a launch picks by its point count:
+ * more than `n_points` points -> the large one (default 400,000; 0: always, UINT32_MAX: never).  Returns the previous
+ * threshold.  Same results either way (bit-identical on the levels that are not split into chunk slabs). */
+uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points);
+
 /* _accumulate over the run of levels [level_begin, level_end) only (items binned beforehand, dy level-major fp32
  * [L][n][F]), the gradient written either as fp32 into grad_table or as bf16 (round to nearest even) into grad_bf16 --
  * exactly one of the two is non-NULL; both are indexed like the table (entry 0 of level 0 first) and OVERWRITTEN.

@@ -19,6 +19,7 @@
 //     NeuS normal and its double backward are dense products instead of a second and a third table gather, and
 //     k_grid_forward_taps encodes a sample together with its six finite-difference taps from shared corner loads.
 #include <string.h>
+#include <stdlib.h>
 
 #include "nsr_common.h"
 
@@ -474,747 +475,6 @@ k_grid_backward_params(const float *__restrict__ x, const void *__restrict__ dy,
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// backward w.r.t. the table, "owner computes" (the default): NO global atomics.
-//
-// Measured on MI355X: device-scope fp32 atomics retire at ~22 G/s chip-wide (they execute memory-side so
-// that the 8 non-coherent XCD L2s stay consistent) -- 1.13 ms for one 98 k-sample step, 3x everything else.
-// Rays of a batch are i.i.d., so fine-level entries are touched ~once per step: there is no reuse to cache,
-// only the atomic *rate* hurts.  So instead every workgroup OWNS a contiguous slice of one level's gradient
-// that fits the CU's 160 KiB LDS (10240 64-bit pairs), scans ALL samples of that level, recomputes the 8
-// corner indices (a few dozen VALU ops -- the chip has ~100x more VALU than atomic throughput), accumulates
-// the corners that fall into its slice with 64-bit fixed-point LDS atomics (ds_add_u64) and finally stores the slice
-// as fp32 with plain coalesced 16-B stores.  ~750 workgroups cover L=16,T=2^19,F=2; each grad entry is written exactly once, so the
-// 50 MB gradient needs no memset either (accumulate=0).  dy is read level-major ([L][N][F], 8-B coalesced).
-// ------------------------------------------------------------------------------------------------
-// slice size / workgroup size, measured at the NeRF step's operating point (tools/table_backward_variants.py, 9.6e4 coherent
-// samples, accumulate / accumulate + AdamW): 2^13 entries x 1024 threads (one workgroup per CU) 87 / 122 us, 2^12 x 512
-// 77 / 111 us, 2^11 x 256 72 / 105 us -- several small workgroups per CU overlap one's item phase (LDS atomics, latency
-// bound) with another's write-out / AdamW phase (HBM streaming).  More items in flight per lane (batch 4, 8) changed nothing.
-#ifndef NSR_OWN_BLOCK
-#define NSR_OWN_BLOCK 256
-#endif
-#ifndef NSR_OWN_LOG2
-#define NSR_OWN_LOG2 11
-#endif
-#ifndef NSR_OWN_BIN_SPT
-#define NSR_OWN_BIN_SPT 4
-#endif
-constexpr int OWN_BLOCK = NSR_OWN_BLOCK;
-constexpr int OWN_POW2_LOG2 = NSR_OWN_LOG2;            // hashed levels: 8192-entry slices (128 KiB at F=2) -> owner = hash bits
-constexpr int OWN_LDS_WORDS = 2 << NSR_OWN_LOG2;       // 64-bit accumulators (measured: 2^13 119 us, 2^12 133 us, 2^11 124 us)
-constexpr int OWN_TARGET_WGS = 32;      // workgroups per level the decomposition aims for
-#ifndef NSR_OWN_RL_MAX
-#define NSR_OWN_RL_MAX 10
-#endif
-#ifndef NSR_OWN_DENSE_WGS
-#define NSR_OWN_DENSE_WGS 64
-#endif
-#ifndef NSR_OWN_BATCH
-#define NSR_OWN_BATCH 2
-#endif
-constexpr int OWN_DENSE_TARGET_WGS = NSR_OWN_DENSE_WGS; // ... for the dense (coarse) levels: every sample lands in few entries and the
-                                         // workgroups serialise on LDS conflicts -- more, smaller item chunks
-                                         // (measured at 1.28e5 surface samples: 32 -> 185 us, 64 -> 177 us, 128 -> 198 us)
-constexpr int OWN_MAX_SLICES = 2048;    // per level (T = 2^24 at 8192-entry slices)
-constexpr int OWN_BIN_BLOCK = 256;      // threads per block of the two binning passes
-constexpr int OWN_BIN_SPT = NSR_OWN_BIN_SPT;  // samples per thread: fewer, larger blocks -> fewer global range reservations
-constexpr float OWN_FIX_SCALE = 68719476736.f;          // 2^36: accumulators are Q27.36 fixed point
-constexpr float OWN_FIX_INV = 1.f / 68719476736.f;
-
-// Decomposition of one level: R slices of its gradient x C item chunks.  C > 1 (small dense levels, where one slice
-// would take every sample and serialise on same-address LDS atomics) writes per-chunk slabs that a second tiny kernel
-// sums; C == 1 stores straight into the gradient.
-struct OwnerMap {
-    // block b runs on XCD b % 8 (round-robin dispatch).  The workgroups of every level are dealt to ALL XCDs: keeping a
-    // level on one XCD (its L2 then serves dy to every slice) was measured slower -- 11 hashed levels do not divide
-    // over 8 XCDs, and the slowest XCD sets the kernel time (1.28e5 samples: 201 us whole-level vs 177 us dealt).
-    uint32_t level_start[NSR_MAX_LEVELS];  // first row (b / 8) of the level; rows [start, start + ceil(wgs / 8))
-    uint32_t n_slices[NSR_MAX_LEVELS];
-    uint32_t n_chunks[NSR_MAX_LEVELS];
-    uint32_t slab_offset[NSR_MAX_LEVELS];  // floats, into the slab workspace (levels with n_chunks > 1)
-    uint32_t entries_per_slice[NSR_MAX_LEVELS];
-    uint32_t bin_offset[NSR_MAX_LEVELS];   // first (level, slice) bin of the level in the counter arrays
-};
-
-// LDS float atomics retire at ~0.33 lane-ops/clk/CU on gfx950, 64-bit INTEGER ones at ~5 (tools/lds_atomics_bench.hip),
-// so the slices accumulate in Q27.36 fixed point: 15x the rate, 1.5e-11 resolution (the reference's tcnn accumulates
-// this gradient in fp16), and -- integer addition being associative -- a bit-reproducible gradient on every level that is
-// not split into chunk slabs (the slabs of the small dense levels are summed in fp32).
-// t = value * 2^36 (|t| < 2^62) -> two's complement int64, built from exact fp32 pieces of |t|.
-__device__ __forceinline__ unsigned long long own_to_fixed(float t)
-{
-    const float a = fabsf(t);
-    const float th = floorf(a * 2.3283064365386963e-10f);  // floor(|t| / 2^32): the high word
-    const float tl = rintf(fmaf(th, -4294967296.f, a));     // |t| - th * 2^32 in [0, 2^32): exact before the rint
-    const unsigned long long v = ((unsigned long long)(uint32_t)th << 32) | (uint32_t)tl;
-    return t < 0.f ? 0ull - v : v;
-}
-
-__device__ __forceinline__ float own_from_fixed(unsigned long long v) { return (float)(long long)v * OWN_FIX_INV; }
-
-// An ITEM is one (y,z) corner pair of one sample on one level: the two x-neighbours share every hash/stride term and
-// nearly always the owning slice.  word = sample << 4 | pair << 2 | mode, mode 0: both corners, 1: only x0, 2: only
-// x0+1 (the pair straddles two slices: dense levels at a slice border or at the wrap-around of the last entries).
-struct PairSlices { uint32_t s0, s1; };
-
-__device__ __forceinline__ PairSlices pair_slices(const LevelGeom &g, const Cell &c, int k, uint32_t epb, bool pow2)
-{
-    const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
-    PairSlices p;
-    if (pow2) {  // x never reaches the slice bits of a hashed level cut into 2^OWN_POW2_LOG2-entry slices
-        const uint32_t h = (cy * PRIME_Y) ^ (cz * PRIME_Z);
-        p.s0 = p.s1 = (h & (g.size - 1u)) >> OWN_POW2_LOG2;
-    } else {
-        p.s0 = corner_index(g, c.c[0], cy, cz) / epb;
-        p.s1 = corner_index(g, c.c[0] + 1u, cy, cz) / epb;
-    }
-    return p;
-}
-
-__device__ __forceinline__ bool own_is_pow2(const LevelGeom &g, uint32_t epb)
-{
-    return !g.dense && epb == (1u << OWN_POW2_LOG2) && (g.size & (g.size - 1u)) == 0u && g.res < (1u << OWN_POW2_LOG2);
-}
-
-
-// ---- finite-difference stencils (neuralangelo, models/geometry.py:181-199): the table gradient of N samples x 7 points --
-// The points of a sample are its position and six +-eps taps (layout [7][N][3], taps clamped to the box).  A tap that stays
-// in the sample's cell of a level moves ONE coordinate inside a trilinear cell, so its corner weights are
-// w(x) + delta * d w / d x_a exactly: everything those taps and the centre contribute to the cell's 8 corners is
-//      w_c * G0  +  sum_a (d w_c / d x_a) * D_a ,    G0 = sum of their dy,  D_a = sum of delta * dy over the taps of axis a
-// (delta in grid units, signed, the clamped taps' actual offsets).  Only taps that CROSS into a neighbouring cell keep
-// items of their own.  At level 16 that is 16 merged + ~24 crossing point-items per sample instead of 112.
-// cross[l][s]: bit t-1 set = tap t is in another cell than the centre on level l.
-__global__ void __launch_bounds__(256)
-k_tap_cross(const float *__restrict__ x7, uint32_t n_c, uint32_t mask_count, uint8_t *__restrict__ cross,
-            const NsrGridDesc d)
-{
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x, level = blockIdx.y;
-    if (s >= n_c || level >= mask_count) return;
-    const LevelGeom g = load_level(d, level);
-    const Cell c0 = locate(g, x7[3ull * s], x7[3ull * s + 1], x7[3ull * s + 2]);
-    uint32_t m = 0;
-#pragma unroll
-    for (int t = 1; t < 7; ++t) {
-        const uint64_t i = (uint64_t)t * n_c + s;
-        const Cell ct = locate(g, x7[3 * i], x7[3 * i + 1], x7[3 * i + 2]);
-        if (ct.c[0] != c0.c[0] || ct.c[1] != c0.c[1] || ct.c[2] != c0.c[2]) m |= 1u << (t - 1);
-    }
-    cross[(uint64_t)level * n_c + s] = (uint8_t)m;
-}
-
-// G0 [L][N][F] and D [L][N][3][F] from the level-major dy of all 7N points ([L][7N][F])
-template <int F>
-__global__ void __launch_bounds__(256)
-k_tap_reduce(const float *__restrict__ x7, const float *__restrict__ dy_lm, const uint8_t *__restrict__ cross,
-             uint32_t n_c, uint32_t mask_count, float *__restrict__ g0, float *__restrict__ dd, const NsrGridDesc d)
-{
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x, level = blockIdx.y;
-    if (s >= n_c || level >= mask_count) return;
-    const float scale = d.scale[level];
-    const uint32_t m = cross[(uint64_t)level * n_c + s];
-    const float *dyl = dy_lm + (uint64_t)level * 7ull * n_c * F;
-    float G[F], D[3][F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) { G[f] = dyl[(uint64_t)s * F + f]; D[0][f] = D[1][f] = D[2][f] = 0.f; }
-#pragma unroll
-    for (int t = 1; t < 7; ++t) {
-        if (m & (1u << (t - 1))) continue;
-        const int a = (t - 1) >> 1;
-        const uint64_t i = (uint64_t)t * n_c + s;
-        // same arithmetic as locate(): the offset of the tap inside the cell, in grid units
-        const float delta = fmaf(scale, x7[3 * i + a], 0.5f) - fmaf(scale, x7[3ull * s + a], 0.5f);
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const float gv = dyl[i * F + f];
-            G[f] += gv;
-            D[a][f] = fmaf(delta, gv, D[a][f]);
-        }
-    }
-    const uint64_t o = (uint64_t)level * n_c + s;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-        g0[o * F + f] = G[f];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) dd[(o * 3 + a) * F + f] = D[a][f];
-    }
-}
-
-// pass 1 (FILL = false): counts[bin] = number of items per (level, slice).
-// pass 2 (FILL = true):  items[level][bin_start + ...] = item words; a block reserves one contiguous range per bin.
-// grid (ceil(n / (OWN_BIN_BLOCK * OWN_BIN_SPT)), L)
-template <bool FILL>
-__global__ void __launch_bounds__(OWN_BIN_BLOCK)
-k_own_bin(const float *__restrict__ x, uint32_t n, uint32_t mask_count, uint32_t *__restrict__ counts,
-          const uint32_t *__restrict__ bin_start, uint32_t *__restrict__ cursors, uint32_t *__restrict__ items,
-          const OwnerMap om, const NsrGridDesc d, const int32_t *__restrict__ n_dev,
-          const uint8_t *__restrict__ cross /* stencil mode: tap points that stay in their sample's cell emit no items */,
-          uint32_t n_c)
-{
-    __shared__ uint32_t hist[OWN_MAX_SLICES];
-    const uint32_t level = blockIdx.y;
-    if (level >= mask_count) return;
-    const uint32_t n_live = live_count(n, n_dev);  // n stays the stride of the per-level item regions
-    if (blockIdx.x * OWN_BIN_SPT * OWN_BIN_BLOCK >= n_live) return;
-    const uint32_t R = om.n_slices[level], epb = om.entries_per_slice[level], bin0 = om.bin_offset[level];
-    const LevelGeom g = load_level(d, level);
-    const bool pow2 = own_is_pow2(g, epb);
-    for (uint32_t s = threadIdx.x; s < R; s += OWN_BIN_BLOCK) hist[s] = 0u;
-    __syncthreads();
-    uint32_t slice[OWN_BIN_SPT][8], rank[OWN_BIN_SPT][8];
-#pragma unroll
-    for (int u = 0; u < OWN_BIN_SPT; ++u) {
-        const uint32_t i = (blockIdx.x * OWN_BIN_SPT + u) * OWN_BIN_BLOCK + threadIdx.x;
-        bool emit = i < n_live;
-        if (emit && cross && i >= n_c) {
-            const uint32_t t = i / n_c, sc = i - t * n_c;
-            emit = (cross[(uint64_t)level * n_c + sc] >> (t - 1)) & 1u;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) slice[u][q] = 0xffffffffu;
-        if (emit) {
-            const Cell c = locate(g, x[3ull * i], x[3ull * i + 1], x[3ull * i + 2]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const PairSlices p = pair_slices(g, c, k, epb, pow2);
-                // slot 2k: the pair (or its x0 half), slot 2k+1: the x0+1 half of a straddling pair
-                slice[u][2 * k] = p.s0;
-                rank[u][2 * k] = atomicAdd(&hist[p.s0], 1u);
-                slice[u][2 * k + 1] = p.s1 != p.s0 ? p.s1 : 0xffffffffu;
-                if (p.s1 != p.s0) rank[u][2 * k + 1] = atomicAdd(&hist[p.s1], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    if constexpr (!FILL) {
-        for (uint32_t s = threadIdx.x; s < R; s += OWN_BIN_BLOCK)
-            if (hist[s]) atomicAdd(&counts[bin0 + s], hist[s]);
-    } else {
-        // reserve this block's range in every bin it touches; hist[s] becomes the range's first item index
-        for (uint32_t s = threadIdx.x; s < R; s += OWN_BIN_BLOCK)
-            if (hist[s]) hist[s] = bin_start[bin0 + s] + atomicAdd(&cursors[bin0 + s], hist[s]);
-        __syncthreads();
-        uint32_t *dst = items + (uint64_t)level * n * 8ull;
-#pragma unroll
-        for (int u = 0; u < OWN_BIN_SPT; ++u) {
-            const uint32_t i = (blockIdx.x * OWN_BIN_SPT + u) * OWN_BIN_BLOCK + threadIdx.x;
-            if (i >= n_live) continue;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (slice[u][q] == 0xffffffffu) continue;  // (also: a tap point that emits nothing)
-                const bool straddle = slice[u][q | 1] != 0xffffffffu;
-                const uint32_t mode = !straddle ? 0u : ((q & 1) ? 2u : 1u);
-                dst[hist[slice[u][q]] + rank[u][q]] = (i << 4) | ((uint32_t)(q >> 1) << 2) | mode;
-            }
-        }
-    }
-}
-
-// per level: exclusive prefix of the bin counts -> bin_start; clears the fill cursors.  grid (L), block 256
-__global__ void __launch_bounds__(256)
-k_own_bin_scan(const uint32_t *__restrict__ counts, uint32_t *__restrict__ bin_start, uint32_t *__restrict__ cursors,
-               const OwnerMap om)
-{
-    __shared__ uint32_t part[256];
-    const uint32_t level = blockIdx.x, R = om.n_slices[level], bin0 = om.bin_offset[level];
-    const uint32_t per = (R + 255u) / 256u, b = threadIdx.x * per, e = min(R, b + per);
-    uint32_t sum = 0;
-    for (uint32_t s = b; s < e; ++s) sum += counts[bin0 + s];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < 256; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; }
-    }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
-    for (uint32_t s = b; s < e; ++s) {
-        bin_start[bin0 + s] = run;
-        run += counts[bin0 + s];
-        cursors[bin0 + s] = 0u;
-    }
-}
-
-template <int F>
-__device__ __forceinline__ void lds_add(unsigned long long *acc, uint32_t rel, float w, const float (&g)[F])
-{
-#pragma unroll
-    for (int f = 0; f < F; ++f) atomicAdd(&acc[rel * F + f], own_to_fixed(w * g[f]));
-}
-
-template <int F>
-__device__ __forceinline__ void lds_add2(unsigned long long *acc, uint32_t rel, float w, const float (&g)[F], float w2,
-                                         const float (&g2)[F])
-{
-#pragma unroll
-    for (int f = 0; f < F; ++f) atomicAdd(&acc[rel * F + f], own_to_fixed(w * g[f] + w2 * g2[f]));
-}
-
-// Optional fused optimizer: the workgroup that owns a slice holds its finished gradient in LDS, so it applies AdamW to
-// that slice right there (reads p / m / v, writes them + the fp16 image) instead of storing the gradient for a separate
-// kernel to read back -- 8 B / parameter less HBM traffic and one 60 us kernel less on the step's critical path.
-// Same arithmetic as csrc/util.hip (nsr_adamw_elem / nsr_adam_schedule): bit-identical parameters.
-struct OwnerAdam {
-    float *p, *m, *v;  // the TABLE slice of the parameter / moment vectors (entry 0 of level 0 first); NULL p: off
-    __half *shadow;
-    const int32_t *step;
-    const float *hyper;
-    double base_lr, b1d, b2d, gamma;
-    int32_t m0, m1, m2;
-    float b1, b2, eps, wd;
-};
-
-template <int F>
-__device__ __forceinline__ void owner_adam4(const OwnerAdam &ad, uint64_t idx, const float (&gr)[4], float lr, float bc1,
-                                            float bc2)
-{
-    float4 pp = *reinterpret_cast<const float4 *>(ad.p + idx), mm = *reinterpret_cast<const float4 *>(ad.m + idx);
-    float4 vv = *reinterpret_cast<const float4 *>(ad.v + idx);
-    float *pa = &pp.x, *ma = &mm.x, *va = &vv.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) nsr_adamw_elem(pa[k], ma[k], va[k], gr[k], lr, ad.b1, ad.b2, ad.eps, ad.wd, bc1, bc2);
-    *reinterpret_cast<float4 *>(ad.p + idx) = pp;
-    *reinterpret_cast<float4 *>(ad.m + idx) = mm;
-    *reinterpret_cast<float4 *>(ad.v + idx) = vv;
-    if (ad.shadow) {
-        __half2 h[2] = {__floats2half2_rn(pa[0], pa[1]), __floats2half2_rn(pa[2], pa[3])};
-        *reinterpret_cast<uint2 *>(ad.shadow + idx) = *reinterpret_cast<uint2 *>(h);
-    }
-}
-
-// Workgroup (level, slice, chunk): accumulates ITS items -- every lane busy, no scan over foreign samples.
-// MODE 0: plain.  MODE 1: stencil mode (see k_tap_cross / k_tap_reduce): items of points < taps_nc carry the merged centre +
-// in-cell taps.  MODE 2: second-order use (`dir` != NULL, optionally with the first-order term dy_first_lm of the same items).
-// (Both are of the form  w_c G0 + sum_a (d w_c / d x_a) D_a  per corner -- mode 2 with G0 = dy_first, D_a = scale dir_a dy --
-// but giving mode 2 the dense levels' run-length walk was measured slower: C3 2.96 -> 3.28 ms.)
-template <int F, int MODE>
-__global__ void __launch_bounds__(OWN_BLOCK)
-k_grid_backward_owner(const float *__restrict__ x, const float *__restrict__ dy_lm /* [L][n][F] */,
-                      const uint32_t *__restrict__ items, const uint32_t *__restrict__ counts,
-                      const uint32_t *__restrict__ bin_start, float *__restrict__ grad_table,
-                      float *__restrict__ slabs, uint32_t n, uint32_t mask_count, float grad_scale, int accumulate,
-                      const OwnerMap om, const NsrGridDesc d, const float *__restrict__ dir,
-                      const float *__restrict__ dy_first_lm /* with dir: first-order term of the SAME items, or NULL */,
-                      const OwnerAdam ad, uint32_t taps_nc /* stencil mode: points < taps_nc are merged centre items */,
-                      const float *__restrict__ tap_g0 /* [L][taps_nc][F] */, const float *__restrict__ tap_dd /* [L][taps_nc][3][F] */,
-                      uint16_t *__restrict__ grad_bf16 /* non-NULL: the gradient leaves as bf16 (the multi-GPU transport buffer) */,
-                      uint32_t row_base /* first block row of this launch: a launch may cover a run of levels only */)
-{
-    constexpr bool TAPS = MODE == 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
-    __shared__ float s_hyper[3];
-    if (ad.p && threadIdx.x == 64) {  // a lane of the second wave: the schedule arithmetic (doubles) runs beside the LDS clear
-        double p1, p2;
-        nsr_adam_schedule(ad.step, ad.hyper, ad.base_lr, ad.b1d, ad.b2d, ad.gamma, ad.m0, ad.m1, ad.m2, s_hyper[0],
-                          s_hyper[1], s_hyper[2], p1, p2);
-    }
-    __shared__ uint32_t s_nonfinite;  // an inf / NaN gradient reached this slice: it is flushed as NaN (GradScaler's
-                                      // found_inf must fire exactly as it does with tcnn's fp16 atomics), never clamped away
-    if (threadIdx.x == 0) s_nonfinite = 0u;
-    const uint32_t xcd = blockIdx.x & 7u, j = (blockIdx.x >> 3) + row_base;
-    uint32_t level = d.n_levels;
-    uint32_t local = 0;
-    for (uint32_t l = 0; l < d.n_levels; ++l) {
-        const uint32_t wgs = om.n_slices[l] * om.n_chunks[l];
-        const uint32_t t = (j - om.level_start[l]) * 8u + xcd;
-        if (j >= om.level_start[l] && t < wgs) { level = l; local = t; }
-    }
-    if (level == d.n_levels) return;  // padding block of a lighter XCD
-    const uint32_t C = om.n_chunks[level], epb = om.entries_per_slice[level];
-    const uint32_t slice = local / C, chunk = local % C;
-    const uint32_t r0 = slice * epb;
-    const LevelGeom g = load_level(d, level);
-    const uint32_t cnt = min(epb, g.size - r0);
-    for (uint32_t k = threadIdx.x; k < cnt * F; k += OWN_BLOCK) acc[k] = 0ull;
-    __syncthreads();
-    if (level < mask_count) {
-        const uint32_t bin = om.bin_offset[level] + slice;
-        const uint32_t m = counts[bin];
-        const uint32_t per = (m + C - 1) / C;
-        const uint32_t i_beg = min(m, chunk * per), i_end = min(m, (chunk + 1) * per);
-        const uint32_t *it = items + (uint64_t)level * n * 8ull + bin_start[bin];
-        const float *dyl = dy_lm + (uint64_t)level * n * F;
-        const float *dyf = dy_first_lm ? dy_first_lm + (uint64_t)level * n * F : nullptr;
-        const float fix = grad_scale * OWN_FIX_SCALE;
-        constexpr int OWN_BATCH = NSR_OWN_BATCH;  // items in flight per lane: item -> (x, dy) is a dependent load chain
-        const float *g0l = TAPS ? tap_g0 + (uint64_t)level * taps_nc * F : nullptr;
-        const float *ddl = TAPS ? tap_dd + (uint64_t)level * taps_nc * 3 * F : nullptr;
-        // the run-length walk below hands every thread a CONTIGUOUS item range: with many items per thread the lanes of a
-        // wave then read 64 different cache lines per load (measured: 1 M uniform samples 1.28 -> 1.90 ms), so it is used
-        // up to NSR_OWN_RL_MAX items per thread only (the NeRF step has ~6); and not for the second-order mode's heavier items
-        const uint32_t rl_q = (i_end - i_beg + OWN_BLOCK - 1) / OWN_BLOCK;
-        if (g.dense && MODE != 2 && rl_q <= NSR_OWN_RL_MAX) {
-            // Dense (coarse) levels: the binning passes lay the items of a slice down in runs of 64 CONSECUTIVE samples of
-            // one corner pair, and consecutive samples of a ray sit in the same coarse cell for tens of steps -- handing a
-            // wave 64 consecutive items makes its lanes hit the same two LDS words (64-way serialised atomics; DESIGN
-            // section 7.2: levels 0-4 cost half of the kernel).  Here every THREAD walks a contiguous range of items and
-            // keeps a run accumulator per corner in registers: one LDS atomic per (run, feature) instead of one per
-            // (item, feature), and the lanes of a wave work on ranges that are far apart (different cells).
-            const uint32_t m_c = i_end - i_beg, q = (m_c + OWN_BLOCK - 1) / OWN_BLOCK;
-            const uint32_t j0 = min(i_end, i_beg + threadIdx.x * q), j1 = min(i_end, j0 + q);
-            uint32_t key_lo = 0xffffffffu, key_hi = 0xffffffffu;
-            float run_lo[F], run_hi[F];
-#pragma unroll
-            for (int f = 0; f < F; ++f) run_lo[f] = run_hi[f] = 0.f;
-            for (uint32_t jb = j0; jb < j1; jb += OWN_BATCH) {
-                uint32_t word[OWN_BATCH];
-                float gb[OWN_BATCH][F], xb[OWN_BATCH][3], db[OWN_BATCH][3][F];
-#pragma unroll
-                for (int u = 0; u < OWN_BATCH; ++u) word[u] = jb + u < j1 ? it[jb + u] : 0xffffffffu;
-#pragma unroll
-                for (int u = 0; u < OWN_BATCH; ++u) {
-                    const uint32_t s = word[u] != 0xffffffffu ? word[u] >> 4 : 0u;
-                    const bool merged = TAPS && s < taps_nc;
-#pragma unroll
-                    for (int f = 0; f < F; ++f) {
-                        gb[u][f] = merged ? g0l[(uint64_t)s * F + f] : dyl[(uint64_t)s * F + f];
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) db[u][a][f] = merged ? ddl[((uint64_t)s * 3 + a) * F + f] : 0.f;
-                    }
-                    xb[u][0] = x[3ull * s]; xb[u][1] = x[3ull * s + 1]; xb[u][2] = x[3ull * s + 2];
-                }
-#pragma unroll
-                for (int u = 0; u < OWN_BATCH; ++u) {
-                    if (word[u] == 0xffffffffu) continue;
-                    const int k = (word[u] >> 2) & 3;
-                    const uint32_t mode = word[u] & 3u;
-                    const Cell c = locate(g, xb[u][0], xb[u][1], xb[u][2]);
-                    const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
-                    const float a1 = (k & 1) ? c.w[1] : 1.f - c.w[1], a2 = (k & 2) ? c.w[2] : 1.f - c.w[2];
-                    const float a12 = a1 * a2;
-                    const float w_lo = (1.f - c.w[0]) * a12, w_hi = c.w[0] * a12;
-                    const uint32_t e_lo = mode != 2u ? corner_index(g, c.c[0], cy, cz) - r0 : 0xffffffffu;
-                    const uint32_t e_hi = mode != 1u ? corner_index(g, c.c[0] + 1u, cy, cz) - r0 : 0xffffffffu;
-                    // stencil mode, merged centre item: + sum_a (d w / d x_a) D_a  (zero D for plain items)
-                    const float s1 = (k & 1) ? 1.f : -1.f, s2 = (k & 2) ? 1.f : -1.f;
-                    const float dy_lo = (1.f - c.w[0]) * s1 * a2, dy_hi = c.w[0] * s1 * a2;
-                    const float dz_lo = (1.f - c.w[0]) * a1 * s2, dz_hi = c.w[0] * a1 * s2;
-                    float v_lo[F], v_hi[F];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) {
-                        if (!isfinite(gb[u][f])) s_nonfinite = 1u;
-                        if constexpr (MODE == 1) {
-                            if (!isfinite(db[u][0][f]) || !isfinite(db[u][1][f]) || !isfinite(db[u][2][f])) s_nonfinite = 1u;
-                            const float t_lo = w_lo * gb[u][f] - a12 * db[u][0][f] + dy_lo * db[u][1][f] + dz_lo * db[u][2][f];
-                            const float t_hi = w_hi * gb[u][f] + a12 * db[u][0][f] + dy_hi * db[u][1][f] + dz_hi * db[u][2][f];
-                            v_lo[f] = fminf(fmaxf(t_lo * fix, -4.6e18f), 4.6e18f);
-                            v_hi[f] = fminf(fmaxf(t_hi * fix, -4.6e18f), 4.6e18f);
-                        } else {  // (the order of operations of the plain kernel: clamp(g * fix), then the weights)
-                            const float v = fminf(fmaxf(gb[u][f] * fix, -4.6e18f), 4.6e18f);
-                            v_lo[f] = w_lo * v;
-                            v_hi[f] = w_hi * v;
-                        }
-                    }
-                    if (e_lo != key_lo) {
-                        if (key_lo != 0xffffffffu) {
-#pragma unroll
-                            for (int f = 0; f < F; ++f) atomicAdd(&acc[key_lo * F + f], own_to_fixed(fminf(fmaxf(run_lo[f], -4.6e18f), 4.6e18f)));
-                        }
-                        key_lo = e_lo;
-#pragma unroll
-                        for (int f = 0; f < F; ++f) run_lo[f] = 0.f;
-                    }
-                    if (e_hi != key_hi) {
-                        if (key_hi != 0xffffffffu) {
-#pragma unroll
-                            for (int f = 0; f < F; ++f) atomicAdd(&acc[key_hi * F + f], own_to_fixed(fminf(fmaxf(run_hi[f], -4.6e18f), 4.6e18f)));
-                        }
-                        key_hi = e_hi;
-#pragma unroll
-                        for (int f = 0; f < F; ++f) run_hi[f] = 0.f;
-                    }
-#pragma unroll
-                    for (int f = 0; f < F; ++f) { run_lo[f] += v_lo[f]; run_hi[f] += v_hi[f]; }
-                }
-            }
-            if (key_lo != 0xffffffffu) {
-#pragma unroll
-                for (int f = 0; f < F; ++f) atomicAdd(&acc[key_lo * F + f], own_to_fixed(fminf(fmaxf(run_lo[f], -4.6e18f), 4.6e18f)));
-            }
-            if (key_hi != 0xffffffffu) {
-#pragma unroll
-                for (int f = 0; f < F; ++f) atomicAdd(&acc[key_hi * F + f], own_to_fixed(fminf(fmaxf(run_hi[f], -4.6e18f), 4.6e18f)));
-            }
-        } else
-        for (uint32_t i0 = i_beg + threadIdx.x; i0 < i_end; i0 += OWN_BLOCK * OWN_BATCH) {
-            uint32_t word[OWN_BATCH];
-            float gb[OWN_BATCH][F], gf[OWN_BATCH][F], xb[OWN_BATCH][3];
-#pragma unroll
-            for (int u = 0; u < OWN_BATCH; ++u) {
-                const uint32_t i = i0 + u * OWN_BLOCK;
-                word[u] = i < i_end ? it[i] : 0xffffffffu;
-            }
-#pragma unroll
-            for (int u = 0; u < OWN_BATCH; ++u) {
-                const uint32_t s = word[u] != 0xffffffffu ? word[u] >> 4 : 0u;
-                const float *src = (TAPS && s < taps_nc) ? g0l : dyl;
-                if constexpr (F == 2) {
-                    const float2 v = *reinterpret_cast<const float2 *>(src + 2ull * s);
-                    gb[u][0] = v.x; gb[u][1] = v.y;
-                } else {
-#pragma unroll
-                    for (int f = 0; f < F; ++f) gb[u][f] = src[(uint64_t)s * F + f];
-                }
-                xb[u][0] = x[3ull * s]; xb[u][1] = x[3ull * s + 1]; xb[u][2] = x[3ull * s + 2];
-#pragma unroll
-                for (int f = 0; f < F; ++f) gf[u][f] = dyf ? dyf[(uint64_t)s * F + f] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < OWN_BATCH; ++u) {
-                if (word[u] == 0xffffffffu) continue;
-                const int k = (word[u] >> 2) & 3;
-                const uint32_t mode = word[u] & 3u;
-                float g_out[F];
-#pragma unroll
-                for (int f = 0; f < F; ++f) {  // to fixed-point units; the clamp only keeps the integer conversion defined
-                    if (!isfinite(gb[u][f])) s_nonfinite = 1u;
-                    g_out[f] = fminf(fmaxf(gb[u][f] * fix, -4.6e18f), 4.6e18f);
-                }
-                const Cell c = locate(g, xb[u][0], xb[u][1], xb[u][2]);
-                const uint32_t cy = c.c[1] + (k & 1), cz = c.c[2] + (k >> 1);
-                const float a1 = (k & 1) ? c.w[1] : 1.f - c.w[1], a2 = (k & 2) ? c.w[2] : 1.f - c.w[2];
-                float w_lo, w_hi;  // weights of the corners x0 and x0 + 1 of this (y,z) pair
-                if (dir) {
-                    // second-order use (double backward of the input gradient): the coefficient of table[corner] in
-                    // sum_d dir_d * d(encoding)/dx_d  =  scale * sum_d dir_d * sign_d(corner) * prod_{e != d} w_e(corner)
-                    const uint32_t smp = word[u] >> 4;
-                    const float g0 = dir[3ull * smp], g1 = dir[3ull * smp + 1], g2 = dir[3ull * smp + 2];
-                    const float s1 = (k & 1) ? 1.f : -1.f, s2 = (k & 2) ? 1.f : -1.f;
-                    const float a0l = 1.f - c.w[0], a0h = c.w[0];
-                    w_lo = g.scale * (-g0 * a1 * a2 + g1 * s1 * a0l * a2 + g2 * s2 * a0l * a1);
-                    w_hi = g.scale * (g0 * a1 * a2 + g1 * s1 * a0h * a2 + g2 * s2 * a0h * a1);
-                    if (!isfinite(w_lo) || !isfinite(w_hi)) { s_nonfinite = 1u; w_lo = w_hi = 0.f; }
-                } else {
-                    w_lo = (1.f - c.w[0]) * (a1 * a2);
-                    w_hi = c.w[0] * (a1 * a2);
-                }
-                if constexpr (TAPS) {
-                    const uint32_t smp = word[u] >> 4;
-                    if (smp < taps_nc) {  // merged centre item: w G0 + sum_a (d w / d x_a) D_a, G0 was loaded as gb
-                        const float s1 = (k & 1) ? 1.f : -1.f, s2 = (k & 2) ? 1.f : -1.f;
-                        const float a12 = a1 * a2, a0l = 1.f - c.w[0], a0h = c.w[0];
-                        float t_lo[F], t_hi[F];
-#pragma unroll
-                        for (int f = 0; f < F; ++f) {
-                            const float dx = ddl[((uint64_t)smp * 3 + 0) * F + f], dyv = ddl[((uint64_t)smp * 3 + 1) * F + f],
-                                        dz = ddl[((uint64_t)smp * 3 + 2) * F + f];
-                            if (!isfinite(dx) || !isfinite(dyv) || !isfinite(dz)) s_nonfinite = 1u;
-                            const float g_ = gb[u][f];
-                            t_lo[f] = fminf(fmaxf((a0l * a12 * g_ - a12 * dx + a0l * s1 * a2 * dyv + a0l * a1 * s2 * dz) * fix, -4.6e18f), 4.6e18f);
-                            t_hi[f] = fminf(fmaxf((a0h * a12 * g_ + a12 * dx + a0h * s1 * a2 * dyv + a0h * a1 * s2 * dz) * fix, -4.6e18f), 4.6e18f);
-                        }
-                        if (mode != 2u) lds_add<F>(acc, corner_index(g, c.c[0], cy, cz) - r0, 1.f, t_lo);
-                        if (mode != 1u) lds_add<F>(acc, corner_index(g, c.c[0] + 1u, cy, cz) - r0, 1.f, t_hi);
-                        continue;
-                    }
-                }
-                if (dyf) {
-                    // first-order and second-order terms of one training step share their items (same samples, same
-                    // corners): w_dir * dy_second + w_trilinear * dy_first leaves as ONE fixed-point atomic per entry
-                    float f_out[F];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) {
-                        if (!isfinite(gf[u][f])) s_nonfinite = 1u;
-                        f_out[f] = fminf(fmaxf(gf[u][f] * fix, -4.6e18f), 4.6e18f);
-                    }
-                    const float f_lo = (1.f - c.w[0]) * (a1 * a2), f_hi = c.w[0] * (a1 * a2);
-                    if (mode != 2u) lds_add2<F>(acc, corner_index(g, c.c[0], cy, cz) - r0, w_lo, g_out, f_lo, f_out);
-                    if (mode != 1u) lds_add2<F>(acc, corner_index(g, c.c[0] + 1u, cy, cz) - r0, w_hi, g_out, f_hi, f_out);
-                    continue;
-                }
-                if (mode != 2u) lds_add<F>(acc, corner_index(g, c.c[0], cy, cz) - r0, w_lo, g_out);
-                if (mode != 1u) lds_add<F>(acc, corner_index(g, c.c[0] + 1u, cy, cz) - r0, w_hi, g_out);
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t nf = cnt * F;  // multiple of 8: level sizes are multiples of 8 entries
-    if (ad.p && C == 1) {  // fused AdamW on the slice this workgroup owns (a non-finite slice updates with NaN gradients)
-        const float lr = s_hyper[0], bc1 = s_hyper[1], bc2 = s_hyper[2];
-        const uint64_t base = (uint64_t)(g.offset + r0) * F;
-        const bool bad = s_nonfinite != 0u;
-        const float qnan = __builtin_nanf("");
-        // every load of the slice's p / m / v is issued before the first store: the pointers may alias as far as the
-        // compiler knows, so a load / compute / store loop would pay one memory round trip per iteration
-        constexpr int ADAM_IT = (OWN_LDS_WORDS + OWN_BLOCK * 4 - 1) / (OWN_BLOCK * 4);
-        float4 pp[ADAM_IT], mm[ADAM_IT], vv[ADAM_IT];
-#pragma unroll
-        for (int it = 0; it < ADAM_IT; ++it) {
-            const uint32_t k = (it * OWN_BLOCK + threadIdx.x) * 4;
-            if (k < nf) {
-                pp[it] = *reinterpret_cast<const float4 *>(ad.p + base + k);
-                mm[it] = *reinterpret_cast<const float4 *>(ad.m + base + k);
-                vv[it] = *reinterpret_cast<const float4 *>(ad.v + base + k);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < ADAM_IT; ++it) {
-            const uint32_t k = (it * OWN_BLOCK + threadIdx.x) * 4;
-            if (k >= nf) continue;
-            float *pa = &pp[it].x, *ma = &mm[it].x, *va = &vv[it].x;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                nsr_adamw_elem(pa[q], ma[q], va[q], bad ? qnan : own_from_fixed(acc[k + q]), lr, ad.b1, ad.b2, ad.eps, ad.wd,
-                               bc1, bc2);
-            *reinterpret_cast<float4 *>(ad.p + base + k) = pp[it];
-            *reinterpret_cast<float4 *>(ad.m + base + k) = mm[it];
-            *reinterpret_cast<float4 *>(ad.v + base + k) = vv[it];
-            if (ad.shadow) {
-                __half2 h[2] = {__floats2half2_rn(pa[0], pa[1]), __floats2half2_rn(pa[2], pa[3])};
-                *reinterpret_cast<uint2 *>(ad.shadow + base + k) = *reinterpret_cast<uint2 *>(h);
-            }
-        }
-        return;
-    }
-    if (s_nonfinite) {
-        const float qnan = __builtin_nanf("");
-        if (grad_bf16 && C == 1) {
-            uint16_t *dst = grad_bf16 + (uint64_t)(g.offset + r0) * F;
-            for (uint32_t k = threadIdx.x; k < nf; k += OWN_BLOCK) dst[k] = 0x7fc0u;
-            return;
-        }
-        float *dst = C > 1 ? slabs + om.slab_offset[level] + ((uint64_t)chunk * g.size + r0) * F
-                           : grad_table + (uint64_t)(g.offset + r0) * F;
-        for (uint32_t k = threadIdx.x; k < nf; k += OWN_BLOCK) dst[k] = qnan;
-        return;
-    }
-    if (C > 1) {
-        float *dst = slabs + om.slab_offset[level] + ((uint64_t)chunk * g.size + r0) * F;
-        for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4)
-            *reinterpret_cast<float4 *>(dst + k) = make_float4(own_from_fixed(acc[k]), own_from_fixed(acc[k + 1]),
-                                                               own_from_fixed(acc[k + 2]), own_from_fixed(acc[k + 3]));
-    } else if (grad_bf16) {  // transport format of the multi-GPU exchange: written once, never accumulated into
-        uint16_t *dst = grad_bf16 + (uint64_t)(g.offset + r0) * F;
-        for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4) {
-            uint2 o;
-            o.x = nsr_pack_bf16x2(own_from_fixed(acc[k]), own_from_fixed(acc[k + 1]));
-            o.y = nsr_pack_bf16x2(own_from_fixed(acc[k + 2]), own_from_fixed(acc[k + 3]));
-            *reinterpret_cast<uint2 *>(dst + k) = o;
-        }
-    } else {
-        float *dst = grad_table + (uint64_t)(g.offset + r0) * F;
-        for (uint32_t k = threadIdx.x * 4; k < nf; k += OWN_BLOCK * 4) {
-            float4 v = make_float4(own_from_fixed(acc[k]), own_from_fixed(acc[k + 1]), own_from_fixed(acc[k + 2]),
-                                   own_from_fixed(acc[k + 3]));
-            if (accumulate) {
-                const float4 o = *reinterpret_cast<const float4 *>(dst + k);
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-            }
-            *reinterpret_cast<float4 *>(dst + k) = v;
-        }
-    }
-}
-
-// grad[level] (+)= sum over that level's chunk slabs (levels with n_chunks > 1 only)
-template <int F>
-__global__ void __launch_bounds__(256)
-k_grid_reduce_slabs(const float *__restrict__ slabs, float *__restrict__ grad_table, int accumulate, const OwnerMap om,
-                    const NsrGridDesc d, const OwnerAdam ad, uint16_t *__restrict__ grad_bf16, uint32_t level_base)
-{
-    const uint32_t level = blockIdx.y + level_base;
-    const uint32_t C = om.n_chunks[level];
-    if (C <= 1) return;
-    __shared__ float s_hyper[3];
-    if (ad.p) {
-        if (threadIdx.x == 0) {
-            double p1, p2;
-            nsr_adam_schedule(ad.step, ad.hyper, ad.base_lr, ad.b1d, ad.b2d, ad.gamma, ad.m0, ad.m1, ad.m2, s_hyper[0],
-                              s_hyper[1], s_hyper[2], p1, p2);
-        }
-        __syncthreads();
-    }
-    const uint32_t nf = d.size[level] * F;
-    const float *src = slabs + om.slab_offset[level];
-    float *dst = grad_table + (uint64_t)d.offset[level] * F;
-    // levels split into many chunks are small (level 0: 8 K floats x 64 slabs): one thread per float4 would leave 2,048
-    // threads walking 64 slabs each.  S lanes share a float4, each sums every S-th slab, a shuffle tree joins them
-    // (fixed order: the result does not depend on the launch).
-    const uint32_t S = C >= 32 ? 8u : (C >= 8 ? 4u : 1u);
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x, sub = t % S, q0 = t / S, qs = gridDim.x * 256 / S;
-    for (uint32_t k = q0 * 4; k < nf; k += qs * 4) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-        for (uint32_t c = sub; c < C; c += S) {  // unrolled: independent loads in flight
-            const float4 v = *reinterpret_cast<const float4 *>(src + (uint64_t)c * nf + k);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        for (uint32_t o = S >> 1; o > 0; o >>= 1) {
-            s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
-            s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
-        }
-        if (sub != 0) continue;
-        if (accumulate) {
-            const float4 o4 = *reinterpret_cast<const float4 *>(dst + k);
-            s.x += o4.x; s.y += o4.y; s.z += o4.z; s.w += o4.w;
-        }
-        if (ad.p) {  // the summed gradient of a dense level goes straight into AdamW (see OwnerAdam)
-            const float gr[4] = {s.x, s.y, s.z, s.w};
-            owner_adam4<F>(ad, (uint64_t)d.offset[level] * F + k, gr, s_hyper[0], s_hyper[1], s_hyper[2]);
-        } else if (grad_bf16) {
-            uint2 o;
-            o.x = nsr_pack_bf16x2(s.x, s.y);
-            o.y = nsr_pack_bf16x2(s.z, s.w);
-            *reinterpret_cast<uint2 *>(grad_bf16 + (uint64_t)d.offset[level] * F + k) = o;
-        } else {
-            *reinterpret_cast<float4 *>(dst + k) = s;
-        }
-    }
-}
-
-// host: build the decomposition; returns the number of blocks, *slab_floats the slab workspace size, *n_bins the number
-// of (level, slice) bins
-static uint32_t make_owner_map(const NsrGridDesc *desc, OwnerMap *om, uint64_t *slab_floats, uint32_t *n_bins)
-{
-    const uint32_t F = desc->n_features, L = desc->n_levels;
-    uint64_t slab = 0;
-    uint32_t bins = 0, rows = 0;
-    for (uint32_t l = 0; l < NSR_MAX_LEVELS; ++l)
-        om->level_start[l] = om->n_slices[l] = om->n_chunks[l] = om->slab_offset[l] = om->entries_per_slice[l] =
-            om->bin_offset[l] = 0;
-    for (uint32_t l = 0; l < L; ++l) {
-        const uint32_t size = desc->size[l], res = desc->resolution[l];
-        const bool dense = (uint64_t)res * res * res <= (uint64_t)size;
-        const uint32_t max_epb = OWN_LDS_WORDS / F;
-        uint32_t epb = max_epb;
-        const uint32_t p2 = 1u << OWN_POW2_LOG2;
-        if (!dense && (size & (size - 1)) == 0 && size >= p2 && p2 <= max_epb && res < p2) epb = p2;
-        const uint32_t R = nsr_div_up(size, epb);
-        const uint32_t target = dense ? OWN_DENSE_TARGET_WGS : OWN_TARGET_WGS;
-        uint32_t C = 1;
-        if (R < target) C = (target + R - 1) / R;  // few slices: split the items instead
-        om->n_slices[l] = R;
-        om->n_chunks[l] = C;
-        om->entries_per_slice[l] = epb;
-        om->slab_offset[l] = (uint32_t)slab;
-        om->bin_offset[l] = bins;
-        bins += R;
-        if (C > 1) slab += (uint64_t)C * size * F;
-        om->level_start[l] = rows;
-        rows += nsr_div_up(R * C, 8);
-    }
-    *slab_floats = slab;
-    *n_bins = bins;
-    return rows * 8;
-}
-
-// row-major dy [n, stride] (half or float) -> level-major fp32 [L][n][F]; 64 samples x all columns per block
-template <int F, bool DY_F32>
-__global__ void __launch_bounds__(256)
-k_dy_to_level_major(const void *__restrict__ dy, uint32_t dy_stride, float *__restrict__ out, uint32_t n, uint32_t L)
-{
-    extern __shared__ float tile[];  // [64][C+1]
-    const uint32_t C = L * F, i0 = blockIdx.x * 64;
-    for (uint32_t k = threadIdx.x; k < 64 * C; k += 256) {
-        const uint32_t r = k / C, c = k % C;
-        tile[r * (C + 1) + c] = (i0 + r < n) ? load_grad<DY_F32>(dy, (uint64_t)(i0 + r) * dy_stride + c) : 0.f;
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 64 * C; k += 256) {
-        const uint32_t l = k / (64 * F), rem = k % (64 * F), r = rem / F, f = rem % F;
-        if (i0 + r < n) out[((uint64_t)l * n + i0 + r) * F + f] = tile[r * (C + 1) + l * F + f];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // backward w.r.t. the input (and its double backward): one lane = one sample, loop over levels.
@@ -1581,142 +841,57 @@ extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int 
 }
 
 
-// workspace (4-byte words): [slabs][level-major dy: L*F*n][counts | bin_start | cursors: n_bins each][items: L*8n]
+// ---- the owner-computes table backward, in two configurations (hashgrid_owner.inc) -------------------------------------
+// Measured (tools/table_backward_variants.py, tools/neus_step_bench.py, round 3), accumulate / accumulate + AdamW at 9.6e4
+// ray-coherent samples: 2^13-entry slices x 1024 threads (one workgroup per CU) 87 / 122 us, 2^12 x 512 77 / 111 us,
+// 2^11 x 256 72 / 105 us -- several small workgroups per CU overlap one's item phase (LDS atomics, latency bound) with
+// another's write-out / AdamW phase (HBM streaming).  With ~1e6 points per launch (the NeuS steps at 4096 rays, the 7 N
+// points of a finite-difference step) the large slices win again: C3 5.62 vs 6.04 ms, C5 15.3 vs 15.9 ms per step -- fewer,
+// longer item lists per workgroup amortise the per-workgroup LDS clear / write-out.  So both are compiled and a launch
+// picks by its point count (the binning and the accumulation of one gradient see the same count).
+namespace own_small {
+#define NSR_OWN_BLOCK 256
+#define NSR_OWN_LOG2 11
+#include "hashgrid_owner.inc"
+#undef NSR_OWN_BLOCK
+#undef NSR_OWN_LOG2
+}  // namespace own_small
+namespace own_large {
+#define NSR_OWN_BLOCK 1024
+#define NSR_OWN_LOG2 13
+#include "hashgrid_owner.inc"
+#undef NSR_OWN_BLOCK
+#undef NSR_OWN_LOG2
+}  // namespace own_large
+
+#ifndef NSR_OWN_LARGE_FROM
+#define NSR_OWN_LARGE_FROM 400000u
+#endif
+static uint32_t g_own_large_from = NSR_OWN_LARGE_FROM;
+static bool own_use_large(uint32_t n) { return n > g_own_large_from; }
+
+// launches of more than `n_points` points use the large-slice configuration (0: always, UINT32_MAX: never); returns the
+// previous threshold.  The binning and the accumulation of one gradient must see the same setting.
+extern "C" uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points)
+{
+    const uint32_t old = g_own_large_from;
+    g_own_large_from = n_points;
+    return old;
+}
+
 extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n)
 {
     if (!desc || check_desc(desc, "nsr_hashgrid_backward_params_workspace_floats")) return 0;
-    OwnerMap om;
-    uint64_t slab = 0;
-    uint32_t n_bins = 0;
-    make_owner_map(desc, &om, &slab, &n_bins);
-    return slab + (uint64_t)desc->n_levels * desc->n_features * n + 3ull * n_bins + (uint64_t)desc->n_levels * 8ull * n;
+    const uint64_t a = own_small::workspace_floats(desc, n), b = own_large::workspace_floats(desc, n);
+    return a > b ? a : b;  // (the configuration is picked per launch: room for either)
 }
 
-// phases: 1 = bin the items (needs only x), 2 = accumulate (needs dy and the bins), 3 = both
+template <typename... A>
 static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_t dy_stride, float *grad_table,
-                          float *workspace, uint32_t n, uint32_t level_mask_count, float grad_scale, int accumulate,
-                          const NsrGridDesc *desc, const int32_t *n_dev, int phases, void *stream,
-                          const float *dir = nullptr, const float *dy_first_lm = nullptr,
-                          const NsrTableAdam *adam = nullptr, uint32_t taps_nc = 0, float *tap_ws = nullptr,
-                          uint16_t *grad_bf16 = nullptr, uint32_t level_begin = 0, uint32_t level_end = 0xffffffffu)
+                          float *workspace, uint32_t n, A... rest)
 {
-    if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_owner")) return rc;
-    NSR_REQUIRE(workspace, "nsr_hashgrid_backward_params_owner: workspace is NULL");
-    NSR_REQUIRE(n == 0 || x, "nsr_hashgrid_backward_params_owner: NULL pointer");
-    NSR_REQUIRE(n < (1u << 28), "nsr_hashgrid_backward_params_owner: at most 2^28 - 1 samples per call");
-    const uint32_t F = desc->n_features, L = desc->n_levels;
-    hipStream_t st = (hipStream_t)stream;
-    OwnerMap om;
-    uint64_t slab_floats = 0;
-    uint32_t n_bins = 0;
-    uint32_t nb = make_owner_map(desc, &om, &slab_floats, &n_bins);
-    for (uint32_t l = 0; l < L; ++l)
-        NSR_REQUIRE(om.n_slices[l] <= (uint32_t)OWN_MAX_SLICES, "nsr_hashgrid_backward_params_owner: level too large");
-    // a launch may cover the run of levels [level_begin, level_end) only (the multi-GPU step exchanges the finest levels'
-    // gradient while the coarse ones are still being accumulated)
-    if (level_end > L) level_end = L;
-    NSR_REQUIRE(level_begin < level_end, "nsr_hashgrid_backward_params_owner: empty level range");
-    const bool partial = level_begin > 0 || level_end < L;
-    NSR_REQUIRE(!partial || (dy_layout == 2 && !adam && taps_nc == 0 && !dir && (phases & 1) == 0),
-                "nsr_hashgrid_backward_params_owner: a level range takes level-major dy, binned items and plain mode");
-    const uint32_t row_base = om.level_start[level_begin];
-    nb = ((level_end < L ? om.level_start[level_end] : nb / 8u) - row_base) * 8u;
-    float *lm = workspace + slab_floats;
-    uint32_t *counts = reinterpret_cast<uint32_t *>(lm + (uint64_t)L * F * n);
-    uint32_t *bin_start = counts + n_bins, *cursors = bin_start + n_bins, *items = cursors + n_bins;
-    // stencil mode (n = 7 taps_nc points, layout [7][taps_nc]): crossing masks | G0 | D in the tap workspace
-    NSR_REQUIRE(taps_nc == 0 || (tap_ws && n == 7u * taps_nc && !dir && !adam),
-                "nsr_hashgrid_backward_params_owner: the stencil mode takes 7 n_centre points and a tap workspace");
-    uint8_t *cross = reinterpret_cast<uint8_t *>(tap_ws);
-    float *tap_g0 = tap_ws ? tap_ws + ((uint64_t)L * taps_nc + 15) / 16 * 4 : nullptr;  // (16-byte aligned behind the masks)
-    float *tap_dd = tap_ws ? tap_g0 + (uint64_t)L * taps_nc * F : nullptr;
-    if (phases & 1) {  // bin the (sample, corner pair) items by owning slice: count, scan, fill
-        NSR_REQUIRE(hipMemsetAsync(counts, 0, n_bins * sizeof(uint32_t), st) == hipSuccess,
-                    "nsr_hashgrid_backward_params_owner: hipMemsetAsync failed");
-        if (n > 0) {
-            const uint8_t *cr = taps_nc ? cross : nullptr;
-            if (taps_nc)
-                hipLaunchKernelGGL(k_tap_cross, dim3(nsr_div_up(taps_nc, 256), L), dim3(256), 0, st, x, taps_nc,
-                                   level_mask_count, cross, *desc);
-            const dim3 bin_grid(nsr_div_up(n, OWN_BIN_BLOCK * OWN_BIN_SPT), L);
-            hipLaunchKernelGGL((k_own_bin<false>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                               bin_start, cursors, items, om, *desc, n_dev, cr, taps_nc);
-            hipLaunchKernelGGL(k_own_bin_scan, dim3(L), dim3(256), 0, st, counts, bin_start, cursors, om);
-            hipLaunchKernelGGL((k_own_bin<true>), bin_grid, dim3(OWN_BIN_BLOCK), 0, st, x, n, level_mask_count, counts,
-                               bin_start, cursors, items, om, *desc, n_dev, cr, taps_nc);
-            NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(bin)");
-        }
-    }
-    if (!(phases & 2)) return NSR_OK;
-    NSR_REQUIRE((grad_table || adam || grad_bf16) && (n == 0 || dy), "nsr_hashgrid_backward_params_owner: NULL pointer");
-    NSR_REQUIRE(!grad_bf16 || (!adam && !accumulate && ((uintptr_t)grad_bf16 & 7) == 0),
-                "nsr_hashgrid_backward_params_owner: the bf16 gradient is written once (no accumulate, no fused AdamW) "
-                "into an 8-byte aligned buffer");
-    OwnerAdam ad;
-    memset(&ad, 0, sizeof(ad));
-    if (adam) {
-        NSR_REQUIRE(adam->params && adam->exp_avg && adam->exp_avg_sq && adam->step && adam->hyper && !accumulate,
-                    "nsr_hashgrid_backward_params_owner: fused AdamW needs params / moments / schedule state and "
-                    "accumulate == 0");
-        NSR_REQUIRE((((uintptr_t)adam->params | (uintptr_t)adam->exp_avg | (uintptr_t)adam->exp_avg_sq) & 15) == 0 &&
-                        ((uintptr_t)adam->shadow & 7) == 0 && ((uintptr_t)adam->hyper & 7) == 0,
-                    "nsr_hashgrid_backward_params_owner: fused AdamW buffers must be 16-byte aligned (fp16 image: 8)");
-        ad.p = adam->params; ad.m = adam->exp_avg; ad.v = adam->exp_avg_sq; ad.shadow = (__half *)adam->shadow;
-        ad.step = adam->step; ad.hyper = adam->hyper;
-        ad.base_lr = adam->base_lr; ad.b1d = adam->beta1; ad.b2d = adam->beta2; ad.gamma = adam->gamma;
-        ad.m0 = adam->milestone0; ad.m1 = adam->milestone1; ad.m2 = adam->milestone2;
-        ad.b1 = (float)adam->beta1; ad.b2 = (float)adam->beta2; ad.eps = adam->eps; ad.wd = adam->weight_decay;
-    }
-    NSR_REQUIRE(dy_layout >= 0 && dy_layout <= 2, "nsr_hashgrid_backward_params_owner: dy_layout must be 0 (half "
-                "row-major), 1 (float row-major) or 2 (float level-major)");
-    const float *dy_lm = (const float *)dy;
-    if (dy_layout != 2 && n > 0) {
-        const uint32_t C = L * F;
-        const size_t lds = 64 * (C + 1) * sizeof(float);
-        DISPATCH_F(F, {
-            if (dy_layout == 1)
-                hipLaunchKernelGGL((k_dy_to_level_major<F, true>), dim3(nsr_div_up(n, 64)), dim3(256), lds, st, dy,
-                                   dy_stride, lm, n, L);
-            else
-                hipLaunchKernelGGL((k_dy_to_level_major<F, false>), dim3(nsr_div_up(n, 64)), dim3(256), lds, st, dy,
-                                   dy_stride, lm, n, L);
-        });
-        NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner(transpose)");
-        dy_lm = lm;
-    }
-    const size_t lds = OWN_LDS_WORDS * sizeof(unsigned long long);
-    DISPATCH_F(F, {
-        static bool attr_set = false;  // per instantiation
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void *)k_grid_backward_owner<F, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        if (taps_nc) {
-            NSR_REQUIRE(n_dev == nullptr, "nsr_hashgrid_backward_params_owner: the stencil mode takes a host-side count");
-            if (n > 0)
-                hipLaunchKernelGGL((k_tap_reduce<F>), dim3(nsr_div_up(taps_nc, 256), L), dim3(256), 0, st, x, dy_lm, cross,
-                                   taps_nc, level_mask_count, tap_g0, tap_dd, *desc);
-            hipLaunchKernelGGL((k_grid_backward_owner<F, 1>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
-                               bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
-                               dy_first_lm, ad, taps_nc, tap_g0, tap_dd, grad_bf16, row_base);
-        } else if (dir) {
-            hipLaunchKernelGGL((k_grid_backward_owner<F, 2>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
-                               bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
-                               dy_first_lm, ad, 0u, nullptr, nullptr, grad_bf16, row_base);
-        } else
-        hipLaunchKernelGGL((k_grid_backward_owner<F, 0>), dim3(nb), dim3(OWN_BLOCK), lds, st, x, dy_lm, items, counts,
-                           bin_start, grad_table, workspace, n, level_mask_count, grad_scale, accumulate, om, *desc, dir,
-                           dy_first_lm, ad, 0u, nullptr, nullptr, grad_bf16, row_base);
-        bool slabs_in_range = false;
-        for (uint32_t l = level_begin; l < level_end; ++l) slabs_in_range |= om.n_chunks[l] > 1;
-        if (slabs_in_range)
-            hipLaunchKernelGGL((k_grid_reduce_slabs<F>), dim3(256, level_end - level_begin), dim3(256), 0, st, workspace,
-                               grad_table, accumulate, om, *desc, ad, grad_bf16, level_begin);
-    });
-    NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_owner");
-    return NSR_OK;
+    return own_use_large(n) ? own_large::owner_backward(x, dy, dy_layout, dy_stride, grad_table, workspace, n, rest...)
+                            : own_small::owner_backward(x, dy, dy_layout, dy_stride, grad_table, workspace, n, rest...);
 }
 
 extern "C" int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,

@@ -104,6 +104,8 @@ def test_no_shipped_kernel_spills_registers():
     names = kernel_meta.demangle(sorted(meta))
     for must in ("k_vmlp_backward<", "k_vmlp_forward<", "k_mlp_forward", "k_grid_backward_owner<", "k_grid_forward"):
         assert any(must in n for n in names), must
-    # one workgroup per CU is not a requirement any more: the owner-computes table backward runs 2^11-entry slices / 256 threads
-    owner = [meta[k] for k, n in zip(sorted(meta), names) if "k_grid_backward_owner<2, 0>" in n]
-    assert owner and owner[0]["wg"] == 256 and owner[0]["vgpr"] <= 128
+    # the owner-computes table backward ships in two configurations (2^11-entry slices x 256 threads for the NeRF step's
+    # ~1e5 samples, 2^13 x 1024 for ~1e6-point launches), picked per launch
+    owner = {n.split("::")[0].split()[-1]: meta[k] for k, n in zip(sorted(meta), names) if "k_grid_backward_owner<2, 0>" in n}
+    assert owner["own_small"]["wg"] == 256 and owner["own_large"]["wg"] == 1024, owner
+    assert all(v["vgpr"] <= 128 for v in owner.values())

@@ -390,3 +390,47 @@ def test_owner_backward_level_ranges_and_bf16_transport(groups):
                                                                   D, None, stream_ptr()), "range bf16 inf")
     off = [int(o) * 2 for o in gd.offset[:17]]
     assert bool(torch.isnan(got16[off[15]:off[16]].float()).any()) and not bool(torch.isnan(got16[off[11]:off[15]].float()).any())
+
+
+def test_owner_backward_small_and_large_slice_configurations_agree():
+    """the two compiled configurations of the owner-computes backward (csrc/hashgrid_owner.inc: 2^11-entry slices x 256 threads
+    and 2^13 x 1024, picked per launch by the point count) give the same gradient: bit-identical on the hashed levels (integer
+    accumulation per entry), fp32-rounding-close on the dense levels that are summed from chunk slabs -- plain, fused-AdamW,
+    second-order and stencil modes"""
+    import ctypes
+    import nsr_hip
+    from nsr_hip import check, lib, ptr, stream_ptr
+    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
+    n, n_tab = 50000, gd.n_entries * 2
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.rand(n, 3, device="cuda", generator=g)
+    dy = torch.randn(16, n, 2, device="cuda", generator=g) * 1e-3
+    dy_rm = torch.randn(n, 32, device="cuda", generator=g) * 1e-3
+    gdir = torch.randn(n, 3, device="cuda", generator=g)
+    ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
+    D = ctypes.byref(gd)
+    off = [int(o) * 2 for o in gd.offset[:17]]
+    res = {}
+    old = lib.nsr_hashgrid_owner_large_from(0)
+    try:
+        for name, thr in (("large", 0), ("small", 0xffffffff)):
+            lib.nsr_hashgrid_owner_large_from(thr)
+            a = torch.empty(n_tab, device="cuda")
+            check(lib.nsr_hashgrid_backward_params_owner(ptr(x), ptr(dy), 2, 0, ptr(a), ptr(ws), n, 16, 1.0, 0, D, None,
+                                                         stream_ptr()), "owner")
+            b = torch.zeros(n_tab, device="cuda")
+            check(lib.nsr_hashgrid_backward_params_owner_with_second_order(ptr(x), ptr(dy), ptr(dy_rm), 32, ptr(gdir), ptr(b),
+                                                                           ptr(ws), n, 16, 0, 0, D, stream_ptr()), "second")
+            res[name] = (a, b)
+    finally:
+        lib.nsr_hashgrid_owner_large_from(old)
+    for k in range(2):
+        s_, l_ = res["small"][k], res["large"][k]
+        assert float(l_.abs().sum()) > 0
+        for lvl in range(16):
+            sl = slice(off[lvl], off[lvl + 1])
+            dense = (int(gd.resolution[lvl]) ** 3) <= int(gd.size[lvl])
+            if dense:
+                assert float((s_[sl] - l_[sl]).norm() / l_[sl].norm()) < 1e-5, (k, lvl)
+            else:
+                assert torch.equal(s_[sl], l_[sl]), (k, lvl)

@@ -23,55 +23,59 @@ def worker():
     gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
     P = gd.n_entries * 2
     res = {"lib": os.path.basename(nsr_hip.LIB_PATH)}
-    for n in (96000, 216000):
-        x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous()
-        dy = torch.randn(16, n, 2, device="cuda") * 1e-3
-        g = torch.empty(P, device="cuda")
-        g16 = torch.empty(P + 64, dtype=torch.bfloat16, device="cuda")
-        ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
-        p, m, v = torch.randn(P, device="cuda") * 1e-2, torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
-        sh = torch.empty(P, dtype=torch.float16, device="cuda")
-        step, hyper = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(12, device="cuda")
-        ad = nsr_hip.NsrTableAdam()
-        ad.params, ad.exp_avg, ad.exp_avg_sq, ad.shadow = p.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr()
-        ad.step, ad.hyper = step.data_ptr(), hyper.data_ptr()
-        ad.base_lr, ad.beta1, ad.beta2, ad.gamma = 0.01, 0.9, 0.99, 0.33
-        ad.milestone0, ad.milestone1, ad.milestone2 = 10000, 15000, 18000
-        ad.eps, ad.weight_decay = 1e-15, 0.01
-        D = ctypes.byref(gd)
+    cfgs = (("small_2^11x256", 0xffffffff), ("large_2^13x1024", 0)) if hasattr(lib, "nsr_hashgrid_owner_large_from") else (("", None),)
+    for cfg_name, thr in cfgs:
+      if thr is not None:
+          lib.nsr_hashgrid_owner_large_from(thr)
+      for n in (96000, 216000, 1000000):
+          x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous()
+          dy = torch.randn(16, n, 2, device="cuda") * 1e-3
+          g = torch.empty(P, device="cuda")
+          g16 = torch.empty(P + 64, dtype=torch.bfloat16, device="cuda")
+          ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
+          p, m, v = torch.randn(P, device="cuda") * 1e-2, torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+          sh = torch.empty(P, dtype=torch.float16, device="cuda")
+          step, hyper = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(12, device="cuda")
+          ad = nsr_hip.NsrTableAdam()
+          ad.params, ad.exp_avg, ad.exp_avg_sq, ad.shadow = p.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr()
+          ad.step, ad.hyper = step.data_ptr(), hyper.data_ptr()
+          ad.base_lr, ad.beta1, ad.beta2, ad.gamma = 0.01, 0.9, 0.99, 0.33
+          ad.milestone0, ad.milestone1, ad.milestone2 = 10000, 15000, 18000
+          ad.eps, ad.weight_decay = 1e-15, 0.01
+          D = ctypes.byref(gd)
 
-        def bin_():
-            check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, D, None, stream_ptr()), "bin")
+          def bin_():
+              check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, D, None, stream_ptr()), "bin")
 
-        def acc():
-            check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x), ptr(dy), 2, 0, ptr(g), ptr(ws), n, 16, 1.0, 0, D,
-                                                                    None, stream_ptr()), "acc")
+          def acc():
+              check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x), ptr(dy), 2, 0, ptr(g), ptr(ws), n, 16, 1.0, 0, D,
+                                                                      None, stream_ptr()), "acc")
 
-        def acc_adam():
-            check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(x), ptr(dy), 2, 0, ptr(ws), n, 16, 1.0, D, None,
-                                                                         ctypes.byref(ad), stream_ptr()), "acc_adam")
+          def acc_adam():
+              check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(x), ptr(dy), 2, 0, ptr(ws), n, 16, 1.0, D, None,
+                                                                           ctypes.byref(ad), stream_ptr()), "acc_adam")
 
-        def acc_bf16(groups):
-            def f():
-                for lo, hi in groups:
-                    check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), None, ptr(g16), ptr(ws), n, 16,
-                                                                                  1.0, lo, hi, D, None, stream_ptr()), "range")
-            return f
+          def acc_bf16(groups):
+              def f():
+                  for lo, hi in groups:
+                      check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), None, ptr(g16), ptr(ws), n, 16,
+                                                                                    1.0, lo, hi, D, None, stream_ptr()), "range")
+              return f
 
-        bin_()
-        r = {"bin_us": median_us(bin_, 5, 30), "accumulate_us": median_us(acc, 5, 30),
-             "accumulate_adam_us": median_us(acc_adam, 5, 30),
-             "accumulate_bf16_us": median_us(acc_bf16([(0, 16)]), 5, 30),
-             "accumulate_bf16_2groups_us": median_us(acc_bf16([(11, 16), (0, 11)]), 5, 30),
-             "accumulate_bf16_hi_only_us": median_us(acc_bf16([(11, 16)]), 5, 30)}
-        # correctness across builds: the fp32 gradient and its bf16 image
-        acc()
-        ref = g.clone()
-        acc_bf16([(11, 16), (0, 11)])()
-        torch.cuda.synchronize()
-        r["bf16_max_rel_err"] = float(((g16[:P].float() - ref).abs() / ref.abs().clamp_min(1e-12)).max())
-        r["grad_norm"] = float(ref.double().norm())
-        res[str(n)] = {k: (round(val, 2) if k.endswith("_us") else val) for k, val in r.items()}
+          bin_()
+          r = {"bin_us": median_us(bin_, 5, 30), "accumulate_us": median_us(acc, 5, 30),
+               "accumulate_adam_us": median_us(acc_adam, 5, 30),
+               "accumulate_bf16_us": median_us(acc_bf16([(0, 16)]), 5, 30),
+               "accumulate_bf16_2groups_us": median_us(acc_bf16([(11, 16), (0, 11)]), 5, 30),
+               "accumulate_bf16_hi_only_us": median_us(acc_bf16([(11, 16)]), 5, 30)}
+          # correctness across builds: the fp32 gradient and its bf16 image
+          acc()
+          ref = g.clone()
+          acc_bf16([(11, 16), (0, 11)])()
+          torch.cuda.synchronize()
+          r["bf16_max_rel_err"] = float(((g16[:P].float() - ref).abs() / ref.abs().clamp_min(1e-12)).max())
+          r["grad_norm"] = float(ref.double().norm())
+          res[f"{cfg_name}:{n}"] = {k: (round(val, 2) if k.endswith("_us") else val) for k, val in r.items()}
     print(json.dumps(res), flush=True)
 
 
