@@ -757,6 +757,27 @@ int nsr_neus_shade_backward(const float *sdf_out, const float *grad, const float
                             float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
                             const int32_t *n_dev, void *stream);
 
+/* The two backward kernels with the gradients of a CALLER-OWNED loss instead of the built-in terms (nsr.models.FusedNeuSModel:
+ * the reference's system forms its loss in torch on the model's output dict and calls backward(), systems/neus.py:96-139).
+ * Every pointer may be NULL (= zero): per ray comp_rgb_full [R][3], comp_rgb [R][3], opacity [R], depth [R]; per sample
+ * weights [n], sdf_samples [n], sdf_grad_samples [n][3], sdf_laplace_samples [n].  Pass loss_weights8 = zeros with it. */
+typedef struct NsrNeusUpstream {
+    const float *comp_rgb_full, *comp_rgb, *opacity, *depth, *weights, *sdf_samples, *sdf_grad_samples, *sdf_laplace_samples;
+} NsrNeusUpstream;
+int nsr_neus_composite_backward_ex(const int32_t *packed_info, const float *alpha, const void *rgb_raw, int rgb_is_f32,
+                                   const float *weights, const float *trans, const float *background,
+                                   uint32_t background_stride, const float *opacity_bg, const float *comp_rgb_full,
+                                   const float *opacity, const float *gt_rgb, const float *fg_mask, const float *acc,
+                                   const float *loss_weights8, float loss_scale, float *d_alpha, float *d_rgb_raw,
+                                   float *d_background, uint32_t n_rays, const int32_t *n_active,
+                                   const NsrNeusUpstream *upstream, const float *t_starts, const float *t_ends, void *stream);
+int nsr_neus_shade_backward_ex(const float *sdf_out, const float *grad, const float *normal, const float *dirs,
+                               const float *t_starts, const float *t_ends, const float *inv_s, float cos_anneal_ratio,
+                               const float *laplace, float eps, float radius, const float *d_alpha, const float *d_tex_in,
+                               uint32_t n_feat, const float *loss_weights8, float loss_scale, float n_samples, float *d_out,
+                               float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
+                               const int32_t *n_dev, const NsrNeusUpstream *upstream, void *stream);
+
 /* occ[i] = clip((sigmoid((sdf + h) inv_s) - sigmoid((sdf - h) inv_s) + 1e-5) / (sigmoid((sdf + h) inv_s) + 1e-5), 0, 1),
  * h = step_size / 2, sdf = sdf_out[i][0] (rows of 16 floats), inv_s clipped to [1e-6, 1e6]   (models/neus.py:90-101) */
 int nsr_neus_occupancy_values(const float *sdf_out, const float *inv_s, float step_size, float *occ, uint32_t n,

@@ -310,6 +310,15 @@ struct NeusLossWeights {
     float rgb_l1, rgb_mse, mask, opaque, eikonal, sparsity, curvature, sparsity_scale;
 };
 
+// upstream gradients of a caller-owned loss (nsr.models.FusedNeuSModel: the reference's system forms its loss in torch on the
+// model's output dict, systems/neus.py:96-139); every pointer may be NULL = zero.  With any of them set the built-in loss
+// terms are off (their weights are passed as zero).
+struct NeusUpstream {
+    const float *comp_rgb_full, *comp_rgb, *opacity, *depth;  // per ray: [R][3], [R][3], [R], [R]
+    const float *weights;                                     // per sample [n]
+    const float *sdf, *sdf_grad, *laplace;                    // per sample [n], [n][3], [n]   (shade backward)
+};
+
 template <bool RGB_F32>
 __global__ void __launch_bounds__(R_BLOCK)
 k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict__ alpha,
@@ -320,7 +329,8 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
                      NeusLossWeights lw, float loss_scale, float *__restrict__ d_alpha,
                      float *__restrict__ d_rgb_raw /* [n][16] fp32, cols 0..2 (3..15 zeroed) */,
                      float *__restrict__ d_bg /* per-ray background: dL/d comp_rgb_bg [n_rays][3] (may be NULL) */,
-                     uint32_t n_rays, const int32_t *__restrict__ n_active)
+                     uint32_t n_rays, const int32_t *__restrict__ n_active, const NeusUpstream up,
+                     const float *__restrict__ t0, const float *__restrict__ t1)
 {
     uint32_t r, start, count;
     if (!wave_ray(packed, n_rays, r, start, count)) return;
@@ -329,7 +339,22 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
     const float op = opacity[r];
     const float n_valid = fmaxf(acc[ACC_VALID], 1.f), n_r = fmaxf(acc[ACC_N], 1.f);
     float dC[3] = {0.f, 0.f, 0.f}, dO = 0.f;
-    if (r < live) {
+    // the caller's loss: dL/d comp_rgb_full (-> colours and, through the background blend, opacity), dL/d comp_rgb (colours
+    // only), dL/d opacity, dL/d depth, dL/d weights
+    float dCr[3] = {0.f, 0.f, 0.f}, dD = 0.f;
+    if (up.comp_rgb_full)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dC[q] = up.comp_rgb_full[3ull * r + q];
+    if (up.comp_rgb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dCr[q] = up.comp_rgb[3ull * r + q];
+    if (up.opacity) dO = up.opacity[r];
+    if (up.depth) dD = up.depth[r];
+    const bool external = up.comp_rgb_full || up.comp_rgb || up.opacity || up.depth || up.weights;
+    if (external) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dO -= bg[(uint64_t)r * bg_stride + q] * dC[q];
+    } else if (r < live) {
         if (op > 0.f || (opacity_bg && opacity_bg[r] > 0.f)) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -361,7 +386,9 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
             a = alpha[i];
 #pragma unroll
             for (int q = 0; q < 3; ++q) rgb[q] = sigmoidf(load_rgb<RGB_F32>(rgb_raw, i, q));
-            gw = dC[0] * rgb[0] + dC[1] * rgb[1] + dC[2] * rgb[2] + dO;
+            gw = (dC[0] + dCr[0]) * rgb[0] + (dC[1] + dCr[1]) * rgb[1] + (dC[2] + dCr[2]) * rgb[2] + dO;
+            if (dD != 0.f) gw += dD * ((t0[i] + t1[i]) * 0.5f);
+            if (up.weights) gw += up.weights[i];
             v = gw * w;
         }
         const float inc = wave_incl_scan_add(v);
@@ -370,7 +397,7 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
             d_alpha[i] = gw * trans[i] - after / fmaxf(1.f - a, 1e-10f);
             float *row = d_rgb_raw + 16 * i;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) row[q] = w * dC[q] * rgb[q] * (1.f - rgb[q]);
+            for (int q = 0; q < 3; ++q) row[q] = w * (dC[q] + dCr[q]) * rgb[q] * (1.f - rgb[q]);
 #pragma unroll
             for (int q = 3; q < 16; ++q) row[q] = 0.f;
         }
@@ -388,7 +415,7 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
                  float *__restrict__ d_out /* [n][16] */, float *__restrict__ gx /* analytic: dL/d(dx01) [n][3] */,
                  float *__restrict__ p_in /* analytic: [n][p_stride], cols 0..2 written */, uint32_t p_stride,
                  float *__restrict__ d_taps /* FD: [6][n] */, float *__restrict__ acc, uint32_t n,
-                 const int32_t *__restrict__ n_dev)
+                 const int32_t *__restrict__ n_dev, const NeusUpstream up)
 {
     float gs_local = 0.f;
     const uint32_t n_live = live_count(n, n_dev);
@@ -426,6 +453,10 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
 #pragma unroll
             for (int k = 0; k < 3; ++k) G[k] = dn[k] * 1e12f;
         }
+        if (up.sdf_grad)  // the caller's loss on sdf_grad_samples (the eikonal term of systems/neus.py:106 formed outside)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) G[k] += up.sdf_grad[3ull * i + k];
+        if (up.sdf) d_sdf += up.sdf[i];
         // sparsity: mean(exp(-scale |sdf|))
         if (lw.sparsity != 0.f) {
             const float sg = sdf > 0.f ? 1.f : (sdf < 0.f ? -1.f : 0.f);
@@ -434,8 +465,9 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
         float *row = d_out + 16ull * i;
         if (FD) {
             const float lap = laplace[i];
-            const float cl = lw.curvature != 0.f
+            float cl = lw.curvature != 0.f
                 ? loss_scale * lw.curvature * (lap > 0.f ? 1.f : (lap < 0.f ? -1.f : 0.f)) / (n_samples * eps * eps) : 0.f;
+            if (up.laplace) cl += up.laplace[i] / (eps * eps);  // laplace = sum (f+ + f- - 2 f) / eps^2
             d_sdf += -6.f * cl;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -692,6 +724,48 @@ extern "C" int nsr_neus_loss_rays(const float *comp_rgb_full, const float *opaci
     return NSR_OK;
 }
 
+static NeusUpstream make_upstream(const NsrNeusUpstream *u)
+{
+    NeusUpstream up;
+    memset(&up, 0, sizeof(up));
+    if (u) {
+        up.comp_rgb_full = u->comp_rgb_full; up.comp_rgb = u->comp_rgb; up.opacity = u->opacity; up.depth = u->depth;
+        up.weights = u->weights; up.sdf = u->sdf_samples; up.sdf_grad = u->sdf_grad_samples; up.laplace = u->sdf_laplace_samples;
+    }
+    return up;
+}
+
+extern "C" int nsr_neus_composite_backward_ex(const int32_t *packed_info, const float *alpha, const void *rgb_raw,
+                                              int rgb_is_f32, const float *weights, const float *trans,
+                                              const float *background, uint32_t background_stride,
+                                              const float *opacity_bg, const float *comp_rgb_full, const float *opacity,
+                                              const float *gt_rgb, const float *fg_mask, const float *acc,
+                                              const float *loss_weights8, float loss_scale, float *d_alpha,
+                                              float *d_rgb_raw, float *d_background, uint32_t n_rays,
+                                              const int32_t *n_active, const NsrNeusUpstream *upstream,
+                                              const float *t_starts, const float *t_ends, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    const NeusUpstream up = make_upstream(upstream);
+    const bool external = up.comp_rgb_full || up.comp_rgb || up.opacity || up.depth || up.weights;
+    NSR_REQUIRE(packed_info && background && weights && trans && opacity && acc && loss_weights8 && d_alpha && d_rgb_raw &&
+                    (external || (comp_rgb_full && gt_rgb)), "nsr_neus_composite_backward: NULL pointer");
+    NSR_REQUIRE(!up.depth || (t_starts && t_ends), "nsr_neus_composite_backward: an upstream depth gradient needs t_starts / t_ends");
+    NSR_REQUIRE(background_stride == 0 || background_stride == 3, "nsr_neus_composite_backward: background_stride is 0 or 3");
+    NeusLossWeights lw;
+    memcpy(&lw, loss_weights8, sizeof(lw));
+    if (rgb_is_f32)
+        hipLaunchKernelGGL(k_neus_composite_bwd<true>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
+                           background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
+                           d_alpha, d_rgb_raw, d_background, n_rays, n_active, up, t_starts, t_ends);
+    else
+        hipLaunchKernelGGL(k_neus_composite_bwd<false>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
+                           background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
+                           d_alpha, d_rgb_raw, d_background, n_rays, n_active, up, t_starts, t_ends);
+    NSR_CHECK_LAUNCH("nsr_neus_composite_backward");
+    return NSR_OK;
+}
+
 extern "C" int nsr_neus_composite_backward(const int32_t *packed_info, const float *alpha, const void *rgb_raw,
                                            int rgb_is_f32, const float *weights, const float *trans,
                                            const float *background, uint32_t background_stride,
@@ -701,22 +775,10 @@ extern "C" int nsr_neus_composite_backward(const int32_t *packed_info, const flo
                                            float *d_rgb_raw, float *d_background, uint32_t n_rays,
                                            const int32_t *n_active, void *stream)
 {
-    if (n_rays == 0) return NSR_OK;
-    NSR_REQUIRE(packed_info && background && weights && trans && comp_rgb_full && opacity && gt_rgb && acc && loss_weights8 &&
-                    d_alpha && d_rgb_raw, "nsr_neus_composite_backward: NULL pointer");
-    NSR_REQUIRE(background_stride == 0 || background_stride == 3, "nsr_neus_composite_backward: background_stride is 0 or 3");
-    NeusLossWeights lw;
-    memcpy(&lw, loss_weights8, sizeof(lw));
-    if (rgb_is_f32)
-        hipLaunchKernelGGL(k_neus_composite_bwd<true>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
-                           background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
-                           d_alpha, d_rgb_raw, d_background, n_rays, n_active);
-    else
-        hipLaunchKernelGGL(k_neus_composite_bwd<false>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
-                           background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
-                           d_alpha, d_rgb_raw, d_background, n_rays, n_active);
-    NSR_CHECK_LAUNCH("nsr_neus_composite_backward");
-    return NSR_OK;
+    return nsr_neus_composite_backward_ex(packed_info, alpha, rgb_raw, rgb_is_f32, weights, trans, background,
+                                          background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc,
+                                          loss_weights8, loss_scale, d_alpha, d_rgb_raw, d_background, n_rays, n_active,
+                                          nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int nsr_neus_shade_backward(const float *sdf_out, const float *grad, const float *normal, const float *dirs,
@@ -727,7 +789,21 @@ extern "C" int nsr_neus_shade_backward(const float *sdf_out, const float *grad, 
                                        float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
                                        const int32_t *n_dev, void *stream)
 {
+    return nsr_neus_shade_backward_ex(sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s, cos_anneal_ratio, laplace, eps,
+                                      radius, d_alpha, d_tex_in, n_feat, loss_weights8, loss_scale, n_samples, d_out, gx, p_in,
+                                      p_stride, d_taps, acc, n, n_dev, nullptr, stream);
+}
+
+extern "C" int nsr_neus_shade_backward_ex(const float *sdf_out, const float *grad, const float *normal, const float *dirs,
+                                          const float *t_starts, const float *t_ends, const float *inv_s,
+                                          float cos_anneal_ratio, const float *laplace, float eps, float radius,
+                                          const float *d_alpha, const float *d_tex_in, uint32_t n_feat,
+                                          const float *loss_weights8, float loss_scale, float n_samples, float *d_out,
+                                          float *gx, float *p_in, uint32_t p_stride, float *d_taps, float *acc, uint32_t n,
+                                          const int32_t *n_dev, const NsrNeusUpstream *upstream, void *stream)
+{
     if (n == 0) return NSR_OK;
+    const NeusUpstream up = make_upstream(upstream);
     const bool fd = d_taps != nullptr;
     NSR_REQUIRE(sdf_out && grad && normal && dirs && t_starts && t_ends && inv_s && d_alpha && d_tex_in && loss_weights8 &&
                     d_out && acc, "nsr_neus_shade_backward: NULL pointer");
@@ -738,11 +814,11 @@ extern "C" int nsr_neus_shade_backward(const float *sdf_out, const float *grad, 
     if (fd)
         hipLaunchKernelGGL(k_neus_shade_bwd<true>, EW_GRID_CAPPED(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
                            cos_anneal_ratio, laplace, eps, radius, d_alpha, d_tex_in, n_feat, lw, loss_scale, n_samples,
-                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev);
+                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev, up);
     else
         hipLaunchKernelGGL(k_neus_shade_bwd<false>, EW_GRID_CAPPED(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
                            cos_anneal_ratio, laplace, eps, radius, d_alpha, d_tex_in, n_feat, lw, loss_scale, n_samples,
-                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev);
+                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev, up);
     NSR_CHECK_LAUNCH("nsr_neus_shade_backward");
     return NSR_OK;
 }

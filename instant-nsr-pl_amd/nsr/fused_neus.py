@@ -542,6 +542,52 @@ class FusedNeuSStep:
 
     def forward_backward(self, rays, gt_rgb, fg_mask, background, compute_grads=True, loss_scale=1.0, march_handle=None,
                          after_march=None):
+        """forward + the system's loss terms (systems/neus.py:96-130, weights = ``loss_weights``) + backward in one go.
+        Gradient contract: ``.grad`` of the hash tables is OVERWRITTEN (the owner-computes backward writes every entry),
+        ``.grad`` of every other parameter (fp32 heads through the weight-norm fold, variance, fused colour MLP) is created
+        when it is None and ADDED to otherwise -- call with ``.grad = None`` (or zeroed) parameters, as the trainers do."""
+        gen = self._step(rays, gt_rgb, fg_mask, background, compute_grads, loss_scale, march_handle, after_march, False)
+        try:
+            next(gen)
+        except StopIteration as stop:  # no gradients asked for / nothing to differentiate
+            return stop.value
+        try:
+            gen.send(None)
+        except StopIteration as stop:
+            return stop.value
+        raise RuntimeError("FusedNeuSStep: the step generator did not finish")
+
+    def release_gradient_buffers(self):
+        """the fp32 heads' ``.grad`` tensors are views of one persistent buffer per network (VanillaBlob.push_gradient): a
+        caller that hands those tensors on (autograd) takes the buffers with them, the next step allocates new ones"""
+        for vb in (self.sdf, None if self.tex_fused else self.tex, getattr(self, "bg_geo", None), getattr(self, "bg_tex", None)):
+            if vb is not None:
+                vb._grad_flat = None
+
+    def render(self, rays, background, need_grad, march_handle=None):
+        """the step split AT THE LOSS (nsr.models.FusedNeuSModel: the reference's system owns loss and backward()).
+        -> (res, finish): ``res`` the forward outputs; ``finish(upstream)`` (None when ``need_grad`` is false or nothing was
+        marched) runs the backward from a dict of upstream gradients -- comp_rgb_full / comp_rgb [R,3], opacity / depth [R,1],
+        weights / sdf_samples / sdf_laplace_samples [N], sdf_grad_samples [N,3] (missing = zero) -- and leaves the parameter
+        gradients in ``.grad`` like ``forward_backward`` does."""
+        gen = self._step(rays, None, None, background, need_grad, 1.0, march_handle, None, True)
+        try:
+            res = next(gen)
+        except StopIteration as stop:
+            return stop.value, None
+
+        def finish(upstream):
+            try:
+                gen.send(upstream or {})
+            except StopIteration:
+                return
+            raise RuntimeError("FusedNeuSStep: the step generator did not finish")
+
+        return res, finish
+
+    def _step(self, rays, gt_rgb, fg_mask, background, compute_grads, loss_scale, march_handle, after_march, external):
+        """generator: runs the forward, yields the result dict, is sent the upstream gradients (``external``) or None (built-in
+        loss terms) and runs the backward.  No torch context manager is held across the yield."""
         m, enc, lw = self.model, self.enc, self.loss_weights
         dev = rays.device
         n_rays = rays.shape[0]
@@ -677,10 +723,11 @@ class FusedNeuSStep:
                                                  ptr(t1), ptr(bg_arg), bg_stride, ptr(weights), ptr(trans), ptr(comp_rgb),
                                                  ptr(opacity), ptr(depth), ptr(comp_normal), ptr(comp_full), n_rays, s),
                   "nsr_neus_composite_forward")
-            gt = gt_rgb.to(F32).contiguous()
+            gt = None if gt_rgb is None else gt_rgb.to(F32).contiguous()
             fg = None if fg_mask is None else fg_mask.to(F32).contiguous()
-            check(lib.nsr_neus_loss_rays(ptr(comp_full), ptr(opacity), ptr(op_bg), ptr(gt), ptr(fg), ptr(acc), n_rays, None,
-                                         s), "nsr_neus_loss_rays")
+            if gt is not None:  # (a caller-owned loss needs no per-ray loss sums)
+                check(lib.nsr_neus_loss_rays(ptr(comp_full), ptr(opacity), ptr(op_bg), ptr(gt), ptr(fg), ptr(acc), n_rays, None,
+                                             s), "nsr_neus_loss_rays")
             lean = getattr(self, "lean_outputs", False) and compute_grads  # a trainer does not read the validity masks
             res = {"comp_rgb": comp_rgb, "comp_normal": comp_normal, "opacity": opacity, "depth": depth,
                    "rays_valid": None if lean else opacity > 0, "comp_rgb_full": comp_full,
@@ -697,17 +744,37 @@ class FusedNeuSStep:
                             "rays_valid_full": None if lean else (opacity > 0) | (bgc["opacity"] > 0),
                             "weights_bg": bgc["weights"], "ray_indices_bg": bgc["ri"], "t_starts_bg": bgc["t0"],
                             "t_ends_bg": bgc["t1"]})
-            if not compute_grads or (N == 0 and bgc is None):
-                return res
-            lw8c = (ctypes.c_float * 8)(*[float(lw.get(k, 0.0)) for k in LOSS_KEYS])
+            done = not compute_grads or (N == 0 and bgc is None)
+        if done:
+            return res
+        # ---- the loss boundary: nothing of torch's thread state (no_grad, current device) is held across this yield ----------
+        upstream = yield res
+        ups = None
+        if external:
+            import nsr_hip
+            ups, keep_up = nsr_hip.NsrNeusUpstream(), []
+            for key, field in (("comp_rgb_full", "comp_rgb_full"), ("comp_rgb", "comp_rgb"), ("opacity", "opacity"),
+                               ("depth", "depth"), ("weights", "weights"), ("sdf_samples", "sdf_samples"),
+                               ("sdf_grad_samples", "sdf_grad_samples"), ("sdf_laplace_samples", "sdf_laplace_samples")):
+                g_up = (upstream or {}).get(key)
+                if g_up is not None:
+                    g_up = g_up.detach().to(F32).contiguous()
+                    keep_up.append(g_up)
+                    setattr(ups, field, g_up.data_ptr())
+        with torch.no_grad(), torch.cuda.device(dev):
+            s = stream_ptr()
+            # the built-in loss terms are off when the caller owns the loss
+            lw8c = (ctypes.c_float * 8)(*[0.0 if (external and k != "sparsity_scale") else float(lw.get(k, 0.0))
+                                          for k in LOSS_KEYS])
+            upp = _byref(ups) if ups is not None else None
             d_alpha = torch.empty(n1, dtype=F32, device=dev)
             d_rgb = torch.empty((n1, 16), dtype=F32, device=dev)
             d_bg = None if bgc is None else torch.empty((n_rays, 3), dtype=F32, device=dev)
-            check(lib.nsr_neus_composite_backward(ptr(packed), ptr(alpha), ptr(rgb_raw), int(tex_f32), ptr(weights),
-                                                  ptr(trans), ptr(bg_arg), bg_stride, ptr(op_bg), ptr(comp_full),
-                                                  ptr(opacity), ptr(gt), ptr(fg), ptr(acc), lw8c, float(loss_scale),
-                                                  ptr(d_alpha), ptr(d_rgb), ptr(d_bg), n_rays, None, s),
-                  "nsr_neus_composite_backward")
+            check(lib.nsr_neus_composite_backward_ex(ptr(packed), ptr(alpha), ptr(rgb_raw), int(tex_f32), ptr(weights),
+                                                     ptr(trans), ptr(bg_arg), bg_stride, ptr(op_bg), ptr(comp_full),
+                                                     ptr(opacity), ptr(gt), ptr(fg), ptr(acc), lw8c, float(loss_scale),
+                                                     ptr(d_alpha), ptr(d_rgb), ptr(d_bg), n_rays, None, upp, ptr(t0), ptr(t1),
+                                                     s), "nsr_neus_composite_backward")
             g_bg = None if bgc is None else self._bg_backward(bgc, d_bg)
             if N == 0:  # background only: nothing flows into the foreground networks
                 return self._finish_bg_only(res, g_bg)
@@ -733,10 +800,10 @@ class FusedNeuSStep:
             else:
                 gx = torch.empty((N, 3), dtype=F32, device=dev)
                 p_in = torch.zeros((N, P), dtype=F32, device=dev)
-            check(lib.nsr_neus_shade_backward(ptr(out), ptr(grad), ptr(normal), ptr(dirs), ptr(t0), ptr(t1), ptr(inv_s),
-                                              anneal, ptr(laplace), eps, self.radius, ptr(d_alpha), ptr(d_tex),
-                                              self.n_feat, lw8c, float(loss_scale), float(N), ptr(d_out), ptr(gx),
-                                              ptr(p_in), P, ptr(d_taps), ptr(acc), N, None, s),
+            check(lib.nsr_neus_shade_backward_ex(ptr(out), ptr(grad), ptr(normal), ptr(dirs), ptr(t0), ptr(t1), ptr(inv_s),
+                                                 anneal, ptr(laplace), eps, self.radius, ptr(d_alpha), ptr(d_tex),
+                                                 self.n_feat, lw8c, float(loss_scale), float(N), ptr(d_out), ptr(gx),
+                                                 ptr(p_in), P, ptr(d_taps), ptr(acc), N, None, upp, s),
                   "nsr_neus_shade_backward")
             if enc.params.grad is None:
                 enc.params.grad = torch.zeros_like(enc.params)

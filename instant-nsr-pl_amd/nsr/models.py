@@ -13,9 +13,11 @@ The reference's Lightning systems never look inside a model -- ``systems/nerf.py
 encode + MLPs + composite as three C calls (csrc/step.hip), and whose backward takes whatever gradients the system's loss
 sends to ``comp_rgb`` / ``opacity`` / ``depth`` / ``weights`` and runs the hand-chained backward (composite -> colour MLP ->
 density MLP -> owner-computes table backward) as one C call.  Loss, optimizer, GradScaler, schedulers stay the caller's.
+``FusedNeuSModel`` does the same for ``models.make('neus', cfg)`` (NeuS, NeuS + NeRF++ background, neuralangelo) with the
+differentiable outputs the reference's NeuS system puts losses on (systems/neus.py:96-139).
 A maintainer switches the reference over with one line (INTEGRATION.md)::
 
-    import nsr.models; nsr.models.register(models)          # models.make('nerf', cfg) now builds FusedNeRFModel
+    import nsr.models; nsr.models.register(models)          # models.make('nerf' | 'neus', cfg) now build the fused entries
 
 The modular path (the reference's own models/*.py on the drop-in tinycudann / nerfacc packages) stays available; this
 entry is the fast one.
@@ -143,7 +145,130 @@ class FusedNeRFModel(HotPathState):
         return {"level": ex.isosurface_levels(self, res), "export_vertex_color": bool(ec.get("export_vertex_color", False))}
 
 
+class _RenderNeuS(torch.autograd.Function):
+    """the differentiable outputs of ``NeuSModel.forward_`` (models/neus.py:205-287) from rays + every parameter of the model;
+    backward hands the gradients the system's loss sends to them (systems/neus.py:96-139) to the fused backward"""
+
+    KEYS = ("comp_rgb_full", "comp_rgb", "opacity", "depth", "weights", "sdf_samples", "sdf_grad_samples", "sdf_laplace_samples")
+
+    @staticmethod
+    def forward(ctx, model, need_grad, rays, background, *params):
+        step = model._runner()
+        res, finish = step.render(rays.detach(), background.detach(), bool(need_grad))
+        model._last = res
+        ctx.finish, ctx.params, ctx.step = finish, params, step
+        ctx.set_materialize_grads(False)  # outputs the loss never touched arrive as None, not as zero tensors
+        outs = [res[k] if k in res else rays.new_zeros(0) for k in _RenderNeuS.KEYS]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        params = ctx.params
+        if ctx.finish is None:  # nothing was marched (or the forward ran without gradients): no parameter saw the loss
+            return (None, None, None, None) + tuple(None for _ in params)
+        up = {k: g for k, g in zip(_RenderNeuS.KEYS, grads) if g is not None and g.numel() > 0}
+        # the fused backward leaves its results in ``.grad``: run it on empty ``.grad`` slots and hand what it produced to
+        # autograd (which accumulates, fires DDP / GradScaler hooks ...), then put the previous contents back
+        saved = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        try:
+            ctx.finish(up)
+            out = [p.grad for p in params]
+            ctx.step.release_gradient_buffers()  # (the small gradients are views of per-network buffers: they leave with them)
+        finally:
+            for p, g in zip(params, saved):
+                p.grad = g
+        ctx.finish = None
+        return (None, None, None, None) + tuple(out)
+
+
+class FusedNeuSModel(HotPathState):
+    """``models.make('neus', config)`` (reference models/neus.py:47-323) on the fused step: NeuS (analytic normals), NeuS with
+    the learned NeRF++ background, neuralangelo (progressive levels, finite differences).  Same constructor argument, same
+    state-dict keys, same output dict (``num_samples*`` are CPU tensors: the counts are already on the host).  Differentiable
+    outputs: comp_rgb_full, comp_rgb, opacity, depth, weights, sdf_samples, sdf_grad_samples, sdf_laplace_samples -- every
+    output the reference's system puts a loss on (systems/neus.py:96-139); comp_normal and the background branch's own
+    outputs (``*_bg``) carry no gradient of their own (the background trains through comp_rgb_full)."""
+
+    def __init__(self, config):
+        cfg = _plain(config)
+        if cfg.get("name") != "neus":
+            raise ValueError("FusedNeuSModel builds the 'neus' model section")
+        super().__init__(cfg)
+        self._step, self._last = None, None
+        self.refresh_owned_by_trainer = False  # this entry refreshes its grids in update_step, like the reference's model
+
+    def _runner(self):
+        if self._step is None:
+            from .fused_neus import FusedNeuSStep
+            self._step = FusedNeuSStep(self, {})
+        return self._step
+
+    # -- systems/base.py:54-57 -> models/neus.py:79-111 -----------------------------------------------------------------
+    def update_step(self, epoch, global_step):
+        self.restore_schedules(global_step)  # cos anneal, progressive level, finite-difference eps
+        cfg = self.config
+        if self.training and cfg["grid_prune"] and global_step % 16 == 0:
+            step = self._runner()
+            step.refresh_occupancy_async(int(global_step), occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
+            if step.bg:
+                self.occupancy_grid_bg.every_n_step(step=int(global_step), occ_eval_fn=step.bg_occ_eval_fn,
+                                                    occ_thre=cfg.get("grid_prune_occ_thre_bg", 0.01))
+
+    def forward_(self, rays):
+        bg = self.background_color if self.background_color is not None else torch.ones(3, device=rays.device)
+        params = [p for p in self.parameters() if p.numel() > 0]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        full, rgb, opacity, depth, weights, sdf, sdf_grad, lap = _RenderNeuS.apply(self, need_grad, rays, bg, *params)
+        last = self._last
+        cpu_count = lambda n: torch.as_tensor([int(n)], dtype=torch.int32)  # noqa: E731
+        out = {"comp_rgb": rgb, "comp_normal": last["comp_normal"], "opacity": opacity, "depth": depth,
+               "rays_valid": opacity > 0, "num_samples": cpu_count(last["num_samples"])}
+        if self.training:
+            t0, t1 = last["t_starts"].view(-1), last["t_ends"].view(-1)
+            out.update({"sdf_samples": sdf, "sdf_grad_samples": sdf_grad, "weights": weights.view(-1),
+                        "points": ((t0 + t1) / 2.0), "intervals": (t1 - t0), "ray_indices": last["ray_indices"].view(-1)})
+            if self.grad_type == "finite_difference":
+                out["sdf_laplace_samples"] = lap
+        if self.config.get("learned_background", False):
+            out.update({"comp_rgb_bg": last["comp_rgb_bg"], "opacity_bg": last["opacity_bg"], "depth_bg": last["depth_bg"],
+                        "rays_valid_bg": last["opacity_bg"] > 0, "num_samples_bg": cpu_count(last["num_samples_bg"])})
+            if self.training:
+                b0, b1 = last["t_starts_bg"].view(-1), last["t_ends_bg"].view(-1)
+                out.update({"weights_bg": last["weights_bg"].view(-1), "points_bg": (b0 + b1) / 2.0, "intervals_bg": b1 - b0,
+                            "ray_indices_bg": last["ray_indices_bg"].view(-1)})
+            out.update({"comp_rgb_full": full, "num_samples_full": cpu_count(last["num_samples_full"]),
+                        "rays_valid_full": (opacity > 0) | (last["opacity_bg"] > 0)})
+        else:  # models/neus.py:259-264: a constant background
+            out.update({"comp_rgb_bg": bg[None, :].expand(*rgb.shape), "num_samples_bg": torch.zeros(1, dtype=torch.int32),
+                        "rays_valid_bg": torch.zeros_like(out["rays_valid"]), "comp_rgb_full": full,
+                        "num_samples_full": cpu_count(last["num_samples"]), "rays_valid_full": opacity > 0})
+        return out
+
+    def forward(self, rays):
+        if self.training:
+            out = self.forward_(rays)
+        else:
+            from .export import chunk_batch
+            with torch.no_grad():
+                out = chunk_batch(self.forward_, int(self.config["ray_chunk"]), True, rays)
+        return {**out, "inv_s": torch.exp(self.variance.variance.detach() * 10.0)}
+
+    def eval(self):
+        self.randomized = False
+        return super().eval()
+
+    def regularizations(self, out):
+        return {}  # models/geometry.py / models/texture.py: both regularizations() are empty for these models
+
+    def isosurface(self):
+        raise NotImplementedError("marching cubes is a CPU library call in the reference (out of the hot path's scope): "
+                                  "nsr.export.isosurface_levels evaluates the level lattice on the device")
+
+
 def register(models_module):
     """point the reference's registry (models/__init__.py:1-13) at the fused entries"""
     models_module.models["nerf"] = FusedNeRFModel
+    models_module.models["neus"] = FusedNeuSModel
     return models_module

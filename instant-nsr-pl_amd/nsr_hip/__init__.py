@@ -65,6 +65,12 @@ class NsrRenderGrads(ctypes.Structure):
                 ("weights", ctypes.c_void_p)]
 
 
+class NsrNeusUpstream(ctypes.Structure):
+    """include/nsr_hip.h: gradients of a caller-owned loss for the NeuS backward kernels (NULL = zero)"""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("comp_rgb_full", "comp_rgb", "opacity", "depth", "weights", "sdf_samples",
+                                               "sdf_grad_samples", "sdf_laplace_samples")]
+
+
 class NsrVanillaLayer(ctypes.Structure):
     """include/nsr_hip.h: the nn.Linear tensors of one VanillaMLP layer (weight_g NULL: plain weight)"""
     _fields_ = [("weight_v", ctypes.c_void_p), ("weight_g", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -224,6 +230,10 @@ SIGNATURES = {
     "nsr_bg_join_gradients": [_P, _P, _U, _U, _P, _U, _P, _P],
     "nsr_neus_composite_backward": [_P, _P, _P, _I, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _U, _P,
                                     _P],
+    "nsr_neus_composite_backward_ex": [_P, _P, _P, _I, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _U, _P,
+                                       _P, _P, _P, _P],
+    "nsr_neus_shade_backward_ex": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
+                                   _P, _U, _P, _P, _P],
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }

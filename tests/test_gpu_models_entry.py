@@ -144,3 +144,109 @@ def test_registry_switch_and_a_short_training_run():
         losses.append(float(loss))
     assert sum(losses[-5:]) / 5 < 0.5 * sum(losses[:5]) / 5, (losses[:5], losses[-5:])
     assert float(model.occupancy_grid.binary.float().mean()) < 0.9   # the model's update_step pruned the grid
+
+
+# ---- models.make('neus', cfg) -> FusedNeuSModel --------------------------------------------------------------------------
+NEUS_LAMBDAS = {"lambda_rgb_mse": 10.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_opaque": 0.05, "lambda_eikonal": 0.1,
+                "lambda_sparsity": 0.02, "sparsity_scale": 1.0}
+
+
+def _neus_pair(name, step):
+    """the reference's NeuS model (modular path, tests/refmirror) and the fused entry with the same parameters / grids"""
+    import nsr
+    import nsr.models
+    import refmirror
+    torch.manual_seed(0)
+    cfg = nsr.configs.get(name)
+    cfg["num_samples_per_ray"] = 256
+    ref = refmirror.NeuSModel(cfg).cuda().train()
+    with torch.no_grad():
+        enc = ref.geometry.encoding.encoding
+        (enc.encoding if hasattr(enc, "encoding") else enc).params.normal_(0, 0.05)
+        ref.geometry.network.layers[0].weight_v[:, 3:].normal_(0, 0.05)
+        if cfg.get("learned_background"):
+            ref.geometry_bg.encoding_with_network.encoding.encoding.params.normal_(0, 0.3)
+    r = float(cfg["radius"])
+    ii = torch.stack(torch.meshgrid(*[torch.arange(128)] * 3, indexing="ij"), -1).float().cuda()
+    ref.occupancy_grid._binary = (((ii + 0.5) / 128 * 2 * r - r).norm(dim=-1) < 0.55 * r)
+    fused = nsr.models.FusedNeuSModel(cfg).cuda().train()
+    res = fused.load_state_dict(ref.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for m in (ref, fused):
+        m.update_step(0, step)   # not a multiple of 16: schedules only, no occupancy refresh
+        m.randomized = False
+        m.background_color = torch.tensor([0.3, 0.5, 0.7], device="cuda")
+    return ref, fused, cfg
+
+
+@pytest.mark.parametrize("name,step", [("neus-blender", 7001), ("neuralangelo", 9005), ("neus-dtu", 7001)])
+def test_fused_neus_entry_runs_the_reference_system_step(name, step):
+    """systems/neus.py:88-139 on both models: same output dict, same losses, same parameter gradients"""
+    import fixture_utils as fu
+    from torch_efficient_distloss import flatten_eff_distloss
+    ref, fused, cfg = _neus_pair(name, step)
+    g = torch.Generator().manual_seed(1)
+    scale = float(cfg["radius"]) / 1.5
+    o = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1) * 4.0 * scale
+    d = torch.nn.functional.normalize(-o + torch.randn(300, 3, generator=g) * 0.45 * scale, dim=-1)
+    rays = torch.cat([o, d], -1).cuda()
+    rgb = torch.rand(300, 3, generator=g).cuda()
+    fg = (torch.rand(300, generator=g) > 0.4).float().cuda()
+    lam = dict(NEUS_LAMBDAS, lambda_curvature=(1e-4 if name == "neuralangelo" else 0.0))
+    outs, grads = [], []
+    for m in (ref, fused):
+        out = m(rays)
+        loss, terms = fu.neus_system_loss(out, rgb, fg, lam)
+        loss = loss + 0.01 * flatten_eff_distloss(out["weights"], out["points"], out["intervals"], out["ray_indices"])
+        loss.backward()
+        outs.append((out, float(loss), {k: float(v) for k, v in terms.items()}))
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None and p.numel()})
+    (o_ref, l_ref, t_ref), (o_fu, l_fu, t_fu) = outs
+    assert set(o_fu) == set(o_ref), set(o_fu) ^ set(o_ref)
+    assert int(o_fu["num_samples"]) == int(o_ref["num_samples"]) > 5000
+    assert int(o_fu["num_samples_full"]) == int(o_ref["num_samples_full"])
+    assert torch.equal(o_fu["ray_indices"], o_ref["ray_indices"])
+    assert torch.equal(o_fu["rays_valid_full"], o_ref["rays_valid_full"])
+    for k in ("comp_rgb_full", "comp_rgb", "opacity", "depth", "comp_normal", "sdf_samples", "sdf_grad_samples", "weights",
+              "points", "intervals"):
+        a, b = o_fu[k].detach().reshape(-1), o_ref[k].detach().reshape(-1)
+        assert a.shape == b.shape, k
+        bad = float(((a - b).abs() > 2e-3 + 2e-3 * b.abs()).float().mean())  # (cell-face outliers: see test_gpu_fused_neus.py)
+        assert bad < 5e-3, (name, k, bad, float((a - b).abs().max()))
+    assert abs(float(o_fu["inv_s"]) - float(o_ref["inv_s"])) < 1e-5 * float(o_ref["inv_s"])
+    for k in t_ref:
+        assert abs(t_fu[k] - t_ref[k]) <= 2e-3 * abs(t_ref[k]) + 1e-5, (name, k, t_fu[k], t_ref[k])
+    assert abs(l_fu - l_ref) < 2e-3 * abs(l_ref)
+    assert set(grads[1]) == set(grads[0]), set(grads[1]) ^ set(grads[0])
+    for k, w in grads[0].items():
+        e = fu.rel_l2(grads[1][k], w)
+        assert e < 2e-2, (name, k, e)
+
+
+def test_fused_neus_entry_accumulates_gradients_and_evaluates_in_chunks():
+    """two backward passes before an optimizer step (accumulate_grad_batches) add up; eval is chunked and gradient-free"""
+    _, fused, cfg = _neus_pair("neus-blender", 7001)
+    g = torch.Generator().manual_seed(2)
+    o = torch.nn.functional.normalize(torch.randn(128, 3, generator=g), dim=-1) * 4.0
+    rays = torch.cat([o, torch.nn.functional.normalize(-o, dim=-1)], -1).cuda()
+
+    def one():
+        out = fused(rays)
+        (out["comp_rgb_full"].mean() + 0.1 * ((out["sdf_grad_samples"].norm(dim=-1) - 1) ** 2).mean()).backward()
+
+    one()
+    first = {k: p.grad.clone() for k, p in fused.named_parameters() if p.grad is not None}
+    one()
+    for k, p in fused.named_parameters():
+        if k in first:
+            assert fu_rel(p.grad, 2 * first[k]) < 1e-5, k
+    fused.eval()
+    fused.config["ray_chunk"] = 50
+    out = fused(rays)
+    assert out["comp_rgb_full"].device.type == "cpu" and not out["comp_rgb_full"].requires_grad
+    assert "sdf_samples" not in out and out["comp_rgb_full"].shape == (128, 3)
+
+
+def fu_rel(a, b):
+    import fixture_utils as fu
+    return fu.rel_l2(a, b)
