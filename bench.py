@@ -313,10 +313,70 @@ def boundary_path(dev, warmup=300, steps=200):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"samples_per_sec": n_samples / dt, "ms_per_step": 1e3 * dt / steps, "train_rays_per_sec": n_rays / dt,
-            "kept_samples_per_step": n_samples / steps, "rays_per_step": n_rays / steps, "final_loss": float(loss),
+            "kept_samples_per_step": n_samples / steps, "rays_per_step": n_rays / steps, "final_loss": float(loss.detach()),
             "warmup": warmup, "steps": steps, "optimizer": opt_kind, "model": "nsr.models.FusedNeRFModel",
             "what": "reference-style step through the model interface: torch ray sampling, model.update_step, model(rays), "
                     ".item() on num_samples, torch smooth-L1 on boolean-masked rays, loss.backward(), torch AdamW, MultiStepLR"}
+
+
+def boundary_path_neus(dev, warmup=100, steps=100):
+    """configs[2] (neus-blender) driven through the drop-in boundary the way the reference's NeuS system drives its model
+    (systems/neus.py:88-139): torch ray sampling -> model.update_step -> out = model(rays) -> dynamic ray count from
+    out['num_samples_full'] -> MSE / L1 on the valid rays, eikonal on sdf_grad_samples, mask BCE on opacity, in torch ->
+    loss.backward() -> torch AdamW with the YAML's parameter groups.  Model: nsr.models.FusedNeuSModel."""
+    import nsr
+    import nsr.models
+    from nsr.scene import SyntheticBlender
+    torch.manual_seed(7)
+    cfg = nsr.configs.get("neus-blender")
+    model = nsr.models.FusedNeuSModel(cfg).to(dev).train()
+    data = SyntheticBlender(n_images=20, w=400, h=400, device=dev, seed=0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    var = [model.variance.variance]
+    rest = [p for p in model.parameters() if p is not var[0] and p.numel() > 0]
+    groups = [{"params": rest, "lr": 0.01}, {"params": var, "lr": 0.001}]
+    try:
+        opt = torch.optim.AdamW(groups, betas=(0.9, 0.99), eps=1e-15, fused=True)
+        opt_kind = "torch.optim.AdamW(fused=True)"
+    except Exception:  # noqa: BLE001
+        opt = torch.optim.AdamW(groups, betas=(0.9, 0.99), eps=1e-15)
+        opt_kind = "torch.optim.AdamW"
+    train_num_rays = cfg["train_num_rays"]
+    target = cfg["train_num_rays"] * (cfg["num_samples_per_ray"] + cfg.get("num_samples_per_ray_bg", 0))
+    n_samples = n_rays = 0
+    t0 = None
+    F = torch.nn.functional
+    for step in range(warmup + steps):
+        if step == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        rays, rgb, fg, bg = data.sample_rays(train_num_rays, gen, cfg["background_color"])
+        model.background_color = bg
+        model.update_step(0, step)
+        out = model(rays)
+        n = int(out["num_samples_full"].sum().item())
+        if cfg["dynamic_ray_sampling"] and n > 0:
+            t = int(train_num_rays * (target / n))
+            train_num_rays = min(int(train_num_rays * 0.9 + t * 0.1), cfg["max_train_num_rays"])
+        valid = out["rays_valid_full"][..., 0]
+        loss = 10.0 * F.mse_loss(out["comp_rgb_full"][valid], rgb[valid])
+        loss = loss + 0.1 * ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()
+        opacity = torch.clamp(out["opacity"].squeeze(-1), 1.0e-3, 1.0 - 1.0e-3)
+        loss = loss + 0.1 * F.binary_cross_entropy(opacity, fg.float())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        if step >= warmup:
+            n_samples += n
+            n_rays += rays.shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"samples_per_sec": n_samples / dt, "ms_per_step": 1e3 * dt / steps, "samples_per_step": n_samples / steps,
+            "rays_per_step": n_rays / steps, "final_loss": float(loss.detach()), "warmup": warmup, "steps": steps,
+            "optimizer": opt_kind, "model": "nsr.models.FusedNeuSModel (neus-blender)",
+            "what": "reference-style NeuS step through the model interface: torch ray sampling, model.update_step, model(rays), "
+                    "torch MSE / eikonal / mask losses, loss.backward(), torch AdamW"}
 
 
 def side_measurement(name, timeout=600):
@@ -623,6 +683,7 @@ def main():
                            "multi-rank path, not a scaling measurement")
         if world == 1 and not args.no_boundary_path:
             res["boundary_path"] = side_measurement("boundary_path")
+            res["boundary_path_neus"] = side_measurement("boundary_path_neus")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         res["other_workloads"] = others

@@ -308,10 +308,14 @@ class FusedNeuSStep:
                                            n_rays, s), "nsr_bg_visibility_prefix")
         check(lib.nsr_pack_from_counts(ptr(kept), ptr(pk), ptr(total), n_rays, s), "nsr_pack_from_counts")
         S = int(total.item())
+        Sa = max(S, 1)  # (nothing kept -- e.g. an empty background grid: the ray kernels still run, on non-NULL arrays)
         c = dict(packed=pk, S=S, M=M, rays_d=rays_d, n_rays=n_rays,
-                 ri=torch.empty(S, dtype=torch.int64, device=dev), t0=torch.empty(S, dtype=F32, device=dev),
-                 t1=torch.empty(S, dtype=F32, device=dev), x01=torch.empty((S, 3), dtype=F32, device=dev),
-                 xin=torch.empty((S, self.bg_n_enc), dtype=F32, device=dev), out=torch.empty((S, 16), dtype=F32, device=dev))
+                 ri=torch.empty(Sa, dtype=torch.int64, device=dev)[:S], t0=torch.empty(Sa, dtype=F32, device=dev)[:S],
+                 t1=torch.empty(Sa, dtype=F32, device=dev)[:S], x01=torch.empty((Sa, 3), dtype=F32, device=dev)[:S],
+                 xin=torch.empty((Sa, self.bg_n_enc), dtype=F32, device=dev)[:S],
+                 out=torch.empty((Sa, 16), dtype=F32, device=dev)[:S])
+        if S == 0:
+            return c
         srcs, dsts = [t0_m, t1_m, x01_m, xin_m, out_m], [c["t0"], c["t1"], c["x01"], c["xin"], c["out"]]
         k = len(srcs)
         sp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])

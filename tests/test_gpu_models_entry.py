@@ -169,6 +169,9 @@ def _neus_pair(name, step):
     r = float(cfg["radius"])
     ii = torch.stack(torch.meshgrid(*[torch.arange(128)] * 3, indexing="ij"), -1).float().cuda()
     ref.occupancy_grid._binary = (((ii + 0.5) / 128 * 2 * r - r).norm(dim=-1) < 0.55 * r)
+    if cfg.get("learned_background"):
+        jj = torch.stack(torch.meshgrid(*[torch.arange(256)] * 3, indexing="ij"), -1).cuda()
+        ref.occupancy_grid_bg._binary = ((jj.sum(-1) % 3) != 0)  # a deterministic 2/3-full pattern of the contracted space
     fused = nsr.models.FusedNeuSModel(cfg).cuda().train()
     res = fused.load_state_dict(ref.state_dict(), strict=True)
     assert not res.missing_keys and not res.unexpected_keys
