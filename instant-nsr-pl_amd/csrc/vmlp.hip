@@ -249,10 +249,12 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 }
 
 // One wave per block: forward recompute + data gradient + weight gradient (+ second-order terms) of its tiles.
-// Register budget: 304-468 (arch + acc), one wave per SIMD, no spills -- after two fixes found in the ISA: the per-column
-// offsets of the d_x stores and of the final partial stores are functions of the lane only, so the compiler computed them
-// BEFORE the tile loop and kept ~70 + ~100 registers alive across it (spilling 57-152 of them in the two-hidden-layer
-// variants); the lane coordinates are now made opaque (empty asm) right where those addresses are needed.
+// Register budget: 380-496 (arch + acc), one wave per SIMD, no spills -- after two fixes found in the ISA: the complete 64-bit
+// per-column offsets of the d_x stores and of the final partial stores are functions of the lane only, so the compiler computed
+// them BEFORE the tile loop and kept ~70 + ~100 registers alive across it (spilling 57-152 of them in the two-hidden-layer
+// variants).  Now the d_x stores use twelve explicit 32-bit column parts + one 64-bit row base per tile, and the epilogue's
+// lane coordinates are made opaque (empty asm) where its addresses are formed.  Measured against the round-2 kernel: colour
+// heads (two hidden layers) 477 vs 576 us and 720 vs 898 us (C5 / C4), SDF network 1303 vs 1320 us (C5), 688 vs 715 us (C3).
 // Measured alternative (round 3): a 128-thread workgroup with a "data" wave (forward / dgrad / d_x) feeding a "weight" wave
 // (all dW accumulators) through the LDS tiles -- <= 248 registers, two waves per SIMD, no spills, all parity tests green --
 // was SLOWER: C5 SDF backward 1.69 ms vs 1.32 ms, colour head 0.49 vs 0.50 ms, C3 step +4 %.  Two barriers per 16-sample
@@ -309,6 +311,17 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
     }
     const uint32_t n_tiles = (n_live + 15) / 16;
     const uint32_t lm_shift = dx_lm_features ? 31u - (uint32_t)__clz((int)dx_lm_features) : 0u;
+    // d_x addressing (see the store below): per-column offsets of this lane's NB0 x 4 output columns, 32 bits each
+    uint32_t col_part[NB0 * 4], col_ok = 0u;
+#pragma unroll
+    for (int q = 0; q < NB0 * 4; ++q) {
+        const uint32_t col = (q >> 2) * 16 + 4 * g + (q & 3);  // input feature of D register (fb = q >> 2, r = q & 3)
+        const bool ok = col >= dx_first && col < dx_first + dx_count;
+        const uint32_t k = ok ? col - dx_first : 0u;
+        // level-major [k / F][n][F], F a power of two: ((k >> s) n + sample) << s | (k & (F - 1))
+        col_part[q] = dx_lm_features ? ((((k >> lm_shift) * n) << lm_shift) | (k & (dx_lm_features - 1u))) : k;
+        col_ok |= ok ? (1u << q) : 0u;
+    }
     // software pipeline: the NEXT tile's inputs (features, output gradient, P) are requested before this tile's MFMA chain
     float xnext[KS], pnext[KS];
     f32x4 donext;
@@ -525,11 +538,10 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
         }
         // ---- input gradient dX^T = W0^T dz0^T ----------------------------------------------------------------------
         if (d_x) {
-            // (lane coordinates made opaque per tile: the per-column store offsets are otherwise hoisted out of the tile loop
-            // as ~70 loop-invariant registers; re-deriving them costs ~30 VALU per tile)
-            int cx = c, gx = g;
-            asm volatile("" : "+v"(cx), "+v"(gx));
-            const uint64_t sx = (uint64_t)tile * 16 + cx;
+            // store offset of column col for sample sx = row_base(sx) + col_part[col]: the column parts are 32-bit loop
+            // invariants (12 registers, set up before the tile loop), the row base is one 64-bit value per tile.  (Left to
+            // itself the compiler hoisted the complete 64-bit per-column offsets: ~70 registers, spilled in the NH = 2 variants.)
+            float *row = d_x + (dx_lm_features ? (s << lm_shift) : s * dx_stride);
 #pragma unroll
             for (int fb = 0; fb < NB0; ++fb) {
                 f32x4 acc = zero4;
@@ -537,22 +549,14 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int col = fb * 16 + cx;
-                        const float wt = col < IN_PAD ? W0t[(nb * 16 + 4 * gx + r) * IN_PAD + col] : 0.f;
+                        const int col = fb * 16 + c;
+                        const float wt = col < IN_PAD ? W0t[(nb * 16 + 4 * g + r) * IN_PAD + col] : 0.f;
                         acc = mfma4(wt, dz0[nb][r], acc);
                     }
-                if (sx < n_live) {
+                if (valid) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t col = fb * 16 + 4 * gx + r;  // input feature
-                        if (col < dx_first || col >= dx_first + dx_count) continue;
-                        const uint32_t k = col - dx_first;
-                        // level-major [k / F][n][F] with F a power of two
-                        const uint64_t off = dx_lm_features
-                            ? ((((uint64_t)(k >> lm_shift) * n + sx) << lm_shift) | (k & (dx_lm_features - 1u)))
-                            : sx * dx_stride + k;
-                        d_x[off] = acc[r];
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (col_ok & (1u << (fb * 4 + r))) row[col_part[fb * 4 + r]] = acc[r];
                 }
             }
         }
@@ -824,6 +828,8 @@ extern "C" int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, con
     NSR_REQUIRE(!p_in || (desc->n_hidden == 1), "nsr_vmlp_backward: second-order terms need one hidden layer");
     NSR_REQUIRE((dx_level_major_features & (dx_level_major_features - 1u)) == 0u,
                 "nsr_vmlp_backward: dx_level_major_features must be a power of two (the hash grid's features per level)");
+    NSR_REQUIRE(!dx_level_major_features || (uint64_t)n * (dx_count ? dx_count : desc->n_in) < (1ull << 32),
+                "nsr_vmlp_backward: level-major d_x offsets are 32-bit (n x columns must stay below 2^32)");
     const uint32_t bf = (uint32_t)nsr_vmlp_blob_floats(desc);
     const uint32_t blocks = vmlp_blocks(n);
     const int ks = desc->in_pad / 4, nh = desc->n_hidden, act = desc->activation;
