@@ -120,7 +120,7 @@ __device__ __forceinline__ f32x4 load_chain(const float *__restrict__ M, int mb,
 }
 
 template <int KS, int NH, int ACT, bool SDF_IN, bool GRAD_IN>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint32_t x_stride,
                const __half *__restrict__ enc, uint32_t enc_stride, uint32_t n_in, uint32_t n_out,
                float *__restrict__ out /* [n_full][16] */, float *__restrict__ out_col0 /* [n - n_full] */,
@@ -218,6 +218,10 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
             }
         }
         if (GRAD_IN) {  // d out[0] / d input = W0^T (act'(z) * Wl[0][:])   (1 hidden layer)
+            // the 48 W0^T fragments below are loop invariant: hoisted, they cost 48 registers and push the kernel past 256
+            // (one wave per SIMD); re-read per tile from L1 (pointer made opaque) it fits two
+            const float *W0g = B.W0;
+            asm volatile("" : "+s"(W0g));
             f32x4 q[4];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -233,7 +237,7 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int col = fb * 16 + c;
-                        const float wt = col < IN_PAD ? B.W0[(nb * 16 + 4 * g + r) * IN_PAD + col] : 0.f;
+                        const float wt = col < IN_PAD ? W0g[(nb * 16 + 4 * g + r) * IN_PAD + col] : 0.f;
                         gh = mfma4(wt, q[nb][r], gh);
                     }
                 if (valid) {
