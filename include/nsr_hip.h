@@ -238,6 +238,35 @@ int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stri
                         const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, void *wgrad_stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * tcnn.NetworkWithInputEncoding -- models/network_utils.py:209-214 (HashGrid -> FullyFusedMLP, one flat parameter
+ * [network | grid]); SURVEY.md section 8(b) `nsr_grid_mlp_forward/backward`.
+ *
+ * Forward in ONE kernel: the wave that runs the MLP encodes its 16-sample tile into the first MFMA operand itself (lane
+ * (sample, g) = levels [g * 8 / F, (g + 1) * 8 / F)); results are bit-identical to nsr_hashgrid_forward + nsr_mlp_forward.
+ * Needs n_levels * n_features == mlp.n_in <= 32 == mlp.in_pad, out_pad 16, 1-2 hidden layers (nsr_grid_mlp_supported).
+ *   out  [n,16] half; acts (NULL for inference) n_hidden * [n,64] half; enc (NULL, or the encoded features for the
+ *   backward: row-major [n, enc_stride] half with enc_stride % 8 == 0, or level-major [L][n][F] with enc_level_major).
+ * It trades the XCD placement of the stand-alone encode for one launch and 128 B / sample less traffic: faster for small
+ * launches, slower for large ones (DESIGN.md section 4 has the measured crossover; nsr_hip/ops.py picks by n).
+ * nsr_grid_mlp_forward_max_blocks: developer switch (grid size cap; 0 = query), returns the previous value.
+ * ------------------------------------------------------------------------------------------------ */
+int nsr_grid_mlp_supported(const NsrGridDesc *grid, const NsrMlpDesc *mlp);
+int nsr_grid_mlp_forward(const float *x, const nsr_half *table, const nsr_half *weights, nsr_half *out, nsr_half *acts,
+                         nsr_half *enc, uint32_t enc_stride, int enc_level_major, uint32_t n, uint32_t level_mask_count,
+                         const NsrGridDesc *grid, const NsrMlpDesc *mlp, const int32_t *n_dev, void *stream);
+uint32_t nsr_grid_mlp_forward_max_blocks(uint32_t max_blocks);
+/* Backward of the pair in one call: MLP data gradient written level-major (what the table backward reads: no transpose,
+ * one trip through HBM), weight gradients (grad_weights fp32, ACCUMULATED, may be NULL), item binning + owner-computes
+ * accumulation into grad_table (fp32, OVERWRITTEN).  dout / out / acts / grad_scale as nsr_mlp_backward; enc as written
+ * by the forward.  workspace: nsr_grid_mlp_backward_workspace_floats() floats. */
+uint64_t nsr_grid_mlp_backward_workspace_floats(const NsrGridDesc *grid, const NsrMlpDesc *mlp, uint32_t n);
+int nsr_grid_mlp_backward(const void *dout, int dout_is_f32, uint32_t dout_stride, const nsr_half *out, const float *x,
+                          const nsr_half *enc, uint32_t enc_stride, int enc_level_major, const nsr_half *acts,
+                          const nsr_half *weights, float *grad_weights, float *grad_table, float *workspace, uint32_t n,
+                          uint32_t level_mask_count, float grad_scale, const NsrGridDesc *grid, const NsrMlpDesc *mlp,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * nerfacc 0.3.3 kernels
  * ------------------------------------------------------------------------------------------------ */
 #define NSR_CONTRACT_AABB 0

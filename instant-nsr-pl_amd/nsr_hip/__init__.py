@@ -134,6 +134,11 @@ SIGNATURES = {
     "nsr_sh4_forward": [_P, _P, _U, _U, _P],
     "nsr_mlp_forward": [_P, _I, _U, _P, _P, _P, _U, _MD, _P],
     "nsr_mlp_forward_ex": [_P, _I, _U, _U, _P, _P, _P, _U, _MD, _P, _P],
+    "nsr_grid_mlp_supported": [_GD, _MD],
+    "nsr_grid_mlp_forward": [_P, _P, _P, _P, _P, _P, _U, _I, _U, _U, _GD, _MD, _P, _P],
+    "nsr_grid_mlp_forward_max_blocks": [_U],
+    "nsr_grid_mlp_backward_workspace_floats": [_GD, _MD, _U],
+    "nsr_grid_mlp_backward": [_P, _I, _U, _P, _P, _P, _U, _I, _P, _P, _P, _P, _P, _U, _U, _F, _GD, _MD, _P],
     "nsr_mlp_backward_workspace_floats": [_MD, _U],
     "nsr_mlp_backward": [_P, _I, _U, _P, _P, _I, _U, _P, _P, _P, _P, _U, _P, _U, _F, _MD, _P],
     "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P],
@@ -237,7 +242,8 @@ SIGNATURES = {
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }
-_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32,
+             "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_taps_workspace_floats": ctypes.c_uint64,

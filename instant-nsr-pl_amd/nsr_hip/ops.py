@@ -5,6 +5,8 @@ stream to ``libnsr_hip.so``.  No arithmetic of the hot path happens in Python.
 """
 import ctypes
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -293,16 +295,66 @@ def mlp(x, params, owner):
     return _Mlp.apply(x, params, owner, _wants_grad(x, params))
 
 
+# Launches of at most this many samples take the one-kernel encode -> MLP forward (csrc/gridmlp.hip); larger ones the
+# XCD-placed encode + MLP pair.  Measured (tools/grid_mlp_ab.py, profiles/r03_grid_mlp_ab.json): 19 vs 27 us at 2,048
+# samples, 21-25 vs 26 us at 8,192; even at 32,768 for ray-ordered positions; from there on the pair wins for unordered
+# positions (262,144 uniform samples: 160 vs 183 us) and ties for ray-ordered ones.
+GRID_MLP_FUSED_MAX_N = int(os.environ.get("NSR_GRID_MLP_FUSED_MAX_N", "16384"))
+
+
+def grid_mlp_supported(gdesc, mdesc):
+    return bool(lib.nsr_grid_mlp_supported(_byref(gdesc), _byref(mdesc)))
+
+
+def grid_mlp_forward(x, table_half, weights_half, gdesc, mdesc, mask_count=None, save_acts=False, want_enc=False,
+                     enc_level_major=False):
+    """one kernel: out [n,16] half, acts (or None), enc (or None; row-major [n, L*F] or level-major [L, n, F])"""
+    n = x.shape[0]
+    mc = gdesc.n_levels if mask_count is None else int(mask_count)
+    C = gdesc.n_levels * gdesc.n_features
+    out = torch.empty((n, mdesc.out_pad), dtype=F16, device=x.device)
+    acts = torch.empty((mdesc.n_hidden, n, 64), dtype=F16, device=x.device) if save_acts else None
+    enc = None
+    if want_enc:
+        enc = torch.empty((gdesc.n_levels, n, gdesc.n_features) if enc_level_major else (n, C), dtype=F16, device=x.device)
+    with torch.cuda.device(x.device), _timed("grid_mlp_forward", n):
+        check(lib.nsr_grid_mlp_forward(ptr(x), ptr(table_half), ptr(weights_half), ptr(out), ptr(acts), ptr(enc),
+                                       0 if (enc is None or enc_level_major) else enc.stride(0), int(enc_level_major), n, mc,
+                                       _byref(gdesc), _byref(mdesc), None, stream_ptr()), "nsr_grid_mlp_forward")
+    return out, acts, enc
+
+
+def grid_mlp_backward(dout, out, x, enc, acts, weights_half, gdesc, mdesc, grad_weights, grad_table, mask_count=None,
+                      grad_scale=128.0, enc_level_major=False):
+    """dgrad (level-major d_enc) + weight gradients (accumulated into grad_weights) + owner-computes table backward
+    (grad_table overwritten) in one call"""
+    n = x.shape[0]
+    mc = gdesc.n_levels if mask_count is None else int(mask_count)
+    nws = lib.nsr_grid_mlp_backward_workspace_floats(_byref(gdesc), _byref(mdesc), n)
+    ws = torch.empty(int(nws), dtype=F32, device=x.device)
+    with torch.cuda.device(x.device), _timed("grid_mlp_backward", n):
+        check(lib.nsr_grid_mlp_backward(ptr(dout), _is_f32(dout), dout.stride(0), ptr(out), ptr(x), ptr(enc),
+                                        0 if enc_level_major else enc.stride(0), int(enc_level_major), ptr(acts),
+                                        ptr(weights_half), ptr(grad_weights), ptr(grad_table), ptr(ws), n, mc,
+                                        float(grad_scale), _byref(gdesc), _byref(mdesc), stream_ptr()),
+              "nsr_grid_mlp_backward")
+
+
 class _GridMlp(Function):
     """tcnn.NetworkWithInputEncoding: encode -> MLP with ONE flat parameter ([network | grid])."""
 
     @staticmethod
     def forward(ctx, x, params, owner, train):
         table, w = owner.table_half(params), owner.weights_half(params)
-        enc = hashgrid_forward(x, table, owner.grid_desc, owner.level_mask_count())
-        out, acts = mlp_forward(enc, w, owner.mlp_desc, save_acts=train)
+        fusable = grid_mlp_supported(owner.grid_desc, owner.mlp_desc)
+        if fusable and x.shape[0] <= GRID_MLP_FUSED_MAX_N:
+            out, acts, enc = grid_mlp_forward(x, table, w, owner.grid_desc, owner.mlp_desc, owner.level_mask_count(),
+                                              save_acts=train, want_enc=train)
+        else:
+            enc = hashgrid_forward(x, table, owner.grid_desc, owner.level_mask_count())
+            out, acts = mlp_forward(enc, w, owner.mlp_desc, save_acts=train)
         ctx.save_for_backward(x, params)
-        ctx.owner, ctx.table, ctx.w, ctx.enc, ctx.out, ctx.acts = owner, table, w, enc, out, acts
+        ctx.owner, ctx.table, ctx.w, ctx.enc, ctx.out, ctx.acts, ctx.fusable = owner, table, w, enc, out, acts, fusable
         res = out[:, :owner.mlp_desc.n_out]
         return res.float() if owner.dtype == torch.float32 else res
 
@@ -318,6 +370,13 @@ class _GridMlp(Function):
         if need_p:  # only the (tiny) MLP slice needs zeroing; the grid slice is overwritten by the owner kernel
             dp = torch.empty_like(params, dtype=F32)
             owner.mlp_slice(dp).zero_()
+        if need_p and not need_x and ctx.fusable:
+            # the MLP's data gradient leaves level-major, as the table backward reads it: no [n, L*F] fp32 round trip, no
+            # transpose kernel
+            grid_mlp_backward(dout.contiguous(), ctx.out, x, ctx.enc, ctx.acts, ctx.w, owner.grid_desc, owner.mlp_desc,
+                              owner.mlp_slice(dp), owner.grid_slice(dp), owner.level_mask_count(),
+                              grad_scale=owner.loss_scale)
+            return None, dp, None, None
         # grads w.r.t. the encoding leave the MLP in fp32 and feed the table backward directly
         d_enc = mlp_backward(dout.contiguous(), ctx.out, ctx.enc, ctx.acts, ctx.w, owner.mlp_desc,
                              grad_weights=owner.mlp_slice(dp) if need_p else None, want_dx=True,

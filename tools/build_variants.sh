@@ -12,7 +12,7 @@ for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   ( hipcc $FLAGS $defs -c "$CS/hashgrid.hip" -o "$OUT/hashgrid_$name.o" &&
     hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libnsr_hip_$name.so" "$OUT/hashgrid_$name.o" \
-      "$CS"/obj/{util,mlp,vmlp,neus,march,render,fused,occupancy,step}.o && echo "built $name ($defs)" ) &
+      "$CS"/obj/{util,gridmlp,mlp,vmlp,neus,march,render,fused,occupancy,step}.o && echo "built $name ($defs)" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
