@@ -64,8 +64,14 @@ int nsr_hashgrid_make_desc(NsrGridDesc *out, uint32_t n_levels, uint32_t n_featu
 int nsr_hashgrid_forward(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                          uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
 
-/* same with the output optionally LEVEL-MAJOR ([L][n][F] halfs; y_stride ignored): every wavefront then stores 64*F
- * consecutive halfs instead of 64 scattered F-half pieces (the fused path's layout; nsr_mlp_forward_ex reads it) */
+/* same with a choice of output layout, y_level_major =
+ *   0: row-major [n, y_stride] (the tcnn API's);
+ *   1: LEVEL-major [L][n][F] halfs (y_stride ignored): every wavefront stores 64*F consecutive halfs instead of 64 scattered
+ *      F-half pieces (the fused NeRF step's layout; nsr_mlp_forward_ex reads it);
+ *   2: TILE-major [ceil(n/16)][L][16][F] halfs (y_stride ignored; the buffer holds ceil(n/16)*16 rows): the 16 rows of an
+ *      MFMA tile are one contiguous block and each level's 16*F halfs are contiguous inside it -- 64-B stores for the
+ *      encode, 2-3 runs per load for the fp32 MLP kernels (nsr_vmlp_*: enc_stride = 0x40000000 | F; the fused NeuS steps).
+ * nsr_hashgrid_forward_jac and nsr_hashgrid_forward_taps (rows = the 7n points) take the same values. */
 int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                             int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
                             const int32_t *n_dev, void *stream);
@@ -725,7 +731,8 @@ int nsr_vmlp_unfold_gradient(const NsrVmlpDesc *desc, const NsrVanillaLayer *lay
                              const float *grad_blob, int accumulate, void *stream);
 /* x: fp32 rows [n][x_stride]; with enc != NULL the input is [2 x - 1 (3 columns of x) | enc (fp16 rows, n_in - 3 columns)]
  * (CompositeEncoding with include_xyz, models/network_utils.py:75-76); enc_stride = 0x80000000 | F selects the level-major
- * encoding [(n_in - 3) / F][n][F] that the fused encode kernels write.  Rows < n_full write all 16 output columns to
+ * encoding [(n_in - 3) / F][n][F] that the fused encode kernels write, enc_stride = 0x40000000 | F the tile-major one
+ * [ceil(n/16)][(n_in - 3) / F][16][F] (nsr_hashgrid_forward_ex, layout 2).  Rows < n_full write all 16 output columns to
  * out[n_full][16], rows >= n_full only column 0 to out_col0[n - n_full] (finite-difference taps).  g_in (may be NULL,
  * one hidden layer): [n][in_pad] = d out[0] / d input (analytic normal, models/geometry.py:176-180). */
 int nsr_vmlp_forward(const NsrVmlpDesc *desc, const float *blob, const float *x, uint32_t x_stride, const nsr_half *enc,

@@ -47,6 +47,21 @@ __device__ __forceinline__ bool map_block(uint32_t n_levels, uint32_t lpx, uint3
     return level < n_levels;
 }
 
+// Where row i, level `level` of an encoding with `rows` rows goes.  layout 0: row-major [rows, y_stride] (what the tcnn API
+// returns; a wave's stores are 64 F-half pieces 2 * y_stride bytes apart -- each leaves the L2 as its own masked sector:
+// measured 160-187 MB of fabric writes for a 17-19 MB output).  1: level-major [L][rows][F] (a wave stores 64 x F
+// consecutive halfs; what the NeRF step and the table backward use).  2: tile-major [rows / 16][L][16][F]: the 16 rows of
+// an MFMA tile are ONE contiguous L * 32 F bytes (as in row-major), and inside it each level's 16 x F halfs are
+// contiguous -- the encode still stores 64-B runs, the fp32 MLP kernels (csrc/vmlp.hip, lane = (row in tile, k mod 4))
+// read 2-3 such runs per load instruction instead of 16 rows.
+__device__ __forceinline__ __half *enc_at(__half *y, int layout, uint64_t i, uint32_t level, uint64_t rows, uint32_t y_stride,
+                                          uint32_t L, uint32_t F)
+{
+    if (layout == 1) return y + ((uint64_t)level * rows + i) * F;
+    if (layout == 2) return y + (((i >> 4) * L + level) * 16 + (i & 15)) * F;
+    return y + i * y_stride + level * F;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -65,7 +80,7 @@ k_grid_forward(const float *__restrict__ x, const __half *__restrict__ table, __
     // row-major [n, y_stride] is what the tcnn API returns; level-major [L][n][F] is what the fused path uses: a wave
     // then stores 64 x F consecutive halfs (measured: the row-major 4-B stores, issued level by level from different
     // XCDs, cost 187 MB of fabric writes for a 19 MB output)
-    __half *yo = level_major ? y + ((uint64_t)level * n + i) * F : y + (uint64_t)i * y_stride + level * F;
+    __half *yo = enc_at(y, level_major, i, level, n, y_stride, d.n_levels, F);
     float acc[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -184,7 +199,7 @@ k_grid_forward_lds(const float *__restrict__ x, const __half *__restrict__ table
 #pragma unroll
             for (int f = 0; f < F; ++f) acc[f] = 0.f;
         }
-        store_enc<F>(level_major ? y + ((uint64_t)level * n + i) * F : y + (uint64_t)i * y_stride + level * F, acc);
+        store_enc<F>(enc_at(y, level_major, i, level, n, y_stride, d.n_levels, F), acc);
     }
 }
 
@@ -243,7 +258,7 @@ k_grid_forward_pair(const float *__restrict__ x, const __half *__restrict__ tabl
 #pragma unroll
             for (int f = 0; f < F; ++f) acc[f] = 0.f;
         }
-        store_enc<F>(level_major ? y + ((uint64_t)level * n + i) * F : y + (uint64_t)i * y_stride + level * F, acc);
+        store_enc<F>(enc_at(y, level_major, i, level, n, y_stride, d.n_levels, F), acc);
     }
 }
 
@@ -285,7 +300,7 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
 {
     // row pointer of point p (0 .. 7n-1): row-major [7n][y_stride] or level-major [L][7n][F]
     const uint64_t n7 = 7ull * n;
-#define TAP_ROW(p) (level_major ? y + ((uint64_t)level * n7 + (p)) * F : y + (uint64_t)(p) * y_stride + level * F)
+#define TAP_ROW(p) enc_at(y, level_major, (p), level, n7, y_stride, d.n_levels, F)
     uint32_t level, blk;
     if (!map_block(d.n_levels, lpx, level, blk)) return;
     const uint32_t i = blk * GRID_BLOCK + threadIdx.x;

@@ -96,19 +96,82 @@ __device__ __forceinline__ Blob split_blob(const float *p)
 // input feature k of sample s.  SDF_IN: [2 x01 - 1 (3) | hash encoding (fp16, row-major)] (CompositeEncoding with
 // include_xyz, models/network_utils.py:75-76); otherwise fp32 rows
 // enc_stride >= 0x80000000: level-major encoding [C/F][n][F] with F = enc_stride & 0xff and n = the row count (what the
-// fused encode kernels write: a wave stores 64 x F consecutive halfs)
+// fused encode kernels write: a wave stores 64 x F consecutive halfs).  enc_stride & 0x40000000: tile-major
+// [n / 16][C/F][16][F] -- the 16 rows of a tile contiguous, each level's 16 x F halfs contiguous inside it: a load
+// instruction of this kernel (lanes = 16 rows x 4 consecutive columns) then touches 2-3 runs of 64 B instead of 16 rows
+// All three layouts are  enc[row_base(s) + (c >> fs) * A + (c & fm)]  for column c: row-major A = 1, fs = 0 (stride in
+// row_base); level-major A = n F; tile-major A = 16 F.  One formula, no divergent paths in the load loops.
+struct EncLayout { uint32_t A, fs, fm; };
+__device__ __forceinline__ EncLayout enc_layout(uint32_t enc_stride, uint32_t n)
+{
+    EncLayout e = {1u, 0u, 0u};
+    if (enc_stride & 0xC0000000u) {
+        const uint32_t F = enc_stride & 0xffu;
+        e.fs = (uint32_t)__builtin_ctz(F); e.fm = F - 1u;
+        e.A = (enc_stride & 0x80000000u) ? n * F : 16u * F;
+    }
+    return e;
+}
+__device__ __forceinline__ uint64_t enc_row_base(uint32_t enc_stride, uint64_t s, uint32_t n_in)
+{
+    if (!(enc_stride & 0xC0000000u)) return s * enc_stride;
+    const uint32_t F = enc_stride & 0xffu;
+    if (enc_stride & 0x80000000u) return s * F;
+    return (s >> 4) * ((uint64_t)(n_in - 3u) * 16u) + (s & 15u) * F;  // (n_in - 3 = L F columns)
+}
+
+// Which input column lane (c, g) feeds into k-step kk of the first layer.  The MFMA reduction index is a dummy: any
+// assignment works as long as the weight fragment uses the same one.  Natural: k = 4 kk + g.  PERMUTED (SDF input of 3 + 32
+// columns, KS = 9): steps 0..7 carry encoding columns 8 g + kk -- lane g owns 8 CONSECUTIVE encoded features = 4 levels at
+// F = 2 -- and step 8 carries x_g (g < 3; lane 3: the padding column).  A lane then fetches its share of a row with ONE
+// 16-byte load (row-major) or four 4-byte loads that are 64-B runs across the 16 rows of the tile (tile- / level-major)
+// instead of nine 2-byte loads.  (With the natural order the backward, which has no registers to keep nine loads in flight,
+// serialised them: harmless for row-major, whose eight later loads hit the lines the first one fetched, but +15-36 % for
+// the tile-major layout the encode kernels want to write.)
+template <bool PERM>
+__device__ __forceinline__ int kmap(int kk, int g)
+{
+    if constexpr (PERM) return kk < 8 ? 3 + 8 * g + kk : (g < 3 ? g : 35);
+    else return 4 * kk + g;
+}
+
+// the lane's 8 encoded features + x_g for the permuted assignment.  enc_stride: row stride (multiple of 8), or
+// 0x40000000 | 2 (tile-major), or 0x80000000 | 2 (level-major)
+__device__ __forceinline__ void load_features_perm(const float *__restrict__ x, uint32_t x_stride,
+                                                   const __half *__restrict__ enc, uint32_t enc_stride, uint64_t s, int g,
+                                                   uint32_t n, float (&dst)[9])
+{
+    if (!(enc_stride & 0xC0000000u)) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(enc + s * enc_stride + 8 * g);
+        const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __half2 h = *reinterpret_cast<const __half2 *>(&r[j]);
+            dst[2 * j] = __low2float(h); dst[2 * j + 1] = __high2float(h);
+        }
+    } else {
+        const bool tile = (enc_stride & 0x40000000u) != 0u;
+        // halfs between consecutive levels, and this lane's first level (4 g) of its row
+        const uint64_t step = tile ? 32ull : 2ull * n;
+        const __half *p = enc + (tile ? (s >> 4) * 512ull + (s & 15u) * 2u : s * 2ull) + (uint64_t)(4 * g) * step;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __half2 h = *reinterpret_cast<const __half2 *>(p + j * step);
+            dst[2 * j] = __low2float(h); dst[2 * j + 1] = __high2float(h);
+        }
+    }
+    dst[8] = g < 3 ? x[s * x_stride + g] * 2.f - 1.f : 0.f;
+}
+
 template <bool SDF_IN>
 __device__ __forceinline__ float load_feature(const float *__restrict__ x, uint32_t x_stride, const __half *__restrict__ enc,
-                                              uint32_t enc_stride, uint32_t n_in, uint64_t s, uint32_t k, uint32_t n)
+                                              const EncLayout &el, uint64_t enc_base, uint32_t n_in, uint64_t s, uint32_t k)
 {
     if (k >= n_in) return 0.f;
     if (SDF_IN) {
         if (k < 3) return x[s * x_stride + k] * 2.f - 1.f;
-        if (enc_stride & 0x80000000u) {
-            const uint32_t F = enc_stride & 0xffu, c = k - 3;
-            return __half2float(enc[((uint64_t)(c / F) * n + s) * F + c % F]);
-        }
-        return __half2float(enc[s * enc_stride + (k - 3)]);
+        const uint32_t c = k - 3;
+        return __half2float(enc[enc_base + (c >> el.fs) * el.A + (c & el.fm)]);
     }
     return x[s * x_stride + k];
 }
@@ -131,12 +194,13 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const Blob B = split_blob<KS, NH>(blob);
     constexpr int IN_PAD = KS * 4;
+    constexpr bool PERM = SDF_IN && KS == 9;  // [x (3) | 32 encoded features]: the permuted k assignment (kmap)
     constexpr int NB0 = (IN_PAD + 15) / 16;
     float wf0[4][KS];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + 4 * kk + g];
+        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g)];
     f32x4 b0f[4], b1f[4], blf, wlf[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
@@ -149,12 +213,22 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
     // software pipeline: the NEXT tile's inputs are requested before this tile's MFMA chain starts (one wave per SIMD: nothing
     // else hides the ~2 us of a global load)
     float xnext[KS];
+    const EncLayout el = enc_layout(enc_stride, n);
     auto load_inputs = [&](uint32_t tile, float (&dst)[KS]) {
         const uint64_t sn = (uint64_t)tile * 16 + c;
         const bool ok = tile < n_tiles && sn < n_live;
+        if constexpr (PERM) {
+            if (ok) load_features_perm(x, x_stride, enc, enc_stride, sn, g, n, dst);
+            else {
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            dst[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, sn, 4 * kk + g, n) : 0.f;
+                for (int kk = 0; kk < KS; ++kk) dst[kk] = 0.f;
+            }
+        } else {
+            const uint64_t eb = SDF_IN ? enc_row_base(enc_stride, sn, n_in) : 0ull;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                dst[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, el, eb, n_in, sn, 4 * kk + g) : 0.f;
+        }
     };
     load_inputs(blockIdx.x, xnext);
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -277,6 +351,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const Blob B = split_blob<KS, NH>(blob);
     constexpr int IN_PAD = KS * 4;
+    constexpr bool PERM = SDF_IN && KS == 9;  // [x (3) | 32 encoded features]: the permuted k assignment (kmap)
     constexpr int NB0 = (IN_PAD + 15) / 16;
     __shared__ __attribute__((aligned(16))) float T_a[16 * LDT];   // activations feeding a layer  [sample][neuron]
     __shared__ __attribute__((aligned(16))) float T_d[16 * LDT];   // pre-activation gradients     [sample][neuron]
@@ -287,7 +362,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + 4 * kk + g];
+        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g)];
     f32x4 b0f[4], b1f[4], uf[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
@@ -329,13 +404,24 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
     // software pipeline: the NEXT tile's inputs (features, output gradient, P) are requested before this tile's MFMA chain
     float xnext[KS], pnext[KS];
     f32x4 donext;
+    const EncLayout el = enc_layout(enc_stride, n);
     auto load_inputs = [&](uint32_t tile, float (&xd)[KS], float (&pd)[KS], f32x4 &dd) {
         const uint64_t sn = (uint64_t)tile * 16 + c;
         const bool ok = tile < n_tiles && sn < n_live;
+        if constexpr (PERM) {
+            if (ok) load_features_perm(x, x_stride, enc, enc_stride, sn, g, n, xd);
+            else {
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            xd[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, enc_stride, n_in, sn, 4 * kk + g, n) : 0.f;
-            if (SECOND) pd[kk] = ok ? p_in[sn * IN_PAD + 4 * kk + g] : 0.f;
+                for (int kk = 0; kk < KS; ++kk) xd[kk] = 0.f;
+            }
+        } else {
+            const uint64_t eb = SDF_IN ? enc_row_base(enc_stride, sn, n_in) : 0ull;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) xd[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, el, eb, n_in, sn, 4 * kk + g) : 0.f;
+        }
+        if (SECOND) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) pd[kk] = ok ? p_in[sn * IN_PAD + kmap<PERM>(kk, g)] : 0.f;
         }
         dd = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok) {
@@ -360,7 +446,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = W0t[(mb * 16 + c) * IN_PAD + 4 * kk + g];
+                for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = W0t[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g)];
         }
         // ---- forward recompute ---------------------------------------------------------------------------------
         float xin[KS], pb[KS];
@@ -504,7 +590,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4 *>(&T_d[c * LDT + mb * 16 + 4 * g]) = q[mb];
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) T_x[c * LDX + 4 * kk + g] = pb[kk];
+            for (int kk = 0; kk < KS; ++kk) T_x[c * LDX + kmap<PERM>(kk, g)] = pb[kk];
             lds_wave_sync();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -526,7 +612,7 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4 *>(&T_d[c * LDT + mb * 16 + 4 * g]) = dz0[mb];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) T_x[c * LDX + 4 * kk + g] = xin[kk];
+        for (int kk = 0; kk < KS; ++kk) T_x[c * LDX + kmap<PERM>(kk, g)] = xin[kk];
         lds_wave_sync();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -787,11 +873,27 @@ extern "C" uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *d, uin
         if (!done_) { nsr_set_error("vmlp: no variant"); return NSR_ERR_INVALID; }                                      \
     } while (0)
 
+// the 3 + 32-column SDF input takes the permuted k assignment (kmap): its loader reads whole 16-byte / 4-byte units
+static int check_sdf_encoding(const NsrVmlpDesc *desc, const nsr_half *enc, uint32_t enc_stride, const char *who)
+{
+    if (!enc || desc->in_pad != 36) return NSR_OK;
+    NSR_REQUIRE(desc->n_in == 35, "%s: a 36-wide padded SDF input must be [x (3) | 32 encoded features] (n_in=%u)", who,
+                desc->n_in);
+    if (enc_stride & 0xC0000000u)
+        NSR_REQUIRE((enc_stride & 0xffu) == 2u && ((uintptr_t)enc & 3) == 0,
+                    "%s: level- / tile-major encodings are read as 2-feature levels (F=%u)", who, enc_stride & 0xffu);
+    else
+        NSR_REQUIRE(enc_stride % 8 == 0 && ((uintptr_t)enc & 15) == 0,
+                    "%s: a row-major encoding needs a 16-byte aligned buffer and a stride that is a multiple of 8 halfs", who);
+    return NSR_OK;
+}
+
 extern "C" int nsr_vmlp_forward(const NsrVmlpDesc *desc, const float *blob, const float *x, uint32_t x_stride,
                                 const nsr_half *enc, uint32_t enc_stride, float *out, float *out_col0, float *g_in,
                                 uint32_t n, uint32_t n_full, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_vmlp(desc, "nsr_vmlp_forward")) return rc;
+    if (int rc = check_sdf_encoding(desc, enc, enc_stride, "nsr_vmlp_forward")) return rc;
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(blob && x && (out || n_full == 0), "nsr_vmlp_forward: NULL pointer");
     NSR_REQUIRE(n_full <= n && (n_full == n || out_col0), "nsr_vmlp_forward: rows beyond n_full need out_col0");
@@ -826,6 +928,7 @@ extern "C" int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, con
                                  uint32_t n, uint32_t n_full, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_vmlp(desc, "nsr_vmlp_backward")) return rc;
+    if (int rc = check_sdf_encoding(desc, enc, enc_stride, "nsr_vmlp_backward")) return rc;
     NSR_REQUIRE(blob && grad_blob && partials && (n == 0 || x), "nsr_vmlp_backward: NULL pointer");
     NSR_REQUIRE(n_full <= n && (n_full == 0 || d_out) && (n_full == n || d_out_col0),
                 "nsr_vmlp_backward: d_out / d_out_col0 do not cover the rows");

@@ -23,6 +23,10 @@ from nerfacc import ContractionType
 from nsr_hip import NsrAdamSegment, NsrVanillaLayer, NsrVmlpDesc, check, lib, ptr, stream_ptr
 from nsr_hip import ops as _ops
 
+# layout of the encoded features between the encode and the fp32 MLP kernels of a step: 2 = tile-major (default),
+# 0 = row-major (developer switch for A/B)
+ENC_LAYOUT = int(os.environ.get("NSR_NEUS_ENC_LAYOUT", "2"))
+
 F32, F16 = torch.float32, torch.float16
 _byref = ctypes.byref
 LOSS_KEYS = ("lambda_rgb_l1", "lambda_rgb_mse", "lambda_mask", "lambda_opaque", "lambda_eikonal", "lambda_sparsity",
@@ -625,16 +629,20 @@ class FusedNeuSStep:
             table = enc.table_half(enc.params)
             positions_ready = torch.cuda.Event()
             positions_ready.record(torch.cuda.current_stream())
-            # row-major encoding [T N][C] (masked levels: zero columns).  Measured: the level-major layout saves 36 us (plain) /
-            # 131 us (taps) in the encode kernels' stores but costs the MFMA kernels 180 / 660 us -- their per-sample
-            # operand loads then touch 16 cache lines instead of one 64-B row
-            encd = torch.empty((T * N, self.n_enc), dtype=F16, device=dev)
+            # encoding of the T N points, TILE-major [T N / 16][L][16][F] (masked levels: zeros): the 16 rows of an MFMA tile
+            # are one contiguous KB as in a row-major [T N][C] array, but inside it every level's 16 x F halfs are contiguous,
+            # so the encode kernels (lane = (point, level)) store 64-B runs instead of 4-B pieces 64 B apart -- row-major
+            # costs ten times the output in fabric writes -- and the fp32 MLP kernels read 2-3 runs per load instead of 16
+            # rows.  (Level-major [L][T N][F] had the encode's gain, 36 us plain / 131 us taps, but cost the MFMA kernels
+            # 180 / 660 us: a tile's operands then sit in 16 far-apart lines.)  NSR_NEUS_ENC_LAYOUT=0 selects row-major.
+            lay = ENC_LAYOUT
+            encd = torch.empty(((T * N + 15) // 16 * 16, self.n_enc), dtype=F16, device=dev)
             if self.fd:  # the sample's corners are gathered once and shared with its six taps
-                check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, 0, mc, _byref(desc),
+                check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, lay, mc, _byref(desc),
                                                     None, s), "nsr_hashgrid_forward_taps")
             else:  # analytic normals: keep the per-level Jacobian (384 B / sample) instead of two more table gathers
                 jac = torch.empty(N * self.n_enc * 3, dtype=F32, device=dev)
-                check(lib.nsr_hashgrid_forward_jac(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, 0, mc, _byref(desc),
+                check(lib.nsr_hashgrid_forward_jac(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, lay, mc, _byref(desc),
                                                    ptr(jac), None, s), "nsr_hashgrid_forward_jac")
             gws = bin_event = tws = None
             if compute_grads and N > 0:
@@ -672,7 +680,8 @@ class FusedNeuSStep:
             taps = torch.empty(6 * N, dtype=F32, device=dev) if self.fd else None
             sd = self.sdf.desc
             P, C, F = int(sd.in_pad), self.n_enc, int(desc.n_features)
-            ENC_LM = C  # row stride of the encoding (0x80000000 | F would select the level-major layout)
+            # how the MLP kernels read the encoding: a row stride, or 0x40000000 | F = tile-major (0x80000000 | F: level-major)
+            ENC_LM = (0x40000000 | F) if lay == 2 else C
             g_in = None if self.fd else torch.empty((N, P), dtype=F32, device=dev)
             check(lib.nsr_vmlp_forward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(out), ptr(taps),
                                        ptr(g_in), T * N, N, None, s), "nsr_vmlp_forward(sdf)")

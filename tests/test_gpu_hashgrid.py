@@ -174,6 +174,11 @@ def test_forward_taps_equals_seven_plain_encodes(mask_count):
     check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(lm), n, 0, 1, mask_count, ctypes.byref(enc.grid_desc),
                                         None, stream_ptr()), "nsr_hashgrid_forward_taps")
     assert torch.equal(lm.permute(1, 0, 2).reshape(7 * n, 32), want)
+    rows = (7 * n + 15) // 16 * 16  # tile-major [rows / 16][L][16][F] (what the fused NeuS steps use): same numbers
+    tm = torch.zeros(rows // 16, 16, 16, 2, dtype=torch.float16, device="cuda")
+    check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(tm), n, 0, 2, mask_count, ctypes.byref(enc.grid_desc),
+                                        None, stream_ptr()), "nsr_hashgrid_forward_taps")
+    assert torch.equal(tm.permute(0, 2, 1, 3).reshape(rows, 32)[:7 * n], want)
     assert float(got[:, 2 * mask_count:].abs().max() if mask_count < 16 else 0.0) == 0.0
 
 
@@ -434,3 +439,30 @@ def test_owner_backward_small_and_large_slice_configurations_agree():
                 assert float((s_[sl] - l_[sl]).norm() / l_[sl].norm()) < 1e-5, (k, lvl)
             else:
                 assert torch.equal(s_[sl], l_[sl]), (k, lvl)
+
+
+@pytest.mark.parametrize("F,n", [(2, 4099), (2, 16), (4, 1000), (1, 333), (8, 50)])
+def test_forward_tile_major_layout_holds_the_same_values(F, n):
+    """y_level_major = 2: [ceil(n/16)][L][16][F] -- plain encode (both forward variants) and the Jacobian-caching one"""
+    import ctypes
+    import nsr_hip
+    from nsr_hip import check, lib, ops, ptr, stream_ptr
+    L = 32 // F if F > 1 else 16
+    gd = nsr_hip.make_grid_desc(L, F, 15, 16, 1.5)
+    g = torch.Generator().manual_seed(F)
+    table = (torch.rand(gd.n_entries * F, generator=g) - 0.5).half().cuda()
+    x = torch.rand(n, 3, generator=g).cuda()
+    want = ops.hashgrid_forward(x, table, gd, L - 1)
+    rows = (n + 15) // 16 * 16
+    for variant in ((0, 1), (0, 2)):
+        lib.nsr_hashgrid_forward_variant(*variant)
+        tm = torch.zeros(rows // 16, L, 16, F, dtype=torch.float16, device="cuda")
+        check(lib.nsr_hashgrid_forward_ex(ptr(x), ptr(table), ptr(tm), n, 0, 2, L - 1, ctypes.byref(gd), None, stream_ptr()),
+              "nsr_hashgrid_forward_ex")
+        assert torch.equal(tm.permute(0, 2, 1, 3).reshape(rows, L * F)[:n], want), variant
+    lib.nsr_hashgrid_forward_variant(0, 2)
+    tm = torch.zeros(rows // 16, L, 16, F, dtype=torch.float16, device="cuda")
+    jac = torch.empty(L, n, F, 3, device="cuda")
+    check(lib.nsr_hashgrid_forward_jac(ptr(x), ptr(table), ptr(tm), n, 0, 2, L - 1, ctypes.byref(gd), ptr(jac), None,
+                                       stream_ptr()), "nsr_hashgrid_forward_jac")
+    assert torch.equal(tm.permute(0, 2, 1, 3).reshape(rows, L * F)[:n], want)

@@ -136,12 +136,26 @@ def test_level_major_encoding_input_gives_the_same_output():
     enc = (torch.randn(n, 32, device="cuda") * 0.1).half()
     enc_lm = enc.view(n, 16, 2).permute(1, 0, 2).contiguous()
     outs = []
-    for e, stride in ((enc, 32), (enc_lm, 0x80000000 | 2)):
+    rows = (n + 15) // 16 * 16  # tile-major [rows / 16][L][16][F]: enc_stride = 0x40000000 | F
+    enc_tm = torch.zeros(rows, 32, dtype=torch.float16, device="cuda")
+    enc_tm[:n] = enc
+    enc_tm = enc_tm.view(rows // 16, 16, 16, 2).permute(0, 2, 1, 3).contiguous()
+    outs, grads = [], []
+    d_out = torch.randn(n, 16, device="cuda")
+    ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(ctypes.byref(vb.desc), n)), device="cuda")
+    for e, stride in ((enc, 32), (enc_lm, 0x80000000 | 2), (enc_tm, 0x40000000 | 2)):
         out = torch.empty(n, 16, device="cuda")
         check(lib.nsr_vmlp_forward(ctypes.byref(vb.desc), ptr(blob), ptr(x01), 3, ptr(e), stride, ptr(out), None, None, n, n,
                                    None, stream_ptr()), "fwd")
         outs.append(out)
-    assert torch.equal(outs[0], outs[1])
+        d_enc, g_blob = torch.empty(32 * n, device="cuda"), torch.empty_like(blob)
+        check(lib.nsr_vmlp_backward(ctypes.byref(vb.desc), ptr(blob), ptr(x01), 3, ptr(e), stride, ptr(d_out), None, None,
+                                    ptr(d_enc), 0, 3, 32, 2, ptr(g_blob), 0, ptr(ws), n, n, None, stream_ptr()), "bwd")
+        grads.append((d_enc, g_blob))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for d_enc, g_blob in grads[1:]:  # the backward reads the same inputs through the same loader
+        assert torch.equal(d_enc, grads[0][0])
+        assert torch.allclose(g_blob, grads[0][1], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("n_in,n_out,n_hidden,weight_norm", [(35, 13, 1, True), (32, 3, 2, False), (11, 13, 1, True),
