@@ -682,6 +682,17 @@ int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x, const voi
                                                        float *workspace, uint32_t n, uint32_t level_mask_count,
                                                        float grad_scale, const NsrGridDesc *desc, const int32_t *n_dev,
                                                        const NsrTableAdam *adam, void *stream);
+/* The same write-out for the two other accumulation modes (the fused NeuS steps, nsr/fused_neus.py): first + second order
+ * in one pass (analytic normals; items already binned when binned != 0) and the finite-difference stencil mode. */
+int nsr_hashgrid_backward_params_owner_with_second_order_adam(const float *x, const float *dy_first_lm, const float *dy,
+                                                              uint32_t dy_stride, const float *g, float *workspace,
+                                                              uint32_t n, uint32_t level_mask_count, int binned,
+                                                              const NsrGridDesc *desc, const NsrTableAdam *adam,
+                                                              void *stream);
+int nsr_hashgrid_backward_params_owner_accumulate_taps_adam(const float *x7, const float *dy_level_major, float *workspace,
+                                                            float *tap_workspace, uint32_t n_centre,
+                                                            uint32_t level_mask_count, const NsrGridDesc *desc,
+                                                            const NsrTableAdam *adam, void *stream);
 /* The optimizer step of the asynchronous trainer in ONE launch: nsr_adam_tick + nsr_adamw_step over up to two tensors
  * (a: hash table + density MLP with its partial re-zeroing, b: colour MLP; n_b == 0: one tensor).  hyper12: 12 floats, 8-byte
  * aligned, zero-initialised ([0..7] as for nsr_adam_tick, [8] ticket counter).  Bit-identical to the separate launches. */

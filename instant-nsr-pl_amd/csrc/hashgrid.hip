@@ -899,6 +899,19 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate_taps(const float *x
                           desc, nullptr, 2, stream, nullptr, nullptr, nullptr, n_centre, tap_workspace);
 }
 
+// ... with AdamW applied to the table in the write-out (NsrTableAdam): no gradient is stored
+extern "C" int nsr_hashgrid_backward_params_owner_accumulate_taps_adam(const float *x7, const float *dy_level_major,
+                                                                       float *workspace, float *tap_workspace,
+                                                                       uint32_t n_centre, uint32_t level_mask_count,
+                                                                       const NsrGridDesc *desc, const NsrTableAdam *adam,
+                                                                       void *stream)
+{
+    NSR_REQUIRE(n_centre > 0 && tap_workspace && adam,
+                "nsr_hashgrid_backward_params_owner_accumulate_taps_adam: empty input / NULL workspace / NULL adam");
+    return owner_backward(x7, dy_level_major, 2, 0, nullptr, workspace, 7u * n_centre, level_mask_count, 1.f, 0, desc, nullptr,
+                          2, stream, nullptr, nullptr, adam, n_centre, tap_workspace);
+}
+
 // first-order table gradient (dy_first, level-major fp32) and the second-order one of the analytic normal (dy row-major
 // fp32 with `g` = dL/d(dx)) in ONE binning + accumulation pass
 extern "C" int nsr_hashgrid_backward_params_owner_with_second_order(const float *x, const float *dy_first_lm,
@@ -912,6 +925,19 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order(const float 
     // queued on a helper stream right after the positions were formed)
     return owner_backward(x, dy, 1, dy_stride, grad_table, workspace, n, level_mask_count, 1.f, accumulate, desc, nullptr,
                           binned ? 2 : 3, stream, g, dy_first_lm);
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner_with_second_order_adam(const float *x, const float *dy_first_lm,
+                                                                         const float *dy, uint32_t dy_stride,
+                                                                         const float *g, float *workspace, uint32_t n,
+                                                                         uint32_t level_mask_count, int binned,
+                                                                         const NsrGridDesc *desc, const NsrTableAdam *adam,
+                                                                         void *stream)
+{
+    NSR_REQUIRE(adam && (n == 0 || (dy_first_lm && dy && g)),
+                "nsr_hashgrid_backward_params_owner_with_second_order_adam: NULL pointer");
+    return owner_backward(x, dy, 1, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
+                          stream, g, dy_first_lm, adam);
 }
 
 extern "C" int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,

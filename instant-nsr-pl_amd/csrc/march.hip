@@ -402,31 +402,35 @@ k_pack_scratch(const float2 *__restrict__ scratch, uint32_t cap, const int32_t *
     }
 }
 
-// exclusive scan of per-ray counts by ONE workgroup (n_rays is a few thousand): 1024 lanes, each owns a
-// contiguous chunk; wave scan + LDS across the 16 waves.  Removes torch.cumsum + stack from the step.
+// exclusive scan of per-ray counts by ONE workgroup (n_rays is a few thousand): PACK_BLOCK lanes, each owns a
+// contiguous chunk; wave scan + LDS across the waves.  Removes torch.cumsum + stack from the step.
+// 256 lanes, not 1024: a 16-wave workgroup has to wait for a CU with four free wave slots on EVERY SIMD, and next to the
+// fp32 MLP kernels (one wave per SIMD holding the whole register file) or the table backward it waited for hundreds of
+// microseconds on the marching stream (rocprofv3 showed 380-430 us "duration" for this 4,096-element scan).
+constexpr int PACK_BLOCK = 256, PACK_WAVES = PACK_BLOCK / 64;
 __device__ __forceinline__ int32_t prefix_total(const int32_t *wave_tot)
 {
     int32_t t = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += wave_tot[k];
+    for (int k = 0; k < PACK_WAVES; ++k) t += wave_tot[k];
     return t;
 }
 
 constexpr uint32_t PACK_LDS = 16384;  // ray counts up to this are staged through LDS (coalesced loads and stores)
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(PACK_BLOCK)
 k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ packed, int32_t *__restrict__ total,
                    uint32_t n, uint32_t capacity, int32_t *__restrict__ stats, const int32_t *__restrict__ n_active)
 {
-    __shared__ int32_t wave_tot[16];
+    __shared__ int32_t wave_tot[PACK_WAVES];
     extern __shared__ int32_t buf[];  // n words when staged (sized by the launch: a fixed 64 KiB would keep this one-workgroup
                                       // kernel waiting for a CU with that much free LDS next to the step's big kernels)
-    const uint32_t tid = threadIdx.x, chunk = (n + 1023) / 1024;
+    const uint32_t tid = threadIdx.x, chunk = (n + PACK_BLOCK - 1) / PACK_BLOCK;
     const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     // slots >= *n_active are dead rays: they were marched (the marching pass runs ahead of the ray count) but keep nothing
     const uint32_t live = n_active ? (uint32_t)max(min(*n_active, (int32_t)n), 0) : n;
     const bool staged = n <= PACK_LDS;
     if (staged) {
-        for (uint32_t k = tid; k < n; k += 1024) buf[k] = k < live ? counts[k] : 0;
+        for (uint32_t k = tid; k < n; k += PACK_BLOCK) buf[k] = k < live ? counts[k] : 0;
         __syncthreads();
     }
     int32_t s = 0;
@@ -462,13 +466,13 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
         __syncthreads();
         const int32_t end_all = capacity ? min(prefix_total(wave_tot), (int32_t)capacity) : prefix_total(wave_tot);
         const bool vec = (reinterpret_cast<uintptr_t>(packed) & 7u) == 0;  // (a caller may hand in a 4-byte aligned view)
-        for (uint32_t k = tid; k < n; k += 1024) {  // count = next start - start (truncation included)
+        for (uint32_t k = tid; k < n; k += PACK_BLOCK) {  // count = next start - start (truncation included)
             const int32_t a = buf[k], b = k + 1 < n ? buf[k + 1] : end_all;
             if (vec) reinterpret_cast<int2 *>(packed)[k] = make_int2(a, b - a);
             else { packed[2ull * k] = a; packed[2ull * k + 1] = b - a; }
         }
     }
-    if (tid == 1023) {
+    if (tid == PACK_BLOCK - 1) {
         const int32_t t = prefix + v;
         total[0] = capacity ? min(t, (int32_t)capacity) : t;
         if (stats) {  // int32[6]: [0] last (unclamped) total, [1] largest, [2] #launches truncated, [4..5] u64 running sum
@@ -771,7 +775,7 @@ extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *pa
     NSR_REQUIRE(capacity < 0x7fffffffu, "nsr_pack_from_counts: capacity must fit int32");
     NSR_REQUIRE(!stats || ((uintptr_t)stats & 7u) == 0, "nsr_pack_from_counts: stats must be 8-byte aligned");
     const size_t lds = n_rays <= PACK_LDS ? (size_t)n_rays * sizeof(int32_t) : 0;
-    hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(1024), lds, (hipStream_t)stream, num_steps, packed_info, total,
+    hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(PACK_BLOCK), lds, (hipStream_t)stream, num_steps, packed_info, total,
                        n_rays, capacity, stats, n_active);
     NSR_CHECK_LAUNCH("nsr_pack_from_counts");
     return NSR_OK;

@@ -132,6 +132,9 @@ class FusedNeuSStep:
             self._bg_setup(cfg)
         # finite differences: fold the taps that stay in their sample's cell into the sample's table-backward items
         self.fold_taps = not os.environ.get("NSR_FD_PLAIN_TAPS")
+        # {"fg": NsrTableAdam, "bg": NsrTableAdam} for ONE step (a trainer sets it): AdamW on the hash tables inside their
+        # backward; adam_applied says which of them a step really updated (a step without samples launches no table backward)
+        self.table_adam, self.adam_applied = None, set()
         self.radius = float(cfg["radius"])
         g = cfg["geometry"]
         self.fd = g["grad_type"] == "finite_difference"
@@ -387,7 +390,14 @@ class FusedNeuSStep:
               "nsr_vmlp_backward(bg density)")
         if enc.params.grad is None:
             enc.params.grad = torch.zeros_like(enc.params)
-        if S > 0:
+        ad = (self.table_adam or {}).get("bg")
+        if S > 0 and ad is not None:
+            torch.cuda.current_stream().wait_event(c["bin_event"])
+            check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(c["x01"]), ptr(d_enc), 2, 0, ptr(c["gws"]), S,
+                                                                         desc.n_levels, 1.0, _byref(desc), None, _byref(ad), s),
+                  "nsr_hashgrid_backward_params_owner_accumulate_adam(bg)")
+            self.adam_applied.add("bg")
+        elif S > 0:
             torch.cuda.current_stream().wait_event(c["bin_event"])
             check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(c["x01"]), ptr(d_enc), 2, 0, ptr(enc.params.grad),
                                                                     ptr(c["gws"]), S, desc.n_levels, 1.0, 0, _byref(desc),
@@ -596,6 +606,7 @@ class FusedNeuSStep:
     def _step(self, rays, gt_rgb, fg_mask, background, compute_grads, loss_scale, march_handle, after_march, external):
         """generator: runs the forward, yields the result dict, is sent the upstream gradients (``external``) or None (built-in
         loss terms) and runs the backward.  No torch context manager is held across the yield."""
+        self.adam_applied = set()
         m, enc, lw = self.model, self.enc, self.loss_weights
         dev = rays.device
         n_rays = rays.shape[0]
@@ -834,18 +845,37 @@ class FusedNeuSStep:
                                         ptr(d_taps), ptr(p_in), ptr(d_enc), 0, 3, C, F, ptr(g_sdf), 0, ptr(ws), T * N, N,
                                         None, s), "nsr_vmlp_backward(sdf)")
             torch.cuda.current_stream().wait_event(bin_event)  # the items are binned (helper stream)
+            # a trainer on one GPU hands over AdamW for the table (self.table_adam): the owner workgroups apply it in their
+            # write-out -- no 50 MB gradient store, no optimizer sweep over the table
+            ad = (self.table_adam or {}).get("fg")
             if self.fd and tws is not None:
-                check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps(ptr(x7), ptr(d_enc), ptr(g_table), ptr(gws),
-                                                                             ptr(tws), N, mc, 0, _byref(desc), s),
-                      "nsr_hashgrid_backward_params_owner_accumulate_taps")
+                if ad is not None:
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps_adam(
+                        ptr(x7), ptr(d_enc), ptr(gws), ptr(tws), N, mc, _byref(desc), _byref(ad), s),
+                        "nsr_hashgrid_backward_params_owner_accumulate_taps_adam")
+                else:
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps(ptr(x7), ptr(d_enc), ptr(g_table), ptr(gws),
+                                                                                 ptr(tws), N, mc, 0, _byref(desc), s),
+                          "nsr_hashgrid_backward_params_owner_accumulate_taps")
             elif self.fd:
-                check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws),
-                                                                        T * N, mc, 1.0, 0, _byref(desc), None, s),
-                      "nsr_hashgrid_backward_params_owner_accumulate")
+                if ad is not None:
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(x7), ptr(d_enc), 2, 0, ptr(gws), T * N, mc,
+                                                                                 1.0, _byref(desc), None, _byref(ad), s),
+                          "nsr_hashgrid_backward_params_owner_accumulate_adam")
+                else:
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x7), ptr(d_enc), 2, 0, ptr(g_table), ptr(gws),
+                                                                            T * N, mc, 1.0, 0, _byref(desc), None, s),
+                          "nsr_hashgrid_backward_params_owner_accumulate")
+            elif ad is not None:
+                check(lib.nsr_hashgrid_backward_params_owner_with_second_order_adam(
+                    ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(gws), N, mc, 1, _byref(desc), _byref(ad), s),
+                    "nsr_hashgrid_backward_params_owner_with_second_order_adam")
             else:  # first- and second-order table gradients share their items: one accumulation pass
                 check(lib.nsr_hashgrid_backward_params_owner_with_second_order(
                     ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(g_table), ptr(gws), N, mc, 0, 1, _byref(desc), s),
                     "nsr_hashgrid_backward_params_owner_with_second_order")
+            if ad is not None:
+                self.adam_applied.add("fg")
         # weight norm / bias gradients through the host-side fold
         if g_bg is not None:
             self.bg_geo.push_gradient(g_bg[0])
@@ -959,6 +989,11 @@ class NeuSTrainer:
                 self.sharded = ShardedAdamW(tc, lr=0.01)
                 guard_stale_state_dict(model, self.sharded)
         self._tables = tuple(m for m in tc if getattr(m, "grid_desc", None) is not None)  # their backward OVERWRITES .grad
+        # one GPU: AdamW on the tables runs inside their backward (NSR_NEUS_SEPARATE_ADAM=1: the stand-alone sweep, for A/B)
+        self.fuse_table_adam = not os.environ.get("NSR_NEUS_SEPARATE_ADAM")
+        self._table_of = {"fg": self.fused.enc}
+        if self.fused.bg:
+            self._table_of["bg"] = self.fused.bg_enc
         self._rest = rest + var
         self.opt_rest = SmallAdamW([(p, 0.01) for p in rest] + [(p, 0.001) for p in var])
         self.fused.lean_outputs = True  # no per-ray validity masks etc. in the step's result dict
@@ -1029,9 +1064,15 @@ class NeuSTrainer:
                 for x in self._pending[:4]:
                     x.record_stream(main)
 
+        scale = neus_lr_scale(t, self.config_name, self.max_steps)
+        self.fused.table_adam = None
+        if self.fuse_table_adam and self.sharded is None and self.world_size == 1:
+            # AdamW on the hash tables inside their backward (csrc/hashgrid_owner.inc: OwnerAdam) at this step's learning rate;
+            # the kernels take step count / bias corrections from the optimizer's device-side state
+            self.fused.table_adam = {k: self.opt.table_update_desc(m, milestones=(), gamma=1.0, lr=self.opt.lr * scale)
+                                     for k, m in self._table_of.items()}
         res = self.fused.forward_backward(rays, rgb, fg, bg, march_handle=handle, after_march=after_march)
         n = res["num_samples"]
-        scale = neus_lr_scale(t, self.config_name, self.max_steps)
         if self.sharded is not None:
             for p in self._rest:  # every rank contributes the same tensor list (a rank may have marched nothing)
                 if p.grad is None:
@@ -1041,7 +1082,7 @@ class NeuSTrainer:
         else:
             if self.world_size > 1:
                 all_reduce_gradients(list(model.parameters()))
-            self.opt.step(lr_scale=scale)
+            self.opt.step(lr_scale=scale, updated_in_backward=[self._table_of[k] for k in self.fused.adam_applied])
         self.opt_rest.step(lr_scale=scale)
         self.global_step += 1
         self.last = {"loss_acc": res["loss_acc"], "n_rays": rays.shape[0], "n_samples": n,

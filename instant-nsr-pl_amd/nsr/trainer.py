@@ -39,11 +39,20 @@ class FusedAdamW:
         self.other = torch.optim.AdamW(other_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) \
             if other_params else None
 
-    def step(self, lr_scale=1.0, grad_unscale=1.0):
+    def step(self, lr_scale=1.0, grad_unscale=1.0, updated_in_backward=()):
+        """``updated_in_backward``: modules whose (whole) parameter vector was already stepped inside their table backward
+        (table_update_desc with this step's lr): only their fp16 image is adopted, and the device-side step counter /
+        running beta powers those kernels read are advanced"""
         self.step_count += 1
+        if updated_in_backward:
+            step_dev, hyper = self._device_schedule_state()
+            _ops.adam_tick(step_dev, hyper, self.lr * lr_scale, self.betas[0], self.betas[1], 1.0, ())
         for m in self.tcnn_modules:
             p = m.params
             exp_avg, exp_avg_sq, shadow = self.state[p]
+            if any(m is u for u in updated_in_backward):
+                m.adopt_shadow(shadow)
+                continue
             _ops.adamw_step(p.data, p.grad, exp_avg, exp_avg_sq, shadow, self.lr * lr_scale, self.betas[0],
                             self.betas[1], self.eps, self.wd, self.step_count, grad_unscale=grad_unscale, zero_grad=True)
             # the kernel already wrote the fp16 copy: hand it to the module instead of re-casting 12.6 M floats
@@ -61,7 +70,7 @@ class FusedAdamW:
             self._hyper = torch.zeros(12, dtype=torch.float32, device=dev)  # lr, bc1, bc2 | running beta powers | ticket
         return self._step_dev, self._hyper
 
-    def table_update_desc(self, module, milestones=(10000, 15000, 18000), gamma=0.33):
+    def table_update_desc(self, module, milestones=(10000, 15000, 18000), gamma=0.33, lr=None):
         """``NsrTableAdam`` for ``module`` (a NetworkWithInputEncoding): AdamW on its hash table applied INSIDE the table
         backward of the asynchronous step (csrc/hashgrid.hip OwnerAdam); ``step_device(skip_table_of=module)`` then
         updates what is left (the MLP weights) and advances the device-side schedule."""
@@ -69,13 +78,15 @@ class FusedAdamW:
         step_dev, hyper = self._device_schedule_state()
         p = module.params
         exp_avg, exp_avg_sq, shadow = self.state[p]
-        n0 = int(module.n_network_params)
+        n0 = int(getattr(module, "n_network_params", 0))  # (a bare tcnn.Encoding: the table is the whole vector)
         ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
         d = NsrTableAdam()
         d.params, d.exp_avg, d.exp_avg_sq = (t.data_ptr() + 4 * n0 for t in (p.data, exp_avg, exp_avg_sq))
         d.shadow = shadow.data_ptr() + 2 * n0
         d.step, d.hyper = step_dev.data_ptr(), hyper.data_ptr()
-        d.base_lr, d.beta1, d.beta2, d.gamma = float(self.lr), float(self.betas[0]), float(self.betas[1]), float(gamma)
+        # ``lr``: this step's learning rate from a host-side schedule (then without milestones / gamma 1)
+        d.base_lr = float(self.lr if lr is None else lr)
+        d.beta1, d.beta2, d.gamma = float(self.betas[0]), float(self.betas[1]), float(gamma)
         d.milestone0, d.milestone1, d.milestone2 = ms
         d.eps, d.weight_decay = float(self.eps), float(self.wd)
         return d

@@ -140,3 +140,48 @@ def test_neus_dtu_trainer_steps_with_background():
     moved = [k for k, v in st.named_parameters() if k in before and not torch.equal(v.detach(), before[k])]
     assert len(moved) == len(before), set(before) - set(moved)
     assert 0 < int(st.occupancy_grid_bg.binary.sum()) <= 256 ** 3
+
+
+@pytest.mark.parametrize("name", ["neus-blender", "neus-dtu", "neuralangelo"])
+def test_table_adamw_inside_the_backward_matches_the_separate_sweep(name):
+    """one GPU: NeuSTrainer hands AdamW on the hash tables to the owner-computes backward (analytic mode with the second-order
+    term, the NeRF++ background's table, the finite-difference stencil mode).  Same parameters as gradient store + k_adamw:
+    the first step bit for bit on the hashed levels (fixed-point sums) up to the bias-correction rounding (device-side
+    running beta powers vs the host's pow); later steps within 6 % of one step's movement in norm."""
+    import nsr
+    from nsr.fused_neus import NeuSTrainer
+    from nsr.scene import SyntheticBlender
+    cfg = nsr.configs.get(name)
+    runs = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        st = nsr.build(cfg).cuda().train()
+        ds = SyntheticBlender(n_images=8, h=64, w=64, device="cuda", environment=bool(cfg["learned_background"]), seed=0)
+        tr = NeuSTrainer(st, ds, cfg, {"lambda_rgb_l1": 1.0, "lambda_eikonal": 0.1}, config_name=name)
+        tr.fuse_table_adam = fused
+        if name == "neuralangelo":
+            tr.global_step = 12000
+        t0 = tr.global_step
+        snaps = []
+        for _ in range(3):
+            last = tr.train_step()
+            assert last["n_samples"] > 0
+            assert (tr.fused.adam_applied == set(tr._table_of)) == fused
+            snaps.append({k: m.params.detach().clone() for k, m in tr._table_of.items()})
+        runs[fused] = snaps
+        assert tr.global_step == t0 + 3
+    lr = 0.01
+    for step in range(3):
+        for k in runs[True][step]:
+            a, b = runs[True][step][k], runs[False][step][k]
+            if step == 0:  # AdamW moves an entry by at most ~lr per step: compare on that scale
+                # (a few entries of the small dense levels, whose slabs are summed in fp32 in a different order, have a
+                # gradient that is pure cancellation noise: with eps = 1e-15 its SIGN decides a full +-lr step)
+                far = ((a - b).abs() > 2e-6 * lr + 1e-9).float().mean()
+                assert float(far) < 1e-4, (name, step, k, float(far))
+            else:
+                # with eps = 1e-15 the normalised step of an entry whose gradient is rounding noise is +-lr whatever its size:
+                # trajectories of such entries separate, so later steps are compared in norm, against one step's movement
+                moved = float((a - runs[True][step - 1][k]).norm())
+                assert float((a - b).norm()) <= 6e-2 * moved, (name, step, k, float((a - b).norm()), moved)
+            assert not torch.equal(a, torch.zeros_like(a))

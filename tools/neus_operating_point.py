@@ -1,0 +1,41 @@
+"""One fused NeuS workload at the reference's operating point (dynamic ray count -> 2^18 samples / step) through
+NeuSTrainer: ms / step, and how much of it the HOST spends queueing the step (time inside train_step, which holds one
+device->host read of the sample count) -- tells a GPU-bound step from a host-bound one.  One JSON line.
+
+    python tools/neus_operating_point.py neus-blender|neus-dtu|neuralangelo [steps]
+"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")]
+import torch
+import nsr
+from nsr.fused_neus import NeuSTrainer
+from nsr.scene import SyntheticBlender
+
+name = sys.argv[1] if len(sys.argv) > 1 else "neus-blender"
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+lam = {"neus-blender": {"lambda_rgb_mse": 10.0, "lambda_rgb_l1": 0.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1},
+       "neus-dtu": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.0, "lambda_eikonal": 0.1},
+       "neuralangelo": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1}}[name]
+dev = "cuda"
+torch.manual_seed(7)
+cfg = nsr.configs.get(name)
+data = SyntheticBlender(n_images=20, w=400, h=400, device=dev, seed=0, environment=bool(cfg["learned_background"]))
+data.all_c2w[:, :, 3] *= float(cfg["radius"]) / 1.5
+model = nsr.build(cfg).to(dev).train()
+tr = NeuSTrainer(model, data, cfg, lam, config_name=name)
+if name == "neuralangelo":
+    tr.global_step = 12000
+for _ in range(n_steps):
+    tr.train_step()
+torch.cuda.synchronize()
+t0, n, host = time.perf_counter(), 0, 0.0
+for _ in range(n_steps):
+    h0 = time.perf_counter()
+    last = tr.train_step()
+    host += time.perf_counter() - h0
+    n += last["n_samples"] + last["n_samples_bg"]
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(json.dumps({"config": name, "ms_per_step": 1e3 * dt / n_steps, "host_ms_in_train_step": 1e3 * host / n_steps,
+                  "samples_per_step": n / n_steps, "rays_per_step": tr.train_num_rays, "samples_per_sec": n / dt}))
