@@ -407,6 +407,12 @@ int nsr_occupancy_update(const nsr_half *mlp_out, uint32_t stride, float density
                          float occ_thre, const uint32_t *cells, const float *occs_old, float *occs_new, uint8_t *binary,
                          float *threshold, uint32_t n_total_cells, uint32_t capacity, const int32_t *n_cells, void *stream);
 
+/* occupancy statistic of a density field on a grid in UN_BOUNDED_SPHERE-contracted space (the NeRF++ background grid,
+ * models/neus.py:103-106): occ[i] = exp(logit[i] + density_bias) * step_size for samples whose grid-unit position lies
+ * inside the unit sphere (|x_unit - 0.5| < 0.5), -1 outside -- nerfacc 0.3.3 `_update` drops those samples before it
+ * evaluates them, and nsr_occupancy_update_values leaves the cell of a negative value untouched. */
+int nsr_occupancy_density_values_sphere(const float *logit, const float *x_unit, float density_bias, float step_size,
+                                        float *occ, uint32_t capacity, const int32_t *n_cells, void *stream);
 /* ... with the occupancy statistic of the selected cells evaluated by the caller (occ_values [capacity] fp32; NeuS:
  * nsr_neus_occupancy_values) instead of derived from a density logit */
 int nsr_occupancy_update_values(const float *occ_values, float ema_decay, float occ_thre, const uint32_t *cells,

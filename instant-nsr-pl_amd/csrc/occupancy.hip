@@ -112,8 +112,24 @@ k_occ_ema_values(const float *__restrict__ occ, float decay, const uint32_t *__r
 {
     const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
     if (i >= live_count(capacity, n_cells)) return;
+    const float v = occ[i];
+    if (v < 0.f) return;  // the caller's "do not touch this cell" (a sample outside the unit sphere of a contracted grid)
     const uint32_t c = cells[i];
-    occs_new[c] = fmaxf(occs_old[c] * decay, occ[i]);
+    occs_new[c] = fmaxf(occs_old[c] * decay, v);
+}
+
+// NeRF++ background grid (models/neus.py:103-106, nerfacc 0.3.3 _update with UN_BOUNDED_SPHERE): occ = exp(logit + bias) *
+// step for samples inside the unit sphere of the grid's contracted space, -1 ("leave the cell alone": nerfacc drops such
+// samples before it evaluates them) outside
+__global__ void __launch_bounds__(EW_BLOCK)
+k_occ_density_values_sphere(const float *__restrict__ logit, const float *__restrict__ x_unit, float bias, float step,
+                            float *__restrict__ occ, uint32_t capacity, const int32_t *__restrict__ n_cells)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= live_count(capacity, n_cells)) return;
+    const float a = x_unit[3ull * i] - 0.5f, b = x_unit[3ull * i + 1] - 0.5f, c = x_unit[3ull * i + 2] - 0.5f;
+    const bool inside = sqrtf(a * a + b * b + c * c) < 0.5f;
+    occ[i] = inside ? expf(logit[i] + bias) * step : -1.f;
 }
 
 constexpr int OCC_PARTS = 256;
@@ -207,6 +223,18 @@ extern "C" int nsr_occupancy_update(const nsr_half *mlp_out, uint32_t stride, fl
     hipLaunchKernelGGL(k_occ_binarize, dim3(nsr_div_up(n_total_cells, EW_BLOCK)), dim3(EW_BLOCK), 0, st, occs_new,
                        partial, occ_thre, threshold, binary, n_total_cells);
     NSR_CHECK_LAUNCH("nsr_occupancy_update");
+    return NSR_OK;
+}
+
+extern "C" int nsr_occupancy_density_values_sphere(const float *logit, const float *x_unit, float density_bias,
+                                                   float step_size, float *occ, uint32_t capacity, const int32_t *n_cells,
+                                                   void *stream)
+{
+    NSR_REQUIRE(logit && x_unit && occ && n_cells, "nsr_occupancy_density_values_sphere: NULL pointer");
+    if (capacity == 0) return NSR_OK;
+    hipLaunchKernelGGL(k_occ_density_values_sphere, dim3(nsr_div_up(capacity, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                       (hipStream_t)stream, logit, x_unit, density_bias, step_size, occ, capacity, n_cells);
+    NSR_CHECK_LAUNCH("nsr_occupancy_density_values_sphere");
     return NSR_OK;
 }
 

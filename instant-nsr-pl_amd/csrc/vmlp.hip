@@ -128,11 +128,15 @@ __device__ __forceinline__ uint64_t enc_row_base(uint32_t enc_stride, uint64_t s
 // instead of nine 2-byte loads.  (With the natural order the backward, which has no registers to keep nine loads in flight,
 // serialised them: harmless for row-major, whose eight later loads hit the lines the first one fetched, but +15-36 % for
 // the tile-major layout the encode kernels want to write.)
+// (enc_only: a 32-input network fed by the encoding alone, x == NULL -- the NeRF++ background's density head in the grid
+// refresh: columns 8 g + kk, step 8 carries the padding columns 32..35)
 template <bool PERM>
-__device__ __forceinline__ int kmap(int kk, int g)
+__device__ __forceinline__ int kmap(int kk, int g, bool enc_only = false)
 {
-    if constexpr (PERM) return kk < 8 ? 3 + 8 * g + kk : (g < 3 ? g : 35);
-    else return 4 * kk + g;
+    if constexpr (PERM) {
+        if (enc_only) return kk < 8 ? 8 * g + kk : 32 + g;
+        return kk < 8 ? 3 + 8 * g + kk : (g < 3 ? g : 35);
+    } else return 4 * kk + g;
 }
 
 // the lane's 8 encoded features + x_g for the permuted assignment.  enc_stride: row stride (multiple of 8), or
@@ -160,7 +164,7 @@ __device__ __forceinline__ void load_features_perm(const float *__restrict__ x, 
             dst[2 * j] = __low2float(h); dst[2 * j + 1] = __high2float(h);
         }
     }
-    dst[8] = g < 3 ? x[s * x_stride + g] * 2.f - 1.f : 0.f;
+    dst[8] = (x && g < 3) ? x[s * x_stride + g] * 2.f - 1.f : 0.f;
 }
 
 template <bool SDF_IN>
@@ -200,7 +204,7 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g)];
+        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g, SDF_IN && !x)];
     f32x4 b0f[4], b1f[4], blf, wlf[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
@@ -874,11 +878,16 @@ extern "C" uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *d, uin
     } while (0)
 
 // the 3 + 32-column SDF input takes the permuted k assignment (kmap): its loader reads whole 16-byte / 4-byte units
-static int check_sdf_encoding(const NsrVmlpDesc *desc, const nsr_half *enc, uint32_t enc_stride, const char *who)
+static int check_sdf_encoding(const NsrVmlpDesc *desc, const float *x, const nsr_half *enc, uint32_t enc_stride,
+                              const char *who)
 {
-    if (!enc || desc->in_pad != 36) return NSR_OK;
-    NSR_REQUIRE(desc->n_in == 35, "%s: a 36-wide padded SDF input must be [x (3) | 32 encoded features] (n_in=%u)", who,
-                desc->n_in);
+    if (!enc || desc->in_pad != 36) {
+        NSR_REQUIRE(!enc || x, "%s: an encoding without positions needs the 32-column, 36-wide padded input", who);
+        return NSR_OK;
+    }
+    NSR_REQUIRE(x ? desc->n_in == 35 : desc->n_in == 32,
+                "%s: a 36-wide padded encoded input is [x (3) | 32 features] (n_in = 35) or, with x == NULL, the 32 features "
+                "alone (n_in = 32); got n_in=%u", who, desc->n_in);
     if (enc_stride & 0xC0000000u)
         NSR_REQUIRE((enc_stride & 0xffu) == 2u && ((uintptr_t)enc & 3) == 0,
                     "%s: level- / tile-major encodings are read as 2-feature levels (F=%u)", who, enc_stride & 0xffu);
@@ -893,9 +902,9 @@ extern "C" int nsr_vmlp_forward(const NsrVmlpDesc *desc, const float *blob, cons
                                 uint32_t n, uint32_t n_full, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_vmlp(desc, "nsr_vmlp_forward")) return rc;
-    if (int rc = check_sdf_encoding(desc, enc, enc_stride, "nsr_vmlp_forward")) return rc;
+    if (int rc = check_sdf_encoding(desc, x, enc, enc_stride, "nsr_vmlp_forward")) return rc;
     if (n == 0) return NSR_OK;
-    NSR_REQUIRE(blob && x && (out || n_full == 0), "nsr_vmlp_forward: NULL pointer");
+    NSR_REQUIRE(blob && (x || enc) && (out || n_full == 0), "nsr_vmlp_forward: NULL pointer");
     NSR_REQUIRE(n_full <= n && (n_full == n || out_col0), "nsr_vmlp_forward: rows beyond n_full need out_col0");
     NSR_REQUIRE(!g_in || desc->n_hidden == 1, "nsr_vmlp_forward: the input gradient is implemented for one hidden layer");
     const uint32_t blocks = vmlp_blocks(n) * 2 > nsr_div_up(n, 16) ? nsr_div_up(n, 16) : vmlp_blocks(n) * 2;
@@ -908,6 +917,7 @@ extern "C" int nsr_vmlp_forward(const NsrVmlpDesc *desc, const float *blob, cons
         if (nh == 1 && act == 0 && !sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 0, false, false>), __VA_ARGS__);    \
         else if (nh == 2 && act == 0 && !sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 2, 0, false, false>), __VA_ARGS__); \
         else if (nh == 1 && act == 1 && sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, false>), __VA_ARGS__); \
+        else if (nh == 1 && act == 0 && sdf && !gin && KSV == 9) hipLaunchKernelGGL((KERNEL<9, 1, 0, true, false>), __VA_ARGS__); \
         else if (nh == 1 && act == 1 && sdf && gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, true>), __VA_ARGS__);   \
         else if (nh == 1 && act == 1 && !sdf && !gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, false>), __VA_ARGS__); \
         else if (nh == 1 && act == 1 && !sdf && gin) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, true>), __VA_ARGS__); \
@@ -928,7 +938,8 @@ extern "C" int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, con
                                  uint32_t n, uint32_t n_full, const int32_t *n_dev, void *stream)
 {
     if (int rc = check_vmlp(desc, "nsr_vmlp_backward")) return rc;
-    if (int rc = check_sdf_encoding(desc, enc, enc_stride, "nsr_vmlp_backward")) return rc;
+    NSR_REQUIRE(n == 0 || x, "nsr_vmlp_backward: x is NULL (the encoding-only input is a forward-only mode)");
+    if (int rc = check_sdf_encoding(desc, x, enc, enc_stride, "nsr_vmlp_backward")) return rc;
     NSR_REQUIRE(blob && grad_blob && partials && (n == 0 || x), "nsr_vmlp_backward: NULL pointer");
     NSR_REQUIRE(n_full <= n && (n_full == 0 || d_out) && (n_full == n || d_out_col0),
                 "nsr_vmlp_backward: d_out / d_out_col0 do not cover the rows");

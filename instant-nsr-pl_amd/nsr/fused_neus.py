@@ -26,6 +26,8 @@ from nsr_hip import ops as _ops
 # layout of the encoded features between the encode and the fp32 MLP kernels of a step: 2 = tile-major (default),
 # 0 = row-major (developer switch for A/B)
 ENC_LAYOUT = int(os.environ.get("NSR_NEUS_ENC_LAYOUT", "2"))
+# grid refresh: draw the random cells in increasing order (sorted_uniform_); 0 = unordered (developer switch for A/B)
+SORTED_REFRESH = not os.environ.get("NSR_NEUS_UNSORTED_REFRESH")
 
 F32, F16 = torch.float32, torch.float16
 _byref = ctypes.byref
@@ -119,6 +121,19 @@ def _vanilla_layers(net):
     layers = net.layers
     mods = list(layers.children()) if hasattr(layers, "children") else list(layers)
     return [m for m in mods if hasattr(m, "bias") and (hasattr(m, "weight") or hasattr(m, "weight_v"))]
+
+
+def sorted_uniform_(buf):
+    """fill ``buf`` with n i.i.d. U[0,1) numbers IN INCREASING ORDER (the order statistics of n uniforms are the normalised
+    partial sums of n + 1 exponentials): the random cells of a grid refresh are then visited in memory order -- neighbouring
+    cells, coherent table gathers in the encode -- and are the same random set in distribution"""
+    n = buf.numel()
+    if n == 0:
+        return buf
+    e = torch.empty(n + 1, dtype=torch.float64, device=buf.device).exponential_()
+    c = torch.cumsum(e, 0)
+    buf.copy_((c[:-1] / c[-1]).clamp_(max=1.0 - 2.0 ** -24))
+    return buf
 
 
 class FusedNeuSStep:
@@ -466,7 +481,11 @@ class FusedNeuSStep:
             s = stream_ptr()
             ob["jitter"][:cap * 3].uniform_()
             if not all_cells:
-                ob["u"].uniform_()
+                if SORTED_REFRESH:
+                    sorted_uniform_(ob["u"][:n_uniform])
+                    sorted_uniform_(ob["u"][n_uniform:])
+                else:
+                    ob["u"].uniform_()
             check(lib.nsr_occupancy_select_cells(ptr(bricks), rx, ry, rz, ptr(ob["u"][:n_uniform]),
                                                  ptr(ob["u"][n_uniform:]), ptr(ob["jitter"]), n_uniform, int(all_cells),
                                                  cap, ptr(ob["brick_offset"]), ptr(ob["occupied"]), ptr(n_occ),
@@ -482,6 +501,84 @@ class FusedNeuSStep:
                                        ptr(ob["out"]), None, None, cap, cap, ptr(n_cells), s), "nsr_vmlp_forward(occupancy)")
             check(lib.nsr_neus_occupancy_values(ptr(ob["out"]), ptr(inv_s), float(m.render_step_size), ptr(ob["occ"]), cap,
                                                 ptr(n_cells), s), "nsr_neus_occupancy_values")
+            check(lib.nsr_occupancy_update_values(ptr(ob["occ"]), float(ema_decay), float(occ_thre), ptr(ob["cells"]),
+                                                  ptr(grid.occs), ptr(ob["occs"]), ptr(binary.view(torch.uint8)),
+                                                  ptr(ob["thr"]), N, cap, ptr(n_cells), s), "nsr_occupancy_update_values")
+            grid.occs.copy_(ob["occs"])
+            check(lib.nsr_grid_pack_bricks(ptr(binary.view(torch.uint8)), rx, ry, rz, ptr(bricks), s),
+                  "nsr_grid_pack_bricks")
+        try:  # the cache of ops.grid_bricks keys on the tensor version, which a raw-pointer write does not bump
+            binary._nsr_bricks = (binary._version, binary.data_ptr(), bricks)
+        except Exception:  # noqa: BLE001
+            pass
+
+    @torch.no_grad()
+    def refresh_bg_occupancy_async(self, step, occ_thre=0.01, ema_decay=0.95, warmup_steps=256):
+        """``OccupancyGrid._update`` of the 256^3 NeRF++ BACKGROUND grid (nerfacc 0.3.3, UN_BOUNDED_SPHERE; reference
+        models/neus.py:103-111) on the current stream, the selected-cell count kept on the device: cell selection, positions,
+        encode (tile-major fp16), the fp32 density head reading the encoding directly, exp(logit + bias) * step inside the unit
+        sphere, EMA / threshold / binarise, brick re-packing -- 11 launches.  The torch formulation of the same refresh
+        (nerfacc/grid.py with ``bg_occ_eval_fn``) spent more than half of its 5.5-7 ms in ~80 torch launches around the encode:
+        int64 cell coordinates, boolean-mask compaction, a row-major fp16 encoding (ten times its size in fabric writes)
+        converted to fp32 for the network."""
+        m, grid, enc, desc = self.model, self.model.occupancy_grid_bg, self.bg_enc, self.bg_enc.grid_desc
+        if self.bg_geo.desc.in_pad != 36 or self.bg_n_enc != 32 or int(desc.n_features) != 2:
+            raise NotImplementedError("device-side background refresh: 16 levels x 2 features -> one hidden layer")
+        dev = grid.occs.device
+        rx, ry, rz = grid._res
+        N = grid.num_cells
+        all_cells = step < warmup_steps
+        n_uniform = N // 4
+        cap = N if all_cells else 2 * n_uniform
+        rows = (cap + 15) // 16 * 16
+        ob = getattr(self, "_occ_buf_bg", None)
+        binary = grid._binary
+        assert binary.is_contiguous() and binary.dtype == torch.bool
+        if ob is None or ob["rows"] < rows:
+            bricks = torch.empty(int(lib.nsr_grid_bricks_words64(rx, ry, rz)), dtype=torch.int64, device=dev)
+            ob = self._occ_buf_bg = dict(
+                rows=rows, bricks=bricks, cells=torch.empty(cap, dtype=torch.int32, device=dev),
+                x_unit=torch.empty(cap * 3, dtype=F32, device=dev), world=torch.empty(cap * 3, dtype=F32, device=dev),
+                x01=torch.empty(cap * 3, dtype=F32, device=dev), enc=torch.empty(rows * self.bg_n_enc, dtype=F16, device=dev),
+                logit=torch.empty(cap, dtype=F32, device=dev), occ=torch.empty(cap, dtype=F32, device=dev),
+                u=torch.empty(2 * n_uniform, dtype=F32, device=dev), jitter=torch.empty(cap * 3, dtype=F32, device=dev),
+                brick_offset=torch.empty(max(bricks.numel(), 1), dtype=torch.int32, device=dev),
+                occupied=torch.empty(N, dtype=torch.int32, device=dev), counts=torch.zeros(4, dtype=torch.int32, device=dev),
+                occs=torch.empty(N, dtype=F32, device=dev), thr=torch.empty(2 + 2 * 256, dtype=F32, device=dev))
+        bricks = ob["bricks"]
+        _ops.grid_bricks(binary, out=bricks)  # the bitfield of the CURRENT grid (cached per tensor version)
+        n_occ, n_cells = ob["counts"][0:1], ob["counts"][1:2]
+        table = enc.table_half(enc.params)
+        blob = self.bg_geo.build(requires_grad=False)
+        sphere = ContractionType.UN_BOUNDED_SPHERE.value
+        with torch.cuda.device(dev):
+            s = stream_ptr()
+            ob["jitter"][:cap * 3].uniform_()
+            if not all_cells:
+                if SORTED_REFRESH:
+                    sorted_uniform_(ob["u"][:n_uniform])
+                    sorted_uniform_(ob["u"][n_uniform:])
+                else:
+                    ob["u"].uniform_()
+            check(lib.nsr_occupancy_select_cells(ptr(bricks), rx, ry, rz, ptr(ob["u"][:n_uniform]),
+                                                 ptr(ob["u"][n_uniform:]), ptr(ob["jitter"]), n_uniform, int(all_cells),
+                                                 cap, ptr(ob["brick_offset"]), ptr(ob["occupied"]), ptr(n_occ),
+                                                 ptr(ob["cells"]), ptr(ob["x_unit"]), ptr(n_cells), s),
+                  "nsr_occupancy_select_cells")
+            # (samples outside the unit sphere have no world position: whatever the two maps make of them is discarded below)
+            check(lib.nsr_contract_inv(ptr(ob["x_unit"]), ptr(grid.roi_aabb), sphere, ptr(ob["world"]), cap, s),
+                  "nsr_contract_inv")
+            check(lib.nsr_contract_to_unisphere(ptr(ob["world"]), self.radius, sphere, ptr(ob["x01"]), cap, s),
+                  "nsr_contract_to_unisphere")
+            check(lib.nsr_hashgrid_forward_ex(ptr(ob["x01"]), ptr(table), ptr(ob["enc"]), cap, 0, 2, desc.n_levels,
+                                              _byref(desc), ptr(n_cells), s), "nsr_hashgrid_forward_ex")
+            # the density head on the encoding alone (x == NULL), column 0 of every row
+            check(lib.nsr_vmlp_forward(_byref(self.bg_geo.desc), ptr(blob), None, 0, ptr(ob["enc"]),
+                                       0x40000000 | int(desc.n_features), None, ptr(ob["logit"]), None, cap, 0, ptr(n_cells), s),
+                  "nsr_vmlp_forward(bg occupancy)")
+            check(lib.nsr_occupancy_density_values_sphere(ptr(ob["logit"]), ptr(ob["x_unit"]), float(self.bg_bias),
+                                                          float(m.render_step_size_bg), ptr(ob["occ"]), cap, ptr(n_cells), s),
+                  "nsr_occupancy_density_values_sphere")
             check(lib.nsr_occupancy_update_values(ptr(ob["occ"]), float(ema_decay), float(occ_thre), ptr(ob["cells"]),
                                                   ptr(grid.occs), ptr(ob["occs"]), ptr(binary.view(torch.uint8)),
                                                   ptr(ob["thr"]), N, cap, ptr(n_cells), s), "nsr_occupancy_update_values")
@@ -1035,7 +1132,9 @@ class NeuSTrainer:
                 self.fused.refresh_occupancy_async(t, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
             else:
                 grid.every_n_step(step=t, occ_eval_fn=self.fused.occ_eval_fn, occ_thre=cfg.get("grid_prune_occ_thre", 0.01))
-            if self.fused.bg:
+            if self.fused.bg and self.device_occupancy_refresh:
+                self.fused.refresh_bg_occupancy_async(t, occ_thre=cfg.get("grid_prune_occ_thre_bg", 0.01))
+            elif self.fused.bg:
                 model.occupancy_grid_bg.every_n_step(step=t, occ_eval_fn=self.fused.bg_occ_eval_fn,
                                                      occ_thre=cfg.get("grid_prune_occ_thre_bg", 0.01))
             refreshed = True

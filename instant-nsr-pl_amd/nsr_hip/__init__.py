@@ -229,6 +229,7 @@ SIGNATURES = {
     "nsr_neus_inv_s": [_P, _P, _P],
     "nsr_neus_occupancy_values": [_P, _P, _F, _P, _U, _P, _P],
     "nsr_occupancy_update_values": [_P, _F, _F, _P, _P, _P, _P, _P, _U, _U, _P, _P],
+    "nsr_occupancy_density_values_sphere": [_P, _P, _F, _F, _P, _U, _P, _P],
     "nsr_neus_variance_gradient": [_P, _P, _P, _I, _P],
     "nsr_bg_visibility_prefix": [_P, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_bg_texture_input": [_P, _U, _P, _P, _P, _U, _U, _P, _P],

@@ -185,3 +185,47 @@ def test_table_adamw_inside_the_backward_matches_the_separate_sweep(name):
                 moved = float((a - runs[True][step - 1][k]).norm())
                 assert float((a - b).norm()) <= 6e-2 * moved, (name, step, k, float((a - b).norm()), moved)
             assert not torch.equal(a, torch.zeros_like(a))
+
+
+@pytest.mark.parametrize("step", [0, 512])
+def test_device_background_refresh_matches_torch_update(step):
+    """FusedNeuSStep.refresh_bg_occupancy_async (cell selection, tile-major encode, density head on the encoding alone,
+    exp(logit + bias) * step inside the unit sphere, EMA / threshold / binarise, bricks) == nerfacc's
+    OccupancyGrid._update_cells with the reference's background occ_eval_fn (models/neus.py:103-106) on the cells / jitter
+    the kernels selected: cells whose sample fell outside the unit sphere keep their value untouched"""
+    import copy
+    import nsr
+    from nsr.fused_neus import FusedNeuSStep
+    from nsr_hip import ops
+    torch.manual_seed(0)
+    cfg = nsr.configs.get("neus-dtu")
+    st = nsr.build(cfg).cuda().train()
+    grid = st.occupancy_grid_bg
+    g = torch.Generator(device="cuda").manual_seed(1)
+    grid.occs.copy_(torch.rand(grid.num_cells, device="cuda", generator=g) * 0.02)
+    grid._binary = (torch.rand(grid._res, device="cuda", generator=g) < 0.05)
+    run = FusedNeuSStep(st)
+    ref = copy.deepcopy(grid)
+    thre = cfg.get("grid_prune_occ_thre_bg", 0.01)
+    run.refresh_bg_occupancy_async(step, occ_thre=thre)
+    ob = run._occ_buf_bg
+    n = int(ob["counts"][1])
+    N = grid.num_cells
+    assert n == (N if step < 256 else N // 4 + min(int(ref._binary.sum()), N // 4))
+    cells = ob["cells"][:n].long()
+    jitter = ob["jitter"][:3 * n].view(n, 3)
+    with torch.no_grad():
+        ref._update_cells(cells, jitter, run.bg_occ_eval_fn, occ_thre=thre, ema_decay=0.95)
+    once = torch.bincount(cells, minlength=N) <= 1
+    # some samples fall outside the unit sphere (corner cells): their cells are left alone by both paths; a sample within
+    # rounding of the sphere's surface may be classified differently by sqrtf and torch's norm -- not compared
+    x = (ref._cell_coords(cells) + jitter) / ref.resolution
+    r = (x - 0.5).norm(dim=1)
+    assert int((r >= 0.5).sum()) > 0
+    on_surface = torch.zeros(N, dtype=torch.bool, device="cuda")
+    on_surface[cells[(r - 0.5).abs() < 1e-5]] = True
+    sel = once & ~on_surface
+    assert torch.allclose(grid.occs[sel], ref.occs[sel], rtol=2e-3, atol=2e-6), \
+        float((grid.occs[sel] - ref.occs[sel]).abs().max())
+    assert float((grid.binary != ref.binary).float().mean()) < 1e-4
+    assert torch.equal(ob["bricks"], ops.grid_bricks(grid.binary.clone()))
