@@ -46,6 +46,15 @@ for c in neus-blender neus-dtu neuralangelo; do
   rm -rf /tmp/pn && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pn -o k -- python /root/repo/tools/neus_step_bench.py --config $c --dynamic --steps 60 --warmup 60 > "$out/neus_step_$c.json" 2>/dev/null
   cp "$(find /tmp/pn -name '*kernel_stats.csv' | head -1)" "$out/fused_${c}_kernel_stats.csv"
 done
+# ... and at the reference's operating point through NeuSTrainer (dynamic ray count -> 2^18 samples / step)
+for c in neus-blender neus-dtu neuralangelo; do
+  python /root/repo/tools/neus_operating_point.py $c 100 2>/dev/null | tail -1 > "$out/neus_op_$c.json"
+  rm -rf /tmp/pn && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pn -o k -- python /root/repo/tools/neus_operating_point.py $c 60 > /dev/null 2>&1
+  cp "$(find /tmp/pn -name '*kernel_stats.csv' | head -1)" "$out/neus_op_${c}_kernel_stats.csv"
+done
+python /root/repo/tools/bg_refresh_profile.py 300 2>/dev/null | tail -1 > "$out/bg_refresh.json"
+NSR_NEUS_TORCH_REFRESH=1 python /root/repo/tools/bg_refresh_profile.py 300 2>/dev/null | tail -1 >> "$out/bg_refresh.json"
+python /root/repo/tools/vmlp_layout_bench.py 2>/dev/null | tail -1 > "$out/vmlp_layout_bench.json"
 # the step through the model interface (bench.py boundary_path): phases and kernel timeline
 cd /root/repo
 python tools/boundary_profile.py > "$out/boundary_phases.json" 2>/dev/null
