@@ -1078,7 +1078,7 @@ class NeuSTrainer:
         # multi-GPU: the hash tables' gradients are reduce-scattered in bf16, each rank steps its shard and the fp16
         # images are all-gathered (nsr.parallel.ShardedAdamW); the small fp32 heads + variance are all-reduced
         self.sharded, self.comm_timings = None, None
-        if world_size > 1:
+        if world_size > 1 or os.environ.get("NSR_FORCE_SHARDED"):  # (the switch: see nsr/trainer.py)
             import torch.distributed as dist
             from .parallel import ShardedAdamW
             if dist.is_initialized():

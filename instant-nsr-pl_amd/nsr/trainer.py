@@ -214,7 +214,9 @@ class Trainer:
         self.opt = FusedAdamW(tc, other)
         # world > 1: reduce-scatter -> AdamW on this rank's 1/P of the table -> all-gather of the fp16 image (nsr/parallel.py)
         self.sharded, self._xchg = None, None
-        if world_size > 1 and not other and dist.is_initialized():
+        # (NSR_FORCE_SHARDED=1: take the multi-GPU exchange with a process group of ANY size -- a one-rank nccl group runs every
+        # RCCL call of the path on a one-GPU box, tests/test_gpu_nccl_single_rank.py)
+        if (world_size > 1 or os.environ.get("NSR_FORCE_SHARDED")) and not other and dist.is_initialized():
             # the table is exchanged in NSR_EXCHANGE_GROUPS ranges cut at level boundaries (default 2: the five finest levels,
             # launched first by the fused step, travel while the other eleven are still being accumulated)
             splits = {}
