@@ -699,6 +699,16 @@ int nsr_hashgrid_backward_params_owner_accumulate_taps_adam(const float *x7, con
                                                             float *tap_workspace, uint32_t n_centre,
                                                             uint32_t level_mask_count, const NsrGridDesc *desc,
                                                             const NsrTableAdam *adam, void *stream);
+/* ... and with the gradient written as bf16 (round to nearest even) into a caller buffer [n_entries * F] -- the send buffer of
+ * the multi-GPU exchange (nsr/parallel.py:ShardedAdamW) -- instead of an fp32 gradient: written once, every entry. */
+int nsr_hashgrid_backward_params_owner_with_second_order_bf16(const float *x, const float *dy_first_lm, const float *dy,
+                                                              uint32_t dy_stride, const float *g, uint16_t *grad_bf16,
+                                                              float *workspace, uint32_t n, uint32_t level_mask_count,
+                                                              int binned, const NsrGridDesc *desc, void *stream);
+int nsr_hashgrid_backward_params_owner_accumulate_taps_bf16(const float *x7, const float *dy_level_major,
+                                                            uint16_t *grad_bf16, float *workspace, float *tap_workspace,
+                                                            uint32_t n_centre, uint32_t level_mask_count,
+                                                            const NsrGridDesc *desc, void *stream);
 /* The optimizer step of the asynchronous trainer in ONE launch: nsr_adam_tick + nsr_adamw_step over up to two tensors
  * (a: hash table + density MLP with its partial re-zeroing, b: colour MLP; n_b == 0: one tensor).  hyper12: 12 floats, 8-byte
  * aligned, zero-initialised ([0..7] as for nsr_adam_tick, [8] ticket counter).  Bit-identical to the separate launches. */

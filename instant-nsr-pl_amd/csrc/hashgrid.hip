@@ -912,6 +912,19 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate_taps_adam(const flo
                           2, stream, nullptr, nullptr, adam, n_centre, tap_workspace);
 }
 
+// ... or written as bf16 into the multi-GPU exchange's send buffer (nsr/parallel.py): no fp32 gradient, no cast kernel
+extern "C" int nsr_hashgrid_backward_params_owner_accumulate_taps_bf16(const float *x7, const float *dy_level_major,
+                                                                       uint16_t *grad_bf16, float *workspace,
+                                                                       float *tap_workspace, uint32_t n_centre,
+                                                                       uint32_t level_mask_count, const NsrGridDesc *desc,
+                                                                       void *stream)
+{
+    NSR_REQUIRE(n_centre > 0 && tap_workspace && grad_bf16,
+                "nsr_hashgrid_backward_params_owner_accumulate_taps_bf16: empty input / NULL workspace / NULL output");
+    return owner_backward(x7, dy_level_major, 2, 0, nullptr, workspace, 7u * n_centre, level_mask_count, 1.f, 0, desc, nullptr,
+                          2, stream, nullptr, nullptr, nullptr, n_centre, tap_workspace, grad_bf16);
+}
+
 // first-order table gradient (dy_first, level-major fp32) and the second-order one of the analytic normal (dy row-major
 // fp32 with `g` = dL/d(dx)) in ONE binning + accumulation pass
 extern "C" int nsr_hashgrid_backward_params_owner_with_second_order(const float *x, const float *dy_first_lm,
@@ -938,6 +951,19 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order_adam(const f
                 "nsr_hashgrid_backward_params_owner_with_second_order_adam: NULL pointer");
     return owner_backward(x, dy, 1, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
                           stream, g, dy_first_lm, adam);
+}
+
+extern "C" int nsr_hashgrid_backward_params_owner_with_second_order_bf16(const float *x, const float *dy_first_lm,
+                                                                         const float *dy, uint32_t dy_stride,
+                                                                         const float *g, uint16_t *grad_bf16,
+                                                                         float *workspace, uint32_t n,
+                                                                         uint32_t level_mask_count, int binned,
+                                                                         const NsrGridDesc *desc, void *stream)
+{
+    NSR_REQUIRE(grad_bf16 && (n == 0 || (dy_first_lm && dy && g)),
+                "nsr_hashgrid_backward_params_owner_with_second_order_bf16: NULL pointer");
+    return owner_backward(x, dy, 1, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
+                          stream, g, dy_first_lm, nullptr, 0u, nullptr, grad_bf16);
 }
 
 extern "C" int nsr_hashgrid_backward_input(const float *x, const nsr_half *table, const void *dy, int dy_is_f32,

@@ -150,6 +150,9 @@ class FusedNeuSStep:
         # {"fg": NsrTableAdam, "bg": NsrTableAdam} for ONE step (a trainer sets it): AdamW on the hash tables inside their
         # backward; adam_applied says which of them a step really updated (a step without samples launches no table backward)
         self.table_adam, self.adam_applied = None, set()
+        # multi-GPU: {"fg": bf16 send buffer, "bg": ...} of nsr.parallel.ShardedAdamW -- the table backward writes the
+        # exchange's transport format itself (no fp32 gradient, no cast); bf16_written: which of them a step really filled
+        self.table_bf16, self.bf16_written = None, set()
         self.radius = float(cfg["radius"])
         g = cfg["geometry"]
         self.fd = g["grad_type"] == "finite_difference"
@@ -406,7 +409,14 @@ class FusedNeuSStep:
         if enc.params.grad is None:
             enc.params.grad = torch.zeros_like(enc.params)
         ad = (self.table_adam or {}).get("bg")
-        if S > 0 and ad is not None:
+        bf = None if ad is not None else (self.table_bf16 or {}).get("bg")
+        if S > 0 and bf is not None:
+            torch.cuda.current_stream().wait_event(c["bin_event"])
+            check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(
+                ptr(c["x01"]), ptr(d_enc), None, ptr(bf), ptr(c["gws"]), S, desc.n_levels, 1.0, 0, desc.n_levels, _byref(desc),
+                None, s), "nsr_hashgrid_backward_params_owner_accumulate_range(bg)")
+            self.bf16_written.add("bg")
+        elif S > 0 and ad is not None:
             torch.cuda.current_stream().wait_event(c["bin_event"])
             check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(c["x01"]), ptr(d_enc), 2, 0, ptr(c["gws"]), S,
                                                                          desc.n_levels, 1.0, _byref(desc), None, _byref(ad), s),
@@ -703,7 +713,7 @@ class FusedNeuSStep:
     def _step(self, rays, gt_rgb, fg_mask, background, compute_grads, loss_scale, march_handle, after_march, external):
         """generator: runs the forward, yields the result dict, is sent the upstream gradients (``external``) or None (built-in
         loss terms) and runs the backward.  No torch context manager is held across the yield."""
-        self.adam_applied = set()
+        self.adam_applied, self.bf16_written = set(), set()
         m, enc, lw = self.model, self.enc, self.loss_weights
         dev = rays.device
         n_rays = rays.shape[0]
@@ -945,7 +955,22 @@ class FusedNeuSStep:
             # a trainer on one GPU hands over AdamW for the table (self.table_adam): the owner workgroups apply it in their
             # write-out -- no 50 MB gradient store, no optimizer sweep over the table
             ad = (self.table_adam or {}).get("fg")
-            if self.fd and tws is not None:
+            bf = None if ad is not None else (self.table_bf16 or {}).get("fg")
+            if bf is not None:
+                if self.fd and tws is not None:
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps_bf16(
+                        ptr(x7), ptr(d_enc), ptr(bf), ptr(gws), ptr(tws), N, mc, _byref(desc), s),
+                        "nsr_hashgrid_backward_params_owner_accumulate_taps_bf16")
+                elif self.fd:
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(
+                        ptr(x7), ptr(d_enc), None, ptr(bf), ptr(gws), T * N, mc, 1.0, 0, desc.n_levels, _byref(desc), None, s),
+                        "nsr_hashgrid_backward_params_owner_accumulate_range")
+                else:
+                    check(lib.nsr_hashgrid_backward_params_owner_with_second_order_bf16(
+                        ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(bf), ptr(gws), N, mc, 1, _byref(desc), s),
+                        "nsr_hashgrid_backward_params_owner_with_second_order_bf16")
+                self.bf16_written.add("fg")
+            elif self.fd and tws is not None:
                 if ad is not None:
                     check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps_adam(
                         ptr(x7), ptr(d_enc), ptr(gws), ptr(tws), N, mc, _byref(desc), _byref(ad), s),
@@ -1170,6 +1195,11 @@ class NeuSTrainer:
             # the kernels take step count / bias corrections from the optimizer's device-side state
             self.fused.table_adam = {k: self.opt.table_update_desc(m, milestones=(), gamma=1.0, lr=self.opt.lr * scale)
                                      for k, m in self._table_of.items()}
+        self.fused.table_bf16 = None
+        if self.sharded is not None and self.sharded.transport == torch.bfloat16 and not os.environ.get("NSR_EXCHANGE_UNFUSED"):
+            # multi-GPU: the table backwards write the exchange's bf16 send buffers themselves
+            self.fused.table_bf16 = {k: self.sharded.send_buffer(m) for k, m in self._table_of.items()
+                                     if self.sharded.state[m]["head"] == 0 and len(self.sharded.ranges(m)) == 1}
         res = self.fused.forward_backward(rays, rgb, fg, bg, march_handle=handle, after_march=after_march)
         n = res["num_samples"]
         if self.sharded is not None:
@@ -1177,7 +1207,8 @@ class NeuSTrainer:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             all_reduce_gradients(self._rest)
-            self.sharded.step(lr_scale=scale, timings=self.comm_timings, overwritten=self._tables)
+            self.sharded.step(lr_scale=scale, timings=self.comm_timings, overwritten=self._tables,
+                              prefilled=[self._table_of[k] for k in self.fused.bf16_written])
         else:
             if self.world_size > 1:
                 all_reduce_gradients(list(model.parameters()))

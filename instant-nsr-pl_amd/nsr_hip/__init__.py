@@ -133,6 +133,8 @@ SIGNATURES = {
     "nsr_hashgrid_backward_params_owner_with_second_order": [_P, _P, _P, _U, _P, _P, _P, _U, _U, _I, _I, _GD, _P],
     "nsr_hashgrid_backward_params_owner_with_second_order_adam": [_P, _P, _P, _U, _P, _P, _U, _U, _I, _GD, _P, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_taps_adam": [_P, _P, _P, _P, _U, _U, _GD, _P, _P],
+    "nsr_hashgrid_backward_params_owner_with_second_order_bf16": [_P, _P, _P, _U, _P, _P, _P, _U, _U, _I, _GD, _P],
+    "nsr_hashgrid_backward_params_owner_accumulate_taps_bf16": [_P, _P, _P, _P, _P, _U, _U, _GD, _P],
     "nsr_sh4_forward": [_P, _P, _U, _U, _P],
     "nsr_mlp_forward": [_P, _I, _U, _P, _P, _P, _U, _MD, _P],
     "nsr_mlp_forward_ex": [_P, _I, _U, _U, _P, _P, _P, _U, _MD, _P, _P],
