@@ -44,7 +44,9 @@ class FusedAdamW:
         (table_update_desc with this step's lr): only their fp16 image is adopted, and the device-side step counter /
         running beta powers those kernels read are advanced"""
         self.step_count += 1
-        if updated_in_backward:
+        if updated_in_backward or getattr(self, "_step_dev", None) is not None:
+            # (once the device-side counter exists it advances with EVERY step -- also one whose backward launched nothing
+            # and whose tables therefore take the sweep below -- or its bias corrections would fall behind the host's)
             step_dev, hyper = self._device_schedule_state()
             _ops.adam_tick(step_dev, hyper, self.lr * lr_scale, self.betas[0], self.betas[1], 1.0, ())
         for m in self.tcnn_modules:
