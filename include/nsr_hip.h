@@ -495,6 +495,23 @@ int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, f
                                      const float *trans, const float *comp_rgb, const float *opacity, const float *gt_rgb,
                                      const float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
                                      uint32_t n_rays, void *stream);
+/* The same forward / backward pair with the loss reduction folded in (csrc/step.hip uses it when one call runs both): the
+ * forward leaves one (loss sum, valid rays) partial per block in `partials` (nsr_composite_l1_partials_floats(n_rays)
+ * floats, no initialisation), every block of the backward sums them in a fixed order and block 0 writes acc2 -- no
+ * atomics and no one-workgroup reduction kernel between the two launches. */
+uint64_t nsr_composite_l1_partials_floats(uint32_t n_rays);
+int nsr_composite_forward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                    const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
+                                    const int32_t *packed_info, const float *background, float *weights, float *trans,
+                                    float *comp_rgb, float *opacity, float *depth, const float *gt_rgb, float *partials,
+                                    uint32_t n_rays, void *stream);
+int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out, uint32_t stride, float density_bias,
+                                              const float *t_starts, const float *t_ends, const nsr_half *rgb,
+                                              uint32_t rgb_stride, const int32_t *packed_info, const float *background,
+                                              const float *weights, const float *trans, const float *comp_rgb,
+                                              const float *opacity, const float *gt_rgb, const float *partials,
+                                              float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
+                                              uint32_t n_rays, void *stream);
 /* acc2[0] += sum of smooth_l1 over valid rays (opacity > 0) x 3 channels, acc2[1] += number of valid rays
  * (loss = acc2[0] / (3*acc2[1]), systems/nerf.py:97); backward writes grad_scale * dloss/dcomp_rgb */
 int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,

@@ -317,10 +317,16 @@ k_composite_forward(const __half *__restrict__ mlp_out, uint32_t stride, float b
                     const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
                     const int32_t *__restrict__ packed, const float *__restrict__ bg, float *__restrict__ weights,
                     float *__restrict__ trans, float *__restrict__ comp_rgb, float *__restrict__ opacity,
-                    float *__restrict__ depth, uint32_t n_rays)
+                    float *__restrict__ depth, uint32_t n_rays,
+                    const float *__restrict__ l1_gt /* with l1_part: the masked smooth-L1 loss against these colours ... */,
+                    float *__restrict__ l1_part /* ... as one partial (sum, valid rays) per block: [2][gridDim.x] */)
 {
     uint32_t r, start, count;
-    if (!wave_ray(packed, n_rays, r, start, count)) return;
+    const bool active = wave_ray(packed, n_rays, r, start, count);
+    if (!active) {
+        if (!l1_part) return;
+        count = 0;  // (an idle wave of the last block still meets the others at the block's partial sum)
+    }
     const uint32_t lane = threadIdx.x & 63;
     float carry = 0.f;  // running sum of sigma*dt
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // opacity, depth, r, g, b
@@ -356,12 +362,35 @@ k_composite_forward(const __half *__restrict__ mlp_out, uint32_t stride, float b
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) acc[q] = wave_sum(acc[q]);
-    if (lane == 0) {
+    float l1_s = 0.f, l1_c = 0.f;
+    if (active && lane == 0) {
         opacity[r] = acc[0];
         depth[r] = acc[1];
         const float rest = 1.f - acc[0];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) comp_rgb[3ull * r + q] = acc[2 + q] + bg[q] * rest;
+        for (int q = 0; q < 3; ++q) {
+            const float v = acc[2 + q] + bg[q] * rest;
+            comp_rgb[3ull * r + q] = v;
+            if (l1_part && acc[0] > 0.f) {  // (the arithmetic of k_smooth_l1_valid_set on the value just stored)
+                const float d = fabsf(v - l1_gt[3ull * r + q]);
+                l1_s += d < 1.f ? 0.5f * d * d : d - 0.5f;
+            }
+        }
+        if (l1_part && acc[0] > 0.f) l1_c = 1.f;
+    }
+    if (l1_part) {
+        // loss sum and valid-ray count of this block's rays: one plain store per block, summed (in a fixed order) by every
+        // block of the backward kernel -- no atomics, no zeroing, no one-workgroup reduction kernel between the two
+        __shared__ float sh[2][RAYS_PER_BLOCK];
+        if (lane == 0) { sh[0][threadIdx.x >> 6] = l1_s; sh[1][threadIdx.x >> 6] = l1_c; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float ts = 0.f, tc = 0.f;
+#pragma unroll
+            for (int w = 0; w < RAYS_PER_BLOCK; ++w) { ts += sh[0][w]; tc += sh[1][w]; }
+            l1_part[blockIdx.x] = ts;
+            l1_part[gridDim.x + blockIdx.x] = tc;
+        }
     }
 }
 
@@ -445,15 +474,32 @@ k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float 
                      const float *__restrict__ g_depth, float *__restrict__ d_rgb, float *__restrict__ d_logit,
                      uint32_t n_rays, const float *__restrict__ l1_comp, const float *__restrict__ l1_opacity,
                      const float *__restrict__ l1_gt, const float *__restrict__ l1_acc, float l1_scale,
-                     const float *__restrict__ g_weights /* dL/d weights[n] of the caller's own loss terms, or NULL */)
+                     const float *__restrict__ g_weights /* dL/d weights[n] of the caller's own loss terms, or NULL */,
+                     const float *__restrict__ l1_part /* [2][gridDim.x] block partials of k_composite_forward, or NULL */,
+                     float *__restrict__ l1_acc_out /* with l1_part: (loss sum, valid rays) for the caller, written by block 0 */)
 {
+    const uint32_t lane = threadIdx.x & 63;
+    float n_valid = 0.f;
+    if (l1_part) {  // every block sums the forward's partials itself (gridDim.x floats x 2, L2-resident), same order everywhere
+        __shared__ float tot[2][R_BLOCK / 64];
+        float s = 0.f, c = 0.f;
+        for (uint32_t k = threadIdx.x; k < gridDim.x; k += R_BLOCK) { s += l1_part[k]; c += l1_part[gridDim.x + k]; }
+        s = wave_sum(s);
+        c = wave_sum(c);
+        if (lane == 0) { tot[0][threadIdx.x >> 6] = s; tot[1][threadIdx.x >> 6] = c; }
+        __syncthreads();
+        s = c = 0.f;
+#pragma unroll
+        for (int w = 0; w < R_BLOCK / 64; ++w) { s += tot[0][w]; c += tot[1][w]; }
+        n_valid = c;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { l1_acc_out[0] = s; l1_acc_out[1] = c; }
+    }
     uint32_t r, start, count;
     if (!wave_ray(packed, n_rays, r, start, count)) return;
-    const uint32_t lane = threadIdx.x & 63;
     float g0, g1, g2;
     if (l1_comp) {  // gradient of the masked smooth-L1 loss evaluated here (k_smooth_l1_valid_bwd without its launch)
         const bool valid = l1_opacity[r] > 0.f;
-        const float inv = l1_scale / fmaxf(3.f * l1_acc[1], 1.f);
+        const float inv = l1_scale / fmaxf(3.f * (l1_part ? n_valid : l1_acc[1]), 1.f);
         float g[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -686,7 +732,7 @@ extern "C" int nsr_composite_forward(const nsr_half *mlp_out, uint32_t stride, f
     NSR_REQUIRE(packed_info && background && comp_rgb && opacity && depth, "nsr_composite_forward: NULL pointer");
     hipLaunchKernelGGL(k_composite_forward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
                        t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, comp_rgb,
-                       opacity, depth, n_rays);
+                       opacity, depth, n_rays, nullptr, nullptr);
     NSR_CHECK_LAUNCH("nsr_composite_forward");
     return NSR_OK;
 }
@@ -736,7 +782,7 @@ extern "C" int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, 
     hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
                        t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb,
                        grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays, nullptr, nullptr, nullptr, nullptr, 0.f,
-                       nullptr);
+                       nullptr, nullptr, nullptr);
     NSR_CHECK_LAUNCH("nsr_composite_backward");
     return NSR_OK;
 }
@@ -754,7 +800,7 @@ extern "C" int nsr_composite_backward_ex(const nsr_half *mlp_out, uint32_t strid
     hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
                        t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb,
                        grad_opacity, grad_depth, grad_rgb, grad_logit, n_rays, nullptr, nullptr, nullptr, nullptr, 0.f,
-                       grad_weights);
+                       grad_weights, nullptr, nullptr);
     NSR_CHECK_LAUNCH("nsr_composite_backward_ex");
     return NSR_OK;
 }
@@ -772,8 +818,52 @@ extern "C" int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_
                     grad_logit, "nsr_composite_backward_smooth_l1: NULL pointer");
     hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
                        t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, nullptr, nullptr,
-                       nullptr, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, acc2, grad_scale, nullptr);
+                       nullptr, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, acc2, grad_scale, nullptr, nullptr,
+                       nullptr);
     NSR_CHECK_LAUNCH("nsr_composite_backward_smooth_l1");
+    return NSR_OK;
+}
+
+// The same pair with the loss reduction folded in: the forward leaves one (loss sum, valid rays) partial per block, every
+// block of the backward sums them -- the one-workgroup reduction kernel between the two (10 us + a launch gap on the
+// step's critical path) is gone.  partials: nsr_composite_l1_partials_floats(n_rays) floats, no initialisation needed.
+extern "C" uint64_t nsr_composite_l1_partials_floats(uint32_t n_rays)
+{
+    return 2ull * ((n_rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+}
+
+extern "C" int nsr_composite_forward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, float density_bias,
+                                               const float *t_starts, const float *t_ends, const nsr_half *rgb,
+                                               uint32_t rgb_stride, const int32_t *packed_info, const float *background,
+                                               float *weights, float *trans, float *comp_rgb, float *opacity, float *depth,
+                                               const float *gt_rgb, float *partials, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && comp_rgb && opacity && depth && gt_rgb && partials,
+                "nsr_composite_forward_smooth_l1: NULL pointer");
+    hipLaunchKernelGGL(k_composite_forward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
+                       t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, comp_rgb,
+                       opacity, depth, n_rays, gt_rgb, partials);
+    NSR_CHECK_LAUNCH("nsr_composite_forward_smooth_l1");
+    return NSR_OK;
+}
+
+extern "C" int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out, uint32_t stride, float density_bias,
+                                                         const float *t_starts, const float *t_ends, const nsr_half *rgb,
+                                                         uint32_t rgb_stride, const int32_t *packed_info,
+                                                         const float *background, const float *weights, const float *trans,
+                                                         const float *comp_rgb, const float *opacity, const float *gt_rgb,
+                                                         const float *partials, float *acc2, float grad_scale,
+                                                         float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && weights && trans && comp_rgb && opacity && gt_rgb && partials && acc2 &&
+                    grad_rgb && grad_logit, "nsr_composite_backward_smooth_l1_partials: NULL pointer");
+    hipLaunchKernelGGL(k_composite_backward, RAY_GRID(n_rays), (const __half *)mlp_out, stride, density_bias, t_starts,
+                       t_ends, (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, nullptr, nullptr,
+                       nullptr, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, nullptr, grad_scale, nullptr,
+                       partials, acc2);
+    NSR_CHECK_LAUNCH("nsr_composite_backward_smooth_l1_partials");
     return NSR_OK;
 }
 

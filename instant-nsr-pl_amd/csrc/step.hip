@@ -187,7 +187,8 @@ extern "C" int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, u
     out->comp_rgb = c.take(R * 3 * 4);
     out->opacity = c.take(R * 4);
     out->depth = c.take(R * 4);
-    out->loss_acc = c.take(2 * 4);
+    // (loss sum, valid rays) + the per-block partials the composite forward leaves for the composite backward
+    out->loss_acc = c.take((2 + nsr_composite_l1_partials_floats(n_rays)) * 4);
     out->trans = c.take(S * 4);
     out->x01 = c.take(S * 3 * 4);
     out->dirs = c.take(S * 3 * 4);
@@ -257,6 +258,10 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     }
     NSR_REQUIRE(F * 2 % 4 == 0, "nsr_nerf_main_pass: n_features_per_level must be even");
     const bool overlap_bins = compute_grads && S > 0 && g_helper.init();
+    // forward and backward in one call with the built-in loss: the (loss sum, valid rays) reduction is folded into the two
+    // compositing kernels instead of a one-workgroup kernel between them (NSR_L1_SEPARATE: A/B switch)
+    static const bool l1_separate = getenv("NSR_L1_SEPARATE") != nullptr;
+    const bool l1_folded = phases == 3 && compute_grads && gt_rgb && !up && S > 0 && n_rays > 0 && !l1_separate;
     if (phases & 1) {
     if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
         if (F == 2 && nh1 <= 2)  // the step's usual shape: one lane per kept sample, all its rows in one round trip
@@ -270,10 +275,28 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                 nullptr, (int64_t *)(ws + L.ray_indices),
                                                 (const nsr_half *)(pw + P.out1), 16, tex_in, n_rays, stream));
     }
-    // fork: bin the table-backward items on the helper stream as soon as the kept positions exist
+    // fork: the table-backward items are binned on the helper stream as soon as the kept positions exist.  The EVENT is
+    // recorded here; the helper's launches are queued BEHIND the colour MLP and the compositing forward -- the host needs
+    // ~7 us per launch, and with the four binning launches queued first the main stream sat idle for 30-45 us waiting for
+    // its next kernel (rocprofv3 timeline: copy_kept_rows ... 46 us ... mlp_forward)
+    if (overlap_bins)
+        NSR_REQUIRE(hipEventRecord(g_helper.fork, st) == hipSuccess, "nsr_nerf_main_pass: helper stream fork failed");
+    {
+        ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
+        NSR_TRY(nsr_mlp_forward_ex(tex_in, 0, 32, 0, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color,
+                                   n_kept_dev, stream));
+    }
+    if (l1_folded) {  // the loss reduction rides in the two compositing kernels (per-block partials behind acc)
+        NSR_TRY(nsr_composite_forward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights,
+                                                trans, comp_rgb, opacity, depth, gt_rgb, acc + 2, n_rays, stream));
+    } else {
+        NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
+                                      comp_rgb, opacity, depth, n_rays, stream));
+        if (gt_rgb)
+            NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
+    }
     if (overlap_bins) {
-        NSR_REQUIRE(hipEventRecord(g_helper.fork, st) == hipSuccess &&
-                        hipStreamWaitEvent(g_helper.stream, g_helper.fork, 0) == hipSuccess,
+        NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, g_helper.fork, 0) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream fork failed");
         {
             ProfScope p(NSR_PROF_GRID_BACKWARD_BIN, S, g_helper.stream);
@@ -283,15 +306,6 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         NSR_REQUIRE(hipEventRecord(g_helper.join, g_helper.stream) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream join failed");
     }
-    {
-        ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
-        NSR_TRY(nsr_mlp_forward_ex(tex_in, 0, 32, 0, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color,
-                                   n_kept_dev, stream));
-    }
-    NSR_TRY(nsr_composite_forward(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
-                                  comp_rgb, opacity, depth, n_rays, stream));
-    if (gt_rgb)
-        NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
     }  // phases & 1
     if (!(phases & 2)) return NSR_OK;
     NSR_REQUIRE(!compute_grads || up || gt_rgb, "nsr_nerf_main_pass: no loss (gt_rgb) and no upstream gradients");
@@ -327,6 +341,10 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     if (up)  // the caller's loss: arbitrary dL/d comp_rgb, dL/d opacity, dL/d depth (+ dL/d weights: distortion loss)
         NSR_TRY(nsr_composite_backward_ex(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                           up->comp_rgb, up->opacity, up->depth, up->weights, d_rgb, d_logit, n_rays, stream));
+    else if (l1_folded)
+        NSR_TRY(nsr_composite_backward_smooth_l1_partials(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept,
+                                                          background, weights, trans, comp_rgb, opacity, gt_rgb, acc + 2, acc,
+                                                          d->loss_scale, d_rgb, d_logit, n_rays, stream));
     else
         NSR_TRY(nsr_composite_backward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background,
                                                  weights, trans, comp_rgb, opacity, gt_rgb, acc, d->loss_scale, d_rgb,

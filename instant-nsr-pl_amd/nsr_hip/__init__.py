@@ -157,6 +157,9 @@ SIGNATURES = {
     "nsr_composite_forward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward_smooth_l1": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P],
+    "nsr_composite_l1_partials_floats": [_U],
+    "nsr_composite_forward_smooth_l1": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
+    "nsr_composite_backward_smooth_l1_partials": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_smooth_l1_valid": [_P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid_set": [_P, _P, _P, _P, _U, _P],
     "nsr_smooth_l1_valid_backward": [_P, _P, _P, _P, _F, _P, _U, _P],
@@ -248,6 +251,7 @@ SIGNATURES = {
                                 _P, _U, _P, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32,
+             "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,

@@ -417,3 +417,51 @@ def test_table_adam_inside_the_backward_trains_like_the_separate_optimizer():
     for x, y in zip(a["losses"], b["losses"]):
         assert abs(x - y) <= 2e-2 * abs(x) + 1e-6, (x, y)
     assert float(b["m1"][3072:].abs().max()) > 0  # the table did receive gradients
+
+
+@pytest.mark.parametrize("n_rays", [8192, 1147, 3, 4])
+def test_loss_reduction_folded_into_the_compositing_kernels(n_rays):
+    """nsr_composite_forward_smooth_l1 + nsr_composite_backward_smooth_l1_partials (per-block partials, summed by every block
+    of the backward) == nsr_composite_forward + nsr_smooth_l1_valid_set + nsr_composite_backward_smooth_l1: the same
+    outputs and gradients bit for bit (the valid-ray count is an exact integer in fp32), the loss sum to rounding"""
+    import ctypes
+    from nsr_hip import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(n_rays)
+    counts = torch.randint(0, 40, (n_rays,), generator=g)
+    counts[::7] = 0  # rays without samples: opacity 0, not valid
+    starts = torch.cumsum(counts, 0) - counts
+    n = int(counts.sum())
+    packed = torch.stack([starts, counts], 1).int().cuda()
+    out1 = (torch.randn(max(n, 1), 16, generator=g) * 2 - 1).half().cuda()
+    out2 = torch.rand(max(n, 1), 16, generator=g).half().cuda()
+    t0 = torch.rand(max(n, 1), generator=g).cuda()
+    t1 = t0 + 0.01
+    bg = torch.tensor([1.0, 0.5, 0.25]).cuda()
+    gt = torch.rand(n_rays, 3, generator=g).cuda()
+    s = stream_ptr()
+
+    def buffers():
+        return dict(w=torch.zeros(max(n, 1)).cuda(), tr=torch.zeros(max(n, 1)).cuda(), rgb=torch.zeros(n_rays, 3).cuda(),
+                    op=torch.zeros(n_rays).cuda(), dp=torch.zeros(n_rays).cuda(), acc=torch.full((2,), -1.0).cuda(),
+                    d_rgb=torch.zeros(max(n, 1), 3).cuda(), d_logit=torch.zeros(max(n, 1)).cuda())
+
+    a, b = buffers(), buffers()
+    check(lib.nsr_composite_forward(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(a["w"]),
+                                    ptr(a["tr"]), ptr(a["rgb"]), ptr(a["op"]), ptr(a["dp"]), n_rays, s), "fwd")
+    check(lib.nsr_smooth_l1_valid_set(ptr(a["rgb"]), ptr(a["op"]), ptr(gt), ptr(a["acc"]), n_rays, s), "l1")
+    check(lib.nsr_composite_backward_smooth_l1(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg),
+                                               ptr(a["w"]), ptr(a["tr"]), ptr(a["rgb"]), ptr(a["op"]), ptr(gt), ptr(a["acc"]),
+                                               1.0, ptr(a["d_rgb"]), ptr(a["d_logit"]), n_rays, s), "bwd")
+    part = torch.full((int(lib.nsr_composite_l1_partials_floats(n_rays)),), float("nan")).cuda()  # needs no initialisation
+    check(lib.nsr_composite_forward_smooth_l1(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg),
+                                              ptr(b["w"]), ptr(b["tr"]), ptr(b["rgb"]), ptr(b["op"]), ptr(b["dp"]), ptr(gt),
+                                              ptr(part), n_rays, s), "fwd folded")
+    check(lib.nsr_composite_backward_smooth_l1_partials(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed),
+                                                        ptr(bg), ptr(b["w"]), ptr(b["tr"]), ptr(b["rgb"]), ptr(b["op"]),
+                                                        ptr(gt), ptr(part), ptr(b["acc"]), 1.0, ptr(b["d_rgb"]),
+                                                        ptr(b["d_logit"]), n_rays, s), "bwd folded")
+    for k in ("w", "tr", "rgb", "op", "dp", "d_rgb", "d_logit"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["acc"][1]) == float(b["acc"][1]) == float((a["op"] > 0).sum())
+    assert abs(float(a["acc"][0]) - float(b["acc"][0])) <= 1e-5 * abs(float(a["acc"][0])) + 1e-7
+    assert float(a["d_rgb"].abs().max()) > 0
