@@ -404,10 +404,12 @@ k_pack_scratch(const float2 *__restrict__ scratch, uint32_t cap, const int32_t *
 
 // exclusive scan of per-ray counts by ONE workgroup (n_rays is a few thousand): PACK_BLOCK lanes, each owns a
 // contiguous chunk; wave scan + LDS across the waves.  Removes torch.cumsum + stack from the step.
-// 256 lanes, not 1024: a 16-wave workgroup has to wait for a CU with four free wave slots on EVERY SIMD, and next to the
-// fp32 MLP kernels (one wave per SIMD holding the whole register file) or the table backward it waited for hundreds of
-// microseconds on the marching stream (rocprofv3 showed 380-430 us "duration" for this 4,096-element scan).
-constexpr int PACK_BLOCK = 256, PACK_WAVES = PACK_BLOCK / 64;
+// Two block sizes.  1024 lanes are the fast ones (8,192 counts: 9 us; the lanes' serial chunk loops are latency chains, at
+// 256 lanes the same scan takes 15-25 us) -- but a 16-wave workgroup has to wait for a CU with four free wave slots on
+// EVERY SIMD, and next to the fp32 MLP kernels of the NeuS steps (one wave per SIMD holding the whole register file) it
+// waited for hundreds of microseconds on the marching stream (rocprofv3: 380-430 us "duration" for a 4,096-element scan).
+// So: up to 2,048 counts (a NeuS step at the reference's operating point) 256 lanes, more (the NeRF step's 8,192 slots) 1024.
+template <int PACK_WAVES>
 __device__ __forceinline__ int32_t prefix_total(const int32_t *wave_tot)
 {
     int32_t t = 0;
@@ -417,10 +419,15 @@ __device__ __forceinline__ int32_t prefix_total(const int32_t *wave_tot)
 }
 
 constexpr uint32_t PACK_LDS = 16384;  // ray counts up to this are staged through LDS (coalesced loads and stores)
+// every lane walks its own contiguous chunk of the staged counts: a chunk of 32 would put all 64 lanes on ONE LDS bank (the
+// 256-thread version of this kernel first took 29 us instead of 9) -- one padding word per 32 keeps the lanes on different banks
+#define PACK_IDX(k) ((k) + ((k) >> 5))
+template <int PACK_BLOCK>
 __global__ void __launch_bounds__(PACK_BLOCK)
 k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ packed, int32_t *__restrict__ total,
                    uint32_t n, uint32_t capacity, int32_t *__restrict__ stats, const int32_t *__restrict__ n_active)
 {
+    constexpr int PACK_WAVES = PACK_BLOCK / 64;
     __shared__ int32_t wave_tot[PACK_WAVES];
     extern __shared__ int32_t buf[];  // n words when staged (sized by the launch: a fixed 64 KiB would keep this one-workgroup
                                       // kernel waiting for a CU with that much free LDS next to the step's big kernels)
@@ -430,11 +437,25 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
     const uint32_t live = n_active ? (uint32_t)max(min(*n_active, (int32_t)n), 0) : n;
     const bool staged = n <= PACK_LDS;
     if (staged) {
-        for (uint32_t k = tid; k < n; k += PACK_BLOCK) buf[k] = k < live ? counts[k] : 0;
+        // eight loads in flight per lane: a plain load / LDS-store loop waits for every load (~1 us each) -- at 8,192 rays and
+        // 256 lanes that alone was 25 us of this kernel
+        for (uint32_t k0 = tid; k0 < n; k0 += PACK_BLOCK * 8) {
+            int32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t k = k0 + u * PACK_BLOCK;
+                v[u] = (k < n && k < live) ? counts[k] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t k = k0 + u * PACK_BLOCK;
+                if (k < n) buf[PACK_IDX(k)] = v[u];
+            }
+        }
         __syncthreads();
     }
     int32_t s = 0;
-    for (uint32_t k = lo; k < hi; ++k) s += staged ? buf[k] : (k < live ? counts[k] : 0);
+    for (uint32_t k = lo; k < hi; ++k) s += staged ? buf[PACK_IDX(k)] : (k < live ? counts[k] : 0);
     // inclusive scan of s across the block
     int32_t v = s;
     const int lane = tid & 63, w = tid >> 6;
@@ -449,14 +470,14 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
     for (int k = 0; k < w; ++k) prefix += wave_tot[k];
     int32_t run = prefix + v - s;  // exclusive prefix of this lane's chunk
     for (uint32_t k = lo; k < hi; ++k) {
-        int32_t c = staged ? buf[k] : (k < live ? counts[k] : 0), start = run;
+        int32_t c = staged ? buf[PACK_IDX(k)] : (k < live ? counts[k] : 0), start = run;
         run += c;
         if (capacity) {  // fixed-size sample buffers: rays past the capacity are truncated (and reported)
             start = min(start, (int32_t)capacity);
             c = min(c, (int32_t)capacity - start);
         }
         if (staged) {  // only this lane touches buf[lo, hi): the start goes to its own slot, the count is rebuilt below
-            buf[k] = start;
+            buf[PACK_IDX(k)] = start;
         } else {
             packed[2ull * k] = start;
             packed[2ull * k + 1] = c;
@@ -464,10 +485,10 @@ k_pack_from_counts(const int32_t *__restrict__ counts, int32_t *__restrict__ pac
     }
     if (staged) {
         __syncthreads();
-        const int32_t end_all = capacity ? min(prefix_total(wave_tot), (int32_t)capacity) : prefix_total(wave_tot);
+        const int32_t end_all = capacity ? min(prefix_total<PACK_WAVES>(wave_tot), (int32_t)capacity) : prefix_total<PACK_WAVES>(wave_tot);
         const bool vec = (reinterpret_cast<uintptr_t>(packed) & 7u) == 0;  // (a caller may hand in a 4-byte aligned view)
         for (uint32_t k = tid; k < n; k += PACK_BLOCK) {  // count = next start - start (truncation included)
-            const int32_t a = buf[k], b = k + 1 < n ? buf[k + 1] : end_all;
+            const int32_t a = buf[PACK_IDX(k)], b = k + 1 < n ? buf[PACK_IDX(k + 1)] : end_all;
             if (vec) reinterpret_cast<int2 *>(packed)[k] = make_int2(a, b - a);
             else { packed[2ull * k] = a; packed[2ull * k + 1] = b - a; }
         }
@@ -774,9 +795,13 @@ extern "C" int nsr_pack_from_counts_capped(const int32_t *num_steps, int32_t *pa
     NSR_REQUIRE(n_rays == 0 || (num_steps && packed_info), "nsr_pack_from_counts: NULL pointer");
     NSR_REQUIRE(capacity < 0x7fffffffu, "nsr_pack_from_counts: capacity must fit int32");
     NSR_REQUIRE(!stats || ((uintptr_t)stats & 7u) == 0, "nsr_pack_from_counts: stats must be 8-byte aligned");
-    const size_t lds = n_rays <= PACK_LDS ? (size_t)n_rays * sizeof(int32_t) : 0;
-    hipLaunchKernelGGL(k_pack_from_counts, dim3(1), dim3(PACK_BLOCK), lds, (hipStream_t)stream, num_steps, packed_info, total,
-                       n_rays, capacity, stats, n_active);
+    const size_t lds = n_rays <= PACK_LDS ? (size_t)(n_rays + (n_rays >> 5) + 1) * sizeof(int32_t) : 0;
+    if (n_rays > 2048)
+        hipLaunchKernelGGL(k_pack_from_counts<1024>, dim3(1), dim3(1024), lds, (hipStream_t)stream, num_steps, packed_info,
+                           total, n_rays, capacity, stats, n_active);
+    else
+        hipLaunchKernelGGL(k_pack_from_counts<256>, dim3(1), dim3(256), lds, (hipStream_t)stream, num_steps, packed_info,
+                           total, n_rays, capacity, stats, n_active);
     NSR_CHECK_LAUNCH("nsr_pack_from_counts");
     return NSR_OK;
 }
