@@ -461,9 +461,9 @@ k_mlp_wgrad(const __half *__restrict__ GT, const void *__restrict__ A, uint32_t 
 }
 
 // grad[k] += inv_scale * sum_b partials[b][k].  2-D grid: x = 256-parameter column blocks, y = row segments; each
-// block sums its rows with 4 independent accumulators and finishes with one fp32 atomic per parameter
-// (n_params * RED_SEGS atomics in total: a few tens of thousands).
-constexpr int RED_SEGS = 8;
+// block sums its rows with 8 independent accumulators and finishes with one fp32 atomic per parameter
+// (n_params * RED_SEGS atomics in total: ~1e5, to distinct addresses).
+constexpr int RED_SEGS = 16;
 __global__ void __launch_bounds__(256)
 k_reduce_partials(const float *__restrict__ partials, float *__restrict__ grad, uint32_t n_params, uint32_t n_blocks,
                   float inv_scale)
@@ -472,16 +472,16 @@ k_reduce_partials(const float *__restrict__ partials, float *__restrict__ grad, 
     if (k >= n_params) return;
     const uint32_t per = (n_blocks + RED_SEGS - 1) / RED_SEGS;
     const uint32_t b0 = blockIdx.y * per, b1 = min(n_blocks, b0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // eight rows in flight per lane: the rows are n_params floats apart, every load is its own ~1 us round trip, and with
+    // four in flight over 49 rows this 7 MB reduction took 21-34 us
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t b = b0;
-    for (; b + 4 <= b1; b += 4) {
-        s0 += partials[(uint64_t)(b + 0) * n_params + k];
-        s1 += partials[(uint64_t)(b + 1) * n_params + k];
-        s2 += partials[(uint64_t)(b + 2) * n_params + k];
-        s3 += partials[(uint64_t)(b + 3) * n_params + k];
+    for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += partials[(uint64_t)(b + u) * n_params + k];
     }
-    for (; b < b1; ++b) s0 += partials[(uint64_t)b * n_params + k];
-    const float s = (s0 + s1) + (s2 + s3);
+    for (; b < b1; ++b) acc[0] += partials[(uint64_t)b * n_params + k];
+    const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     if (b1 > b0) unsafeAtomicAdd(grad + k, s * inv_scale);
 }
 
