@@ -102,6 +102,12 @@ int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_la
  * sorts the (sample, corner pair) items by owning slice into `workspace`), _accumulate needs dy and that workspace. */
 int nsr_hashgrid_backward_params_owner_bin(const float *x, float *workspace, uint32_t n, uint32_t level_mask_count,
                                            const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
+/* ... when the items will be consumed by nsr_hashgrid_backward_params_owner_with_second_order* with binned != 0: the slice
+ * configuration of a launch depends on the point count AND on the kind of pass (second-order items cost about twice a plain
+ * one's), and binning and accumulation have to agree on it. */
+int nsr_hashgrid_backward_params_owner_bin_second_order(const float *x, float *workspace, uint32_t n,
+                                                        uint32_t level_mask_count, const NsrGridDesc *desc,
+                                                        const int32_t *n_dev, void *stream);
 int nsr_hashgrid_backward_params_owner_accumulate(const float *x, const void *dy, int dy_layout, uint32_t dy_stride,
                                                   float *grad_table, float *workspace, uint32_t n,
                                                   uint32_t level_mask_count, float grad_scale, int accumulate,

@@ -790,7 +790,16 @@ namespace own_large {
 #define NSR_OWN_LARGE_FROM 400000u
 #endif
 static uint32_t g_own_large_from = NSR_OWN_LARGE_FROM;
-static bool own_use_large(uint32_t n) { return n > g_own_large_from; }
+// g_own_second_order: the launch (binning or accumulation) belongs to a first + second-order pass -- its items cost about
+// twice a plain one's (two more gathers, the directional-derivative weights), so the large configuration pays from half
+// the point count (measured at the NeuS operating point, 2.6e5 samples: C3 step 1.457 -> 1.415 ms)
+static thread_local bool g_own_second_order = false;
+static bool own_use_large(uint32_t n) { return (g_own_second_order ? 2ull * n : (uint64_t)n) > g_own_large_from; }
+struct SecondOrderScope {
+    bool old;
+    explicit SecondOrderScope(bool on) : old(g_own_second_order) { g_own_second_order = on; }
+    ~SecondOrderScope() { g_own_second_order = old; }
+};
 
 // launches of more than `n_points` points use the large-slice configuration (0: always, UINT32_MAX: never); returns the
 // previous threshold.  The binning and the accumulation of one gradient must see the same setting.
@@ -829,6 +838,16 @@ extern "C" int nsr_hashgrid_backward_params_owner_bin(const float *x, float *wor
                                                       uint32_t level_mask_count, const NsrGridDesc *desc,
                                                       const int32_t *n_dev, void *stream)
 {
+    return owner_backward(x, nullptr, 2, 0, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, n_dev, 1, stream);
+}
+
+// ... for items that a ..._with_second_order accumulation (binned != 0) will consume: the slice configuration of a launch is
+// picked from the point count AND the kind of pass, and binning and accumulation must agree on it
+extern "C" int nsr_hashgrid_backward_params_owner_bin_second_order(const float *x, float *workspace, uint32_t n,
+                                                                   uint32_t level_mask_count, const NsrGridDesc *desc,
+                                                                   const int32_t *n_dev, void *stream)
+{
+    SecondOrderScope scope(true);
     return owner_backward(x, nullptr, 2, 0, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, n_dev, 1, stream);
 }
 
@@ -933,6 +952,7 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order(const float 
                                                                     uint32_t level_mask_count, int accumulate,
                                                                     int binned, const NsrGridDesc *desc, void *stream)
 {
+    SecondOrderScope scope(true);
     NSR_REQUIRE(n == 0 || (dy_first_lm && dy && g), "nsr_hashgrid_backward_params_owner_with_second_order: NULL pointer");
     // binned != 0: the items of these positions are already in `workspace` (nsr_hashgrid_backward_params_owner_bin, e.g.
     // queued on a helper stream right after the positions were formed)
@@ -947,6 +967,7 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order_adam(const f
                                                                          const NsrGridDesc *desc, const NsrTableAdam *adam,
                                                                          void *stream)
 {
+    SecondOrderScope scope(true);
     NSR_REQUIRE(adam && (n == 0 || (dy_first_lm && dy && g)),
                 "nsr_hashgrid_backward_params_owner_with_second_order_adam: NULL pointer");
     return owner_backward(x, dy, 1, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
@@ -960,6 +981,7 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order_bf16(const f
                                                                          uint32_t level_mask_count, int binned,
                                                                          const NsrGridDesc *desc, void *stream)
 {
+    SecondOrderScope scope(true);
     NSR_REQUIRE(grad_bf16 && (n == 0 || (dy_first_lm && dy && g)),
                 "nsr_hashgrid_backward_params_owner_with_second_order_bf16: NULL pointer");
     return owner_backward(x, dy, 1, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,

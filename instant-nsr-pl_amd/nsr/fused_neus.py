@@ -782,8 +782,9 @@ class FusedNeuSStep:
                               "nsr_hashgrid_backward_params_owner_bin_taps")
                         tws.record_stream(self._helper)
                     else:
-                        check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x7), ptr(gws), T * N, mc, _byref(desc), None,
-                                                                         stream_ptr()),
+                        bin_fn = lib.nsr_hashgrid_backward_params_owner_bin if self.fd else \
+                            lib.nsr_hashgrid_backward_params_owner_bin_second_order  # (same slice configuration as the pass)
+                        check(bin_fn(ptr(x7), ptr(gws), T * N, mc, _byref(desc), None, stream_ptr()),
                               "nsr_hashgrid_backward_params_owner_bin")
                     bin_event = torch.cuda.Event()
                     bin_event.record(self._helper)

@@ -122,6 +122,7 @@ SIGNATURES = {
     "nsr_hashgrid_backward_params_workspace_floats": [_GD, _U],
     "nsr_hashgrid_backward_params_owner": [_P, _P, _I, _U, _P, _P, _U, _U, _F, _I, _GD, _P, _P],
     "nsr_hashgrid_backward_params_owner_bin": [_P, _P, _U, _U, _GD, _P, _P],
+    "nsr_hashgrid_backward_params_owner_bin_second_order": [_P, _P, _U, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_owner_accumulate": [_P, _P, _I, _U, _P, _P, _U, _U, _F, _I, _GD, _P, _P],
     "nsr_hashgrid_backward_input": [_P, _P, _P, _I, _U, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_backward_input": [_P, _P, _P, _I, _U, _P, _P, _U, _P, _P, _U, _U, _GD, _P],

@@ -214,10 +214,21 @@ def test_owner_backward_with_second_order_equals_two_passes():
     assert float((a - b).norm() / a.norm()) < 1e-6
     # ... and with the binning done ahead of time (what the fused step queues on a helper stream)
     c = torch.empty_like(a)
-    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, ctypes.byref(desc), None, s), "bin")
-    check(lib.nsr_hashgrid_backward_params_owner_with_second_order(ptr(x), ptr(dy_first), off, 36, ptr(gx), ptr(c), ptr(ws), n,
-                                                                   16, 0, 1, ctypes.byref(desc), s), "merged, pre-binned")
-    assert float((c - b).norm() / b.norm()) < 1e-6
+    # (binning and accumulation pick the slice configuration from the point count AND the kind of pass: with the threshold
+    # between n and 2 n a plain launch takes the small configuration, a second-order one the large -- the binning entry for
+    # second-order passes has to follow)
+    for thr in (0xffffffff, int(1.5 * n), 0):
+        old = lib.nsr_hashgrid_owner_large_from(thr)
+        try:
+            c = torch.empty_like(a)
+            check(lib.nsr_hashgrid_backward_params_owner_bin_second_order(ptr(x), ptr(ws), n, 16, ctypes.byref(desc), None, s),
+                  "bin")
+            check(lib.nsr_hashgrid_backward_params_owner_with_second_order(ptr(x), ptr(dy_first), off, 36, ptr(gx), ptr(c),
+                                                                           ptr(ws), n, 16, 0, 1, ctypes.byref(desc), s),
+                  "merged, pre-binned")
+        finally:
+            lib.nsr_hashgrid_owner_large_from(old)
+        assert float((c - b).norm() / b.norm()) < 1e-6, thr
     assert float(a.abs().max()) > 0
 
 

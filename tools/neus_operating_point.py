@@ -2,7 +2,7 @@
 NeuSTrainer: ms / step, and how much of it the HOST spends queueing the step (time inside train_step, which holds one
 device->host read of the sample count) -- tells a GPU-bound step from a host-bound one.  One JSON line.
 
-    python tools/neus_operating_point.py neus-blender|neus-dtu|neuralangelo [steps]
+    python tools/neus_operating_point.py neus-blender|neus-dtu|neuralangelo [steps [owner_large_from]]
 """
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,9 @@ from nsr.scene import SyntheticBlender
 
 name = sys.argv[1] if len(sys.argv) > 1 else "neus-blender"
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+if len(sys.argv) > 3:  # developer switch: point count from which the table backward takes its 2^13 x 1024 configuration
+    from nsr_hip import lib
+    lib.nsr_hashgrid_owner_large_from(int(sys.argv[3]))
 lam = {"neus-blender": {"lambda_rgb_mse": 10.0, "lambda_rgb_l1": 0.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1},
        "neus-dtu": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.0, "lambda_eikonal": 0.1},
        "neuralangelo": {"lambda_rgb_mse": 0.0, "lambda_rgb_l1": 1.0, "lambda_mask": 0.1, "lambda_eikonal": 0.1}}[name]
