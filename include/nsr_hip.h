@@ -166,6 +166,11 @@ int nsr_hashgrid_forward_jac(const float *x, const nsr_half *table, nsr_half *y,
 int nsr_hashgrid_jac_apply(const float *jac, uint32_t n, const NsrGridDesc *desc, const float *dy, uint32_t dy_stride,
                            float *dx, const float *g, float *d_dy, uint32_t d_dy_stride, const int32_t *n_dev,
                            void *stream);
+/* ... optionally leaving a level-major copy [L][n][F] of dy behind (with dx): the layout the table backward's second-order
+ * term reads (nsr_hashgrid_backward_params_owner_with_second_order*: dy_stride == 0 means "dy is level-major") */
+int nsr_hashgrid_jac_apply_ex(const float *jac, uint32_t n, const NsrGridDesc *desc, const float *dy, uint32_t dy_stride,
+                              float *dx, const float *g, float *d_dy, uint32_t d_dy_stride, float *dy_level_major_out,
+                              const int32_t *n_dev, void *stream);
 
 /* Encode a sample and its six finite-difference taps in one launch (models/geometry.py:181-197): x7 [7][n][3] as written by
  * nsr_neus_points (row 0 the sample, rows 1 + 2k / 2 + 2k the +-eps taps along axis k: only that axis may differ from the

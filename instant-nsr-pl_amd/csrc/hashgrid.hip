@@ -668,7 +668,8 @@ constexpr int JAC_BLOCK = 256;
 __global__ void __launch_bounds__(JAC_BLOCK)
 k_jac_apply(const float *__restrict__ jac, uint32_t n, uint32_t L, uint32_t F, const float *__restrict__ dy,
             uint32_t dy_stride, float *__restrict__ dx, const float *__restrict__ g, float *__restrict__ d_dy,
-            uint32_t d_dy_stride, const int32_t *__restrict__ n_dev)
+            uint32_t d_dy_stride, const int32_t *__restrict__ n_dev,
+            float *__restrict__ dy_lm_out /* with dx: also leave dy level-major [L][n][F] (the tile is in LDS anyway) */)
 {
     extern __shared__ float tile[];  // [JAC_BLOCK][C + 1]
     const uint32_t C = L * F, ld = C + 1;
@@ -680,6 +681,13 @@ k_jac_apply(const float *__restrict__ jac, uint32_t n, uint32_t L, uint32_t F, c
         for (uint32_t k = threadIdx.x; k < rows * C; k += JAC_BLOCK)
             tile[(k / C) * ld + k % C] = dy[(uint64_t)(i0 + k / C) * dy_stride + k % C];
         __syncthreads();
+        if (dy_lm_out) {  // what the table backward's second-order term reads: saves it a transposing pass over dy
+            const uint32_t per = rows * F;
+            for (uint32_t k = threadIdx.x; k < L * per; k += JAC_BLOCK) {
+                const uint32_t l = k / per, rem = k % per, r = rem / F, f = rem % F;
+                dy_lm_out[((uint64_t)l * n + i0 + r) * F + f] = tile[r * ld + l * F + f];
+            }
+        }
     }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     const bool live = i < n_live;
@@ -711,12 +719,21 @@ extern "C" int nsr_hashgrid_jac_apply(const float *jac, uint32_t n, const NsrGri
                                       uint32_t dy_stride, float *dx, const float *g, float *d_dy, uint32_t d_dy_stride,
                                       const int32_t *n_dev, void *stream)
 {
+    return nsr_hashgrid_jac_apply_ex(jac, n, desc, dy, dy_stride, dx, g, d_dy, d_dy_stride, nullptr, n_dev, stream);
+}
+
+extern "C" int nsr_hashgrid_jac_apply_ex(const float *jac, uint32_t n, const NsrGridDesc *desc, const float *dy,
+                                         uint32_t dy_stride, float *dx, const float *g, float *d_dy, uint32_t d_dy_stride,
+                                         float *dy_level_major_out, const int32_t *n_dev, void *stream)
+{
     if (int rc = check_desc(desc, "nsr_hashgrid_jac_apply")) return rc;
+    NSR_REQUIRE(!dy_level_major_out || (dx && dy), "nsr_hashgrid_jac_apply: the level-major copy is of dy (needs dx, dy)");
     if (n == 0) return NSR_OK;
     NSR_REQUIRE(jac && ((dx && dy) || (d_dy && g)), "nsr_hashgrid_jac_apply: NULL pointer");
     const size_t lds = (size_t)JAC_BLOCK * (desc->n_levels * desc->n_features + 1) * sizeof(float);
     hipLaunchKernelGGL(k_jac_apply, dim3(nsr_div_up(n, JAC_BLOCK)), dim3(JAC_BLOCK), lds, (hipStream_t)stream, jac, n, desc->n_levels,
-                       desc->n_features, dx ? dy : nullptr, dy_stride, dx, d_dy ? g : nullptr, d_dy, d_dy_stride, n_dev);
+                       desc->n_features, dx ? dy : nullptr, dy_stride, dx, d_dy ? g : nullptr, d_dy, d_dy_stride, n_dev,
+                       dy_level_major_out);
     NSR_CHECK_LAUNCH("nsr_hashgrid_jac_apply");
     return NSR_OK;
 }
@@ -956,7 +973,7 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order(const float 
     NSR_REQUIRE(n == 0 || (dy_first_lm && dy && g), "nsr_hashgrid_backward_params_owner_with_second_order: NULL pointer");
     // binned != 0: the items of these positions are already in `workspace` (nsr_hashgrid_backward_params_owner_bin, e.g.
     // queued on a helper stream right after the positions were formed)
-    return owner_backward(x, dy, 1, dy_stride, grad_table, workspace, n, level_mask_count, 1.f, accumulate, desc, nullptr,
+    return owner_backward(x, dy, dy_stride ? 1 : 2, dy_stride, grad_table, workspace, n, level_mask_count, 1.f, accumulate, desc, nullptr,
                           binned ? 2 : 3, stream, g, dy_first_lm);
 }
 
@@ -970,7 +987,7 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order_adam(const f
     SecondOrderScope scope(true);
     NSR_REQUIRE(adam && (n == 0 || (dy_first_lm && dy && g)),
                 "nsr_hashgrid_backward_params_owner_with_second_order_adam: NULL pointer");
-    return owner_backward(x, dy, 1, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
+    return owner_backward(x, dy, dy_stride ? 1 : 2, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
                           stream, g, dy_first_lm, adam);
 }
 
@@ -984,7 +1001,7 @@ extern "C" int nsr_hashgrid_backward_params_owner_with_second_order_bf16(const f
     SecondOrderScope scope(true);
     NSR_REQUIRE(grad_bf16 && (n == 0 || (dy_first_lm && dy && g)),
                 "nsr_hashgrid_backward_params_owner_with_second_order_bf16: NULL pointer");
-    return owner_backward(x, dy, 1, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
+    return owner_backward(x, dy, dy_stride ? 1 : 2, dy_stride, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, nullptr, binned ? 2 : 3,
                           stream, g, dy_first_lm, nullptr, 0u, nullptr, grad_bf16);
 }
 

@@ -813,8 +813,11 @@ class FusedNeuSStep:
             dx01 = None
             if not self.fd:  # J^T (d sdf / d encoding): models/geometry.py:176-180 through the encoder
                 dx01 = torch.empty((N, 3), dtype=F32, device=dev)
-                check(lib.nsr_hashgrid_jac_apply(ptr(jac), N, _byref(desc), _off(g_in, 3), P, ptr(dx01), None, None, 0, None,
-                                                 s), "nsr_hashgrid_jac_apply(J^T dy)")
+                # (with gradients: the kernel also leaves d sdf / d encoding level-major -- its tile is in LDS anyway -- which
+                # is how the table backward's second-order term reads it: no transposing pass there)
+                g_lm = torch.empty(self.n_enc * N, dtype=F32, device=dev) if compute_grads else None
+                check(lib.nsr_hashgrid_jac_apply_ex(ptr(jac), N, _byref(desc), _off(g_in, 3), P, ptr(dx01), None, None, 0,
+                                                    ptr(g_lm), None, s), "nsr_hashgrid_jac_apply(J^T dy)")
             acc = torch.zeros(16, dtype=F32, device=dev)
             inv_s = self._inv_s()
             anneal = float(getattr(m, "cos_anneal_ratio", 1.0))
@@ -968,7 +971,7 @@ class FusedNeuSStep:
                         "nsr_hashgrid_backward_params_owner_accumulate_range")
                 else:
                     check(lib.nsr_hashgrid_backward_params_owner_with_second_order_bf16(
-                        ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(bf), ptr(gws), N, mc, 1, _byref(desc), s),
+                        ptr(x7), ptr(d_enc), ptr(g_lm), 0, ptr(gx), ptr(bf), ptr(gws), N, mc, 1, _byref(desc), s),
                         "nsr_hashgrid_backward_params_owner_with_second_order_bf16")
                 self.bf16_written.add("fg")
             elif self.fd and tws is not None:
@@ -991,11 +994,11 @@ class FusedNeuSStep:
                           "nsr_hashgrid_backward_params_owner_accumulate")
             elif ad is not None:
                 check(lib.nsr_hashgrid_backward_params_owner_with_second_order_adam(
-                    ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(gws), N, mc, 1, _byref(desc), _byref(ad), s),
+                    ptr(x7), ptr(d_enc), ptr(g_lm), 0, ptr(gx), ptr(gws), N, mc, 1, _byref(desc), _byref(ad), s),
                     "nsr_hashgrid_backward_params_owner_with_second_order_adam")
             else:  # first- and second-order table gradients share their items: one accumulation pass
                 check(lib.nsr_hashgrid_backward_params_owner_with_second_order(
-                    ptr(x7), ptr(d_enc), _off(g_in, 3), P, ptr(gx), ptr(g_table), ptr(gws), N, mc, 0, 1, _byref(desc), s),
+                    ptr(x7), ptr(d_enc), ptr(g_lm), 0, ptr(gx), ptr(g_table), ptr(gws), N, mc, 0, 1, _byref(desc), s),
                     "nsr_hashgrid_backward_params_owner_with_second_order")
             if ad is not None:
                 self.adam_applied.add("fg")

@@ -130,6 +130,7 @@ SIGNATURES = {
     "nsr_hashgrid_forward_variant": [_I, _I],
     "nsr_hashgrid_forward_jac": [_P, _P, _P, _U, _U, _I, _U, _GD, _P, _P, _P],
     "nsr_hashgrid_jac_apply": [_P, _U, _GD, _P, _U, _P, _P, _P, _U, _P, _P],
+    "nsr_hashgrid_jac_apply_ex": [_P, _U, _GD, _P, _U, _P, _P, _P, _U, _P, _P, _P],
     "nsr_hashgrid_forward_taps": [_P, _P, _P, _U, _U, _I, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_owner_with_second_order": [_P, _P, _P, _U, _P, _P, _P, _U, _U, _I, _I, _GD, _P],
     "nsr_hashgrid_backward_params_owner_with_second_order_adam": [_P, _P, _P, _U, _P, _P, _U, _U, _I, _GD, _P, _P],

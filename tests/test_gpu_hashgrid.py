@@ -230,6 +230,12 @@ def test_owner_backward_with_second_order_equals_two_passes():
             lib.nsr_hashgrid_owner_large_from(old)
         assert float((c - b).norm() / b.norm()) < 1e-6, thr
     assert float(a.abs().max()) > 0
+    # the second-order dy handed over level-major (dy_stride == 0): what nsr_hashgrid_jac_apply_ex leaves behind
+    dy_lm = dy_second[:, 3:35].reshape(n, 16, 2).permute(1, 0, 2).contiguous()
+    e = torch.empty_like(a)
+    check(lib.nsr_hashgrid_backward_params_owner_with_second_order(ptr(x), ptr(dy_first), ptr(dy_lm), 0, ptr(gx), ptr(e), ptr(ws),
+                                                                   n, 16, 0, 0, ctypes.byref(desc), s), "merged, level-major dy")
+    assert float((e - b).norm() / b.norm()) < 1e-6  # (the small dense levels sum their slabs in fp32, order not fixed)
 
 
 @pytest.mark.parametrize("mask_count", [16, 9])
@@ -261,6 +267,12 @@ def test_cached_jacobian_reproduces_input_gradient_and_its_double_backward(mask_
     d_dy = torch.zeros(n, 36, device="cuda")
     check(lib.nsr_hashgrid_jac_apply(ptr(jac), n, ctypes.byref(desc), off, 36, ptr(dx), ptr(gx),
                                      ctypes.c_void_p(d_dy.data_ptr() + 12), 36, None, s), "jac_apply")
+    lm_copy = torch.empty(16, n, 2, device="cuda")  # ..._ex: the same products + a level-major copy of dy
+    dx2 = torch.empty_like(dx)
+    check(lib.nsr_hashgrid_jac_apply_ex(ptr(jac), n, ctypes.byref(desc), off, 36, ptr(dx2), None, None, 0, ptr(lm_copy), None, s),
+          "jac_apply_ex")
+    assert torch.equal(dx2, dx)
+    assert torch.equal(lm_copy.permute(1, 0, 2).reshape(n, 32), dy[:, 3:35])
     want_dx = torch.empty(n, 3, device="cuda")
     check(lib.nsr_hashgrid_backward_input(ptr(x), ptr(table), off, 1, 36, ptr(want_dx), n, mask_count, ctypes.byref(desc), s),
           "bwd_input")
