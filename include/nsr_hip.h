@@ -99,7 +99,7 @@ int nsr_hashgrid_backward_params_owner(const float *x, const void *dy, int dy_la
                                        void *stream);
 
 /* The same in two phases, so that a caller can overlap the first with other work: _bin needs only the positions (it
- * sorts the (sample, corner pair) items by owning slice into `workspace`), _accumulate needs dy and that workspace. */
+ * sorts the (sample, corner pair) items by owning slice into `workspace`, one launch), _accumulate needs dy and that workspace. */
 int nsr_hashgrid_backward_params_owner_bin(const float *x, float *workspace, uint32_t n, uint32_t level_mask_count,
                                            const NsrGridDesc *desc, const int32_t *n_dev, void *stream);
 /* ... when the items will be consumed by nsr_hashgrid_backward_params_owner_with_second_order* with binned != 0: the slice
@@ -118,6 +118,19 @@ int nsr_hashgrid_backward_params_owner_accumulate(const float *x, const void *dy
  * more than `n_points` points -> the large one (default 400,000; 0: always, UINT32_MAX: never).  Returns the previous
  * threshold.  Same results either way (bit-identical on the levels that are not split into chunk slabs). */
 uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points);
+
+/* Run-time knobs of the owner-computes decomposition (A/B switches; the gradient is the same bits under every setting).
+ * key 0: placement of the (level, slice, chunk) work units on the eight XCDs -- 1 (default): contiguous, cost-balanced ranges
+ * of the unit list per XCD, so that an XCD's L2 serves the x / dy gathers of one or two levels; 0: dealt round-robin.
+ * key 1 / 2: weight of a unit's write-out share / item share in that balance (default 1 / 1).
+ * key 3: hashed levels up to this resolution merge runs of same-entry items in registers (default 320; dense levels always).
+ * key 4: ... while a thread walks at most this many items (default 12).  Returns the previous value. */
+float nsr_hashgrid_owner_tune(int key, float value);
+/* The unit -> XCD map a launch over the levels [level_begin, level_end) would use (host arithmetic only, no GPU):
+ * out[0] = blocks, out[1..9] = first unit of XCD 0..8, out[10..10+L] = first unit of level 0..L, then n_slices[L],
+ * n_chunks[L].  large: the 2^13 x 1024 configuration instead of 2^11 x 256. */
+int nsr_hashgrid_owner_debug_map(const NsrGridDesc *desc, int large, uint32_t level_begin, uint32_t level_end,
+                                 int with_adam, uint32_t *out);
 
 /* _accumulate over the run of levels [level_begin, level_end) only (items binned beforehand, dy level-major fp32
  * [L][n][F]), the gradient written either as fp32 into grad_table or as bf16 (round to nearest even) into grad_bf16 --

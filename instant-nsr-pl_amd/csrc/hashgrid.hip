@@ -788,6 +788,18 @@ extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int 
 // points of a finite-difference step) the large slices win again: C3 5.62 vs 6.04 ms, C5 15.3 vs 15.9 ms per step -- fewer,
 // longer item lists per workgroup amortise the per-workgroup LDS clear / write-out.  So both are compiled and a launch
 // picks by its point count (the binning and the accumulation of one gradient see the same count).
+//
+// Run-time knobs of the decomposition (nsr_hashgrid_owner_tune; A/B switches of tools/table_backward_variants.py -- the
+// gradient is the same bits under every setting):
+struct OwnTune {
+    int listed;            // 1: contiguous cost-balanced unit ranges per XCD (default), 0: units dealt round-robin (round 3)
+    float cost_adam;       // weight of a unit's write-out share in the balance
+    float cost_items;      // weight of a unit's item share
+    uint32_t rl_max_res;   // hashed levels up to this resolution take the run-merging walk (dense levels always do)
+    uint32_t rl_max_q;     // ... while a thread has at most this many items
+};
+static OwnTune g_own_tune = {1, 1.0f, 1.0f, 320u, 12u};
+
 namespace own_small {
 #define NSR_OWN_BLOCK 256
 #define NSR_OWN_LOG2 11
@@ -825,6 +837,34 @@ extern "C" uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points)
     const uint32_t old = g_own_large_from;
     g_own_large_from = n_points;
     return old;
+}
+
+// key 0: placement (0 dealt / 1 listed), 1: cost_adam, 2: cost_items, 3: rl_max_res, 4: rl_max_q; returns the previous value
+extern "C" float nsr_hashgrid_owner_tune(int key, float value)
+{
+    float old = 0.f;
+    switch (key) {
+    case 0: old = (float)g_own_tune.listed; g_own_tune.listed = value != 0.f; break;
+    case 1: old = g_own_tune.cost_adam; g_own_tune.cost_adam = value; break;
+    case 2: old = g_own_tune.cost_items; g_own_tune.cost_items = value; break;
+    case 3: old = (float)g_own_tune.rl_max_res; g_own_tune.rl_max_res = (uint32_t)value; break;
+    case 4: old = (float)g_own_tune.rl_max_q; g_own_tune.rl_max_q = (uint32_t)value; break;
+    default: break;
+    }
+    return old;
+}
+
+// the unit -> XCD map a launch over the levels [level_begin, level_end) would use (host arithmetic only: tests/test_capi.py)
+// out[0] = blocks, out[1..9] = xcd_start, out[10..10+L] = unit_start, then n_slices[L], n_chunks[L]
+extern "C" int nsr_hashgrid_owner_debug_map(const NsrGridDesc *desc, int large, uint32_t level_begin, uint32_t level_end,
+                                            int with_adam, uint32_t *out)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_owner_debug_map")) return rc;
+    NSR_REQUIRE(out, "nsr_hashgrid_owner_debug_map: out is NULL");
+    if (level_end > desc->n_levels) level_end = desc->n_levels;
+    if (large) own_large::owner_debug_map(desc, level_begin, level_end, with_adam, out);
+    else own_small::owner_debug_map(desc, level_begin, level_end, with_adam, out);
+    return NSR_OK;
 }
 
 extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n)

@@ -207,6 +207,8 @@ SIGNATURES = {
     "nsr_nerf_render_backward": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P],
     "nsr_nerf_main_pass_exchange": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _P],
     "nsr_hashgrid_owner_large_from": [_U],
+    "nsr_hashgrid_owner_tune": [ctypes.c_int, ctypes.c_float],
+    "nsr_hashgrid_owner_debug_map": [_GD, ctypes.c_int, _U, _U, ctypes.c_int, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_range": [_P, _P, _P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_taps_workspace_floats": [_GD, _U],
     "nsr_hashgrid_backward_params_owner_bin_taps": [_P, _P, _P, _U, _U, _GD, _P],
@@ -252,7 +254,7 @@ SIGNATURES = {
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }
-_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32,
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
@@ -281,6 +283,10 @@ def load_library(path=LIB_PATH):
 
 
 lib = load_library()
+# NSR_OWN_TUNE="key=value,key=value": developer switch for A/B runs of the table backward's decomposition
+# (nsr_hashgrid_owner_tune; e.g. "0=0" = the round-3 placement of the work units)
+for _kv in filter(None, os.environ.get("NSR_OWN_TUNE", "").split(",")):
+    lib.nsr_hashgrid_owner_tune(int(_kv.split("=")[0]), float(_kv.split("=")[1]))
 
 
 def check(rc, what=""):

@@ -1,9 +1,10 @@
-"""A/B of the owner-computes table backward across differently tuned builds (tools/build_variants.sh): item binning,
-accumulation with the gradient stored (fp32 / bf16 in one or two level groups) and with AdamW applied inside, at the two
-operating points of bench.py (~9.6e4 kept samples steady state, ~2.2e5 in the short driver run), ray-coherent positions.
-One JSON line per build.
+"""A/B of the owner-computes table backward across builds (tools/build_variants.sh, tools/build_baseline.sh) and across the
+run-time knobs of the decomposition (nsr_hashgrid_owner_tune): item binning, accumulation with the gradient stored (fp32 /
+bf16 in one or two level groups) and with AdamW applied inside, at the two operating points of bench.py (~9.6e4 kept samples
+steady state, ~2.2e5 in the short driver run) and at a NeuS-sized launch, ray-coherent positions.  One JSON line per
+(build, setting); per-level fp64 sums of the gradient so that builds can be compared bit for bit offline.
 
-    python tools/table_backward_variants.py build/variants/libnsr_hip_*.so
+    python tools/table_backward_variants.py build/variants/libnsr_hip_*.so instant-nsr-pl_amd/nsr_hip/libnsr_hip.so
 """
 import json
 import os
@@ -11,6 +12,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (name, {tune key: value}); keys of nsr_hashgrid_owner_tune: 0 placement, 1 cost_adam, 2 cost_items, 3 rl_max_res, 4 rl_max_q
+SETTINGS = [("default", {}), ("dealt", {0: 0}), ("listed_items0.5", {2: 0.5}), ("listed_items2", {2: 2.0}),
+            ("listed_items4", {2: 4.0}), ("rl_dense_only", {3: 0}), ("rl_all_levels", {3: 1e6}), ("rl_off", {4: 0}),
+            ("rl_q24", {4: 24}), ("dealt_rl_dense_only", {0: 0, 3: 0})]
+DEFAULTS = {0: 1, 1: 1.0, 2: 1.0, 3: 320, 4: 12}
 
 
 def worker():
@@ -22,61 +28,68 @@ def worker():
     from kernel_microbench import coherent, median_us
     gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
     P = gd.n_entries * 2
-    res = {"lib": os.path.basename(nsr_hip.LIB_PATH)}
-    cfgs = (("small_2^11x256", 0xffffffff), ("large_2^13x1024", 0)) if hasattr(lib, "nsr_hashgrid_owner_large_from") else (("", None),)
-    for cfg_name, thr in cfgs:
-      if thr is not None:
-          lib.nsr_hashgrid_owner_large_from(thr)
-      for n in (96000, 216000, 1000000):
-          x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous()
-          dy = torch.randn(16, n, 2, device="cuda") * 1e-3
-          g = torch.empty(P, device="cuda")
-          g16 = torch.empty(P + 64, dtype=torch.bfloat16, device="cuda")
-          ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
-          p, m, v = torch.randn(P, device="cuda") * 1e-2, torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
-          sh = torch.empty(P, dtype=torch.float16, device="cuda")
-          step, hyper = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(12, device="cuda")
-          ad = nsr_hip.NsrTableAdam()
-          ad.params, ad.exp_avg, ad.exp_avg_sq, ad.shadow = p.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr()
-          ad.step, ad.hyper = step.data_ptr(), hyper.data_ptr()
-          ad.base_lr, ad.beta1, ad.beta2, ad.gamma = 0.01, 0.9, 0.99, 0.33
-          ad.milestone0, ad.milestone1, ad.milestone2 = 10000, 15000, 18000
-          ad.eps, ad.weight_decay = 1e-15, 0.01
-          D = ctypes.byref(gd)
+    off = [int(o) * 2 for o in gd.offset[:17]]
+    tunable = lib.nsr_hashgrid_owner_tune(0, 1.0) >= 0  # (the stub of a baseline build returns -1)
+    sizes = tuple(int(v) for v in os.environ.get("NSR_VARIANT_SIZES", "96000,216000,1000000").split(","))
+    for sname, tune in (SETTINGS if tunable else [("build_default", {})]):
+        if tunable:
+            for k, v in DEFAULTS.items():
+                lib.nsr_hashgrid_owner_tune(k, float(tune.get(k, v)))
+        res = {"lib": os.path.basename(nsr_hip.LIB_PATH), "setting": sname}
+        for cfg_name, thr in (("small_2^11x256", 0xffffffff), ("large_2^13x1024", 0)):
+            lib.nsr_hashgrid_owner_large_from(thr)
+            for n in sizes:
+                if (cfg_name.startswith("small") and n > 300000) or (cfg_name.startswith("large") and n < 200000):
+                    continue  # (each configuration at the sizes it is picked for, and both at the crossover)
+                x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous()
+                dy = torch.randn(16, n, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 1e-3
+                g = torch.empty(P, device="cuda")
+                g16 = torch.empty(P + 64, dtype=torch.bfloat16, device="cuda")
+                ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
+                p, m, v = torch.randn(P, device="cuda") * 1e-2, torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+                sh = torch.empty(P, dtype=torch.float16, device="cuda")
+                step, hyper = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(12, device="cuda")
+                ad = nsr_hip.NsrTableAdam()
+                ad.params, ad.exp_avg, ad.exp_avg_sq, ad.shadow = p.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr()
+                ad.step, ad.hyper = step.data_ptr(), hyper.data_ptr()
+                ad.base_lr, ad.beta1, ad.beta2, ad.gamma = 0.01, 0.9, 0.99, 0.33
+                ad.milestone0, ad.milestone1, ad.milestone2 = 10000, 15000, 18000
+                ad.eps, ad.weight_decay = 1e-15, 0.01
+                D = ctypes.byref(gd)
 
-          def bin_():
-              check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, D, None, stream_ptr()), "bin")
+                def bin_():
+                    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, 16, D, None, stream_ptr()), "bin")
 
-          def acc():
-              check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x), ptr(dy), 2, 0, ptr(g), ptr(ws), n, 16, 1.0, 0, D,
-                                                                      None, stream_ptr()), "acc")
+                def acc():
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x), ptr(dy), 2, 0, ptr(g), ptr(ws), n, 16, 1.0, 0,
+                                                                            D, None, stream_ptr()), "acc")
 
-          def acc_adam():
-              check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(x), ptr(dy), 2, 0, ptr(ws), n, 16, 1.0, D, None,
-                                                                           ctypes.byref(ad), stream_ptr()), "acc_adam")
+                def acc_adam():
+                    check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(x), ptr(dy), 2, 0, ptr(ws), n, 16, 1.0, D,
+                                                                                 None, ctypes.byref(ad), stream_ptr()), "acc_adam")
 
-          def acc_bf16(groups):
-              def f():
-                  for lo, hi in groups:
-                      check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), None, ptr(g16), ptr(ws), n, 16,
-                                                                                    1.0, lo, hi, D, None, stream_ptr()), "range")
-              return f
+                def acc_bf16(groups):
+                    def f():
+                        for lo, hi in groups:
+                            check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), None, ptr(g16), ptr(ws), n,
+                                                                                          16, 1.0, lo, hi, D, None, stream_ptr()),
+                                  "range")
+                    return f
 
-          bin_()
-          r = {"bin_us": median_us(bin_, 5, 30), "accumulate_us": median_us(acc, 5, 30),
-               "accumulate_adam_us": median_us(acc_adam, 5, 30),
-               "accumulate_bf16_us": median_us(acc_bf16([(0, 16)]), 5, 30),
-               "accumulate_bf16_2groups_us": median_us(acc_bf16([(11, 16), (0, 11)]), 5, 30),
-               "accumulate_bf16_hi_only_us": median_us(acc_bf16([(11, 16)]), 5, 30)}
-          # correctness across builds: the fp32 gradient and its bf16 image
-          acc()
-          ref = g.clone()
-          acc_bf16([(11, 16), (0, 11)])()
-          torch.cuda.synchronize()
-          r["bf16_max_rel_err"] = float(((g16[:P].float() - ref).abs() / ref.abs().clamp_min(1e-12)).max())
-          r["grad_norm"] = float(ref.double().norm())
-          res[f"{cfg_name}:{n}"] = {k: (round(val, 2) if k.endswith("_us") else val) for k, val in r.items()}
-    print(json.dumps(res), flush=True)
+                bin_()
+                r = {"bin_us": median_us(bin_, 5, 30), "accumulate_us": median_us(acc, 5, 30),
+                     "accumulate_adam_us": median_us(acc_adam, 5, 30)}
+                if sname in ("default", "build_default", "dealt"):
+                    r["accumulate_bf16_2groups_us"] = median_us(acc_bf16([(11, 16), (0, 11)]), 5, 30)
+                    r["accumulate_bf16_hi_only_us"] = median_us(acc_bf16([(11, 16)]), 5, 30)
+                acc()
+                torch.cuda.synchronize()
+                gd64 = g.double()
+                r["grad_norm"] = float(gd64.norm())
+                r["level_sums"] = [float(gd64[off[l]:off[l + 1]].sum()) for l in range(16)]
+                r["level_abs_sums"] = [float(gd64[off[l]:off[l + 1]].abs().sum()) for l in range(16)]
+                res[f"{cfg_name}:{n}"] = {k: (round(val, 2) if k.endswith("_us") else val) for k, val in r.items()}
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
@@ -86,4 +99,4 @@ if __name__ == "__main__":
         for so in sys.argv[1:]:
             env = dict(os.environ, NSR_HIP_LIB=os.path.abspath(so), NSR_VARIANT_WORKER="1")
             p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
-            print(p.stdout.strip() or json.dumps({"lib": so, "error": p.stderr[-400:]}), flush=True)
+            print(p.stdout.strip() or json.dumps({"lib": so, "error": p.stderr[-600:]}), flush=True)
