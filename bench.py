@@ -646,8 +646,11 @@ def main():
             kern[name] = {"launches": launches, "avg_us": 1e3 * ms_total / max(launches, 1),
                           "units_per_launch": units / max(launches, 1)}
         # the table backward = item binning (on the main pass's helper stream, overlapped) + accumulation: one operation
+        tb_pieces = None
         if "hashgrid_backward_bin" in prof and "hashgrid_backward_params" in prof:
             acc_ms, launches, units = prof["hashgrid_backward_params"]
+            tb_pieces = {"binning_helper_stream_us": 1e3 * prof["hashgrid_backward_bin"][0] / max(launches, 1),
+                         "accumulate_main_stream_us": 1e3 * acc_ms / max(launches, 1)}
             prof["hashgrid_backward_params"] = (acc_ms + prof["hashgrid_backward_bin"][0], launches, units)
         cand = {k: v for k, v in prof.items() if k.startswith("hashgrid") and k != "hashgrid_backward_bin"}
         if cand:
@@ -670,7 +673,8 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "traffic": traffic, "traffic_source": traffic_note,
                     "algorithmic_bytes_per_sample": bps, "samples_per_launch": units / launches,
                     "optimizer_bytes_per_launch": opt_bytes, "algorithmic_bytes_per_launch": per_launch,
-                    "avg_launch_us": 1e3 * ms_total / launches}
+                    "avg_launch_us": 1e3 * ms_total / launches,
+                    "pieces": tb_pieces if name == "hashgrid_backward_params" else None}
             if fused_opt and prof_sep and "hashgrid_backward_params" in prof_sep:
                 ms_b = prof_sep["hashgrid_backward_params"][0] + prof_sep.get("hashgrid_backward_bin", (0.0,))[0]
                 n_l = prof_sep["hashgrid_backward_params"][1]

@@ -120,11 +120,14 @@ int nsr_hashgrid_backward_params_owner_accumulate(const float *x, const void *dy
 uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points);
 
 /* Run-time knobs of the owner-computes decomposition (A/B switches; the gradient is the same bits under every setting).
- * key 0: placement of the (level, slice, chunk) work units on the eight XCDs -- 1 (default): contiguous, cost-balanced ranges
- * of the unit list per XCD, so that an XCD's L2 serves the x / dy gathers of one or two levels; 0: dealt round-robin.
- * key 1 / 2: weight of a unit's write-out share / item share in that balance (default 1 / 1).
- * key 3: hashed levels up to this resolution merge runs of same-entry items in registers (default 320; dense levels always).
- * key 4: ... while a thread walks at most this many items (default 12).  Returns the previous value. */
+ * key 0: placement of the (level, slice, chunk) work units on the eight XCDs -- 0: dealt round-robin; 1: XCD k
+ * takes the k-th contiguous, cost-balanced range of the unit list (one or two levels per L2: the least x / dy fetch); 2: level
+ * l belongs to the XCD pair l mod 4, a pair's units are dealt to its two XCDs (a level's dy is fetched by 2 L2s instead of 8; default).
+ * key 1 / 2: weight of a unit's write-out share / item share in the cost balance of placement 1 (default 1 / 3).
+ * key 3: log2 of the entries per slice of a dense level (default 11).  key 4: workgroups a dense level is cut into at least,
+ * slices x item chunks (default 64).  key 5: fp32 merge of runs of same-entry lanes before the LDS atomics -- 0: off, 1: on the
+ * chunked dense levels (default; their result is summed from fp32 chunk slabs anyway), 2: on every dense level.
+ * Returns the previous value. */
 float nsr_hashgrid_owner_tune(int key, float value);
 /* The unit -> XCD map a launch over the levels [level_begin, level_end) would use (host arithmetic only, no GPU):
  * out[0] = blocks, out[1..9] = first unit of XCD 0..8, out[10..10+L] = first unit of level 0..L, then n_slices[L],
@@ -729,6 +732,17 @@ int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x, const voi
                                                        float *workspace, uint32_t n, uint32_t level_mask_count,
                                                        float grad_scale, const NsrGridDesc *desc, const int32_t *n_dev,
                                                        const NsrTableAdam *adam, void *stream);
+/* ... over the run of levels [level_begin, level_end) only (dy level-major fp32, items binned beforehand): the fused NeRF step
+ * launches the small dense levels (chunk slabs + slab reduction, the slowest workgroups of a trained scene) on a stream of
+ * their own beside the other levels (measured slower than one launch: csrc/step.hip).  nsr_hashgrid_owner_first_unchunked_level:
+ * where that cut is for a launch of n points. */
+int nsr_hashgrid_backward_params_owner_accumulate_adam_range(const float *x, const float *dy_level_major, float *workspace,
+                                                             uint32_t n, uint32_t level_mask_count, float grad_scale,
+                                                             uint32_t level_begin, uint32_t level_end,
+                                                             const NsrGridDesc *desc, const int32_t *n_dev,
+                                                             const NsrTableAdam *adam, void *stream);
+uint32_t nsr_hashgrid_owner_first_unchunked_level(const NsrGridDesc *desc, uint32_t n);
+
 /* The same write-out for the two other accumulation modes (the fused NeuS steps, nsr/fused_neus.py): first + second order
  * in one pass (analytic normals; items already binned when binned != 0) and the finite-difference stencil mode. */
 int nsr_hashgrid_backward_params_owner_with_second_order_adam(const float *x, const float *dy_first_lm, const float *dy,

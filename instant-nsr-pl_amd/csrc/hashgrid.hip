@@ -792,13 +792,14 @@ extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int 
 // Run-time knobs of the decomposition (nsr_hashgrid_owner_tune; A/B switches of tools/table_backward_variants.py -- the
 // gradient is the same bits under every setting):
 struct OwnTune {
-    int listed;            // 1: contiguous cost-balanced unit ranges per XCD (default), 0: units dealt round-robin (round 3)
+    int placement;         // 0: units dealt over the XCDs, 1: contiguous cost-balanced ranges, 2: levels striped over XCD pairs (default)
     float cost_adam;       // weight of a unit's write-out share in the balance
     float cost_items;      // weight of a unit's item share
-    uint32_t rl_max_res;   // hashed levels up to this resolution take the run-merging walk (dense levels always do)
-    uint32_t rl_max_q;     // ... while a thread has at most this many items
+    uint32_t dense_epb_log2;  // entries per slice of a dense level (log2)
+    uint32_t dense_wgs;       // workgroups a dense level is cut into at least (slices x item chunks)
+    uint32_t merge_dense;     // 2: every dense level merges runs of same-entry lanes in fp32 registers, 1: the chunked ones (default), 0: none
 };
-static OwnTune g_own_tune = {1, 1.0f, 1.0f, 320u, 12u};
+static OwnTune g_own_tune = {2, 1.0f, 3.0f, 11u, 64u, 1u};
 
 namespace own_small {
 #define NSR_OWN_BLOCK 256
@@ -839,16 +840,17 @@ extern "C" uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points)
     return old;
 }
 
-// key 0: placement (0 dealt / 1 listed), 1: cost_adam, 2: cost_items, 3: rl_max_res, 4: rl_max_q; returns the previous value
+// key 0: placement (0 dealt / 1 listed / 2 striped), 1: cost_adam, 2: cost_items, 3: dense_epb_log2, 4: dense_wgs, 5: merge_dense
 extern "C" float nsr_hashgrid_owner_tune(int key, float value)
 {
     float old = 0.f;
     switch (key) {
-    case 0: old = (float)g_own_tune.listed; g_own_tune.listed = value != 0.f; break;
+    case 0: old = (float)g_own_tune.placement; g_own_tune.placement = value < 0.5f ? 0 : (value < 1.5f ? 1 : 2); break;
     case 1: old = g_own_tune.cost_adam; g_own_tune.cost_adam = value; break;
     case 2: old = g_own_tune.cost_items; g_own_tune.cost_items = value; break;
-    case 3: old = (float)g_own_tune.rl_max_res; g_own_tune.rl_max_res = (uint32_t)value; break;
-    case 4: old = (float)g_own_tune.rl_max_q; g_own_tune.rl_max_q = (uint32_t)value; break;
+    case 3: old = (float)g_own_tune.dense_epb_log2; g_own_tune.dense_epb_log2 = (uint32_t)value; break;
+    case 4: old = (float)g_own_tune.dense_wgs; g_own_tune.dense_wgs = (uint32_t)value; break;
+    case 5: old = (float)g_own_tune.merge_dense; g_own_tune.merge_dense = (uint32_t)value; break;
     default: break;
     }
     return old;
@@ -943,6 +945,28 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x
     NSR_REQUIRE(adam, "nsr_hashgrid_backward_params_owner_accumulate_adam: adam is NULL");
     return owner_backward(x, dy, dy_layout, dy_stride, nullptr, workspace, n, level_mask_count, grad_scale, 0, desc, n_dev,
                           2, stream, nullptr, nullptr, adam);
+}
+
+// ... over the run of levels [level_begin, level_end) only (level-major fp32 dy, items binned beforehand): a step may put the
+// small dense levels -- whose hot chunks are the slowest workgroups of a trained scene, and whose chunk slabs need the
+// reduction launch behind them -- on a stream of their own beside the other levels (csrc/step.hip)
+extern "C" int nsr_hashgrid_backward_params_owner_accumulate_adam_range(const float *x, const float *dy_level_major,
+                                                                        float *workspace, uint32_t n,
+                                                                        uint32_t level_mask_count, float grad_scale,
+                                                                        uint32_t level_begin, uint32_t level_end,
+                                                                        const NsrGridDesc *desc, const int32_t *n_dev,
+                                                                        const NsrTableAdam *adam, void *stream)
+{
+    NSR_REQUIRE(adam, "nsr_hashgrid_backward_params_owner_accumulate_adam_range: adam is NULL");
+    return owner_backward(x, dy_level_major, 2, 0, nullptr, workspace, n, level_mask_count, grad_scale, 0, desc, n_dev, 2,
+                          stream, nullptr, nullptr, adam, 0, nullptr, nullptr, level_begin, level_end);
+}
+
+// first level that is NOT cut into item chunks in the slice configuration a launch of n points takes
+extern "C" uint32_t nsr_hashgrid_owner_first_unchunked_level(const NsrGridDesc *desc, uint32_t n)
+{
+    if (!desc || check_desc(desc, "nsr_hashgrid_owner_first_unchunked_level")) return 0;
+    return own_use_large(n) ? own_large::owner_first_unchunked_level(desc) : own_small::owner_first_unchunked_level(desc);
 }
 
 // ---- stencil mode: the 7 n_centre points of a finite-difference step (positions [7][n_centre][3]: sample, then the six

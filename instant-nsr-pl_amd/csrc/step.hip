@@ -328,6 +328,12 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
             return NSR_OK;
         }
     }
+    if (compute_grads && S == 0 && grad_table)
+        // nothing kept: the table gradient of this step is zero -- WRITTEN as zeros, because callers rely on the table backward
+        // overwriting every entry (nsr/parallel.py ShardedAdamW.step(overwritten=...) never clears it: a stale gradient would
+        // be sent into the reduce-scatter again)
+        NSR_REQUIRE(hipMemsetAsync(grad_table, 0, (uint64_t)d->grid.n_entries * d->grid.n_features * sizeof(float), st) ==
+                        hipSuccess, "nsr_nerf_main_pass: hipMemsetAsync failed");
     if (!compute_grads || S == 0) return NSR_OK;
     NSR_REQUIRE(grad_density_mlp && (grad_table || table_adam || xchg) && grad_color_mlp, "nsr_nerf_main_pass: NULL gradient buffer");
     float *d_rgb = (float *)(ws + L.d_rgb), *d_logit = (float *)(ws + L.d_logit);
@@ -382,6 +388,9 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
             NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess,
                         "nsr_nerf_main_pass: helper stream join failed");
             if (table_adam)  // the optimizer's update of the table happens inside the backward (no gradient store)
+                // (round 4: launching the small dense levels -- the slowest workgroups on a trained scene -- on a stream of their own
+                // beside the other levels was built and measured: 125-135 us for that launch alone, step 0.511 -> 0.546 ms; their
+                // chains are hidden better INSIDE the one launch, where they are dispatched first)
                 NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam(x01, d_enc, 2, 0, (float *)(ws + L.grid_ws), S,
                                                                            d->grid.n_levels, 1.0f, &d->grid, n_kept_dev,
                                                                            table_adam, stream));

@@ -153,6 +153,7 @@ class FusedNeuSStep:
         # multi-GPU: {"fg": bf16 send buffer, "bg": ...} of nsr.parallel.ShardedAdamW -- the table backward writes the
         # exchange's transport format itself (no fp32 gradient, no cast); bf16_written: which of them a step really filled
         self.table_bf16, self.bf16_written = None, set()
+        self.grad_written = set()  # tables whose fp32 .grad this step wrote (or cleared): the others' is a previous step's
         self.radius = float(cfg["radius"])
         g = cfg["geometry"]
         self.fd = g["grad_type"] == "finite_difference"
@@ -428,8 +429,10 @@ class FusedNeuSStep:
                                                                     ptr(c["gws"]), S, desc.n_levels, 1.0, 0, _byref(desc),
                                                                     None, s),
                   "nsr_hashgrid_backward_params_owner_accumulate(bg)")
+            self.grad_written.add("bg")
         else:
             enc.params.grad.zero_()
+            self.grad_written.add("bg")
         return g_geo, g_tex
 
     def _finish_bg_only(self, res, g_bg):
@@ -713,7 +716,7 @@ class FusedNeuSStep:
     def _step(self, rays, gt_rgb, fg_mask, background, compute_grads, loss_scale, march_handle, after_march, external):
         """generator: runs the forward, yields the result dict, is sent the upstream gradients (``external``) or None (built-in
         loss terms) and runs the backward.  No torch context manager is held across the yield."""
-        self.adam_applied, self.bf16_written = set(), set()
+        self.adam_applied, self.bf16_written, self.grad_written = set(), set(), set()
         m, enc, lw = self.model, self.enc, self.loss_weights
         dev = rays.device
         n_rays = rays.shape[0]
@@ -1002,6 +1005,8 @@ class FusedNeuSStep:
                     "nsr_hashgrid_backward_params_owner_with_second_order")
             if ad is not None:
                 self.adam_applied.add("fg")
+            elif bf is None:
+                self.grad_written.add("fg")
         # weight norm / bias gradients through the host-side fold
         if g_bg is not None:
             self.bg_geo.push_gradient(g_bg[0])
@@ -1074,6 +1079,16 @@ class SmallAdamW:
         for p, _ in live:
             p.grad = None
 
+    def state_dict(self):
+        return {"step_count": self.step_count, "m": None if self._m is None else self._m.detach().clone(),
+                "v": None if self._v is None else self._v.detach().clone()}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step_count"])
+        if self._m is not None and sd.get("m") is not None:
+            self._m.copy_(sd["m"])
+            self._v.copy_(sd["v"])
+
 
 class NeuSTrainer:
     """one-process-per-GPU training step of the reference's NeuSSystem (systems/neus.py:87-152) on the fused runner:
@@ -1126,6 +1141,8 @@ class NeuSTrainer:
         self.device_occupancy_refresh = not os.environ.get("NSR_NEUS_TORCH_REFRESH")  # foreground grid (A/B switch)
         self._pending, self._side = None, None
         self.last = {}
+        from .trainer import resync_after_model_load
+        resync_after_model_load(self)
 
     def state_dict(self):
         """``model.state_dict()`` with every fp32 parameter current; at world > 1 a COLLECTIVE (every rank calls it): the
@@ -1134,9 +1151,24 @@ class NeuSTrainer:
         return checkpoint_state_dict(self.model, self.sharded)
 
     def save(self, path):
-        sd = self.state_dict()
+        """model + training state (optimizer moments of the tables and of the small fp32 tensors, step counts, dynamic ray
+        count, sampler state); a COLLECTIVE at world > 1"""
+        from .trainer import training_state
+        sd, ts = self.state_dict(), training_state(self, (self.opt_rest,))
         if self.rank == 0:
-            torch.save({"state_dict": sd, "global_step": self.global_step}, path)
+            torch.save({"state_dict": sd, "global_step": self.global_step, "training_state": ts}, path)
+
+    def load(self, path_or_ckpt):
+        """resume (reference launch.py:112-113): weights, optimizer state, step counter.  Every rank calls it."""
+        from .trainer import restore_training_state
+        ck = torch.load(path_or_ckpt, map_location=self.device) if isinstance(path_or_ckpt, (str, bytes, os.PathLike)) \
+            else path_or_ckpt
+        self.model.load_state_dict(ck["state_dict"])
+        if ck.get("training_state") is not None:
+            restore_training_state(self, ck["training_state"], (self.opt_rest,))
+        else:
+            self.global_step = int(ck.get("global_step", 0))
+        self._pending = None
 
     def _next_batch(self, stream_ctx):
         from .fused import prepare_train_rays
@@ -1211,8 +1243,11 @@ class NeuSTrainer:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             all_reduce_gradients(self._rest)
+            done = self.fused.bf16_written | self.fused.grad_written
             self.sharded.step(lr_scale=scale, timings=self.comm_timings, overwritten=self._tables,
-                              prefilled=[self._table_of[k] for k in self.fused.bf16_written])
+                              prefilled=[self._table_of[k] for k in self.fused.bf16_written],
+                              # a rank that marched nothing launched no table backward: its .grad is LAST step's
+                              absent=[m for k, m in self._table_of.items() if k not in done])
         else:
             if self.world_size > 1:
                 all_reduce_gradients(list(model.parameters()))

@@ -202,11 +202,7 @@ class ShardedAdamW:
                 for k in ("master", "exp_avg", "exp_avg_sq", "g32"):
                     st[k] = torch.zeros(S_all, device=dev)
                 st["shard16"] = torch.zeros(S_all, dtype=torch.float16, device=dev)
-                for a, b in st["ranges"]:  # this rank's slice of every range: [a + r S, a + (r + 1) S), S = (b - a) / P
-                    S = (b - a) // P
-                    lo, hi = a + self.rank * S, min(a + (self.rank + 1) * S, body)
-                    if hi > lo:
-                        st["master"][a // P:a // P + hi - lo].copy_(p.data[head + lo:head + hi])
+                self._scatter_body(st, "master", p.data)
                 self.wire_bytes += S_all * (P - 1) * (torch.finfo(transport).bits // 8 + 2)
             else:
                 st["ranges"] = []
@@ -218,6 +214,66 @@ class ShardedAdamW:
         if n_small:
             self.wire_bytes += 2 * n_small * 4 * (P - 1) // P
         self._comm, self._done, self._done_timed = None, None, None
+
+    def _scatter_body(self, st, key, full):
+        """st[key] (this rank's shard, range by range) <- the body part of the full vector ``full`` [n]"""
+        P, head, body = self.world, st["head"], st["body"]
+        for a, b in st["ranges"]:  # this rank's slice of every range: [a + r S, a + (r + 1) S), S = (b - a) / P
+            S = (b - a) // P
+            lo, hi = a + self.rank * S, min(a + (self.rank + 1) * S, body)
+            if hi > lo:
+                st[key][a // P:a // P + hi - lo].copy_(full[head + lo:head + hi])
+
+    def _gather_body(self, st, key, out):
+        """out [n]: body part <- every rank's shard st[key] (a collective)"""
+        full = torch.empty(st["body_pad"], device=st[key].device)
+        for a, b in st["ranges"]:
+            S = (b - a) // self.world
+            _all_gather_shards(full[a:b], st[key][a // self.world:a // self.world + S].contiguous(), self.world, self.rank, "ring")
+        out[st["head"]:].copy_(full[:st["body"]])
+
+    # ---- checkpoints -------------------------------------------------------------------------------------------------------
+    def gather_moments(self, modules):
+        """[(exp_avg, exp_avg_sq)] as FULL fp32 vectors, one pair per module of ``modules`` (a collective: every rank calls
+        it): the checkpoint format is the single-process optimizer's, so a run resumes at any world size"""
+        out = []
+        for m in modules:
+            st = self.state[m]
+            ea, eas = torch.zeros(st["n"], device=m.params.device), torch.zeros(st["n"], device=m.params.device)
+            o, h = st["small_off"], st["head"]
+            if h:
+                ea[:h].copy_(self.small_m[o:o + h])
+                eas[:h].copy_(self.small_v[o:o + h])
+            if st["ranges"]:
+                self._gather_body(st, "exp_avg", ea)
+                self._gather_body(st, "exp_avg_sq", eas)
+            out.append((ea, eas))
+        return out
+
+    def load(self, modules, moments, step_count):
+        """re-seed from the modules' (freshly loaded) fp32 ``params``: sharded masters, fp16 shards and the fp16 image; with
+        ``moments`` ([(exp_avg, exp_avg_sq)] full vectors, ``gather_moments`` order) also the optimizer state"""
+        for k, m in enumerate(modules):
+            st = self.state[m]
+            p = m.params
+            st["shadow"][:st["n"]].copy_(p.data)
+            if st["ranges"]:
+                self._scatter_body(st, "master", p.data)
+                st["shard16"].copy_(st["master"])
+            if moments is not None:
+                ea, eas = moments[k]
+                o, h = st["small_off"], st["head"]
+                if h:
+                    self.small_m[o:o + h].copy_(ea[:h])
+                    self.small_v[o:o + h].copy_(eas[:h])
+                if st["ranges"]:
+                    self._scatter_body(st, "exp_avg", ea)
+                    self._scatter_body(st, "exp_avg_sq", eas)
+            if hasattr(m, "adopt_shadow"):
+                m.adopt_shadow(st["shadow"][:st["n"]])
+        if step_count is not None:
+            self.step_count = int(step_count)
+        self.master_current = True
 
     # ---- what a fused step writes into directly ---------------------------------------------------------------------
     def send_buffer(self, module):
@@ -250,14 +306,16 @@ class ShardedAdamW:
             sh.copy_(p)
             g.zero_()
 
-    def step(self, lr_scale=1.0, timings=None, ready=None, prefilled=(), direct_small=(), overwritten=()):
+    def step(self, lr_scale=1.0, timings=None, ready=None, prefilled=(), direct_small=(), overwritten=(), absent=()):
         """One optimizer step over all modules, exchange included.
 
         ``prefilled``: modules whose send buffer already holds this step's body gradient (otherwise it is cast from
         ``params.grad``).  ``direct_small``: modules whose head gradient was written into ``small_grad_view`` (otherwise it
         is copied from ``params.grad`` and that slice is re-zeroed).  ``overwritten``: modules whose body gradient in
         ``params.grad`` is overwritten by every step (the owner-computes table backward) -- the others' is re-zeroed after the
-        cast.  ``ready``: {"small": event, module: [event per range, in
+        cast.  ``absent``: modules whose backward did not run this step (a rank that kept no sample): their body
+        contributes zeros -- whatever ``params.grad`` holds is a previous step's gradient.  A module whose ``params.grad`` is
+        None contributes zeros too.  ``ready``: {"small": event, module: [event per range, in
         exchange order]} -- torch events the communication stream waits for before it touches the respective gradient
         (default: everything queued on the current stream so far).  ``timings`` (dict or None): when given, HIP-event
         tuples around reduce-scatter / AdamW / all-gather of every range are appended to ``timings["events"]`` and around
@@ -317,9 +375,13 @@ class ShardedAdamW:
                     head, S = st["head"], (b - a) // self.world
                     if m not in prefilled:
                         hi = min(b, st["body"])
-                        st["send"][a:hi].copy_(m.params.grad[head + a:head + hi])  # fp32 -> transport dtype
-                        if m not in overwritten:
-                            m.params.grad[head + a:head + hi].zero_()
+                        g = m.params.grad
+                        if g is None or m in absent:
+                            st["send"][a:hi].zero_()
+                        else:
+                            st["send"][a:hi].copy_(g[head + a:head + hi])  # fp32 -> transport dtype
+                            if m not in overwritten:
+                                g[head + a:head + hi].zero_()
                     sl = slice(a // self.world, a // self.world + S)
                     e = [tev() for _ in range(4)] if tev else None
                     if e:
@@ -355,12 +417,7 @@ class ShardedAdamW:
             st = self.state[m]
             if not st["ranges"]:
                 continue
-            full = torch.empty(st["body_pad"], device=st["master"].device)
-            for a, b in st["ranges"]:
-                S = (b - a) // self.world
-                _all_gather_shards(full[a:b], st["master"][a // self.world:a // self.world + S].contiguous(), self.world,
-                                   self.rank, "ring")
-            m.params.data[st["head"]:].copy_(full[:st["body"]])
+            self._gather_body(st, "master", m.params.data)
         self.master_current = True
 
 

@@ -65,6 +65,34 @@ class FusedAdamW:
             self.other.step()
             self.other.zero_grad(set_to_none=False)
 
+    # ---- checkpoints (reference launch.py --resume: Lightning restores optimizer state and step count) ----------------------
+    def state_dict(self):
+        return {"step_count": self.step_count,
+                "moments": [(self.state[m.params][0].detach().clone(), self.state[m.params][1].detach().clone())
+                            for m in self.tcnn_modules],
+                "other": self.other.state_dict() if self.other is not None else None}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step_count"])
+        for m, (ea, eas) in zip(self.tcnn_modules, sd["moments"]):
+            self.state[m.params][0].copy_(ea)
+            self.state[m.params][1].copy_(eas)
+        if self.other is not None and sd.get("other") is not None:
+            self.other.load_state_dict(sd["other"])
+        self.resync()
+
+    def resync(self):
+        """after the parameters were written from outside (``load_state_dict``): the fp16 images the kernels read are
+        re-cast from them and the device-side schedule state (step counter, running beta powers) restarts from the host's
+        step count"""
+        for m in self.tcnn_modules:
+            shadow = self.state[m.params][2]
+            shadow.copy_(m.params.data)
+            m.adopt_shadow(shadow)
+        if getattr(self, "_step_dev", None) is not None:
+            self._step_dev.fill_(self.step_count)
+            self._hyper.zero_()  # (power cache keyed on a step that no longer matches: recomputed by the next launch)
+
     def _device_schedule_state(self):
         dev = self.tcnn_modules[0].params.device
         if getattr(self, "_step_dev", None) is None:
@@ -140,6 +168,47 @@ def checkpoint_state_dict(model, sharded):
     if sharded is not None:
         sharded.gather_master()
     return model.state_dict()
+
+
+def training_state(trainer, extra_optimizers=()):
+    """everything a resumed run needs beside the model (reference launch.py --resume / Lightning's checkpoint): optimizer
+    moments and step counts (gathered from the ranks' shards at world > 1: a COLLECTIVE, and the checkpoint loads at any
+    world size), the step counter, the dynamic ray count, the ray sampler's generator state"""
+    opt = trainer.opt.state_dict()
+    if trainer.sharded is not None:
+        opt["step_count"] = trainer.sharded.step_count
+        opt["moments"] = trainer.sharded.gather_moments(trainer.opt.tcnn_modules)
+    st = {"optimizer": opt, "global_step": int(trainer.global_step), "train_num_rays": int(trainer.train_num_rays),
+          "generator": trainer.gen.get_state(), "extra": [o.state_dict() for o in extra_optimizers]}
+    a = getattr(trainer, "_as", None)
+    if a is not None:  # asynchronous mode keeps the dynamic ray count on the device
+        st["train_num_rays"] = int(a["n_rays"].item())
+    return st
+
+
+def restore_training_state(trainer, st, extra_optimizers=()):
+    trainer.opt.load_state_dict(st["optimizer"])
+    if trainer.sharded is not None:
+        trainer.sharded.load(trainer.opt.tcnn_modules, st["optimizer"]["moments"], st["optimizer"]["step_count"])
+    for o, sd in zip(extra_optimizers, st.get("extra", [])):
+        o.load_state_dict(sd)
+    trainer.global_step = int(st["global_step"])
+    trainer.train_num_rays = int(st["train_num_rays"])
+    if st.get("generator") is not None:
+        trainer.gen.set_state(st["generator"].cpu())
+    a = getattr(trainer, "_as", None)
+    if a is not None:
+        a["n_rays"].fill_(trainer.train_num_rays)
+
+
+def resync_after_model_load(trainer):
+    """``model.load_state_dict()`` on a model a trainer was already built around: without this the optimizer's fp16 images
+    (and, at world > 1, the sharded fp32 masters the next all-gather is cast from) would silently revert the loaded weights"""
+    def hook(module, incompatible):
+        trainer.opt.resync()
+        if trainer.sharded is not None:
+            trainer.sharded.load(trainer.opt.tcnn_modules, None, None)
+    trainer.model.register_load_state_dict_post_hook(hook)
 
 
 def guard_stale_state_dict(model, sharded):
@@ -246,6 +315,7 @@ class Trainer:
             from .fused import FusedNeRFStep
             self.fused = FusedNeRFStep(model)
             self.opt.table_grad_overwritten = True
+        resync_after_model_load(self)
 
     # ---- checkpoints -------------------------------------------------------------------------------------------------
     def state_dict(self):
@@ -255,9 +325,25 @@ class Trainer:
         return checkpoint_state_dict(self.model, self.sharded)
 
     def save(self, path):
-        sd = self.state_dict()
+        """model + training state (optimizer moments, step counts, dynamic ray count, sampler state); a COLLECTIVE at world > 1"""
+        sd, ts = self.state_dict(), training_state(self)
         if self.rank == 0:
-            torch.save({"state_dict": sd, "global_step": self.global_step}, path)
+            torch.save({"state_dict": sd, "global_step": self.global_step, "training_state": ts}, path)
+
+    def load(self, path_or_ckpt):
+        """resume (reference launch.py:112-113 ``trainer.fit(..., ckpt_path=args.resume)``): weights, optimizer state, step
+        counter.  Every rank calls it."""
+        ck = torch.load(path_or_ckpt, map_location=self.device) if isinstance(path_or_ckpt, (str, bytes, os.PathLike)) \
+            else path_or_ckpt
+        self.model.load_state_dict(ck["state_dict"])  # (the post-hook re-seeds fp16 images / sharded masters)
+        if ck.get("training_state") is not None:
+            restore_training_state(self, ck["training_state"])
+        else:
+            self.global_step = int(ck.get("global_step", 0))
+        self._pending = None  # batches marched ahead belong to the old run
+        if self._as is not None:
+            self._as["marched_upto"] = self._as["packed_upto"] = self.global_step - 1
+            self._as["events"].clear()
 
     def _all_reduce_grads(self):
         if self.world_size > 1 and self.sharded is None:

@@ -214,6 +214,8 @@ SIGNATURES = {
     "nsr_hashgrid_backward_params_owner_bin_taps": [_P, _P, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_taps": [_P, _P, _P, _P, _P, _U, _U, _I, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_adam": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P, _P, _P],
+    "nsr_hashgrid_backward_params_owner_accumulate_adam_range": [_P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P, _P],
+    "nsr_hashgrid_owner_first_unchunked_level": [_GD, _U],
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
                             ctypes.POINTER(ctypes.c_uint64)],
@@ -254,7 +256,7 @@ SIGNATURES = {
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }
-_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float,
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_hashgrid_owner_first_unchunked_level": ctypes.c_uint32,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,

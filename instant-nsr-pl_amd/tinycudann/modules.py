@@ -107,7 +107,7 @@ class Module(torch.nn.Module):
         self.loss_scale = 128.0
         dev = _current_device()
         self.params = torch.nn.Parameter(self._initial_params(seed, dev).to(torch.float32), requires_grad=True)
-        self._shadow, self._shadow_key, self._shadow_trusted = None, None, False
+        self._shadow, self._shadow_key, self._shadow_trusted, self._shadow_lazy = None, None, False, False
 
     # ---- fp16 shadow (tcnn casts params to fp16 on every call) --------------------------------------------------
     def half_params(self, params):
@@ -118,9 +118,14 @@ class Module(torch.nn.Module):
         the fp16 image itself in the pass that updates the parameters hands it over (``adopt_shadow``); it is then used as
         is until the parameter tensor is replaced or modified in place (version counter), or ``invalidate()`` is called."""
         key = (params.data_ptr(), params._version, params.device)
-        if self._shadow is None or key != self._shadow_key or not self._shadow_trusted:
+        # inference in eval() mode (chunked rendering, export) reuses a cast made in that mode for as long as the version key
+        # holds -- one 75 MB cast per chunk otherwise; a `.data` write in between needs invalidate().  NOT in train() mode, not
+        # even under no_grad: the reference's sphere_init writes `.data` right after construction, possibly behind a forward
+        # (tests/test_gpu_shims.py::test_sphere_init_through_params_data_is_seen_and_trains)
+        lazy_ok = not self.training
+        if self._shadow is None or key != self._shadow_key or not (self._shadow_trusted or (lazy_ok and self._shadow_lazy)):
             self._shadow = params.detach().to(torch.float16).contiguous()
-            self._shadow_key, self._shadow_trusted = key, False
+            self._shadow_key, self._shadow_trusted, self._shadow_lazy = key, False, lazy_ok
         return self._shadow
 
     def adopt_shadow(self, shadow):
@@ -130,7 +135,11 @@ class Module(torch.nn.Module):
 
     def invalidate(self):
         """call after writing to ``params.data`` directly (``.data`` writes do not bump the version counter)"""
-        self._shadow_key, self._shadow_trusted = None, False
+        self._shadow_key, self._shadow_trusted, self._shadow_lazy = None, False, False
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate()  # (load_state_dict copies into params under no_grad; an adopted fp16 image is stale now)
 
     def _prep(self, x):
         if not x.is_cuda:

@@ -236,3 +236,50 @@ def test_sharded_adamw_bf16_transport_stays_in_step(tmp_path):
         dev = (got - w).abs()
         assert float(dev.mean()) < 1e-4 and float(dev.max()) <= 3 * 0.0101
         assert float((dev > 3 * 0.01 * 2 ** -7).float().mean()) < 5e-3
+
+
+def _absent_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nsr.parallel import ShardedAdamW
+    mods = [_FakeTcnnModule(3072 + 40000, 7, n_network_params=3072)]
+    if rank == 1:
+        mods[0].params.grad = None  # a rank whose first steps kept no sample never allocated the table gradient
+    opt = ShardedAdamW(mods, lr=0.01, transport=torch.float32, small_numel=1 << 10)
+    sent = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(50 * step + rank)
+        fresh = torch.randn(3072 + 40000, generator=g) * 1e-2
+        kw = {}
+        if rank == 1 and step == 0:
+            fresh = torch.zeros_like(fresh)          # .grad is None: contributes zeros
+        elif rank == 1 and step == 2:
+            kw = dict(absent=(mods[0],))              # no backward ran: .grad still holds step 1's gradient
+            fresh[3072:] = 0.0                        # (its head is copied from .grad as usual below)
+            mods[0].params.grad[:3072].copy_(fresh[:3072])
+        if not (rank == 1 and step in (0, 2)):
+            if mods[0].params.grad is None:
+                mods[0].params.grad = torch.zeros(3072 + 40000)
+            mods[0].params.grad.copy_(fresh)
+        sent.append(fresh.clone())
+        opt.step(overwritten=(mods[0],), **kw)     # the table backward overwrites: nobody clears the body for it
+    opt.gather_master()
+    torch.save({"sent": sent, "master": mods[0].params.detach().clone()}, os.path.join(out, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_rank_without_samples_contributes_zeros(tmp_path):
+    """a rank whose step launched no table backward (``absent``) or that never allocated the gradient (``.grad`` is
+    None) must contribute ZEROS to the reduce-scatter, not the previous step's gradient that ``overwritten`` left in place"""
+    world, port = 2, _free_port()
+    mp.spawn(_absent_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
+    mean = [[(r[0]["sent"][s] + r[1]["sent"][s]) / world] for s in range(3)]
+    want = _reference_adamw([3072 + 40000], [7], mean, [1.0, 1.0, 1.0])[0]
+    assert torch.equal(r[0]["master"], r[1]["master"])
+    assert torch.allclose(r[0]["master"], want, rtol=1e-5, atol=1e-7)

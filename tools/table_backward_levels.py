@@ -16,11 +16,18 @@ from kernel_microbench import coherent, median_us
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
-    res = {"n": n, "cases": {}}
-    for dist in ("E2_coherent", "E1_uniform"):
-        x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous() if dist == "E2_coherent" else \
-            torch.rand(n, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
-        dy = torch.randn(16, n, 2, device="cuda")
+    res = {"n": n, "cases": {}, "lib": os.path.basename(nsr_hip.LIB_PATH)}
+    if lib.nsr_hashgrid_owner_tune(0, 0.0) < 0:
+        pass  # (a baseline build: the knob is a stub)
+    real = torch.load(os.environ["NSR_VARIANT_DATA"]) if os.environ.get("NSR_VARIANT_DATA") else None
+    for dist in (tuple(real.keys()) if real else ("E2_coherent", "E1_uniform")):
+        if real:  # captured from training steps (tools/dump_step_inputs.py)
+            x, dy = real[dist]["x"].cuda().contiguous(), real[dist]["dy"].cuda().contiguous()
+            n = x.shape[0]
+        else:
+            x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous() if dist == "E2_coherent" else \
+                torch.rand(n, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+            dy = torch.randn(16, n, 2, device="cuda")
         g = torch.empty(gd.n_entries * 2, device="cuda")
         ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
         out = {}

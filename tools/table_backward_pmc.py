@@ -13,7 +13,7 @@ import nsr_hip
 from nsr_hip import check, lib, ptr, stream_ptr
 from kernel_microbench import coherent
 
-CASES = [(placement, n) for placement in (1, 0) for n in (96000, 216000)]
+CASES = [(placement, n) for placement in (0, 2, 1) for n in (96000, 216000)]
 REPS = 6
 
 if __name__ == "__main__":

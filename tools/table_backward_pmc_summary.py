@@ -31,5 +31,5 @@ for ci, (placement, n) in enumerate(CASES):
             ent[k] = {"fetch_MB": 2 * 1024 * sum(f) / len(f) / 1e6, "write_MB": 1024 * sum(w) / len(w) / 1e6}
     tot = sum(v["fetch_MB"] + v["write_MB"] for v in ent.values())
     alg = (140 * n + 26 * N_TABLE) / 1e6
-    out[f"{'listed' if placement else 'dealt'}:{n}"] = dict(ent, total_MB=tot, algorithmic_MB=alg, ratio=tot / alg if alg else None)
+    out[f"{('dealt', 'listed', 'striped')[placement]}:{n}"] = dict(ent, total_MB=tot, algorithmic_MB=alg, ratio=tot / alg if alg else None)
 print(json.dumps(out, indent=1))

@@ -13,10 +13,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (name, {tune key: value}); keys of nsr_hashgrid_owner_tune: 0 placement, 1 cost_adam, 2 cost_items, 3 rl_max_res, 4 rl_max_q
-SETTINGS = [("default", {}), ("dealt", {0: 0}), ("listed_items0.5", {2: 0.5}), ("listed_items2", {2: 2.0}),
-            ("listed_items4", {2: 4.0}), ("rl_dense_only", {3: 0}), ("rl_all_levels", {3: 1e6}), ("rl_off", {4: 0}),
-            ("rl_q24", {4: 24}), ("dealt_rl_dense_only", {0: 0, 3: 0})]
-DEFAULTS = {0: 1, 1: 1.0, 2: 1.0, 3: 320, 4: 12}
+SETTINGS = [("default", {}), ("dealt", {0: 0}), ("listed", {0: 1}), ("merge_all_dense", {5: 2}), ("merge_off", {5: 0})]
+if os.environ.get("NSR_VARIANT_SETTINGS"):
+    SETTINGS = [s_ for s_ in SETTINGS if s_[0] in os.environ["NSR_VARIANT_SETTINGS"].split(",")]
+DEFAULTS = {0: 2, 1: 1.0, 2: 3.0, 3: 11, 4: 64, 5: 1}
 
 
 def worker():
@@ -31,6 +31,9 @@ def worker():
     off = [int(o) * 2 for o in gd.offset[:17]]
     tunable = lib.nsr_hashgrid_owner_tune(0, 1.0) >= 0  # (the stub of a baseline build returns -1)
     sizes = tuple(int(v) for v in os.environ.get("NSR_VARIANT_SIZES", "96000,216000,1000000").split(","))
+    real = torch.load(os.environ["NSR_VARIANT_DATA"]) if os.environ.get("NSR_VARIANT_DATA") else None
+    if real is not None:  # positions / gradients captured from training steps (tools/dump_step_inputs.py)
+        sizes = tuple(real.keys())
     for sname, tune in (SETTINGS if tunable else [("build_default", {})]):
         if tunable:
             for k, v in DEFAULTS.items():
@@ -38,11 +41,18 @@ def worker():
         res = {"lib": os.path.basename(nsr_hip.LIB_PATH), "setting": sname}
         for cfg_name, thr in (("small_2^11x256", 0xffffffff), ("large_2^13x1024", 0)):
             lib.nsr_hashgrid_owner_large_from(thr)
-            for n in sizes:
-                if (cfg_name.startswith("small") and n > 300000) or (cfg_name.startswith("large") and n < 200000):
-                    continue  # (each configuration at the sizes it is picked for, and both at the crossover)
-                x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous()
-                dy = torch.randn(16, n, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 1e-3
+            for size in sizes:
+                if real is not None:
+                    x, dy = real[size]["x"].cuda().contiguous(), real[size]["dy"].cuda().contiguous()
+                    n, label = x.shape[0], f"{size}{x.shape[0]}"
+                    if cfg_name.startswith("large") and n < 200000:
+                        continue
+                else:
+                    n, label = size, str(size)
+                    if (cfg_name.startswith("small") and n > 300000) or (cfg_name.startswith("large") and n < 200000):
+                        continue  # (each configuration at the sizes it is picked for, and both at the crossover)
+                    x = coherent((n + 63) // 64 * 64, per_ray=16)[:n].contiguous()
+                    dy = torch.randn(16, n, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 1e-3
                 g = torch.empty(P, device="cuda")
                 g16 = torch.empty(P + 64, dtype=torch.bfloat16, device="cuda")
                 ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
@@ -76,19 +86,32 @@ def worker():
                                   "range")
                     return f
 
+                def timed(fn, warm=5, iters=30):
+                    """median of `fn` alone, the items re-binned (untimed) in front of every launch: an accumulation consumes
+                    the ticket counters of its binning"""
+                    ts = []
+                    for k in range(warm + iters):
+                        bin_()
+                        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a_.record(); fn(); b_.record()
+                        torch.cuda.synchronize()
+                        if k >= warm:
+                            ts.append(a_.elapsed_time(b_) * 1e3)
+                    return sorted(ts)[len(ts) // 2]
+
                 bin_()
-                r = {"bin_us": median_us(bin_, 5, 30), "accumulate_us": median_us(acc, 5, 30),
-                     "accumulate_adam_us": median_us(acc_adam, 5, 30)}
+                r = {"bin_us": median_us(bin_, 5, 30), "accumulate_us": timed(acc), "accumulate_adam_us": timed(acc_adam)}
                 if sname in ("default", "build_default", "dealt"):
-                    r["accumulate_bf16_2groups_us"] = median_us(acc_bf16([(11, 16), (0, 11)]), 5, 30)
-                    r["accumulate_bf16_hi_only_us"] = median_us(acc_bf16([(11, 16)]), 5, 30)
+                    r["accumulate_bf16_2groups_us"] = timed(acc_bf16([(11, 16), (0, 11)]))
+                    r["accumulate_bf16_hi_only_us"] = timed(acc_bf16([(11, 16)]))
+                bin_()
                 acc()
                 torch.cuda.synchronize()
                 gd64 = g.double()
                 r["grad_norm"] = float(gd64.norm())
                 r["level_sums"] = [float(gd64[off[l]:off[l + 1]].sum()) for l in range(16)]
                 r["level_abs_sums"] = [float(gd64[off[l]:off[l + 1]].abs().sum()) for l in range(16)]
-                res[f"{cfg_name}:{n}"] = {k: (round(val, 2) if k.endswith("_us") else val) for k, val in r.items()}
+                res[f"{cfg_name}:{label}"] = {k: (round(val, 2) if k.endswith("_us") else val) for k, val in r.items()}
         print(json.dumps(res), flush=True)
 
 
