@@ -319,6 +319,66 @@ def boundary_path(dev, warmup=300, steps=200):
                     ".item() on num_samples, torch smooth-L1 on boolean-masked rays, loss.backward(), torch AdamW, MultiStepLR"}
 
 
+def modular_path(dev, warmup=60, steps=100):
+    """The reference's OWN model code path on the drop-in packages: ``models/nerf.py:61-127`` statement by statement (its
+    restatement in tests/refmirror -- /root/reference itself cannot travel to the GPU box) over ``tinycudann`` / ``nerfacc`` =
+    the HIP packages, every call through autograd, driven the way Lightning drives it with ``precision: 16``
+    (configs/nerf-blender.yaml:103): ``torch.autocast(float16)`` + ``GradScaler(init_scale=65536)`` + ``torch.optim.AdamW`` +
+    MultiStepLR, the system's statements of systems/nerf.py:33-106 around it.  The slowest of the three tiers (fused trainer >
+    fused model entry > this): what a maintainer gets by only putting ``instant-nsr-pl_amd`` on PYTHONPATH."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import nsr
+    import refmirror
+    from nsr.scene import SyntheticBlender
+    torch.manual_seed(42)
+    cfg = nsr.configs.get("nerf-blender")
+    model = refmirror.NeRFModel(cfg).to(dev).train()
+    data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10000, 15000, 18000], gamma=0.33)
+    scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+    train_num_rays = cfg["train_num_rays"]
+    target = cfg["train_num_rays"] * cfg["num_samples_per_ray"]
+    n_samples = n_rays = skipped = 0
+    t0 = None
+    for step in range(warmup + steps):
+        if step == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        rays, rgb, fg, bg = data.sample_rays(train_num_rays, gen, cfg["background_color"])
+        model.background_color = bg
+        model.update_step(0, step)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = model(rays)
+            n = int(out["num_samples"].sum().item())
+            if cfg["dynamic_ray_sampling"] and n > 0:
+                t = int(train_num_rays * (target / n))
+                train_num_rays = min(int(train_num_rays * 0.9 + t * 0.1), cfg["max_train_num_rays"])
+            valid = out["rays_valid"][..., 0]
+            loss = torch.nn.functional.smooth_l1_loss(out["comp_rgb"][valid], rgb[valid])
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scale_before = scaler.get_scale()
+        scaler.step(opt)
+        scaler.update()
+        skipped += int(scaler.get_scale() < scale_before)
+        sched.step()
+        if step >= warmup:
+            n_samples += n
+            n_rays += rays.shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"samples_per_sec": n_samples / dt, "ms_per_step": 1e3 * dt / steps, "train_rays_per_sec": n_rays / dt,
+            "kept_samples_per_step": n_samples / steps, "rays_per_step": n_rays / steps, "final_loss": float(loss.detach()),
+            "warmup": warmup, "steps": steps, "steps_skipped_by_grad_scaler": skipped, "grad_scale": scaler.get_scale(),
+            "optimizer": "torch.optim.AdamW + GradScaler(65536) under torch.autocast(float16)",
+            "model": "tests/refmirror NeRFModel (= models/nerf.py:61-127) on the drop-in tinycudann / nerfacc packages",
+            "what": "the reference's own model statements through autograd on the HIP packages, Lightning precision-16 protocol; "
+                    "early in training (steps 60-160 of a fresh model: few rays, dense grid)"}
+
+
 def boundary_path_neus(dev, warmup=100, steps=100):
     """configs[2] (neus-blender) driven through the drop-in boundary the way the reference's NeuS system drives its model
     (systems/neus.py:88-139): torch ray sampling -> model.update_step -> out = model(rays) -> dynamic ray count from
@@ -712,6 +772,7 @@ def main():
         if world == 1 and not args.no_boundary_path:
             res["boundary_path"] = side_measurement("boundary_path")
             res["boundary_path_neus"] = side_measurement("boundary_path_neus")
+            res["modular_path"] = side_measurement("modular_path")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         res["other_workloads"] = others

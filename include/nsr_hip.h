@@ -334,6 +334,12 @@ int nsr_ray_march_write(const float *rays_o, const float *rays_d, const float *t
 uint64_t nsr_grid_bricks_words64(int res_x, int res_y, int res_z);
 int nsr_grid_pack_bricks(const uint8_t *grid_binary, int res_x, int res_y, int res_z, uint64_t *bricks, void *stream);
 uint32_t nsr_ray_march_capacity(const float *roi_host /*host[6]*/, float step_size);
+/* rays carried per 64-lane wave by the brick marcher (1..64; 0 = chosen by the ray count: a wave is as slow as its slowest
+ * ray and pays both sides of every divergent branch, and few rays leave most SIMDs idle).  Returns the previous setting. */
+uint32_t nsr_ray_march_rays_per_wave(uint32_t rays_per_wave);
+/* the wave-per-ray marcher (one ray per wave, 64 candidate samples tested at once; AABB contraction, cone_angle 0; same bits
+ * as the lane-per-ray kernel): 0 never, 1 for launches of at most 32,768 rays (default), 2 always.  Returns the previous mode. */
+int nsr_ray_march_wave_mode(int mode);
 int nsr_ray_march_bricks_count(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
                                const float *roi, const uint64_t *bricks, int res_x, int res_y, int res_z,
                                int contraction, float step_size, float cone_angle, int32_t *num_steps, float *scratch,
@@ -606,6 +612,8 @@ typedef struct NsrNerfMainLayout {
 #define NSR_PROF_MLP_BACKWARD_COLOR 4
 #define NSR_PROF_MLP_BACKWARD_DENSITY 5
 #define NSR_PROF_GRID_BACKWARD_BIN 6 /* item binning of the table backward, on the main pass's helper stream */
+/* the stream the main pass runs its overlapped work on (item binning, weight-gradient kernels); created on first use */
+void *nsr_nerf_helper_stream(void);
 void nsr_profile_enable(int on);
 int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches, uint64_t *units);
 

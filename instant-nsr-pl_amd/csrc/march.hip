@@ -318,12 +318,17 @@ k_ray_march_bricks(const float *__restrict__ rays_o, const float *__restrict__ r
                    uint32_t n_any_words, int3 res, int type, float step, float cone_angle,
                    const int32_t *__restrict__ packed_info, int32_t *__restrict__ num_steps,
                    int64_t *__restrict__ ray_indices, float *__restrict__ t_starts, float *__restrict__ t_ends,
-                   float2 *__restrict__ scratch, uint32_t cap, uint32_t n_rays)
+                   float2 *__restrict__ scratch, uint32_t cap, uint32_t n_rays, uint32_t rays_per_wave)
 {
     extern __shared__ uint32_t any_lds[];
     for (uint32_t k = threadIdx.x; k < n_any_words; k += MARCH_BLOCK) any_lds[k] = any_bits[k];
     __syncthreads();
-    const uint32_t i = blockIdx.x * MARCH_BLOCK + threadIdx.x;
+    // A wave takes as long as its slowest ray (up to ~1,000 dependent visits) and pays for both sides of every branch its
+    // lanes disagree on; 8,192 rays are 128 full waves on a chip with 1,024 SIMDs.  So a launch of few rays spreads them:
+    // only the first `rays_per_wave` lanes of a wave carry a ray (launch_bricks picks 64 / 16 / 8 by the ray count).
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane >= rays_per_wave) return;
+    const uint32_t i = ((blockIdx.x * MARCH_BLOCK + threadIdx.x) >> 6) * rays_per_wave + lane;
     if (i >= n_rays) return;
     Roi r;
 #pragma unroll
@@ -382,6 +387,213 @@ k_ray_march_bricks(const float *__restrict__ rays_o, const float *__restrict__ r
         }
     }
     if (MODE != 1) num_steps[i] = (int32_t)j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// WAVE-PER-RAY marcher (AABB contraction, cone_angle == 0: the bounded scenes of every reference config).
+//
+// The lane-per-ray kernel above is one dependent chain per ray -- position, three divisions, voxel index, brick word, bit
+// test, next t: ~700 clk per visit, up to ~1,000 visits -- and a launch lasts as long as its longest ray: 360 us for 8,192
+// rays whether they sit 64 or 4 to a wave (tools/march_bench.py), with 7/8 of the chip idle.  What is sequential in
+// nerfacc's loop is only the fp32 recurrence of t; WHICH t values get visited depends on occupancy, but the candidates do
+// not:
+//   * inside an occupied stretch the samples are t0' = t1, t1' = t0' + dt: lane j takes the j-th of the next 64 (every lane
+//     runs the 64 adds, they are cheap), all 64 occupancy tests -- the expensive part -- run at once, a ballot finds the
+//     first sample that is empty or beyond t_max, the lanes in front of it store their samples;
+//   * in empty space the loop visits a SUBSEQUENCE of b' = b + dt: lane n takes b_n, tests it and computes the voxel-exit
+//     distance; "add dt until t >= t_mid + distance" is a search for the first b_m >= target among the 64 candidates (six
+//     rounds of lane shuffles for all lanes at once), and the loop's walk through the window is a chase over those
+//     indices with wave-uniform lane reads.
+// Every float is produced by the same operations in the same order as in the serial loop: the outputs are bit-identical
+// (tests/test_gpu_march.py compares both kernels with the C oracle).
+// ------------------------------------------------------------------------------------------------
+constexpr int MARCH_WAVE_BLOCK = 256;  // 4 rays per workgroup (they share the LDS copy of the any-bits)
+
+template <int MODE, bool POW2>
+__global__ void __launch_bounds__(MARCH_WAVE_BLOCK)
+k_ray_march_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ t_min,
+                 const float *__restrict__ t_max, const float *__restrict__ roi,
+                 const unsigned long long *__restrict__ bricks, const uint32_t *__restrict__ any_bits,
+                 uint32_t n_any_words, int3 res, float step, const int32_t *__restrict__ packed_info,
+                 int32_t *__restrict__ num_steps, int64_t *__restrict__ ray_indices, float *__restrict__ t_starts,
+                 float *__restrict__ t_ends, float2 *__restrict__ scratch, uint32_t cap, uint32_t n_rays)
+{
+    extern __shared__ uint32_t any_lds[];
+    for (uint32_t k = threadIdx.x; k < n_any_words; k += MARCH_WAVE_BLOCK) any_lds[k] = any_bits[k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = (blockIdx.x * MARCH_WAVE_BLOCK + threadIdx.x) >> 6;
+    if (i >= n_rays) return;  // (wave-uniform)
+    Roi r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.lo[k] = roi[k]; r.hi[k] = roi[3 + k]; }
+    const float o[3] = {rays_o[3ull * i], rays_o[3ull * i + 1], rays_o[3ull * i + 2]};
+    const float d[3] = {rays_d[3ull * i], rays_d[3ull * i + 1], rays_d[3ull * i + 2]};
+    const float inv_d[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
+    const float near = t_min[i], far = t_max[i];
+    const float dt = calc_dt(near, 0.f, step, 1e10f);  // cone_angle 0: the step size, always
+    const float half = dt * 0.5f;
+    const float rr[3] = {(float)res.x, (float)res.y, (float)res.z};
+    const float inv_rr[3] = {1.f / rr[0], 1.f / rr[1], 1.f / rr[2]};
+    const int nby = res.y >> 2, nbz = res.z >> 2;
+    int64_t base = 0;
+    if (MODE == 1) base = packed_info[2ull * i];
+    float2 *row = (MODE == 2) ? scratch + (uint64_t)i * cap : nullptr;
+
+    // occupancy of the sample at t (+ the distance to the voxel's exit): the visit of the serial loop, per lane
+    auto visit = [&](float t, float &dist) -> bool {
+        const float p[3] = {__builtin_fmaf(t, d[0], o[0]), __builtin_fmaf(t, d[1], o[1]), __builtin_fmaf(t, d[2], o[2])};
+        float u[3];
+        roi_to_unit(p, r, u);
+        bool occ = false;
+        if (!outside_roi(p, r)) {
+            int ix = (int)(u[0] * rr[0]), iy = (int)(u[1] * rr[1]), iz = (int)(u[2] * rr[2]);
+            ix = min(max(ix, 0), res.x - 1);
+            iy = min(max(iy, 0), res.y - 1);
+            iz = min(max(iz, 0), res.z - 1);
+            const uint32_t id = (uint32_t)(((ix >> 2) * nby + (iy >> 2)) * nbz + (iz >> 2));
+            if ((any_lds[id >> 5] >> (id & 31u)) & 1u)
+                occ = (bricks[id] >> (((ix & 3) * 4 + (iy & 3)) * 4 + (iz & 3))) & 1ull;
+        }
+        dist = distance_to_next_voxel_u<POW2>(u, d, inv_d, r, rr, inv_rr);
+        return occ;
+    };
+
+    // n sequential fp32 additions of dt starting from a (a > 0) stay on an arithmetic progression of BIT PATTERNS while the
+    // sums stay inside a's binade: a = m u (u the binade's ulp, m an integer), the exact sum m u + dt rounds to (m + k) u with
+    // k = round(dt / u) whenever dt / u is not an exact tie -- the same k for every m.  -> true and k_ulp when a + n adds can
+    // be taken that way (wave-uniform: a is); otherwise the caller runs the additions.
+    auto progression = [&](float a, int n, int &k_ulp) -> bool {
+        const int bits = __float_as_int(a);
+        if (!(a > 0.f) || (bits >> 23) == 0 || (bits >> 23) >= 254) return false;
+        const float ulp = __int_as_float(((bits >> 23) - 23) << 23);  // 2^(e - 23)  (e - 23 > 0 for every t a scene produces)
+        if (((bits >> 23) - 23) <= 0) return false;
+        const float x = dt / ulp;  // exact (a power of two)
+        const float fl = floorf(x);
+        if (x - fl == 0.5f || !(x < 8388608.f) || x < 1.f) return false;  // tie / step smaller than an ulp or huge: run the additions
+        k_ulp = (int)rintf(x);
+        return ((bits + n * k_ulp) >> 23) == (bits >> 23);  // the last sum is still in the binade
+    };
+
+    uint32_t count = 0;
+    float t0 = near, t1 = t0 + dt, tm = (t0 + t1) * 0.5f;
+    bool empty_mode = false, has_pending = false;
+    float pending = 0.f;
+    while (true) {
+        if (!empty_mode) {
+            // ---- the next 64 samples of an occupied stretch: lane j = the state after j steps  t0 = t1, t1 = t0 + dt
+            float a0, a1, my0, my1;
+            int k_ulp;
+            if (progression(t1, 64, k_ulp)) {  // t1_j = t1 + j adds of dt = t1's bit pattern + j * k_ulp (see progression())
+                const int b1 = __float_as_int(t1);
+                my1 = __int_as_float(b1 + lane * k_ulp);
+                my0 = lane == 0 ? t0 : __int_as_float(b1 + (lane - 1) * k_ulp);
+                a0 = __int_as_float(b1 + 63 * k_ulp);
+                a1 = __int_as_float(b1 + 64 * k_ulp);
+            } else {
+                a0 = t0; a1 = t1; my0 = t0; my1 = t1;
+#pragma unroll 1
+                for (int j = 0; j < 64; ++j) {  // (rare: a binade boundary inside the window, or a step that ties)
+                    if (lane == j) { my0 = a0; my1 = a1; }
+                    const float n0 = a1;
+                    a1 = n0 + dt;
+                    a0 = n0;
+                }
+            }
+            const float mytm = lane == 0 ? tm : (my0 + my1) * 0.5f;  // (lane 0: t_mid as the loop arrived with it)
+            float dist;
+            const bool occ = visit(mytm, dist);
+            const unsigned long long ok = __ballot((mytm < far) && occ);
+            const int ff = ok == ~0ull ? 64 : (int)__ffsll((long long)~ok) - 1;  // first sample that ends the stretch
+            if (lane < ff) {
+                const uint32_t j = count + (uint32_t)lane;
+                if (MODE == 1) {
+                    t_starts[base + j] = my0;
+                    t_ends[base + j] = my1;
+                    ray_indices[base + j] = (int64_t)i;
+                } else if (MODE == 2) {
+                    if (j < cap) row[j] = make_float2(my0, my1);
+                }
+            }
+            count += (uint32_t)ff;
+            if (ff == 64) {
+                t0 = a0; t1 = a1; tm = (a0 + a1) * 0.5f;
+                continue;
+            }
+            const float ftm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mytm), ff));
+            if (!(ftm < far)) break;
+            tm = ftm;  // an EMPTY visit at tm comes next (t0 / t1 are re-derived behind the skip)
+            empty_mode = true;
+            has_pending = false;
+        } else {
+            // ---- empty space: the loop visits a subsequence of  b_0 = tm, b_{n+1} = b_n + dt ; lane n holds b_n
+            float b = tm, acc = tm;
+            int k_ulp;
+            const bool fast = progression(tm, 63, k_ulp);
+            if (fast) {
+                b = __int_as_float(__float_as_int(tm) + lane * k_ulp);
+                acc = __int_as_float(__float_as_int(tm) + 63 * k_ulp);
+            } else {
+#pragma unroll 1
+                for (int n = 1; n < 64; ++n) {
+                    acc = acc + dt;
+                    if (lane == n) b = acc;
+                }
+            }
+            float dist;
+            const bool occ = visit(b, dist);
+            const float tgt = b + dist;  // t_target of a visit at b: "do t_mid += dt while t_mid < t_target"
+            // nxt = smallest m > lane with b_m >= tgt (64: beyond this window), for every lane at once
+            int nxt;
+            const int d_ulp = __float_as_int(tgt) - __float_as_int(b);  // (same binade: tgt - b in units of its ulp)
+            const bool same_binade = ((__float_as_int(tgt) ^ __float_as_int(b)) >> 23) == 0;
+            if (fast && __all(same_binade || !(b < far))) {
+                // b_m = b + (m - lane) k_ulp ulps exactly, so the first b_m >= tgt is ceil(d_ulp / k_ulp) adds away (at least one:
+                // the loop is a do-while)
+                int q = (int)(((uint32_t)(d_ulp > 0 ? d_ulp : 0) + (uint32_t)k_ulp - 1u) / (uint32_t)k_ulp);
+                q = q < 1 ? 1 : q;
+                nxt = (same_binade && q < 64 - lane) ? lane + q : 64;
+                if (!same_binade) nxt = 64;  // (only lanes beyond t_max: never reached by the chase)
+            } else {
+                int lo = lane + 1, hi = 64;
+#pragma unroll
+                for (int s6 = 0; s6 < 6; ++s6) {
+                    const int mid = (lo + hi) >> 1;
+                    const float v = __shfl(b, mid < 64 ? mid : 63, 64);
+                    if (lo < hi) {
+                        if (mid < 64 && !(v < tgt)) hi = mid; else lo = mid + 1;
+                    }
+                }
+                nxt = lo;
+            }
+            int cur = 0;
+            if (has_pending) {  // a skip that began in an earlier window: first b_m (m >= 1) that is not < pending
+                const unsigned long long ge = __ballot(!(b < pending)) & ~1ull;
+                cur = ge ? (int)__ffsll((long long)ge) - 1 : 64;
+            }
+            bool done = false;
+            const unsigned long long occ_mask = __ballot(occ);
+            cur = __builtin_amdgcn_readfirstlane(cur);  // (the walk through the window is wave-uniform: scalar lane reads)
+            while (true) {
+                if (cur >= 64) {  // the skip runs past this window: go on from b_63 with the same target
+                    tm = acc;
+                    has_pending = true;
+                    break;
+                }
+                const float bc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), cur));
+                if (!(bc < far)) { done = true; break; }
+                if ((occ_mask >> cur) & 1ull) {  // an occupied sample: t0 / t1 as the loop derives them behind a skip
+                    t0 = bc - half; t1 = bc + half; tm = bc;
+                    empty_mode = false;
+                    break;
+                }
+                pending = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tgt), cur));
+                cur = __builtin_amdgcn_readlane(nxt, cur);
+            }
+            if (done) break;
+        }
+    }
+    if (MODE != 1 && lane == 0) num_steps[i] = (int32_t)count;
 }
 
 // wave per ray: copy the ray's scratch row to its packed position
@@ -714,6 +926,22 @@ extern "C" uint32_t nsr_ray_march_capacity(const float *roi_host, float step_siz
     return n > 65536.0 ? 0u : (uint32_t)n;
 }
 
+static int g_march_wave = 1;  // wave-per-ray kernel: 0 never, 1 for launches of <= 32,768 rays (default), 2 always
+extern "C" int nsr_ray_march_wave_mode(int mode)
+{
+    const int old = g_march_wave;
+    g_march_wave = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    return old;
+}
+
+static uint32_t g_rays_per_wave = 0;  // 0: by the ray count
+extern "C" uint32_t nsr_ray_march_rays_per_wave(uint32_t rays_per_wave)
+{
+    const uint32_t old = g_rays_per_wave;
+    g_rays_per_wave = rays_per_wave > 64u ? 64u : rays_per_wave;
+    return old;
+}
+
 static int launch_bricks(int mode, const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
                          const float *roi, const uint64_t *bricks, int rx, int ry, int rz, int type, float step,
                          float cone, const int32_t *packed, int32_t *num_steps, int64_t *ri, float *t0, float *t1,
@@ -724,13 +952,38 @@ static int launch_bricks(int mode, const float *rays_o, const float *rays_d, con
     const uint32_t *any_bits = (const uint32_t *)(bricks + nb);
     const size_t lds = n_words * sizeof(uint32_t);
     NSR_REQUIRE(lds <= 64 * 1024, "nsr_ray_march(bricks): grid too large for the LDS any-bit table");
-    const dim3 grid(nsr_div_up(n_rays, MARCH_BLOCK)), block(MARCH_BLOCK);
+    // wave-per-ray kernel: bounded scenes (AABB, fixed step) and launches small enough that the chip is not full of rays anyway
+    if (type == NSR_CONTRACT_AABB && cone == 0.f && g_march_wave != 0 && (g_march_wave == 2 || n_rays <= 32768u)) {
+        const dim3 wgrid(nsr_div_up((uint64_t)n_rays * 64ull, MARCH_WAVE_BLOCK)), wblock(MARCH_WAVE_BLOCK);
+        const int3 wres = make_int3(rx, ry, rz);
+        const bool wpow2 = !(rx & (rx - 1)) && !(ry & (ry - 1)) && !(rz & (rz - 1));
+#define NSR_LAUNCH_WAVE(M, P)                                                                                          \
+    hipLaunchKernelGGL((k_ray_march_wave<M, P>), wgrid, wblock, lds, (hipStream_t)stream, rays_o, rays_d, t_min, t_max, \
+                       roi, (const unsigned long long *)bricks, any_bits, n_words, wres, step, packed, num_steps, ri, t0, \
+                       t1, (float2 *)scratch, cap, n_rays)
+        if (wpow2) {
+            if (mode == 0) NSR_LAUNCH_WAVE(0, true);
+            else if (mode == 1) NSR_LAUNCH_WAVE(1, true);
+            else NSR_LAUNCH_WAVE(2, true);
+        } else {
+            if (mode == 0) NSR_LAUNCH_WAVE(0, false);
+            else if (mode == 1) NSR_LAUNCH_WAVE(1, false);
+            else NSR_LAUNCH_WAVE(2, false);
+        }
+#undef NSR_LAUNCH_WAVE
+        return NSR_OK;
+    }
+    // rays per wave: full waves once the launch fills the chip's SIMDs several times over (the window-batched launches of
+    // the asynchronous trainer), 16 or 8 lanes per wave for the single ray sets of the model-interface path
+    // (nsr_ray_march_rays_per_wave overrides: A/B)
+    uint32_t rpw = g_rays_per_wave ? g_rays_per_wave : (n_rays >= 65536u ? 64u : (n_rays >= 16384u ? 16u : 8u));
+    const dim3 grid(nsr_div_up(nsr_div_up(n_rays, rpw) * 64ull, MARCH_BLOCK)), block(MARCH_BLOCK);
     const int3 res = make_int3(rx, ry, rz);
     const bool pow2 = !(rx & (rx - 1)) && !(ry & (ry - 1)) && !(rz & (rz - 1));
 #define NSR_LAUNCH_BRICKS(M, P)                                                                                        \
     hipLaunchKernelGGL((k_ray_march_bricks<M, P>), grid, block, lds, (hipStream_t)stream, rays_o, rays_d, t_min, t_max, \
                        roi, (const unsigned long long *)bricks, any_bits, n_words, res, type, step, cone, packed,      \
-                       num_steps, ri, t0, t1, (float2 *)scratch, cap, n_rays)
+                       num_steps, ri, t0, t1, (float2 *)scratch, cap, n_rays, rpw)
     if (pow2) {
         if (mode == 0) NSR_LAUNCH_BRICKS(0, true);
         else if (mode == 1) NSR_LAUNCH_BRICKS(1, true);

@@ -126,6 +126,10 @@ struct HelperStream {
 };
 static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
 
+// the helper stream's handle (created on first use), for callers that queue follow-up work behind the weight-gradient
+// kernels themselves (the trainer's optimizer launch for the MLP weights); NULL if it could not be created
+extern "C" void *nsr_nerf_helper_stream(void) { return g_helper.init() ? (void *)g_helper.stream : nullptr; }
+
 extern "C" int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marched, NsrNerfPruneLayout *out)
 {
     NSR_REQUIRE(d && out, "nsr_nerf_prune_layout: NULL pointer");

@@ -533,7 +533,8 @@ class FusedNeRFStep:
         """the training step on ray set ``rs`` (filled by march_async, possibly on another stream -- the caller orders
         the streams) with NO host synchronisation: the marched / kept sample counts stay on the device, all buffers
         have fixed capacities (rs['m_cap'], s_cap) and every kernel is launched for the capacity.
-        ``after_prune_queued(total_kept)`` runs once the pruning pass is queued (device int32[1] tensor).
+        ``after_prune_queued(total_kept, pruned_event)`` runs once the whole step is queued; ``pruned_event`` was recorded right
+        behind the pruning pass (``total_kept``: device int32[1] tensor).
         ``exchange`` = (NsrTableExchange, grad_density_mlp, grad_color_mlp): the ray-sharded form of the main pass -- the table
         gradient leaves as bf16 in level groups with an event behind each, the MLP gradients go into the given fp32 views
         (nsr/parallel.py ShardedAdamW); ``.grad`` of the parameters is not touched."""
@@ -567,8 +568,18 @@ class FusedNeRFStep:
                                               ptr(mb["t1"]), ptr(rs["packed"]), ptr(table), ptr(w1), ptr(ab["pws"]),
                                               ptr(kept), ptr(packed2), ptr(total), m_cap, slots, ptr(rs["total"]),
                                               int(s_cap), ptr(kept_stats), ptr(x01m), s), "nsr_nerf_prune_pass")
+            # what the caller queues behind the pruning pass (the next step's ray count / packing, on a side stream) waits for
+            # THIS event; the call itself comes after the main pass is queued -- the main stream must not sit idle behind the
+            # pruning pass while the host issues side-stream launches (rocprofv3 timeline, round 3: pack ... 72 us ... copy_kept_rows)
+            pruned = None
             if after_prune_queued is not None:
-                after_prune_queued(total)
+                pruned = self._pruned_events[self._pruned_next] if hasattr(self, "_pruned_events") else None
+                if pruned is None:
+                    self._pruned_events = [torch.cuda.Event() for _ in range(4)]
+                    self._pruned_next = 0
+                    pruned = self._pruned_events[0]
+                self._pruned_next = (self._pruned_next + 1) % 4
+                pruned.record()
             if exchange is not None:
                 xd, g_density, g_color = exchange
                 with _ops.timed("fused:main_pass"):
@@ -594,6 +605,8 @@ class FusedNeRFStep:
                                              int(bool(compute_grads)), ptr(total), ptr(x01m),
                                              _byref(table_adam) if (table_adam is not None and compute_grads) else None,
                                              s), "nsr_nerf_main_pass")
+            if after_prune_queued is not None:
+                after_prune_queued(total, pruned)
             L, ws = ab["ML"], ab["ws"]
 
             def view(off, n, dtype, shape):

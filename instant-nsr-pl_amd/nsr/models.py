@@ -46,7 +46,10 @@ class _RenderNeRF(torch.autograd.Function):
     """comp_rgb, opacity, depth, weights = render(rays, background; geometry params, texture params)"""
 
     @staticmethod
-    def forward(ctx, model, need_grad, rays, background, p_geometry, p_texture):
+    def forward(ctx, model, need_grad, rays, background, p_geometry, p_texture, *p_empty):
+        # (p_empty: the zero-element parameters of parameter-free modules -- the SH encoding -- ride along so that they receive
+        # their (empty) gradient like every other parameter: DDP(find_unused_parameters=False) waits for one from each)
+        ctx.empty_shapes = [tuple(p.shape) for p in p_empty]
         # (need_grad is decided by the caller: grad mode is always off inside Function.forward)
         step = model._runner()
         out, state = step.render_forward(rays.detach(), background.detach(), prepare_backward=need_grad)
@@ -64,7 +67,7 @@ class _RenderNeRF(torch.autograd.Function):
             g_comp = torch.zeros((ctx.state["n_rays"], 3), device=ctx.state["ws"].device)
         g1, g2 = ctx.step.render_backward(ctx.state, g_comp, g_opacity, g_depth, g_weights)
         ctx.state = None  # the workspaces go back to the allocator
-        return None, None, None, None, g1, g2
+        return (None, None, None, None, g1, g2) + tuple(g1.new_zeros(sh) for sh in ctx.empty_shapes)
 
 
 class FusedNeRFModel(HotPathState):
@@ -107,7 +110,9 @@ class FusedNeRFModel(HotPathState):
         bg = self.background_color if self.background_color is not None else torch.ones(3, device=rays.device)
         ewn, tex = self.geometry.encoding_with_network, self.texture.network
         need_grad = torch.is_grad_enabled() and (ewn.params.requires_grad or tex.params.requires_grad)
-        comp_rgb, opacity, depth, weights, ray_indices = _RenderNeRF.apply(self, need_grad, rays, bg, ewn.params, tex.params)
+        empty = [p for p in self.parameters() if p.numel() == 0 and p.requires_grad]
+        comp_rgb, opacity, depth, weights, ray_indices = _RenderNeRF.apply(self, need_grad, rays, bg, ewn.params, tex.params,
+                                                                           *empty)
         last = self._last
         out = {"comp_rgb": comp_rgb, "opacity": opacity, "depth": depth, "rays_valid": opacity > 0,
                "num_samples": torch.as_tensor([last["num_samples"]], dtype=torch.int32)}
@@ -174,7 +179,8 @@ class _RenderNeuS(torch.autograd.Function):
             p.grad = None
         try:
             ctx.finish(up)
-            out = [p.grad for p in params]
+            # (zero-element parameters -- the SH encoding -- get their empty gradient: DDP waits for one from every parameter)
+            out = [p.grad if (p.grad is not None or p.numel() > 0) else torch.zeros_like(p) for p in params]
             ctx.step.release_gradient_buffers()  # (the small gradients are views of per-network buffers: they leave with them)
         finally:
             for p, g in zip(params, saved):
@@ -218,7 +224,7 @@ class FusedNeuSModel(HotPathState):
 
     def forward_(self, rays):
         bg = self.background_color if self.background_color is not None else torch.ones(3, device=rays.device)
-        params = [p for p in self.parameters() if p.numel() > 0]
+        params = [p for p in self.parameters() if p.requires_grad or p.numel() > 0]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         full, rgb, opacity, depth, weights, sdf, sdf_grad, lap = _RenderNeuS.apply(self, need_grad, rays, bg, *params)
         last = self._last

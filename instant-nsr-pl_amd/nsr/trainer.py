@@ -555,6 +555,13 @@ class Trainer:
     def _train_step_async(self):
         return self._train_step_async_graphable() if self.use_graphs else self._train_step_async_ahead()
 
+    def _helper_stream(self):
+        """the C orchestration's helper stream (csrc/step.hip) as a torch stream, or None (NSR_ADAM_ON_MAIN: A/B switch)"""
+        if getattr(self, "_helper", None) is None and not os.environ.get("NSR_ADAM_ON_MAIN"):
+            ptr = _lib.nsr_nerf_helper_stream()
+            self._helper = torch.cuda.ExternalStream(ptr, device=self.device) if ptr else None
+        return getattr(self, "_helper", None)
+
     def _train_step_async_ahead(self):
         """The asynchronous step with the marching passes batched over the occupancy WINDOW.
 
@@ -646,9 +653,8 @@ class Trainer:
         rs = sets[t % W]
         model.background_color = rs["bg"]
 
-        def after_prune_queued(total):
-            e = torch.cuda.Event()
-            e.record(main)
+        def after_prune_queued(total, e):
+            # (called once the whole step is queued; ``e`` was recorded on the main stream right behind the pruning pass)
             # the ray-count update feeds only the NEXT step's packing: it runs on the side stream, off the main queue
             stream = side if self.pipeline_march else main
             with torch.cuda.stream(stream), torch.cuda.device(self.device):
@@ -673,7 +679,17 @@ class Trainer:
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            if fuse_table:
+            if fuse_table and self._helper_stream() is not None:
+                # what is left for the optimizer (the MLP weights: one launch that also advances the device-side schedule) runs
+                # on the main pass's helper stream, right behind the weight-gradient kernels it reads from -- underneath the
+                # table backward, off the step's own chain; the main stream only waits for its event
+                hs = self._helper
+                with torch.cuda.stream(hs):
+                    self.opt.step_device(skip_table_of=fused.ewn)
+                    ev_opt = a.setdefault("opt_events", [torch.cuda.Event() for _ in range(4)])[t % 4]
+                    ev_opt.record(hs)
+                main.wait_event(ev_opt)
+            elif fuse_table:
                 self.opt.step_device(skip_table_of=fused.ewn)
             else:
                 self._optimizer_step(True, exchanged=xchg is not None)
@@ -747,7 +763,7 @@ class Trainer:
                                   bricks=a["bricks"])
         model.background_color = rs["bg"]
 
-        def after_prune_queued(total):
+        def after_prune_queued(total, _pruned=None):
             with torch.cuda.device(self.device):
                 _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(a["n_rays"]),
                                                  int(self.train_num_samples) if dynamic else 0,
@@ -758,9 +774,10 @@ class Trainer:
                 return
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
-            ev = torch.cuda.Event()
-            ev.record(main)             # pruning pass + count update of THIS step; its main pass is queued later
-            self._side.wait_event(ev)
+            if _pruned is None:
+                _pruned = torch.cuda.Event()
+                _pruned.record(main)
+            self._side.wait_event(_pruned)  # pruning pass of THIS step (its main pass is queued behind it already)
             with torch.cuda.stream(self._side):
                 fused.march_async(a["sets"][1 - k], self.dataset, self.gen, a["n_rays"], a["m_cap"], stats_m,
                                   cfg["background_color"], bricks=a["bricks"])

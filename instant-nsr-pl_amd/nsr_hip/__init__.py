@@ -207,6 +207,9 @@ SIGNATURES = {
     "nsr_nerf_render_backward": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P],
     "nsr_nerf_main_pass_exchange": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _P],
     "nsr_hashgrid_owner_large_from": [_U],
+    "nsr_ray_march_rays_per_wave": [_U],
+    "nsr_ray_march_wave_mode": [ctypes.c_int],
+    "nsr_nerf_helper_stream": [],
     "nsr_hashgrid_owner_tune": [ctypes.c_int, ctypes.c_float],
     "nsr_hashgrid_owner_debug_map": [_GD, ctypes.c_int, _U, _U, ctypes.c_int, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_range": [_P, _P, _P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P],
@@ -256,7 +259,7 @@ SIGNATURES = {
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }
-_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_hashgrid_owner_first_unchunked_level": ctypes.c_uint32,
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_hashgrid_owner_first_unchunked_level": ctypes.c_uint32,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,

@@ -153,6 +153,19 @@ class Module(torch.nn.Module):
                f"dtype={self.dtype}, n_params={self.params.numel()}"
 
 
+class _WithEmptyParams(torch.autograd.Function):
+    """identity on ``y`` that makes the module's zero-element ``params`` part of the graph (its gradient: an empty tensor)"""
+
+    @staticmethod
+    def forward(ctx, y, params):
+        ctx.shape = params.shape
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g.new_zeros(ctx.shape, dtype=torch.float32)
+
+
 class Encoding(Module):
     def __init__(self, n_input_dims, encoding_config, seed=1337, dtype=None):
         self.n_input_dims = int(n_input_dims)
@@ -189,6 +202,10 @@ class Encoding(Module):
         x = self._prep(x)
         if self.kind == "sh":
             y = _ops.sh4_forward(x.detach())  # no gradient to directions (unused by the reference)
+            if torch.is_grad_enabled() and self.params.requires_grad:
+                # tcnn hands autograd a (zero-element) parameter gradient for parameter-free encodings too; DDP with
+                # find_unused_parameters=False (reference launch.py:93-107) waits for one from EVERY parameter
+                y = _WithEmptyParams.apply(y, self.params)
         else:
             y = _ops.grid_encode(x, self.params, self)
         return y if self.dtype == torch.float16 else y.to(self.dtype)

@@ -1,0 +1,39 @@
+"""Workload for the PMC passes behind bench.py's `roofline_secondary`: what BASELINE.json's north_star asks to be evidenced by
+rocprof -- HBM GB/s on the hash gather and MFMA utilisation on the fused fp16 MLP.  2^18 samples, the nerf-blender density
+network (HashGrid L16 T2^19 F2 -> 32 -> 64 -> 16): 20 launches each of the stand-alone encode (k_grid_forward_pair), the
+fused MLP forward, its backward (k_mlp_dgrad + the k_mlp_wgrad kernels) and the one-kernel encode -> MLP, on E1 (uniform) or
+E2 (ray-coherent) positions (argv[1]).  Prints the HIP-event medians of the same launches as JSON (argv[2] = out file).
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/ps -o s -- python tools/secondary_pmc.py E2
+"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "instant-nsr-pl_amd"), os.path.join(ROOT, "tools")]
+import torch
+import nsr_hip
+from nsr_hip import ops
+from kernel_microbench import coherent, median_us
+
+if __name__ == "__main__":
+    kind = sys.argv[1] if len(sys.argv) > 1 else "E2"
+    n = 1 << 18
+    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
+    md = nsr_hip.make_mlp_desc(32, 16, 1, "none")
+    g = torch.Generator().manual_seed(0)
+    table = ((torch.rand(gd.n_entries * 2, generator=g) * 2 - 1) * 0.1).half().cuda()
+    w = (torch.randn(64 * 32 + 1024, generator=g) * 0.1).half().cuda()
+    x = coherent(n, per_ray=64) if kind == "E2" else torch.rand(n, 3, device="cuda")
+    dout = torch.randn(n, 16, device="cuda")
+    gw = torch.zeros(64 * 32 + 1024, device="cuda")
+    enc = ops.hashgrid_forward(x, table, gd)
+    out, acts = ops.mlp_forward(enc, w, md, save_acts=True)
+    res = {"kind": kind, "n": n,
+           "hashgrid_forward_us": median_us(lambda: ops.hashgrid_forward(x, table, gd), 5, 20),
+           "mlp_forward_us": median_us(lambda: ops.mlp_forward(enc, w, md, save_acts=True), 5, 20),
+           "mlp_backward_us": median_us(lambda: ops.mlp_backward(dout, out, enc, acts, w, md, grad_weights=gw, want_dx=True,
+                                                                 grad_scale=128.0), 5, 20),
+           "grid_mlp_forward_us": median_us(lambda: ops.grid_mlp_forward(x, table, w, gd, md), 5, 20)}
+    torch.cuda.synchronize()
+    if len(sys.argv) > 2:
+        json.dump(res, open(sys.argv[2], "w"))
+    print(json.dumps(res))
