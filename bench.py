@@ -189,11 +189,11 @@ def cpu_config0_step(cores, seconds_budget=5.0):
 
 def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
     """HBM-side bytes per launch of the dominant operation from the PMC passes of THIS round (tools/collect_profiles.sh ->
-    profiles/r03_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
+    profiles/r04_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
     run in) -- used only when a pass ran in the same regime (same warmup / steps, or its recorded samples per launch
     within 15 % of this run's); otherwise the field is null"""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"))
-                 if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json",
+                                                                         "r02_pmc_traffic.json")) if os.path.exists(q)), None)
     if path is None:
         return None, "no PMC file"
     pmc = json.load(open(path))
@@ -744,6 +744,42 @@ def main():
                             "item binning + accumulation only)", "avg_launch_us": 1e3 * ms_b / max(n_l, 1),
                     "samples_per_launch": prof_sep["_samples"] / max(n_l, 1), "achieved": ach_b,
                     "frac": ach_b / HBM_PEAK_GBS}
+        # what north_star asks to be evidenced beside the dominant kernel: HBM GB/s on the hash gather, MFMA utilisation on the
+        # fused fp16 MLP.  Durations are THIS run's HIP-event averages; counters come from the PMC passes of the round
+        # (tools/secondary_pmc.sh -> profiles/r04_secondary_pmc.json, 2^18 ray-coherent samples: labelled, never mixed into `value`)
+        secondary = None
+        try:
+            sp = os.path.join(ROOT, "profiles", "r04_secondary_pmc.json")
+            pm = json.load(open(sp))["E2"]["kernels"] if os.path.exists(sp) else {}
+            pick = lambda pre: next((v for k, v in pm.items() if k.startswith(pre)), {})  # noqa: E731
+            gk, fk, dk, wk = pick("k_grid_forward"), pick("k_mlp_forward"), pick("k_mlp_dgrad"), pick("k_mlp_wgrad")
+            secondary = {}
+            if "hashgrid_forward" in kern:
+                k = kern["hashgrid_forward"]
+                ach = ENC_FWD_BYTES_PER_SAMPLE * k["units_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
+                secondary["hash_gather"] = {
+                    "kernel": "k_grid_forward_pair", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_sample": ENC_FWD_BYTES_PER_SAMPLE,
+                    "samples_per_launch": k["units_per_launch"], "avg_launch_us": k["avg_us"],
+                    "pmc_2e18_coherent": {c: gk.get(c) for c in ("fetch_MB", "write_MB", "l2_hit_rate")} or None,
+                    "note": "588 B/sample counts every corner gather as if it came from HBM: the 24 MB table lives in the L2s / "
+                            "the Infinity Cache (PMC: fabric fetch per launch far below it), so the kernel is bound by L2 "
+                            "request rate, not by HBM"}
+            for name, key, pmk, flops in (("mlp_forward_density", "mlp_forward_h1", fk, 2 * (32 * 64 + 64 * 16)),
+                                          ("mlp_forward_color", "mlp_forward_h2", fk, 2 * (32 * 64 + 64 * 64 + 64 * 16))):
+                if key in kern:
+                    k = kern[key]
+                    tf = flops * k["units_per_launch"] / (k["avg_us"] * 1e-6) / 1e12
+                    secondary[name] = {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s (fp16 dense)",
+                                       "frac": tf / 2500.0, "avg_launch_us": k["avg_us"], "samples_per_launch": k["units_per_launch"],
+                                       "pmc_mfma_busy_per_wave_cycle": pmk.get("mfma_busy_per_wave_cycle"),
+                                       "note": "a 64-wide MLP moves 160-290 B per sample for 6-14 kFLOP: HBM-stream bound by two "
+                                               "orders of magnitude below the MFMA peak; the MFMA pipe's busy share is the PMC figure"}
+            secondary["mlp_backward_pmc_mfma_busy_per_wave_cycle"] = {"k_mlp_dgrad": dk.get("mfma_busy_per_wave_cycle"),
+                                                                      "k_mlp_wgrad": wk.get("mfma_busy_per_wave_cycle")}
+            secondary["pmc_source"] = "profiles/r04_secondary_pmc.json" if pm else None
+        except Exception as e:  # noqa: BLE001
+            secondary = {"error": repr(e)[:200]}
         res = {
             "metric": "hash-encoded MLP samples/sec, full training step (march + encode + MLP + composite, fwd+bwd, "
                       "AdamW), nerf-blender lego config",
@@ -764,7 +800,7 @@ def main():
             "transient": transient,
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
             "steady_state": steady,
-            "roofline": roof, "kernels": kern, "phase_ms_per_step": phases, "gradient_exchange": comm,
+            "roofline": roof, "roofline_secondary": secondary, "kernels": kern, "phase_ms_per_step": phases, "gradient_exchange": comm,
         }
         if shared_device:
             res["note"] = (f"{world} ranks SHARE one GPU over gloo (fewer GPUs than ranks on this box): a smoke run of the "

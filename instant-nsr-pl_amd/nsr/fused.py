@@ -21,7 +21,13 @@ _byref = ctypes.byref
 
 
 class FusedNeRFStep:
-    def __init__(self, model, early_stop_eps=1e-4, grad_scale=128.0, native=True):
+    def __init__(self, model, early_stop_eps=1e-4, grad_scale=None, native=True):
+        # the fp16 MLP backward scales dL/dy before it rounds it to fp16 (tcnn: loss_scale 128 ON TOP of Lightning's
+        # GradScaler(65536), configs/nerf-blender.yaml:103 -- 2^23 together).  The fused step has no GradScaler; with 128 alone
+        # the late-training gradients (loss ~1e-4 over ~25,000 colour values) sit at the fp16 subnormal edge
+        if grad_scale is None:
+            import os
+            grad_scale = float(os.environ.get("NSR_GRAD_SCALE", "65536"))
         self.native = native  # True: one C call per phase (csrc/step.hip); False: every launch issued from Python
         cfg = model.config
         if cfg["learned_background"] or not cfg["grid_prune"]:

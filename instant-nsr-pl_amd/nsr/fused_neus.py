@@ -152,6 +152,8 @@ class FusedNeuSStep:
         self.table_adam, self.adam_applied = None, set()
         # multi-GPU: {"fg": bf16 send buffer, "bg": ...} of nsr.parallel.ShardedAdamW -- the table backward writes the
         # exchange's transport format itself (no fp32 gradient, no cast); bf16_written: which of them a step really filled
+        # scale of dL/dy in front of the fp16 rounding of the fused colour MLP's backward (see nsr/fused.py: 128 alone costs 0.25 dB)
+        self.grad_scale = float(os.environ.get("NSR_GRAD_SCALE", "65536"))
         self.table_bf16, self.bf16_written = None, set()
         self.grad_written = set()  # tables whose fp32 .grad this step wrote (or cleared): the others' is a previous step's
         self.radius = float(cfg["radius"])
@@ -922,7 +924,7 @@ class FusedNeuSStep:
                 if tex.params.grad is None:
                     tex.params.grad = torch.zeros_like(tex.params)
                 d_tex = _ops.mlp_backward(d_rgb, rgb_raw, tex_in, acts2, w2, tex.mlp_desc, grad_weights=tex.params.grad,
-                                          want_dx=True, grad_scale=128.0)
+                                          want_dx=True, grad_scale=self.grad_scale)
             else:
                 td = self.tex.desc
                 d_tex = torch.empty((N, 32), dtype=F32, device=dev)
@@ -1199,6 +1201,11 @@ class NeuSTrainer:
                 model.occupancy_grid_bg.every_n_step(step=t, occ_eval_fn=self.fused.bg_occ_eval_fn,
                                                      occ_thre=cfg.get("grid_prune_occ_thre_bg", 0.01))
             refreshed = True
+            if self.world_size > 1:  # DDP's broadcast_buffers: every rank goes on with rank 0's grids
+                from .parallel import sync_occupancy_grid
+                sync_occupancy_grid(grid)
+                if self.fused.bg:
+                    sync_occupancy_grid(model.occupancy_grid_bg)
         if refreshed or (cfg["grid_prune"] and t % 16 == 0):
             self._pending = None  # marched through the old grid
         main = torch.cuda.current_stream()

@@ -50,6 +50,26 @@ def broadcast_parameters(module, src=0):
             m.invalidate()
 
 
+def sync_occupancy_grid(grid, src=0):
+    """every rank continues with rank ``src``'s occupancy grid.  The reference gets this from DDP (``broadcast_buffers=True``,
+    launch.py:93-107: rank 0's buffers -- the grid's ``occs`` / ``_binary`` among them -- are broadcast at every forward); the
+    ranks refresh their grids from identical weights, but the refresh draws random cells and jitters, and grids that drift
+    apart would march different sample sets through replicas that are supposed to see the same model.  Called behind every
+    refresh (each 16th step: 10 MB over xGMI); re-packs the 4^3-brick bitfield the marchers read."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    binary = grid._binary
+    u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
+    dist.broadcast(grid.occs, src=src)
+    dist.broadcast(u8, src=src)
+    tag = getattr(binary, "_nsr_bricks", None)
+    if tag is not None and binary.is_cuda:  # the packed copy (a persistent buffer other code holds on to): re-pack in place
+        from nsr_hip import check, lib, ptr, stream_ptr
+        rx, ry, rz = (int(v) for v in binary.shape)
+        with torch.cuda.device(binary.device):
+            check(lib.nsr_grid_pack_bricks(ptr(u8), rx, ry, rz, ptr(tag[2]), stream_ptr()), "nsr_grid_pack_bricks")
+
+
 HALF_TRANSPORT_SCALE = 1024.0
 
 

@@ -19,7 +19,7 @@ import tinycudann as tcnn
 from nsr_hip import ops as _ops
 from nsr_hip import check as _check, lib as _lib, ptr as _ptr, stream_ptr as _stream_ptr
 
-from .parallel import ShardedAdamW, all_reduce_gradients, broadcast_parameters, shard_seed
+from .parallel import ShardedAdamW, all_reduce_gradients, broadcast_parameters, shard_seed, sync_occupancy_grid
 
 
 class FusedAdamW:
@@ -288,14 +288,19 @@ class Trainer:
         # (NSR_FORCE_SHARDED=1: take the multi-GPU exchange with a process group of ANY size -- a one-rank nccl group runs every
         # RCCL call of the path on a one-GPU box, tests/test_gpu_nccl_single_rank.py)
         if (world_size > 1 or os.environ.get("NSR_FORCE_SHARDED")) and not other and dist.is_initialized():
-            # the table is exchanged in NSR_EXCHANGE_GROUPS ranges cut at level boundaries (default 2: the five finest levels,
-            # launched first by the fused step, travel while the other eleven are still being accumulated)
+            # the table is exchanged in NSR_EXCHANGE_GROUPS (1..4) ranges cut at level boundaries (default 2: the five finest
+            # levels, launched first by the fused step, travel while the other eleven are still being accumulated); the n - 1 cut
+            # levels: NSR_EXCHANGE_SPLIT_LEVELS (comma list), default 11 / 13,9 / 13,10,6 for 2 / 3 / 4 groups
             splits = {}
+            n_groups = max(1, min(4, int(os.environ.get("NSR_EXCHANGE_GROUPS", "2"))))
+            default_cuts = {1: [], 2: [11], 3: [13, 9], 4: [13, 10, 6]}[n_groups]
+            env_cuts = os.environ.get("NSR_EXCHANGE_SPLIT_LEVELS", os.environ.get("NSR_EXCHANGE_SPLIT_LEVEL", ""))
+            cuts = [int(v) for v in env_cuts.split(",") if v.strip()][:n_groups - 1] if env_cuts else default_cuts
             for m in tc:
                 gd = getattr(m, "grid_desc", None)
-                if gd is not None and int(os.environ.get("NSR_EXCHANGE_GROUPS", "2")) > 1:
-                    lv = min(int(os.environ.get("NSR_EXCHANGE_SPLIT_LEVEL", "11")), gd.n_levels - 1)
-                    splits[m] = [int(gd.offset[lv]) * int(gd.n_features)]
+                if gd is not None and cuts:
+                    lvs = sorted({min(max(c, 1), gd.n_levels - 1) for c in cuts})
+                    splits[m] = [int(gd.offset[lv]) * int(gd.n_features) for lv in lvs]
             self.sharded = ShardedAdamW(tc, splits=splits)
             guard_stale_state_dict(model, self.sharded)
         self.comm_timings = None
@@ -447,6 +452,8 @@ class Trainer:
         pending, self._pending = getattr(self, "_pending", None), None
         with _ops.timed("phase:occupancy_update"):
             model.update_step(0, self.global_step)
+            if self.world_size > 1 and cfg["grid_prune"] and self.global_step % 16 == 0:
+                sync_occupancy_grid(model.occupancy_grid)
         if pending is None:
             with _ops.timed("phase:sample_rays"):
                 rays, ro, rd, rgb, fg, bg, t_min, t_max = prepare_train_rays(
@@ -585,8 +592,12 @@ class Trainer:
                 _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # first packing (cached afterwards)
                 if t % 16 == 0:
                     fused.refresh_occupancy_async(t, a["bricks"])
+                    if self.world_size > 1:
+                        sync_occupancy_grid(model.occupancy_grid)  # (DDP's broadcast_buffers: rank 0's grid everywhere)
             else:
                 model.update_step(0, t)
+                if self.world_size > 1 and cfg["grid_prune"] and t % 16 == 0:
+                    sync_occupancy_grid(model.occupancy_grid)
         _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # re-packed in place after a grid refresh
         main = torch.cuda.current_stream()
         if self._side is None:

@@ -55,9 +55,14 @@ def main():
         assert tr.sharded is not None, "multi-rank trainers exchange the tables through ShardedAdamW"
         first = digests(model)
         counts = []
-        for _ in range(6):
+        for _ in range(6 if not name.endswith("-async") else 20):  # (the asynchronous run crosses a grid refresh at step 16)
             counts.append(int(tr.train_step()["n_samples"]))
         torch.cuda.synchronize()
+        # the occupancy grids are synchronised behind every refresh (DDP broadcast_buffers semantics): identical on all ranks
+        gsum = torch.stack([model.occupancy_grid._binary.sum().double(), model.occupancy_grid.occs.double().sum()])
+        gall = [torch.empty_like(gsum) for _ in range(world)]
+        dist.all_gather(gall, gsum)
+        assert all(torch.equal(g, gall[0]) for g in gall), "occupancy grids drifted apart between the ranks"
         mine = digests(model)
         groups = None
         if name.endswith("-async"):

@@ -1,4 +1,4 @@
 cd /root/repo
-HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29533 tests/entry_protocol_worker.py > /tmp/w.log 2>&1
-grep -n "rank0\]:" /tmp/w.log | head -30 | cut -c1-400
-grep "ENTRY_PROTOCOL_REPORT" /tmp/w.log | cut -c1-3000
+mkdir -p gpurun_out/r04
+timeout 1500 python bench.py > gpurun_out/r04/bench_default.json 2> gpurun_out/r04/bench_default.err; tail -c 400 gpurun_out/r04/bench_default.json; echo
+bash tools/secondary_pmc.sh r04 2>&1 | tail -40

@@ -25,10 +25,18 @@ if __name__ == "__main__":
     x = coherent(n, per_ray=64) if kind == "E2" else torch.rand(n, 3, device="cuda")
     dout = torch.randn(n, 16, device="cuda")
     gw = torch.zeros(64 * 32 + 1024, device="cuda")
-    enc = ops.hashgrid_forward(x, table, gd)
+    import ctypes
+    from nsr_hip import check, lib, ptr, stream_ptr
+    enc = (torch.randn(n, 32, device="cuda") * 0.1).half()  # (not produced by the encode: its launches are what the counters average)
+    enc_lm = torch.empty(16 * n * 2, dtype=torch.float16, device="cuda")
     out, acts = ops.mlp_forward(enc, w, md, save_acts=True)
+
+    def encode_level_major():  # the layout the training step's encode writes ([L][n][F]: csrc/step.hip nsr_nerf_prune_pass)
+        check(lib.nsr_hashgrid_forward_ex(ptr(x), ptr(table), ptr(enc_lm), n, 32, 1, 16, ctypes.byref(gd), None, stream_ptr()),
+              "nsr_hashgrid_forward_ex")
+
     res = {"kind": kind, "n": n,
-           "hashgrid_forward_us": median_us(lambda: ops.hashgrid_forward(x, table, gd), 5, 20),
+           "hashgrid_forward_us": median_us(encode_level_major, 5, 20),
            "mlp_forward_us": median_us(lambda: ops.mlp_forward(enc, w, md, save_acts=True), 5, 20),
            "mlp_backward_us": median_us(lambda: ops.mlp_backward(dout, out, enc, acts, w, md, grad_weights=gw, want_dx=True,
                                                                  grad_scale=128.0), 5, 20),
