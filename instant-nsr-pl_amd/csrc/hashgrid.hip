@@ -801,9 +801,15 @@ struct OwnTune {
 };
 static OwnTune g_own_tune = {2, 1.0f, 3.0f, 11u, 64u, 1u};
 
+#ifndef NSR_OWN_SMALL_LOG2
+#define NSR_OWN_SMALL_LOG2 11
+#endif
+#ifndef NSR_OWN_SMALL_BLOCK
+#define NSR_OWN_SMALL_BLOCK 256
+#endif
 namespace own_small {
-#define NSR_OWN_BLOCK 256
-#define NSR_OWN_LOG2 11
+#define NSR_OWN_BLOCK NSR_OWN_SMALL_BLOCK
+#define NSR_OWN_LOG2 NSR_OWN_SMALL_LOG2
 #include "hashgrid_owner.inc"
 #undef NSR_OWN_BLOCK
 #undef NSR_OWN_LOG2
