@@ -269,6 +269,16 @@ int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stri
                         const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                         uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
                         const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, void *wgrad_stream);
+/* The two halves of nsr_mlp_backward_split as separate calls: phases 1 = the dgrad kernel (it also saves what the
+ * weight-gradient kernels need in `partials`), 2 = the weight-gradient kernels + their reduction on `stream` (dout may be
+ * NULL), 3 = both on `stream`.  The fused NeRF step forks its helper stream once, behind the second network's dgrad. */
+int nsr_mlp_backward_phases(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                            const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                            uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
+                            float *grad_weights, float *dx, uint32_t dx_stride, uint32_t dx_level_major_features,
+                            float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, const int32_t *n_dev,
+                            void *stream, int phases);
+
 
 /* ------------------------------------------------------------------------------------------------
  * tcnn.NetworkWithInputEncoding -- models/network_utils.py:209-214 (HashGrid -> FullyFusedMLP, one flat parameter
@@ -614,6 +624,11 @@ typedef struct NsrNerfMainLayout {
 #define NSR_PROF_GRID_BACKWARD_BIN 6 /* item binning of the table backward, on the main pass's helper stream */
 /* the stream the main pass runs its overlapped work on (item binning, weight-gradient kernels); created on first use */
 void *nsr_nerf_helper_stream(void);
+/* `stream` waits for the point of the last main pass where its kept rows exist (behind nsr_nerf_main_pass*'s first kernel) */
+int nsr_nerf_wait_kept_rows(void *stream);
+/* on != 0: the main pass does not join its weight-gradient kernels itself -- the caller queues its optimizer launch behind
+ * them on nsr_nerf_helper_stream() and makes the step's stream wait for that.  Returns the previous setting. */
+int nsr_nerf_defer_wgrad_join(int on);
 void nsr_profile_enable(int on);
 int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches, uint64_t *units);
 
@@ -781,6 +796,15 @@ int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *exp_avg_a, f
                              double base_lr, double beta1, double beta2, double gamma, int32_t milestone0,
                              int32_t milestone1, int32_t milestone2, float eps, float weight_decay, float grad_unscale,
                              int zero_grad, void *stream);
+/* The same launch with the advanced schedule state written to (step_out, hyper12_out) instead of in place -- the other half
+ * of a double buffer: a kernel on another stream (the table backward's fused AdamW, NsrTableAdam) may read (step, hyper12)
+ * while this launch runs.  The ticket word stays in hyper12[8].  step_out == step && hyper12_out == hyper12: in place. */
+int nsr_adamw_step_scheduled_to(float *params_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a, nsr_half *shadow_a,
+                                uint64_t n_a, uint64_t zero_first_n_a, float *params_b, float *grad_b, float *exp_avg_b,
+                                float *exp_avg_sq_b, nsr_half *shadow_b, uint64_t n_b, int32_t *step, float *hyper12,
+                                int32_t *step_out, float *hyper12_out, double base_lr, double beta1, double beta2,
+                                double gamma, int32_t milestone0, int32_t milestone1, int32_t milestone2, float eps,
+                                float weight_decay, float grad_unscale, int zero_grad, void *stream);
 /* the one collective of the path is the mean all-reduce of the gradients; the 50 MB table
  * gradient travels as fp16 (dst = half(src * scale) before, dst = float(src) * scale after; nsr/parallel.py) */
 int nsr_scale_to_half(const float *src, nsr_half *dst, uint64_t n, float scale, void *stream);

@@ -20,6 +20,7 @@
 //     block meet through per-wave LDS regions and plain loads (NO LDS float atomics: ds_add_f32 retires 0.33 lane-ops
 //     per clock on gfx950), one fp32 partial per block, summed by k_reduce_partials.
 #include "nsr_common.h"
+#include <stdlib.h>
 #include "mlp_frag.h"
 
 namespace {
@@ -502,10 +503,12 @@ uint32_t n_params_of(const NsrMlpDesc *d) { return WIDTH * d->in_pad + (d->n_hid
 
 uint32_t bwd_blocks(uint32_t n)
 {
-    // wgrad: 32-sample tiles, ~2 tiles per wave, at most 512 blocks (one partial row each)
+    // wgrad: 32-sample tiles, ~2 tiles per wave, at most NSR_WGRAD_MAX_BLOCKS blocks (one partial row of the whole network's
+    // parameters each: 28 KB for 32 -> 64 -> 64 -> 16, written by the wgrad kernels and read back by k_reduce_partials)
+    static const uint32_t cap = getenv("NSR_WGRAD_MAX_BLOCKS") ? (uint32_t)atoi(getenv("NSR_WGRAD_MAX_BLOCKS")) : 512u;
     const uint32_t n_tiles = (n + 31) / 32;
     uint32_t nb = (n_tiles + WAVES * 2 - 1) / (WAVES * 2);
-    return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+    return nb < 1 ? 1 : (nb > cap ? cap : nb);
 }
 
 // workspace layout (floats): [partials: nb * n_params][gpre^T: n_hidden * 64 * ldn halfs][gout^T: 16 * ldn halfs]
@@ -603,12 +606,14 @@ static void launch_wgrad(const __half *GT, const void *A, int a_kind, uint32_t a
 // the dgrad kernel (they read what it saved, nothing downstream of dx reads what they write): a caller that only needs
 // dx to go on -- the next network's backward, the table backward -- keeps them off its critical path and joins
 // `wgrad_stream` before the optimizer.
-extern "C" int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
-                                      const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
-                                      uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
-                                      float *grad_weights, float *dx, uint32_t dx_stride,
-                                      uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
-                                      const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, void *wgrad_stream)
+// phases: 1 = the dgrad kernel (also saves the pre-activation gradients when grad_weights is given), 2 = the weight-gradient
+// kernels + their reduction (reading what a phase-1 call saved in `partials`), 3 = both
+static int mlp_backward_impl(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                             const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                             uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
+                             float *grad_weights, float *dx, uint32_t dx_stride, uint32_t dx_level_major_features,
+                             float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, const int32_t *n_dev,
+                             void *stream, void *wgrad_stream, int phases)
 {
     if (int rc = check_mlp(desc, "nsr_mlp_backward")) return rc;
     if (n == 0) return NSR_OK;
@@ -631,6 +636,7 @@ extern "C" int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_
     const uint32_t n_tiles = (n + 15) / 16;
     uint32_t blocks = (n_tiles + WAVES - 1) / WAVES;
     if (blocks > 2048) blocks = 2048;  // weights staged in LDS once per workgroup: the cap barely matters (256..2048 measured)
+    if (phases & 1)
     DISPATCH_MLP(in_pad / 16, nh, {
         constexpr int NP = WIDTH * KIN * 16 + (NH - 1) * WIDTH * WIDTH + 16 * WIDTH;
         const size_t lds = NP * sizeof(_Float16);
@@ -640,8 +646,8 @@ extern "C" int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_
                            (int)desc->output_activation, grad_scale, n_dev);
     });
     NSR_CHECK_LAUNCH("nsr_mlp_backward(dgrad)");
-    if (!grad_weights) return NSR_OK;
-    if (wgrad_stream && wgrad_stream != stream) {
+    if (!grad_weights || !(phases & 2)) return NSR_OK;
+    if ((phases & 1) && wgrad_stream && wgrad_stream != stream) {
         static hipEvent_t ring[8] = {};
         static unsigned next = 0;
         hipEvent_t &ev = ring[next++ & 7u];
@@ -680,6 +686,35 @@ extern "C" int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_
                        nb, 1.f / grad_scale);
     NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
     return NSR_OK;
+}
+
+extern "C" int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                                      const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                                      uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
+                                      float *grad_weights, float *dx, uint32_t dx_stride,
+                                      uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
+                                      const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, void *wgrad_stream)
+{
+    return mlp_backward_impl(dout, dout_is_f32, dout_stride, dout_extra_col0, out, x, x_is_f32, x_stride, x_level_major_features,
+                             acts, weights, grad_weights, dx, dx_stride, dx_level_major_features, partials, n, grad_scale, desc,
+                             n_dev, stream, wgrad_stream, 3);
+}
+
+// the two halves of nsr_mlp_backward_split as separate calls: `phases` 1 = dgrad (+ what the weight-gradient kernels need,
+// saved in `partials`), 2 = weight-gradient kernels + reduction on `stream`.  A step with two MLPs forks its helper stream
+// ONCE behind the second dgrad instead of once per network (an event record costs the issuing stream ~8 us: csrc/step.hip)
+extern "C" int nsr_mlp_backward_phases(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                                       const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                                       uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
+                                       float *grad_weights, float *dx, uint32_t dx_stride,
+                                       uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
+                                       const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, int phases)
+{
+    NSR_REQUIRE(phases >= 1 && phases <= 3, "nsr_mlp_backward_phases: phases must be 1, 2 or 3");
+    if (phases == 2 && n > 0) NSR_REQUIRE(x && acts && partials && grad_weights, "nsr_mlp_backward_phases: NULL pointer");
+    return mlp_backward_impl(phases == 2 ? (dout ? dout : x) : dout, dout_is_f32, dout_stride, dout_extra_col0, out, x, x_is_f32,
+                             x_stride, x_level_major_features, acts, weights, grad_weights, dx, dx_stride,
+                             dx_level_major_features, partials, n, grad_scale, desc, n_dev, stream, nullptr, phases);
 }
 
 extern "C" int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,

@@ -112,7 +112,7 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
 // beside the colour MLP / compositing / MLP backward chain instead of in front of the accumulation kernel.
 struct HelperStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr;
     bool ok = false;
     bool init()
     {
@@ -121,6 +121,7 @@ struct HelperStream {
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventCreateWithFlags(&join_wgrad, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork_wgrad, hipEventDisableTiming) != hipSuccess) return false;
         return ok = true;
     }
 };
@@ -129,6 +130,26 @@ static HelperStream g_helper;  // one per process (= per GPU: one process per GP
 // the helper stream's handle (created on first use), for callers that queue follow-up work behind the weight-gradient
 // kernels themselves (the trainer's optimizer launch for the MLP weights); NULL if it could not be created
 extern "C" void *nsr_nerf_helper_stream(void) { return g_helper.init() ? (void *)g_helper.stream : nullptr; }
+
+// `stream` waits for the point of the LAST main pass where the kept rows exist (the event the pass records for its own item
+// binning): what a caller queues behind the pruning pass on another stream -- the next step's ray count and packing -- can
+// hang on it instead of costing the main stream an event record of its own
+extern "C" int nsr_nerf_wait_kept_rows(void *stream)
+{
+    NSR_REQUIRE(g_helper.ok, "nsr_nerf_wait_kept_rows: no main pass has run");
+    NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_helper.fork, 0) == hipSuccess, "nsr_nerf_wait_kept_rows: hipStreamWaitEvent failed");
+    return NSR_OK;
+}
+
+// 1: the main pass leaves the join with its weight-gradient kernels to the caller, who queues more work behind them on the
+// helper stream (the optimizer launch) and makes the main stream wait for THAT instead -- one wait at the end of a step, not two
+static bool g_defer_wgrad_join = false;
+extern "C" int nsr_nerf_defer_wgrad_join(int on)
+{
+    const int old = g_defer_wgrad_join ? 1 : 0;
+    g_defer_wgrad_join = on != 0;
+    return old;
+}
 
 extern "C" int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marched, NsrNerfPruneLayout *out)
 {
@@ -359,6 +380,33 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         NSR_TRY(nsr_composite_backward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background,
                                                  weights, trans, comp_rgb, opacity, gt_rgb, acc, d->loss_scale, d_rgb,
                                                  d_logit, n_rays, stream));
+    // Every event a stream records costs IT ~8-10 us before its next kernel starts (the HIP-event scopes around the two dgrads
+    // read 37 us for 27 us kernels; with ONE fork for both networks' weight-gradient kernels, behind the second dgrad, 30 and
+    // 22 us).  Measured in the step, round 4: the single fork is nevertheless SLOWER (0.525 vs 0.505 ms) -- the colour
+    // network's kernels start 35 us later and the helper stream's chain (weight gradients, reductions, the optimizer launch)
+    // ends behind the table backward instead of underneath it.  So: one fork per network; NSR_WGRAD_ONE_FORK for A/B.
+    static const bool two_forks = getenv("NSR_WGRAD_ONE_FORK") == nullptr;
+    if (wg && !two_forks) {
+        {
+            ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
+            NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
+                                            32, 0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream, 1));
+        }
+        {
+            ProfScope p(NSR_PROF_MLP_BACKWARD_DENSITY, S, stream);
+            NSR_TRY(nsr_mlp_backward_phases(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
+                                            grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
+                                            &d->mlp_density, n_kept_dev, stream, 1));
+        }
+        NSR_REQUIRE(hipEventRecord(g_helper.fork_wgrad, st) == hipSuccess &&
+                        hipStreamWaitEvent(g_helper.stream, g_helper.fork_wgrad, 0) == hipSuccess,
+                    "nsr_nerf_main_pass: weight-gradient fork failed");
+        NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex, 32, 0,
+                                        part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, wg, 2));
+        NSR_TRY(nsr_mlp_backward_phases(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
+                                        grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
+                                        &d->mlp_density, n_kept_dev, wg, 2));
+    } else {
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
         NSR_TRY(nsr_mlp_backward_split(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
@@ -369,6 +417,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         NSR_TRY(nsr_mlp_backward_split(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
                                        grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
                                        &d->mlp_density, n_kept_dev, stream, wg));
+    }
     }
     if (xchg && xchg->event_small)  // the MLP weight gradients are final behind what is queued on their stream by now
         NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_small, wg ? g_helper.stream : st) == hipSuccess,
@@ -408,7 +457,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                        d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
         }
     }
-    if (wg)  // join: the optimizer step that follows on `stream` reads the MLP gradients
+    if (wg && !g_defer_wgrad_join)  // join: the optimizer step that follows on `stream` reads the MLP gradients
         NSR_REQUIRE(hipEventRecord(g_helper.join_wgrad, g_helper.stream) == hipSuccess &&
                         hipStreamWaitEvent(st, g_helper.join_wgrad, 0) == hipSuccess,
                     "nsr_nerf_main_pass: weight-gradient join failed");

@@ -329,14 +329,16 @@ __device__ __forceinline__ void adamw_span(float *__restrict__ p, float *__restr
 }
 
 __global__ void __launch_bounds__(EW_BLOCK)
-k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *__restrict__ step, float *__restrict__ hyper /* 12 floats */,
+k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *step, float *hyper /* 12 floats */, int32_t *step_out, float *hyper_out,
                   double base_lr, double b1d, double b2d, double gamma, int32_t m0, int32_t m1, int32_t m2, float b1,
                   float b2, float eps, float wd, float unscale, int zero_grad)
 {
     __shared__ float hs[3];
     __shared__ double pws[2];
-    double *pw = reinterpret_cast<double *>(hyper + 4);
-    int32_t *pw_step = reinterpret_cast<int32_t *>(hyper + 3);
+    // the advanced schedule state goes to (step_out, hyper_out): the same words, or the other half of a double buffer when
+    // a kernel on ANOTHER stream (the table backward's fused AdamW) reads this step's state while this launch runs
+    double *pw = reinterpret_cast<double *>(hyper_out + 4);
+    int32_t *pw_step = reinterpret_cast<int32_t *>(hyper_out + 3);
     const int32_t s = *step + 1;
     if (threadIdx.x == 0) {
         float lr0, c1, c2;
@@ -357,9 +359,9 @@ k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *__restrict__ step, float *__res
         uint32_t *ticket = reinterpret_cast<uint32_t *>(hyper + 8);
         if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
             *ticket = 0;
-            *step = s;
+            *step_out = s;
             pw[0] = pws[0]; pw[1] = pws[1]; *pw_step = s;
-            hyper[0] = hs[0]; hyper[1] = hs[1]; hyper[2] = hs[2];
+            hyper_out[0] = hs[0]; hyper_out[1] = hs[1]; hyper_out[2] = hs[2];
         }
     }
 }
@@ -518,15 +520,17 @@ extern "C" int nsr_adam_tick(int32_t *step, float *hyper, double base_lr, double
     return NSR_OK;
 }
 
-extern "C" int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a,
-                                        nsr_half *shadow_a, uint64_t n_a, uint64_t zero_first_n_a, float *params_b,
-                                        float *grad_b, float *exp_avg_b, float *exp_avg_sq_b, nsr_half *shadow_b,
-                                        uint64_t n_b, int32_t *step, float *hyper12, double base_lr, double beta1,
-                                        double beta2, double gamma, int32_t milestone0, int32_t milestone1,
-                                        int32_t milestone2, float eps, float weight_decay, float grad_unscale,
-                                        int zero_grad, void *stream)
+extern "C" int nsr_adamw_step_scheduled_to(float *params_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a,
+                                           nsr_half *shadow_a, uint64_t n_a, uint64_t zero_first_n_a, float *params_b,
+                                           float *grad_b, float *exp_avg_b, float *exp_avg_sq_b, nsr_half *shadow_b,
+                                           uint64_t n_b, int32_t *step, float *hyper12, int32_t *step_out,
+                                           float *hyper12_out, double base_lr, double beta1, double beta2, double gamma,
+                                           int32_t milestone0, int32_t milestone1, int32_t milestone2, float eps,
+                                           float weight_decay, float grad_unscale, int zero_grad, void *stream)
 {
     NSR_REQUIRE(step && hyper12 && ((uintptr_t)hyper12 & 7u) == 0, "nsr_adamw_step_scheduled: step / hyper (8-byte aligned)");
+    NSR_REQUIRE(step_out && hyper12_out && ((uintptr_t)hyper12_out & 7u) == 0 && (step_out == step) == (hyper12_out == hyper12),
+                "nsr_adamw_step_scheduled: step_out / hyper_out (8-byte aligned; both in place or both elsewhere)");
     NSR_REQUIRE(n_a > 0 && params_a && grad_a && exp_avg_a && exp_avg_sq_a, "nsr_adamw_step_scheduled: NULL pointer");
     NSR_REQUIRE(n_b == 0 || (params_b && grad_b && exp_avg_b && exp_avg_sq_b), "nsr_adamw_step_scheduled: NULL pointer");
     NSR_REQUIRE((((uintptr_t)params_a | (uintptr_t)grad_a | (uintptr_t)exp_avg_a | (uintptr_t)exp_avg_sq_a |
@@ -539,10 +543,24 @@ extern "C" int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *e
     uint64_t blocks = (n_a / 4 + EW_BLOCK - 1) / EW_BLOCK + 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adamw_scheduled, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, step,
-                       hyper12, base_lr, beta1, beta2, gamma, milestone0, milestone1, milestone2, (float)beta1,
+                       hyper12, step_out, hyper12_out, base_lr, beta1, beta2, gamma, milestone0, milestone1, milestone2, (float)beta1,
                        (float)beta2, eps, weight_decay, grad_unscale, zero_grad);
     NSR_CHECK_LAUNCH("nsr_adamw_step_scheduled");
     return NSR_OK;
+}
+
+extern "C" int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a,
+                                        nsr_half *shadow_a, uint64_t n_a, uint64_t zero_first_n_a, float *params_b,
+                                        float *grad_b, float *exp_avg_b, float *exp_avg_sq_b, nsr_half *shadow_b,
+                                        uint64_t n_b, int32_t *step, float *hyper12, double base_lr, double beta1,
+                                        double beta2, double gamma, int32_t milestone0, int32_t milestone1,
+                                        int32_t milestone2, float eps, float weight_decay, float grad_unscale,
+                                        int zero_grad, void *stream)
+{
+    return nsr_adamw_step_scheduled_to(params_a, grad_a, exp_avg_a, exp_avg_sq_a, shadow_a, n_a, zero_first_n_a, params_b,
+                                       grad_b, exp_avg_b, exp_avg_sq_b, shadow_b, n_b, step, hyper12, step, hyper12, base_lr,
+                                       beta1, beta2, gamma, milestone0, milestone1, milestone2, eps, weight_decay,
+                                       grad_unscale, zero_grad, stream);
 }
 
 extern "C" int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segments, float beta1, float beta2, float eps,

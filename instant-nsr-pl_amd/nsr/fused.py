@@ -46,6 +46,8 @@ class FusedNeRFStep:
         self.desc = nsr_hip.NsrNerfStepDesc(self.ewn.grid_desc, self.ewn.mlp_desc, self.tex.mlp_desc, self.radius,
                                             ContractionType.AABB.value, self.bias, self.eps, self.grad_scale, 1.0)
         self._PL, self._ML = nsr_hip.NsrNerfPruneLayout(), nsr_hip.NsrNerfMainLayout()
+        import os
+        self.kept_rows_event = not os.environ.get("NSR_PRUNED_EVENT")  # A/B switch: a torch event behind the pruning pass instead
 
     # ---- small launch helpers (all on torch's current stream) -------------------------------------------------
     def _positions(self, rays_o, rays_d, ri, t0, t1, want_dirs):
@@ -535,7 +537,7 @@ class FusedNeRFStep:
         return ab
 
     def forward_backward_async(self, rs, s_cap, kept_stats, loss_scale=1.0, compute_grads=True, after_prune_queued=None,
-                               table_adam=None, exchange=None):
+                               table_adam=None, exchange=None, defer_wgrad_join=False):
         """the training step on ray set ``rs`` (filled by march_async, possibly on another stream -- the caller orders
         the streams) with NO host synchronisation: the marched / kept sample counts stay on the device, all buffers
         have fixed capacities (rs['m_cap'], s_cap) and every kernel is launched for the capacity.
@@ -578,7 +580,7 @@ class FusedNeRFStep:
             # THIS event; the call itself comes after the main pass is queued -- the main stream must not sit idle behind the
             # pruning pass while the host issues side-stream launches (rocprofv3 timeline, round 3: pack ... 72 us ... copy_kept_rows)
             pruned = None
-            if after_prune_queued is not None:
+            if after_prune_queued is not None and not (compute_grads and self.kept_rows_event):
                 pruned = self._pruned_events[self._pruned_next] if hasattr(self, "_pruned_events") else None
                 if pruned is None:
                     self._pruned_events = [torch.cuda.Event() for _ in range(4)]
@@ -586,6 +588,8 @@ class FusedNeRFStep:
                     pruned = self._pruned_events[0]
                 self._pruned_next = (self._pruned_next + 1) % 4
                 pruned.record()
+            # (else: the main pass records an event of its own one kernel later, behind the kept-row copy -- the caller's side
+            # stream waits for that one, lib.nsr_nerf_wait_kept_rows: one event record less on the step's stream)
             if exchange is not None:
                 xd, g_density, g_color = exchange
                 with _ops.timed("fused:main_pass"):
@@ -602,15 +606,21 @@ class FusedNeRFStep:
                             p.grad = torch.zeros_like(p)
                 g1 = ewn.params.grad if compute_grads else None
                 g2 = tex.params.grad if compute_grads else None
-                check(lib.nsr_nerf_main_pass(_byref(d), ptr(ab["pws"]), m_cap, ptr(rs["packed"]), ptr(packed2),
-                                             ptr(mb["t0"]), ptr(mb["t1"]), ptr(rs["rd"]), ptr(rs["bg"]), ptr(rs["rgb"]),
-                                             ptr(w1), ptr(w2),
-                                             ptr(ewn.mlp_slice(g1)) if compute_grads else None,
-                                             ptr(ewn.grid_slice(g1)) if compute_grads else None,
-                                             ptr(g2) if compute_grads else None, ptr(ab["ws"]), int(s_cap), slots,
-                                             int(bool(compute_grads)), ptr(total), ptr(x01m),
-                                             _byref(table_adam) if (table_adam is not None and compute_grads) else None,
-                                             s), "nsr_nerf_main_pass")
+                if defer_wgrad_join:  # the caller joins the helper stream itself (behind more work it queues there)
+                    lib.nsr_nerf_defer_wgrad_join(1)
+                try:
+                    check(lib.nsr_nerf_main_pass(_byref(d), ptr(ab["pws"]), m_cap, ptr(rs["packed"]), ptr(packed2),
+                                                 ptr(mb["t0"]), ptr(mb["t1"]), ptr(rs["rd"]), ptr(rs["bg"]), ptr(rs["rgb"]),
+                                                 ptr(w1), ptr(w2),
+                                                 ptr(ewn.mlp_slice(g1)) if compute_grads else None,
+                                                 ptr(ewn.grid_slice(g1)) if compute_grads else None,
+                                                 ptr(g2) if compute_grads else None, ptr(ab["ws"]), int(s_cap), slots,
+                                                 int(bool(compute_grads)), ptr(total), ptr(x01m),
+                                                 _byref(table_adam) if (table_adam is not None and compute_grads) else None,
+                                                 s), "nsr_nerf_main_pass")
+                finally:
+                    if defer_wgrad_join:
+                        lib.nsr_nerf_defer_wgrad_join(0)
             if after_prune_queued is not None:
                 after_prune_queued(total, pruned)
             L, ws = ab["ML"], ab["ws"]

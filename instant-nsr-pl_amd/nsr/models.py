@@ -42,6 +42,18 @@ def _plain(cfg):
     return cfg
 
 
+def _fp16_backward_scale(model, under_autocast):
+    """scale of dL/dy in front of the fp16 rounding of the fused MLPs' backward.  tcnn multiplies by 128 ON TOP of what arrives
+    (its loss_scale for fp16 networks); under Lightning's precision-16 protocol what arrives already carries GradScaler's
+    65536.  So: 128 when the forward ran under autocast (that protocol: the scaler supplies the rest; 65536 here on top of it
+    overflows fp16), 65536 otherwise (no scaler in front: 128 alone leaves late-training gradients at the fp16 subnormal
+    edge, nsr/fused.py).  ``model.fp16_grad_scale`` (a float) overrides the choice."""
+    fixed = getattr(model, "fp16_grad_scale", None)
+    if fixed is not None:
+        return float(fixed)
+    return 128.0 if under_autocast else 65536.0
+
+
 class _RenderNeRF(torch.autograd.Function):
     """comp_rgb, opacity, depth, weights = render(rays, background; geometry params, texture params)"""
 
@@ -55,6 +67,7 @@ class _RenderNeRF(torch.autograd.Function):
         out, state = step.render_forward(rays.detach(), background.detach(), prepare_backward=need_grad)
         ctx.prepared = bool(need_grad)
         ctx.step, ctx.state = step, state
+        ctx.grad_scale = _fp16_backward_scale(model, torch.is_autocast_enabled())
         model._last = out  # the non-differentiable outputs (ray_indices, t_starts, t_ends, counts) for forward_()
         ctx.mark_non_differentiable(out["ray_indices"])
         return out["comp_rgb"], out["opacity"], out["depth"], out["weights"], out["ray_indices"]
@@ -65,6 +78,7 @@ class _RenderNeRF(torch.autograd.Function):
             raise RuntimeError("FusedNeRFModel: backward through a forward that ran without gradients enabled")
         if g_comp is None:  # the loss did not touch the colours: their upstream gradient is zero
             g_comp = torch.zeros((ctx.state["n_rays"], 3), device=ctx.state["ws"].device)
+        ctx.step.desc.grad_scale = ctx.grad_scale
         g1, g2 = ctx.step.render_backward(ctx.state, g_comp, g_opacity, g_depth, g_weights)
         ctx.state = None  # the workspaces go back to the allocator
         return (None, None, None, None, g1, g2) + tuple(g1.new_zeros(sh) for sh in ctx.empty_shapes)
@@ -162,6 +176,7 @@ class _RenderNeuS(torch.autograd.Function):
         res, finish = step.render(rays.detach(), background.detach(), bool(need_grad))
         model._last = res
         ctx.finish, ctx.params, ctx.step = finish, params, step
+        ctx.grad_scale = _fp16_backward_scale(model, torch.is_autocast_enabled())
         ctx.set_materialize_grads(False)  # outputs the loss never touched arrive as None, not as zero tensors
         outs = [res[k] if k in res else rays.new_zeros(0) for k in _RenderNeuS.KEYS]
         return tuple(outs)
@@ -178,6 +193,7 @@ class _RenderNeuS(torch.autograd.Function):
         for p in params:
             p.grad = None
         try:
+            ctx.step.grad_scale = ctx.grad_scale
             ctx.finish(up)
             # (zero-element parameters -- the SH encoding -- get their empty gradient: DDP waits for one from every parameter)
             out = [p.grad if (p.grad is not None or p.numel() > 0) else torch.zeros_like(p) for p in params]

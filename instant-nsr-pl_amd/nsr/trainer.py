@@ -44,7 +44,7 @@ class FusedAdamW:
         (table_update_desc with this step's lr): only their fp16 image is adopted, and the device-side step counter /
         running beta powers those kernels read are advanced"""
         self.step_count += 1
-        if updated_in_backward or getattr(self, "_step_dev", None) is not None:
+        if updated_in_backward or self._step_dev is not None:
             # (once the device-side counter exists it advances with EVERY step -- also one whose backward launched nothing
             # and whose tables therefore take the sweep below -- or its bias corrections would fall behind the host's)
             step_dev, hyper = self._device_schedule_state()
@@ -89,15 +89,27 @@ class FusedAdamW:
             shadow = self.state[m.params][2]
             shadow.copy_(m.params.data)
             m.adopt_shadow(shadow)
-        if getattr(self, "_step_dev", None) is not None:
-            self._step_dev.fill_(self.step_count)
-            self._hyper.zero_()  # (power cache keyed on a step that no longer matches: recomputed by the next launch)
+        if self._step_dev is not None:
+            self._step_bufs.fill_(self.step_count)
+            self._hyper_bufs.zero_()  # (power cache keyed on a step that no longer matches: recomputed by the next launch)
+
+    # the device-side schedule state is a DOUBLE buffer: ``step_device(other_stream_reads=True)`` writes the advanced state
+    # into the other half and flips, so that the table backward's fused AdamW (main stream) may read this step's half while
+    # the MLP launch that advances the schedule runs on the helper stream
+    @property
+    def _step_dev(self):
+        return None if getattr(self, "_step_bufs", None) is None else self._step_bufs[self._cur]
+
+    @property
+    def _hyper(self):
+        return None if getattr(self, "_step_bufs", None) is None else self._hyper_bufs[self._cur]
 
     def _device_schedule_state(self):
         dev = self.tcnn_modules[0].params.device
-        if getattr(self, "_step_dev", None) is None:
-            self._step_dev = torch.tensor([self.step_count], dtype=torch.int32, device=dev)
-            self._hyper = torch.zeros(12, dtype=torch.float32, device=dev)  # lr, bc1, bc2 | running beta powers | ticket
+        if getattr(self, "_step_bufs", None) is None:
+            self._cur = 0
+            self._step_bufs = torch.full((2, 4), self.step_count, dtype=torch.int32, device=dev)[:, :1]
+            self._hyper_bufs = torch.zeros(2, 16, dtype=torch.float32, device=dev)[:, :12]  # lr, bc1, bc2 | running beta powers | ticket
         return self._step_dev, self._hyper
 
     def table_update_desc(self, module, milestones=(10000, 15000, 18000), gamma=0.33, lr=None):
@@ -121,7 +133,7 @@ class FusedAdamW:
         d.eps, d.weight_decay = float(self.eps), float(self.wd)
         return d
 
-    def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33, skip_table_of=None):
+    def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33, skip_table_of=None, other_stream_reads=False):
         """the same update with the step counter, MultiStepLR scale and bias corrections kept ON THE DEVICE
         (nsr_adam_tick): no per-step host scalar, so the launches can be replayed from a captured graph"""
         if self.other is not None:
@@ -136,11 +148,17 @@ class FusedAdamW:
             assert len(rest) <= 1 and n0 > 0 and n0 % 4 == 0
             segs = [tuple(t[:n0] for t in (m0.params.data, m0.params.grad) + tuple(self.state[m0.params])) + (0,)]
             segs += [(m.params.data, m.params.grad) + tuple(self.state[m.params]) + (0,) for m in rest]
+            out = None
+            if other_stream_reads:
+                out = (self._step_bufs[self._cur ^ 1], self._hyper_bufs[self._cur ^ 1])
             _ops.adamw_step_scheduled(segs, self._step_dev, self._hyper, self.lr, self.betas[0], self.betas[1], gamma,
-                                      milestones, self.eps, self.wd)
+                                      milestones, self.eps, self.wd, out=out)
+            if other_stream_reads:
+                self._cur ^= 1
             for m in self.tcnn_modules:
                 m.adopt_shadow(self.state[m.params][2])
             return
+        assert not other_stream_reads
 
         def zero_n(m):  # the fused step overwrites the hash-table slice of the gradient: zero only the MLP slice in front
             n_zero = getattr(m, "n_network_params", 0) if getattr(m, "grid_desc", None) is not None else 0
@@ -669,7 +687,10 @@ class Trainer:
             # the ray-count update feeds only the NEXT step's packing: it runs on the side stream, off the main queue
             stream = side if self.pipeline_march else main
             with torch.cuda.stream(stream), torch.cuda.device(self.device):
-                stream.wait_event(e)
+                if e is not None:
+                    stream.wait_event(e)
+                elif stream is not main:  # the main pass's own event behind its kept-row copy (csrc/step.hip)
+                    _check(_lib.nsr_nerf_wait_kept_rows(_stream_ptr()), "nsr_nerf_wait_kept_rows")
                 _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(a["n_rays"]),
                                                  int(self.train_num_samples) if dynamic else 0,
                                                  int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), _stream_ptr()),
@@ -685,7 +706,9 @@ class Trainer:
         xchg = self._exchange() if (self.sharded is not None and not os.environ.get("NSR_EXCHANGE_UNFUSED")) else None
         res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued,
                                            table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None,
-                                           exchange=(xchg["desc"], xchg["g_density"], xchg["g_color"]) if xchg else None)
+                                           exchange=(xchg["desc"], xchg["g_density"], xchg["g_color"]) if xchg else None,
+                                           # (this trainer joins the helper stream itself, behind its optimizer launch)
+                                           defer_wgrad_join=bool(fuse_table and self._helper_stream() is not None))
         a["total_kept"] = res["num_samples"]
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
@@ -696,7 +719,7 @@ class Trainer:
                 # table backward, off the step's own chain; the main stream only waits for its event
                 hs = self._helper
                 with torch.cuda.stream(hs):
-                    self.opt.step_device(skip_table_of=fused.ewn)
+                    self.opt.step_device(skip_table_of=fused.ewn, other_stream_reads=True)
                     ev_opt = a.setdefault("opt_events", [torch.cuda.Event() for _ in range(4)])[t % 4]
                     ev_opt.record(hs)
                 main.wait_event(ev_opt)

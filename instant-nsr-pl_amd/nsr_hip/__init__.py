@@ -149,6 +149,7 @@ SIGNATURES = {
     "nsr_mlp_backward": [_P, _I, _U, _P, _P, _I, _U, _P, _P, _P, _P, _U, _P, _U, _F, _MD, _P],
     "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P],
     "nsr_mlp_backward_split": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P, _P],
+    "nsr_mlp_backward_phases": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P, _I],
     "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P, _P],
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_copy_ray_prefixes": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
@@ -210,6 +211,8 @@ SIGNATURES = {
     "nsr_ray_march_rays_per_wave": [_U],
     "nsr_ray_march_wave_mode": [ctypes.c_int],
     "nsr_nerf_helper_stream": [],
+    "nsr_nerf_wait_kept_rows": [_P],
+    "nsr_nerf_defer_wgrad_join": [ctypes.c_int],
     "nsr_hashgrid_owner_tune": [ctypes.c_int, ctypes.c_float],
     "nsr_hashgrid_owner_debug_map": [_GD, ctypes.c_int, _U, _U, ctypes.c_int, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_range": [_P, _P, _P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P],
@@ -228,6 +231,8 @@ SIGNATURES = {
     "nsr_adam_tick": [_P, _P, _D, _D, _D, _D, _I, _I, _I, _P],
     "nsr_adamw_step_scheduled": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _D, _D, _D, _D, _I, _I,
                                  _I, _F, _F, _F, _I, _P],
+    "nsr_adamw_step_scheduled_to": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _D, _D, _D, _D,
+                                    _I, _I, _I, _F, _F, _F, _I, _P],
     "nsr_vmlp_blob_floats": [_VD],
     "nsr_vmlp_backward_workspace_floats": [_VD, _U],
     "nsr_vmlp_forward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _U, _U, _P, _P],

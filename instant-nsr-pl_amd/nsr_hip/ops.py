@@ -768,20 +768,23 @@ def adamw_step(params, grad, exp_avg, exp_avg_sq, shadow_half, lr, beta1, beta2,
 
 
 def adamw_step_scheduled(tensors, step_dev, hyper12, base_lr, beta1, beta2, gamma, milestones, eps, weight_decay,
-                         grad_unscale=1.0, zero_grad=True):
+                         grad_unscale=1.0, zero_grad=True, out=None):
     """``adam_tick`` + ``adamw_step`` over one or two tensors in ONE launch (bit-identical).  ``tensors``: list of
-    (params, grad, exp_avg, exp_avg_sq, shadow_half, zero_first_n); ``hyper12``: 12 zero-initialised floats"""
+    (params, grad, exp_avg, exp_avg_sq, shadow_half, zero_first_n); ``hyper12``: 12 zero-initialised floats; ``out``:
+    (step_dev, hyper12) that receive the advanced schedule state (default: in place)"""
     assert 1 <= len(tensors) <= 2 and hyper12.numel() >= 12
+    step_out, hyper_out = out if out is not None else (step_dev, hyper12)
     ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
     a = tensors[0]
     b = tensors[1] if len(tensors) == 2 else (None,) * 5 + (0,)
     with torch.cuda.device(a[0].device):
-        check(lib.nsr_adamw_step_scheduled(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), a[0].numel(), int(a[5]),
-                                           ptr(b[0]), ptr(b[1]), ptr(b[2]), ptr(b[3]), ptr(b[4]),
-                                           0 if b[0] is None else b[0].numel(), ptr(step_dev), ptr(hyper12),
-                                           float(base_lr), float(beta1), float(beta2), float(gamma), ms[0], ms[1], ms[2],
-                                           float(eps), float(weight_decay), float(grad_unscale), int(zero_grad),
-                                           stream_ptr()), "nsr_adamw_step_scheduled")
+        check(lib.nsr_adamw_step_scheduled_to(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), a[0].numel(), int(a[5]),
+                                              ptr(b[0]), ptr(b[1]), ptr(b[2]), ptr(b[3]), ptr(b[4]),
+                                              0 if b[0] is None else b[0].numel(), ptr(step_dev), ptr(hyper12),
+                                              ptr(step_out), ptr(hyper_out),
+                                              float(base_lr), float(beta1), float(beta2), float(gamma), ms[0], ms[1], ms[2],
+                                              float(eps), float(weight_decay), float(grad_unscale), int(zero_grad),
+                                              stream_ptr()), "nsr_adamw_step_scheduled")
 
 
 def adam_tick(step_dev, hyper_dev, base_lr, beta1, beta2, gamma, milestones):

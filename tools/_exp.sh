@@ -1,16 +1,8 @@
 cd /root/repo
-NSR_VARIANT_SETTINGS=default NSR_VARIANT_DATA=build/step_inputs.pt timeout 900 python tools/table_backward_variants.py instant-nsr-pl_amd/nsr_hip/libnsr_hip.so build/variants/libnsr_hip_l10.so build/variants/libnsr_hip_l12.so build/variants/libnsr_hip_l10b128.so build/variants/libnsr_hip_l11b512.so > gpurun_out/tb_real8.jsonl 2> gpurun_out/tb_real8.err
-python - gpurun_out/tb_real8.jsonl <<'PY'
-import json, sys
-for ln in open(sys.argv[1]):
-    d = json.loads(ln)
-    if "error" in d: print(d); continue
-    print(d["lib"][-18:], d.get("setting"), {k.split("_")[0][:5] + k.split(":")[1]: (v["bin_us"], v["accumulate_us"], v["accumulate_adam_us"]) for k, v in d.items() if ":" in k})
-PY
-tail -2 gpurun_out/tb_real8.err
+timeout 600 python -m pytest tests/test_gpu_fused.py tests/test_gpu_resume.py -x -q 2>&1 | tail -2
 LEAN="--no-cpu-baseline --no-other-workloads --no-boundary-path"
-for v in base l10 l12; do
-  case $v in base) envs="A=1";; *) envs="NSR_HIP_LIB=/root/repo/build/variants/libnsr_hip_$v.so";; esac
-  env $envs NSR_BENCH_NO_STEADY=1 timeout 600 python bench.py --steps 200 --warmup 20 $LEAN 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],4), {k:round(v['avg_us'],1) for k,v in d['kernels'].items() if k.startswith('hashgrid')})"
+for v in new two_forks pruned_event adam_main; do
+  case $v in new) envs="A=1";; two_forks) envs="NSR_WGRAD_TWO_FORKS=1";; pruned_event) envs="NSR_PRUNED_EVENT=1";; adam_main) envs="NSR_ADAM_ON_MAIN=1";; esac
+  env $envs timeout 600 python bench.py --steps 200 --warmup 20 $LEAN 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],4), round(d['steady_state']['ms_per_step'],4), 'host', round(d['host_enqueue_ms_per_step'],3), {k:round(v['avg_us'],1) for k,v in d['kernels'].items() if k.startswith('hashgrid') or k.startswith('mlp_backward')}, d['final_loss'])"
 done
