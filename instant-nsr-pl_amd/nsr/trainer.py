@@ -727,8 +727,11 @@ class Trainer:
                 self.opt.step_device(skip_table_of=fused.ewn)
             else:
                 self._optimizer_step(True, exchanged=xchg is not None)
-        a["last_step_event"] = torch.cuda.Event()
-        a["last_step_event"].record(main)
+        if a["marched_upto"] < t + 1 or os.environ.get("NSR_STEP_EVENT_ALWAYS"):
+            # (only a step whose successor queues a marching launch on the side stream needs the marker -- an event record on
+            # the main stream costs ~9 us of the step's chain)
+            a["last_step_event"] = torch.cuda.Event()
+            a["last_step_event"].record(main)
         for key in [k for k in ev if k[1] < t - 2]:
             del ev[key]
         self.global_step += 1
