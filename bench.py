@@ -520,6 +520,8 @@ def main():
     ap.add_argument("--setup-steps", type=int, default=300,
                     help="untimed steps in front of the warm-up that bring the dynamic ray count / occupancy grid to the "
                          "operating point (8,192 rays per step)")
+    ap.add_argument("--burn-in-steps", type=int, default=1500,
+                    help="steps of a throwaway model in front of everything (box warm-up: libraries, clocks); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the C3 / C4 / C5 side measurements")
     ap.add_argument("--no-boundary-path", action="store_true", help="skip the step through nsr.models.FusedNeRFModel")
@@ -553,10 +555,21 @@ def main():
     from nsr.trainer import Trainer
     from nsr_hip import ops
 
-    torch.manual_seed(42)
     cfg = nsr.configs.get("nerf-blender")
-    model = nsr.build(cfg).to(dev).train()
     data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
+    if args.burn_in_steps > 0:
+        # a fresh box runs its first process slowly for the first second or so (libraries paging in, host and GPU clocks
+        # ramping: the same command line measured 0.63 ms/step as the first process on a box and 0.50 as the second): steps
+        # of a THROWAWAY model on the same data, before the measured model exists -- nothing of it is reused
+        torch.manual_seed(1)
+        tmp = Trainer(nsr.build(cfg).to(dev).train(), data, cfg, rank=0, world_size=1, seed=1, async_mode=not args.sync_steps)
+        for _ in range(args.burn_in_steps):
+            tmp.train_step()
+        torch.cuda.synchronize()
+        del tmp
+        torch.cuda.empty_cache()
+    torch.manual_seed(42)
+    model = nsr.build(cfg).to(dev).train()
     tr = Trainer(model, data, cfg, rank=rank, world_size=world, seed=42, async_mode=not args.sync_steps)
     tr.pipeline_march = not args.no_pipeline
     tr.use_graphs = args.graphs
@@ -791,7 +804,8 @@ def main():
                                    "100x800x800 views", "parallelism": f"ray-sharded dp{world}"},
             "train_rays_per_sec": n_rays / dt, "samples_per_step_per_gpu": n_samples / args.steps / world,
             "rays_per_step_per_gpu": n_rays / args.steps / world, "final_loss": final_loss,
-            "regime": {"setup_steps": args.setup_steps, "warmup_steps": args.warmup, "timed_steps": args.steps,
+            "regime": {"burn_in_steps_of_a_throwaway_model": args.burn_in_steps, "setup_steps": args.setup_steps,
+                       "warmup_steps": args.warmup, "timed_steps": args.steps,
                        "kept_samples_per_step": n_samples / args.steps / world,
                        "marched_samples_per_step": (n_marched / args.steps) if n_marched else None,
                        "rays_per_step": n_rays / args.steps / world,
@@ -816,8 +830,8 @@ def main():
             reg = dict(res["regime"], roofline_units_per_launch={k: v["units_per_launch"] for k, v in kern.items()
                                                                  if k.startswith("hashgrid")},
                        # per-step kernels: the dispatch ordinals of the 64 steps the per-kernel durations are taken on
-                       roofline_dispatch_window=[args.setup_steps + args.warmup + args.steps,
-                                                 args.setup_steps + args.warmup + args.steps + 64])
+                       roofline_dispatch_window=[args.burn_in_steps + args.setup_steps + args.warmup + args.steps,
+                                                 args.burn_in_steps + args.setup_steps + args.warmup + args.steps + 64])
             json.dump(reg, open(os.environ["NSR_BENCH_REGIME_OUT"], "w"))
         print(json.dumps(res))
     if world > 1:

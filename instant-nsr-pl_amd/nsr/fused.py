@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from nerfacc import ContractionType
-from nsr_hip import check, lib, ptr, stream_ptr
+from nsr_hip import check, device_guard, lib, ptr, stream_ptr
 from nsr_hip import ops as _ops
 
 F32, F16 = torch.float32, torch.float16
@@ -474,17 +474,19 @@ class FusedNeRFStep:
         if m_cap is not None:
             self.pack_async(rs, n_active if pack_masks else None, m_cap, stats)
 
-    def pack_async(self, rs, n_active, m_cap, stats):
+    def pack_async(self, rs, n_active, m_cap, stats, stream=None):
         """packed_info / total of ray set ``rs`` from its marched counts, clamped to ``m_cap``; slots >= n_active[0]
-        (device) keep nothing.  Separate from the marching pass so that the pass can run before the ray count exists."""
+        (device) keep nothing.  Separate from the marching pass so that the pass can run before the ray count exists.
+        ``stream``: raw stream pointer (default: the current stream)"""
         check(lib.nsr_pack_from_counts_capped(ptr(rs["counts"]), ptr(rs["packed"]), ptr(rs["total"]), rs["slots"],
-                                              int(m_cap), ptr(stats), ptr(n_active), stream_ptr()),
+                                              int(m_cap), ptr(stats), ptr(n_active),
+                                              stream if stream is not None else stream_ptr()),
               "nsr_pack_from_counts_capped")
         rs["m_cap"] = int(m_cap)
         if rs.get("marched") is not None:
             rs["marched"]["valid"] = False  # sample arrays of an earlier packing of this ring slot
 
-    def write_async(self, rs, consumer_stream=None):
+    def write_async(self, rs, consumer_stream=None, stream=None):
         """sample arrays of ray set ``rs`` (ray index, t_starts, t_ends, unit-cube positions of every marched sample) from
         its marching scratch + packed_info, into buffers that belong to the ring slot -- queued on the CURRENT stream right
         behind ``pack_async`` (the marching side stream), so the step itself starts at the hash encode.
@@ -502,8 +504,8 @@ class FusedNeRFStep:
                     mb[k].record_stream(consumer_stream)
         grid, d = self.model.occupancy_grid, self.desc
         rx, ry, rz = (int(v) for v in grid.binary.shape)
-        with torch.no_grad(), torch.cuda.device(dev):
-            s = stream_ptr()
+        with device_guard(dev):
+            s = stream if stream is not None else stream_ptr()
             check(lib.nsr_ray_march_bricks_write(ptr(rs["ro"]), ptr(rs["rd"]), ptr(rs["t_min"]), ptr(rs["t_max"]),
                                                  ptr(grid.roi_aabb), None, rx, ry, rz, ContractionType.AABB.value,
                                                  float(self.model.render_step_size), 0.0, ptr(rs["packed"]),
@@ -553,7 +555,7 @@ class FusedNeRFStep:
         ab = self._async_buffers(slots, m_cap, int(s_cap), dev)
         meta = ab["meta"]
         kept, packed2, total = meta[:slots], meta[slots:3 * slots].view(slots, 2), meta[3 * slots:]
-        with torch.no_grad(), torch.cuda.device(dev):
+        with torch.no_grad(), device_guard(dev):
             s = stream_ptr()
             grid = self.model.occupancy_grid
             rx, ry, rz = (int(v) for v in grid.binary.shape)
@@ -587,7 +589,7 @@ class FusedNeRFStep:
                     self._pruned_next = 0
                     pruned = self._pruned_events[0]
                 self._pruned_next = (self._pruned_next + 1) % 4
-                pruned.record()
+                pruned.record(torch.cuda.current_stream())
             # (else: the main pass records an event of its own one kernel later, behind the kept-row copy -- the caller's side
             # stream waits for that one, lib.nsr_nerf_wait_kept_rows: one event record less on the step's stream)
             if exchange is not None:

@@ -9,6 +9,7 @@ data-path collective is one mean all-reduce of the gradients per step over RCCL 
 counts, lagged capacity control), the marching passes two steps ahead on a side stream, the occupancy refresh on the
 device.  ``async_mode=False`` keeps the step that reads its counts back (and ``fused=False`` the modular autograd path).
 """
+import ctypes
 import os
 
 import torch
@@ -133,7 +134,8 @@ class FusedAdamW:
         d.eps, d.weight_decay = float(self.eps), float(self.wd)
         return d
 
-    def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33, skip_table_of=None, other_stream_reads=False):
+    def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33, skip_table_of=None, other_stream_reads=False,
+                    stream=None):
         """the same update with the step counter, MultiStepLR scale and bias corrections kept ON THE DEVICE
         (nsr_adam_tick): no per-step host scalar, so the launches can be replayed from a captured graph"""
         if self.other is not None:
@@ -152,7 +154,7 @@ class FusedAdamW:
             if other_stream_reads:
                 out = (self._step_bufs[self._cur ^ 1], self._hyper_bufs[self._cur ^ 1])
             _ops.adamw_step_scheduled(segs, self._step_dev, self._hyper, self.lr, self.betas[0], self.betas[1], gamma,
-                                      milestones, self.eps, self.wd, out=out)
+                                      milestones, self.eps, self.wd, out=out, stream=stream)
             if other_stream_reads:
                 self._cur ^= 1
             for m in self.tcnn_modules:
@@ -324,6 +326,10 @@ class Trainer:
         self.comm_timings = None
         # asynchronous single-GPU steps: AdamW on the table inside the table backward (NSR_TABLE_ADAM_SEPARATE: A/B switch)
         self.fuse_table_update = not os.environ.get("NSR_TABLE_ADAM_SEPARATE")
+        # developer A/B switches of the asynchronous step, read once (an environment lookup per step is host time)
+        self._write_inline = bool(os.environ.get("NSR_WRITE_INLINE"))
+        self._exchange_unfused = bool(os.environ.get("NSR_EXCHANGE_UNFUSED"))
+        self._step_event_always = bool(os.environ.get("NSR_STEP_EVENT_ALWAYS"))
         self.last = {}
         self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None
         # use_graphs: replay the queued launches of a step from a captured HIP graph.  Correct (tests/test_gpu_fused.py)
@@ -648,19 +654,21 @@ class Trainer:
             a["marched_upto"] = u1 - 1
 
         def queue_pack(u, stream):
-            with torch.cuda.stream(stream):
-                pruned = ev.get(("prune", u - 1))
-                if pruned is not None:
-                    stream.wait_event(pruned)  # the ray count of step u is final behind step u - 1's pruning pass
-                marched = ev.get(("march", u))
-                if marched is not None:
-                    stream.wait_event(marched)
-                fused.pack_async(sets[u % W], a["n_rays"], a["m_cap"], stats_m)
-                if stream is not main and not os.environ.get("NSR_WRITE_INLINE"):  # ... and the sample arrays + positions, off the step's own chain
-                    fused.write_async(sets[u % W], consumer_stream=main)
-                e = torch.cuda.Event()
-                e.record(stream)
-                ev[("pack", u)] = e
+            # (launches take the raw stream pointer, events their stream explicitly: a ``with torch.cuda.stream(...)`` block
+            # costs the host ~25 us per step in device-index / current-stream bookkeeping)
+            sp = ctypes.c_void_p(stream.cuda_stream)
+            pruned = ev.get(("prune", u - 1))
+            if pruned is not None:
+                stream.wait_event(pruned)  # the ray count of step u is final behind step u - 1's pruning pass
+            marched = ev.get(("march", u))
+            if marched is not None:
+                stream.wait_event(marched)
+            fused.pack_async(sets[u % W], a["n_rays"], a["m_cap"], stats_m, stream=sp)
+            if stream is not main and not self._write_inline:  # ... and the sample arrays + positions, off the step's own chain
+                fused.write_async(sets[u % W], consumer_stream=main, stream=sp)
+            e = torch.cuda.Event()
+            e.record(stream)
+            ev[("pack", u)] = e
             a["packed_upto"] = u
 
         def window_end(u):  # first step after u that marches through a NEW grid (exclusive end of u's window)
@@ -686,24 +694,24 @@ class Trainer:
             # (called once the whole step is queued; ``e`` was recorded on the main stream right behind the pruning pass)
             # the ray-count update feeds only the NEXT step's packing: it runs on the side stream, off the main queue
             stream = side if self.pipeline_march else main
-            with torch.cuda.stream(stream), torch.cuda.device(self.device):
-                if e is not None:
-                    stream.wait_event(e)
-                elif stream is not main:  # the main pass's own event behind its kept-row copy (csrc/step.hip)
-                    _check(_lib.nsr_nerf_wait_kept_rows(_stream_ptr()), "nsr_nerf_wait_kept_rows")
-                _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(a["n_rays"]),
-                                                 int(self.train_num_samples) if dynamic else 0,
-                                                 int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), _stream_ptr()),
-                       "nsr_update_ray_count")
-                e2 = torch.cuda.Event()
-                e2.record(stream)
+            sp = ctypes.c_void_p(stream.cuda_stream)
+            if e is not None:
+                stream.wait_event(e)
+            elif stream is not main:  # the main pass's own event behind its kept-row copy (csrc/step.hip)
+                _check(_lib.nsr_nerf_wait_kept_rows(sp), "nsr_nerf_wait_kept_rows")
+            _check(_lib.nsr_update_ray_count(_ptr(total), _ptr(a["n_rays"]),
+                                             int(self.train_num_samples) if dynamic else 0,
+                                             int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), sp),
+                   "nsr_update_ray_count")
+            e2 = torch.cuda.Event()
+            e2.record(stream)
             ev[("prune", t)] = e2  # "the ray count of step t + 1 is final"
             if self.pipeline_march and a["marched_upto"] >= t + 1 and a["packed_upto"] < t + 1:
                 queue_pack(t + 1, side)           # the only work between this pruning pass and the next one
 
         # one GPU: AdamW on the hash table happens inside the table backward (no gradient store / optimizer read-back)
         fuse_table = self.world_size == 1 and self.sharded is None and self.fuse_table_update
-        xchg = self._exchange() if (self.sharded is not None and not os.environ.get("NSR_EXCHANGE_UNFUSED")) else None
+        xchg = self._exchange() if (self.sharded is not None and not self._exchange_unfused) else None
         res = fused.forward_backward_async(rs, a["s_cap"], stats_s, after_prune_queued=after_prune_queued,
                                            table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None,
                                            exchange=(xchg["desc"], xchg["g_density"], xchg["g_color"]) if xchg else None,
@@ -718,16 +726,15 @@ class Trainer:
                 # on the main pass's helper stream, right behind the weight-gradient kernels it reads from -- underneath the
                 # table backward, off the step's own chain; the main stream only waits for its event
                 hs = self._helper
-                with torch.cuda.stream(hs):
-                    self.opt.step_device(skip_table_of=fused.ewn, other_stream_reads=True)
-                    ev_opt = a.setdefault("opt_events", [torch.cuda.Event() for _ in range(4)])[t % 4]
-                    ev_opt.record(hs)
+                self.opt.step_device(skip_table_of=fused.ewn, other_stream_reads=True, stream=ctypes.c_void_p(hs.cuda_stream))
+                ev_opt = a.setdefault("opt_events", [torch.cuda.Event() for _ in range(4)])[t % 4]
+                ev_opt.record(hs)
                 main.wait_event(ev_opt)
             elif fuse_table:
                 self.opt.step_device(skip_table_of=fused.ewn)
             else:
                 self._optimizer_step(True, exchanged=xchg is not None)
-        if a["marched_upto"] < t + 1 or os.environ.get("NSR_STEP_EVENT_ALWAYS"):
+        if a["marched_upto"] < t + 1 or self._step_event_always:
             # (only a step whose successor queues a marching launch on the side stream needs the marker -- an event record on
             # the main stream costs ~9 us of the step's chain)
             a["last_step_event"] = torch.cuda.Event()

@@ -305,7 +305,29 @@ def check(rc, what=""):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream of the current device as a void* (the raw accessors: ``torch.cuda.current_stream()`` costs the
+    host ~8 us per call -- device-index normalisation, an availability check that reads the environment, a Stream object)"""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(dev):
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already the current device (the context manager costs the host
+    ~10 us; a training process runs with its one device current)"""
+    idx = dev.index if isinstance(dev, torch.device) else int(dev)
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NO_GUARD
+    return torch.cuda.device(idx)
 
 
 def ptr(t):

@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import NsrError, check, lib, ptr, stream_ptr
+from . import NsrError, check, device_guard, lib, ptr, stream_ptr
 
 _byref = ctypes.byref
 F32, F16 = torch.float32, torch.float16
@@ -768,7 +768,7 @@ def adamw_step(params, grad, exp_avg, exp_avg_sq, shadow_half, lr, beta1, beta2,
 
 
 def adamw_step_scheduled(tensors, step_dev, hyper12, base_lr, beta1, beta2, gamma, milestones, eps, weight_decay,
-                         grad_unscale=1.0, zero_grad=True, out=None):
+                         grad_unscale=1.0, zero_grad=True, out=None, stream=None):
     """``adam_tick`` + ``adamw_step`` over one or two tensors in ONE launch (bit-identical).  ``tensors``: list of
     (params, grad, exp_avg, exp_avg_sq, shadow_half, zero_first_n); ``hyper12``: 12 zero-initialised floats; ``out``:
     (step_dev, hyper12) that receive the advanced schedule state (default: in place)"""
@@ -777,14 +777,14 @@ def adamw_step_scheduled(tensors, step_dev, hyper12, base_lr, beta1, beta2, gamm
     ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
     a = tensors[0]
     b = tensors[1] if len(tensors) == 2 else (None,) * 5 + (0,)
-    with torch.cuda.device(a[0].device):
+    with device_guard(a[0].device):
         check(lib.nsr_adamw_step_scheduled_to(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), a[0].numel(), int(a[5]),
                                               ptr(b[0]), ptr(b[1]), ptr(b[2]), ptr(b[3]), ptr(b[4]),
                                               0 if b[0] is None else b[0].numel(), ptr(step_dev), ptr(hyper12),
                                               ptr(step_out), ptr(hyper_out),
                                               float(base_lr), float(beta1), float(beta2), float(gamma), ms[0], ms[1], ms[2],
                                               float(eps), float(weight_decay), float(grad_unscale), int(zero_grad),
-                                              stream_ptr()), "nsr_adamw_step_scheduled")
+                                              stream if stream is not None else stream_ptr()), "nsr_adamw_step_scheduled")
 
 
 def adam_tick(step_dev, hyper_dev, base_lr, beta1, beta2, gamma, milestones):

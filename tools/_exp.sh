@@ -1,4 +1,11 @@
 #!/bin/bash
 cd /root/repo
-NSR_VARIANT_DATA=build/step_inputs.pt python tools/bin_variants.py build/variants/libnsr_hip_b256.so build/variants/libnsr_hip_b512.so build/variants/libnsr_hip_b1024.so build/variants/libnsr_hip_b512s.so build/variants/libnsr_hip_b1024s.so > gpurun_out/bin_variants.jsonl 2>&1
-cat gpurun_out/bin_variants.jsonl
+LEAN="--no-cpu-baseline --no-other-workloads --no-boundary-path"
+for i in 1 2 3; do
+python bench.py --gpus 1 --steps 20 --warmup 5 $LEAN > gpurun_out/bench_cold$i.json 2>gpurun_out/bench_cold$i.err
+python - $i <<'PY'
+import json,sys
+d=json.load(open('/root/repo/gpurun_out/bench_cold%s.json'%sys.argv[1]))
+print(sys.argv[1], {k:d[k] for k in ("value","ms_per_step","host_enqueue_ms_per_step")}, d["steady_state"]["ms_per_step"], d["transient"]["ms_per_step"], d["regime"]["kept_samples_per_step"])
+PY
+done
