@@ -152,7 +152,7 @@ class FusedNeuSStep:
         self.table_adam, self.adam_applied = None, set()
         # multi-GPU: {"fg": bf16 send buffer, "bg": ...} of nsr.parallel.ShardedAdamW -- the table backward writes the
         # exchange's transport format itself (no fp32 gradient, no cast); bf16_written: which of them a step really filled
-        # scale of dL/dy in front of the fp16 rounding of the fused colour MLP's backward (see nsr/fused.py: 128 alone costs 0.25 dB)
+        # scale of dL/dy in front of the fp16 rounding of the fused colour MLP's backward (see nsr/fused.py: tcnn's 128 sits on top of Lightning's GradScaler(65536); this step has no scaler)
         self.grad_scale = float(os.environ.get("NSR_GRAD_SCALE", "65536"))
         self.table_bf16, self.bf16_written = None, set()
         self.grad_written = set()  # tables whose fp32 .grad this step wrote (or cleared): the others' is a previous step's
