@@ -321,14 +321,18 @@ class Trainer:
                 if gd is not None and cuts:
                     lvs = sorted({min(max(c, 1), gd.n_levels - 1) for c in cuts})
                     splits[m] = [int(gd.offset[lv]) * int(gd.n_features) for lv in lvs]
-            self.sharded = ShardedAdamW(tc, splits=splits)
+            # NSR_TRANSPORT=fp32: the table gradient travels as fp32 (the A/B of the bf16 transport: tools/train_psnr.py at
+            # world 2); the backward then stores a dense fp32 gradient and the exchange takes it from there
+            fp32 = os.environ.get("NSR_TRANSPORT", "bf16") == "fp32"
+            self.sharded = ShardedAdamW(tc, splits=splits, transport=torch.float32 if fp32 else torch.bfloat16)
+            self._force_unfused_exchange = fp32
             guard_stale_state_dict(model, self.sharded)
         self.comm_timings = None
         # asynchronous single-GPU steps: AdamW on the table inside the table backward (NSR_TABLE_ADAM_SEPARATE: A/B switch)
         self.fuse_table_update = not os.environ.get("NSR_TABLE_ADAM_SEPARATE")
         # developer A/B switches of the asynchronous step, read once (an environment lookup per step is host time)
         self._write_inline = bool(os.environ.get("NSR_WRITE_INLINE"))
-        self._exchange_unfused = bool(os.environ.get("NSR_EXCHANGE_UNFUSED"))
+        self._exchange_unfused = bool(os.environ.get("NSR_EXCHANGE_UNFUSED")) or getattr(self, "_force_unfused_exchange", False)
         self._step_event_always = bool(os.environ.get("NSR_STEP_EVENT_ALWAYS"))
         self.last = {}
         self.fused, self._pending, self._side, self.pipeline_march, self._n_rays_dev = None, None, None, True, None

@@ -29,6 +29,15 @@ ap.add_argument("--seed", type=int, default=42)
 args = ap.parse_args()
 torch.manual_seed(args.seed)
 dev = torch.device("cuda", 0)
+# world > 1 (python -m torch.distributed.run --nproc-per-node 2 ... tools/train_psnr.py --path fused): ray-sharded data
+# parallel through the trainer's own exchange; on a box with fewer GPUs than ranks the ranks share cuda:0 over gloo (RCCL
+# refuses two ranks per device).  NSR_TRANSPORT=fp32|bf16 picks the table gradient's wire format.
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    import torch.distributed as dist
+    assert args.path == "fused", "the multi-rank run goes through nsr.trainer.Trainer"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo" if torch.cuda.device_count() < world else "nccl")
 cfg = nsr.configs.get("nerf-blender")
 train = SyntheticBlender(n_images=100, w=args.res, h=args.res, device=dev, seed=0)
 test = SyntheticBlender(n_images=args.test_views, w=args.res, h=args.res, device=dev, seed=12345)  # unseen cameras
@@ -38,7 +47,7 @@ extra = {}
 if args.path == "fused":
     from nsr.trainer import Trainer
     model = nsr.build(cfg).to(dev).train()
-    tr = Trainer(model, train, cfg, seed=args.seed, async_mode=True)
+    tr = Trainer(model, train, cfg, rank=rank, world_size=world, seed=args.seed, async_mode=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.train_step()
@@ -113,7 +122,12 @@ with torch.no_grad():
         gt = test.all_images[i].view(-1, 3) * fg + (1 - fg)
         mse = torch.mean((comp.to(dev).clamp(0, 1) - gt) ** 2)  # chunk_batch offloads to the CPU like the reference
         psnrs.append(float(-10.0 * torch.log10(mse)))
-print(json.dumps(dict({"path": args.path, "steps": args.steps, "seed": args.seed, "train_seconds": dt,
+if world > 1:
+    extra.update(world_size=world, transport=os.environ.get("NSR_TRANSPORT", "bf16"),
+                 note="samples / rays per second are rank 0's own; every rank draws its own rays")
+    dist.barrier()
+if rank == 0:
+  print(json.dumps(dict({"path": args.path, "steps": args.steps, "seed": args.seed, "train_seconds": dt,
                        "ms_per_step": 1e3 * dt / args.steps, "samples_per_sec": n_samples / dt, "rays_per_sec": n_rays / dt,
                        "final_train_loss": final_loss, "parameters_finite": params_finite,
                        "test_psnr": sum(psnrs) / len(psnrs), "test_psnr_per_view": psnrs, "test_res": args.res}, **extra)))
