@@ -297,6 +297,25 @@ int nsr_grid_mlp_supported(const NsrGridDesc *grid, const NsrMlpDesc *mlp);
 int nsr_grid_mlp_forward(const float *x, const nsr_half *table, const nsr_half *weights, nsr_half *out, nsr_half *acts,
                          nsr_half *enc, uint32_t enc_stride, int enc_level_major, uint32_t n, uint32_t level_mask_count,
                          const NsrGridDesc *grid, const NsrMlpDesc *mlp, const int32_t *n_dev, void *stream);
+/* The sigma pass of occupancy-grid ray marching (reference models/nerf.py:65-93: `sigma_fn` evaluated on every marched sample
+ * inside nerfacc.ray_marching, then the transmittance cut T >= early_stop_eps) as ONE ray-ordered kernel: a workgroup takes a
+ * ray and evaluates hash encode + density MLP on its samples 64 at a time, runs the visibility prefix of
+ * nsr_visibility_prefix on them and STOPS once the ray's transmittance fell below early_stop_eps -- the samples behind the cut
+ * (~60 % on a trained scene) are never encoded.  x: unit-cube positions of the marched samples [n_rows, 3] in ray order,
+ * packed_info (start, count) per ray, t_starts / t_ends [n_rows].  Outputs for the samples in front of (and in the 64-sample
+ * window that reaches) the cut, bit-identical to nsr_hashgrid_forward (level-major) + nsr_mlp_forward + nsr_visibility_prefix:
+ * enc level-major [L][n_rows][F] half, acts [n_hidden][n_rows][64] (may be NULL), out [n_rows, 16], kept_counts [n_rays].
+ * Rows behind the cut are left untouched.  Needs nsr_grid_mlp_supported(grid, mlp) and no output activation. */
+int nsr_sigma_rays(const float *x, const nsr_half *table, const nsr_half *weights, nsr_half *out, nsr_half *acts,
+                   nsr_half *enc, uint32_t n_rows, const int32_t *packed_info, const float *t_starts, const float *t_ends,
+                   float density_bias, float early_stop_eps, int32_t *kept_counts, uint32_t n_rays, const NsrGridDesc *grid,
+                   const NsrMlpDesc *mlp, void *stream);
+/* workgroups of a nsr_sigma_rays launch (persistent: ray r -> workgroup r mod blocks; default 768); 0 only queries */
+uint32_t nsr_sigma_rays_blocks(uint32_t blocks);
+/* which sigma pass nsr_nerf_prune_pass takes: 0 (default) the three stand-alone launches, 1 nsr_sigma_rays (measured slower on
+ * MI355X: its gathers lose the per-XCD level placement of the stand-alone encode); mode < 0 only
+ * queries.  Returns the previous mode. */
+int nsr_nerf_sigma_mode(int mode);
 uint32_t nsr_grid_mlp_forward_max_blocks(uint32_t max_blocks);
 /* Backward of the pair in one call: MLP data gradient written level-major (what the table backward reads: no transpose,
  * one trip through HBM), weight gradients (grad_weights fp32, ACCUMULATED, may be NULL), item binning + owner-computes

@@ -164,6 +164,21 @@ extern "C" int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marche
     return NSR_OK;
 }
 
+// the sigma pass of nsr_nerf_prune_pass: 0 (default) = stand-alone encode + MLP + visibility prefix over every marched sample,
+// 1 = the ray-ordered kernel that stops at the transmittance cut (nsr_sigma_rays).  Returns the previous mode.
+// Measured (tools/sigma_rays_bench.py, profiles/r04_sigma_rays_bench.json: ray sets of a trained model, 2.5e5 marched / 9.1e4
+// kept samples, 1.5e5 inside windows that reach their ray's cut): 85-87 us for the three launches, 109-121 us for the
+// ray-ordered kernel although it touches 60 % of the samples -- every wave of it gathers from all 16 levels (24 MB of table
+// against 4 MB of L2 per XCD: the gathers are served by the Infinity Cache), while the stand-alone encode keeps two levels per
+// XCD and hits its L2 94 % of the time.  The step: 0.569 vs 0.538 ms.  Kept as an entry point with its parity tests.
+static int g_sigma_rays = 0;
+extern "C" int nsr_nerf_sigma_mode(int mode)
+{
+    const int old = g_sigma_rays;
+    if (mode >= 0) g_sigma_rays = mode != 0;
+    return old;
+}
+
 extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
                                    const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                                    const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
@@ -183,18 +198,27 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
     if (!x01_marched)
         NSR_TRY(nsr_sample_positions_unit(rays_o, rays_d, ray_indices, t_starts, t_ends, d->radius, d->contraction,
                                           (float *)(ws + L.x01), nullptr, n_marched, n_marched_dev, stream));
-    {
+    if (g_sigma_rays && nsr_grid_mlp_supported(&d->grid, &d->mlp_density) &&
+        d->mlp_density.output_activation == NSR_ACT_NONE) {
+        // encode + density MLP + transmittance cut in ONE ray-ordered kernel that stops at each ray's cut (csrc/gridmlp.hip:
+        // ~40 % of the marched samples lie behind it); bit-identical kept counts / rows to the three launches below
         ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
-        NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
-                                        stream));
+        NSR_TRY(nsr_sigma_rays(x01, table, w_density, out1, acts1, enc, n_marched, packed_info, t_starts, t_ends,
+                               d->density_bias, d->early_stop_eps, kept_counts, n_rays, &d->grid, &d->mlp_density, stream));
+    } else {
+        {
+            ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
+            NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
+                                            stream));
+        }
+        {
+            ProfScope p(NSR_PROF_MLP_FORWARD_DENSITY, n_marched, stream);
+            NSR_TRY(nsr_mlp_forward_ex(enc, 0, C, d->grid.n_features, w_density, out1, acts1, n_marched, &d->mlp_density,
+                                       n_marched_dev, stream));
+        }
+        NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
+                                      kept_counts, n_rays, stream));
     }
-    {
-        ProfScope p(NSR_PROF_MLP_FORWARD_DENSITY, n_marched, stream);
-        NSR_TRY(nsr_mlp_forward_ex(enc, 0, C, d->grid.n_features, w_density, out1, acts1, n_marched, &d->mlp_density,
-                                   n_marched_dev, stream));
-    }
-    NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
-                                  kept_counts, n_rays, stream));
     NSR_TRY(nsr_pack_from_counts_capped(kept_counts, packed_kept, total_kept, n_rays, kept_capacity, kept_stats, nullptr,
                                         stream));
     return NSR_OK;

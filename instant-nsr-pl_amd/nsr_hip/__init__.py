@@ -231,6 +231,9 @@ SIGNATURES = {
     "nsr_adam_tick": [_P, _P, _D, _D, _D, _D, _I, _I, _I, _P],
     "nsr_adamw_step_scheduled": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _D, _D, _D, _D, _I, _I,
                                  _I, _F, _F, _F, _I, _P],
+    "nsr_sigma_rays": [_P, _P, _P, _P, _P, _P, _U, _P, _P, _P, _F, _F, _P, _U, _GD, _MD, _P],
+    "nsr_nerf_sigma_mode": [_I],
+    "nsr_sigma_rays_blocks": [_U],
     "nsr_adamw_step_scheduled_to": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _D, _D, _D, _D,
                                     _I, _I, _I, _F, _F, _F, _I, _P],
     "nsr_vmlp_blob_floats": [_VD],
@@ -297,6 +300,13 @@ lib = load_library()
 # (nsr_hashgrid_owner_tune; e.g. "0=0" = the round-3 placement of the work units)
 for _kv in filter(None, os.environ.get("NSR_OWN_TUNE", "").split(",")):
     lib.nsr_hashgrid_owner_tune(int(_kv.split("=")[0]), float(_kv.split("=")[1]))
+
+
+# NSR_SIGMA_MODE=0: the sigma pass of the NeRF step as three stand-alone launches (A/B switch for nsr_nerf_sigma_mode)
+if os.environ.get("NSR_SIGMA_MODE") is not None:
+    lib.nsr_nerf_sigma_mode(int(os.environ["NSR_SIGMA_MODE"]))
+if os.environ.get("NSR_SIGMA_BLOCKS"):
+    lib.nsr_sigma_rays_blocks(int(os.environ["NSR_SIGMA_BLOCKS"]))
 
 
 def check(rc, what=""):
