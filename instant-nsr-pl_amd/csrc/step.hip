@@ -76,6 +76,34 @@ struct ProfScope {
 };
 }  // namespace
 
+// ---- opt-in HOST timing of the main pass (NSR_HOST_TIMING=1): where the host's time to queue the pass goes, printed at exit
+#include <chrono>
+namespace {
+struct HostTimer {
+    bool on = getenv("NSR_HOST_TIMING") != nullptr;
+    double acc[16] = {};
+    uint64_t calls = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { if (on) { t = std::chrono::steady_clock::now(); ++calls; } }
+    void mark(int i)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::micro>(now - t).count();
+        t = now;
+    }
+    ~HostTimer()
+    {
+        if (!on || !calls) return;
+        static const char *names[16] = {"set-up", "copy kept rows", "fork record + colour MLP forward", "composite forward",
+                                        "helper: wait + binning + join record", "composite backward", "colour MLP backward",
+                                        "density MLP backward", "join wait + table backward", "wgrad join", "", "", "", "", "", ""};
+        fprintf(stderr, "nsr_nerf_main_pass host time over %llu calls (us per call):\n", (unsigned long long)calls);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, "  %-40s %7.2f\n", names[i], acc[i] / (double)calls);
+    }
+} g_ht;
+}  // namespace
+
 extern "C" void nsr_profile_enable(int on) { g_prof_on = on != 0; }
 
 extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches, uint64_t *units)
@@ -272,6 +300,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     NSR_REQUIRE(d && prune_workspace && workspace && packed_marched && packed_kept, "nsr_nerf_main_pass: NULL pointer");
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
                 "[16 features | 16 SH] (reference models/texture.py:26 with feature_dim 16)");
+    g_ht.start();
     NsrNerfPruneLayout P;
     NsrNerfMainLayout L;
     NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &P));
@@ -311,6 +340,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // compositing kernels instead of a one-workgroup kernel between them (NSR_L1_SEPARATE: A/B switch)
     static const bool l1_separate = getenv("NSR_L1_SEPARATE") != nullptr;
     const bool l1_folded = phases == 3 && compute_grads && gt_rgb && !up && S > 0 && n_rays > 0 && !l1_separate;
+    g_ht.mark(0);
     if (phases & 1) {
     if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
         if (F == 2 && nh1 <= 2)  // the step's usual shape: one lane per kept sample, all its rows in one round trip
@@ -328,6 +358,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // recorded here; the helper's launches are queued BEHIND the colour MLP and the compositing forward -- the host needs
     // ~7 us per launch, and with the four binning launches queued first the main stream sat idle for 30-45 us waiting for
     // its next kernel (rocprofv3 timeline: copy_kept_rows ... 46 us ... mlp_forward)
+    g_ht.mark(1);
     if (overlap_bins)
         NSR_REQUIRE(hipEventRecord(g_helper.fork, st) == hipSuccess, "nsr_nerf_main_pass: helper stream fork failed");
     {
@@ -335,6 +366,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         NSR_TRY(nsr_mlp_forward_ex(tex_in, 0, 32, 0, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color,
                                    n_kept_dev, stream));
     }
+    g_ht.mark(2);
     if (l1_folded) {  // the loss reduction rides in the two compositing kernels (per-block partials behind acc)
         NSR_TRY(nsr_composite_forward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights,
                                                 trans, comp_rgb, opacity, depth, gt_rgb, acc + 2, n_rays, stream));
@@ -344,6 +376,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         if (gt_rgb)
             NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));  // writes acc: no memset needed
     }
+    g_ht.mark(3);
     if (overlap_bins) {
         NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, g_helper.fork, 0) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream fork failed");
@@ -356,6 +389,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                     "nsr_nerf_main_pass: helper stream join failed");
     }
     }  // phases & 1
+    g_ht.mark(4);
     if (!(phases & 2)) return NSR_OK;
     NSR_REQUIRE(!compute_grads || up || gt_rgb, "nsr_nerf_main_pass: no loss (gt_rgb) and no upstream gradients");
     NSR_REQUIRE(!(table_adam && compute_grads && S == 0), "nsr_nerf_main_pass: the fused table update needs a non-empty "
@@ -410,6 +444,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // network's kernels start 35 us later and the helper stream's chain (weight gradients, reductions, the optimizer launch)
     // ends behind the table backward instead of underneath it.  So: one fork per network; NSR_WGRAD_ONE_FORK for A/B.
     static const bool two_forks = getenv("NSR_WGRAD_ONE_FORK") == nullptr;
+    g_ht.mark(5);
     if (wg && !two_forks) {
         {
             ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
@@ -436,6 +471,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         NSR_TRY(nsr_mlp_backward_split(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
                                        32, 0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream, wg));
     }
+    g_ht.mark(6);
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_DENSITY, S, stream);
         NSR_TRY(nsr_mlp_backward_split(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
@@ -443,6 +479,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                        &d->mlp_density, n_kept_dev, stream, wg));
     }
     }
+    g_ht.mark(7);
     if (xchg && xchg->event_small)  // the MLP weight gradients are final behind what is queued on their stream by now
         NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_small, wg ? g_helper.stream : st) == hipSuccess,
                     "nsr_nerf_main_pass_exchange: hipEventRecord failed");
@@ -481,6 +518,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                        d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
         }
     }
+    g_ht.mark(8);
     if (wg && !g_defer_wgrad_join)  // join: the optimizer step that follows on `stream` reads the MLP gradients
         NSR_REQUIRE(hipEventRecord(g_helper.join_wgrad, g_helper.stream) == hipSuccess &&
                         hipStreamWaitEvent(st, g_helper.join_wgrad, 0) == hipSuccess,
