@@ -109,3 +109,34 @@ def test_no_shipped_kernel_spills_registers():
     owner = {n.split("::")[0].split()[-1]: meta[k] for k, n in zip(sorted(meta), names) if "k_grid_backward_owner<2, 0>" in n}
     assert owner["own_small"]["wg"] == 256 and owner["own_large"]["wg"] == 1024, owner
     assert all(v["vgpr"] <= 128 for v in owner.values())
+
+
+def test_ctypes_structures_mirror_the_header_layout(tmp_path):
+    """every struct of include/nsr_hip.h that crosses the boundary by value or by pointer: sizeof and the offset of every field
+    as gcc lays them out == the ctypes mirror in nsr_hip/__init__.py (a drifted field silently shifts every pointer behind it)"""
+    import ctypes
+    import subprocess
+    import nsr_hip
+    names = ["NsrGridDesc", "NsrMlpDesc", "NsrTableAdam", "NsrTableExchange", "NsrRenderGrads", "NsrNeusUpstream",
+             "NsrVanillaLayer", "NsrAdamSegment", "NsrVmlpDesc", "NsrNerfStepDesc", "NsrNerfPruneLayout", "NsrNerfMainLayout"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "nsr_hip.h"', 'int main(void) {']
+    for n in names:
+        cls = getattr(nsr_hip, n)
+        lines.append(f'  printf("{n} sizeof %zu\\n", sizeof({n}));')
+        for f in cls._fields_:
+            lines.append(f'  printf("{n} {f[0]} %zu\\n", offsetof({n}, {f[0]}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        n, f, v = ln.split()
+        got[(n, f)] = int(v)
+    for n in names:
+        cls = getattr(nsr_hip, n)
+        assert got[(n, "sizeof")] == ctypes.sizeof(cls), n
+        for f in cls._fields_:
+            assert got[(n, f[0])] == getattr(cls, f[0]).offset, (n, f[0])

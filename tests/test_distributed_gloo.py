@@ -283,3 +283,35 @@ def test_sharded_adamw_rank_without_samples_contributes_zeros(tmp_path):
     want = _reference_adamw([3072 + 40000], [7], mean, [1.0, 1.0, 1.0])[0]
     assert torch.equal(r[0]["master"], r[1]["master"])
     assert torch.allclose(r[0]["master"], want, rtol=1e-5, atol=1e-7)
+
+
+def _grid_sync_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerfacc import OccupancyGrid
+    from nsr.parallel import sync_occupancy_grid
+    grid = OccupancyGrid(torch.tensor([-1.0, -1, -1, 1, 1, 1]), resolution=16)
+    g = torch.Generator().manual_seed(7 + rank)  # every rank refreshed its own grid from its own random cells
+    grid.occs.copy_(torch.rand(grid.occs.shape, generator=g))
+    grid._binary.copy_((torch.rand(grid._binary.shape, generator=g) > 0.5))
+    before = (grid.occs.clone(), grid._binary.clone())
+    sync_occupancy_grid(grid)
+    torch.save({"before": before, "after": (grid.occs.clone(), grid._binary.clone())}, os.path.join(out, f"grid{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_occupancy_grids_follow_rank_zero(tmp_path):
+    """DDP's broadcast_buffers semantics (reference launch.py:93-107 wraps the system in DDP: rank 0's buffers, the occupancy
+    grid's ``occs`` / ``_binary`` among them, are broadcast): after ``sync_occupancy_grid`` every rank holds rank 0's grid"""
+    world, port = 2, _free_port()
+    mp.spawn(_grid_sync_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"grid{r}.pt")) for r in range(world))
+    assert not torch.equal(r0["before"][0], r1["before"][0]) and not torch.equal(r0["before"][1], r1["before"][1])
+    for k in (0, 1):
+        assert torch.equal(r0["after"][k], r0["before"][k])   # rank 0 keeps its grid
+        assert torch.equal(r1["after"][k], r0["before"][k])   # ... and rank 1 now has it
