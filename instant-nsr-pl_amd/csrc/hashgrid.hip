@@ -789,8 +789,9 @@ extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int 
 // longer item lists per workgroup amortise the per-workgroup LDS clear / write-out.  So both are compiled and a launch
 // picks by its point count (the binning and the accumulation of one gradient see the same count).
 //
-// Run-time knobs of the decomposition (nsr_hashgrid_owner_tune; A/B switches of tools/table_backward_variants.py -- the
-// gradient is the same bits under every setting):
+// Run-time knobs of the decomposition (nsr_hashgrid_owner_tune; A/B switches of tools/table_backward_variants.py).  The
+// gradient of the hashed levels is the same bits under every setting (integer sums); on the dense levels the chunk slabs and
+// the row merge add in fp32, so placement / chunking / merge settings change their association (agreement to ~1e-6):
 struct OwnTune {
     int placement;         // 0: units dealt over the XCDs, 1: contiguous cost-balanced ranges, 2: levels striped over XCD pairs (default)
     float cost_adam;       // weight of a unit's write-out share in the balance
