@@ -279,6 +279,21 @@ int nsr_mlp_backward_phases(const void *dout, int dout_is_f32, uint32_t dout_str
                             float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc, const int32_t *n_dev,
                             void *stream, int phases);
 
+/* Round 5 -- the data gradients of BOTH networks of the NeRF step in one kernel: the colour network's input is
+ * [16 geometry features | SH4(dir)] (models/texture.py:24-26), so its input gradient's first 16 columns ARE the density
+ * network's output gradient (+ d_logit on column 0, models/geometry.py:127); the 16-wide d_feature row stays in the lanes'
+ * registers.  d_rgb [n,3], d_logit [n] in; d_enc level-major fp32 [16][n][2] out; the pre-activation gradients are saved in the
+ * two networks' backward workspaces where nsr_mlp_backward_phases(..., 1) puts them, so nsr_mlp_backward_phases(..., 2)
+ * follows unchanged; every value is bit-identical to the two-launch sequence.  _supported: colour 32 -> 64 x (1..2) -> 3
+ * sigmoid, density 32 -> 64 x (1..2) -> 16 linear.  _max_blocks: launch-size knob (0 queries), returns the previous value. */
+int nsr_mlp_dgrad_pair_supported(const NsrMlpDesc *color, const NsrMlpDesc *density);
+uint32_t nsr_mlp_dgrad_pair_max_blocks(uint32_t blocks);
+int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, const nsr_half *out_color, const nsr_half *acts_color,
+                       const nsr_half *w_color, float *partials_color, const nsr_half *acts_density,
+                       const nsr_half *w_density, float *partials_density, float *d_enc_level_major, uint32_t n,
+                       float grad_scale, const NsrMlpDesc *color, const NsrMlpDesc *density, const int32_t *n_dev,
+                       void *stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * tcnn.NetworkWithInputEncoding -- models/network_utils.py:209-214 (HashGrid -> FullyFusedMLP, one flat parameter
@@ -529,6 +544,20 @@ int nsr_nerf_copy_kept_rows(const int32_t *packed_marched, const int32_t *packed
                             nsr_half *enc_out, nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels,
                             uint32_t n_hidden, uint32_t marched_capacity, uint32_t kept_capacity, const float *rays_d,
                             int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays, void *stream);
+/* Round 5 -- the packing folded into that copy: nsr_visibility_prefix_sums leaves, beside the kept counts, one sum per block
+ * of 8 rays (block_sums: nsr_div_up(n_rays, 8) words, 16-byte aligned); every wave of the copy then forms its ray's offset
+ * itself and WRITES packed_kept [n_rays,2], total_kept[1] and the statistics of nsr_pack_from_counts_capped (stats may be
+ * NULL; rays past kept_capacity samples are truncated as there): one launch instead of scan + copy in the step's chain. */
+int nsr_visibility_prefix_sums(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                               const float *t_ends, const int32_t *packed_info, float early_stop_eps, int32_t *kept_counts,
+                               int32_t *block_sums, uint32_t n_rays, void *stream);
+int nsr_nerf_copy_kept_rows_scan(const int32_t *packed_marched, const int32_t *kept_counts, const int32_t *block_sums,
+                                 int32_t *packed_kept, int32_t *total_kept, int32_t *stats, const float *t_starts,
+                                 const float *t_ends, const float *x01, const nsr_half *enc, const nsr_half *out1,
+                                 const nsr_half *acts1, float *t_starts_out, float *t_ends_out, float *x01_out,
+                                 nsr_half *enc_out, nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels,
+                                 uint32_t n_hidden, uint32_t marched_capacity, uint32_t kept_capacity, const float *rays_d,
+                                 int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays, void *stream);
 /* tex_in[n,32] (half) = [mlp_out[:, :16] | SH4((dirs+1)/2)]   (texture.py:24-26) */
 int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in, uint32_t n,
                       const int32_t *n_dev, void *stream);
@@ -574,6 +603,25 @@ int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out, uint32_t 
                                               const float *opacity, const float *gt_rgb, const float *partials,
                                               float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
                                               uint32_t n_rays, void *stream);
+/* Round 5 -- flat segmented compositing (models/nerf.py:105-109 and its backward): one lane per SAMPLE over the packed
+ * arrays instead of one wave per ray (a ray of the step keeps 10-15 samples: > 80 % idle lanes) -- a wave takes 8 consecutive
+ * rays, i.e. one contiguous sample range, transmittance and the per-ray sums are segmented DPP scans with a carry between
+ * 64-sample chunks.  packed_info must be an exclusive scan over the rays (what nsr_pack_from_counts* / the folded packing
+ * write), 8-byte aligned.  forward: partials (may be NULL) = the loss partials of the folded masked smooth-L1 against gt_rgb
+ * (nsr_composite_l1_partials_floats(n_rays) floats).  backward: EITHER the upstream gradients grad_comp_rgb [R,3] (+
+ * optional grad_opacity [R], grad_depth [R], grad_weights [n]) OR the built-in loss on (comp_rgb, opacity, gt_rgb) with its
+ * (sum, valid rays) read from acc2 (partials == NULL) or summed from the forward's partials (acc2 then receives them). */
+int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                               const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
+                               const float *background, float *weights, float *trans, float *comp_rgb, float *opacity,
+                               float *depth, const float *gt_rgb, float *partials, uint32_t n_rays, void *stream);
+int nsr_composite_backward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
+                                const float *background, const float *weights, const float *trans,
+                                const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
+                                const float *grad_weights, const float *comp_rgb, const float *opacity, const float *gt_rgb,
+                                const float *partials, float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
+                                uint32_t n_rays, void *stream);
 /* acc2[0] += sum of smooth_l1 over valid rays (opacity > 0) x 3 channels, acc2[1] += number of valid rays
  * (loss = acc2[0] / (3*acc2[1]), systems/nerf.py:97); backward writes grad_scale * dloss/dcomp_rgb */
 int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,
@@ -641,6 +689,13 @@ typedef struct NsrNerfMainLayout {
 #define NSR_PROF_MLP_BACKWARD_COLOR 4
 #define NSR_PROF_MLP_BACKWARD_DENSITY 5
 #define NSR_PROF_GRID_BACKWARD_BIN 6 /* item binning of the table backward, on the main pass's helper stream */
+#define NSR_PROF_GRID_BACKWARD_DENSE 7 /* dense levels of the table backward (nsr_hashgrid_backward_params_dense), own stream */
+/* Round 5 -- forms of the step's kernels, switchable for same-process A/B runs and as a fallback (all default to 1):
+ * key 0: nsr_mlp_dgrad_pair instead of two data-gradient launches; key 1: the dense levels of the table backward through
+ * nsr_hashgrid_backward_params_dense on a stream of their own, the owner launch covering the hashed levels only; key 2:
+ * nsr_composite_*_flat instead of one wave per ray; key 3: the two networks' weight-gradient kernels on two helper streams
+ * (with key 0).  value < 0 queries; returns the previous value (-1: unknown key). */
+int nsr_nerf_step_variant(int key, int value);
 /* the stream the main pass runs its overlapped work on (item binning, weight-gradient kernels); created on first use */
 void *nsr_nerf_helper_stream(void);
 /* `stream` waits for the point of the last main pass where its kept rows exist (behind nsr_nerf_main_pass*'s first kernel) */
@@ -660,6 +715,16 @@ int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const flo
                         const nsr_half *w_density, void *workspace, int32_t *kept_counts, int32_t *packed_kept,
                         int32_t *total_kept, uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
                         uint32_t kept_capacity, int32_t *kept_stats, const float *x01_marched, void *stream);
+/* Round 5 -- the same pass for a caller that queues nsr_nerf_main_pass* / nsr_nerf_render_forward on the SAME stream with
+ * the SAME packed_kept / total_kept right behind it: packed_kept, total_kept and kept_stats are then written by that pass's
+ * first kernel (nsr_nerf_copy_kept_rows_scan) and nothing may read them in between; the one-workgroup scan leaves the
+ * step's chain.  Falls back to the plain pass for shapes that copy does not cover. */
+int nsr_nerf_prune_pass_deferred(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
+                                 const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                 const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
+                                 void *workspace, int32_t *kept_counts, int32_t *packed_kept, int32_t *total_kept,
+                                 uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
+                                 uint32_t kept_capacity, int32_t *kept_stats, const float *x01_marched, void *stream);
 /* x01_marched (may be NULL; both passes): unit-cube positions [n_marched, 3] of the marched samples computed by the caller
  * ahead of the step (nsr_sample_positions_unit on its marching stream); NULL: formed inside, in the workspace */
 int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, uint32_t n_rays, NsrNerfMainLayout *out);
@@ -784,6 +849,25 @@ int nsr_hashgrid_backward_params_owner_accumulate_adam_range(const float *x, con
                                                              const NsrGridDesc *desc, const int32_t *n_dev,
                                                              const NsrTableAdam *adam, void *stream);
 uint32_t nsr_hashgrid_owner_first_unchunked_level(const NsrGridDesc *desc, uint32_t n);
+
+/* Round 5 -- the leading DENSE levels (resolution^3 <= size) of the table backward without owner workgroups
+ * (csrc/hashgrid_dense.inc; serves the backward of reference models/network_utils.py:209-214): the samples of a step are in
+ * ray order and consecutive samples of a ray stay in one cell of a coarse level, so runs of lanes in the same cell are merged
+ * in registers (segmented DPP scan) and only a run's last lane adds its 8 corner sums to a Q27.36 fixed-point buffer with
+ * device-scope integer atomics (order-independent sums).  nsr_hashgrid_dense_levels: how many leading levels that is (the
+ * owner calls of the same step then take [that, L): nsr_hashgrid_backward_params_owner_bin_range +
+ * ..._owner_accumulate_range / ..._owner_accumulate_adam_range).  phases: 1 = clear the accumulators (memset on `stream`),
+ * 2 = accumulate (x [n,3], dy level-major fp32 [L][n][F]), 4 = write out -- AdamW on those levels' parameters (adam), or
+ * their gradient as fp32 (grad_table: the TABLE's base, accumulate != 0 adds) or bf16 (grad_bf16: the table's base); exactly
+ * one of the three.  workspace / n: the owner calls' (nsr_hashgrid_backward_params_workspace_floats has room for both). */
+uint32_t nsr_hashgrid_dense_levels(const NsrGridDesc *desc);
+int nsr_hashgrid_backward_params_dense(const float *x, const float *dy_level_major, float *grad_table, void *grad_bf16,
+                                       const NsrTableAdam *adam, float *workspace, uint32_t n, uint32_t level_mask_count,
+                                       float grad_scale, int accumulate, const NsrGridDesc *desc, const int32_t *n_dev,
+                                       int phases, void *stream);
+int nsr_hashgrid_backward_params_owner_bin_range(const float *x, float *workspace, uint32_t n, uint32_t level_mask_count,
+                                                 uint32_t level_begin, uint32_t level_end, const NsrGridDesc *desc,
+                                                 const int32_t *n_dev, void *stream);
 
 /* The same write-out for the two other accumulation modes (the fused NeuS steps, nsr/fused_neus.py): first + second order
  * in one pass (analytic normals; items already binned when binned != 0) and the finite-difference stencil mode. */

@@ -13,6 +13,7 @@
 //   gather_train_rays     : pixel gather + get_rays + normalise + background blend     (systems/nerf.py:38-79)
 //
 // One wavefront per ray for everything segmented (shuffle scans, no LDS, deterministic order).
+#include <string.h>
 #include "nsr_common.h"
 
 namespace {
@@ -96,6 +97,51 @@ k_visibility_prefix(const __half *__restrict__ mlp_out, uint32_t stride, float b
         if (carry < eps) break;  // wave-uniform: everything after is invisible
     }
     if (lane == 0) kept[r] = (int32_t)n_kept;
+}
+
+// The same with one sum per block of VIS_RPB rays beside the counts: the kept-row copy of the main pass forms each ray's offset
+// from these (k_copy_kept_rows<.., true>), which takes the one-workgroup scan kernel between the two out of the step's chain.
+constexpr int VIS_BLOCK = 512;
+constexpr int VIS_RPB = VIS_BLOCK / NSR_WAVE;  // 8 rays per block
+__global__ void __launch_bounds__(VIS_BLOCK)
+k_visibility_prefix_sums(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
+                         const float *__restrict__ t1, const int32_t *__restrict__ packed, float eps,
+                         int32_t *__restrict__ kept, int32_t *__restrict__ block_sums, uint32_t n_rays)
+{
+    __shared__ int32_t sh[VIS_RPB];
+    const uint32_t r = blockIdx.x * VIS_RPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint32_t n_kept = 0;
+    if (r < n_rays) {
+        const uint32_t start = (uint32_t)packed[2ull * r], count = (uint32_t)packed[2ull * r + 1];
+        float carry = 1.f;
+        for (uint32_t c = 0; c < count; c += 64) {
+            const uint32_t k = c + lane;
+            const bool ok = k < count;
+            float one_minus_alpha = 1.f;
+            if (ok) {
+                const float sigma = expf(__half2float(mlp_out[(uint64_t)(start + k) * stride]) + bias);
+                const float alpha = 1.f - expf(-sigma * (t1[start + k] - t0[start + k]));
+                one_minus_alpha = 1.f - alpha;
+            }
+            const float inc = wave_incl_scan_mul(one_minus_alpha);
+            float exc = __shfl_up(inc, 1, 64);
+            if (lane == 0) exc = 1.f;
+            const float T = carry * exc;
+            const unsigned long long m = __ballot(ok && T >= eps);
+            n_kept += (uint32_t)__popcll(m);
+            carry *= __shfl(inc, 63, 64);
+            if (carry < eps) break;
+        }
+        if (lane == 0) kept[r] = (int32_t)n_kept;
+    }
+    if (lane == 0) sh[threadIdx.x >> 6] = (int32_t)n_kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < VIS_RPB; ++w) t += sh[w];
+        block_sums[blockIdx.x] = t;
+    }
 }
 
 __global__ void __launch_bounds__(R_BLOCK)
@@ -229,16 +275,66 @@ struct KeptRows {
 // PLANES16: exactly 16 encoding planes (every reference config: 16 levels x 2 features) -- the body is then straight-line
 // code and every row stays in registers; with the generic plane loop in between, the compiler kept the activation rows in
 // SCRATCH (an un-promoted 128-byte array per hidden layer: 8 + 8 scratch round trips per sample on the step's critical path)
-template <int NH, bool PLANES16>
+// SCAN: packed_new does not exist yet -- the wave forms its ray's offset itself from the per-ray kept counts and the sums
+// k_visibility_prefix_sums left per block of VIS_RPB rays (<= 8,192 of them: sixteen 16-byte loads per lane at most, all L2
+// hits), clamps it to the capacity exactly as k_pack_from_counts does, and WRITES packed_new[r]; the wave of the last ray also
+// publishes the total and the packing statistics.
+struct KeptScan {
+    const int32_t *kept, *block_sums;
+    int32_t *total, *stats;
+    uint32_t capacity;
+};
+
+template <int NH, bool PLANES16, bool SCAN>
 __global__ void __launch_bounds__(R_BLOCK)
-k_copy_kept_rows(const int32_t *__restrict__ packed_old, const int32_t *__restrict__ packed_new, const KeptRows kr,
+k_copy_kept_rows(const int32_t *__restrict__ packed_old, int32_t *__restrict__ packed_new, const KeptRows kr,
                  const float *__restrict__ rays_d, int64_t *__restrict__ ri_o, __half *__restrict__ tex_in,
-                 uint32_t n_rays)
+                 uint32_t n_rays, const KeptScan ks)
 {
     const uint32_t r = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= n_rays) return;
     const uint32_t src = (uint32_t)packed_old[2ull * r];
-    const uint32_t dst = (uint32_t)packed_new[2ull * r], cnt = (uint32_t)packed_new[2ull * r + 1];
+    uint32_t dst, cnt;
+    if constexpr (SCAN) {
+        const uint32_t nb = r / VIS_RPB;  // whole blocks of rays in front of r
+        int32_t part = 0;
+        for (uint32_t b = lane * 4u; b < nb; b += 256u) {
+            if (b + 4u <= nb) {
+                const int4 v = *reinterpret_cast<const int4 *>(ks.block_sums + b);
+                part += (v.x + v.y) + (v.z + v.w);
+            } else {
+                for (uint32_t q = b; q < nb; ++q) part += ks.block_sums[q];
+            }
+        }
+        const uint32_t rr = nb * VIS_RPB + lane;  // the rays of r's own block in front of it
+        if (rr < r) part += ks.kept[rr];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        const int32_t own = ks.kept[r];
+        int32_t start = part, c = own;
+        if (ks.capacity) {  // fixed-size sample buffers: rays past the capacity are truncated (and reported)
+            start = min(start, (int32_t)ks.capacity);
+            c = min(c, (int32_t)ks.capacity - start);
+        }
+        if (lane == 0) {
+            *reinterpret_cast<int2 *>(packed_new + 2ull * r) = make_int2(start, c);
+            if (r == n_rays - 1u) {
+                const int32_t t = part + own;
+                ks.total[0] = ks.capacity ? min(t, (int32_t)ks.capacity) : t;
+                if (ks.stats) {  // (as k_pack_from_counts)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(ks.stats + 4), (unsigned long long)t);
+                    atomicMax(&ks.stats[1], t);
+                    if (ks.capacity && t > (int32_t)ks.capacity) atomicAdd(&ks.stats[2], 1);
+                    ks.stats[0] = t;
+                }
+            }
+        }
+        dst = (uint32_t)start;
+        cnt = (uint32_t)c;
+    } else {
+        dst = (uint32_t)packed_new[2ull * r];
+        cnt = (uint32_t)packed_new[2ull * r + 1];
+    }
     if (cnt == 0) return;
     u32x4 sh_lo, sh_hi;  // (by value: punning an array of half2 through a pointer would put it -- and the rows below -- in scratch)
     {
@@ -541,6 +637,252 @@ k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float 
             d_logit[idx] = g_sd * dt * expf(fminf(z, 15.f));
         }
         carry += __shfl(inc, 63, 64);
+    }
+}
+
+// ---- flat segmented compositing (round 5) ------------------------------------------------------------------------------------
+// The wave-per-ray kernels above leave > 80 % of their lanes idle at the step's operating point (8,192 ray slots, ~1e5 kept
+// samples: a ray keeps 10-15 samples, two thirds of the slots keep none) and cost 30-45 us of the step's chain.  Here a wave
+// takes FLAT_RPW consecutive rays; their kept samples are ONE contiguous range of the packed arrays (packed_info of the step is
+// an exclusive scan: start[r + 1] = start[r] + count[r], empty rays included), which the wave walks 64 samples at a time, one
+// lane per SAMPLE whatever the ray boundaries: the transmittance prefix and the five per-ray sums are segmented scans (DPP
+// row shifts + row broadcasts, registers only), a ray that straddles two 64-sample chunks hands a wave-uniform carry to the
+// next chunk.  No atomics, no LDS except the block's loss partial, every sum in a fixed order: deterministic.
+constexpr int FLAT_RPW = 8;                          // rays per wave
+constexpr int FLAT_BLOCK = 256;                      // threads per block
+constexpr int FLAT_RPB = FLAT_RPW * FLAT_BLOCK / 64; // rays per block
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float flat_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// inclusive segmented sum over the wave; dist = lane - (first lane of this lane's segment inside the wave)
+__device__ __forceinline__ float flat_seg_scan(float v, uint32_t dist, uint32_t lane)
+{
+    const uint32_t in_row = lane & 15u;
+    float t;
+    t = flat_dpp<0x111, 0xf>(v); if (dist >= 1u && in_row >= 1u) v += t;
+    t = flat_dpp<0x112, 0xf>(v); if (dist >= 2u && in_row >= 2u) v += t;
+    t = flat_dpp<0x114, 0xf>(v); if (dist >= 4u && in_row >= 4u) v += t;
+    t = flat_dpp<0x118, 0xf>(v); if (dist >= 8u && in_row >= 8u) v += t;
+    t = flat_dpp<0x142, 0xa>(v); if ((lane & 16u) && dist > in_row) v += t;           // row_bcast:15 into rows 1, 3
+    t = flat_dpp<0x143, 0xc>(v); if (lane >= 32u && dist >= lane - 31u) v += t;       // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+// the wave's rays: lanes 0 .. FLAT_RPW-1 hold (start, count) of ray r0 + lane; [begin, end) = the samples of all of them
+struct FlatRays { uint32_t r0, nv, begin, end; int st, cn; uint32_t e[FLAT_RPW]; /* ends of the rays: wave-uniform */ };
+__device__ __forceinline__ FlatRays flat_rays(const int32_t *__restrict__ packed, uint32_t n_rays, uint32_t lane)
+{
+    FlatRays f;
+    f.r0 = (blockIdx.x * (FLAT_BLOCK / 64) + (threadIdx.x >> 6)) * FLAT_RPW;
+    f.nv = f.r0 < n_rays ? min((uint32_t)FLAT_RPW, n_rays - f.r0) : 0u;
+    f.st = 0; f.cn = 0;
+    if (lane < f.nv) {
+        const int2 pk = *reinterpret_cast<const int2 *>(packed + 2ull * (f.r0 + lane));
+        f.st = pk.x; f.cn = pk.y;
+    }
+    const int ev = f.st + f.cn;
+#pragma unroll
+    for (int j = 0; j < FLAT_RPW; ++j) f.e[j] = (uint32_t)__builtin_amdgcn_readlane(ev, j);
+    f.begin = f.nv ? (uint32_t)__builtin_amdgcn_readlane(f.st, 0) : 0u;
+    f.end = 0u;
+#pragma unroll
+    for (int j = 0; j < FLAT_RPW; ++j)
+        if ((uint32_t)j < f.nv) f.end = f.e[j];  // (the last valid ray's end: starts and ends never decrease)
+    return f;
+}
+// local ray (0 .. nv-1) of sample i in [begin, end): the first one whose end lies behind i
+__device__ __forceinline__ uint32_t flat_ray_of(const FlatRays &f, uint32_t i)
+{
+    uint32_t q = 0;
+#pragma unroll
+    for (int j = 0; j < FLAT_RPW - 1; ++j) q += ((uint32_t)j + 1u < f.nv && i >= f.e[j]) ? 1u : 0u;
+    return q;
+}
+
+__global__ void __launch_bounds__(FLAT_BLOCK)
+k_composite_forward_flat(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
+                         const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
+                         const int32_t *__restrict__ packed, const float *__restrict__ bg, float *__restrict__ weights,
+                         float *__restrict__ trans, float *__restrict__ comp_rgb, float *__restrict__ opacity,
+                         float *__restrict__ depth, uint32_t n_rays, const float *__restrict__ l1_gt,
+                         float *__restrict__ l1_part /* [2][gridDim.x] or NULL */)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const FlatRays f = flat_rays(packed, n_rays, lane);
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    float l1_s = 0.f, l1_c = 0.f;
+    if (lane < f.nv && f.cn == 0) {  // a ray without samples: background, outside the loss (opacity 0)
+        const uint32_t r = f.r0 + lane;
+        opacity[r] = 0.f;
+        depth[r] = 0.f;
+        comp_rgb[3ull * r] = b0; comp_rgb[3ull * r + 1] = b1; comp_rgb[3ull * r + 2] = b2;
+    }
+    float c_sd = 0.f, c_acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // carries of the ray that is open at the chunk's first lane
+    for (uint32_t c = f.begin; c < f.end; c += 64) {
+        const uint32_t i = c + lane;
+        const bool ok = i < f.end;
+        const uint32_t q = flat_ray_of(f, ok ? i : f.end - 1u);
+        const uint32_t rs = (uint32_t)__shfl(f.st, (int)q, 64), rc = (uint32_t)__shfl(f.cn, (int)q, 64);
+        const uint32_t k = (ok ? i : f.end - 1u) - rs;        // position inside the ray
+        const bool open = k > lane;                            // the ray began in an earlier chunk
+        const uint32_t dist = open ? lane : k;
+        float sd = 0.f, a = 0.f, mid = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        if (ok) {
+            const float ts = t0[i], te = t1[i];
+            const float sigma = expf(__half2float(mlp_out[(uint64_t)i * stride]) + bias);
+            sd = sigma * (te - ts);
+            a = 1.f - expf(-sd);
+            mid = (ts + te) / 2.f;
+            const __half *c3 = rgb + (uint64_t)i * rgb_stride;
+            cr = __half2float(c3[0]); cg = __half2float(c3[1]); cb = __half2float(c3[2]);
+        }
+        const float inc = flat_seg_scan(sd, dist, lane);
+        // exclusive prefix by shift, not as inc - sd: an overflowed density gives inf - inf = NaN (see k_composite_forward)
+        float exc = __shfl_up(inc, 1, 64);
+        if (dist == 0u) exc = 0.f;
+        const float T = expf(-((open ? c_sd : 0.f) + exc));
+        const float w = ok ? T * a : 0.f;
+        float v[5] = {w, w * mid, w * cr, w * cg, w * cb};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v[j] = flat_seg_scan(v[j], dist, lane) + (open ? c_acc[j] : 0.f);
+        if (ok) {
+            weights[i] = w;
+            trans[i] = T;
+            if (k + 1u == rc) {  // last sample of its ray: the sums are complete
+                const uint32_t r = f.r0 + q;
+                opacity[r] = v[0];
+                depth[r] = v[1];
+                const float rest = 1.f - v[0];
+                const float o3[3] = {v[2] + b0 * rest, v[3] + b1 * rest, v[4] + b2 * rest};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    comp_rgb[3ull * r + j] = o3[j];
+                    if (l1_part && v[0] > 0.f) {
+                        const float d = fabsf(o3[j] - l1_gt[3ull * r + j]);
+                        l1_s += d < 1.f ? 0.5f * d * d : d - 0.5f;
+                    }
+                }
+                if (l1_part && v[0] > 0.f) l1_c += 1.f;
+            }
+        }
+        // carry: the ray of lane 63 continues behind this chunk iff lane 63 is not its last sample
+        const float n_sd = (open ? c_sd : 0.f) + inc;
+        const bool cont = ok && (k + 1u < rc);
+        c_sd = __shfl(cont ? n_sd : 0.f, 63, 64);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) c_acc[j] = __shfl(cont ? v[j] : 0.f, 63, 64);
+    }
+    if (l1_part) {
+        __shared__ float sh[2][FLAT_BLOCK / 64];
+        l1_s = wave_sum(l1_s);
+        l1_c = wave_sum(l1_c);
+        if (lane == 0) { sh[0][threadIdx.x >> 6] = l1_s; sh[1][threadIdx.x >> 6] = l1_c; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float ts = 0.f, tc = 0.f;
+#pragma unroll
+            for (int w = 0; w < FLAT_BLOCK / 64; ++w) { ts += sh[0][w]; tc += sh[1][w]; }
+            l1_part[blockIdx.x] = ts;
+            l1_part[gridDim.x + blockIdx.x] = tc;
+        }
+    }
+}
+
+// backward of the above w.r.t. rgb and the density logit; the ray's samples are walked from its END (suffix sums)
+__global__ void __launch_bounds__(FLAT_BLOCK)
+k_composite_backward_flat(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
+                          const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
+                          const int32_t *__restrict__ packed, const float *__restrict__ bg,
+                          const float *__restrict__ weights, const float *__restrict__ trans,
+                          const float *__restrict__ g_comp, const float *__restrict__ g_opacity,
+                          const float *__restrict__ g_depth, float *__restrict__ d_rgb, float *__restrict__ d_logit,
+                          uint32_t n_rays, const float *__restrict__ l1_comp, const float *__restrict__ l1_opacity,
+                          const float *__restrict__ l1_gt, const float *__restrict__ l1_acc, float l1_scale,
+                          const float *__restrict__ g_weights, const float *__restrict__ l1_part,
+                          float *__restrict__ l1_acc_out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    float n_valid = 0.f;
+    if (l1_part) {  // every block sums the forward's partials itself, same order everywhere
+        __shared__ float tot[2][FLAT_BLOCK / 64];
+        float s = 0.f, c = 0.f;
+        for (uint32_t k = threadIdx.x; k < gridDim.x; k += FLAT_BLOCK) { s += l1_part[k]; c += l1_part[gridDim.x + k]; }
+        s = wave_sum(s);
+        c = wave_sum(c);
+        if (lane == 0) { tot[0][threadIdx.x >> 6] = s; tot[1][threadIdx.x >> 6] = c; }
+        __syncthreads();
+        s = c = 0.f;
+#pragma unroll
+        for (int w = 0; w < FLAT_BLOCK / 64; ++w) { s += tot[0][w]; c += tot[1][w]; }
+        n_valid = c;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { l1_acc_out[0] = s; l1_acc_out[1] = c; }
+    }
+    const FlatRays f = flat_rays(packed, n_rays, lane);
+    if (f.end <= f.begin) return;
+    // the upstream gradients of this wave's rays, held by lanes 0 .. nv-1
+    float rg0 = 0.f, rg1 = 0.f, rg2 = 0.f, rgo = 0.f, rgd = 0.f;
+    if (lane < f.nv) {
+        const uint32_t r = f.r0 + lane;
+        if (l1_comp) {
+            const bool valid = l1_opacity[r] > 0.f;
+            const float inv = l1_scale / fmaxf(3.f * (l1_part ? n_valid : l1_acc[1]), 1.f);
+            float g[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float d = l1_comp[3ull * r + j] - l1_gt[3ull * r + j];
+                const float gq = fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+                g[j] = valid ? gq * inv : 0.f;
+            }
+            rg0 = g[0]; rg1 = g[1]; rg2 = g[2];
+        } else {
+            rg0 = g_comp[3ull * r]; rg1 = g_comp[3ull * r + 1]; rg2 = g_comp[3ull * r + 2];
+        }
+        rgo = g_opacity ? g_opacity[r] : 0.f;
+        rgd = g_depth ? g_depth[r] : 0.f;
+    }
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    float c_v = 0.f;  // suffix sum of gT_i T_i of the ray that is open at the chunk's first lane
+    const uint32_t total = f.end - f.begin;
+    for (uint32_t c = 0; c < total; c += 64) {
+        const uint32_t j = c + lane;
+        const bool ok = j < total;
+        const uint32_t i = f.end - 1u - (ok ? j : total - 1u);
+        const uint32_t q = flat_ray_of(f, i);
+        const uint32_t rs = (uint32_t)__shfl(f.st, (int)q, 64), rc = (uint32_t)__shfl(f.cn, (int)q, 64);
+        const uint32_t k = rs + rc - 1u - i;                   // position counted from the ray's end
+        const bool open = k > lane;
+        const uint32_t dist = open ? lane : k;
+        const float g0 = __shfl(rg0, (int)q, 64), g1 = __shfl(rg1, (int)q, 64), g2 = __shfl(rg2, (int)q, 64);
+        const float gop = __shfl(rgo, (int)q, 64), gdp = __shfl(rgd, (int)q, 64);
+        float v = 0.f, gw = 0.f, T = 0.f, a = 0.f, dt = 0.f, z = 0.f;
+        if (ok) {
+            const float ts = t0[i], te = t1[i];
+            dt = te - ts;
+            z = __half2float(mlp_out[(uint64_t)i * stride]) + bias;
+            const float sd = expf(z) * dt;
+            a = 1.f - expf(-sd);
+            T = trans[i];
+            const __half *c3 = rgb + (uint64_t)i * rgb_stride;
+            const float w = weights[i];
+            gw = g0 * (__half2float(c3[0]) - b0) + g1 * (__half2float(c3[1]) - b1) + g2 * (__half2float(c3[2]) - b2) +
+                 gop + gdp * ((ts + te) / 2.f) + (g_weights ? g_weights[i] : 0.f);
+            d_rgb[3ull * i] = w * g0;
+            d_rgb[3ull * i + 1] = w * g1;
+            d_rgb[3ull * i + 2] = w * g2;
+            v = gw * a * T;  // gT_i * T_i
+        }
+        const float inc = flat_seg_scan(v, dist, lane);
+        float exc = __shfl_up(inc, 1, 64);
+        if (dist == 0u) exc = 0.f;
+        if (ok) {
+            const float g_sd = gw * T * (1.f - a) - ((open ? c_v : 0.f) + exc);
+            d_logit[i] = g_sd * dt * expf(fminf(z, 15.f));
+        }
+        const bool cont = ok && (k + 1u < rc);
+        c_v = __shfl(cont ? (open ? c_v : 0.f) + inc : 0.f, 63, 64);
     }
 }
 
@@ -867,6 +1209,53 @@ extern "C" int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out
     return NSR_OK;
 }
 
+// flat forms of the compositing pair (k_composite_*_flat): packed_info must be an exclusive scan over the rays (what
+// nsr_pack_from_counts* / the fused compaction write).  partials (may be NULL): the loss partials of the folded smooth-L1,
+// nsr_composite_l1_partials_floats(n_rays) floats as for the wave-per-ray pair.
+extern "C" int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                          const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
+                                          const int32_t *packed_info, const float *background, float *weights, float *trans,
+                                          float *comp_rgb, float *opacity, float *depth, const float *gt_rgb, float *partials,
+                                          uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && comp_rgb && opacity && depth && weights && trans,
+                "nsr_composite_forward_flat: NULL pointer");
+    NSR_REQUIRE(!partials || gt_rgb, "nsr_composite_forward_flat: the loss partials need gt_rgb");
+    NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_composite_forward_flat: packed_info must be 8-byte aligned");
+    hipLaunchKernelGGL(k_composite_forward_flat, dim3(nsr_div_up(n_rays, FLAT_RPB)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,
+                       (const __half *)mlp_out, stride, density_bias, t_starts, t_ends, (const __half *)rgb, rgb_stride,
+                       packed_info, background, weights, trans, comp_rgb, opacity, depth, n_rays, gt_rgb, partials);
+    NSR_CHECK_LAUNCH("nsr_composite_forward_flat");
+    return NSR_OK;
+}
+
+// upstream gradients: either (grad_comp_rgb [+ grad_opacity, grad_depth, grad_weights]) or the masked smooth-L1 loss on
+// (comp_rgb, opacity, gt_rgb) with its (sum, valid) either in acc2 (partials == NULL) or as the forward's partials (then
+// acc2 receives the totals)
+extern "C" int nsr_composite_backward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                           const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
+                                           const int32_t *packed_info, const float *background, const float *weights,
+                                           const float *trans, const float *grad_comp_rgb, const float *grad_opacity,
+                                           const float *grad_depth, const float *grad_weights, const float *comp_rgb,
+                                           const float *opacity, const float *gt_rgb, const float *partials, float *acc2,
+                                           float grad_scale, float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && background && weights && trans && grad_rgb && grad_logit, "nsr_composite_backward_flat: NULL pointer");
+    NSR_REQUIRE((grad_comp_rgb != nullptr) != (comp_rgb != nullptr), "nsr_composite_backward_flat: either upstream gradients "
+                "or the built-in loss");
+    NSR_REQUIRE(!comp_rgb || (opacity && gt_rgb && acc2), "nsr_composite_backward_flat: the built-in loss needs opacity, gt_rgb, acc2");
+    NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_composite_backward_flat: packed_info must be 8-byte aligned");
+    hipLaunchKernelGGL(k_composite_backward_flat, dim3(nsr_div_up(n_rays, FLAT_RPB)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,
+                       (const __half *)mlp_out, stride, density_bias, t_starts, t_ends, (const __half *)rgb, rgb_stride,
+                       packed_info, background, weights, trans, grad_comp_rgb, grad_opacity, grad_depth, grad_rgb, grad_logit,
+                       n_rays, comp_rgb, opacity, gt_rgb, partials ? nullptr : acc2, grad_scale, grad_weights, partials,
+                       partials ? acc2 : nullptr);
+    NSR_CHECK_LAUNCH("nsr_composite_backward_flat");
+    return NSR_OK;
+}
+
 extern "C" int nsr_gather_train_rays(const float *images, const float *masks, const float *directions, const float *c2w,
                                      const int64_t *index, const int64_t *px, const int64_t *py, const float *background,
                                      int height, int width, int apply_mask, float *rays, float *rgb, float *fg,
@@ -911,13 +1300,13 @@ extern "C" int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int3
     return NSR_OK;
 }
 
-extern "C" int nsr_nerf_copy_kept_rows(const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
-                                       const float *t_ends, const float *x01, const nsr_half *enc, const nsr_half *out1,
-                                       const nsr_half *acts1, float *t_starts_out, float *t_ends_out, float *x01_out,
-                                       nsr_half *enc_out, nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels,
-                                       uint32_t n_hidden, uint32_t marched_capacity, uint32_t kept_capacity,
-                                       const float *rays_d, int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays,
-                                       void *stream)
+static int copy_kept_rows_impl(const int32_t *packed_marched, int32_t *packed_kept, const float *t_starts,
+                               const float *t_ends, const float *x01, const nsr_half *enc, const nsr_half *out1,
+                               const nsr_half *acts1, float *t_starts_out, float *t_ends_out, float *x01_out,
+                               nsr_half *enc_out, nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels,
+                               uint32_t n_hidden, uint32_t marched_capacity, uint32_t kept_capacity, const float *rays_d,
+                               int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays, const KeptScan *scan,
+                               void *stream)
 {
     if (n_rays == 0) return NSR_OK;
     NSR_REQUIRE(packed_marched && packed_kept && t_starts && t_ends && x01 && enc && out1 && acts1 && t_starts_out &&
@@ -932,19 +1321,74 @@ extern "C" int nsr_nerf_copy_kept_rows(const int32_t *packed_marched, const int3
     kr.enc_sp = marched_capacity; kr.enc_dp = kept_capacity;
     kr.acts_sl = (uint64_t)marched_capacity * 8; kr.acts_dl = (uint64_t)kept_capacity * 8;
     kr.planes = n_levels;
-    if (n_hidden == 1 && n_levels == 16)
-        hipLaunchKernelGGL((k_copy_kept_rows<1, true>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
-                           ray_indices_out, (__half *)tex_in, n_rays);
-    else if (n_hidden == 2 && n_levels == 16)
-        hipLaunchKernelGGL((k_copy_kept_rows<2, true>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
-                           ray_indices_out, (__half *)tex_in, n_rays);
-    else if (n_hidden == 1)
-        hipLaunchKernelGGL((k_copy_kept_rows<1, false>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
-                           ray_indices_out, (__half *)tex_in, n_rays);
-    else
-        hipLaunchKernelGGL((k_copy_kept_rows<2, false>), RAY_GRID(n_rays), packed_marched, packed_kept, kr, rays_d,
-                           ray_indices_out, (__half *)tex_in, n_rays);
+    KeptScan ks;
+    memset(&ks, 0, sizeof(ks));
+    if (scan) ks = *scan;
+#define NSR_COPY(NH, P16)                                                                                                 \
+    do {                                                                                                                  \
+        if (scan)                                                                                                         \
+            hipLaunchKernelGGL((k_copy_kept_rows<NH, P16, true>), RAY_GRID(n_rays), packed_marched, packed_kept, kr,      \
+                               rays_d, ray_indices_out, (__half *)tex_in, n_rays, ks);                                    \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_copy_kept_rows<NH, P16, false>), RAY_GRID(n_rays), packed_marched, packed_kept, kr,     \
+                               rays_d, ray_indices_out, (__half *)tex_in, n_rays, ks);                                    \
+    } while (0)
+    if (n_hidden == 1 && n_levels == 16) NSR_COPY(1, true);
+    else if (n_hidden == 2 && n_levels == 16) NSR_COPY(2, true);
+    else if (n_hidden == 1) NSR_COPY(1, false);
+    else NSR_COPY(2, false);
+#undef NSR_COPY
     NSR_CHECK_LAUNCH("nsr_nerf_copy_kept_rows");
+    return NSR_OK;
+}
+
+extern "C" int nsr_nerf_copy_kept_rows(const int32_t *packed_marched, const int32_t *packed_kept, const float *t_starts,
+                                       const float *t_ends, const float *x01, const nsr_half *enc, const nsr_half *out1,
+                                       const nsr_half *acts1, float *t_starts_out, float *t_ends_out, float *x01_out,
+                                       nsr_half *enc_out, nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels,
+                                       uint32_t n_hidden, uint32_t marched_capacity, uint32_t kept_capacity,
+                                       const float *rays_d, int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays,
+                                       void *stream)
+{
+    return copy_kept_rows_impl(packed_marched, const_cast<int32_t *>(packed_kept), t_starts, t_ends, x01, enc, out1, acts1,
+                               t_starts_out, t_ends_out, x01_out, enc_out, out1_out, acts1_out, n_levels, n_hidden,
+                               marched_capacity, kept_capacity, rays_d, ray_indices_out, tex_in, n_rays, nullptr, stream);
+}
+
+// ... with the packing folded in: packed_kept [n_rays][2], total_kept[1] (and the statistics of nsr_pack_from_counts_capped,
+// stats may be NULL) are WRITTEN here from kept_counts + the block sums of nsr_visibility_prefix_sums; rays past
+// `kept_capacity` samples are truncated as there.  One launch instead of nsr_pack_from_counts_capped + nsr_nerf_copy_kept_rows.
+extern "C" int nsr_nerf_copy_kept_rows_scan(const int32_t *packed_marched, const int32_t *kept_counts,
+                                            const int32_t *block_sums, int32_t *packed_kept, int32_t *total_kept,
+                                            int32_t *stats, const float *t_starts, const float *t_ends, const float *x01,
+                                            const nsr_half *enc, const nsr_half *out1, const nsr_half *acts1,
+                                            float *t_starts_out, float *t_ends_out, float *x01_out, nsr_half *enc_out,
+                                            nsr_half *out1_out, nsr_half *acts1_out, uint32_t n_levels, uint32_t n_hidden,
+                                            uint32_t marched_capacity, uint32_t kept_capacity, const float *rays_d,
+                                            int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays, void *stream)
+{
+    NSR_REQUIRE(kept_counts && block_sums && total_kept, "nsr_nerf_copy_kept_rows_scan: NULL pointer");
+    NSR_REQUIRE(((uintptr_t)block_sums & 15u) == 0 && ((uintptr_t)packed_kept & 7u) == 0 && (!stats || ((uintptr_t)stats & 7u) == 0),
+                "nsr_nerf_copy_kept_rows_scan: block_sums must be 16-byte, packed_kept / stats 8-byte aligned");
+    NSR_REQUIRE(kept_capacity < 0x7fffffffu, "nsr_nerf_copy_kept_rows_scan: capacity must fit int32");
+    KeptScan ks;
+    ks.kept = kept_counts; ks.block_sums = block_sums; ks.total = total_kept; ks.stats = stats; ks.capacity = kept_capacity;
+    return copy_kept_rows_impl(packed_marched, packed_kept, t_starts, t_ends, x01, enc, out1, acts1, t_starts_out, t_ends_out,
+                               x01_out, enc_out, out1_out, acts1_out, n_levels, n_hidden, marched_capacity, kept_capacity,
+                               rays_d, ray_indices_out, tex_in, n_rays, &ks, stream);
+}
+
+// kept counts per ray (as nsr_visibility_prefix) + one sum per block of 8 rays: block_sums holds nsr_div_up(n_rays, 8) words
+extern "C" int nsr_visibility_prefix_sums(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                          const float *t_ends, const int32_t *packed_info, float early_stop_eps,
+                                          int32_t *kept_counts, int32_t *block_sums, uint32_t n_rays, void *stream)
+{
+    if (n_rays == 0) return NSR_OK;
+    NSR_REQUIRE(packed_info && kept_counts && block_sums, "nsr_visibility_prefix_sums: NULL pointer");
+    hipLaunchKernelGGL(k_visibility_prefix_sums, dim3(nsr_div_up(n_rays, VIS_RPB)), dim3(VIS_BLOCK), 0, (hipStream_t)stream,
+                       (const __half *)mlp_out, stride, density_bias, t_starts, t_ends, packed_info, early_stop_eps,
+                       kept_counts, block_sums, n_rays);
+    NSR_CHECK_LAUNCH("nsr_visibility_prefix_sums");
     return NSR_OK;
 }
 

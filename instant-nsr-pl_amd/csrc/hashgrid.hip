@@ -876,11 +876,89 @@ extern "C" int nsr_hashgrid_owner_debug_map(const NsrGridDesc *desc, int large, 
     return NSR_OK;
 }
 
+#include "hashgrid_dense.inc"
+
+// the owner's part of the workspace (either configuration), rounded to 16 bytes: where the dense-level accumulators start
+static uint64_t owner_workspace_floats(const NsrGridDesc *desc, uint32_t n)
+{
+    const uint64_t a = own_small::workspace_floats(desc, n), b = own_large::workspace_floats(desc, n);
+    return ((a > b ? a : b) + 3ull) & ~3ull;  // (the configuration is picked per launch: room for either)
+}
+
 extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n)
 {
     if (!desc || check_desc(desc, "nsr_hashgrid_backward_params_workspace_floats")) return 0;
-    const uint64_t a = own_small::workspace_floats(desc, n), b = own_large::workspace_floats(desc, n);
-    return a > b ? a : b;  // (the configuration is picked per launch: room for either)
+    return owner_workspace_floats(desc, n) + dense_levels::dl_workspace_floats(desc);
+}
+
+// ---- the dense (coarse) levels through ray-run merged fixed-point atomics (hashgrid_dense.inc) -------------------------------
+// number of leading dense levels: the level range [0, k) this path covers; the owner launch of the same step takes [k, L)
+extern "C" uint32_t nsr_hashgrid_dense_levels(const NsrGridDesc *desc)
+{
+    if (!desc || check_desc(desc, "nsr_hashgrid_dense_levels")) return 0;
+    return dense_levels::dl_count(desc);
+}
+
+// phases: 1 = clear the accumulators (a memset on `stream`), 2 = accumulate the samples' contributions (x [n,3] in RAY ORDER --
+// any order is correct, ray order is what makes it cheap --, dy level-major fp32 [L][n][F]), 4 = write out: AdamW on the dense
+// levels' parameters (adam), or their gradient as fp32 (grad_table, the table's base; accumulate != 0 adds) or bf16
+// (grad_bf16, the table's base).  workspace / n as for the owner calls of the same step (same workspace, same n).
+extern "C" int nsr_hashgrid_backward_params_dense(const float *x, const float *dy_level_major, float *grad_table,
+                                                  void *grad_bf16, const NsrTableAdam *adam, float *workspace, uint32_t n,
+                                                  uint32_t level_mask_count, float grad_scale, int accumulate,
+                                                  const NsrGridDesc *desc, const int32_t *n_dev, int phases, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_dense")) return rc;
+    NSR_REQUIRE(workspace, "nsr_hashgrid_backward_params_dense: workspace is NULL");
+    NSR_REQUIRE(phases >= 1 && phases <= 7, "nsr_hashgrid_backward_params_dense: phases is a mask of 1 | 2 | 4");
+    const uint32_t D = dense_levels::dl_count(desc), F = desc->n_features;
+    if (D == 0) return NSR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(workspace + owner_workspace_floats(desc, n));
+    const uint64_t words = dense_levels::dl_acc_words64(desc);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(acc + words);
+    if (phases & 1)
+        NSR_REQUIRE(hipMemsetAsync(acc, 0, words * 8 + 32 * 4, st) == hipSuccess,
+                    "nsr_hashgrid_backward_params_dense: hipMemsetAsync failed");
+    if ((phases & 2) && n > 0) {
+        NSR_REQUIRE(x && dy_level_major, "nsr_hashgrid_backward_params_dense: NULL pointer");
+        const uint32_t lv = level_mask_count < D ? level_mask_count : D;
+        if (lv > 0) {
+            DISPATCH_F(F, hipLaunchKernelGGL((dense_levels::k_dense_levels_accumulate<F>),
+                                             dim3(nsr_div_up(n, dense_levels::DL_BLOCK), lv), dim3(dense_levels::DL_BLOCK), 0,
+                                             st, x, dy_level_major, n, level_mask_count, grad_scale, acc, flags, *desc, n_dev));
+            NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_dense(accumulate)");
+        }
+    }
+    if (phases & 4) {
+        NSR_REQUIRE((adam != nullptr) + (grad_table != nullptr) + (grad_bf16 != nullptr) == 1,
+                    "nsr_hashgrid_backward_params_dense: exactly one of adam / grad_table / grad_bf16");
+        own_small::OwnerAdam ad;
+        memset(&ad, 0, sizeof(ad));
+        if (adam) {
+            NSR_REQUIRE(adam->params && adam->exp_avg && adam->exp_avg_sq && adam->step && adam->hyper && !accumulate,
+                        "nsr_hashgrid_backward_params_dense: fused AdamW needs params / moments / schedule state and "
+                        "accumulate == 0");
+            NSR_REQUIRE((((uintptr_t)adam->params | (uintptr_t)adam->exp_avg | (uintptr_t)adam->exp_avg_sq) & 15) == 0 &&
+                            ((uintptr_t)adam->shadow & 7) == 0 && ((uintptr_t)adam->hyper & 7) == 0,
+                        "nsr_hashgrid_backward_params_dense: fused AdamW buffers must be 16-byte aligned (fp16 image: 8)");
+            ad.p = adam->params; ad.m = adam->exp_avg; ad.v = adam->exp_avg_sq; ad.shadow = (__half *)adam->shadow;
+            ad.step = adam->step; ad.hyper = adam->hyper;
+            ad.base_lr = adam->base_lr; ad.b1d = adam->beta1; ad.b2d = adam->beta2; ad.gamma = adam->gamma;
+            ad.m0 = adam->milestone0; ad.m1 = adam->milestone1; ad.m2 = adam->milestone2;
+            ad.b1 = (float)adam->beta1; ad.b2 = (float)adam->beta2; ad.eps = adam->eps; ad.wd = adam->weight_decay;
+        }
+        NSR_REQUIRE(!grad_bf16 || (!accumulate && ((uintptr_t)grad_bf16 & 7) == 0),
+                    "nsr_hashgrid_backward_params_dense: the bf16 gradient is written once into an 8-byte aligned buffer");
+        NSR_REQUIRE(!grad_table || ((uintptr_t)grad_table & 15) == 0,
+                    "nsr_hashgrid_backward_params_dense: grad_table must be 16-byte aligned");
+        const uint32_t blocks = nsr_div_up(words, (uint64_t)dense_levels::DL_BLOCK * 4);
+        DISPATCH_F(F, hipLaunchKernelGGL((dense_levels::k_dense_levels_finish<F>), dim3(blocks < 1024 ? blocks : 1024),
+                                         dim3(dense_levels::DL_BLOCK), 0, st, acc, flags, D, grad_table, accumulate,
+                                         (uint16_t *)grad_bf16, *desc, ad));
+        NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_dense(finish)");
+    }
+    return NSR_OK;
 }
 
 template <typename... A>
@@ -905,6 +983,17 @@ extern "C" int nsr_hashgrid_backward_params_owner_bin(const float *x, float *wor
                                                       const int32_t *n_dev, void *stream)
 {
     return owner_backward(x, nullptr, 2, 0, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, n_dev, 1, stream);
+}
+
+// ... of the levels [level_begin, level_end) only (the others' items are then never looked at: their gradient comes from
+// elsewhere -- nsr_hashgrid_backward_params_dense for the leading dense levels)
+extern "C" int nsr_hashgrid_backward_params_owner_bin_range(const float *x, float *workspace, uint32_t n,
+                                                            uint32_t level_mask_count, uint32_t level_begin,
+                                                            uint32_t level_end, const NsrGridDesc *desc,
+                                                            const int32_t *n_dev, void *stream)
+{
+    return owner_backward(x, nullptr, 2, 0, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, n_dev, 1, stream, nullptr,
+                          nullptr, nullptr, 0, nullptr, nullptr, level_begin, level_end);
 }
 
 // ... for items that a ..._with_second_order accumulation (binned != 0) will consume: the slice configuration of a launch is

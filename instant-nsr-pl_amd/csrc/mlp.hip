@@ -347,6 +347,206 @@ k_mlp_dgrad(const void *__restrict__ dout, int dout_f32, uint32_t dout_stride, c
     }
 }
 
+// ---- the data gradients of BOTH networks of the NeRF step in one kernel ------------------------------------------------------
+// models/texture.py:24-26 feeds the colour network [16 geometry features | SH4(dir)]; the geometry features are the density
+// network's outputs 0..15, so  dL/d(out_density) = dL/d(tex_in)[:, :16]  (+ dL/d logit on column 0): the colour network's input
+// gradient IS the density network's output gradient, row by row.  In the transposed MFMA layout the first output block of the
+// colour network's W0^T product leaves lane (n, g) with columns 4g .. 4g+3 of ITS sample -- exactly the D layout the density
+// network's chain starts from.  So the 16 x fp32 d_feature row never goes through HBM (128 B written + 64 B read per sample by
+// the two-kernel sequence), the SH half of d(tex_in) is never computed, and the step's chain has one launch (+ one event) less.
+// Every value is formed by the same operations as in the two k_mlp_dgrad launches: dX, the saved pre-activation gradients and
+// therefore the weight gradients are bit-identical (tests/test_gpu_mlp.py).
+template <int NHC /* hidden layers, colour */, int NHD /* hidden layers, density */>
+__global__ void __launch_bounds__(MLP_BLOCK, (NHC + NHD <= 3) ? 3 : 2)
+k_mlp_dgrad_pair(const float *__restrict__ d_rgb /* [n,3] */, const float *__restrict__ d_logit /* [n] */,
+                 const __half *__restrict__ out_c /* [n,16] sigmoid outputs */, const __half *__restrict__ acts_c,
+                 const __half *__restrict__ Wc_, __half *__restrict__ gpre_c, __half *__restrict__ gout_c,
+                 const __half *__restrict__ acts_d, const __half *__restrict__ Wd_, __half *__restrict__ gpre_d,
+                 __half *__restrict__ gout_d, float *__restrict__ d_enc /* level-major [16][n][2] */, uint32_t ldn,
+                 uint32_t n, float grad_scale, const int32_t *__restrict__ n_dev)
+{
+    const uint32_t n_live = live_count(n, n_dev);
+    constexpr int IN_PAD = 32;
+    constexpr int NP_C = WIDTH * IN_PAD + (NHC - 1) * WIDTH * WIDTH + 16 * WIDTH;
+    constexpr int NP_D = WIDTH * IN_PAD + (NHD - 1) * WIDTH * WIDTH + 16 * WIDTH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4;
+    const uint32_t wave = (blockIdx.x * MLP_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * MLP_BLOCK) >> 6;
+    const uint32_t n_tiles = (n_live + 15) / 16;
+    {
+        _Float16 *Wl_ = reinterpret_cast<_Float16 *>(smem);
+        const _Float16 *Wg = reinterpret_cast<const _Float16 *>(Wc_);
+        for (int k = threadIdx.x * 8; k < NP_C; k += MLP_BLOCK * 8)
+            *reinterpret_cast<uint4 *>(Wl_ + k) = *reinterpret_cast<const uint4 *>(Wg + k);
+        Wg = reinterpret_cast<const _Float16 *>(Wd_);
+        for (int k = threadIdx.x * 8; k < NP_D; k += MLP_BLOCK * 8)
+            *reinterpret_cast<uint4 *>(Wl_ + NP_C + k) = *reinterpret_cast<const uint4 *>(Wg + k);
+    }
+    __syncthreads();
+    const _Float16 *Wc = reinterpret_cast<const _Float16 *>(smem), *Wd = Wc + NP_C;
+    // colour network: W_out^T, hidden W^T, and the rows 0..15 of W0^T (the only input columns whose gradient is needed)
+    const _Float16 *Wcl = Wc + WIDTH * IN_PAD + (NHC - 1) * WIDTH * WIDTH;
+    half8 atl_c[4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) atl_c[ib] = load_at_natural(Wcl, WIDTH, ib * 16 + nl, g, 16);
+    half8 ath_c[NHC > 1 ? NHC - 1 : 1][4][2];
+#pragma unroll
+    for (int h = 0; h < NHC - 1; ++h) {
+        const _Float16 *Wh = Wc + WIDTH * IN_PAD + h * WIDTH * WIDTH;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) ath_c[h][ib][kc] = load_at_sigma(Wh, WIDTH, ib * 16 + nl, kc, g);
+    }
+    half8 at0_c[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) at0_c[kc] = load_at_sigma(Wc, IN_PAD, nl, kc, g);
+    // density network
+    const _Float16 *Wdl = Wd + WIDTH * IN_PAD + (NHD - 1) * WIDTH * WIDTH;
+    half8 atl_d[4];
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) atl_d[ib] = load_at_natural(Wdl, WIDTH, ib * 16 + nl, g, 16);
+    half8 ath_d[NHD > 1 ? NHD - 1 : 1][4][2];
+#pragma unroll
+    for (int h = 0; h < NHD - 1; ++h) {
+        const _Float16 *Wh = Wd + WIDTH * IN_PAD + h * WIDTH * WIDTH;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) ath_d[h][ib][kc] = load_at_sigma(Wh, WIDTH, ib * 16 + nl, kc, g);
+    }
+    half8 at0_d[2][2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) at0_d[ib][kc] = load_at_sigma(Wd, IN_PAD, ib * 16 + nl, kc, g);
+    const float inv_scale = 1.f / grad_scale;
+    const int src_lo = nl + 16 * ((2 * g) & 3), src_hi = nl + 16 * ((2 * g + 1) & 3);
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint32_t s = tile * 16 + nl;
+        const bool valid = s < n_live;
+        // ---------------- colour network: dOut = d_rgb * sigmoid' (columns 0..2), scaled -------------------------------------
+        f32x4 d_o = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t c = 4 * g + r;
+                if (c < 3) {
+                    float v = d_rgb[(uint64_t)s * 3 + c];
+                    const float o = __half2float(out_c[(uint64_t)s * 16 + c]);
+                    v *= o * (1.f - o);
+                    d_o[r] = v * grad_scale;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gout_c[t32_off(s, 4 * g + r, 16)] = __float2half_rn(d_o[r]);
+        }
+        half8 bo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lo = __shfl(d_o[r], src_lo, 64), hi = __shfl(d_o[r], src_hi, 64);
+            bo[r] = (g < 2) ? (_Float16)lo : (_Float16)0;
+            bo[4 + r] = (g < 2) ? (_Float16)hi : (_Float16)0;
+        }
+        f32x4 dh[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            dh[ib] = mfma32(atl_c[ib], bo, c);
+        }
+        f32x4 dfeat = {0.f, 0.f, 0.f, 0.f};  // dL/d tex_in[:, 4g .. 4g+3] (unscaled), this lane's sample
+#pragma unroll
+        for (int h = NHC - 1; h >= 0; --h) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const f32x4 hact = valid ? load_h4(acts_c + ((uint64_t)h * n + s) * WIDTH + ib * 16 + 4 * g)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[ib][r] = hact[r] > 0.f ? dh[ib][r] : 0.f;
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gpre_c[(uint64_t)h * WIDTH * ldn + t32_off(s, ib * 16 + 4 * g + r, WIDTH)] = __float2half_rn(dh[ib][r]);
+                }
+            }
+            const half8 b0 = pack_b(dh[0], dh[1]), b1 = pack_b(dh[2], dh[3]);
+            if (h > 0) {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma32(ath_c[h > 0 ? h - 1 : 0][ib][0], b0, c);
+                    dh[ib] = mfma32(ath_c[h > 0 ? h - 1 : 0][ib][1], b1, c);
+                }
+            } else {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                c = mfma32(at0_c[0], b0, c);
+                c = mfma32(at0_c[1], b1, c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dfeat[r] = c[r] * inv_scale;  // (what the two-kernel path stores as d_tex)
+            }
+        }
+        // ---------------- density network: dOut = d feature (+ d logit on column 0), no output activation -------------------
+        if (valid) {
+            if (g == 0) dfeat[0] += d_logit[s];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d_o[r] = dfeat[r] * grad_scale;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gout_d[t32_off(s, 4 * g + r, 16)] = __float2half_rn(d_o[r]);
+        } else {
+            d_o = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lo = __shfl(d_o[r], src_lo, 64), hi = __shfl(d_o[r], src_hi, 64);
+            bo[r] = (g < 2) ? (_Float16)lo : (_Float16)0;
+            bo[4 + r] = (g < 2) ? (_Float16)hi : (_Float16)0;
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            dh[ib] = mfma32(atl_d[ib], bo, c);
+        }
+#pragma unroll
+        for (int h = NHD - 1; h >= 0; --h) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const f32x4 hact = valid ? load_h4(acts_d + ((uint64_t)h * n + s) * WIDTH + ib * 16 + 4 * g)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[ib][r] = hact[r] > 0.f ? dh[ib][r] : 0.f;
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gpre_d[(uint64_t)h * WIDTH * ldn + t32_off(s, ib * 16 + 4 * g + r, WIDTH)] = __float2half_rn(dh[ib][r]);
+                }
+            }
+            const half8 b0 = pack_b(dh[0], dh[1]), b1 = pack_b(dh[2], dh[3]);
+            if (h > 0) {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma32(ath_d[h > 0 ? h - 1 : 0][ib][0], b0, c);
+                    dh[ib] = mfma32(ath_d[h > 0 ? h - 1 : 0][ib][1], b1, c);
+                }
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma32(at0_d[ib][0], b0, c);
+                    c = mfma32(at0_d[ib][1], b1, c);
+                    if (valid) {  // level-major [16][n][2]: columns 4g+r of block ib are levels 8 ib + 2g and 8 ib + 2g + 1
+                        const uint32_t lv = 8 * ib + 2 * g;
+                        *reinterpret_cast<float2 *>(d_enc + ((uint64_t)lv * n + s) * 2) = make_float2(c[0] * inv_scale, c[1] * inv_scale);
+                        *reinterpret_cast<float2 *>(d_enc + ((uint64_t)(lv + 1) * n + s) * 2) = make_float2(c[2] * inv_scale, c[3] * inv_scale);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- wgrad ------------------------------------------------------------------------------------------------------
 // dW[o][k] = sum_n G[n][o] A[n][k] with the SAMPLE index on the MFMA k axis (v_mfma_f32_16x16x32_f16, 32 samples per
 // instruction).  The fragment of lane (i = lane&15, g = lane>>4) is 8 CONSECUTIVE samples of ONE column: with the
@@ -685,6 +885,66 @@ static int mlp_backward_impl(const void *dout, int dout_is_f32, uint32_t dout_st
     hipLaunchKernelGGL(k_reduce_partials, dim3(nsr_div_up(np, 256), RED_SEGS), dim3(256), 0, st, partials, grad_weights, np,
                        nb, 1.f / grad_scale);
     NSR_CHECK_LAUNCH("nsr_mlp_backward(reduce)");
+    return NSR_OK;
+}
+
+// ---- both networks' data gradients in one launch (k_mlp_dgrad_pair) ----------------------------------------------------------
+// 1 when the pair kernel covers these two networks: colour [16 features | 16 SH] -> 64 x (1..2) -> 3 sigmoid, density 32 -> 64 x
+// (1..2) -> 16 linear outputs (the reference's nerf-blender shapes, models/texture.py:23-30 + models/geometry.py:122-130)
+extern "C" int nsr_mlp_dgrad_pair_supported(const NsrMlpDesc *color, const NsrMlpDesc *density)
+{
+    if (!color || !density) return 0;
+    return color->in_pad == 32 && color->n_in == 32 && color->n_out == 3 && color->out_pad == 16 &&
+           color->output_activation == NSR_ACT_SIGMOID && color->n_hidden >= 1 && color->n_hidden <= 2 &&
+           density->in_pad == 32 && density->n_in == 32 && density->n_out == 16 && density->out_pad == 16 &&
+           density->output_activation == NSR_ACT_NONE && density->n_hidden >= 1 && density->n_hidden <= 2;
+}
+
+static uint32_t g_dgrad_pair_max_blocks = 2048;
+extern "C" uint32_t nsr_mlp_dgrad_pair_max_blocks(uint32_t blocks)
+{
+    const uint32_t old = g_dgrad_pair_max_blocks;
+    if (blocks) g_dgrad_pair_max_blocks = blocks;
+    return old;
+}
+
+// d_rgb [n,3] fp32 and d_logit [n] fp32 in, d_enc level-major fp32 [16][n][2] out; the pre-activation gradients the
+// weight-gradient kernels read are saved into the two networks' backward workspaces exactly where nsr_mlp_backward_phases(..., 1)
+// puts them, so nsr_mlp_backward_phases(..., 2) follows unchanged.
+extern "C" int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, const nsr_half *out_color,
+                                  const nsr_half *acts_color, const nsr_half *w_color, float *partials_color,
+                                  const nsr_half *acts_density, const nsr_half *w_density, float *partials_density,
+                                  float *d_enc_level_major, uint32_t n, float grad_scale, const NsrMlpDesc *color,
+                                  const NsrMlpDesc *density, const int32_t *n_dev, void *stream)
+{
+    NSR_REQUIRE(nsr_mlp_dgrad_pair_supported(color, density), "nsr_mlp_dgrad_pair: network shapes not covered "
+                "(colour 32 -> 64 x 1..2 -> 3 sigmoid, density 32 -> 64 x 1..2 -> 16)");
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(d_rgb && d_logit && out_color && acts_color && w_color && partials_color && acts_density && w_density &&
+                    partials_density && d_enc_level_major, "nsr_mlp_dgrad_pair: NULL pointer");
+    NSR_REQUIRE(grad_scale > 0.f, "nsr_mlp_dgrad_pair: grad_scale must be > 0");
+    const uint32_t nb = bwd_blocks(n), ldn = mlp_ldn(n);
+    __half *gpre_c = reinterpret_cast<__half *>(partials_color + (uint64_t)nb * n_params_of(color));
+    __half *gout_c = gpre_c + (uint64_t)color->n_hidden * 64 * ldn;
+    __half *gpre_d = reinterpret_cast<__half *>(partials_density + (uint64_t)nb * n_params_of(density));
+    __half *gout_d = gpre_d + (uint64_t)density->n_hidden * 64 * ldn;
+    const uint32_t n_tiles = (n + 15) / 16;
+    uint32_t blocks = (n_tiles + WAVES - 1) / WAVES;
+    if (blocks > g_dgrad_pair_max_blocks) blocks = g_dgrad_pair_max_blocks;
+    const size_t lds = (size_t)(n_params_of(color) + n_params_of(density)) * sizeof(_Float16);
+#define NSR_PAIR(NHC, NHD)                                                                                               \
+    hipLaunchKernelGGL((k_mlp_dgrad_pair<NHC, NHD>), dim3(blocks), dim3(MLP_BLOCK), lds, (hipStream_t)stream, d_rgb, d_logit, \
+                       (const __half *)out_color, (const __half *)acts_color, (const __half *)w_color, gpre_c, gout_c,    \
+                       (const __half *)acts_density, (const __half *)w_density, gpre_d, gout_d, d_enc_level_major, ldn, n, \
+                       grad_scale, n_dev)
+    switch (color->n_hidden * 10 + density->n_hidden) {
+    case 11: NSR_PAIR(1, 1); break;
+    case 12: NSR_PAIR(1, 2); break;
+    case 21: NSR_PAIR(2, 1); break;
+    default: NSR_PAIR(2, 2); break;
+    }
+#undef NSR_PAIR
+    NSR_CHECK_LAUNCH("nsr_mlp_dgrad_pair");
     return NSR_OK;
 }
 

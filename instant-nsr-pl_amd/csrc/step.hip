@@ -138,18 +138,21 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
 
 // Helper stream of the main pass: the item binning of the table backward depends only on the sample positions, so it runs
 // beside the colour MLP / compositing / MLP backward chain instead of in front of the accumulation kernel.
+// (round 5) two more streams: `stream_b` takes the density network's weight-gradient kernels beside the colour network's on
+// `stream`, `stream_c` the dense levels' table backward (csrc/hashgrid_dense.inc) beside the owner launch of the hashed levels
 struct HelperStream {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_b = nullptr, stream_c = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr;
+    hipEvent_t dgrad_done = nullptr, wgrad_b_done = nullptr, dense_done = nullptr;
     bool ok = false;
     bool init()
     {
         if (ok) return true;
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&join_wgrad, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&fork_wgrad, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking) != hipSuccess) return false;
+        for (hipEvent_t *e : {&fork, &join, &join_wgrad, &fork_wgrad, &dgrad_done, &wgrad_b_done, &dense_done})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return false;
         return ok = true;
     }
 };
@@ -168,6 +171,32 @@ extern "C" int nsr_nerf_wait_kept_rows(void *stream)
     NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_helper.fork, 0) == hipSuccess, "nsr_nerf_wait_kept_rows: hipStreamWaitEvent failed");
     return NSR_OK;
 }
+
+// Round-5 forms of the step's kernels, switchable for same-process A/B runs (tools/step_variants.py) and as a fallback:
+//   key 0: both networks' data gradients in ONE kernel (nsr_mlp_dgrad_pair) instead of two launches + a d_feature round trip
+//   key 1: the dense levels' table gradient through ray-run merged fixed-point atomics on a stream of their own
+//          (nsr_hashgrid_backward_params_dense), the owner launch covering the hashed levels only
+//   key 2: flat segmented compositing (nsr_composite_*_flat) instead of one wave per ray
+//   key 3: the two networks' weight-gradient kernels on two helper streams (only with key 0)
+// value < 0 queries; returns the previous value.  All default to 1.
+static int g_variant[8] = {1, 1, 1, 1, 0, 0, 0, 0};
+extern "C" int nsr_nerf_step_variant(int key, int value)
+{
+    if (key < 0 || key >= 8) return -1;
+    const int old = g_variant[key];
+    if (value >= 0) g_variant[key] = value;
+    return old;
+}
+
+// nsr_nerf_prune_pass_deferred leaves the packing of the kept counts to the next main pass's kept-row copy
+struct DeferredPack {
+    bool pending = false;
+    const int32_t *kept = nullptr, *sums = nullptr;
+    int32_t *packed = nullptr, *total = nullptr, *stats = nullptr;
+    uint32_t n_rays = 0, capacity = 0;
+};
+static DeferredPack g_deferred;
+constexpr uint64_t PRUNE_SUMS_BYTES = 65536 / 8 * 4;  // block sums of up to 65,536 rays, behind the prune workspace's rows
 
 // 1: the main pass leaves the join with its weight-gradient kernels to the caller, who queues more work behind them on the
 // helper stream (the optimizer launch) and makes the main stream wait for THAT instead -- one wait at the end of a step, not two
@@ -188,8 +217,16 @@ extern "C" int nsr_nerf_prune_layout(const NsrNerfStepDesc *d, uint32_t n_marche
     out->enc = c.take(M * C * 2);
     out->out1 = c.take(M * 16 * 2);
     out->acts1 = c.take(M * 64 * 2 * d->mlp_density.n_hidden);
+    (void)c.take(PRUNE_SUMS_BYTES);  // (nsr_nerf_prune_pass_deferred: prune_sums_offset)
     out->total_bytes = c.off;
     return NSR_OK;
+}
+
+static uint64_t prune_sums_offset(const NsrNerfStepDesc *d, uint32_t n_marched)
+{
+    NsrNerfPruneLayout L;
+    (void)nsr_nerf_prune_layout(d, n_marched, &L);
+    return L.total_bytes - align_up(PRUNE_SUMS_BYTES);
 }
 
 // the sigma pass of nsr_nerf_prune_pass: 0 (default) = stand-alone encode + MLP + visibility prefix over every marched sample,
@@ -207,14 +244,15 @@ extern "C" int nsr_nerf_sigma_mode(int mode)
     return old;
 }
 
-extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
-                                   const int64_t *ray_indices, const float *t_starts, const float *t_ends,
-                                   const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
-                                   void *workspace, int32_t *kept_counts, int32_t *packed_kept, int32_t *total_kept,
-                                   uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
-                                   uint32_t kept_capacity, int32_t *kept_stats, const float *x01_marched, void *stream)
+static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
+                      const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                      const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
+                      void *workspace, int32_t *kept_counts, int32_t *packed_kept, int32_t *total_kept,
+                      uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
+                      uint32_t kept_capacity, int32_t *kept_stats, const float *x01_marched, void *stream, bool defer_pack)
 {
     NSR_REQUIRE(d && workspace && kept_counts && packed_kept && total_kept, "nsr_nerf_prune_pass: NULL pointer");
+    g_deferred.pending = false;
     NsrNerfPruneLayout L;
     NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &L));
     char *ws = (char *)workspace;
@@ -244,12 +282,53 @@ extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o
             NSR_TRY(nsr_mlp_forward_ex(enc, 0, C, d->grid.n_features, w_density, out1, acts1, n_marched, &d->mlp_density,
                                        n_marched_dev, stream));
         }
+        // deferred packing: the kept-row copy of the main pass that follows forms the offsets itself from per-block sums
+        // (the step's usual network shapes only: what nsr_nerf_copy_kept_rows covers)
+        if (defer_pack && n_rays > 0 && n_rays <= 65536u && d->grid.n_features == 2 && d->mlp_density.n_hidden <= 2) {
+            int32_t *sums = (int32_t *)(ws + prune_sums_offset(d, n_marched));
+            NSR_TRY(nsr_visibility_prefix_sums(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
+                                               kept_counts, sums, n_rays, stream));
+            g_deferred.pending = true;
+            g_deferred.kept = kept_counts; g_deferred.sums = sums; g_deferred.packed = packed_kept;
+            g_deferred.total = total_kept; g_deferred.stats = kept_stats; g_deferred.n_rays = n_rays;
+            g_deferred.capacity = kept_capacity;
+            return NSR_OK;
+        }
         NSR_TRY(nsr_visibility_prefix(out1, 16, d->density_bias, t_starts, t_ends, packed_info, d->early_stop_eps,
                                       kept_counts, n_rays, stream));
     }
     NSR_TRY(nsr_pack_from_counts_capped(kept_counts, packed_kept, total_kept, n_rays, kept_capacity, kept_stats, nullptr,
                                         stream));
     return NSR_OK;
+}
+
+extern "C" int nsr_nerf_prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
+                                   const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                   const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
+                                   void *workspace, int32_t *kept_counts, int32_t *packed_kept, int32_t *total_kept,
+                                   uint32_t n_marched, uint32_t n_rays, const int32_t *n_marched_dev,
+                                   uint32_t kept_capacity, int32_t *kept_stats, const float *x01_marched, void *stream)
+{
+    return prune_pass(d, rays_o, rays_d, ray_indices, t_starts, t_ends, packed_info, table, w_density, workspace, kept_counts,
+                      packed_kept, total_kept, n_marched, n_rays, n_marched_dev, kept_capacity, kept_stats, x01_marched,
+                      stream, false);
+}
+
+// The same pass for a caller that queues nsr_nerf_main_pass* / nsr_nerf_render_forward on the SAME stream with the SAME
+// packed_kept / total_kept right behind it: packed_kept, total_kept and the statistics are then written by that pass's first
+// kernel (the kept-row copy forms the offsets itself) -- the one-workgroup scan between the two is gone from the step's chain.
+// Nothing else may read packed_kept / total_kept in between.  Falls back to the plain pass for shapes the copy does not cover.
+extern "C" int nsr_nerf_prune_pass_deferred(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
+                                            const int64_t *ray_indices, const float *t_starts, const float *t_ends,
+                                            const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
+                                            void *workspace, int32_t *kept_counts, int32_t *packed_kept,
+                                            int32_t *total_kept, uint32_t n_marched, uint32_t n_rays,
+                                            const int32_t *n_marched_dev, uint32_t kept_capacity, int32_t *kept_stats,
+                                            const float *x01_marched, void *stream)
+{
+    return prune_pass(d, rays_o, rays_d, ray_indices, t_starts, t_ends, packed_info, table, w_density, workspace, kept_counts,
+                      packed_kept, total_kept, n_marched, n_rays, n_marched_dev, kept_capacity, kept_stats, x01_marched,
+                      stream, true);
 }
 
 extern "C" int nsr_nerf_main_layout(const NsrNerfStepDesc *d, uint32_t n_kept, uint32_t n_rays, NsrNerfMainLayout *out)
@@ -340,10 +419,30 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // compositing kernels instead of a one-workgroup kernel between them (NSR_L1_SEPARATE: A/B switch)
     static const bool l1_separate = getenv("NSR_L1_SEPARATE") != nullptr;
     const bool l1_folded = phases == 3 && compute_grads && gt_rgb && !up && S > 0 && n_rays > 0 && !l1_separate;
+    // round-5 forms (nsr_nerf_step_variant): the dense levels of the table backward on their own stream, flat compositing
+    const uint32_t n_dense = nsr_hashgrid_dense_levels(&d->grid);
+    const bool use_dense = g_variant[1] && overlap_bins && !xchg && n_dense > 0 && n_dense < Lv;
+    const bool flat = g_variant[2] != 0;
     g_ht.mark(0);
     if (phases & 1) {
+    const bool deferred = g_deferred.pending;
+    g_deferred.pending = false;
+    if (deferred)
+        NSR_REQUIRE(g_deferred.packed == packed_kept && g_deferred.n_rays == n_rays && (!n_kept_dev || g_deferred.total == n_kept_dev),
+                    "nsr_nerf_main_pass: the pass behind nsr_nerf_prune_pass_deferred must take the same packed_kept / "
+                    "total_kept / n_rays");
+    if (deferred && S == 0)  // (no sample buffer: nothing to copy, the packing is still owed)
+        NSR_TRY(nsr_pack_from_counts_capped(g_deferred.kept, g_deferred.packed, g_deferred.total, n_rays, g_deferred.capacity,
+                                            g_deferred.stats, nullptr, stream));
     if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
-        if (F == 2 && nh1 <= 2)  // the step's usual shape: one lane per kept sample, all its rows in one round trip
+        if (deferred)  // packing folded into the copy: packed_kept / total_kept are written by this launch
+            NSR_TRY(nsr_nerf_copy_kept_rows_scan(packed_marched, g_deferred.kept, g_deferred.sums, g_deferred.packed,
+                                                 g_deferred.total, g_deferred.stats, t_starts, t_ends, x01m,
+                                                 (const nsr_half *)(pw + P.enc), (const nsr_half *)(pw + P.out1),
+                                                 (const nsr_half *)(pw + P.acts1), t0, t1, x01, enc, out1, acts1, Lv, nh1,
+                                                 n_marched, S, rays_d, (int64_t *)(ws + L.ray_indices), tex_in, n_rays,
+                                                 stream));
+        else if (F == 2 && nh1 <= 2)  // the step's usual shape: one lane per kept sample, all its rows in one round trip
             NSR_TRY(nsr_nerf_copy_kept_rows(packed_marched, packed_kept, t_starts, t_ends, x01m,
                                             (const nsr_half *)(pw + P.enc), (const nsr_half *)(pw + P.out1),
                                             (const nsr_half *)(pw + P.acts1), t0, t1, x01, enc, out1, acts1, Lv, nh1,
@@ -367,7 +466,13 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                    n_kept_dev, stream));
     }
     g_ht.mark(2);
-    if (l1_folded) {  // the loss reduction rides in the two compositing kernels (per-block partials behind acc)
+    if (flat) {  // one lane per sample (csrc/fused.hip k_composite_forward_flat); the loss partials ride along when folded
+        NSR_TRY(nsr_composite_forward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
+                                           comp_rgb, opacity, depth, l1_folded ? gt_rgb : nullptr,
+                                           l1_folded ? acc + 2 : nullptr, n_rays, stream));
+        if (!l1_folded && gt_rgb)
+            NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
+    } else if (l1_folded) {  // the loss reduction rides in the two compositing kernels (per-block partials behind acc)
         NSR_TRY(nsr_composite_forward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights,
                                                 trans, comp_rgb, opacity, depth, gt_rgb, acc + 2, n_rays, stream));
     } else {
@@ -380,8 +485,15 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     if (overlap_bins) {
         NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, g_helper.fork, 0) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream fork failed");
+        if (use_dense)  // (its accumulators are cleared on the stream the dense kernels run on: ordered behind last step's)
+            NSR_TRY(nsr_hashgrid_backward_params_dense(nullptr, nullptr, nullptr, nullptr, nullptr, (float *)(ws + L.grid_ws), S,
+                                                       Lv, 1.0f, 0, &d->grid, n_kept_dev, 1, g_helper.stream_c));
         {
             ProfScope p(NSR_PROF_GRID_BACKWARD_BIN, S, g_helper.stream);
+            if (use_dense)  // the owner launch takes the hashed levels only: nothing else needs items
+                NSR_TRY(nsr_hashgrid_backward_params_owner_bin_range(x01, (float *)(ws + L.grid_ws), S, Lv, n_dense, Lv,
+                                                                     &d->grid, n_kept_dev, g_helper.stream));
+            else
             NSR_TRY(nsr_hashgrid_backward_params_owner_bin(x01, (float *)(ws + L.grid_ws), S, d->grid.n_levels, &d->grid,
                                                            n_kept_dev, g_helper.stream));
         }
@@ -427,7 +539,15 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // dgrad and the table backward -- only dx continues down the main chain
     static const bool wgrad_inline = getenv("NSR_WGRAD_INLINE") != nullptr;  // diagnostic A/B switch
     void *wg = (overlap_bins && !wgrad_inline) ? (void *)g_helper.stream : nullptr;
-    if (up)  // the caller's loss: arbitrary dL/d comp_rgb, dL/d opacity, dL/d depth (+ dL/d weights: distortion loss)
+    if (flat && up)
+        NSR_TRY(nsr_composite_backward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
+                                            up->comp_rgb, up->opacity, up->depth, up->weights, nullptr, nullptr, nullptr,
+                                            nullptr, nullptr, d->loss_scale, d_rgb, d_logit, n_rays, stream));
+    else if (flat)  // built-in masked smooth-L1: (sum, valid rays) from the forward's partials when folded, from acc otherwise
+        NSR_TRY(nsr_composite_backward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
+                                            nullptr, nullptr, nullptr, nullptr, comp_rgb, opacity, gt_rgb,
+                                            l1_folded ? acc + 2 : nullptr, acc, d->loss_scale, d_rgb, d_logit, n_rays, stream));
+    else if (up)  // the caller's loss: arbitrary dL/d comp_rgb, dL/d opacity, dL/d depth (+ dL/d weights: distortion loss)
         NSR_TRY(nsr_composite_backward_ex(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                           up->comp_rgb, up->opacity, up->depth, up->weights, d_rgb, d_logit, n_rays, stream));
     else if (l1_folded)
@@ -445,7 +565,36 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // ends behind the table backward instead of underneath it.  So: one fork per network; NSR_WGRAD_ONE_FORK for A/B.
     static const bool two_forks = getenv("NSR_WGRAD_ONE_FORK") == nullptr;
     g_ht.mark(5);
-    if (wg && !two_forks) {
+    const bool pair = g_variant[0] && nsr_mlp_dgrad_pair_supported(&d->mlp_color, &d->mlp_density) && C == 32;
+    bool dgrad_event = false;  // g_helper.dgrad_done recorded behind the last data-gradient kernel
+    if (pair) {
+        {   // both networks' data gradients in one launch; d_feature stays in registers (csrc/mlp.hip k_mlp_dgrad_pair)
+            ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
+            NSR_TRY(nsr_mlp_dgrad_pair(d_rgb, d_logit, out2, acts2, w_color, part2, acts1, w_density, part1, d_enc, S,
+                                       d->grad_scale, &d->mlp_color, &d->mlp_density, n_kept_dev, stream));
+        }
+        void *wg_c = wg, *wg_d = wg;
+        if (wg) {
+            NSR_REQUIRE(hipEventRecord(g_helper.dgrad_done, st) == hipSuccess &&
+                            hipStreamWaitEvent(g_helper.stream, g_helper.dgrad_done, 0) == hipSuccess,
+                        "nsr_nerf_main_pass: weight-gradient fork failed");
+            dgrad_event = true;
+            if (g_variant[3]) {  // the density network's weight-gradient kernels beside the colour network's
+                wg_d = (void *)g_helper.stream_b;
+                NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_b, g_helper.dgrad_done, 0) == hipSuccess,
+                            "nsr_nerf_main_pass: weight-gradient fork failed");
+            }
+        }
+        NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, nullptr, 32, 0,
+                                        part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, wg_c ? wg_c : stream, 2));
+        NSR_TRY(nsr_mlp_backward_phases(d_enc, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
+                                        grad_density_mlp, nullptr, C, d->grid.n_features, part1, S, d->grad_scale,
+                                        &d->mlp_density, n_kept_dev, wg_d ? wg_d : stream, 2));
+        if (wg && wg_d != wg)  // whatever is queued on the helper stream from here on sees both networks' gradients
+            NSR_REQUIRE(hipEventRecord(g_helper.wgrad_b_done, g_helper.stream_b) == hipSuccess &&
+                            hipStreamWaitEvent(g_helper.stream, g_helper.wgrad_b_done, 0) == hipSuccess,
+                        "nsr_nerf_main_pass: weight-gradient join failed");
+    } else if (wg && !two_forks) {
         {
             ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
             NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
@@ -496,6 +645,33 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                 NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_group[g], st) == hipSuccess,
                             "nsr_nerf_main_pass_exchange: hipEventRecord failed");
         }
+    } else if (use_dense) {
+        // dense levels: ray-run merged atomics + their write-out on stream_c, beside the owner launch of the hashed levels
+        if (!dgrad_event)
+            NSR_REQUIRE(hipEventRecord(g_helper.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: dense-level fork failed");
+        NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_c, g_helper.dgrad_done, 0) == hipSuccess,
+                    "nsr_nerf_main_pass: dense-level fork failed");
+        {
+            ProfScope p(NSR_PROF_GRID_BACKWARD_DENSE, S, g_helper.stream_c);
+            NSR_TRY(nsr_hashgrid_backward_params_dense(x01, d_enc, table_adam ? nullptr : grad_table, nullptr, table_adam,
+                                                       (float *)(ws + L.grid_ws), S, Lv, 1.0f, 0, &d->grid, n_kept_dev, 2 | 4,
+                                                       g_helper.stream_c));
+        }
+        NSR_REQUIRE(hipEventRecord(g_helper.dense_done, g_helper.stream_c) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
+        NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess, "nsr_nerf_main_pass: helper stream join failed");
+        {
+            ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
+            if (table_adam)
+                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam_range(x01, d_enc, (float *)(ws + L.grid_ws), S, Lv,
+                                                                                 1.0f, n_dense, Lv, &d->grid, n_kept_dev,
+                                                                                 table_adam, stream));
+            else
+                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_range(x01, d_enc, grad_table, nullptr,
+                                                                            (float *)(ws + L.grid_ws), S, Lv, 1.0f, n_dense, Lv,
+                                                                            &d->grid, n_kept_dev, stream));
+        }
+        // (whoever reads the table next on this stream -- the next step's encode, the caller's optimizer -- sees all levels)
+        NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.dense_done, 0) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
     } else {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
         if (overlap_bins) {

@@ -48,6 +48,9 @@ class FusedNeRFStep:
         self._PL, self._ML = nsr_hip.NsrNerfPruneLayout(), nsr_hip.NsrNerfMainLayout()
         import os
         self.kept_rows_event = not os.environ.get("NSR_PRUNED_EVENT")  # A/B switch: a torch event behind the pruning pass instead
+        # packing of the kept counts folded into the main pass's kept-row copy (nsr_nerf_prune_pass_deferred): used wherever a
+        # main pass follows the pruning pass on the same stream with nothing reading packed_kept / total in between
+        self.defer_pack = not os.environ.get("NSR_PACK_SEPARATE")
 
     # ---- small launch helpers (all on torch's current stream) -------------------------------------------------
     def _positions(self, rays_o, rays_d, ri, t0, t1, want_dirs):
@@ -254,9 +257,10 @@ class FusedNeRFStep:
                       "nsr_ray_march_bricks_write")
                 check(lib.nsr_nerf_prune_layout(_byref(d), m_cap, _byref(self._PL)), "nsr_nerf_prune_layout")
                 pws = torch.empty(max(int(self._PL.total_bytes), 256), dtype=torch.uint8, device=dev)
-                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), ptr(packed),
-                                              ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2), ptr(total_s), m_cap, n_rays,
-                                              ptr(total_m), s_cap, ptr(stats[8:16]), None, s), "nsr_nerf_prune_pass")
+                prune = lib.nsr_nerf_prune_pass_deferred if self.defer_pack else lib.nsr_nerf_prune_pass
+                check(prune(_byref(d), ptr(rays_o), ptr(rays_d), ptr(ri), ptr(t0), ptr(t1), ptr(packed),
+                            ptr(table), ptr(w1), ptr(pws), ptr(kept), ptr(packed2), ptr(total_s), m_cap, n_rays,
+                            ptr(total_m), s_cap, ptr(stats[8:16]), None, s), "nsr_nerf_prune_pass")
                 check(lib.nsr_nerf_main_layout(_byref(d), s_cap, n_rays, _byref(self._ML)), "nsr_nerf_main_layout")
                 L = copy.copy(self._ML)
                 ws = torch.empty(int(L.total_bytes), dtype=torch.uint8, device=dev)
@@ -573,11 +577,15 @@ class FusedNeRFStep:
             else:
                 x01m = mb["x01"]
                 mb["valid"] = False  # consumed: the ring slot is re-marched before its next use
+            # (the kept counts are packed by the main pass's first kernel unless something is queued behind the pruning pass
+            # that reads the count before it: the torch-event variants below)
+            defer = self.defer_pack and (after_prune_queued is None or (compute_grads and self.kept_rows_event))
+            prune = lib.nsr_nerf_prune_pass_deferred if defer else lib.nsr_nerf_prune_pass
             with _ops.timed("fused:march_prune"):
-                check(lib.nsr_nerf_prune_pass(_byref(d), ptr(rs["ro"]), ptr(rs["rd"]), ptr(mb["ri"]), ptr(mb["t0"]),
-                                              ptr(mb["t1"]), ptr(rs["packed"]), ptr(table), ptr(w1), ptr(ab["pws"]),
-                                              ptr(kept), ptr(packed2), ptr(total), m_cap, slots, ptr(rs["total"]),
-                                              int(s_cap), ptr(kept_stats), ptr(x01m), s), "nsr_nerf_prune_pass")
+                check(prune(_byref(d), ptr(rs["ro"]), ptr(rs["rd"]), ptr(mb["ri"]), ptr(mb["t0"]),
+                            ptr(mb["t1"]), ptr(rs["packed"]), ptr(table), ptr(w1), ptr(ab["pws"]),
+                            ptr(kept), ptr(packed2), ptr(total), m_cap, slots, ptr(rs["total"]),
+                            int(s_cap), ptr(kept_stats), ptr(x01m), s), "nsr_nerf_prune_pass")
             # what the caller queues behind the pruning pass (the next step's ray count / packing, on a side stream) waits for
             # THIS event; the call itself comes after the main pass is queued -- the main stream must not sit idle behind the
             # pruning pass while the host issues side-stream launches (rocprofv3 timeline, round 3: pack ... 72 us ... copy_kept_rows)
