@@ -611,6 +611,7 @@ int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out, uint32_t 
  * (nsr_composite_l1_partials_floats(n_rays) floats).  backward: EITHER the upstream gradients grad_comp_rgb [R,3] (+
  * optional grad_opacity [R], grad_depth [R], grad_weights [n]) OR the built-in loss on (comp_rgb, opacity, gt_rgb) with its
  * (sum, valid rays) read from acc2 (partials == NULL) or summed from the forward's partials (acc2 then receives them). */
+int nsr_composite_flat_rays_per_wave(int rays); /* 4 (default), 8 or 16; 0 queries; returns the previous value */
 int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
                                const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
                                const float *background, float *weights, float *trans, float *comp_rgb, float *opacity,
@@ -690,12 +691,20 @@ typedef struct NsrNerfMainLayout {
 #define NSR_PROF_MLP_BACKWARD_DENSITY 5
 #define NSR_PROF_GRID_BACKWARD_BIN 6 /* item binning of the table backward, on the main pass's helper stream */
 #define NSR_PROF_GRID_BACKWARD_DENSE 7 /* dense levels of the table backward (nsr_hashgrid_backward_params_dense), own stream */
-/* Round 5 -- forms of the step's kernels, switchable for same-process A/B runs and as a fallback (all default to 1):
+/* Round 5 -- forms of the step's kernels, switchable for same-process A/B runs and as a fallback (keys 0, 2, 5 default to 1,
+ * keys 1 and 3 -- measured slower inside the step -- to 0):
  * key 0: nsr_mlp_dgrad_pair instead of two data-gradient launches; key 1: the dense levels of the table backward through
  * nsr_hashgrid_backward_params_dense on a stream of their own, the owner launch covering the hashed levels only; key 2:
  * nsr_composite_*_flat instead of one wave per ray; key 3: the two networks' weight-gradient kernels on two helper streams
- * (with key 0).  value < 0 queries; returns the previous value (-1: unknown key). */
+ * (with key 0); key 5: the pass's fork events ride on the kernels in front of them (hipExtLaunchKernelGGL stop event)
+ * instead of being recorded behind them.  value < 0 queries; returns the previous value (-1: unknown key). */
 int nsr_nerf_step_variant(int key, int value);
+/* key 4 of the above (default 0): the weight-gradient kernels of nsr_mlp_dgrad_pair's networks are queued BEHIND the table
+ * backward instead of beside it, for a caller that defers its join with them (nsr_nerf_defer_wgrad_join) and hands the event
+ * of its optimizer launch for the network weights to nsr_nerf_wait_before_mlp: one-shot -- the NEXT pruning pass makes its
+ * stream wait for that hipEvent_t between its hash encode and its density MLP instead of the step's stream waiting in front
+ * of the encode.  NULL clears.  The caller must wait for the event itself before anything else reads the weights. */
+int nsr_nerf_wait_before_mlp(void *event);
 /* the stream the main pass runs its overlapped work on (item binning, weight-gradient kernels); created on first use */
 void *nsr_nerf_helper_stream(void);
 /* `stream` waits for the point of the last main pass where its kept rows exist (behind nsr_nerf_main_pass*'s first kernel) */

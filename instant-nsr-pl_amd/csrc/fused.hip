@@ -648,9 +648,7 @@ k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float 
 // lane per SAMPLE whatever the ray boundaries: the transmittance prefix and the five per-ray sums are segmented scans (DPP
 // row shifts + row broadcasts, registers only), a ray that straddles two 64-sample chunks hands a wave-uniform carry to the
 // next chunk.  No atomics, no LDS except the block's loss partial, every sum in a fixed order: deterministic.
-constexpr int FLAT_RPW = 8;                          // rays per wave
-constexpr int FLAT_BLOCK = 256;                      // threads per block
-constexpr int FLAT_RPB = FLAT_RPW * FLAT_BLOCK / 64; // rays per block
+constexpr int FLAT_BLOCK = 256;                      // threads per block; a wave takes RPW rays (4, 8 or 16: nsr_composite_flat_rays_per_wave)
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float flat_dpp(float v)
@@ -672,12 +670,13 @@ __device__ __forceinline__ float flat_seg_scan(float v, uint32_t dist, uint32_t 
 }
 
 // the wave's rays: lanes 0 .. FLAT_RPW-1 hold (start, count) of ray r0 + lane; [begin, end) = the samples of all of them
-struct FlatRays { uint32_t r0, nv, begin, end; int st, cn; uint32_t e[FLAT_RPW]; /* ends of the rays: wave-uniform */ };
-__device__ __forceinline__ FlatRays flat_rays(const int32_t *__restrict__ packed, uint32_t n_rays, uint32_t lane)
+template <int RPW> struct FlatRays { uint32_t r0, nv, begin, end; int st, cn; uint32_t e[RPW]; /* ends of the rays: wave-uniform */ };
+template <int RPW>
+__device__ __forceinline__ FlatRays<RPW> flat_rays(const int32_t *__restrict__ packed, uint32_t n_rays, uint32_t lane)
 {
-    FlatRays f;
-    f.r0 = (blockIdx.x * (FLAT_BLOCK / 64) + (threadIdx.x >> 6)) * FLAT_RPW;
-    f.nv = f.r0 < n_rays ? min((uint32_t)FLAT_RPW, n_rays - f.r0) : 0u;
+    FlatRays<RPW> f;
+    f.r0 = (blockIdx.x * (FLAT_BLOCK / 64) + (threadIdx.x >> 6)) * RPW;
+    f.nv = f.r0 < n_rays ? min((uint32_t)RPW, n_rays - f.r0) : 0u;
     f.st = 0; f.cn = 0;
     if (lane < f.nv) {
         const int2 pk = *reinterpret_cast<const int2 *>(packed + 2ull * (f.r0 + lane));
@@ -685,23 +684,25 @@ __device__ __forceinline__ FlatRays flat_rays(const int32_t *__restrict__ packed
     }
     const int ev = f.st + f.cn;
 #pragma unroll
-    for (int j = 0; j < FLAT_RPW; ++j) f.e[j] = (uint32_t)__builtin_amdgcn_readlane(ev, j);
+    for (int j = 0; j < RPW; ++j) f.e[j] = (uint32_t)__builtin_amdgcn_readlane(ev, j);
     f.begin = f.nv ? (uint32_t)__builtin_amdgcn_readlane(f.st, 0) : 0u;
     f.end = 0u;
 #pragma unroll
-    for (int j = 0; j < FLAT_RPW; ++j)
+    for (int j = 0; j < RPW; ++j)
         if ((uint32_t)j < f.nv) f.end = f.e[j];  // (the last valid ray's end: starts and ends never decrease)
     return f;
 }
 // local ray (0 .. nv-1) of sample i in [begin, end): the first one whose end lies behind i
-__device__ __forceinline__ uint32_t flat_ray_of(const FlatRays &f, uint32_t i)
+template <int RPW>
+__device__ __forceinline__ uint32_t flat_ray_of(const FlatRays<RPW> &f, uint32_t i)
 {
     uint32_t q = 0;
 #pragma unroll
-    for (int j = 0; j < FLAT_RPW - 1; ++j) q += ((uint32_t)j + 1u < f.nv && i >= f.e[j]) ? 1u : 0u;
+    for (int j = 0; j < RPW - 1; ++j) q += ((uint32_t)j + 1u < f.nv && i >= f.e[j]) ? 1u : 0u;
     return q;
 }
 
+template <int RPW>
 __global__ void __launch_bounds__(FLAT_BLOCK)
 k_composite_forward_flat(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
                          const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
@@ -711,7 +712,7 @@ k_composite_forward_flat(const __half *__restrict__ mlp_out, uint32_t stride, fl
                          float *__restrict__ l1_part /* [2][gridDim.x] or NULL */)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const FlatRays f = flat_rays(packed, n_rays, lane);
+    const FlatRays<RPW> f = flat_rays<RPW>(packed, n_rays, lane);
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
     float l1_s = 0.f, l1_c = 0.f;
     if (lane < f.nv && f.cn == 0) {  // a ray without samples: background, outside the loss (opacity 0)
@@ -792,6 +793,7 @@ k_composite_forward_flat(const __half *__restrict__ mlp_out, uint32_t stride, fl
 }
 
 // backward of the above w.r.t. rgb and the density logit; the ray's samples are walked from its END (suffix sums)
+template <int RPW>
 __global__ void __launch_bounds__(FLAT_BLOCK)
 k_composite_backward_flat(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
                           const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
@@ -820,7 +822,7 @@ k_composite_backward_flat(const __half *__restrict__ mlp_out, uint32_t stride, f
         n_valid = c;
         if (blockIdx.x == 0 && threadIdx.x == 0) { l1_acc_out[0] = s; l1_acc_out[1] = c; }
     }
-    const FlatRays f = flat_rays(packed, n_rays, lane);
+    const FlatRays<RPW> f = flat_rays<RPW>(packed, n_rays, lane);
     if (f.end <= f.begin) return;
     // the upstream gradients of this wave's rays, held by lanes 0 .. nv-1
     float rg0 = 0.f, rg1 = 0.f, rg2 = 0.f, rgo = 0.f, rgd = 0.f;
@@ -1209,6 +1211,16 @@ extern "C" int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out
     return NSR_OK;
 }
 
+// rays per wave of the flat compositing kernels (4, 8 or 16; forward and backward of one step must see the same value: the
+// loss partials are per block); 0 queries.  Returns the previous value.
+static int g_flat_rpw = 4;  // (measured in the step: 4 -> 0.3775, 8 -> 0.3802, 16 -> 0.3817 ms)
+extern "C" int nsr_composite_flat_rays_per_wave(int rays)
+{
+    const int old = g_flat_rpw;
+    if (rays == 4 || rays == 8 || rays == 16) g_flat_rpw = rays;
+    return old;
+}
+
 // flat forms of the compositing pair (k_composite_*_flat): packed_info must be an exclusive scan over the rays (what
 // nsr_pack_from_counts* / the fused compaction write).  partials (may be NULL): the loss partials of the folded smooth-L1,
 // nsr_composite_l1_partials_floats(n_rays) floats as for the wave-per-ray pair.
@@ -1223,9 +1235,15 @@ extern "C" int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stri
                 "nsr_composite_forward_flat: NULL pointer");
     NSR_REQUIRE(!partials || gt_rgb, "nsr_composite_forward_flat: the loss partials need gt_rgb");
     NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_composite_forward_flat: packed_info must be 8-byte aligned");
-    hipLaunchKernelGGL(k_composite_forward_flat, dim3(nsr_div_up(n_rays, FLAT_RPB)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,
-                       (const __half *)mlp_out, stride, density_bias, t_starts, t_ends, (const __half *)rgb, rgb_stride,
-                       packed_info, background, weights, trans, comp_rgb, opacity, depth, n_rays, gt_rgb, partials);
+#define NSR_FLAT_FWD(RPW)                                                                                                    \
+    hipLaunchKernelGGL((k_composite_forward_flat<RPW>), dim3(nsr_div_up(n_rays, RPW * FLAT_BLOCK / 64)), dim3(FLAT_BLOCK), 0,     \
+                       (hipStream_t)stream, (const __half *)mlp_out, stride, density_bias, t_starts, t_ends,                     \
+                       (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, comp_rgb, opacity, depth,       \
+                       n_rays, gt_rgb, partials)
+    if (g_flat_rpw == 4) NSR_FLAT_FWD(4);
+    else if (g_flat_rpw == 16) NSR_FLAT_FWD(16);
+    else NSR_FLAT_FWD(8);
+#undef NSR_FLAT_FWD
     NSR_CHECK_LAUNCH("nsr_composite_forward_flat");
     return NSR_OK;
 }
@@ -1247,11 +1265,16 @@ extern "C" int nsr_composite_backward_flat(const nsr_half *mlp_out, uint32_t str
                 "or the built-in loss");
     NSR_REQUIRE(!comp_rgb || (opacity && gt_rgb && acc2), "nsr_composite_backward_flat: the built-in loss needs opacity, gt_rgb, acc2");
     NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_composite_backward_flat: packed_info must be 8-byte aligned");
-    hipLaunchKernelGGL(k_composite_backward_flat, dim3(nsr_div_up(n_rays, FLAT_RPB)), dim3(FLAT_BLOCK), 0, (hipStream_t)stream,
-                       (const __half *)mlp_out, stride, density_bias, t_starts, t_ends, (const __half *)rgb, rgb_stride,
-                       packed_info, background, weights, trans, grad_comp_rgb, grad_opacity, grad_depth, grad_rgb, grad_logit,
-                       n_rays, comp_rgb, opacity, gt_rgb, partials ? nullptr : acc2, grad_scale, grad_weights, partials,
-                       partials ? acc2 : nullptr);
+#define NSR_FLAT_BWD(RPW)                                                                                                    \
+    hipLaunchKernelGGL((k_composite_backward_flat<RPW>), dim3(nsr_div_up(n_rays, RPW * FLAT_BLOCK / 64)), dim3(FLAT_BLOCK), 0,    \
+                       (hipStream_t)stream, (const __half *)mlp_out, stride, density_bias, t_starts, t_ends,                     \
+                       (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb, grad_opacity,    \
+                       grad_depth, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, partials ? nullptr : acc2,           \
+                       grad_scale, grad_weights, partials, partials ? acc2 : nullptr)
+    if (g_flat_rpw == 4) NSR_FLAT_BWD(4);
+    else if (g_flat_rpw == 16) NSR_FLAT_BWD(16);
+    else NSR_FLAT_BWD(8);
+#undef NSR_FLAT_BWD
     NSR_CHECK_LAUNCH("nsr_composite_backward_flat");
     return NSR_OK;
 }
@@ -1327,11 +1350,13 @@ static int copy_kept_rows_impl(const int32_t *packed_marched, int32_t *packed_ke
 #define NSR_COPY(NH, P16)                                                                                                 \
     do {                                                                                                                  \
         if (scan)                                                                                                         \
-            hipLaunchKernelGGL((k_copy_kept_rows<NH, P16, true>), RAY_GRID(n_rays), packed_marched, packed_kept, kr,      \
-                               rays_d, ray_indices_out, (__half *)tex_in, n_rays, ks);                                    \
+            NSR_LAUNCH_STOP((k_copy_kept_rows<NH, P16, true>), dim3(nsr_div_up(n_rays, RAYS_PER_BLOCK)), dim3(R_BLOCK), 0,   \
+                            (hipStream_t)stream, packed_marched, packed_kept, kr,                                        \
+                            rays_d, ray_indices_out, (__half *)tex_in, n_rays, ks);                                       \
         else                                                                                                              \
-            hipLaunchKernelGGL((k_copy_kept_rows<NH, P16, false>), RAY_GRID(n_rays), packed_marched, packed_kept, kr,     \
-                               rays_d, ray_indices_out, (__half *)tex_in, n_rays, ks);                                    \
+            NSR_LAUNCH_STOP((k_copy_kept_rows<NH, P16, false>), dim3(nsr_div_up(n_rays, RAYS_PER_BLOCK)), dim3(R_BLOCK), 0,  \
+                            (hipStream_t)stream, packed_marched, packed_kept, kr,                                        \
+                            rays_d, ray_indices_out, (__half *)tex_in, n_rays, ks);                                       \
     } while (0)
     if (n_hidden == 1 && n_levels == 16) NSR_COPY(1, true);
     else if (n_hidden == 2 && n_levels == 16) NSR_COPY(2, true);

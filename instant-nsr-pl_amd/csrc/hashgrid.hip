@@ -899,6 +899,7 @@ extern "C" uint32_t nsr_hashgrid_dense_levels(const NsrGridDesc *desc)
     return dense_levels::dl_count(desc);
 }
 
+static int g_dense_probe = 0;  // timing probes of tools/dense_levels_bench.py (NSR_DENSE_PROBE, read once): never set in product runs
 // phases: 1 = clear the accumulators (a memset on `stream`), 2 = accumulate the samples' contributions (x [n,3] in RAY ORDER --
 // any order is correct, ray order is what makes it cheap --, dy level-major fp32 [L][n][F]), 4 = write out: AdamW on the dense
 // levels' parameters (adam), or their gradient as fp32 (grad_table, the table's base; accumulate != 0 adds) or bf16
@@ -913,6 +914,8 @@ extern "C" int nsr_hashgrid_backward_params_dense(const float *x, const float *d
     NSR_REQUIRE(phases >= 1 && phases <= 7, "nsr_hashgrid_backward_params_dense: phases is a mask of 1 | 2 | 4");
     const uint32_t D = dense_levels::dl_count(desc), F = desc->n_features;
     if (D == 0) return NSR_OK;
+    static const bool probe_read = [] { if (const char *e = getenv("NSR_DENSE_PROBE")) g_dense_probe = atoi(e); return true; }();
+    (void)probe_read;
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(workspace + owner_workspace_floats(desc, n));
     const uint64_t words = dense_levels::dl_acc_words64(desc);
@@ -926,7 +929,8 @@ extern "C" int nsr_hashgrid_backward_params_dense(const float *x, const float *d
         if (lv > 0) {
             DISPATCH_F(F, hipLaunchKernelGGL((dense_levels::k_dense_levels_accumulate<F>),
                                              dim3(nsr_div_up(n, dense_levels::DL_BLOCK), lv), dim3(dense_levels::DL_BLOCK), 0,
-                                             st, x, dy_level_major, n, level_mask_count, grad_scale, acc, flags, *desc, n_dev));
+                                             st, x, dy_level_major, n, level_mask_count, grad_scale, acc, flags, *desc, n_dev,
+                                             g_dense_probe));
             NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_dense(accumulate)");
         }
     }

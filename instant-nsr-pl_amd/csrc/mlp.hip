@@ -933,7 +933,7 @@ extern "C" int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, cons
     if (blocks > g_dgrad_pair_max_blocks) blocks = g_dgrad_pair_max_blocks;
     const size_t lds = (size_t)(n_params_of(color) + n_params_of(density)) * sizeof(_Float16);
 #define NSR_PAIR(NHC, NHD)                                                                                               \
-    hipLaunchKernelGGL((k_mlp_dgrad_pair<NHC, NHD>), dim3(blocks), dim3(MLP_BLOCK), lds, (hipStream_t)stream, d_rgb, d_logit, \
+    NSR_LAUNCH_STOP((k_mlp_dgrad_pair<NHC, NHD>), dim3(blocks), dim3(MLP_BLOCK), lds, (hipStream_t)stream, d_rgb, d_logit, \
                        (const __half *)out_color, (const __half *)acts_color, (const __half *)w_color, gpre_c, gout_c,    \
                        (const __half *)acts_density, (const __half *)w_density, gpre_d, gout_d, d_enc_level_major, ldn, n, \
                        grad_scale, n_dev)

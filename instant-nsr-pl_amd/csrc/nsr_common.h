@@ -1,6 +1,7 @@
 // Shared helpers for libnsr_hip.so (gfx950 only; 64-wide wavefronts assumed throughout).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
@@ -28,6 +29,20 @@ void nsr_set_error(const char *fmt, ...);
     } while (0)
 
 static inline uint32_t nsr_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// One-shot "stop event" of the NEXT launch made through NSR_LAUNCH_STOP on this thread: the event then rides on the kernel's
+// own completion packet (hipExtLaunchKernelGGL) instead of costing the stream a packet of its own behind it -- measured 2.4 us
+// less per fork on the step's chain (tools/event_cost.hip; tools/stop_event_order.hip: a waiter on another stream is ordered
+// behind the kernel's completion).  The orchestration (csrc/step.hip) sets it right before the call whose kernel it belongs to
+// and falls back to hipEventRecord when the callee did not consume it.
+extern thread_local hipEvent_t nsr_next_stop_event;
+#define NSR_LAUNCH_STOP(kernel, grid, block, lds, stream, ...)                                                       \
+    do {                                                                                                             \
+        hipEvent_t se_ = nsr_next_stop_event;                                                                        \
+        nsr_next_stop_event = nullptr;                                                                               \
+        if (se_) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, se_, 0, __VA_ARGS__);              \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
+    } while (0)
 
 // Device-side row counts: an entry point that takes (n, n_dev) launches for the CAPACITY n and uses n for array
 // strides; when n_dev != NULL only the first min(*n_dev, n) rows are live.  Lets a whole training step be queued

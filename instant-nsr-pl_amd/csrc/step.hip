@@ -175,17 +175,37 @@ extern "C" int nsr_nerf_wait_kept_rows(void *stream)
 // Round-5 forms of the step's kernels, switchable for same-process A/B runs (tools/step_variants.py) and as a fallback:
 //   key 0: both networks' data gradients in ONE kernel (nsr_mlp_dgrad_pair) instead of two launches + a d_feature round trip
 //   key 1: the dense levels' table gradient through ray-run merged fixed-point atomics on a stream of their own
-//          (nsr_hashgrid_backward_params_dense), the owner launch covering the hashed levels only
+//          (nsr_hashgrid_backward_params_dense), the owner launch covering the hashed levels only.  DEFAULT 0: measured
+//          (profiles/r05_dense_levels_bench.json, r05_step_variants*.json) -- isolated, the dense path is 41 + 11 us beside
+//          a 79 us owner launch instead of one 97 us launch; inside the step its 8e5 device-scope atomics and the extra
+//          launches contend with the weight-gradient kernels and the owner itself (150 us instead of 123): +4 % per step
 //   key 2: flat segmented compositing (nsr_composite_*_flat) instead of one wave per ray
-//   key 3: the two networks' weight-gradient kernels on two helper streams (only with key 0)
-// value < 0 queries; returns the previous value.  All default to 1.
-static int g_variant[8] = {1, 1, 1, 1, 0, 0, 0, 0};
+//   key 3: the two networks' weight-gradient kernels on two helper streams (only with key 0).  DEFAULT 0: measured with the
+//          rest of the forms on, one stream 0.363 ms per step, two streams 0.371 (more kernels beside the table backward)
+//   key 4: the weight-gradient kernels queued behind the table backward (under the next step's encode) instead of beside it;
+//          needs a caller that defers its join with them to nsr_nerf_wait_before_mlp (default 0)
+//   key 5: the pass's fork events ride on the kernels in front of them (hipExtLaunchKernelGGL stop event) instead of being
+//          recorded behind them
+// value < 0 queries; returns the previous value.  Keys 0, 2, 5 default to 1.
+static int g_variant[8] = {1, 0, 1, 0, 0, 1, 0, 0};
 extern "C" int nsr_nerf_step_variant(int key, int value)
 {
     if (key < 0 || key >= 8) return -1;
     const int old = g_variant[key];
     if (value >= 0) g_variant[key] = value;
     return old;
+}
+
+// One-shot: the NEXT pruning pass makes its stream wait for `event` between its hash encode and its density MLP (the first
+// kernel that reads network weights).  A trainer whose optimizer launch for the MLP weights runs on the helper stream hands
+// that launch's event over instead of making the step's stream wait for it in front of the encode: the weight-gradient
+// kernels + the optimizer then have the encode's duration to finish.  NULL clears.  The caller must make its stream wait for
+// the event itself before anything ELSE reads the weights on it (occupancy refresh, evaluation, checkpoints).
+static hipEvent_t g_wait_before_mlp = nullptr;
+extern "C" int nsr_nerf_wait_before_mlp(void *event)
+{
+    g_wait_before_mlp = (hipEvent_t)event;
+    return NSR_OK;
 }
 
 // nsr_nerf_prune_pass_deferred leaves the packing of the kept counts to the next main pass's kept-row copy
@@ -268,6 +288,11 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
         d->mlp_density.output_activation == NSR_ACT_NONE) {
         // encode + density MLP + transmittance cut in ONE ray-ordered kernel that stops at each ray's cut (csrc/gridmlp.hip:
         // ~40 % of the marched samples lie behind it); bit-identical kept counts / rows to the three launches below
+        if (g_wait_before_mlp) {
+            NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_wait_before_mlp, 0) == hipSuccess,
+                        "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
+            g_wait_before_mlp = nullptr;
+        }
         ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
         NSR_TRY(nsr_sigma_rays(x01, table, w_density, out1, acts1, enc, n_marched, packed_info, t_starts, t_ends,
                                d->density_bias, d->early_stop_eps, kept_counts, n_rays, &d->grid, &d->mlp_density, stream));
@@ -276,6 +301,11 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
             ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
             NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
                                             stream));
+        }
+        if (g_wait_before_mlp) {  // (nsr_nerf_wait_before_mlp: the network weights of this step are final behind this event)
+            NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_wait_before_mlp, 0) == hipSuccess,
+                        "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
+            g_wait_before_mlp = nullptr;
         }
         {
             ProfScope p(NSR_PROF_MLP_FORWARD_DENSITY, n_marched, stream);
@@ -434,6 +464,12 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     if (deferred && S == 0)  // (no sample buffer: nothing to copy, the packing is still owed)
         NSR_TRY(nsr_pack_from_counts_capped(g_deferred.kept, g_deferred.packed, g_deferred.total, n_rays, g_deferred.capacity,
                                             g_deferred.stats, nullptr, stream));
+    // key 5: the fork events of the pass ride on the kernels they follow (NSR_LAUNCH_STOP) instead of being recorded behind them
+    bool fork_pending = true;
+    if (overlap_bins && g_variant[5] && S > 0 && F == 2 && nh1 <= 2) {
+        nsr_next_stop_event = g_helper.fork;
+        fork_pending = false;
+    }
     if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
         if (deferred)  // packing folded into the copy: packed_kept / total_kept are written by this launch
             NSR_TRY(nsr_nerf_copy_kept_rows_scan(packed_marched, g_deferred.kept, g_deferred.sums, g_deferred.packed,
@@ -458,7 +494,11 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // ~7 us per launch, and with the four binning launches queued first the main stream sat idle for 30-45 us waiting for
     // its next kernel (rocprofv3 timeline: copy_kept_rows ... 46 us ... mlp_forward)
     g_ht.mark(1);
-    if (overlap_bins)
+    if (overlap_bins && nsr_next_stop_event == g_helper.fork) {  // the copy did not take it (the generic row copy)
+        nsr_next_stop_event = nullptr;
+        fork_pending = true;
+    }
+    if (overlap_bins && fork_pending)
         NSR_REQUIRE(hipEventRecord(g_helper.fork, st) == hipSuccess, "nsr_nerf_main_pass: helper stream fork failed");
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
@@ -567,21 +607,18 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     g_ht.mark(5);
     const bool pair = g_variant[0] && nsr_mlp_dgrad_pair_supported(&d->mlp_color, &d->mlp_density) && C == 32;
     bool dgrad_event = false;  // g_helper.dgrad_done recorded behind the last data-gradient kernel
-    if (pair) {
-        {   // both networks' data gradients in one launch; d_feature stays in registers (csrc/mlp.hip k_mlp_dgrad_pair)
-            ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
-            NSR_TRY(nsr_mlp_dgrad_pair(d_rgb, d_logit, out2, acts2, w_color, part2, acts1, w_density, part1, d_enc, S,
-                                       d->grad_scale, &d->mlp_color, &d->mlp_density, n_kept_dev, stream));
-        }
+    bool late_wgrad = false;
+    // the weight-gradient kernels + reductions of both networks (behind nsr_mlp_dgrad_pair), forked from `st` through `fork`
+    auto queue_wgrads = [&](hipEvent_t fork, bool *recorded, bool already_recorded) -> int {
         void *wg_c = wg, *wg_d = wg;
         if (wg) {
-            NSR_REQUIRE(hipEventRecord(g_helper.dgrad_done, st) == hipSuccess &&
-                            hipStreamWaitEvent(g_helper.stream, g_helper.dgrad_done, 0) == hipSuccess,
+            NSR_REQUIRE((already_recorded || hipEventRecord(fork, st) == hipSuccess) &&
+                            hipStreamWaitEvent(g_helper.stream, fork, 0) == hipSuccess,
                         "nsr_nerf_main_pass: weight-gradient fork failed");
-            dgrad_event = true;
+            if (recorded) *recorded = true;
             if (g_variant[3]) {  // the density network's weight-gradient kernels beside the colour network's
                 wg_d = (void *)g_helper.stream_b;
-                NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_b, g_helper.dgrad_done, 0) == hipSuccess,
+                NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_b, fork, 0) == hipSuccess,
                             "nsr_nerf_main_pass: weight-gradient fork failed");
             }
         }
@@ -594,6 +631,23 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
             NSR_REQUIRE(hipEventRecord(g_helper.wgrad_b_done, g_helper.stream_b) == hipSuccess &&
                             hipStreamWaitEvent(g_helper.stream, g_helper.wgrad_b_done, 0) == hipSuccess,
                         "nsr_nerf_main_pass: weight-gradient join failed");
+        return NSR_OK;
+    };
+    if (pair) {
+        late_wgrad = wg && g_variant[4] && g_defer_wgrad_join && !xchg;
+        const bool ride = wg && g_variant[5] && !late_wgrad && !g_prof_on;  // (the profiling scope records its own events)
+        if (ride) nsr_next_stop_event = g_helper.dgrad_done;
+        {   // both networks' data gradients in one launch; d_feature stays in registers (csrc/mlp.hip k_mlp_dgrad_pair)
+            ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
+            NSR_TRY(nsr_mlp_dgrad_pair(d_rgb, d_logit, out2, acts2, w_color, part2, acts1, w_density, part1, d_enc, S,
+                                       d->grad_scale, &d->mlp_color, &d->mlp_density, n_kept_dev, stream));
+        }
+        // key 4: the weight-gradient kernels are queued BEHIND the table backward instead of beside it (they then run under the
+        // next step's encode; only for a caller that defers its join with them: nsr_nerf_defer_wgrad_join + nsr_nerf_wait_before_mlp)
+        const bool rode = ride && nsr_next_stop_event == nullptr;
+        nsr_next_stop_event = nullptr;
+        if (rode) dgrad_event = true;
+        if (!late_wgrad) NSR_TRY(queue_wgrads(g_helper.dgrad_done, &dgrad_event, rode));
     } else if (wg && !two_forks) {
         {
             ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
@@ -694,6 +748,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                        d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
         }
     }
+    if (late_wgrad) NSR_TRY(queue_wgrads(g_helper.fork_wgrad, nullptr, false));  // (the fork event sits behind the table backward)
     g_ht.mark(8);
     if (wg && !g_defer_wgrad_join)  // join: the optimizer step that follows on `stream` reads the MLP gradients
         NSR_REQUIRE(hipEventRecord(g_helper.join_wgrad, g_helper.stream) == hipSuccess &&

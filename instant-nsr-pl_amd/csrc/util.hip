@@ -6,6 +6,8 @@
 
 static thread_local char g_err[512] = "";
 
+thread_local hipEvent_t nsr_next_stop_event = nullptr;
+
 void nsr_set_error(const char *fmt, ...)
 {
     va_list ap;

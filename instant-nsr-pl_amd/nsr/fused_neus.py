@@ -1112,6 +1112,7 @@ class NeuSTrainer:
                                                              config.get("num_samples_per_ray_bg", 0))
         self.train_num_rays = config["train_num_rays"]
         self.global_step = 0
+        self.seed = int(seed)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(shard_seed(seed, rank))
         if world_size > 1:

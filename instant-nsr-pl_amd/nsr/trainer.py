@@ -198,8 +198,17 @@ def training_state(trainer, extra_optimizers=()):
     if trainer.sharded is not None:
         opt["step_count"] = trainer.sharded.step_count
         opt["moments"] = trainer.sharded.gather_moments(trainer.opt.tcnn_modules)
+    # every rank samples its own rays (nsr.parallel.shard_seed): the sampler states are saved PER RANK (a collective, like the
+    # moments above) -- restoring rank 0's state everywhere would make all ranks draw the same batch after a resume
+    gen_state = trainer.gen.get_state()
+    world = int(getattr(trainer, "world_size", 1))
+    if world > 1 and dist.is_available() and dist.is_initialized():
+        states = [None] * world
+        dist.all_gather_object(states, gen_state.cpu())
+    else:
+        states = [gen_state]
     st = {"optimizer": opt, "global_step": int(trainer.global_step), "train_num_rays": int(trainer.train_num_rays),
-          "generator": trainer.gen.get_state(), "extra": [o.state_dict() for o in extra_optimizers]}
+          "generator": states[0], "generators": states, "extra": [o.state_dict() for o in extra_optimizers]}
     a = getattr(trainer, "_as", None)
     if a is not None:  # asynchronous mode keeps the dynamic ray count on the device
         st["train_num_rays"] = int(a["n_rays"].item())
@@ -214,8 +223,16 @@ def restore_training_state(trainer, st, extra_optimizers=()):
         o.load_state_dict(sd)
     trainer.global_step = int(st["global_step"])
     trainer.train_num_rays = int(st["train_num_rays"])
-    if st.get("generator") is not None:
-        trainer.gen.set_state(st["generator"].cpu())
+    world, rank = int(getattr(trainer, "world_size", 1)), int(getattr(trainer, "rank", 0))
+    states = st.get("generators") or ([st["generator"]] if st.get("generator") is not None else [])
+    if len(states) == world and states[rank] is not None:
+        trainer.gen.set_state(states[rank].cpu())  # same world size: every rank continues its own stream
+    elif world > 1:
+        # resumed at another world size: no saved stream belongs to this rank -- a fresh per-rank stream, distinct across ranks
+        # and across resume points (never rank 0's state on every rank: all ranks would then sample identical rays)
+        trainer.gen.manual_seed(shard_seed(int(getattr(trainer, "seed", 0)) + 7919 * int(st["global_step"]), rank))
+    elif states:
+        trainer.gen.set_state(states[0].cpu())
     a = getattr(trainer, "_as", None)
     if a is not None:
         a["n_rays"].fill_(trainer.train_num_rays)
@@ -292,6 +309,7 @@ class Trainer:
         self.train_num_samples = config["train_num_rays"] * config["num_samples_per_ray"]  # systems/nerf.py:27
         self.train_num_rays = config["train_num_rays"]
         self.global_step = 0
+        self.seed = int(seed)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(shard_seed(seed, rank))  # per-rank ray batches (see module docstring)
         if world_size > 1:
@@ -330,6 +348,11 @@ class Trainer:
         self.comm_timings = None
         # asynchronous single-GPU steps: AdamW on the table inside the table backward (NSR_TABLE_ADAM_SEPARATE: A/B switch)
         self.fuse_table_update = not os.environ.get("NSR_TABLE_ADAM_SEPARATE")
+        # the step's stream waits for the helper stream's optimizer launch (network weights) in front of the next density MLP
+        # instead of in front of the next encode (csrc/step.hip nsr_nerf_wait_before_mlp); settle() for every other reader
+        self.defer_weights_wait = not os.environ.get("NSR_WEIGHTS_WAIT_EARLY")
+        for mod in [model] + list(model.children()):
+            mod.register_forward_pre_hook(lambda _m, _inp: self.settle())
         # developer A/B switches of the asynchronous step, read once (an environment lookup per step is host time)
         self._write_inline = bool(os.environ.get("NSR_WRITE_INLINE"))
         self._exchange_unfused = bool(os.environ.get("NSR_EXCHANGE_UNFUSED")) or getattr(self, "_force_unfused_exchange", False)
@@ -352,6 +375,10 @@ class Trainer:
 
     # ---- checkpoints -------------------------------------------------------------------------------------------------
     def state_dict(self):
+        self.settle()
+        return self._state_dict()
+
+    def _state_dict(self):
         """``model.state_dict()`` (reference key set, tests/golden/state_dict_keys.json) with every fp32 parameter current.
         Multi-GPU: the tables' fp32 master values live in the owners' shards (nsr.parallel.ShardedAdamW), so this is a
         COLLECTIVE -- every rank calls it (rank 0 alone then writes the file: ``save``)."""
@@ -368,6 +395,7 @@ class Trainer:
         counter.  Every rank calls it."""
         ck = torch.load(path_or_ckpt, map_location=self.device) if isinstance(path_or_ckpt, (str, bytes, os.PathLike)) \
             else path_or_ckpt
+        self.settle()
         self.model.load_state_dict(ck["state_dict"])  # (the post-hook re-seeds fp16 images / sharded masters)
         if ck.get("training_state") is not None:
             restore_training_state(self, ck["training_state"])
@@ -377,6 +405,16 @@ class Trainer:
         if self._as is not None:
             self._as["marched_upto"] = self._as["packed_upto"] = self.global_step - 1
             self._as["events"].clear()
+
+    def settle(self):
+        """make the current stream wait for work the asynchronous step left pending on its helper streams (the optimizer
+        launch for the network weights when ``defer_weights_wait``): called before anything but the next training step reads
+        the parameters -- evaluation, checkpoints, the occupancy refresh"""
+        a = self._as
+        if a is not None and a.get("weights_event") is not None:
+            torch.cuda.current_stream().wait_event(a["weights_event"])
+            _check(_lib.nsr_nerf_wait_before_mlp(None), "nsr_nerf_wait_before_mlp")
+            a["weights_event"] = None
 
     def _all_reduce_grads(self):
         if self.world_size > 1 and self.sharded is None:
@@ -581,6 +619,7 @@ class Trainer:
     def counters(self):
         """totals since the first asynchronous step (synchronises): marched / kept samples, rays, truncated launches"""
         a = self._async_state()
+        self.settle()
         torch.cuda.synchronize(self.device)
         st = a["stats"].cpu()
         u64 = lambda lo, hi: (int(lo) & 0xffffffff) | ((int(hi) & 0xffffffff) << 32)
@@ -733,7 +772,14 @@ class Trainer:
                 self.opt.step_device(skip_table_of=fused.ewn, other_stream_reads=True, stream=ctypes.c_void_p(hs.cuda_stream))
                 ev_opt = a.setdefault("opt_events", [torch.cuda.Event() for _ in range(4)])[t % 4]
                 ev_opt.record(hs)
-                main.wait_event(ev_opt)
+                if self.defer_weights_wait and not (cfg["grid_prune"] and (t + 1) % 16 == 0):
+                    # the next step's stream waits for the new network weights between its encode and its density MLP, not in
+                    # front of the encode (csrc/step.hip nsr_nerf_wait_before_mlp); anything else that reads them: settle()
+                    _check(_lib.nsr_nerf_wait_before_mlp(ctypes.c_void_p(ev_opt.cuda_event)), "nsr_nerf_wait_before_mlp")
+                    a["weights_event"] = ev_opt
+                else:  # (the next step starts with the occupancy refresh, which evaluates the density network)
+                    main.wait_event(ev_opt)
+                    a["weights_event"] = None
             elif fuse_table:
                 self.opt.step_device(skip_table_of=fused.ewn)
             else:

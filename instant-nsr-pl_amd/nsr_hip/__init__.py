@@ -230,9 +230,11 @@ SIGNATURES = {
     "nsr_mlp_dgrad_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _F, _MD, _MD, _P, _P],
     "nsr_visibility_prefix_sums": [_P, _U, _F, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_copy_kept_rows_scan": [_P] * 18 + [_U, _U, _U, _U, _P, _P, _P, _U, _P],
+    "nsr_composite_flat_rays_per_wave": [_I],
     "nsr_composite_forward_flat": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward_flat": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_step_variant": [_I, _I],
+    "nsr_nerf_wait_before_mlp": [_P],
     "nsr_nerf_prune_pass_deferred": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),

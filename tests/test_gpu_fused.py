@@ -57,8 +57,12 @@ def test_fused_step_matches_modular_autograd():
     model.zero_grad(set_to_none=True)
     step = FusedNeRFStep(model, native=True)
     res = step.forward_backward(rays, gt, bg)
-    for k in ("comp_rgb", "opacity", "depth", "weights", "ray_indices", "t_starts", "t_ends"):
+    for k in ("ray_indices", "t_starts", "t_ends"):
         assert torch.equal(res[k], res_py[k]), k
+    # (round 5: the native orchestration composites with the flat segmented kernels, the Python-issued path with one wave per
+    # ray -- the scans associate differently: agreement to fp32 rounding; tests/test_gpu_round5.py compares the two directly)
+    for k in ("comp_rgb", "opacity", "depth", "weights"):
+        assert torch.allclose(res[k], res_py[k], rtol=2e-5, atol=2e-6), k
     assert (model.geometry.encoding_with_network.params.grad - f1_py).norm() / f1_py.norm() < 1e-5
     assert (model.texture.network.params.grad - f2_py).norm() / f2_py.norm() < 1e-5
     assert res["num_samples"] == int(out["num_samples"])

@@ -21,35 +21,42 @@ model = nsr.build(cfg).to(dev).train()
 data = SyntheticBlender(n_images=int(os.environ.get("NSR_LATE_IMAGES", "100")), w=400, h=400, device=dev, seed=0)
 tr = Trainer(model, data, cfg, seed=42, async_mode=True)
 
-# name -> (variant keys 0..3, defer_pack)
+# name -> (variant keys 0..5, defer_pack, defer_weights_wait, rays per wave of the flat compositing)
 SETTINGS = {
-    "all_off": ((0, 0, 0, 0), False),
-    "pair_only": ((1, 0, 0, 0), False),
-    "pair_two_wgrad_streams": ((1, 0, 0, 1), False),
-    "dense_only": ((0, 1, 0, 0), False),
-    "flat_only": ((0, 0, 1, 0), False),
-    "defer_pack_only": ((0, 0, 0, 0), True),
-    "all_on": ((1, 1, 1, 1), True),
-    "all_on_one_wgrad_stream": ((1, 1, 1, 0), True),
+    "all_off": ((0, 0, 0, 0, 0, 0), False, False, 8),
+    "flat_pack_weights": ((0, 0, 1, 0, 0, 0), True, True, 8),
+    "flat_pack_weights_ride": ((0, 0, 1, 0, 0, 1), True, True, 8),
+    "flat4_pack_weights_ride": ((0, 0, 1, 0, 0, 1), True, True, 4),
+    "flat16_pack_weights_ride": ((0, 0, 1, 0, 0, 1), True, True, 16),
+    "pair_flat_pack_weights_ride": ((1, 0, 1, 1, 0, 1), True, True, 8),
+    "pair1_flat_pack_weights_ride": ((1, 0, 1, 0, 0, 1), True, True, 8),
+    "pair_flat_pack_ride": ((1, 0, 1, 1, 0, 1), True, False, 8),
 }
 only = os.environ.get("NSR_VARIANTS")
 if only:
     SETTINGS = {k: v for k, v in SETTINGS.items() if k in only.split(",")}
 
 
-def apply(keys, defer):
+def apply(keys, defer, defer_w, rpw):
+    tr.settle()
     for k, v in enumerate(keys):
         lib.nsr_nerf_step_variant(k, v)
+    lib.nsr_composite_flat_rays_per_wave(rpw)
     tr.fused.defer_pack = defer
+    tr.defer_weights_wait = defer_w
 
 
 for _ in range(n_train):
     tr.train_step()
 torch.cuda.synchronize()
 res = {k: [] for k in SETTINGS}
+names = list(SETTINGS)
 for r in range(rounds):
-    for name, (keys, defer) in SETTINGS.items():
-        apply(keys, defer)
+    order = names[r % len(names):] + names[:r % len(names)]  # rotated: the drift of the sample counts hits every setting alike
+    if r % 2:
+        order = order[::-1]
+    for name in order:
+        apply(*SETTINGS[name])
         for _ in range(16):
             tr.train_step()
         torch.cuda.synchronize()
@@ -65,7 +72,7 @@ for r in range(rounds):
                           "kept_per_step": (c1["samples"] - c0["samples"]) / n_timed,
                           "marched_per_step": (c1["marched"] - c0["marched"]) / n_timed,
                           "loss": float(tr.last["loss"])})
-apply((1, 1, 1, 1), True)
+apply((1, 0, 1, 1, 0, 1), True, False, 8)
 out = {"train_steps": n_train, "timed_steps": n_timed, "rounds": rounds, "global_step": tr.global_step,
        "settings": {k: {"ms_per_step": [round(x["ms_per_step"], 4) for x in v],
                         "host_ms_per_step": [round(x["host_ms_per_step"], 4) for x in v],
