@@ -607,7 +607,7 @@ int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out, uint32_t 
  * arrays instead of one wave per ray (a ray of the step keeps 10-15 samples: > 80 % idle lanes) -- a wave takes 8 consecutive
  * rays, i.e. one contiguous sample range, transmittance and the per-ray sums are segmented DPP scans with a carry between
  * 64-sample chunks.  packed_info must be an exclusive scan over the rays (what nsr_pack_from_counts* / the folded packing
- * write), 8-byte aligned.  forward: partials (may be NULL) = the loss partials of the folded masked smooth-L1 against gt_rgb
+ * write).  forward: partials (may be NULL) = the loss partials of the folded masked smooth-L1 against gt_rgb
  * (nsr_composite_l1_partials_floats(n_rays) floats).  backward: EITHER the upstream gradients grad_comp_rgb [R,3] (+
  * optional grad_opacity [R], grad_depth [R], grad_weights [n]) OR the built-in loss on (comp_rgb, opacity, gt_rgb) with its
  * (sum, valid rays) read from acc2 (partials == NULL) or summed from the forward's partials (acc2 then receives them). */

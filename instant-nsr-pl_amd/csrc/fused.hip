@@ -317,7 +317,8 @@ k_copy_kept_rows(const int32_t *__restrict__ packed_old, int32_t *__restrict__ p
             c = min(c, (int32_t)ks.capacity - start);
         }
         if (lane == 0) {
-            *reinterpret_cast<int2 *>(packed_new + 2ull * r) = make_int2(start, c);
+            packed_new[2ull * r] = start;
+            packed_new[2ull * r + 1] = c;
             if (r == n_rays - 1u) {
                 const int32_t t = part + own;
                 ks.total[0] = ks.capacity ? min(t, (int32_t)ks.capacity) : t;
@@ -679,8 +680,8 @@ __device__ __forceinline__ FlatRays<RPW> flat_rays(const int32_t *__restrict__ p
     f.nv = f.r0 < n_rays ? min((uint32_t)RPW, n_rays - f.r0) : 0u;
     f.st = 0; f.cn = 0;
     if (lane < f.nv) {
-        const int2 pk = *reinterpret_cast<const int2 *>(packed + 2ull * (f.r0 + lane));
-        f.st = pk.x; f.cn = pk.y;
+        f.st = packed[2ull * (f.r0 + lane)];  // (two 4-byte loads: callers hand in 4-byte aligned views)
+        f.cn = packed[2ull * (f.r0 + lane) + 1];
     }
     const int ev = f.st + f.cn;
 #pragma unroll
@@ -1234,7 +1235,6 @@ extern "C" int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stri
     NSR_REQUIRE(packed_info && background && comp_rgb && opacity && depth && weights && trans,
                 "nsr_composite_forward_flat: NULL pointer");
     NSR_REQUIRE(!partials || gt_rgb, "nsr_composite_forward_flat: the loss partials need gt_rgb");
-    NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_composite_forward_flat: packed_info must be 8-byte aligned");
 #define NSR_FLAT_FWD(RPW)                                                                                                    \
     hipLaunchKernelGGL((k_composite_forward_flat<RPW>), dim3(nsr_div_up(n_rays, RPW * FLAT_BLOCK / 64)), dim3(FLAT_BLOCK), 0,     \
                        (hipStream_t)stream, (const __half *)mlp_out, stride, density_bias, t_starts, t_ends,                     \
@@ -1264,7 +1264,6 @@ extern "C" int nsr_composite_backward_flat(const nsr_half *mlp_out, uint32_t str
     NSR_REQUIRE((grad_comp_rgb != nullptr) != (comp_rgb != nullptr), "nsr_composite_backward_flat: either upstream gradients "
                 "or the built-in loss");
     NSR_REQUIRE(!comp_rgb || (opacity && gt_rgb && acc2), "nsr_composite_backward_flat: the built-in loss needs opacity, gt_rgb, acc2");
-    NSR_REQUIRE(((uintptr_t)packed_info & 7u) == 0, "nsr_composite_backward_flat: packed_info must be 8-byte aligned");
 #define NSR_FLAT_BWD(RPW)                                                                                                    \
     hipLaunchKernelGGL((k_composite_backward_flat<RPW>), dim3(nsr_div_up(n_rays, RPW * FLAT_BLOCK / 64)), dim3(FLAT_BLOCK), 0,    \
                        (hipStream_t)stream, (const __half *)mlp_out, stride, density_bias, t_starts, t_ends,                     \
@@ -1393,8 +1392,8 @@ extern "C" int nsr_nerf_copy_kept_rows_scan(const int32_t *packed_marched, const
                                             int64_t *ray_indices_out, nsr_half *tex_in, uint32_t n_rays, void *stream)
 {
     NSR_REQUIRE(kept_counts && block_sums && total_kept, "nsr_nerf_copy_kept_rows_scan: NULL pointer");
-    NSR_REQUIRE(((uintptr_t)block_sums & 15u) == 0 && ((uintptr_t)packed_kept & 7u) == 0 && (!stats || ((uintptr_t)stats & 7u) == 0),
-                "nsr_nerf_copy_kept_rows_scan: block_sums must be 16-byte, packed_kept / stats 8-byte aligned");
+    NSR_REQUIRE(((uintptr_t)block_sums & 15u) == 0 && (!stats || ((uintptr_t)stats & 7u) == 0),
+                "nsr_nerf_copy_kept_rows_scan: block_sums must be 16-byte, stats 8-byte aligned");
     NSR_REQUIRE(kept_capacity < 0x7fffffffu, "nsr_nerf_copy_kept_rows_scan: capacity must fit int32");
     KeptScan ks;
     ks.kept = kept_counts; ks.block_sums = block_sums; ks.total = total_kept; ks.stats = stats; ks.capacity = kept_capacity;

@@ -453,6 +453,10 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     const uint32_t n_dense = nsr_hashgrid_dense_levels(&d->grid);
     const bool use_dense = g_variant[1] && overlap_bins && !xchg && n_dense > 0 && n_dense < Lv;
     const bool flat = g_variant[2] != 0;
+    // (a stream that is being captured into a graph takes plain launches + event records only)
+    hipStreamCaptureStatus capture_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &capture_status);
+    const bool capturing = capture_status != hipStreamCaptureStatusNone;
     g_ht.mark(0);
     if (phases & 1) {
     const bool deferred = g_deferred.pending;
@@ -466,7 +470,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                             g_deferred.stats, nullptr, stream));
     // key 5: the fork events of the pass ride on the kernels they follow (NSR_LAUNCH_STOP) instead of being recorded behind them
     bool fork_pending = true;
-    if (overlap_bins && g_variant[5] && S > 0 && F == 2 && nh1 <= 2) {
+    if (overlap_bins && g_variant[5] && !capturing && S > 0 && F == 2 && nh1 <= 2) {
         nsr_next_stop_event = g_helper.fork;
         fork_pending = false;
     }
@@ -635,7 +639,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     };
     if (pair) {
         late_wgrad = wg && g_variant[4] && g_defer_wgrad_join && !xchg;
-        const bool ride = wg && g_variant[5] && !late_wgrad && !g_prof_on;  // (the profiling scope records its own events)
+        const bool ride = wg && g_variant[5] && !capturing && !late_wgrad && !g_prof_on;  // (the profiling scope records its own events)
         if (ride) nsr_next_stop_event = g_helper.dgrad_done;
         {   // both networks' data gradients in one launch; d_feature stays in registers (csrc/mlp.hip k_mlp_dgrad_pair)
             ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
