@@ -439,6 +439,72 @@ def boundary_path_neus(dev, warmup=100, steps=100):
                     "torch MSE / eikonal / mask losses, loss.backward(), torch AdamW"}
 
 
+def whole_run(dev, data, cfg, n_steps=20000, late_at=10000, late_steps=200, test_views=4, test_res=400, seed=43):
+    """The WHOLE training run of the reference schedule (configs/nerf-blender.yaml:96: 20,000 steps under the 8,192-ray cap,
+    MultiStepLR milestones 10k / 15k / 18k) with a fresh model through the same asynchronous trainer the driver-timed region
+    uses: wall time from the first step to the end of the last (one synchronisation), kept samples / rays from the device
+    counters, PSNR on unseen views through the eval path (PSNR@20k is part of BASELINE.json's metric); inside it, `late_steps`
+    steps at step `late_at` are bracketed by two synchronisations -> the LATE regime (sparse grid, ~4e4 kept samples per step),
+    which is where a run spends most of its steps.  -> (whole_run, late_regime)"""
+    import nsr
+    from nsr.export import render_rays
+    from nsr.scene import SyntheticBlender, get_rays
+    from nsr.trainer import Trainer
+    torch.manual_seed(seed)
+    model = nsr.build(cfg).to(dev).train()
+    tr = Trainer(model, data, cfg, rank=0, world_size=1, seed=seed, async_mode=True)
+    late = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 0
+    while k < n_steps:
+        if k == late_at and late_at + late_steps <= n_steps:
+            torch.cuda.synchronize()
+            c0, tl = tr.counters(), time.perf_counter()
+            for _ in range(late_steps):
+                tr.train_step()
+            th = time.perf_counter()
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - tl
+            c1 = tr.counters()
+            late = {"at_step": late_at, "timed_steps": late_steps, "ms_per_step": 1e3 * dtl / late_steps,
+                    "host_enqueue_ms_per_step": 1e3 * (th - tl) / late_steps,
+                    "samples_per_sec": (c1["samples"] - c0["samples"]) / dtl,
+                    "kept_samples_per_step": (c1["samples"] - c0["samples"]) / late_steps,
+                    "marched_samples_per_step": (c1["marched"] - c0["marched"]) / late_steps,
+                    "rays_per_step": (c1["rays"] - c0["rays"]) / late_steps}
+            k += late_steps
+            continue
+        tr.train_step()
+        k += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = tr.counters()
+    final_loss = float(tr.last["loss"])
+    finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    test = SyntheticBlender(n_images=test_views, w=test_res, h=test_res, device=dev, seed=12345)  # unseen cameras
+    model.eval()
+    psnrs = []
+    with torch.no_grad():
+        for i in range(test_views):
+            o, d = get_rays(test.directions.view(-1, 3), test.all_c2w[i:i + 1].expand(test_res * test_res, -1, -1))
+            rays = torch.cat([o, torch.nn.functional.normalize(d, p=2, dim=-1)], -1)
+            comp = render_rays(tr.fused, rays)["comp_rgb"]
+            fg = test.all_fg_masks[i].view(-1, 1)
+            gt = test.all_images[i].view(-1, 3) * fg + (1 - fg)
+            psnrs.append(float(-10.0 * torch.log10(torch.mean((comp.to(dev).clamp(0, 1) - gt) ** 2))))
+    whole = {"steps": n_steps, "seconds": dt, "ms_per_step": 1e3 * dt / n_steps, "samples_per_sec": c["samples"] / dt,
+             "rays_per_sec": c["rays"] / dt, "kept_samples_per_step": c["samples"] / n_steps,
+             "marched_samples_per_step": c["marched"] / n_steps, "truncated_launches": c["truncated"],
+             "final_train_loss": final_loss, "parameters_finite": finite, "test_psnr": sum(psnrs) / len(psnrs),
+             "test_psnr_per_view": psnrs, "test_views": f"{test_views} unseen {test_res}x{test_res} views of the procedural scene",
+             "note": "fresh model, the reference's 20,000-step schedule, wall time of the whole loop (the two synchronisations of "
+                     "the late-regime window included), rank 0, one GPU; procedural lego-like scene (no dataset on the box)"}
+    del tr, model
+    torch.cuda.empty_cache()
+    return whole, late
+
+
 def side_measurement(name, timeout=600):
     """run bench.<name>(cuda:0) in a child process and return its JSON: a side measurement must not be able to take the
     headline line down (a GPU fault kills the process it happens in)"""
@@ -525,6 +591,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the C3 / C4 / C5 side measurements")
     ap.add_argument("--no-boundary-path", action="store_true", help="skip the step through nsr.models.FusedNeRFModel")
+    ap.add_argument("--no-whole-run", action="store_true",
+                    help="skip the 20,000-step run of a fresh model (whole_run / late_regime blocks, ~10 s)")
+    ap.add_argument("--whole-run-steps", type=int, default=20000, help="length of that run (configs/nerf-blender.yaml:96)")
     ap.add_argument("--no-pipeline", action="store_true", help="diagnostic: march in order instead of on the side stream")
     ap.add_argument("--graphs", action="store_true", help="replay each step from a captured HIP graph (measured slower)")
     ap.add_argument("--sync-steps", action="store_true",
@@ -636,7 +705,7 @@ def main():
         c2 = tr.counters()
         live_m, live_s = c2["marched"] - c1["marched"], c2["samples"] - c1["samples"]
         live = {"hashgrid_forward": live_m, "mlp_forward_h1": live_m, "hashgrid_backward_params": live_s,
-                "hashgrid_backward_bin": live_s, "mlp_forward_h2": live_s, "mlp_backward_h1": live_s,
+                "hashgrid_backward_bin": live_s, "hashgrid_backward_dense": live_s, "mlp_forward_h2": live_s, "mlp_backward_h1": live_s,
                 "mlp_backward_h2": live_s}
         prof = {k: ((v[0], v[1], float(live[k])) if k in live else v) for k, v in prof.items()}
         ops.profile_begin()
@@ -698,6 +767,37 @@ def main():
         tot[0] = tmax[0]
     dt, n_samples, n_rays = (float(v) for v in tot.tolist())
 
+    # Same-process A/B of the step's round-5 forms against the round-4 forms of the same kernels (nsr.trainer.ROUND4_FORMS:
+    # two data-gradient launches, one wave per ray compositing, scan + copy, events recorded behind kernels, the step's stream
+    # waiting for the MLP optimizer in front of the encode): windows of 160 steps, interleaved A B B A, same trainer, same
+    # regime -- box-to-box variation (+-5 % on this pool) cancels, which it does not between rounds
+    forms_ab = None
+    if world == 1 and tr.async_mode and not shared_device and not os.environ.get("NSR_BENCH_NO_FORMS_AB"):
+        from nsr.trainer import ROUND4_FORMS, ROUND5_FORMS, set_step_forms
+        acc = {"round4_forms": [], "round5_forms": []}
+        for name in ("round4_forms", "round5_forms", "round5_forms", "round4_forms"):
+            set_step_forms(tr, ROUND4_FORMS if name == "round4_forms" else ROUND5_FORMS)
+            for _ in range(16):
+                tr.train_step()
+            sync()
+            a0, ta = tr.counters(), time.perf_counter()
+            for _ in range(160):
+                tr.train_step()
+            sync()
+            dta = time.perf_counter() - ta
+            a1 = tr.counters()
+            acc[name].append((1e3 * dta / 160, (a1["samples"] - a0["samples"]) / 160))
+        set_step_forms(tr, ROUND5_FORMS)
+        forms_ab = {k: {"ms_per_step": [round(x[0], 4) for x in v], "kept_samples_per_step": [round(x[1]) for x in v],
+                        "mean_ms_per_step": sum(x[0] for x in v) / len(v)} for k, v in acc.items()}
+        forms_ab["round5_over_round4"] = forms_ab["round5_forms"]["mean_ms_per_step"] / forms_ab["round4_forms"]["mean_ms_per_step"]
+        forms_ab["at_step"] = int(tr.global_step)
+
+    whole = late = None
+    if (world == 1 and tr.async_mode and not shared_device and not args.no_whole_run
+            and not os.environ.get("NSR_BENCH_NO_WHOLE_RUN")):
+        whole, late = whole_run(dev, data, cfg, n_steps=args.whole_run_steps, late_at=min(10000, args.whole_run_steps // 2))
+
     async_mode, fuse_table_update = tr.async_mode, tr.fuse_table_update
     n_table_params = tr.fused.ewn.grid_desc.n_entries * tr.fused.ewn.grid_desc.n_features
     final_loss = float(tr.last["loss"])  # (a LazyLoss of the most recent step: read before anything else runs)
@@ -725,7 +825,7 @@ def main():
             tb_pieces = {"binning_helper_stream_us": 1e3 * prof["hashgrid_backward_bin"][0] / max(launches, 1),
                          "accumulate_main_stream_us": 1e3 * acc_ms / max(launches, 1)}
             prof["hashgrid_backward_params"] = (acc_ms + prof["hashgrid_backward_bin"][0], launches, units)
-        cand = {k: v for k, v in prof.items() if k.startswith("hashgrid") and k != "hashgrid_backward_bin"}
+        cand = {k: v for k, v in prof.items() if k.startswith("hashgrid") and k not in ("hashgrid_backward_bin", "hashgrid_backward_dense")}
         if cand:
             name = max(cand, key=lambda k: cand[k][0])
             ms_total, launches, units = cand[name]
@@ -813,7 +913,7 @@ def main():
                                "set-up in front of the warm-up (--setup-steps); the start-up transient is the `transient` block"},
             "transient": transient,
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
-            "steady_state": steady,
+            "steady_state": steady, "step_forms_ab": forms_ab, "whole_run": whole, "late_regime": late,
             "roofline": roof, "roofline_secondary": secondary, "kernels": kern, "phase_ms_per_step": phases, "gradient_exchange": comm,
         }
         if shared_device:

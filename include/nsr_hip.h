@@ -286,6 +286,9 @@ int nsr_mlp_backward_phases(const void *dout, int dout_is_f32, uint32_t dout_str
  * two networks' backward workspaces where nsr_mlp_backward_phases(..., 1) puts them, so nsr_mlp_backward_phases(..., 2)
  * follows unchanged; every value is bit-identical to the two-launch sequence.  _supported: colour 32 -> 64 x (1..2) -> 3
  * sigmoid, density 32 -> 64 x (1..2) -> 16 linear.  _max_blocks: launch-size knob (0 queries), returns the previous value. */
+/* at most `blocks` workgroups per weight-gradient launch (1 .. 512, default 128 or NSR_WGRAD_MAX_BLOCKS; 0 queries); returns the
+ * previous cap.  Both halves of one backward must see the same value. */
+uint32_t nsr_mlp_wgrad_max_blocks(uint32_t blocks);
 int nsr_mlp_dgrad_pair_supported(const NsrMlpDesc *color, const NsrMlpDesc *density);
 uint32_t nsr_mlp_dgrad_pair_max_blocks(uint32_t blocks);
 int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, const nsr_half *out_color, const nsr_half *acts_color,

@@ -701,21 +701,31 @@ int check_mlp(const NsrMlpDesc *d, const char *who)
 
 uint32_t n_params_of(const NsrMlpDesc *d) { return WIDTH * d->in_pad + (d->n_hidden - 1) * WIDTH * WIDTH + 16 * WIDTH; }
 
-uint32_t bwd_blocks(uint32_t n)
+// wgrad: 32-sample tiles, ~2 tiles per wave, at most g_wgrad_cap blocks (one partial row of the whole network's parameters each:
+// 28 KB for 32 -> 64 -> 64 -> 16, written by the wgrad kernels and read back by k_reduce_partials).  The cap is a run-time knob
+// (nsr_mlp_wgrad_max_blocks, NSR_WGRAD_MAX_BLOCKS): with the step's join deferred to the next density MLP
+// (nsr_nerf_wait_before_mlp) the weight-gradient kernels have ~170 us to finish, and FEWER blocks (each holds 64 KB of LDS)
+// leave the table backward they run beside more of the chip.
+constexpr uint32_t WGRAD_CAP_MAX = 512;
+static uint32_t g_wgrad_cap = [] {
+    const char *e = getenv("NSR_WGRAD_MAX_BLOCKS");
+    const uint32_t v = e ? (uint32_t)atoi(e) : 128u;  // (measured in the step: 512 -> 0.373, 256 -> 0.368, 128 -> 0.365, 64 -> 0.370, 32 -> 0.391 ms)
+    return v < 1 ? 1u : (v > WGRAD_CAP_MAX ? WGRAD_CAP_MAX : v);
+}();
+uint32_t bwd_blocks_capped(uint32_t n, uint32_t cap)
 {
-    // wgrad: 32-sample tiles, ~2 tiles per wave, at most NSR_WGRAD_MAX_BLOCKS blocks (one partial row of the whole network's
-    // parameters each: 28 KB for 32 -> 64 -> 64 -> 16, written by the wgrad kernels and read back by k_reduce_partials)
-    static const uint32_t cap = getenv("NSR_WGRAD_MAX_BLOCKS") ? (uint32_t)atoi(getenv("NSR_WGRAD_MAX_BLOCKS")) : 512u;
     const uint32_t n_tiles = (n + 31) / 32;
     uint32_t nb = (n_tiles + WAVES * 2 - 1) / (WAVES * 2);
     return nb < 1 ? 1 : (nb > cap ? cap : nb);
 }
+uint32_t bwd_blocks(uint32_t n) { return bwd_blocks_capped(n, g_wgrad_cap); }
 
 // workspace layout (floats): [partials: nb * n_params][gpre^T: n_hidden * 64 * ldn halfs][gout^T: 16 * ldn halfs]
+// (sized for the LARGEST cap: the knob may move between the allocation and the launches)
 uint64_t bwd_ws_floats(const NsrMlpDesc *d, uint32_t n)
 {
     const uint64_t ldn = (n + 31u) & ~31u;
-    const uint64_t part = (uint64_t)bwd_blocks(n) * n_params_of(d);
+    const uint64_t part = (uint64_t)bwd_blocks_capped(n, WGRAD_CAP_MAX) * n_params_of(d);
     return part + ((uint64_t)d->n_hidden * 64 * ldn + 16 * ldn) / 2 + 64;
 }
 
@@ -777,6 +787,15 @@ extern "C" int nsr_mlp_forward_ex(const void *x, int x_is_f32, uint32_t x_stride
                                     desc->n_in, (int)desc->output_activation, x_level_major_features, n_dev));
     NSR_CHECK_LAUNCH("nsr_mlp_forward");
     return NSR_OK;
+}
+
+// at most `blocks` workgroups per weight-gradient launch (1 .. 512; 0 queries); returns the previous cap.  Data-gradient and
+// weight-gradient halves of one backward must see the same value (they share the workspace layout).
+extern "C" uint32_t nsr_mlp_wgrad_max_blocks(uint32_t blocks)
+{
+    const uint32_t old = g_wgrad_cap;
+    if (blocks) g_wgrad_cap = blocks > WGRAD_CAP_MAX ? WGRAD_CAP_MAX : blocks;
+    return old;
 }
 
 extern "C" uint64_t nsr_mlp_backward_workspace_floats(const NsrMlpDesc *desc, uint32_t n)

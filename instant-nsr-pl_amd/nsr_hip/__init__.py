@@ -225,6 +225,7 @@ SIGNATURES = {
     "nsr_hashgrid_dense_levels": [_GD],
     "nsr_hashgrid_backward_params_dense": [_P, _P, _P, _P, _P, _P, _U, _U, _F, _I, _GD, _P, _I, _P],
     "nsr_hashgrid_backward_params_owner_bin_range": [_P, _P, _U, _U, _U, _U, _GD, _P, _P],
+    "nsr_mlp_wgrad_max_blocks": [_U],
     "nsr_mlp_dgrad_pair_supported": [_MD, _MD],
     "nsr_mlp_dgrad_pair_max_blocks": [_U],
     "nsr_mlp_dgrad_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _F, _MD, _MD, _P, _P],
@@ -282,7 +283,7 @@ SIGNATURES = {
                                 _P, _U, _P, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_hashgrid_owner_first_unchunked_level": ctypes.c_uint32,
-             "nsr_hashgrid_dense_levels": ctypes.c_uint32, "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32,
+             "nsr_hashgrid_dense_levels": ctypes.c_uint32, "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,

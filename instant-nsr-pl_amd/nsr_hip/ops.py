@@ -23,7 +23,8 @@ _NATIVE_ON = False
 
 
 _NATIVE_TAGS = {0: "hashgrid_forward", 1: "hashgrid_backward_params", 2: "mlp_forward_h1", 3: "mlp_forward_h2",
-                4: "mlp_backward_h2", 5: "mlp_backward_h1", 6: "hashgrid_backward_bin"}
+                4: "mlp_backward_h2", 5: "mlp_backward_h1", 6: "hashgrid_backward_bin", 7: "hashgrid_backward_dense"}
+# (tag 4 times nsr_mlp_dgrad_pair -- both networks' data gradients in one launch -- when the step uses it; tag 5 is then absent)
 
 
 def profile_begin(native_only=False):
