@@ -700,7 +700,9 @@ typedef struct NsrNerfMainLayout {
  * nsr_hashgrid_backward_params_dense on a stream of their own, the owner launch covering the hashed levels only; key 2:
  * nsr_composite_*_flat instead of one wave per ray; key 3: the two networks' weight-gradient kernels on two helper streams
  * (with key 0); key 5: the pass's fork events ride on the kernels in front of them (hipExtLaunchKernelGGL stop event)
- * instead of being recorded behind them.  value < 0 queries; returns the previous value (-1: unknown key). */
+ * instead of being recorded behind them; key 6: the pass's events are created with hipEventReleaseToDevice; key 7: the table
+ * backward is issued before the helper streams' weight-gradient launches (host order).  value < 0 queries; returns the
+ * previous value (-1: unknown key). */
 int nsr_nerf_step_variant(int key, int value);
 /* key 4 of the above (default 0): the weight-gradient kernels of nsr_mlp_dgrad_pair's networks are queued BEHIND the table
  * backward instead of beside it, for a caller that defers its join with them (nsr_nerf_defer_wgrad_join) and hands the event

@@ -140,10 +140,13 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
 // beside the colour MLP / compositing / MLP backward chain instead of in front of the accumulation kernel.
 // (round 5) two more streams: `stream_b` takes the density network's weight-gradient kernels beside the colour network's on
 // `stream`, `stream_c` the dense levels' table backward (csrc/hashgrid_dense.inc) beside the owner launch of the hashed levels
+struct HelperEvents { hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr, dgrad_done = nullptr,
+                                  wgrad_b_done = nullptr, dense_done = nullptr; };
 struct HelperStream {
     hipStream_t stream = nullptr, stream_b = nullptr, stream_c = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr;
-    hipEvent_t dgrad_done = nullptr, wgrad_b_done = nullptr, dense_done = nullptr;
+    // two sets of the pass's events: [0] plain, [1] created with hipEventReleaseToDevice (a device-scope release when the event
+    // is recorded instead of the default system-scope one: every waiter is a stream of this device) -- nsr_nerf_step_variant key 6
+    HelperEvents ev[2];
     bool ok = false;
     bool init()
     {
@@ -151,12 +154,16 @@ struct HelperStream {
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
         if (hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking) != hipSuccess) return false;
         if (hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking) != hipSuccess) return false;
-        for (hipEvent_t *e : {&fork, &join, &join_wgrad, &fork_wgrad, &dgrad_done, &wgrad_b_done, &dense_done})
-            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return false;
+        for (int k = 0; k < 2; ++k)
+            for (hipEvent_t *e : {&ev[k].fork, &ev[k].join, &ev[k].join_wgrad, &ev[k].fork_wgrad, &ev[k].dgrad_done,
+                                  &ev[k].wgrad_b_done, &ev[k].dense_done})
+                if (hipEventCreateWithFlags(e, hipEventDisableTiming | (k ? hipEventReleaseToDevice : 0u)) != hipSuccess) return false;
         return ok = true;
     }
 };
 static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
+static int g_variant[8] = {1, 0, 1, 0, 0, 1, 0, 0};  // nsr_nerf_step_variant (below)
+#define HEV (g_helper.ev[g_variant[6] ? 1 : 0])
 
 // the helper stream's handle (created on first use), for callers that queue follow-up work behind the weight-gradient
 // kernels themselves (the trainer's optimizer launch for the MLP weights); NULL if it could not be created
@@ -168,7 +175,7 @@ extern "C" void *nsr_nerf_helper_stream(void) { return g_helper.init() ? (void *
 extern "C" int nsr_nerf_wait_kept_rows(void *stream)
 {
     NSR_REQUIRE(g_helper.ok, "nsr_nerf_wait_kept_rows: no main pass has run");
-    NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_helper.fork, 0) == hipSuccess, "nsr_nerf_wait_kept_rows: hipStreamWaitEvent failed");
+    NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, HEV.fork, 0) == hipSuccess, "nsr_nerf_wait_kept_rows: hipStreamWaitEvent failed");
     return NSR_OK;
 }
 
@@ -186,8 +193,10 @@ extern "C" int nsr_nerf_wait_kept_rows(void *stream)
 //          needs a caller that defers its join with them to nsr_nerf_wait_before_mlp (default 0)
 //   key 5: the pass's fork events ride on the kernels in front of them (hipExtLaunchKernelGGL stop event) instead of being
 //          recorded behind them
+//   key 6: the pass's events are the set created with hipEventReleaseToDevice (device-scope release at the record)
+//   key 7: the table backward is ISSUED before the weight-gradient launches of the helper streams (host order only)
 // value < 0 queries; returns the previous value.  Keys 0, 2, 5 default to 1.
-static int g_variant[8] = {1, 0, 1, 0, 0, 1, 0, 0};
+
 extern "C" int nsr_nerf_step_variant(int key, int value)
 {
     if (key < 0 || key >= 8) return -1;
@@ -471,7 +480,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // key 5: the fork events of the pass ride on the kernels they follow (NSR_LAUNCH_STOP) instead of being recorded behind them
     bool fork_pending = true;
     if (overlap_bins && g_variant[5] && !capturing && S > 0 && F == 2 && nh1 <= 2) {
-        nsr_next_stop_event = g_helper.fork;
+        nsr_next_stop_event = HEV.fork;
         fork_pending = false;
     }
     if (S > 0) {  // nothing kept (e.g. an empty occupancy grid): the per-ray outputs below are still produced
@@ -498,12 +507,12 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // ~7 us per launch, and with the four binning launches queued first the main stream sat idle for 30-45 us waiting for
     // its next kernel (rocprofv3 timeline: copy_kept_rows ... 46 us ... mlp_forward)
     g_ht.mark(1);
-    if (overlap_bins && nsr_next_stop_event == g_helper.fork) {  // the copy did not take it (the generic row copy)
+    if (overlap_bins && nsr_next_stop_event == HEV.fork) {  // the copy did not take it (the generic row copy)
         nsr_next_stop_event = nullptr;
         fork_pending = true;
     }
     if (overlap_bins && fork_pending)
-        NSR_REQUIRE(hipEventRecord(g_helper.fork, st) == hipSuccess, "nsr_nerf_main_pass: helper stream fork failed");
+        NSR_REQUIRE(hipEventRecord(HEV.fork, st) == hipSuccess, "nsr_nerf_main_pass: helper stream fork failed");
     {
         ProfScope p(NSR_PROF_MLP_FORWARD_COLOR, S, stream);
         NSR_TRY(nsr_mlp_forward_ex(tex_in, 0, 32, 0, w_color, out2, compute_grads ? acts2 : nullptr, S, &d->mlp_color,
@@ -527,7 +536,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     }
     g_ht.mark(3);
     if (overlap_bins) {
-        NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, g_helper.fork, 0) == hipSuccess,
+        NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, HEV.fork, 0) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream fork failed");
         if (use_dense)  // (its accumulators are cleared on the stream the dense kernels run on: ordered behind last step's)
             NSR_TRY(nsr_hashgrid_backward_params_dense(nullptr, nullptr, nullptr, nullptr, nullptr, (float *)(ws + L.grid_ws), S,
@@ -541,7 +550,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
             NSR_TRY(nsr_hashgrid_backward_params_owner_bin(x01, (float *)(ws + L.grid_ws), S, d->grid.n_levels, &d->grid,
                                                            n_kept_dev, g_helper.stream));
         }
-        NSR_REQUIRE(hipEventRecord(g_helper.join, g_helper.stream) == hipSuccess,
+        NSR_REQUIRE(hipEventRecord(HEV.join, g_helper.stream) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream join failed");
     }
     }  // phases & 1
@@ -610,8 +619,8 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     static const bool two_forks = getenv("NSR_WGRAD_ONE_FORK") == nullptr;
     g_ht.mark(5);
     const bool pair = g_variant[0] && nsr_mlp_dgrad_pair_supported(&d->mlp_color, &d->mlp_density) && C == 32;
-    bool dgrad_event = false;  // g_helper.dgrad_done recorded behind the last data-gradient kernel
-    bool late_wgrad = false;
+    bool dgrad_event = false;  // HEV.dgrad_done recorded behind the last data-gradient kernel
+    bool late_wgrad = false, wgrads_after_issue = false;
     // the weight-gradient kernels + reductions of both networks (behind nsr_mlp_dgrad_pair), forked from `st` through `fork`
     auto queue_wgrads = [&](hipEvent_t fork, bool *recorded, bool already_recorded) -> int {
         void *wg_c = wg, *wg_d = wg;
@@ -632,15 +641,15 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                         grad_density_mlp, nullptr, C, d->grid.n_features, part1, S, d->grad_scale,
                                         &d->mlp_density, n_kept_dev, wg_d ? wg_d : stream, 2));
         if (wg && wg_d != wg)  // whatever is queued on the helper stream from here on sees both networks' gradients
-            NSR_REQUIRE(hipEventRecord(g_helper.wgrad_b_done, g_helper.stream_b) == hipSuccess &&
-                            hipStreamWaitEvent(g_helper.stream, g_helper.wgrad_b_done, 0) == hipSuccess,
+            NSR_REQUIRE(hipEventRecord(HEV.wgrad_b_done, g_helper.stream_b) == hipSuccess &&
+                            hipStreamWaitEvent(g_helper.stream, HEV.wgrad_b_done, 0) == hipSuccess,
                         "nsr_nerf_main_pass: weight-gradient join failed");
         return NSR_OK;
     };
     if (pair) {
         late_wgrad = wg && g_variant[4] && g_defer_wgrad_join && !xchg;
         const bool ride = wg && g_variant[5] && !capturing && !late_wgrad && !g_prof_on;  // (the profiling scope records its own events)
-        if (ride) nsr_next_stop_event = g_helper.dgrad_done;
+        if (ride) nsr_next_stop_event = HEV.dgrad_done;
         {   // both networks' data gradients in one launch; d_feature stays in registers (csrc/mlp.hip k_mlp_dgrad_pair)
             ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
             NSR_TRY(nsr_mlp_dgrad_pair(d_rgb, d_logit, out2, acts2, w_color, part2, acts1, w_density, part1, d_enc, S,
@@ -651,7 +660,12 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         const bool rode = ride && nsr_next_stop_event == nullptr;
         nsr_next_stop_event = nullptr;
         if (rode) dgrad_event = true;
-        if (!late_wgrad) NSR_TRY(queue_wgrads(g_helper.dgrad_done, &dgrad_event, rode));
+        if (!late_wgrad && wg && g_variant[7] && !xchg) {
+            // (host order only: the fork event is recorded now, the helper streams' launches are issued behind the table backward's)
+            if (!rode) NSR_REQUIRE(hipEventRecord(HEV.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: weight-gradient fork failed");
+            dgrad_event = true;
+            wgrads_after_issue = true;
+        } else if (!late_wgrad) NSR_TRY(queue_wgrads(HEV.dgrad_done, &dgrad_event, rode));
     } else if (wg && !two_forks) {
         {
             ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
@@ -664,8 +678,8 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                             grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
                                             &d->mlp_density, n_kept_dev, stream, 1));
         }
-        NSR_REQUIRE(hipEventRecord(g_helper.fork_wgrad, st) == hipSuccess &&
-                        hipStreamWaitEvent(g_helper.stream, g_helper.fork_wgrad, 0) == hipSuccess,
+        NSR_REQUIRE(hipEventRecord(HEV.fork_wgrad, st) == hipSuccess &&
+                        hipStreamWaitEvent(g_helper.stream, HEV.fork_wgrad, 0) == hipSuccess,
                     "nsr_nerf_main_pass: weight-gradient fork failed");
         NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex, 32, 0,
                                         part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, wg, 2));
@@ -692,7 +706,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                     "nsr_nerf_main_pass_exchange: hipEventRecord failed");
     if (xchg) {
         NSR_REQUIRE(overlap_bins, "nsr_nerf_main_pass_exchange: the helper stream is not available");
-        NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess, "nsr_nerf_main_pass: helper stream join failed");
+        NSR_REQUIRE(hipStreamWaitEvent(st, HEV.join, 0) == hipSuccess, "nsr_nerf_main_pass: helper stream join failed");
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);  // (all groups: one operation)
         for (uint32_t g = 0; g < xchg->n_groups; ++g) {
             NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_range(x01, d_enc, nullptr, xchg->grad_bf16,
@@ -706,8 +720,8 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     } else if (use_dense) {
         // dense levels: ray-run merged atomics + their write-out on stream_c, beside the owner launch of the hashed levels
         if (!dgrad_event)
-            NSR_REQUIRE(hipEventRecord(g_helper.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: dense-level fork failed");
-        NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_c, g_helper.dgrad_done, 0) == hipSuccess,
+            NSR_REQUIRE(hipEventRecord(HEV.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: dense-level fork failed");
+        NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_c, HEV.dgrad_done, 0) == hipSuccess,
                     "nsr_nerf_main_pass: dense-level fork failed");
         {
             ProfScope p(NSR_PROF_GRID_BACKWARD_DENSE, S, g_helper.stream_c);
@@ -715,8 +729,8 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                        (float *)(ws + L.grid_ws), S, Lv, 1.0f, 0, &d->grid, n_kept_dev, 2 | 4,
                                                        g_helper.stream_c));
         }
-        NSR_REQUIRE(hipEventRecord(g_helper.dense_done, g_helper.stream_c) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
-        NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess, "nsr_nerf_main_pass: helper stream join failed");
+        NSR_REQUIRE(hipEventRecord(HEV.dense_done, g_helper.stream_c) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
+        NSR_REQUIRE(hipStreamWaitEvent(st, HEV.join, 0) == hipSuccess, "nsr_nerf_main_pass: helper stream join failed");
         {
             ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
             if (table_adam)
@@ -729,11 +743,11 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                                             &d->grid, n_kept_dev, stream));
         }
         // (whoever reads the table next on this stream -- the next step's encode, the caller's optimizer -- sees all levels)
-        NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.dense_done, 0) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
+        NSR_REQUIRE(hipStreamWaitEvent(st, HEV.dense_done, 0) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
     } else {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
         if (overlap_bins) {
-            NSR_REQUIRE(hipStreamWaitEvent(st, g_helper.join, 0) == hipSuccess,
+            NSR_REQUIRE(hipStreamWaitEvent(st, HEV.join, 0) == hipSuccess,
                         "nsr_nerf_main_pass: helper stream join failed");
             if (table_adam)  // the optimizer's update of the table happens inside the backward (no gradient store)
                 // (round 4: launching the small dense levels -- the slowest workgroups on a trained scene -- on a stream of their own
@@ -752,11 +766,12 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                        d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
         }
     }
-    if (late_wgrad) NSR_TRY(queue_wgrads(g_helper.fork_wgrad, nullptr, false));  // (the fork event sits behind the table backward)
+    if (late_wgrad) NSR_TRY(queue_wgrads(HEV.fork_wgrad, nullptr, false));  // (the fork event sits behind the table backward)
+    if (wgrads_after_issue) NSR_TRY(queue_wgrads(HEV.dgrad_done, nullptr, true));
     g_ht.mark(8);
     if (wg && !g_defer_wgrad_join)  // join: the optimizer step that follows on `stream` reads the MLP gradients
-        NSR_REQUIRE(hipEventRecord(g_helper.join_wgrad, g_helper.stream) == hipSuccess &&
-                        hipStreamWaitEvent(st, g_helper.join_wgrad, 0) == hipSuccess,
+        NSR_REQUIRE(hipEventRecord(HEV.join_wgrad, g_helper.stream) == hipSuccess &&
+                        hipStreamWaitEvent(st, HEV.join_wgrad, 0) == hipSuccess,
                     "nsr_nerf_main_pass: weight-gradient join failed");
     return NSR_OK;
 }

@@ -44,24 +44,26 @@ def _replay_tcnn(c, call, T, mods):
     assert torch.allclose(y.float().cpu(), want.float(), rtol=rtol, atol=atol), (c, "y", _rel(y, want))
     if call["n_gy"] == 0:
         return
-    gtol = 5e-3 if is_grid else 2e-2
+    # input gradients: 5e-3 through an encoding, SURVEY A.8's 1e-2 through an MLP -- except the two-hidden-layer colour network
+    # against the trace's fp32-recorded gradient: the fp16 chain's floor there is 1.6e-2 (measured; tests/test_gpu_mlp.py)
+    gtol = 5e-3 if is_grid else (2e-2 if int(getattr(getattr(m, "mlp_desc", None), "n_hidden", 1)) >= 2 else 1e-2)
     if call["n_ggx"] > 0:  # first-order input gradient with a graph, then the backward that differentiates it again
         gy0 = T[f"c{c}/gy0"].cuda().to(y.dtype).requires_grad_(True)
         (gx0,) = torch.autograd.grad(y, x, gy0, create_graph=True)
-        assert _rel(gx0, T[f"c{c}/gx0"]) < gtol, (c, "gx0", _rel(gx0, T[f"c{c}/gx0"]))
+        fu.assert_grad(gx0, T[f"c{c}/gx0"], (c, "gx0", "grid" if is_grid else "mlp"), rel=gtol)
         outs, grads = [gx0], [T[f"c{c}/ggx0"].cuda().to(gx0.dtype)]
         if call["n_gy"] > 1:
             outs.append(y)
             grads.append(T[f"c{c}/gy1"].cuda().to(y.dtype))
         torch.autograd.backward(outs, grads)
         if call["n_gx"] > 1:
-            assert _rel(x.grad, T[f"c{c}/gx1"]) < 2e-2, (c, "gx1", _rel(x.grad, T[f"c{c}/gx1"]))
+            fu.assert_grad(x.grad, T[f"c{c}/gx1"], (c, "gx1"))
         if call["n_ggy"] > 0:  # J . ggx: what flows on into the SDF network
-            assert _rel(gy0.grad, T[f"c{c}/ggy0"]) < 2e-2, (c, "ggy0", _rel(gy0.grad, T[f"c{c}/ggy0"]))
+            fu.assert_grad(gy0.grad, T[f"c{c}/ggy0"], (c, "ggy0"))
     else:
         torch.autograd.backward([y], [T[f"c{c}/gy0"].cuda().to(y.dtype)])
         if call["x_req"] and call["n_gx"] > 0:
-            assert _rel(x.grad, T[f"c{c}/gx0"]) < gtol, (c, "gx0", _rel(x.grad, T[f"c{c}/gx0"]))
+            fu.assert_grad(x.grad, T[f"c{c}/gx0"], (c, "gx0", "grid" if is_grid else "mlp"), rel=gtol)
 
 
 def _replay_nerfacc(c, call, T, nerfacc):

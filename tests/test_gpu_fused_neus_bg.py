@@ -63,7 +63,7 @@ def test_fused_neus_background_matches_reference_fixture():
     for k in BG_KEYS + ("geometry.encoding.encoding.params", "texture.network.layers.0.weight",
                         "geometry.network.layers.0.weight_v", "geometry.network.layers.2.weight_v"):
         assert params[k].grad is not None, k
-        assert fu.rel_l2(params[k].grad.cpu(), fx["grad/" + k]) < 2e-2, (k, fu.rel_l2(params[k].grad.cpu(), fx["grad/" + k]))
+        fu.assert_grad(params[k].grad, fx["grad/" + k], k)
 
 
 def test_fused_neus_background_matches_modular_path():
@@ -117,7 +117,7 @@ def test_fused_neus_background_matches_modular_path():
     now = dict(m.named_parameters())
     for k, w in ref.items():
         assert now[k].grad is not None, k
-        assert fu.rel_l2(now[k].grad, w) < 2e-2, (k, fu.rel_l2(now[k].grad, w), _cos(now[k].grad, w))
+        fu.assert_grad(now[k].grad, w, k)
 
 
 def test_neus_dtu_trainer_steps_with_background():

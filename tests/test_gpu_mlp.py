@@ -73,8 +73,14 @@ def test_backward_parity(n_in, n_out, n_hidden, act, n):
     cos_w = torch.nn.functional.cosine_similarity(gw, ref_w, dim=0)
     cos_x = torch.nn.functional.cosine_similarity(dx.flatten(), ref_x.flatten(), dim=0)
     assert cos_w > 0.999 and cos_x > 0.999, (cos_w, cos_x)
-    assert (gw - ref_w).norm() / ref_w.norm() < 2e-2
-    assert (dx - ref_x).norm() / ref_x.norm() < 2e-2
+    import fixture_utils as fu
+    # rel-L2 <= 1e-2 and cosine >= 0.999.  The reference here is FP32 autograd; the kernel (like tcnn's) carries fp16
+    # activations and an fp16 gradient chain: through one hidden layer it measures 4-8e-3, through two or three 1.2-1.8e-2
+    # (profiles/r05_grad_parity.json) -- the fp16 chain's floor against an fp32 reference, so those shapes take 2e-2 (cosine
+    # still >= 0.999: measured 0.99985-0.99993); the fused paths, compared with fp16-emulating fixtures, all meet 1e-2
+    rel = 1e-2 if n_hidden == 1 else 2e-2
+    fu.assert_grad(gw, ref_w, ("weights", n_in, n_out, n_hidden, act), rel=rel)
+    fu.assert_grad(dx, ref_x, ("input", n_in, n_out, n_hidden, act), rel=rel)
 
 
 def test_backward_accumulates_into_grad():

@@ -2,7 +2,7 @@
 set -u
 out=/root/repo/gpurun_out/r05g; mkdir -p "$out"
 cd /root/repo
-for n in 450 2500; do
+for n in 2500; do
 timeout 900 python tools/step_variants.py $n 160 4 > "$out/variants_$n.json" 2> "$out/variants_$n.err"; tail -3 "$out/variants_$n.err"
 python - "$out/variants_$n.json" <<'PY'
 import json, sys
