@@ -490,7 +490,7 @@ class FusedNeRFStep:
         if rs.get("marched") is not None:
             rs["marched"]["valid"] = False  # sample arrays of an earlier packing of this ring slot
 
-    def write_async(self, rs, consumer_stream=None, stream=None):
+    def write_async(self, rs, consumer_stream=None, stream=None, writer_stream=None):
         """sample arrays of ray set ``rs`` (ray index, t_starts, t_ends, unit-cube positions of every marched sample) from
         its marching scratch + packed_info, into buffers that belong to the ring slot -- queued on the CURRENT stream right
         behind ``pack_async`` (the marching side stream), so the step itself starts at the hash encode.
@@ -506,6 +506,17 @@ class FusedNeRFStep:
             if consumer_stream is not None:
                 for k in ("ri", "t0", "t1", "x01"):
                     mb[k].record_stream(consumer_stream)
+            if writer_stream is not None:
+                #  the buffers were just carved from the CURRENT stream's allocator pool but are written through a raw
+                # pointer of ``writer_stream``: tell the allocator, and order the writer behind whatever the current stream still
+                # has queued on a recycled block
+                cur = torch.cuda.current_stream(dev)
+                for k in ("ri", "t0", "t1", "x01"):
+                    mb[k].record_stream(writer_stream)
+                if writer_stream != cur:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    writer_stream.wait_event(ev)
         grid, d = self.model.occupancy_grid, self.desc
         rx, ry, rz = (int(v) for v in grid.binary.shape)
         with device_guard(dev):

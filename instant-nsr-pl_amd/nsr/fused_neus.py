@@ -1130,7 +1130,9 @@ class NeuSTrainer:
             from .parallel import ShardedAdamW
             if dist.is_initialized():
                 from .trainer import guard_stale_state_dict
-                self.sharded = ShardedAdamW(tc, lr=0.01)
+                # NSR_TRANSPORT=fp32: the table gradients travel as fp32 (the A/B of the bf16 wire format, as in nsr/trainer.py)
+                fp32 = os.environ.get("NSR_TRANSPORT", "bf16") == "fp32"
+                self.sharded = ShardedAdamW(tc, lr=0.01, transport=torch.float32 if fp32 else torch.bfloat16)
                 guard_stale_state_dict(model, self.sharded)
         self._tables = tuple(m for m in tc if getattr(m, "grid_desc", None) is not None)  # their backward OVERWRITES .grad
         # one GPU: AdamW on the tables runs inside their backward (NSR_NEUS_SEPARATE_ADAM=1: the stand-alone sweep, for A/B)
@@ -1207,6 +1209,13 @@ class NeuSTrainer:
                 sync_occupancy_grid(grid)
                 if self.fused.bg:
                     sync_occupancy_grid(model.occupancy_grid_bg)
+        elif self.world_size > 1 and cfg["grid_prune"] and t % 16 == 0:
+            #  the model refreshed its grids itself inside update_step (the reference's own model object): the ranks'
+            # grids are synchronised here all the same
+            from .parallel import sync_occupancy_grid
+            sync_occupancy_grid(grid)
+            if self.fused.bg:
+                sync_occupancy_grid(model.occupancy_grid_bg)
         if refreshed or (cfg["grid_prune"] and t % 16 == 0):
             self._pending = None  # marched through the old grid
         main = torch.cuda.current_stream()

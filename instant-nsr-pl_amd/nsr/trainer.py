@@ -423,6 +423,7 @@ class Trainer:
         if self._as is not None:
             self._as["marched_upto"] = self._as["packed_upto"] = self.global_step - 1
             self._as["events"].clear()
+            self._as["last_step_event"] = None  # (belongs to the run that was replaced)
 
     def settle(self):
         """make the current stream wait for work the asynchronous step left pending on its helper streams (the optimizer
@@ -499,6 +500,8 @@ class Trainer:
         model.background_color = bg
         with _ops.timed("phase:occupancy_update"):
             model.update_step(0, self.global_step)
+            if self.world_size > 1 and self.config.get("grid_prune") and self.global_step % 16 == 0:
+                sync_occupancy_grid(model.occupancy_grid)  # (every step variant keeps the ranks' grids equal)
         with _ops.timed("phase:forward"):
             out = model(rays)
         n_samples = int(out["num_samples_full" if "num_samples_full" in out else "num_samples"].sum().item())
@@ -726,7 +729,7 @@ class Trainer:
                 stream.wait_event(marched)
             fused.pack_async(sets[u % W], a["n_rays"], a["m_cap"], stats_m, stream=sp)
             if stream is not main and not self._write_inline:  # ... and the sample arrays + positions, off the step's own chain
-                fused.write_async(sets[u % W], consumer_stream=main, stream=sp)
+                fused.write_async(sets[u % W], consumer_stream=main, stream=sp, writer_stream=stream)
             e = torch.cuda.Event()
             e.record(stream)
             ev[("pack", u)] = e
@@ -777,7 +780,8 @@ class Trainer:
                                            table_adam=self.opt.table_update_desc(fused.ewn) if fuse_table else None,
                                            exchange=(xchg["desc"], xchg["g_density"], xchg["g_color"]) if xchg else None,
                                            # (this trainer joins the helper stream itself, behind its optimizer launch)
-                                           defer_wgrad_join=bool(fuse_table and self._helper_stream() is not None))
+                                           defer_wgrad_join=bool(fuse_table and self._helper_stream() is not None
+                                                                 and not os.environ.get("NSR_WGRAD_INLINE")))
         a["total_kept"] = res["num_samples"]
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
@@ -826,6 +830,8 @@ class Trainer:
             a["pending"] = False
         with _ops.timed("phase:occupancy_update"):
             model.update_step(0, self.global_step)
+            if self.world_size > 1 and cfg["grid_prune"] and self.global_step % 16 == 0:
+                sync_occupancy_grid(model.occupancy_grid)
         _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # re-packed in place after a grid refresh
         k = self.global_step & 1
         inorder = not a["pending"]
@@ -886,10 +892,11 @@ class Trainer:
                 return
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
-            if _pruned is None:
-                _pruned = torch.cuda.Event()
-                _pruned.record(main)
-            self._side.wait_event(_pruned)  # pruning pass of THIS step (its main pass is queued behind it already)
+            # (always an event recorded HERE, behind the ray-count update queued above on the main stream -- an event
+            # recorded right behind the pruning pass would let the side stream's marching read the count before it is updated)
+            _pruned = torch.cuda.Event()
+            _pruned.record(main)
+            self._side.wait_event(_pruned)
             with torch.cuda.stream(self._side):
                 fused.march_async(a["sets"][1 - k], self.dataset, self.gen, a["n_rays"], a["m_cap"], stats_m,
                                   cfg["background_color"], bricks=a["bricks"])

@@ -382,3 +382,80 @@ def test_resume_restores_per_rank_sampler_states(tmp_path):
         assert torch.equal(r["same_world"][0], r["same_world"][1])  # each rank continues ITS stream
     assert not torch.equal(r0["same_world"][1], r1["same_world"][1])  # ... and they are different streams
     assert not torch.equal(r0["other_world"], r1["other_world"])
+
+
+def _world8_worker(rank, world, port, out, phase):
+    """phase "train": world ranks step 3 times and rank 0 keeps the gathered checkpoint (masters + moments + step count);
+    phase "resume": a DIFFERENT world loads it and takes one more step"""
+    for p in (ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nsr.parallel import ShardedAdamW
+    # the real table's raggedness in small: [3072 MLP weights | 12,599,920 mod-like odd body], two level-group cuts
+    n_body = 70003
+    mods = [_FakeTcnnModule(3072 + n_body, 7, n_network_params=3072), _FakeTcnnModule(7168, 8)]
+    opt = ShardedAdamW(mods, lr=0.01, transport=torch.float32, small_numel=1 << 14, splits={mods[0]: [20000, 50001]})
+    G = world * 8
+    st = opt.state[mods[0]]
+    shapes = {"ranges": opt.ranges(mods[0]), "send": int(opt.send_buffer(mods[0]).numel()), "shard": int(st["master"].numel()),
+              "shadow": int(st["shadow"].numel())}
+    if phase == "resume":
+        ck = torch.load(os.path.join(out, "ckpt.pt"))
+        for m, p in zip(mods, ck["params"]):
+            m.params.data.copy_(p)
+        opt.load(mods, ck["moments"], ck["step_count"])
+    steps = range(3) if phase == "train" else range(3, 4)
+    grads = []
+    for step in steps:
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        for m in mods:
+            m.params.grad.copy_(torch.randn(m.params.numel(), generator=g) * 1e-2)
+        grads.append([m.params.grad.clone() for m in mods])
+        kw = dict(absent=(mods[0],)) if (phase == "train" and step == 1 and rank == world - 1) else {}
+        if kw:
+            grads[-1][0][3072:] = 0.0  # (no table backward ran on this rank: it contributes zeros for the body)
+        opt.step(overwritten=(mods[0],), **kw)
+    moments = opt.gather_moments(mods)
+    opt.gather_master()
+    res = {"grads": grads, "master": [m.params.detach().clone() for m in mods], "shadows": [m.shadow.clone() for m in mods],
+           "shapes": shapes, "G": G}
+    if phase == "train" and rank == 0:
+        torch.save({"params": res["master"], "moments": moments, "step_count": opt.step_count}, os.path.join(out, "ckpt.pt"))
+    torch.save(res, os.path.join(out, f"{phase}{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_world8_shapes_absent_rank_and_resume_at_world2(tmp_path):
+    """the shapes `bench.py --gpus 8` meets for the first time on a real node: ranges padded to world x 8 = 64 elements, 1/8
+    shards, a rank without samples in one step, the gathered checkpoint of the world-8 run loaded by a world-2 run -- every
+    rank bit-identical, the result = torch.optim.AdamW on the mean gradients of all four steps"""
+    world, port = 8, _free_port()
+    mp.spawn(_world8_worker, args=(world, port, str(tmp_path), "train"), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"train{k}.pt") for k in range(world)]
+    G, n_body = 64, 70003
+    pad = -(-n_body // G) * G
+    sh = r[0]["shapes"]
+    assert sh["ranges"] == [(-(-50001 // G) * G, pad), (-(-20000 // G) * G, -(-50001 // G) * G), (0, -(-20000 // G) * G)]
+    assert all(a % G == 0 and b % G == 0 for a, b in sh["ranges"])
+    assert sh["send"] == pad and sh["shard"] == pad // world and sh["shadow"] >= 3072 + n_body
+    for k in range(1, world):
+        assert r[k]["shapes"] == sh
+        for a, b in zip(r[0]["shadows"], r[k]["shadows"]):
+            assert torch.equal(a, b)
+        for a, b in zip(r[0]["master"], r[k]["master"]):
+            assert torch.equal(a, b)
+    mean8 = [[sum(r[k]["grads"][s][i] for k in range(world)) / world for i in range(2)] for s in range(3)]
+    # ... resumed by TWO ranks from rank 0's file
+    port2 = _free_port()
+    mp.spawn(_world8_worker, args=(2, port2, str(tmp_path), "resume"), nprocs=2, join=True)
+    q = [torch.load(tmp_path / f"resume{k}.pt") for k in range(2)]
+    assert q[0]["shapes"]["shard"] == -(-n_body // 16) * 16 // 2 and q[0]["G"] == 16
+    for a, b in zip(q[0]["master"], q[1]["master"]):
+        assert torch.equal(a, b)
+    mean2 = [[sum(q[k]["grads"][0][i] for k in range(2)) / 2 for i in range(2)]]
+    want = _reference_adamw([3072 + n_body, 7168], [7, 8], mean8 + mean2, [1.0, 1.0, 1.0, 1.0])
+    for got, w in zip(q[0]["master"], want):
+        assert torch.allclose(got, w, rtol=2e-5, atol=2e-7), float((got - w).abs().max())
