@@ -189,10 +189,10 @@ def cpu_config0_step(cores, seconds_budget=5.0):
 
 def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
     """HBM-side bytes per launch of the dominant operation from the PMC passes of THIS round (tools/collect_profiles.sh ->
-    profiles/r04_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
+    profiles/r05_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
     run in) -- used only when a pass ran in the same regime (same warmup / steps, or its recorded samples per launch
     within 15 % of this run's); otherwise the field is null"""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json",
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
                                                                          "r02_pmc_traffic.json")) if os.path.exists(q)), None)
     if path is None:
         return None, "no PMC file"

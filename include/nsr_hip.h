@@ -176,6 +176,10 @@ int nsr_hashgrid_forward_variant(int lds_levels, int levels_per_lane);
  * the corner values it already holds, and the two dense products the analytic normal needs from it
  * (models/geometry.py:176-180): dx = J^T dy (first-order input gradient) and d_dy = J g (its double backward) --
  * instead of gathering the table a second and a third time (nsr_hashgrid_backward_input / _backward_backward_input). */
+/* levels [0, 8) (half = 1) or [8, 16) (half = 2) of a 16-level grid only; both halves together == nsr_hashgrid_forward_ex */
+int nsr_hashgrid_forward_half(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                              int y_level_major, uint32_t level_mask_count, int half, const NsrGridDesc *desc,
+                              const int32_t *n_dev, void *stream);
 int nsr_hashgrid_forward_jac(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                              int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, float *jac,
                              const int32_t *n_dev, void *stream);
@@ -710,6 +714,12 @@ int nsr_nerf_step_variant(int key, int value);
  * stream wait for that hipEvent_t between its hash encode and its density MLP instead of the step's stream waiting in front
  * of the encode.  NULL clears.  The caller must wait for the event itself before anything else reads the weights. */
 int nsr_nerf_wait_before_mlp(void *event);
+/* key 8 of nsr_nerf_step_variant (default 0): the table backward with AdamW inside runs as two launches (levels [0, 8), then
+ * [8, 16)) and the NEXT pruning pass encodes levels [0, 8) on a helper stream beside the second launch (nsr_hashgrid_forward_half).
+ * That helper stream must wait for the pruning pass's inputs itself: hand the hipEvent_t behind which positions / marched count
+ * exist (recorded on the caller's marching stream) to nsr_nerf_set_inputs_event before every pruning pass (one-shot; without
+ * it the pass encodes in one launch as before). */
+int nsr_nerf_set_inputs_event(void *event);
 /* the stream the main pass runs its overlapped work on (item binning, weight-gradient kernels); created on first use */
 void *nsr_nerf_helper_stream(void);
 /* `stream` waits for the point of the last main pass where its kept rows exist (behind nsr_nerf_main_pass*'s first kernel) */

@@ -208,15 +208,19 @@ template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward_pair(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
                     uint32_t y_stride, uint32_t mask_count, uint32_t level_begin, int level_major, const NsrGridDesc d,
-                    const int32_t *__restrict__ n_dev)
+                    const int32_t *__restrict__ n_dev,
+                    uint32_t half /* 0: all 16 levels; 1 / 2: levels [0, 8) / [8, 16) only (round 5: the encode of the next step's
+                                     first half runs beside the table backward of the second -- csrc/step.hip).  A half launch pairs
+                                     levels (lo + p, lo + p + 4) on XCDs p and p + 4: still two levels = 4 MB of table per L2 */)
 {
-    const uint32_t xcd = blockIdx.x & 7u, blk = blockIdx.x >> 3;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t blk = half ? (blockIdx.x >> 3) * 2u + (xcd >> 2) : blockIdx.x >> 3;
     const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
     if (i >= live_count(n, n_dev)) return;
     const float x0 = x[3ull * i], x1 = x[3ull * i + 1], x2 = x[3ull * i + 2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const uint32_t level = xcd + 8u * h;
+        const uint32_t level = half ? (half - 1u) * 8u + (xcd & 3u) + 4u * h : xcd + 8u * h;
         if (level >= d.n_levels || level < level_begin) continue;
         float acc[F];
         if (level < mask_count) {
@@ -630,7 +634,7 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
         DISPATCH_F(desc->n_features,
                    hipLaunchKernelGGL((k_grid_forward_pair<F>), dim3(8u * nsr_div_up(n, GRID_BLOCK)), dim3(GRID_BLOCK), 0,
                                       (hipStream_t)stream, x, (const __half *)table, (__half *)y, n, y_stride,
-                                      level_mask_count, level_begin, y_level_major, *desc, n_dev));
+                                      level_mask_count, level_begin, y_level_major, *desc, n_dev, 0u));
         NSR_CHECK_LAUNCH("nsr_hashgrid_forward(pair)");
         return NSR_OK;
     }
@@ -639,6 +643,25 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
                                   (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
                                   *desc, n_dev, (float *)nullptr, level_begin));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward");
+    return NSR_OK;
+}
+
+// levels [0, 8) (half = 1) or [8, 16) (half = 2) of a 16-level grid only, in the pair kernel's XCD placement; the two halves
+// together write exactly what nsr_hashgrid_forward_ex writes (bit for bit: the same per-level arithmetic)
+extern "C" int nsr_hashgrid_forward_half(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                                         int y_level_major, uint32_t level_mask_count, int half, const NsrGridDesc *desc,
+                                         const int32_t *n_dev, void *stream)
+{
+    if (int rc = check_desc(desc, "nsr_hashgrid_forward_half")) return rc;
+    NSR_REQUIRE(desc->n_levels == 16 && (half == 1 || half == 2), "nsr_hashgrid_forward_half: 16 levels, half 1 or 2");
+    NSR_REQUIRE(y_level_major || y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward_half: y_stride too small");
+    if (n == 0) return NSR_OK;
+    NSR_REQUIRE(x && table && y, "nsr_hashgrid_forward_half: NULL pointer");
+    DISPATCH_F(desc->n_features,
+               hipLaunchKernelGGL((k_grid_forward_pair<F>), dim3(8u * nsr_div_up(nsr_div_up(n, GRID_BLOCK), 2)), dim3(GRID_BLOCK), 0,
+                                  (hipStream_t)stream, x, (const __half *)table, (__half *)y, n, y_stride, level_mask_count, 0u,
+                                  y_level_major, *desc, n_dev, (uint32_t)half));
+    NSR_CHECK_LAUNCH("nsr_hashgrid_forward_half");
     return NSR_OK;
 }
 

@@ -141,7 +141,7 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
 // (round 5) two more streams: `stream_b` takes the density network's weight-gradient kernels beside the colour network's on
 // `stream`, `stream_c` the dense levels' table backward (csrc/hashgrid_dense.inc) beside the owner launch of the hashed levels
 struct HelperEvents { hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr, dgrad_done = nullptr,
-                                  wgrad_b_done = nullptr, dense_done = nullptr; };
+                                  wgrad_b_done = nullptr, dense_done = nullptr, table_a_done = nullptr, enc_a_done = nullptr; };
 struct HelperStream {
     hipStream_t stream = nullptr, stream_b = nullptr, stream_c = nullptr;
     // two sets of the pass's events: [0] plain, [1] created with hipEventReleaseToDevice (a device-scope release when the event
@@ -156,13 +156,13 @@ struct HelperStream {
         if (hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking) != hipSuccess) return false;
         for (int k = 0; k < 2; ++k)
             for (hipEvent_t *e : {&ev[k].fork, &ev[k].join, &ev[k].join_wgrad, &ev[k].fork_wgrad, &ev[k].dgrad_done,
-                                  &ev[k].wgrad_b_done, &ev[k].dense_done})
+                                  &ev[k].wgrad_b_done, &ev[k].dense_done, &ev[k].table_a_done, &ev[k].enc_a_done})
                 if (hipEventCreateWithFlags(e, hipEventDisableTiming | (k ? hipEventReleaseToDevice : 0u)) != hipSuccess) return false;
         return ok = true;
     }
 };
 static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
-static int g_variant[8] = {1, 0, 1, 0, 0, 1, 0, 0};  // nsr_nerf_step_variant (below)
+static int g_variant[12] = {1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0};  // nsr_nerf_step_variant (below)
 #define HEV (g_helper.ev[g_variant[6] ? 1 : 0])
 
 // the helper stream's handle (created on first use), for callers that queue follow-up work behind the weight-gradient
@@ -195,11 +195,14 @@ extern "C" int nsr_nerf_wait_kept_rows(void *stream)
 //          recorded behind them
 //   key 6: the pass's events are the set created with hipEventReleaseToDevice (device-scope release at the record)
 //   key 7: the table backward is ISSUED before the weight-gradient launches of the helper streams (host order only)
+//   key 8: the table backward (with AdamW inside) as TWO launches, levels [0, 8) then [8, 16), and the NEXT pruning pass's encode
+//          as two halves: levels [0, 8) on a helper stream as soon as the first launch has retired -- beside the second --, levels
+//          [8, 16) on the step's stream; needs nsr_nerf_set_inputs_event (the next step's positions come from another stream)
 // value < 0 queries; returns the previous value.  Keys 0, 2, 5 default to 1.
 
 extern "C" int nsr_nerf_step_variant(int key, int value)
 {
-    if (key < 0 || key >= 8) return -1;
+    if (key < 0 || key >= 12) return -1;
     const int old = g_variant[key];
     if (value >= 0) g_variant[key] = value;
     return old;
@@ -210,6 +213,16 @@ extern "C" int nsr_nerf_step_variant(int key, int value)
 // that launch's event over instead of making the step's stream wait for it in front of the encode: the weight-gradient
 // kernels + the optimizer then have the encode's duration to finish.  NULL clears.  The caller must make its stream wait for
 // the event itself before anything ELSE reads the weights on it (occupancy refresh, evaluation, checkpoints).
+// (key 8) one-shot: the event behind which the NEXT pruning pass's inputs (positions, marched count: written on the caller's
+// marching stream) exist -- its first encode half runs on a helper stream that has to wait for them itself
+static hipEvent_t g_inputs_event = nullptr;
+static bool g_table_a_pending = false;  // the last main pass recorded HEV.table_a_done between its two table-backward launches
+extern "C" int nsr_nerf_set_inputs_event(void *event)
+{
+    g_inputs_event = (hipEvent_t)event;
+    return NSR_OK;
+}
+
 static hipEvent_t g_wait_before_mlp = nullptr;
 extern "C" int nsr_nerf_wait_before_mlp(void *event)
 {
@@ -306,7 +319,28 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
         NSR_TRY(nsr_sigma_rays(x01, table, w_density, out1, acts1, enc, n_marched, packed_info, t_starts, t_ends,
                                d->density_bias, d->early_stop_eps, kept_counts, n_rays, &d->grid, &d->mlp_density, stream));
     } else {
-        {
+        // (only when the positions were written AHEAD of the pass, on the caller's marching stream: formed inside this pass they
+        // exist on `stream` alone, and the helper stream's half would race with the kernel that writes them)
+        const bool split_encode = g_variant[8] && g_table_a_pending && g_inputs_event && x01_marched && d->grid.n_levels == 16 &&
+                                  g_helper.init();
+        hipEvent_t inputs_event = g_inputs_event;
+        g_table_a_pending = false;
+        g_inputs_event = nullptr;
+        if (split_encode) {
+            // levels [0, 8) were final behind the previous main pass's first table-backward launch: their encode runs on the
+            // helper stream beside the second launch; levels [8, 16) follow on this stream
+            NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_c, inputs_event, 0) == hipSuccess &&
+                            hipStreamWaitEvent(g_helper.stream_c, HEV.table_a_done, 0) == hipSuccess,
+                        "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
+            NSR_TRY(nsr_hashgrid_forward_half(x01, table, enc, n_marched, C, 1, d->grid.n_levels, 1, &d->grid, n_marched_dev,
+                                              g_helper.stream_c));
+            NSR_REQUIRE(hipEventRecord(HEV.enc_a_done, g_helper.stream_c) == hipSuccess, "nsr_nerf_prune_pass: hipEventRecord failed");
+            ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
+            NSR_TRY(nsr_hashgrid_forward_half(x01, table, enc, n_marched, C, 1, d->grid.n_levels, 2, &d->grid, n_marched_dev,
+                                              stream));
+            NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, HEV.enc_a_done, 0) == hipSuccess,
+                        "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
+        } else {
             ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
             NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
                                             stream));
@@ -749,7 +783,16 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         if (overlap_bins) {
             NSR_REQUIRE(hipStreamWaitEvent(st, HEV.join, 0) == hipSuccess,
                         "nsr_nerf_main_pass: helper stream join failed");
-            if (table_adam)  // the optimizer's update of the table happens inside the backward (no gradient store)
+            if (table_adam && g_variant[8] && Lv == 16 && !capturing) {
+                // two launches, levels [0, 8) then [8, 16), an event between them: the next pruning pass's encode of the first
+                // half starts behind it (prune_pass above)
+                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam_range(x01, d_enc, (float *)(ws + L.grid_ws), S, Lv, 1.0f,
+                                                                                 0, 8, &d->grid, n_kept_dev, table_adam, stream));
+                NSR_REQUIRE(hipEventRecord(HEV.table_a_done, st) == hipSuccess, "nsr_nerf_main_pass: hipEventRecord failed");
+                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam_range(x01, d_enc, (float *)(ws + L.grid_ws), S, Lv, 1.0f,
+                                                                                 8, 16, &d->grid, n_kept_dev, table_adam, stream));
+                g_table_a_pending = true;
+            } else if (table_adam)  // the optimizer's update of the table happens inside the backward (no gradient store)
                 // (round 4: launching the small dense levels -- the slowest workgroups on a trained scene -- on a stream of their own
                 // beside the other levels was built and measured: 125-135 us for that launch alone, step 0.511 -> 0.546 ms; their
                 // chains are hidden better INSIDE the one launch, where they are dispatched first)

@@ -20,6 +20,22 @@ F32, F16 = torch.float32, torch.float16
 _byref = ctypes.byref
 
 
+class _PendingCount:
+    """the (marched, kept) sample counts of a lazy ``render_forward``: ``previous()`` -- the last call's, already on the host (None
+    before the second call); ``current()`` -- this call's, waiting for its pinned copy"""
+
+    def __init__(self, bb):
+        self._bb, self._pending, self._prev = bb, bb["pending"], bb["prev_counts"]
+
+    def previous(self):
+        return self._prev
+
+    def current(self):
+        host, ev = self._pending
+        ev.synchronize()
+        return int(host[0]), int(host[8])
+
+
 class FusedNeRFStep:
     def __init__(self, model, early_stop_eps=1e-4, grad_scale=None, native=True):
         # the fp16 MLP backward scales dL/dy before it rounds it to fp16 (tcnn: loss_scale 128 ON TOP of Lightning's
@@ -203,12 +219,18 @@ class FusedNeRFStep:
                     "loss_acc": view(L.loss_acc, 2, F32, (2,)), "_workspace": ws}
 
     # ---- the step split at the loss (nsr.models.FusedNeRFModel: the reference's system owns loss and backward()) ---------
-    def render_forward(self, rays, background, prepare_backward):
+    def render_forward(self, rays, background, prepare_backward, lazy=False):
         """march + sigma pass + main forward of ``NeRFModel.forward_`` (models/nerf.py:61-127) queued as one run of launches
         with ONE host synchronisation at its end: the marched / kept sample counts stay on the device, the buffers have
         capacities that follow the counts of the previous calls (a call whose counts exceed them is re-queued with larger
         ones from the marcher's scratch rows).  Returns the reference's output tensors plus the state ``render_backward``
-        needs (everything lives in two workspaces)."""
+        needs (everything lives in two workspaces).
+
+        ``lazy``: NO synchronisation -- the counts are copied to pinned memory behind the pass and read by the NEXT call (which
+        sizes its buffers from them, one call late, like the asynchronous trainer: a call whose counts exceed its capacities is
+        truncated and reported in ``self.render_truncated``); ``out['num_samples']`` / ``['num_marched']`` are then None and
+        ``out['count']`` is a handle (``.current()`` waits for this call's counts, ``.previous()`` returns the last call's), the
+        per-sample outputs are capacity-sized (rows >= the live count are unspecified)."""
         m, ewn, tex, d = self.model, self.ewn, self.tex, self.desc
         grid = m.occupancy_grid
         dev = rays.device
@@ -221,7 +243,10 @@ class FusedNeRFStep:
             bb = self._bb = dict(slots=slots, dev=dev, cap=cap, counts=torch.empty(slots, dtype=torch.int32, device=dev),
                                  scratch=torch.empty(slots * cap * 2, dtype=F32, device=dev),
                                  stats=torch.zeros(16, dtype=torch.int32, device=dev),
-                                 host=torch.zeros(16, dtype=torch.int32).pin_memory(), m_cap=1 << 19, s_cap=1 << 18)
+                                 host=torch.zeros(16, dtype=torch.int32).pin_memory(), m_cap=1 << 19, s_cap=1 << 18,
+                                 hosts=[torch.zeros(16, dtype=torch.int32).pin_memory() for _ in range(2)], pending=None,
+                                 prev_counts=None, flip=0)
+            self.render_truncated = 0
         rx, ry, rz = (int(v) for v in grid.binary.shape)
         with torch.no_grad(), torch.cuda.device(dev):
             s = stream_ptr()
@@ -240,6 +265,20 @@ class FusedNeRFStep:
             table, w1, w2 = half[ewn.n_network_params:], half[:ewn.n_network_params], tex.half_params(tex.params)
             bg = background.to(F32).contiguous()
             import copy
+            if lazy and bb["pending"] is not None:
+                # the counts of the PREVIOUS lazy call (its pass finished long ago: the host is one step behind at most)
+                host_p, ev_p = bb["pending"]
+                ev_p.synchronize()
+                Mp, Sp = int(host_p[0]), int(host_p[8])
+                bb["prev_counts"], bb["pending"] = (Mp, Sp), None
+                # (capacities follow the counts one call late: more head-room than the synchronising path's 1.3 x)
+                grow = lambda n: -(-int(1.6 * n) // 65536) * 65536  # noqa: E731
+                if Mp > bb["m_cap"] or Sp > bb["s_cap"]:
+                    self.render_truncated += 1  # that call's samples were cut at its capacities
+                if Mp > 0.75 * bb["m_cap"] or Mp < 0.3 * bb["m_cap"]:
+                    bb["m_cap"] = max(grow(max(Mp, 1)), 1 << 18)
+                if Sp > 0.75 * bb["s_cap"] or Sp < 0.3 * bb["s_cap"]:
+                    bb["s_cap"] = max(grow(max(Sp, 1)), 1 << 17)
             while True:
                 m_cap, s_cap = bb["m_cap"], bb["s_cap"]
                 meta = torch.empty(5 * n_rays + 2, dtype=torch.int32, device=dev)  # packed | kept | packed_kept | totals
@@ -267,6 +306,15 @@ class FusedNeRFStep:
                 check(lib.nsr_nerf_render_forward(_byref(d), ptr(pws), m_cap, ptr(packed), ptr(packed2), ptr(t0), ptr(t1),
                                                   ptr(rays_d), ptr(bg), ptr(w1), ptr(w2), ptr(ws), s_cap, n_rays,
                                                   int(bool(prepare_backward)), ptr(total_s), None, s), "nsr_nerf_render_forward")
+                if lazy:  # no synchronisation: the counts travel to pinned memory behind the pass, the next call reads them
+                    host = bb["hosts"][bb["flip"]]
+                    bb["flip"] ^= 1
+                    host.copy_(stats, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    bb["pending"] = (host, ev)
+                    M = S = None
+                    break
                 # the ONE synchronisation of the forward: both counts (unclamped) in one pinned read-back
                 host = bb["host"]
                 host.copy_(stats, non_blocking=True)
@@ -288,10 +336,13 @@ class FusedNeRFStep:
         def view(off, n, dtype, shape):
             return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)
 
+        Sv = S if S is not None else s_cap  # (lazy: capacity-sized views, the live count is not on the host yet)
         out = {"comp_rgb": view(L.comp_rgb, n_rays * 3, F32, (n_rays, 3)), "opacity": view(L.opacity, n_rays, F32, (n_rays, 1)),
-               "depth": view(L.depth, n_rays, F32, (n_rays, 1)), "weights": view(L.weights, S, F32, (S,)),
-               "ray_indices": view(L.ray_indices, S, torch.int64, (S,)), "t_starts": view(L.t_starts, S, F32, (S,)),
-               "t_ends": view(L.t_ends, S, F32, (S,)), "num_samples": S, "num_marched": M}
+               "depth": view(L.depth, n_rays, F32, (n_rays, 1)), "weights": view(L.weights, Sv, F32, (Sv,)),
+               "ray_indices": view(L.ray_indices, Sv, torch.int64, (Sv,)), "t_starts": view(L.t_starts, Sv, F32, (Sv,)),
+               "t_ends": view(L.t_ends, Sv, F32, (Sv,)), "num_samples": S, "num_marched": M}
+        if lazy:
+            out["count"] = _PendingCount(bb)
         state = dict(pws=pws, ws=ws, packed=packed, packed2=packed2, rays_d=rays_d, bg=bg, M=m_cap, S=s_cap, S_live=S,
                      n_kept_dev=total_s, n_rays=n_rays, w1=w1, w2=w2, keep=(meta, half, smp))
         return out, state
@@ -305,7 +356,7 @@ class FusedNeRFStep:
         g1 = torch.empty_like(ewn.params)
         g1[:ewn.n_network_params].zero_()  # the MLP slices are accumulated into, the table slice is overwritten
         g2 = torch.zeros_like(tex.params)
-        if state["S_live"] == 0:
+        if state["S_live"] is not None and state["S_live"] == 0:  # (None: a lazy forward -- the kernels read the device-side count)
             g1.zero_()
             return g1, g2
         up = nsr_hip.NsrRenderGrads()

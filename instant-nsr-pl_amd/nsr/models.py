@@ -54,6 +54,133 @@ def _fp16_backward_scale(model, under_autocast):
     return 128.0 if under_autocast else 65536.0
 
 
+# ---- outputs that do not stall the host (round 5) -----------------------------------------------------------------------------
+# The reference's training_step (systems/nerf.py:87-99) synchronises three times on the model's outputs: ``.sum().item()`` on
+# num_samples and two boolean-mask indexings with rays_valid (a nonzero each).  With ``model.lazy_outputs`` (default in training)
+# the fused forward queues its launches and returns at once; the system's OWN statements then run unchanged on:
+#   * ``num_samples``: a count whose ``.sum().item()`` gives the kept samples of the PREVIOUS forward (already in pinned memory:
+#     the dynamic ray count is a 0.9 / 0.1 moving average, one step of lag moves it by nothing measurable -- PSNR checked,
+#     profiles/r05_psnr_paths.json) -- ``.current()`` gives this forward's, waiting for it;
+#   * ``rays_valid``: a bool tensor subclass; ``x[rays_valid[..., 0]]`` is DEFERRED (rows + mask), and F.smooth_l1_loss /
+#     mse_loss / l1_loss of two such selections over the same mask are computed as masked means on the device -- the same
+#     number as the loss of the gathered rows, no nonzero(), gradients through autograd.  Anything else done to a deferred
+#     selection materialises it (one synchronisation, the reference's behaviour);
+#   * per-sample outputs (weights, points, intervals, ray_indices): sliced to the live count only when somebody reads them.
+class _LazyCount:
+    def __init__(self, handle):
+        self._h = handle
+
+    def current(self):
+        return self._h.current()[1]
+
+    def _value(self):
+        prev = self._h.previous()
+        return prev[1] if prev is not None else self._h.current()[1]  # (the first forward has no predecessor: its own count)
+
+    def sum(self, *a, **k):
+        return self
+
+    def item(self):
+        return int(self._value())
+
+    __int__ = item
+
+    def __float__(self):
+        return float(self._value())
+
+    def tensor(self):
+        return torch.as_tensor([self._value()], dtype=torch.int32)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        args = tuple(a.tensor() if isinstance(a, _LazyCount) else a for a in args)
+        return func(*args, **(kwargs or {}))
+
+
+class _ValidMask(torch.Tensor):
+    """``rays_valid`` of a lazy forward: indexing another tensor's rows with it is deferred (``_MaskedRows``)"""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], _ValidMask) \
+                and not isinstance(args[0], _ValidMask) and args[1].dim() == 1 and args[0].dim() >= 1 \
+                and args[0].shape[0] == args[1].shape[0]:
+            return _MaskedRows(args[0], args[1].as_subclass(torch.Tensor))
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        if func is torch.Tensor.__getitem__ and isinstance(out, torch.Tensor) and out.dtype == torch.bool:
+            return out.as_subclass(_ValidMask)  # (rays_valid[..., 0] stays a validity mask)
+        return out
+
+
+class _MaskedRows:
+    """``base[mask]`` not yet gathered"""
+    _LOSSES = None
+
+    def __init__(self, base, mask):
+        self.base, self.mask = base, mask
+
+    def materialize(self):
+        return self.base[self.mask]
+
+    def __getattr__(self, name):  # anything the deferred form does not know: the gathered tensor's
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        import torch.nn.functional as F
+        kwargs = dict(kwargs or {})
+        if func in (F.smooth_l1_loss, F.mse_loss, F.l1_loss, F.huber_loss) and len(args) >= 2 \
+                and isinstance(args[0], _MaskedRows) and isinstance(args[1], _MaskedRows) \
+                and args[0].mask.data_ptr() == args[1].mask.data_ptr() and args[0].mask.shape == args[1].mask.shape \
+                and kwargs.get("reduction", "mean") == "mean" and len(args) == 2 \
+                and kwargs.get("size_average") is None and kwargs.get("reduce") is None:
+            a, b = args
+            kwargs["reduction"] = "none"
+            per = func(a.base, b.base, **kwargs)
+            m = a.mask.view(-1, *([1] * (per.dim() - 1))).to(per.dtype)
+            n = (m.sum() * (per.numel() // max(per.shape[0], 1))).clamp(min=1.0)
+            return (per * m).sum() / n
+        args = tuple(x.materialize() if isinstance(x, _MaskedRows) else x for x in args)
+        kwargs = {k: (v.materialize() if isinstance(v, _MaskedRows) else v) for k, v in kwargs.items()}
+        return func(*args, **kwargs)
+
+
+class _LazyOutputs(dict):
+    """the model's output dict whose per-sample entries are capacity-sized until read (then: one wait for the count)"""
+
+    def __init__(self, eager, lazy, count):
+        super().__init__(eager)
+        self._lazy, self._count = dict(lazy), count
+        for k in self._lazy:
+            dict.__setitem__(self, k, None)
+
+    def _resolve(self, k):
+        if k in self._lazy:
+            S = self._count.current()
+            dict.__setitem__(self, k, self._lazy.pop(k)[:S])
+
+    def __getitem__(self, k):
+        self._resolve(k)
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if k in self:
+            return self[k]
+        return default
+
+    def items(self):
+        for k in list(self._lazy):
+            self._resolve(k)
+        return dict.items(self)
+
+    def values(self):
+        for k in list(self._lazy):
+            self._resolve(k)
+        return dict.values(self)
+
+
 class _RenderNeRF(torch.autograd.Function):
     """comp_rgb, opacity, depth, weights = render(rays, background; geometry params, texture params)"""
 
@@ -64,7 +191,8 @@ class _RenderNeRF(torch.autograd.Function):
         ctx.empty_shapes = [tuple(p.shape) for p in p_empty]
         # (need_grad is decided by the caller: grad mode is always off inside Function.forward)
         step = model._runner()
-        out, state = step.render_forward(rays.detach(), background.detach(), prepare_backward=need_grad)
+        out, state = step.render_forward(rays.detach(), background.detach(), prepare_backward=need_grad,
+                                         lazy=bool(model.training and getattr(model, "lazy_outputs", False)))
         ctx.prepared = bool(need_grad)
         ctx.step, ctx.state = step, state
         ctx.grad_scale = _fp16_backward_scale(model, torch.is_autocast_enabled())
@@ -96,6 +224,10 @@ class FusedNeRFModel(HotPathState):
             raise ValueError("FusedNeRFModel builds the 'nerf' model section")
         super().__init__(cfg)
         self._step, self._last, self._bricks = None, None, None
+        import os
+        # training forwards return without a host synchronisation (see _LazyCount / _ValidMask above); False: the round-4
+        # behaviour (one synchronisation per forward, num_samples a CPU tensor, plain bool rays_valid)
+        self.lazy_outputs = not os.environ.get("NSR_BOUNDARY_EAGER")
 
     def _runner(self):
         if self._step is None:
@@ -128,6 +260,13 @@ class FusedNeRFModel(HotPathState):
         comp_rgb, opacity, depth, weights, ray_indices = _RenderNeRF.apply(self, need_grad, rays, bg, ewn.params, tex.params,
                                                                            *empty)
         last = self._last
+        if last.get("count") is not None:  # a lazy forward: nothing here waits for the GPU
+            count = _LazyCount(last["count"])
+            t0, t1 = last["t_starts"], last["t_ends"]
+            return _LazyOutputs({"comp_rgb": comp_rgb, "opacity": opacity, "depth": depth,
+                                 "rays_valid": (opacity > 0).as_subclass(_ValidMask), "num_samples": count},
+                                {"weights": weights.view(-1), "points": ((t0 + t1) / 2.0).view(-1),
+                                 "intervals": (t1 - t0).view(-1), "ray_indices": ray_indices.view(-1)}, count)
         out = {"comp_rgb": comp_rgb, "opacity": opacity, "depth": depth, "rays_valid": opacity > 0,
                "num_samples": torch.as_tensor([last["num_samples"]], dtype=torch.int32)}
         if self.training:
@@ -138,7 +277,8 @@ class FusedNeRFModel(HotPathState):
 
     def forward(self, rays):
         if self.training:
-            return {**self.forward_(rays)}
+            out = self.forward_(rays)
+            return out if isinstance(out, _LazyOutputs) else {**out}
         from .export import chunk_batch
         with torch.no_grad():
             return {**chunk_batch(self.forward_, int(self.config["ray_chunk"]), True, rays)}

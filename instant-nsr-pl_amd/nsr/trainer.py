@@ -751,6 +751,10 @@ class Trainer:
         if a["packed_upto"] < t:
             queue_pack(t, main)
         main.wait_event(ev[("pack", t)])
+        if _lib.nsr_nerf_step_variant(8, -1) > 0:
+            # (the pruning pass encodes its first level half on a helper stream beside the previous step's second table-backward
+            # launch: that stream waits for this step's positions itself -- csrc/step.hip nsr_nerf_set_inputs_event)
+            _check(_lib.nsr_nerf_set_inputs_event(ctypes.c_void_p(ev[("pack", t)].cuda_event)), "nsr_nerf_set_inputs_event")
         rs = sets[t % W]
         model.background_color = rs["bg"]
 

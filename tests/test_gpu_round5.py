@@ -454,3 +454,102 @@ def test_async_trainer_with_and_without_the_round5_forms():
         assert abs(x - y) <= 3e-2 * abs(x) + 1e-6, (x, y)
     assert b["losses"][-1] < 0.7 * b["losses"][0] and a["truncated"] == b["truncated"] == 0
     assert abs(a["samples"] - b["samples"]) <= 0.02 * a["samples"]
+
+
+def test_model_entry_lazy_outputs_match_the_synchronising_ones():
+    """nsr.models.FusedNeRFModel with ``lazy_outputs``: the reference system's own statements (systems/nerf.py:87-99) on the
+    non-synchronising outputs give the loss and the parameter gradients of the same statements on the eager outputs;
+    ``num_samples.sum().item()`` is the previous forward's count, ``.current()`` this one's; per-sample outputs are sliced to
+    the live count when read"""
+    import nsr
+    import nsr.models
+    torch.manual_seed(0)
+    cfg = nsr.configs.get("nerf-blender")
+    model = nsr.models.FusedNeRFModel(cfg).cuda().train()
+    with torch.no_grad():
+        model.geometry.encoding_with_network.params[3072:].normal_(0, 0.08)
+    model.randomized = False
+    ii = torch.stack(torch.meshgrid(*[torch.arange(128)] * 3, indexing="ij"), -1).float().cuda()
+    model.occupancy_grid._binary = (((ii + 0.5) / 128 * 3 - 1.5).norm(dim=-1) < 1.1)
+    model.background_color = torch.tensor([0.3, 0.6, 0.9], device="cuda")
+    res = {}
+    for lazy in (False, True, True):
+        rays, gt = _rays(700, seed=3 if lazy else 1)
+        if len(res) == 2:
+            rays, gt = _rays(700, seed=1)  # third pass: the eager pass's rays again, now lazily
+        model.lazy_outputs = lazy
+        model.zero_grad(set_to_none=True)
+        out = model(rays)
+        n_item = out["num_samples"].sum().item()
+        valid = out["rays_valid"][..., 0]
+        loss = torch.nn.functional.smooth_l1_loss(out["comp_rgb"][out["rays_valid"][..., 0]], gt[out["rays_valid"][..., 0]])
+        loss.backward()
+        torch.cuda.synchronize()
+        res[len(res)] = dict(lazy=lazy, n_item=int(n_item), loss=float(loss), out=out, valid=valid,
+                             current=(out["num_samples"].current() if lazy else int(n_item)),
+                             g1=model.geometry.encoding_with_network.params.grad.clone(), g2=model.texture.network.params.grad.clone(),
+                             weights=out["weights"].detach().clone(), ri=out["ray_indices"].clone())
+    e, l1, l2 = res[0], res[1], res[2]
+    assert type(l1["out"]).__name__ == "_LazyOutputs" and type(l1["valid"]).__name__ == "_ValidMask"
+    assert l1["n_item"] == l1["current"] > 0            # first lazy forward: no predecessor, its own count
+    assert l2["n_item"] == l1["current"]                # second: the PREVIOUS forward's count ...
+    assert l2["current"] == e["n_item"]                 # ... while .current() is this forward's (same rays as the eager pass)
+    assert abs(l2["loss"] - e["loss"]) <= 1e-6 * abs(e["loss"]) + 1e-9
+    assert torch.equal(l2["ri"], e["ri"]) and l2["weights"].shape == e["weights"].shape
+    assert torch.allclose(l2["weights"], e["weights"], rtol=1e-6, atol=1e-8)
+    for k in ("g1", "g2"):
+        assert float((l2[k] - e[k]).norm()) <= 2e-4 * float(e[k].norm()), (k, float((l2[k] - e[k]).norm() / e[k].norm()))
+    # anything else done to a deferred selection gathers it (the reference's behaviour)
+    sel = l2["out"]["comp_rgb"][l2["valid"]]
+    assert sel.shape == (int(l2["valid"].sum()), 3) and torch.equal(sel.detach(), l2["out"]["comp_rgb"].detach()[l2["valid"].as_subclass(torch.Tensor)])
+    assert model._runner().render_truncated == 0
+
+
+@pytest.mark.parametrize("n", [100000, 4097, 5])
+def test_encode_in_two_level_halves_equals_the_one_launch_encode(n):
+    import nsr_hip
+    from nsr_hip import check, lib, ptr, stream_ptr
+    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, 3, generator=g).cuda()
+    table = (torch.randn(gd.n_entries * 2, generator=g) * 0.1).half().cuda()
+    a = torch.full((16, n, 2), 7.0).half().cuda()
+    b = torch.full((16, n, 2), -7.0).half().cuda()
+    s = stream_ptr()
+    check(lib.nsr_hashgrid_forward_ex(ptr(x), ptr(table), ptr(a), n, 32, 1, 16, ctypes.byref(gd), None, s), "fwd")
+    for half in (1, 2):
+        check(lib.nsr_hashgrid_forward_half(ptr(x), ptr(table), ptr(b), n, 32, 1, 16, half, ctypes.byref(gd), None, s), "half")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+def test_async_trainer_with_the_pipelined_encode_matches_without():
+    """key 8 (two table-backward launches, the next encode's first level half beside the second) is scheduling only: the same
+    trajectory as without, to the run-to-run noise of the step"""
+    import nsr
+    import refmirror
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    from nsr_hip import lib
+    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
+    cfg = dict(nsr.configs.get("nerf-blender"))
+    cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
+    out = {}
+    try:
+        for on in (0, 1):
+            lib.nsr_nerf_step_variant(8, on)
+            torch.manual_seed(0)
+            model = refmirror.NeRFModel(cfg).cuda().train()
+            tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
+            losses = [float(tr.train_step()["loss"]) for _ in range(48)]
+            torch.cuda.synchronize()
+            c = tr.counters()
+            out[on] = dict(losses=losses, samples=c["samples"], truncated=c["truncated"])
+    finally:
+        lib.nsr_nerf_step_variant(8, 0)
+    a, b = out[0], out[1]
+    assert abs(a["losses"][0] - b["losses"][0]) <= 1e-5 * abs(a["losses"][0])
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) <= 3e-2 * abs(x) + 1e-6, (x, y)
+    assert b["losses"][-1] < 0.7 * b["losses"][0] and a["truncated"] == b["truncated"] == 0
+    assert abs(a["samples"] - b["samples"]) <= 0.02 * a["samples"]

@@ -16,14 +16,26 @@ adam = fetch.get("k_adamw", {}).get("avg")
 # (counters are averaged over the last dispatches of each kernel = the profiling steps bench.py's roofline refers to)
 fetch_ratio = (adam * 2 * 1024) / (16.0 * n_params) if adam else 0.5
 corr = 1.0 / fetch_ratio if 0.3 < fetch_ratio < 0.8 else 1.0
+# round 5: a stand-alone k_adamw sweep of the table calibrates the read side in the same collection (tools/fetch_calibration.sh)
+calib = None
+for q in (os.path.join(d, "fetch_calibration.json"), os.path.join(os.path.dirname(d.rstrip("/")), "fetch_calibration.json")):
+    if os.path.exists(q):
+        calib = json.load(open(q))
+        break
+if not adam and calib and calib.get("read_side_multiplier"):
+    corr, fetch_ratio = float(calib["read_side_multiplier"]), float(calib["fetch_measured_over_expected"])
 names = sorted(set(fetch) | set(write))
 ops = {"hashgrid_backward_params": [k for k in names if k.startswith(("k_own_bin", "k_grid_backward_owner", "k_grid_reduce_slabs"))],
        # whichever forward variant the library dispatched (plain / two-levels-per-lane / LDS-staged)
        "hashgrid_forward": [k for k in names if k.startswith("k_grid_forward")]}
 res = {"_unit": "HBM-side bytes per launch = (FETCH_SIZE x correction + WRITE_SIZE) x 1024, separate --pmc passes",
-       "_fetch_calibration": {"kernel": "k_adamw" if adam else None, "measured_over_expected": fetch_ratio,
+       "_fetch_calibration": {"kernel": "k_adamw" if (adam or calib) else None,
+                              "source": "in-run k_adamw dispatches" if adam else ("stand-alone sweep (tools/fetch_calibration.py: 16 B read / "
+                                        "18 B written per parameter, 12,599,920 parameters)" if calib else None),
+                              "write_measured_over_expected": (calib or {}).get("write_measured_over_expected"),
+                              "measured_over_expected": fetch_ratio,
                               "read_side_multiplier": corr,
-                              "note": None if adam else "no stand-alone k_adamw sweep in this run (AdamW on the table runs inside "
+                              "note": None if (adam or calib) else "no stand-alone k_adamw sweep in this run (AdamW on the table runs inside "
                                       "the table backward): the guide's x2 read-side correction is applied as is; the "
                                       "same-box calibration of an earlier pass measured 0.5003"},
        "_regime": regime}

@@ -21,14 +21,11 @@ model = nsr.build(cfg).to(dev).train()
 data = SyntheticBlender(n_images=int(os.environ.get("NSR_LATE_IMAGES", "100")), w=400, h=400, device=dev, seed=0)
 tr = Trainer(model, data, cfg, seed=42, async_mode=True)
 
-# name -> (variant keys 0..7, defer_pack, defer_weights_wait, rays per wave of the flat compositing, wgrad block cap)
+# name -> (variant keys 0..8, defer_pack, defer_weights_wait, rays per wave of the flat compositing, wgrad block cap)
 SETTINGS = {
-    "all_off": ((0, 0, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
-    "shipped": ((1, 0, 1, 0, 0, 1, 0, 0), True, True, 4, 128),
-    "shipped_release_device": ((1, 0, 1, 0, 0, 1, 1, 0), True, True, 4, 128),
-    "shipped_owner_first": ((1, 0, 1, 0, 0, 1, 0, 1), True, True, 4, 128),
-    "shipped_both": ((1, 0, 1, 0, 0, 1, 1, 1), True, True, 4, 128),
-    "shipped_no_ride": ((1, 0, 1, 0, 0, 0, 0, 0), True, True, 4, 128),
+    "all_off": ((0, 0, 0, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
+    "shipped": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
+    "shipped_pipelined_encode": ((1, 0, 1, 0, 0, 1, 0, 0, 1), True, True, 4, 128),
 }
 only = os.environ.get("NSR_VARIANTS")
 if only:
@@ -72,7 +69,7 @@ for r in range(rounds):
                           "kept_per_step": (c1["samples"] - c0["samples"]) / n_timed,
                           "marched_per_step": (c1["marched"] - c0["marched"]) / n_timed,
                           "loss": float(tr.last["loss"])})
-apply((1, 0, 1, 0, 0, 1, 0, 0), True, True, 4, 128)
+apply((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128)
 out = {"train_steps": n_train, "timed_steps": n_timed, "rounds": rounds, "global_step": tr.global_step,
        "settings": {k: {"ms_per_step": [round(x["ms_per_step"], 4) for x in v],
                         "host_ms_per_step": [round(x["host_ms_per_step"], 4) for x in v],
