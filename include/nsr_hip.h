@@ -290,7 +290,7 @@ int nsr_mlp_backward_phases(const void *dout, int dout_is_f32, uint32_t dout_str
  * two networks' backward workspaces where nsr_mlp_backward_phases(..., 1) puts them, so nsr_mlp_backward_phases(..., 2)
  * follows unchanged; every value is bit-identical to the two-launch sequence.  _supported: colour 32 -> 64 x (1..2) -> 3
  * sigmoid, density 32 -> 64 x (1..2) -> 16 linear.  _max_blocks: launch-size knob (0 queries), returns the previous value. */
-/* at most `blocks` workgroups per weight-gradient launch (1 .. 512, default 128 or NSR_WGRAD_MAX_BLOCKS; 0 queries); returns the
+/* at most `blocks` workgroups per weight-gradient launch (1 .. 512, default 512 or NSR_WGRAD_MAX_BLOCKS; 0 queries); returns the
  * previous cap.  Both halves of one backward must see the same value. */
 uint32_t nsr_mlp_wgrad_max_blocks(uint32_t blocks);
 int nsr_mlp_dgrad_pair_supported(const NsrMlpDesc *color, const NsrMlpDesc *density);
@@ -705,8 +705,9 @@ typedef struct NsrNerfMainLayout {
  * nsr_composite_*_flat instead of one wave per ray; key 3: the two networks' weight-gradient kernels on two helper streams
  * (with key 0); key 5: the pass's fork events ride on the kernels in front of them (hipExtLaunchKernelGGL stop event)
  * instead of being recorded behind them; key 6: the pass's events are created with hipEventReleaseToDevice; key 7: the table
- * backward is issued before the helper streams' weight-gradient launches (host order).  value < 0 queries; returns the
- * previous value (-1: unknown key). */
+ * backward is issued before the helper streams' weight-gradient launches (host order); key 9: the value is the block cap of
+ * the pass's own weight-gradient launches (nsr_mlp_wgrad_max_blocks around them only; default 128, 0 = leave the library's).
+ * value < 0 queries; returns the previous value (-1: unknown key). */
 int nsr_nerf_step_variant(int key, int value);
 /* key 4 of the above (default 0): the weight-gradient kernels of nsr_mlp_dgrad_pair's networks are queued BEHIND the table
  * backward instead of beside it, for a caller that defers its join with them (nsr_nerf_defer_wgrad_join) and hands the event

@@ -709,7 +709,7 @@ uint32_t n_params_of(const NsrMlpDesc *d) { return WIDTH * d->in_pad + (d->n_hid
 constexpr uint32_t WGRAD_CAP_MAX = 512;
 static uint32_t g_wgrad_cap = [] {
     const char *e = getenv("NSR_WGRAD_MAX_BLOCKS");
-    const uint32_t v = e ? (uint32_t)atoi(e) : 128u;  // (measured in the step: 512 -> 0.373, 256 -> 0.368, 128 -> 0.365, 64 -> 0.370, 32 -> 0.391 ms)
+    const uint32_t v = e ? (uint32_t)atoi(e) : WGRAD_CAP_MAX;  // (the NeRF step lowers it around its own launches: csrc/step.hip)
     return v < 1 ? 1u : (v > WGRAD_CAP_MAX ? WGRAD_CAP_MAX : v);
 }();
 uint32_t bwd_blocks_capped(uint32_t n, uint32_t cap)

@@ -162,7 +162,7 @@ struct HelperStream {
     }
 };
 static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
-static int g_variant[12] = {1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0};  // nsr_nerf_step_variant (below)
+static int g_variant[12] = {1, 0, 1, 0, 0, 1, 0, 0, 0, 128, 0, 0};  // nsr_nerf_step_variant (below)
 #define HEV (g_helper.ev[g_variant[6] ? 1 : 0])
 
 // the helper stream's handle (created on first use), for callers that queue follow-up work behind the weight-gradient
@@ -195,6 +195,9 @@ extern "C" int nsr_nerf_wait_kept_rows(void *stream)
 //          recorded behind them
 //   key 6: the pass's events are the set created with hipEventReleaseToDevice (device-scope release at the record)
 //   key 7: the table backward is ISSUED before the weight-gradient launches of the helper streams (host order only)
+//   key 9: block cap of the pass's weight-gradient launches (nsr_mlp_wgrad_max_blocks, set around the pass's own launches only;
+//          default 128 -- measured in the step: 512 -> 0.373, 256 -> 0.368, 128 -> 0.365, 64 -> 0.370, 32 -> 0.391 ms: with the
+//          join deferred to the next density MLP fewer 64 KB-LDS blocks leave the table backward more of the chip; 0 = leave it)
 //   key 8: the table backward (with AdamW inside) as TWO launches, levels [0, 8) then [8, 16), and the NEXT pruning pass's encode
 //          as two halves: levels [0, 8) on a helper stream as soon as the first launch has retired -- beside the second --, levels
 //          [8, 16) on the step's stream; needs nsr_nerf_set_inputs_event (the next step's positions come from another stream)
@@ -652,6 +655,14 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // ends behind the table backward instead of underneath it.  So: one fork per network; NSR_WGRAD_ONE_FORK for A/B.
     static const bool two_forks = getenv("NSR_WGRAD_ONE_FORK") == nullptr;
     g_ht.mark(5);
+    // (the weight-gradient block cap is a library-wide knob other callers -- the NeuS steps, the drop-in tcnn modules -- leave at
+    // its default: lowered for this pass's launches only, restored on every way out)
+    struct WgradCap {
+        uint32_t old = 0;
+        bool set = false;
+        explicit WgradCap(int cap) { if (cap > 0) { old = nsr_mlp_wgrad_max_blocks((uint32_t)cap); set = true; } }
+        ~WgradCap() { if (set) (void)nsr_mlp_wgrad_max_blocks(old); }
+    } wgrad_cap(wg && g_defer_wgrad_join ? g_variant[9] : 0);
     const bool pair = g_variant[0] && nsr_mlp_dgrad_pair_supported(&d->mlp_color, &d->mlp_density) && C == 32;
     bool dgrad_event = false;  // HEV.dgrad_done recorded behind the last data-gradient kernel
     bool late_wgrad = false, wgrads_after_issue = false;

@@ -304,7 +304,7 @@ def multistep_lr_scale(step, milestones=(10000, 15000, 18000), gamma=0.33):
 # The forms of the asynchronous NeRF step (csrc/step.hip nsr_nerf_step_variant keys 0..5 + the host-side switches), for
 # same-process A/B runs: bench.py's `step_forms_ab` block and tools/step_variants.py run windows of steps under each
 ROUND5_FORMS = dict(keys=(1, 0, 1, 0, 0, 1), defer_pack=True, defer_weights_wait=True, flat_rays_per_wave=4, wgrad_max_blocks=128)
-ROUND4_FORMS = dict(keys=(0, 0, 0, 0, 0, 0), defer_pack=False, defer_weights_wait=False, flat_rays_per_wave=4, wgrad_max_blocks=512)
+ROUND4_FORMS = dict(keys=(0, 0, 0, 0, 0, 0), defer_pack=False, defer_weights_wait=False, flat_rays_per_wave=4, wgrad_max_blocks=0)
 
 
 def set_step_forms(trainer, forms):
@@ -314,7 +314,7 @@ def set_step_forms(trainer, forms):
     for k, v in enumerate(forms["keys"]):
         _lib.nsr_nerf_step_variant(k, int(v))
     _lib.nsr_composite_flat_rays_per_wave(int(forms["flat_rays_per_wave"]))
-    _lib.nsr_mlp_wgrad_max_blocks(int(forms["wgrad_max_blocks"]))
+    _lib.nsr_nerf_step_variant(9, int(forms["wgrad_max_blocks"]))  # (0: the pass leaves the library's cap of 512 alone)
     trainer.fused.defer_pack = bool(forms["defer_pack"])
     trainer.defer_weights_wait = bool(forms["defer_weights_wait"])
 

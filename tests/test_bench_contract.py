@@ -40,3 +40,24 @@ def test_default_command_line_times_the_operating_point():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"--setup-steps", type=int, default=300' in src and '"--burn-in-steps", type=int, default=1500' in src
     assert '"--gpus", type=int, default=1' in src and "burn_in_steps_of_a_throwaway_model" in src
+
+
+def test_round5_blocks_are_on_the_line():
+    """the driver's line carries the whole 20,000-step run (seconds, samples/s, PSNR) and the late regime, and the
+    same-process A/B of the step's forms; the traffic figure comes from this round's PMC passes when they exist"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"whole_run": whole', '"late_regime": late', '"step_forms_ab": forms_ab', '"--whole-run-steps", type=int, default=20000',
+                '"test_psnr"', '"at_step": late_at'):
+        assert key in src, key
+    assert src.index('"r05_pmc_traffic.json"') < src.index('"r04_pmc_traffic.json"')
+    cal = os.path.join(ROOT, "profiles", "r05_fetch_calibration.json")
+    if os.path.exists(cal):  # the stand-alone k_adamw sweep: FETCH_SIZE under-reports by 2 on gfx950, WRITE_SIZE is exact
+        c = json.load(open(cal))
+        assert abs(c["fetch_measured_over_expected"] - 0.5) < 0.02 and abs(c["write_measured_over_expected"] - 1.0) < 0.03
+
+
+def test_step_forms_are_named_in_one_place():
+    """the forms bench.py's A/B switches between are the trainer module's (no second copy of the key tuples)"""
+    src = open(os.path.join(ROOT, "instant-nsr-pl_amd", "nsr", "trainer.py")).read()
+    assert "ROUND5_FORMS = dict(keys=(1, 0, 1, 0, 0, 1)" in src and "ROUND4_FORMS = dict(keys=(0, 0, 0, 0, 0, 0)" in src
+    assert "from nsr.trainer import ROUND4_FORMS, ROUND5_FORMS, set_step_forms" in open(os.path.join(ROOT, "bench.py")).read()

@@ -22,11 +22,20 @@ data = SyntheticBlender(n_images=int(os.environ.get("NSR_LATE_IMAGES", "100")), 
 tr = Trainer(model, data, cfg, seed=42, async_mode=True)
 
 # name -> (variant keys 0..8, defer_pack, defer_weights_wait, rays per wave of the flat compositing, wgrad block cap)
+# keys: 0 pair dgrad, 1 dense levels through atomics, 2 flat compositing, 3 two wgrad streams, 4 wgrads behind the table backward,
+#       5 fork events ride on kernels, 6 events with a device-scope release, 7 table backward issued first, 8 pipelined half encodes
 SETTINGS = {
-    "all_off": ((0, 0, 0, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
-    "shipped": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
-    "shipped_pipelined_encode": ((1, 0, 1, 0, 0, 1, 0, 0, 1), True, True, 4, 128),
+    "round4_forms": ((0, 0, 0, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
+    "pair_only": ((1, 0, 0, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
+    "flat_only": ((0, 0, 1, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
+    "defer_pack_only": ((0, 0, 0, 0, 0, 0, 0, 0, 0), True, False, 4, 512),
+    "defer_weights_only": ((0, 0, 0, 0, 0, 0, 0, 0, 0), False, True, 4, 512),
+    "round5_forms": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
+    "round5_without_pair": ((0, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
+    "round5_plus_dense_atomics": ((1, 1, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
+    "round5_plus_pipelined_encode": ((1, 0, 1, 0, 0, 1, 0, 0, 1), True, True, 4, 128),
 }
+HOST_DELAY = float(os.environ.get("NSR_HOST_DELAY_US", "0")) * 1e-6
 only = os.environ.get("NSR_VARIANTS")
 if only:
     SETTINGS = {k: v for k, v in SETTINGS.items() if k in only.split(",")}
@@ -35,7 +44,7 @@ if only:
 def apply(keys, defer, defer_w, rpw, cap=512):
     tr.settle()
     torch.cuda.synchronize()
-    lib.nsr_mlp_wgrad_max_blocks(cap)
+    lib.nsr_nerf_step_variant(9, 0 if cap >= 512 else cap)
     for k, v in enumerate(keys):
         lib.nsr_nerf_step_variant(k, v)
     lib.nsr_composite_flat_rays_per_wave(rpw)
@@ -61,6 +70,10 @@ for r in range(rounds):
         t0 = time.perf_counter()
         for _ in range(n_timed):
             tr.train_step()
+            if HOST_DELAY > 0:  # (experiment: is the step's critical path coupled to the host's enqueue time?)
+                td = time.perf_counter() + HOST_DELAY
+                while time.perf_counter() < td:
+                    pass
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
