@@ -152,13 +152,20 @@ struct HelperStream {
     {
         if (ok) return true;
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking) != hipSuccess) return false;
+        // (stream_b / stream_c only when a form that uses them is switched on -- need_extra(): HIP maps streams to a pool of 4
+        // hardware queues; streams nobody uses must not shift which queue the step's three working streams get)
         for (int k = 0; k < 2; ++k)
             for (hipEvent_t *e : {&ev[k].fork, &ev[k].join, &ev[k].join_wgrad, &ev[k].fork_wgrad, &ev[k].dgrad_done,
                                   &ev[k].wgrad_b_done, &ev[k].dense_done, &ev[k].table_a_done, &ev[k].enc_a_done})
                 if (hipEventCreateWithFlags(e, hipEventDisableTiming | (k ? hipEventReleaseToDevice : 0u)) != hipSuccess) return false;
         return ok = true;
+    }
+    bool need_extra()
+    {
+        if (!init()) return false;
+        if (!stream_b && hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking) != hipSuccess) return false;
+        if (!stream_c && hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking) != hipSuccess) return false;
+        return true;
     }
 };
 static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
@@ -325,7 +332,7 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
         // (only when the positions were written AHEAD of the pass, on the caller's marching stream: formed inside this pass they
         // exist on `stream` alone, and the helper stream's half would race with the kernel that writes them)
         const bool split_encode = g_variant[8] && g_table_a_pending && g_inputs_event && x01_marched && d->grid.n_levels == 16 &&
-                                  g_helper.init();
+                                  g_helper.need_extra();
         hipEvent_t inputs_event = g_inputs_event;
         g_table_a_pending = false;
         g_inputs_event = nullptr;
@@ -497,7 +504,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     const bool l1_folded = phases == 3 && compute_grads && gt_rgb && !up && S > 0 && n_rays > 0 && !l1_separate;
     // round-5 forms (nsr_nerf_step_variant): the dense levels of the table backward on their own stream, flat compositing
     const uint32_t n_dense = nsr_hashgrid_dense_levels(&d->grid);
-    const bool use_dense = g_variant[1] && overlap_bins && !xchg && n_dense > 0 && n_dense < Lv;
+    const bool use_dense = g_variant[1] && overlap_bins && !xchg && n_dense > 0 && n_dense < Lv && g_helper.need_extra();
     const bool flat = g_variant[2] != 0;
     // (a stream that is being captured into a graph takes plain launches + event records only)
     hipStreamCaptureStatus capture_status = hipStreamCaptureStatusNone;
@@ -674,7 +681,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                             hipStreamWaitEvent(g_helper.stream, fork, 0) == hipSuccess,
                         "nsr_nerf_main_pass: weight-gradient fork failed");
             if (recorded) *recorded = true;
-            if (g_variant[3]) {  // the density network's weight-gradient kernels beside the colour network's
+            if (g_variant[3] && g_helper.need_extra()) {  // the density network's weight-gradient kernels beside the colour network's
                 wg_d = (void *)g_helper.stream_b;
                 NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_b, fork, 0) == hipSuccess,
                             "nsr_nerf_main_pass: weight-gradient fork failed");

@@ -21,6 +21,7 @@ import torch
 
 from nerfacc import ContractionType
 from nsr_hip import NsrAdamSegment, NsrVanillaLayer, NsrVmlpDesc, check, lib, ptr, stream_ptr
+from nsr_hip import shared_stream as _shared_stream
 from nsr_hip import ops as _ops
 
 # layout of the encoded features between the encode and the fp32 MLP kernels of a step: 2 = tile-major (default),
@@ -447,7 +448,7 @@ class FusedNeuSStep:
         """run ``fn(stream_ptr)`` on the helper stream behind everything queued so far; -> completion event"""
         dev = tensors[0].device
         if getattr(self, "_helper", None) is None:
-            self._helper = torch.cuda.Stream(device=dev)
+            self._helper = _shared_stream(dev, "helper")
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self._helper.wait_event(ready)
@@ -775,7 +776,7 @@ class FusedNeuSStep:
                 nws = int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), T * N))
                 gws = torch.empty(nws, dtype=F32, device=dev)
                 if getattr(self, "_helper", None) is None:
-                    self._helper = torch.cuda.Stream(device=dev)
+                    self._helper = _shared_stream(dev, "helper")
                 if self.fd and self.fold_taps:  # in-cell taps are folded into their sample's items (stencil mode)
                     tws = torch.empty(int(lib.nsr_hashgrid_backward_params_taps_workspace_floats(_byref(desc), N)), dtype=F32,
                                       device=dev)
@@ -1233,7 +1234,7 @@ class NeuSTrainer:
             # step's encode / networks / backward -- unless the next step refreshes the grid first
             if cfg["grid_prune"] and (t + 1) % 16 != 0:
                 if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
+                    self._side = _shared_stream(self.device, "side")
                 ev = torch.cuda.Event()
                 ev.record(main)
                 self._side.wait_event(ev)

@@ -349,7 +349,8 @@ class ShardedAdamW:
         main = torch.cuda.current_stream() if cuda else None
         if overlap:
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=self.modules[0].params.device)
+                from nsr_hip import shared_stream as _shared_stream
+                self._comm = _shared_stream(self.modules[0].params.device, "comm")
             comm = self._comm
             now = torch.cuda.Event()
             now.record(main)

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 import tinycudann as tcnn
 from nsr_hip import ops as _ops
-from nsr_hip import check as _check, lib as _lib, ptr as _ptr, stream_ptr as _stream_ptr
+from nsr_hip import check as _check, lib as _lib, ptr as _ptr, shared_stream as _shared_stream, stream_ptr as _stream_ptr
 
 from .parallel import ShardedAdamW, all_reduce_gradients, broadcast_parameters, shard_seed, sync_occupancy_grid
 
@@ -121,6 +121,14 @@ class FusedAdamW:
         step_dev, hyper = self._device_schedule_state()
         p = module.params
         exp_avg, exp_avg_sq, shadow = self.state[p]
+        # (built once per half of the schedule's double buffer: a ctypes struct per step is host time the asynchronous step
+        # does not have -- its host and GPU times are within 15 % of each other)
+        ck = (id(module), self._cur, tuple(milestones), gamma, lr, p.data_ptr(), exp_avg.data_ptr(), shadow.data_ptr())
+        cache = self.__dict__.setdefault("_table_desc_cache", {})
+        if ck in cache:
+            return cache[ck]
+        if len(cache) > 8:
+            cache.clear()
         n0 = int(getattr(module, "n_network_params", 0))  # (a bare tcnn.Encoding: the table is the whole vector)
         ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
         d = NsrTableAdam()
@@ -132,6 +140,7 @@ class FusedAdamW:
         d.beta1, d.beta2, d.gamma = float(self.betas[0]), float(self.betas[1]), float(gamma)
         d.milestone0, d.milestone1, d.milestone2 = ms
         d.eps, d.weight_decay = float(self.eps), float(self.wd)
+        cache[ck] = d
         return d
 
     def step_device(self, milestones=(10000, 15000, 18000), gamma=0.33, skip_table_of=None, other_stream_reads=False,
@@ -146,6 +155,34 @@ class FusedAdamW:
             # the table of ``skip_table_of`` was updated inside its backward (table_update_desc): what is left are the MLP
             # weights in front of it and the other module -- one launch, which also advances the schedule
             m0, n0 = skip_table_of, int(skip_table_of.n_network_params)
+            if other_stream_reads and stream is not None and m0.params.grad is not None:
+                # the asynchronous step's launch, with its arguments resolved once per half of the schedule's double buffer
+                ck = (id(m0), self._cur, m0.params.data_ptr(), m0.params.grad.data_ptr(), tuple(milestones), gamma)
+                cache = self.__dict__.setdefault("_step_args_cache", {})
+                args = cache.get(ck)
+                if args is None:
+                    if len(cache) > 8:
+                        cache.clear()
+                    rest = [m for m in self.tcnn_modules if m is not m0]
+                    assert len(rest) <= 1 and n0 > 0 and n0 % 4 == 0 and all(m.params.grad is not None for m in rest)
+                    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+                    a = (m0.params.data, m0.params.grad) + tuple(self.state[m0.params])
+                    ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
+                    if rest:
+                        b = (rest[0].params.data, rest[0].params.grad) + tuple(self.state[rest[0].params])
+                        bargs = tuple(P(t) for t in b) + (b[0].numel(),)
+                    else:
+                        bargs = (None,) * 5 + (0,)
+                    args = cache[ck] = (tuple(P(t) for t in a) + (n0, 0) + bargs +
+                                        (P(self._step_bufs[self._cur]), P(self._hyper_bufs[self._cur]),
+                                         P(self._step_bufs[self._cur ^ 1]), P(self._hyper_bufs[self._cur ^ 1]),
+                                         float(self.lr), float(self.betas[0]), float(self.betas[1]), float(gamma), ms[0], ms[1], ms[2],
+                                         float(self.eps), float(self.wd), 1.0, 1), rest)
+                _check(_lib.nsr_adamw_step_scheduled_to(*args[0], stream), "nsr_adamw_step_scheduled")
+                self._cur ^= 1
+                for m in self.tcnn_modules:
+                    m.adopt_shadow(self.state[m.params][2])
+                return
             rest = [m for m in self.tcnn_modules if m is not m0]
             assert len(rest) <= 1 and n0 > 0 and n0 % 4 == 0
             segs = [tuple(t[:n0] for t in (m0.params.data, m0.params.grad) + tuple(self.state[m0.params])) + (0,)]
@@ -563,7 +600,7 @@ class Trainer:
                 return
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                self._side = _shared_stream(self.device, "side")
             ev = torch.cuda.Event()
             ev.record(main)             # covers everything up to the pruning pass + count update of THIS step --
             self._side.wait_event(ev)   # not its main pass / backward / optimizer, which are queued later
@@ -689,7 +726,7 @@ class Trainer:
         _ops.grid_bricks(model.occupancy_grid.binary, out=a["bricks"])  # re-packed in place after a grid refresh
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _shared_stream(self.device, "side")
         side = self._side
         if a.get("bricks_event") is None or (cfg["grid_prune"] and t % 16 == 0):
             a["bricks_event"] = torch.cuda.Event()
@@ -700,6 +737,13 @@ class Trainer:
             a["marched_upto"] = a["packed_upto"] = t - 1
         sets, ev = a["sets3"], a["events"]
         stats_m, stats_s = a["stats"][0:8], a["stats"][8:16]
+        ring = a.get("event_ring")
+        if ring is None:  # (torch events are re-used: an entry of ``ev`` lives for at most 3 steps, creating one costs microseconds)
+            ring = a["event_ring"] = [[torch.cuda.Event() for _ in range(16)], 0]
+
+        def new_event():
+            ring[1] = (ring[1] + 1) & 15
+            return ring[0][ring[1]]
         refresh = lambda u: bool(cfg["grid_prune"]) and u % 16 == 0  # step u marches through a grid refreshed at its start
 
         def queue_march(u0, u1, stream):
@@ -730,7 +774,7 @@ class Trainer:
             fused.pack_async(sets[u % W], a["n_rays"], a["m_cap"], stats_m, stream=sp)
             if stream is not main and not self._write_inline:  # ... and the sample arrays + positions, off the step's own chain
                 fused.write_async(sets[u % W], consumer_stream=main, stream=sp, writer_stream=stream)
-            e = torch.cuda.Event()
+            e = new_event()
             e.record(stream)
             ev[("pack", u)] = e
             a["packed_upto"] = u
@@ -771,7 +815,7 @@ class Trainer:
                                              int(self.train_num_samples) if dynamic else 0,
                                              int(cfg["max_train_num_rays"]), _ptr(a["rays_accum"]), sp),
                    "nsr_update_ray_count")
-            e2 = torch.cuda.Event()
+            e2 = new_event()
             e2.record(stream)
             ev[("prune", t)] = e2  # "the ray count of step t + 1 is final"
             if self.pipeline_march and a["marched_upto"] >= t + 1 and a["packed_upto"] < t + 1:
@@ -895,7 +939,7 @@ class Trainer:
             if not launch_next:
                 return
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                self._side = _shared_stream(self.device, "side")
             # (always an event recorded HERE, behind the ray-count update queued above on the main stream -- an event
             # recorded right behind the pruning pass would let the side stream's marching read the count before it is updated)
             _pruned = torch.cuda.Event()

@@ -358,6 +358,24 @@ def device_guard(dev):
     return torch.cuda.device(idx)
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_stream(device, role):
+    """ONE torch stream per (device, role) for the whole process ("side": the trainers' marching stream, "helper": the NeuS
+    runner's helper stream, "comm": the gradient exchange's).  HIP maps streams to a small pool of hardware queues (4 by
+    default) in the order they are first used; every trainer object used to create its own side stream, so the SECOND trainer of
+    a process (bench.py: the measured model behind its burn-in model) could land on the hardware queue of the step's own stream
+    and serialise with it -- measured as two modes of the same step, 8 % apart, depending on how many trainers a process had
+    built before (tools/forms_regime_ab.py).  With process-wide streams the mapping is the same for every trainer."""
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
+    s = _SHARED_STREAMS.get(key)
+    if s is None:
+        s = _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def ptr(t):
     """device pointer of a contiguous GPU tensor (None -> NULL)"""
     if t is None:

@@ -34,6 +34,10 @@ SETTINGS = {
     "round5_without_pair": ((0, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
     "round5_plus_dense_atomics": ((1, 1, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
     "round5_plus_pipelined_encode": ((1, 0, 1, 0, 0, 1, 0, 0, 1), True, True, 4, 128),
+    "round5_cap256": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 256),
+    "round5_cap512": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 512),
+    "round5_without_pair_cap512": ((0, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 512),
+    "round5_two_wgrad_streams_cap512": ((1, 0, 1, 1, 0, 1, 0, 0, 0), True, True, 4, 512),
 }
 HOST_DELAY = float(os.environ.get("NSR_HOST_DELAY_US", "0")) * 1e-6
 only = os.environ.get("NSR_VARIANTS")
