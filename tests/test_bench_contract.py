@@ -20,12 +20,16 @@ def _bench():
 
 def test_committed_pmc_passes_cover_both_command_lines():
     bench = _bench()
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+    name = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))  # (bench.py takes the newest round's passes)
     assert {"w20_s200", "w5_s20"} <= set(pmc["regimes"])
     for key, (w, s) in {"w20_s200": (20, 200), "w5_s20": (5, 20)}.items():
         ent = pmc["regimes"][key]["hashgrid_backward_params"]
         got, src = bench.pmc_traffic("hashgrid_backward_params", ent["samples_per_launch"], w, s)
-        assert got == ent["bytes_per_launch"] and "r04_pmc_traffic.json" in src
+        assert got == ent["bytes_per_launch"] and name in src
+        if name.startswith("r05"):  # the read side is calibrated by a stand-alone sweep of the same collection (VERDICT r4 #2a)
+            cal = pmc["regimes"][key]["_fetch_calibration"]
+            assert cal["kernel"] == "k_adamw" and abs(cal["measured_over_expected"] - 0.5) < 0.02
         # measured traffic can only exceed what the operation must move (140 B / sample + 26 B / table parameter)
         algorithmic = 140.0 * ent["samples_per_launch"] + 26.0 * 12599920
         assert algorithmic < got < 2.0 * algorithmic

@@ -10,8 +10,8 @@ cd /root/repo
 bash tools/fetch_calibration.sh "$out/fetch_calibration.json" > /dev/null 2>&1
 python bench.py > "$out/bench_w20_s200.json" 2> "$out/bench_w20_s200.stderr"; tail -c 300 "$out/bench_w20_s200.json"; echo
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_w5_s20.json" 2> "$out/bench_w5_s20.stderr"; tail -c 200 "$out/bench_w5_s20.json"; echo
-LEAN="--no-cpu-baseline --no-other-workloads --no-boundary-path"
-export NSR_BENCH_NO_STEADY=1
+LEAN="--no-cpu-baseline --no-other-workloads --no-boundary-path --no-whole-run"
+export NSR_BENCH_NO_STEADY=1 NSR_BENCH_NO_FORMS_AB=1
 cd /tmp && export TMPDIR=/tmp
 for regime in "20 200" "5 20"; do
   set -- $regime; w=$1; st=$2
@@ -44,7 +44,7 @@ json.dump({"_what": "HBM-side traffic per launch from rocprofv3 --pmc FETCH_SIZE
                     "(warmup, steps) command line; see tools/pmc_traffic.py", "regimes": regimes},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 PY
-unset NSR_BENCH_NO_STEADY
+unset NSR_BENCH_NO_STEADY NSR_BENCH_NO_FORMS_AB
 # the three NeuS workloads at the reference's operating point through NeuSTrainer (dynamic ray count -> 2^18 samples / step)
 for c in neus-blender neus-dtu neuralangelo; do
   python /root/repo/tools/neus_operating_point.py $c 100 2>/dev/null | tail -1 > "$out/neus_op_$c.json"
