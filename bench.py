@@ -262,7 +262,7 @@ def other_workloads(dev, rank=0, world=1, sync=None, n_steps=60):
     return out
 
 
-def boundary_path(dev, warmup=300, steps=200):
+def boundary_path(dev, warmup=300, steps=200, late_at=3000, late_steps=200):
     """The same training step driven THROUGH THE DROP-IN BOUNDARY the way the reference's system drives its model
     (systems/nerf.py:33-99, systems/base.py:54-57): torch ray sampling -> model.update_step -> out = model(rays) ->
     dynamic ray count from out['num_samples'] -> smooth-L1 on the valid rays in torch -> loss.backward() ->
@@ -288,11 +288,19 @@ def boundary_path(dev, warmup=300, steps=200):
     train_num_rays = cfg["train_num_rays"]
     target = cfg["train_num_rays"] * cfg["num_samples_per_ray"]
     n_samples = n_rays = 0
-    t0 = None
-    for step in range(warmup + steps):
+    t0 = dt = None
+    late = {"samples": 0, "rays": 0, "t0": None}
+    for step in range(max(warmup + steps, late_at + late_steps if late_steps else 0)):
         if step == warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+        if step == warmup + steps:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            first_loss = float(loss.detach())
+        if late_steps and step == late_at:
+            torch.cuda.synchronize()
+            late["t0"] = time.perf_counter()
         rays, rgb, fg, bg = data.sample_rays(train_num_rays, gen, cfg["background_color"])  # preprocess_data
         model.background_color = bg
         model.update_step(0, step)                                                           # on_train_batch_start
@@ -307,16 +315,29 @@ def boundary_path(dev, warmup=300, steps=200):
         loss.backward()
         opt.step()
         sched.step()
-        if step >= warmup:
+        if warmup <= step < warmup + steps:
             n_samples += n
             n_rays += rays.shape[0]
+        if late["t0"] is not None:
+            late["samples"] += n
+            late["rays"] += rays.shape[0]
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"samples_per_sec": n_samples / dt, "ms_per_step": 1e3 * dt / steps, "train_rays_per_sec": n_rays / dt,
-            "kept_samples_per_step": n_samples / steps, "rays_per_step": n_rays / steps, "final_loss": float(loss.detach()),
-            "warmup": warmup, "steps": steps, "optimizer": opt_kind, "model": "nsr.models.FusedNeRFModel",
-            "what": "reference-style step through the model interface: torch ray sampling, model.update_step, model(rays), "
-                    ".item() on num_samples, torch smooth-L1 on boolean-masked rays, loss.backward(), torch AdamW, MultiStepLR"}
+    t_end = time.perf_counter()
+    if dt is None:
+        dt, first_loss = t_end - t0, float(loss.detach())
+    res = {"samples_per_sec": n_samples / dt, "ms_per_step": 1e3 * dt / steps, "train_rays_per_sec": n_rays / dt,
+           "kept_samples_per_step": n_samples / steps, "rays_per_step": n_rays / steps, "final_loss": first_loss,
+           "warmup": warmup, "steps": steps, "optimizer": opt_kind, "model": "nsr.models.FusedNeRFModel",
+           "lazy_outputs": bool(getattr(model, "lazy_outputs", False)),
+           "what": "reference-style step through the model interface: torch ray sampling, model.update_step, model(rays), "
+                   ".item() on num_samples, torch smooth-L1 on boolean-masked rays, loss.backward(), torch AdamW, MultiStepLR"}
+    if late["t0"] is not None:
+        dl = t_end - late["t0"]
+        res["late"] = {"at_step": late_at, "timed_steps": late_steps, "ms_per_step": 1e3 * dl / late_steps,
+                       "samples_per_sec": late["samples"] / dl, "kept_samples_per_step": late["samples"] / late_steps,
+                       "rays_per_step": late["rays"] / late_steps, "final_loss": float(loss.detach()),
+                       "note": "the same loop run on to a pruned grid: where the entry's removed host waits show (DESIGN 5.1b)"}
+    return res
 
 
 def modular_path(dev, warmup=60, steps=100):

@@ -1086,6 +1086,21 @@ int nsr_bg_composite_backward(const int32_t *packed_info, const float *out16, fl
 int nsr_bg_join_gradients(const float *d_logit, const float *d_tex_in, uint32_t stride, uint32_t n_feat, float *d_out16,
                           uint32_t n, const int32_t *n_dev, void *stream);
 
+/* ---- masked mean losses of the systems' training steps (reference systems/nerf.py:97 `F.smooth_l1_loss(out['comp_rgb'][
+ * out['rays_valid'][...,0]], batch['rgb'][out['rays_valid'][...,0]])`, systems/neus.py:98,102 `F.mse_loss` / `F.l1_loss` over
+ * `rays_valid_full`): mean over the rows with mask != 0 WITHOUT the boolean-mask gathers (torch: a nonzero + a host
+ * synchronisation each).  pred / target [n_rows][channels] fp32, mask [n_rows] bytes (a torch.bool tensor).
+ * kind 0 smooth-L1 (beta), 1 MSE, 2 L1, 3 Huber (delta = beta): torch.nn.functional semantics, reduction "mean".
+ * out [nsr_masked_loss_out_floats()]: out[0] = loss (0 when no row is valid -- torch returns NaN there), out[1] = number of
+ * selected elements, the rest = per-workgroup partial sums, added by one wave in index order: bit-reproducible.
+ * backward: d_pred = *grad_out * d loss / d pred (0 in masked-out rows); forward_out = the forward's `out`. ---- */
+uint32_t nsr_masked_loss_out_floats(void);
+int nsr_masked_loss_forward(const float *pred, const float *target, const uint8_t *mask, uint32_t n_rows, uint32_t channels,
+                            int kind, float beta, float *out, void *stream);
+int nsr_masked_loss_backward(const float *pred, const float *target, const uint8_t *mask, uint32_t n_rows, uint32_t channels,
+                             int kind, float beta, const float *forward_out, const float *grad_out, float *d_pred,
+                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

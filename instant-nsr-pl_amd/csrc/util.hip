@@ -391,6 +391,100 @@ k_adamw_multi(const AdamMulti t, float b1, float b2, float eps, float wd, float 
     }
 }
 
+
+// ---- masked mean losses of the reference's systems (systems/nerf.py:97 smooth-L1, systems/neus.py:98,102 MSE / L1 over
+// `x[rays_valid[..., 0]]` pairs): the boolean-mask gathers (a nonzero + a host synchronisation each in torch) never happen --
+// per-block partial sums + one wave that adds them in index order (bit-reproducible), one elementwise kernel for d loss / d pred.  kind: 0 smooth-L1(beta), 1 MSE, 2 L1, 3 Huber(delta = beta) -- torch.nn.functional semantics.
+constexpr uint32_t ML_MAX_BLOCKS = 256;
+
+__device__ __forceinline__ float masked_loss_value(float d, int kind, float beta)
+{
+    const float a = fabsf(d);
+    switch (kind) {
+    case 0: return (beta > 0.f && a < beta) ? 0.5f * d * d / beta : a - 0.5f * beta;
+    case 1: return d * d;
+    case 2: return a;
+    default: return a <= beta ? 0.5f * d * d : beta * (a - 0.5f * beta);
+    }
+}
+
+__device__ __forceinline__ float masked_loss_slope(float d, int kind, float beta)
+{
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    const float a = fabsf(d);
+    switch (kind) {
+    case 0: return (beta > 0.f && a < beta) ? d / beta : sg;
+    case 1: return 2.f * d;
+    case 2: return sg;
+    default: return a <= beta ? d : beta * sg;
+    }
+}
+
+// partial sums: block b owns the elements [b, b + 1) * ML_CHUNK ..., 8 per thread and pass, loads issued unconditionally (a
+// branch on the mask would put two dependent memory round trips into every pass); the partials are summed by ONE wave in index
+// order (k_masked_loss_finish), so the result does not depend on which block finished first.
+__global__ void __launch_bounds__(EW_BLOCK)
+k_masked_loss_partials(const float *__restrict__ pred, const float *__restrict__ target, const uint8_t *__restrict__ mask,
+                       uint32_t n_rows, uint32_t channels, int kind, float beta, float *__restrict__ partials)
+{
+    __shared__ float s_sum[EW_BLOCK / NSR_WAVE], s_cnt[EW_BLOCK / NSR_WAVE];
+    const uint32_t n = n_rows * channels;
+    float sum = 0.f, cnt = 0.f;
+    for (uint32_t base = blockIdx.x * (EW_BLOCK * 8); base < n; base += gridDim.x * (EW_BLOCK * 8)) {
+        float p[8], t[8];
+        uint8_t m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * EW_BLOCK + threadIdx.x;
+            const bool in = i < n;
+            const uint32_t j = in ? i : 0u;
+            p[k] = pred[j];
+            t[k] = target[j];
+            m[k] = in ? mask[j / channels] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (m[k]) { sum += masked_loss_value(p[k] - t[k], kind, beta); cnt += 1.f; }
+    }
+    sum = wave_sum(sum);
+    cnt = wave_sum(cnt);
+    const int w = threadIdx.x / NSR_WAVE;
+    if ((threadIdx.x & (NSR_WAVE - 1)) == 0) { s_sum[w] = sum; s_cnt[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.f, tc = 0.f;
+        for (int k = 0; k < EW_BLOCK / NSR_WAVE; ++k) { ts += s_sum[k]; tc += s_cnt[k]; }
+        partials[2 * blockIdx.x] = ts;
+        partials[2 * blockIdx.x + 1] = tc;
+    }
+}
+
+__global__ void __launch_bounds__(NSR_WAVE)
+k_masked_loss_finish(const float *__restrict__ partials, uint32_t n_blocks, float *__restrict__ out)
+{
+    float ts = 0.f, tc = 0.f;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += NSR_WAVE) { ts += partials[2 * b]; tc += partials[2 * b + 1]; }
+    ts = wave_sum(ts);
+    tc = wave_sum(tc);
+    if (threadIdx.x == 0) {
+        out[0] = tc > 0.f ? ts / tc : 0.f;  // (no valid row: 0 -- torch's mean over an empty selection is NaN)
+        out[1] = tc;
+    }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_masked_loss_backward(const float *__restrict__ pred, const float *__restrict__ target, const uint8_t *__restrict__ mask,
+                       uint32_t n_rows, uint32_t channels, int kind, float beta, const float *__restrict__ fwd_out,
+                       const float *__restrict__ grad_out, float *__restrict__ d_pred)
+{
+    const uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (i >= n_rows * channels) return;
+    const float cnt = fwd_out[1];
+    float g = 0.f;
+    if (cnt > 0.f && mask[i / channels]) g = *grad_out * masked_loss_slope(pred[i] - target[i], kind, beta) / cnt;
+    d_pred[i] = g;
+}
+
 }  // namespace
 
 extern "C" int nsr_sh4_forward(const float *u, nsr_half *y, uint32_t n, uint32_t y_stride, void *stream)
@@ -587,5 +681,38 @@ extern "C" int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segmen
     hipLaunchKernelGGL(k_adamw_multi, dim3(bx, n_segments), dim3(EW_BLOCK), 0, (hipStream_t)stream, t, beta1, beta2, eps,
                        weight_decay, bias_correction1, bias_correction2, zero_grad);
     NSR_CHECK_LAUNCH("nsr_adamw_multi");
+    return NSR_OK;
+}
+
+extern "C" uint32_t nsr_masked_loss_out_floats(void) { return 2 + 2 * ML_MAX_BLOCKS; }
+
+extern "C" int nsr_masked_loss_forward(const float *pred, const float *target, const uint8_t *mask, uint32_t n_rows,
+                                       uint32_t channels, int kind, float beta, float *out, void *stream)
+{
+    NSR_REQUIRE(out, "nsr_masked_loss_forward: NULL output");
+    NSR_REQUIRE(kind >= 0 && kind <= 3, "nsr_masked_loss_forward: kind %d (0 smooth-L1, 1 MSE, 2 L1, 3 Huber)", kind);
+    NSR_REQUIRE(channels >= 1 && (uint64_t)n_rows * channels < (1ull << 32), "nsr_masked_loss_forward: bad shape");
+    NSR_REQUIRE(n_rows == 0 || (pred && target && mask), "nsr_masked_loss_forward: NULL pointer");
+    uint32_t nb = nsr_div_up((uint64_t)n_rows * channels, EW_BLOCK * 8);
+    if (nb > ML_MAX_BLOCKS) nb = ML_MAX_BLOCKS;
+    if (nb > 0)
+        hipLaunchKernelGGL(k_masked_loss_partials, dim3(nb), dim3(EW_BLOCK), 0, (hipStream_t)stream, pred, target, mask, n_rows,
+                           channels, kind, beta, out + 2);
+    hipLaunchKernelGGL(k_masked_loss_finish, dim3(1), dim3(NSR_WAVE), 0, (hipStream_t)stream, out + 2, nb, out);
+    NSR_CHECK_LAUNCH("nsr_masked_loss_forward");
+    return NSR_OK;
+}
+
+extern "C" int nsr_masked_loss_backward(const float *pred, const float *target, const uint8_t *mask, uint32_t n_rows,
+                                        uint32_t channels, int kind, float beta, const float *forward_out,
+                                        const float *grad_out, float *d_pred, void *stream)
+{
+    NSR_REQUIRE(kind >= 0 && kind <= 3, "nsr_masked_loss_backward: kind %d (0 smooth-L1, 1 MSE, 2 L1, 3 Huber)", kind);
+    NSR_REQUIRE(channels >= 1 && (uint64_t)n_rows * channels < (1ull << 32), "nsr_masked_loss_backward: bad shape");
+    if (n_rows == 0) return NSR_OK;
+    NSR_REQUIRE(pred && target && mask && forward_out && grad_out && d_pred, "nsr_masked_loss_backward: NULL pointer");
+    hipLaunchKernelGGL(k_masked_loss_backward, dim3(nsr_div_up((uint64_t)n_rows * channels, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                       (hipStream_t)stream, pred, target, mask, n_rows, channels, kind, beta, forward_out, grad_out, d_pred);
+    NSR_CHECK_LAUNCH("nsr_masked_loss_backward");
     return NSR_OK;
 }

@@ -22,6 +22,8 @@ A maintainer switches the reference over with one line (INTEGRATION.md)::
 The modular path (the reference's own models/*.py on the drop-in tinycudann / nerfacc packages) stays available; this
 entry is the fast one.
 """
+import os
+
 import torch
 
 from .state import HotPathState
@@ -60,10 +62,10 @@ def _fp16_backward_scale(model, under_autocast):
 # the fused forward queues its launches and returns at once; the system's OWN statements then run unchanged on:
 #   * ``num_samples``: a count whose ``.sum().item()`` gives the kept samples of the PREVIOUS forward (already in pinned memory:
 #     the dynamic ray count is a 0.9 / 0.1 moving average, one step of lag moves it by nothing measurable -- PSNR checked,
-#     profiles/r05_psnr_paths.json) -- ``.current()`` gives this forward's, waiting for it;
+#     profiles/r05_psnr_boundary_lazy.json) -- ``.current()`` gives this forward's, waiting for it;
 #   * ``rays_valid``: a bool tensor subclass; ``x[rays_valid[..., 0]]`` is DEFERRED (rows + mask), and F.smooth_l1_loss /
-#     mse_loss / l1_loss of two such selections over the same mask are computed as masked means on the device -- the same
-#     number as the loss of the gathered rows, no nonzero(), gradients through autograd.  Anything else done to a deferred
+#     mse_loss / l1_loss of two such selections over the same mask are computed as masked means on the device (_MaskedLoss: two
+#     launches) -- the same number as the loss of the gathered rows, no nonzero().  Anything else done to a deferred
 #     selection materialises it (one synchronisation, the reference's behaviour);
 #   * per-sample outputs (weights, points, intervals, ray_indices): sliced to the live count only when somebody reads them.
 class _LazyCount:
@@ -137,6 +139,9 @@ class _MaskedRows:
                 and kwargs.get("reduction", "mean") == "mean" and len(args) == 2 \
                 and kwargs.get("size_average") is None and kwargs.get("reduce") is None:
             a, b = args
+            fused = _MaskedLoss.maybe(func, a, b, kwargs)
+            if fused is not None:
+                return fused
             kwargs["reduction"] = "none"
             per = func(a.base, b.base, **kwargs)
             m = a.mask.view(-1, *([1] * (per.dim() - 1))).to(per.dtype)
@@ -145,6 +150,54 @@ class _MaskedRows:
         args = tuple(x.materialize() if isinstance(x, _MaskedRows) else x for x in args)
         kwargs = {k: (v.materialize() if isinstance(v, _MaskedRows) else v) for k, v in kwargs.items()}
         return func(*args, **kwargs)
+
+
+class _MaskedLoss(torch.autograd.Function):
+    """``F.smooth_l1_loss / mse_loss / l1_loss / huber_loss(pred[valid], target[valid])`` (reduction "mean") of two deferred
+    selections over the same mask as two launches (``nsr_masked_loss_forward / _backward``; systems/nerf.py:97,
+    systems/neus.py:98,102) instead of torch's eight elementwise / reduction kernels forward and as many backward; summed in a
+    fixed order.  No valid row -> 0 (torch: NaN)."""
+
+    @staticmethod
+    def maybe(func, a, b, kwargs):
+        import torch.nn.functional as F
+        kinds = {F.smooth_l1_loss: (0, "beta"), F.mse_loss: (1, None), F.l1_loss: (2, None), F.huber_loss: (3, "delta")}
+        pred, target, mask = a.base, b.base, a.mask
+        if (func not in kinds or not pred.is_cuda or pred.dtype != torch.float32 or target.dtype != torch.float32
+                or pred.shape != target.shape or pred.dim() not in (1, 2) or target.requires_grad or mask.dtype != torch.bool
+                or not (pred.is_contiguous() and target.is_contiguous() and mask.is_contiguous())
+                or any(v is not None for k, v in kwargs.items() if k not in ("reduction", "beta", "delta"))
+                or os.environ.get("NSR_MASKED_LOSS_TORCH")):
+            return None
+        kind, knob = kinds[func]
+        beta = float(kwargs.get(knob, 1.0)) if knob else 0.0
+        if kind == 0 and beta == 0.0:
+            kind = 2  # (torch: smooth-L1 with beta = 0 is L1)
+        return _MaskedLoss.apply(pred, target, mask, kind, beta)
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, kind, beta):
+        from nsr_hip import lib, check, ptr, stream_ptr
+        out = torch.empty(int(lib.nsr_masked_loss_out_floats()), dtype=torch.float32, device=pred.device)
+        n, ch = int(pred.shape[0]), (int(pred.shape[1]) if pred.dim() == 2 else 1)
+        with torch.cuda.device(pred.device):
+            check(lib.nsr_masked_loss_forward(ptr(pred), ptr(target), ptr(mask), n, ch, kind, beta, ptr(out), stream_ptr()),
+                  "nsr_masked_loss_forward")
+        ctx.save_for_backward(pred, target, mask, out)
+        ctx.args = (n, ch, kind, beta)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from nsr_hip import lib, check, ptr, stream_ptr
+        pred, target, mask, out = ctx.saved_tensors
+        n, ch, kind, beta = ctx.args
+        d = torch.empty_like(pred)
+        g = g.to(torch.float32).contiguous()
+        with torch.cuda.device(pred.device):
+            check(lib.nsr_masked_loss_backward(ptr(pred), ptr(target), ptr(mask), n, ch, kind, beta, ptr(out), ptr(g), ptr(d),
+                                               stream_ptr()), "nsr_masked_loss_backward")
+        return d, None, None, None, None
 
 
 class _LazyOutputs(dict):
@@ -159,7 +212,8 @@ class _LazyOutputs(dict):
     def _resolve(self, k):
         if k in self._lazy:
             S = self._count.current()
-            dict.__setitem__(self, k, self._lazy.pop(k)[:S])
+            v = self._lazy.pop(k)
+            dict.__setitem__(self, k, (v() if callable(v) else v)[:S])  # (callable: derived arrays nobody may ever read)
 
     def __getitem__(self, k):
         self._resolve(k)
@@ -265,8 +319,8 @@ class FusedNeRFModel(HotPathState):
             t0, t1 = last["t_starts"], last["t_ends"]
             return _LazyOutputs({"comp_rgb": comp_rgb, "opacity": opacity, "depth": depth,
                                  "rays_valid": (opacity > 0).as_subclass(_ValidMask), "num_samples": count},
-                                {"weights": weights.view(-1), "points": ((t0 + t1) / 2.0).view(-1),
-                                 "intervals": (t1 - t0).view(-1), "ray_indices": ray_indices.view(-1)}, count)
+                                {"weights": weights.view(-1), "points": lambda: ((t0 + t1) / 2.0).view(-1),
+                                 "intervals": lambda: (t1 - t0).view(-1), "ray_indices": ray_indices.view(-1)}, count)
         out = {"comp_rgb": comp_rgb, "opacity": opacity, "depth": depth, "rays_valid": opacity > 0,
                "num_samples": torch.as_tensor([last["num_samples"]], dtype=torch.int32)}
         if self.training:
@@ -411,6 +465,12 @@ class FusedNeuSModel(HotPathState):
     def forward(self, rays):
         if self.training:
             out = self.forward_(rays)
+            if not os.environ.get("NSR_BOUNDARY_EAGER"):
+                # systems/neus.py:98,102 index comp_rgb_full / rgb with rays_valid_full[..., 0]: deferred selections, the MSE /
+                # L1 over them as masked means on the device (see _ValidMask / _MaskedLoss above) -- no nonzero(), no wait
+                for k in ("rays_valid", "rays_valid_bg", "rays_valid_full"):
+                    if k in out and out[k].dtype == torch.bool:
+                        out[k] = out[k].as_subclass(_ValidMask)
         else:
             from .export import chunk_batch
             with torch.no_grad():

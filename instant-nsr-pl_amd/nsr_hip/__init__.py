@@ -262,6 +262,9 @@ SIGNATURES = {
                                _P, _P],
     "nsr_neus_composite_forward": [_P, _P, _P, _I, _P, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_neus_loss_rays": [_P, _P, _P, _P, _P, _P, _U, _P, _P],
+    "nsr_masked_loss_out_floats": [],
+    "nsr_masked_loss_forward": [_P, _P, _P, _U, _U, _I, _F, _P, _P],
+    "nsr_masked_loss_backward": [_P, _P, _P, _U, _U, _I, _F, _P, _P, _P, _P],
     "nsr_vmlp_fold": [_VD, _P, _U, _P, _P],
     "nsr_vmlp_unfold_gradient": [_VD, _P, _U, _P, _I, _P],
     "nsr_adamw_multi": [_P, _U, _F, _F, _F, _F, _F, _F, _I, _P],
@@ -285,7 +288,7 @@ SIGNATURES = {
                                 _P, _U, _P, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_hashgrid_owner_first_unchunked_level": ctypes.c_uint32,
-             "nsr_hashgrid_dense_levels": ctypes.c_uint32, "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32,
+             "nsr_hashgrid_dense_levels": ctypes.c_uint32, "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32, "nsr_masked_loss_out_floats": ctypes.c_uint32,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,

@@ -553,3 +553,68 @@ def test_async_trainer_with_the_pipelined_encode_matches_without():
         assert abs(x - y) <= 3e-2 * abs(x) + 1e-6, (x, y)
     assert b["losses"][-1] < 0.7 * b["losses"][0] and a["truncated"] == b["truncated"] == 0
     assert abs(a["samples"] - b["samples"]) <= 0.02 * a["samples"]
+
+
+@pytest.mark.parametrize("kind", ["smooth_l1", "smooth_l1_beta", "mse", "l1", "huber"])
+@pytest.mark.parametrize("n,ch", [(8192, 3), (777, 1), (5, 3)])
+def test_masked_loss_of_deferred_selections_equals_the_loss_of_the_gathered_rows(kind, n, ch):
+    """systems/nerf.py:97, systems/neus.py:98,102: ``F.<loss>(pred[valid], target[valid])`` on two deferred selections over one
+    validity mask (nsr_masked_loss_forward / _backward) against the same statement on plain tensors: value and d / d pred"""
+    import torch.nn.functional as F
+    from nsr.models import _MaskedRows, _ValidMask
+    fn, kw = {"smooth_l1": (F.smooth_l1_loss, {}), "smooth_l1_beta": (F.smooth_l1_loss, {"beta": 0.05}), "mse": (F.mse_loss, {}),
+              "l1": (F.l1_loss, {}), "huber": (F.huber_loss, {"delta": 0.1})}[kind]
+    g = torch.Generator().manual_seed(n + ch)
+    shape = (n, ch) if ch > 1 else (n,)
+    pred = torch.rand(shape, generator=g).cuda().requires_grad_(True)
+    target = torch.rand(shape, generator=g).cuda()
+    mask = (torch.rand(n, generator=g) < 0.6).cuda()
+    ref = fn(pred[mask], target[mask], **kw) * 3.0
+    g_ref, = torch.autograd.grad(ref, pred)
+    valid = mask.clone().as_subclass(_ValidMask)
+    a, b = pred[valid], target[valid]
+    assert isinstance(a, _MaskedRows) and isinstance(b, _MaskedRows)
+    out = fn(a, b, **kw) * 3.0
+    assert out.grad_fn is not None and "MaskedLoss" in type(out.grad_fn.next_functions[0][0]).__name__
+    g_out, = torch.autograd.grad(out, pred)
+    assert abs(float(out) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-9
+    assert torch.allclose(g_out, g_ref, rtol=1e-5, atol=1e-9)
+    assert torch.equal(g_out[~mask], torch.zeros_like(g_out[~mask]))
+    # the fixed summation order: the same bits every time
+    assert float(fn(pred[valid], target[valid], **kw)) == float(fn(pred[valid], target[valid], **kw))
+    # nothing valid: 0 and a zero gradient (torch: NaN)
+    none = torch.zeros(n, dtype=torch.bool).cuda().as_subclass(_ValidMask)
+    z = fn(pred[none], target[none], **kw)
+    gz, = torch.autograd.grad(z, pred)
+    assert float(z) == 0.0 and not gz.any()
+
+
+def test_neus_model_entry_masks_defer_the_selections():
+    """nsr.models.FusedNeuSModel in training: ``rays_valid_full`` is a _ValidMask, the system's MSE / L1 statements
+    (systems/neus.py:98,102) give the values and the parameter gradients of the same statements on plain masks"""
+    import torch.nn.functional as F
+    from test_gpu_models_entry import _neus_pair
+    _, model, cfg = _neus_pair("neus-blender", 7001)
+    g = torch.Generator().manual_seed(1)
+    o = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1) * 4.0
+    d = torch.nn.functional.normalize(-o + torch.randn(300, 3, generator=g) * 0.45, dim=-1)
+    rays, gt = torch.cat([o, d], -1).cuda(), torch.rand(300, 3, generator=g).cuda()
+    res = []
+    for plain in (False, True):
+        model.zero_grad(set_to_none=True)
+        out = model(rays)
+        valid = out["rays_valid_full"][..., 0]
+        assert type(valid).__name__ == "_ValidMask"
+        if plain:
+            valid = valid.as_subclass(torch.Tensor)
+        mse = F.mse_loss(out["comp_rgb_full"][valid], gt[valid])
+        l1 = F.l1_loss(out["comp_rgb_full"][valid], gt[valid])
+        (10.0 * mse + l1).backward()
+        torch.cuda.synchronize()
+        res.append((float(mse), float(l1), [p.grad.clone() for p in model.parameters() if p.grad is not None and p.numel()]))
+    (m0, a0, g0), (m1, a1, g1) = res
+    assert 0 < int(out["rays_valid_full"].sum()) < 300
+    assert abs(m0 - m1) <= 2e-6 * abs(m1) and abs(a0 - a1) <= 2e-6 * abs(a1)
+    assert len(g0) == len(g1) > 0
+    for x, y in zip(g0, g1):
+        assert float((x - y).norm()) <= 2e-4 * float(y.norm()) + 1e-12
