@@ -38,6 +38,8 @@ SETTINGS = {
     "round5_cap512": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 512),
     "round5_without_pair_cap512": ((0, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 512),
     "round5_two_wgrad_streams_cap512": ((1, 0, 1, 1, 0, 1, 0, 0, 0), True, True, 4, 512),
+    # (sixth field: nsr_nerf_sigma_mode -- 1 = the ray-ordered sigma pass that stops at each ray's transmittance cut)
+    "round5_sigma_rays": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128, 1),
 }
 HOST_DELAY = float(os.environ.get("NSR_HOST_DELAY_US", "0")) * 1e-6
 only = os.environ.get("NSR_VARIANTS")
@@ -45,9 +47,10 @@ if only:
     SETTINGS = {k: v for k, v in SETTINGS.items() if k in only.split(",")}
 
 
-def apply(keys, defer, defer_w, rpw, cap=512):
+def apply(keys, defer, defer_w, rpw, cap=512, sigma_mode=0):
     tr.settle()
     torch.cuda.synchronize()
+    lib.nsr_nerf_sigma_mode(sigma_mode)
     lib.nsr_nerf_step_variant(9, 0 if cap >= 512 else cap)
     for k, v in enumerate(keys):
         lib.nsr_nerf_step_variant(k, v)
