@@ -33,16 +33,27 @@ dev = torch.device("cuda", 0)
 # parallel through the trainer's own exchange; on a box with fewer GPUs than ranks the ranks share cuda:0 over gloo (RCCL
 # refuses two ranks per device).  NSR_TRANSPORT=fp32|bf16 picks the table gradient's wire format.
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+extra = {}
 if world > 1:
     import torch.distributed as dist
     assert args.path == "fused", "the multi-rank run goes through nsr.trainer.Trainer"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo" if torch.cuda.device_count() < world else "nccl")
+elif os.environ.get("NSR_FORCE_SHARDED"):
+    # ONE rank in an nccl (= RCCL) group: the trainer's multi-GPU exchange with its real wire format (NSR_TRANSPORT=bf16|fp32: the
+    # table gradient is rounded to the wire format before the one-rank reduce-scatter), sharded AdamW and fp16 all-gather over
+    # the WHOLE schedule -- what a one-GPU box can say about the bf16 default (the sum over ranks is not exercised)
+    import torch.distributed as dist
+    assert args.path == "fused"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    extra["exchange"] = {"backend": "nccl", "world": 1, "transport": os.environ.get("NSR_TRANSPORT", "bf16")}
 cfg = nsr.configs.get("nerf-blender")
 train = SyntheticBlender(n_images=100, w=args.res, h=args.res, device=dev, seed=0)
 test = SyntheticBlender(n_images=args.test_views, w=args.res, h=args.res, device=dev, seed=12345)  # unseen cameras
 milestones = [10000, 15000, 18000]
-extra = {}
 
 if args.path == "fused":
     from nsr.trainer import Trainer
