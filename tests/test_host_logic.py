@@ -70,3 +70,63 @@ def test_sample_buffer_capacity_controller():
     assert 65536 <= shrunk < cap // 2 + 16384
     # few rays in use of many slots: the ray count still has room to climb, and the counts with it
     assert next_capacity(cap, 60000, 1024, 8192, False) >= next_capacity(cap, 60000, 8192, 8192, False)
+
+
+def test_deferred_selections_and_lazy_outputs_on_the_host():
+    """nsr.models._ValidMask / _MaskedRows / _LazyOutputs / _LazyCount (the model entries' non-synchronising outputs) on CPU
+    tensors -- the host logic alone: a selection by the validity mask is deferred, the systems' mean losses over two such
+    selections (systems/nerf.py:97, systems/neus.py:98,102) equal the losses of the gathered rows in value and gradient (here
+    through the elementwise fallback: the kernels need a GPU), anything else gathers, per-sample outputs are sliced when read"""
+    import torch
+    import torch.nn.functional as F
+    from nsr.models import _LazyCount, _LazyOutputs, _MaskedRows, _ValidMask
+    g = torch.Generator().manual_seed(0)
+    pred = torch.rand(300, 3, generator=g, requires_grad=True)
+    target = torch.rand(300, 3, generator=g)
+    mask = torch.rand(300, 1, generator=g) < 0.6
+    valid = mask.as_subclass(_ValidMask)[..., 0]
+    assert type(valid) is _ValidMask and valid.shape == (300,)
+    a, b = pred[valid], target[valid]
+    assert isinstance(a, _MaskedRows) and isinstance(b, _MaskedRows)
+    for fn, kw in ((F.smooth_l1_loss, {}), (F.smooth_l1_loss, {"beta": 0.1}), (F.mse_loss, {}), (F.l1_loss, {}),
+                   (F.huber_loss, {"delta": 0.2})):
+        ref = fn(pred[mask[:, 0]], target[mask[:, 0]], **kw)
+        out = fn(a, b, **kw)
+        assert torch.allclose(out, ref, rtol=1e-6, atol=1e-9), fn.__name__
+        g_ref, = torch.autograd.grad(ref, pred)
+        g_out, = torch.autograd.grad(out, pred)
+        assert torch.allclose(g_out, g_ref, rtol=1e-5, atol=1e-9), fn.__name__
+    # a reduction the deferred form does not know, and attribute access, gather the rows (the reference's behaviour)
+    assert torch.equal(F.mse_loss(a, b, reduction="sum"), F.mse_loss(pred[mask[:, 0]], target[mask[:, 0]], reduction="sum"))
+    assert a.shape == (int(mask.sum()), 3) and torch.equal(a.detach(), pred.detach()[mask[:, 0]])
+    # selections over DIFFERENT masks are not fused
+    other = (~mask).as_subclass(_ValidMask)[..., 0]
+    assert torch.equal((pred[valid].materialize()).detach(), pred.detach()[mask[:, 0]])
+    assert pred[other].shape[0] + pred[valid].shape[0] == 300
+    # the mask itself stays an ordinary bool tensor for everything else
+    assert int(valid.sum()) == int(mask.sum()) and type(valid.sum()) is torch.Tensor
+    assert type(~valid) is not _MaskedRows and torch.equal((valid | ~valid).as_subclass(torch.Tensor), torch.ones(300, dtype=torch.bool))
+
+    class Handle:  # what FusedNeRFStep.render_forward(lazy=True) hands over: (marched, kept) of the last / this call
+        def __init__(self, prev, cur):
+            self.prev, self.cur, self.waits = prev, cur, 0
+
+        def previous(self):
+            return self.prev
+
+        def current(self):
+            self.waits += 1
+            return self.cur
+
+    h = Handle((1000, 400), (900, 350))
+    n = _LazyCount(h)
+    assert n.sum().item() == 400 and int(n) == 400 and n.current() == 350 and h.waits == 1
+    assert int(_LazyCount(Handle(None, (7, 5))).sum().item()) == 5           # the first forward has no predecessor
+    assert torch.equal(torch.as_tensor([3]) + n, torch.as_tensor([403]))    # any torch function sees a one-element tensor
+    h = Handle((1000, 400), (900, 350))
+    w = torch.arange(512.)
+    out = _LazyOutputs({"comp_rgb": pred}, {"weights": w, "points": lambda: w * 2.0}, _LazyCount(h))
+    assert h.waits == 0 and out["comp_rgb"] is pred and h.waits == 0         # ray outputs: no wait
+    assert out["weights"].shape == (350,) and h.waits == 1                   # sample outputs: sliced to the live count when read
+    assert torch.equal(out.get("points"), w[:350] * 2.0) and set(out) == {"comp_rgb", "weights", "points"}
+    assert all(v is not None for v in dict(out.items()).values())
