@@ -715,6 +715,14 @@ int nsr_nerf_step_variant(int key, int value);
  * stream wait for that hipEvent_t between its hash encode and its density MLP instead of the step's stream waiting in front
  * of the encode.  NULL clears.  The caller must wait for the event itself before anything else reads the weights. */
 int nsr_nerf_wait_before_mlp(void *event);
+/* key 10 of nsr_nerf_step_variant (default 0): nsr_nerf_main_pass queues its table backward (with AdamW inside) on the helper
+ * stream, in order behind its own binning launch -- no join in front of it on the caller's stream -- and the weight-gradient
+ * kernels of both networks inline on the caller's stream behind the data-gradient kernel -- no fork.  Only for a caller that
+ * set nsr_nerf_defer_wgrad_join and passes table_adam (no exchange).  nsr_nerf_last_pass_form(): bit 0 = the last main pass took
+ * this form: the caller's optimizer launch for the MLP weights then belongs on ITS stream, followed by nsr_nerf_wait_table(stream)
+ * (a no-op when nothing is pending; the next pruning / main pass calls it itself for a caller that did not). */
+int nsr_nerf_last_pass_form(void);
+int nsr_nerf_wait_table(void *stream);
 /* key 8 of nsr_nerf_step_variant (default 0): the table backward with AdamW inside runs as two launches (levels [0, 8), then
  * [8, 16)) and the NEXT pruning pass encodes levels [0, 8) on a helper stream beside the second launch (nsr_hashgrid_forward_half).
  * That helper stream must wait for the pruning pass's inputs itself: hand the hipEvent_t behind which positions / marched count

@@ -141,7 +141,8 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
 // (round 5) two more streams: `stream_b` takes the density network's weight-gradient kernels beside the colour network's on
 // `stream`, `stream_c` the dense levels' table backward (csrc/hashgrid_dense.inc) beside the owner launch of the hashed levels
 struct HelperEvents { hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr, dgrad_done = nullptr,
-                                  wgrad_b_done = nullptr, dense_done = nullptr, table_a_done = nullptr, enc_a_done = nullptr; };
+                                  wgrad_b_done = nullptr, dense_done = nullptr, table_a_done = nullptr, enc_a_done = nullptr,
+                                  table_done = nullptr; };
 struct HelperStream {
     hipStream_t stream = nullptr, stream_b = nullptr, stream_c = nullptr;
     // two sets of the pass's events: [0] plain, [1] created with hipEventReleaseToDevice (a device-scope release when the event
@@ -156,7 +157,7 @@ struct HelperStream {
         // hardware queues; streams nobody uses must not shift which queue the step's three working streams get)
         for (int k = 0; k < 2; ++k)
             for (hipEvent_t *e : {&ev[k].fork, &ev[k].join, &ev[k].join_wgrad, &ev[k].fork_wgrad, &ev[k].dgrad_done,
-                                  &ev[k].wgrad_b_done, &ev[k].dense_done, &ev[k].table_a_done, &ev[k].enc_a_done})
+                                  &ev[k].wgrad_b_done, &ev[k].dense_done, &ev[k].table_a_done, &ev[k].enc_a_done, &ev[k].table_done})
                 if (hipEventCreateWithFlags(e, hipEventDisableTiming | (k ? hipEventReleaseToDevice : 0u)) != hipSuccess) return false;
         return ok = true;
     }
@@ -205,6 +206,11 @@ extern "C" int nsr_nerf_wait_kept_rows(void *stream)
 //   key 9: block cap of the pass's weight-gradient launches (nsr_mlp_wgrad_max_blocks, set around the pass's own launches only;
 //          default 128 -- measured in the step: 512 -> 0.373, 256 -> 0.368, 128 -> 0.365, 64 -> 0.370, 32 -> 0.391 ms: with the
 //          join deferred to the next density MLP fewer 64 KB-LDS blocks leave the table backward more of the chip; 0 = leave it)
+//   key 10: the table backward (with AdamW inside) on the HELPER stream, in order behind its own binning launch -- no join in
+//          front of it on the step's stream --, the weight-gradient kernels inline on the step's stream behind the data-gradient
+//          kernel -- no fork --; the caller queues its MLP optimizer launch on the step's stream and then
+//          nsr_nerf_wait_table(stream).  Only with nsr_nerf_defer_wgrad_join, the fused table update and no exchange;
+//          nsr_nerf_last_pass_form() says whether the last pass took it
 //   key 8: the table backward (with AdamW inside) as TWO launches, levels [0, 8) then [8, 16), and the NEXT pruning pass's encode
 //          as two halves: levels [0, 8) on a helper stream as soon as the first launch has retired -- beside the second --, levels
 //          [8, 16) on the step's stream; needs nsr_nerf_set_inputs_event (the next step's positions come from another stream)
@@ -296,6 +302,25 @@ extern "C" int nsr_nerf_sigma_mode(int mode)
     return old;
 }
 
+// key 10: the last main pass left its table update running on the helper stream (HEV.table_done is recorded behind it)
+static bool g_table_pending = false;
+static hipEvent_t g_table_event = nullptr;
+static int g_last_form = 0;
+// bit 0: the last nsr_nerf_main_pass ran its table backward on the helper stream and its weight gradients on the caller's
+// stream (key 10): the MLP optimizer launch belongs on the caller's stream, followed by nsr_nerf_wait_table
+extern "C" int nsr_nerf_last_pass_form(void) { return g_last_form; }
+// make `stream` wait for the table update of the last main pass if it is still running on the helper stream (key 10); a no-op
+// otherwise.  Every later reader of the table on `stream` -- the next step's encode, an occupancy refresh, a checkpoint -- is
+// then ordered behind it.
+extern "C" int nsr_nerf_wait_table(void *stream)
+{
+    if (!g_table_pending) return NSR_OK;
+    NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_table_event, 0) == hipSuccess,
+                "nsr_nerf_wait_table: hipStreamWaitEvent failed");
+    g_table_pending = false;
+    return NSR_OK;
+}
+
 static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
                       const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                       const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
@@ -305,6 +330,7 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
 {
     NSR_REQUIRE(d && workspace && kept_counts && packed_kept && total_kept, "nsr_nerf_prune_pass: NULL pointer");
     g_deferred.pending = false;
+    NSR_TRY(nsr_nerf_wait_table(stream));  // (a caller that did not order its stream behind a key-10 table update itself)
     NsrNerfPruneLayout L;
     NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &L));
     char *ws = (char *)workspace;
@@ -463,6 +489,8 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
                 "[16 features | 16 SH] (reference models/texture.py:26 with feature_dim 16)");
     g_ht.start();
+    NSR_TRY(nsr_nerf_wait_table(stream));  // (a key-10 table update of an earlier pass still running on the helper stream)
+    g_last_form = 0;
     NsrNerfPruneLayout P;
     NsrNerfMainLayout L;
     NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &P));
@@ -673,6 +701,10 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     const bool pair = g_variant[0] && nsr_mlp_dgrad_pair_supported(&d->mlp_color, &d->mlp_density) && C == 32;
     bool dgrad_event = false;  // HEV.dgrad_done recorded behind the last data-gradient kernel
     bool late_wgrad = false, wgrads_after_issue = false;
+    // key 10: the table backward goes to the helper stream (behind its binning launch: no join on `st`), the weight gradients
+    // stay on `st` (no fork): the step's stream meets the helper stream once, in nsr_nerf_wait_table
+    const bool owner_on_helper = g_variant[10] && pair && wg && g_defer_wgrad_join && !xchg && !use_dense && overlap_bins &&
+                                 table_adam && !capturing && !g_variant[8] && !g_variant[4] && phases == 3;
     // the weight-gradient kernels + reductions of both networks (behind nsr_mlp_dgrad_pair), forked from `st` through `fork`
     auto queue_wgrads = [&](hipEvent_t fork, bool *recorded, bool already_recorded) -> int {
         void *wg_c = wg, *wg_d = wg;
@@ -712,7 +744,29 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         const bool rode = ride && nsr_next_stop_event == nullptr;
         nsr_next_stop_event = nullptr;
         if (rode) dgrad_event = true;
-        if (!late_wgrad && wg && g_variant[7] && !xchg) {
+        if (owner_on_helper) {
+            if (!rode) NSR_REQUIRE(hipEventRecord(HEV.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: table-backward fork failed");
+            dgrad_event = true;
+            // the table backward first (host order): in order behind this pass's binning launch on the helper stream
+            NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, HEV.dgrad_done, 0) == hipSuccess,
+                        "nsr_nerf_main_pass: table-backward fork failed");
+            {
+                ProfScope p(NSR_PROF_GRID_BACKWARD, S, g_helper.stream);
+                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam(x01, d_enc, 2, 0, (float *)(ws + L.grid_ws), S,
+                                                                           d->grid.n_levels, 1.0f, &d->grid, n_kept_dev,
+                                                                           table_adam, g_helper.stream));
+            }
+            NSR_REQUIRE(hipEventRecord(HEV.table_done, g_helper.stream) == hipSuccess, "nsr_nerf_main_pass: hipEventRecord failed");
+            g_table_event = HEV.table_done;
+            g_table_pending = true;
+            g_last_form = 1;
+            // the weight gradients of both networks inline, behind the data-gradient kernel they read from
+            NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, nullptr, 32,
+                                            0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream, 2));
+            NSR_TRY(nsr_mlp_backward_phases(d_enc, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
+                                            grad_density_mlp, nullptr, C, d->grid.n_features, part1, S, d->grad_scale,
+                                            &d->mlp_density, n_kept_dev, stream, 2));
+        } else if (!late_wgrad && wg && g_variant[7] && !xchg) {
             // (host order only: the fork event is recorded now, the helper streams' launches are issued behind the table backward's)
             if (!rode) NSR_REQUIRE(hipEventRecord(HEV.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: weight-gradient fork failed");
             dgrad_event = true;
@@ -796,7 +850,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         }
         // (whoever reads the table next on this stream -- the next step's encode, the caller's optimizer -- sees all levels)
         NSR_REQUIRE(hipStreamWaitEvent(st, HEV.dense_done, 0) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
-    } else {
+    } else if (!owner_on_helper) {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
         if (overlap_bins) {
             NSR_REQUIRE(hipStreamWaitEvent(st, HEV.join, 0) == hipSuccess,

@@ -352,6 +352,8 @@ def set_step_forms(trainer, forms):
         _lib.nsr_nerf_step_variant(k, int(v))
     _lib.nsr_composite_flat_rays_per_wave(int(forms["flat_rays_per_wave"]))
     _lib.nsr_nerf_step_variant(9, int(forms["wgrad_max_blocks"]))  # (0: the pass leaves the library's cap of 512 alone)
+    # key 10: table backward on the helper stream, weight gradients + MLP optimizer on the step's stream (csrc/step.hip)
+    _lib.nsr_nerf_step_variant(10, int(forms.get("table_on_helper", 0)))
     trainer.fused.defer_pack = bool(forms["defer_pack"])
     trainer.defer_weights_wait = bool(forms["defer_weights_wait"])
 
@@ -471,6 +473,8 @@ class Trainer:
             torch.cuda.current_stream().wait_event(a["weights_event"])
             _check(_lib.nsr_nerf_wait_before_mlp(None), "nsr_nerf_wait_before_mlp")
             a["weights_event"] = None
+        if a is not None:  # (a table update still running on the helper stream: nsr_nerf_step_variant key 10)
+            _check(_lib.nsr_nerf_wait_table(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "nsr_nerf_wait_table")
 
     def _all_reduce_grads(self):
         if self.world_size > 1 and self.sharded is None:
@@ -834,7 +838,15 @@ class Trainer:
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            if fuse_table and self._helper_stream() is not None:
+            if fuse_table and (_lib.nsr_nerf_last_pass_form() & 1):
+                # the pass ran its table backward on the helper stream and its weight gradients HERE (nsr_nerf_step_variant key
+                # 10): the optimizer launch for the MLP weights follows them on this stream -- no event towards the next
+                # density MLP --, then this stream meets the helper stream once, behind the table update
+                mp = ctypes.c_void_p(main.cuda_stream)
+                self.opt.step_device(skip_table_of=fused.ewn, other_stream_reads=True, stream=mp)
+                _check(_lib.nsr_nerf_wait_table(mp), "nsr_nerf_wait_table")
+                a["weights_event"] = None
+            elif fuse_table and self._helper_stream() is not None:
                 # what is left for the optimizer (the MLP weights: one launch that also advances the device-side schedule) runs
                 # on the main pass's helper stream, right behind the weight-gradient kernels it reads from -- underneath the
                 # table backward, off the step's own chain; the main stream only waits for its event

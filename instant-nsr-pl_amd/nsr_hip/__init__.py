@@ -236,6 +236,8 @@ SIGNATURES = {
     "nsr_composite_backward_flat": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_step_variant": [_I, _I],
     "nsr_nerf_wait_before_mlp": [_P],
+    "nsr_nerf_wait_table": [_P],
+    "nsr_nerf_last_pass_form": [],
     "nsr_nerf_set_inputs_event": [_P],
     "nsr_hashgrid_forward_half": [_P, _P, _P, _U, _U, _I, _U, _I, _GD, _P, _P],
     "nsr_nerf_prune_pass_deferred": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],

@@ -555,6 +555,50 @@ def test_async_trainer_with_the_pipelined_encode_matches_without():
     assert abs(a["samples"] - b["samples"]) <= 0.02 * a["samples"]
 
 
+def test_async_trainer_with_the_table_backward_on_the_helper_stream_matches_without():
+    """key 10 (table backward on the helper stream behind its binning, weight gradients and the MLP optimizer launch on the
+    step's stream, one meeting of the two streams per step) is scheduling only: the pass reports the form, the trajectory is
+    the one without it to the run-to-run noise of the step, checkpoints and evaluation see the finished table"""
+    import nsr
+    import refmirror
+    from nsr.scene import SyntheticBlender
+    from nsr.trainer import Trainer
+    from nsr_hip import lib
+    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
+    cfg = dict(nsr.configs.get("nerf-blender"))
+    cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
+    out = {}
+    try:
+        for on in (0, 1):
+            lib.nsr_nerf_step_variant(10, on)
+            torch.manual_seed(0)
+            model = refmirror.NeRFModel(cfg).cuda().train()
+            tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
+            losses, forms = [], set()
+            for _ in range(48):
+                losses.append(float(tr.train_step()["loss"]))
+                forms.add(int(lib.nsr_nerf_last_pass_form()))
+            sd = tr.state_dict()  # (settles: the table update on the helper stream is behind it)
+            torch.cuda.synchronize()
+            c = tr.counters()
+            table = model.geometry.encoding_with_network.params.detach().float().clone()
+            out[on] = dict(losses=losses, samples=c["samples"], truncated=c["truncated"], forms=forms, table=table,
+                           finite=all(bool(torch.isfinite(v).all()) for v in sd.values() if torch.is_tensor(v) and v.is_floating_point()))
+    finally:
+        lib.nsr_nerf_step_variant(10, 0)
+    a, b = out[0], out[1]
+    assert a["forms"] == {0} and b["forms"] == {1}
+    assert abs(a["losses"][0] - b["losses"][0]) <= 1e-5 * abs(a["losses"][0])
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) <= 3e-2 * abs(x) + 1e-6, (x, y)
+    assert b["losses"][-1] < 0.7 * b["losses"][0] and a["truncated"] == b["truncated"] == 0
+    assert abs(a["samples"] - b["samples"]) <= 0.02 * a["samples"]
+    assert a["finite"] and b["finite"]
+    # (no entry-wise comparison of the tables: with Adam's eps = 1e-15 a last-bit difference in a rarely-hit entry's gradient
+    # moves it by a full learning-rate step -- the two runs differ in summation order of the weight-gradient partials)
+    assert bool(torch.isfinite(b["table"]).all()) and float(b["table"].norm()) > 0
+
+
 @pytest.mark.parametrize("kind", ["smooth_l1", "smooth_l1_beta", "mse", "l1", "huber"])
 @pytest.mark.parametrize("n,ch", [(8192, 3), (777, 1), (5, 3)])
 def test_masked_loss_of_deferred_selections_equals_the_loss_of_the_gathered_rows(kind, n, ch):

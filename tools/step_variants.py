@@ -40,6 +40,9 @@ SETTINGS = {
     "round5_two_wgrad_streams_cap512": ((1, 0, 1, 1, 0, 1, 0, 0, 0), True, True, 4, 512),
     # (sixth field: nsr_nerf_sigma_mode -- 1 = the ray-ordered sigma pass that stops at each ray's transmittance cut)
     "round5_sigma_rays": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128, 1),
+    # (key 10: the table backward on the helper stream behind its binning, weight gradients + MLP optimizer on the step's stream)
+    "round5_table_on_helper": ((1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1), True, True, 4, 128),
+    "round5_table_on_helper_cap512": ((1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1), True, True, 4, 512),
 }
 HOST_DELAY = float(os.environ.get("NSR_HOST_DELAY_US", "0")) * 1e-6
 only = os.environ.get("NSR_VARIANTS")
@@ -51,9 +54,11 @@ def apply(keys, defer, defer_w, rpw, cap=512, sigma_mode=0):
     tr.settle()
     torch.cuda.synchronize()
     lib.nsr_nerf_sigma_mode(sigma_mode)
-    lib.nsr_nerf_step_variant(9, 0 if cap >= 512 else cap)
+    lib.nsr_nerf_step_variant(10, 0)
     for k, v in enumerate(keys):
-        lib.nsr_nerf_step_variant(k, v)
+        if k != 9:
+            lib.nsr_nerf_step_variant(k, v)
+    lib.nsr_nerf_step_variant(9, 0 if cap >= 512 else cap)
     lib.nsr_composite_flat_rays_per_wave(rpw)
     tr.fused.defer_pack = defer
     tr.defer_weights_wait = defer_w
