@@ -93,6 +93,17 @@ class _LazyCount:
     def tensor(self):
         return torch.as_tensor([self._value()], dtype=torch.int32)
 
+    def __getattr__(self, name):  # anything else: the one-element CPU tensor the synchronising entry returns
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.tensor(), name)
+
+    def __index__(self):
+        return int(self._value())
+
+    def __bool__(self):
+        return bool(self._value())
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         args = tuple(a.tensor() if isinstance(a, _LazyCount) else a for a in args)
@@ -129,6 +140,17 @@ class _MaskedRows:
     def __getattr__(self, name):  # anything the deferred form does not know: the gathered tensor's
         return getattr(self.materialize(), name)
 
+    # (Python looks operators up on the type, not through __getattr__: arithmetic / indexing / comparisons on a deferred
+    # selection gather it first, like every other use the deferred form does not know)
+    def __len__(self):
+        return len(self.materialize())
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         import torch.nn.functional as F
@@ -150,6 +172,34 @@ class _MaskedRows:
         args = tuple(x.materialize() if isinstance(x, _MaskedRows) else x for x in args)
         kwargs = {k: (v.materialize() if isinstance(v, _MaskedRows) else v) for k, v in kwargs.items()}
         return func(*args, **kwargs)
+
+
+def _gathering_operator(name):
+    def op(self, *args):
+        args = tuple(a.materialize() if isinstance(a, _MaskedRows) else a for a in args)
+        return getattr(self.materialize(), name)(*args)
+    op.__name__ = name
+    return op
+
+
+for _name in ("add radd sub rsub mul rmul truediv rtruediv floordiv rfloordiv mod rmod pow rpow matmul rmatmul neg pos abs invert "
+              "and rand or ror xor rxor lt le gt ge eq ne").split():
+    setattr(_MaskedRows, f"__{_name}__", _gathering_operator(f"__{_name}__"))
+_MaskedRows.__hash__ = object.__hash__  # (__eq__ is elementwise, as a tensor's)
+
+
+def _count_operator(name):
+    def op(self, *args):
+        args = tuple(a.tensor() if isinstance(a, _LazyCount) else a for a in args)
+        return getattr(self.tensor(), name)(*args)
+    op.__name__ = name
+    return op
+
+
+for _name in "add radd sub rsub mul rmul truediv rtruediv floordiv rfloordiv lt le gt ge eq ne neg".split():
+    setattr(_LazyCount, f"__{_name}__", _count_operator(f"__{_name}__"))
+_LazyCount.__hash__ = object.__hash__
+del _name
 
 
 class _MaskedLoss(torch.autograd.Function):

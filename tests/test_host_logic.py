@@ -99,6 +99,12 @@ def test_deferred_selections_and_lazy_outputs_on_the_host():
     # a reduction the deferred form does not know, and attribute access, gather the rows (the reference's behaviour)
     assert torch.equal(F.mse_loss(a, b, reduction="sum"), F.mse_loss(pred[mask[:, 0]], target[mask[:, 0]], reduction="sum"))
     assert a.shape == (int(mask.sum()), 3) and torch.equal(a.detach(), pred.detach()[mask[:, 0]])
+    # operators are looked up on the type: they gather too
+    rows, trow = pred.detach()[mask[:, 0]], target[mask[:, 0]]
+    assert torch.equal((a - b).detach(), rows - trow) and torch.equal((2.0 * a).detach(), 2.0 * rows) and torch.equal((-a).detach(), -rows)
+    assert torch.equal(((a - b).abs().mean()).detach(), (rows - trow).abs().mean()) and torch.equal(abs(b), trow.abs())
+    assert len(a) == rows.shape[0] and torch.equal(a[0].detach(), rows[0]) and torch.equal((a > 0.5), rows > 0.5)
+    assert torch.equal((a ** 2).detach(), rows ** 2) and torch.equal((a / (b + 1.0)).detach(), rows / (trow + 1.0))
     # selections over DIFFERENT masks are not fused
     other = (~mask).as_subclass(_ValidMask)[..., 0]
     assert torch.equal((pred[valid].materialize()).detach(), pred.detach()[mask[:, 0]])
@@ -123,6 +129,8 @@ def test_deferred_selections_and_lazy_outputs_on_the_host():
     assert n.sum().item() == 400 and int(n) == 400 and n.current() == 350 and h.waits == 1
     assert int(_LazyCount(Handle(None, (7, 5))).sum().item()) == 5           # the first forward has no predecessor
     assert torch.equal(torch.as_tensor([3]) + n, torch.as_tensor([403]))    # any torch function sees a one-element tensor
+    assert torch.equal(n + 1, torch.as_tensor([401], dtype=torch.int32)) and bool((n.sum() > 0).all()) and float(n.sum() / 2) == 200.0
+    assert n.shape == (1,) and n.dtype == torch.int32 and n.float().item() == 400.0 and bool(n)
     h = Handle((1000, 400), (900, 350))
     w = torch.arange(512.)
     out = _LazyOutputs({"comp_rgb": pred}, {"weights": w, "points": lambda: w * 2.0}, _LazyCount(h))
