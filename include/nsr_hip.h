@@ -618,7 +618,26 @@ int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out, uint32_t 
  * (nsr_composite_l1_partials_floats(n_rays) floats).  backward: EITHER the upstream gradients grad_comp_rgb [R,3] (+
  * optional grad_opacity [R], grad_depth [R], grad_weights [n]) OR the built-in loss on (comp_rgb, opacity, gt_rgb) with its
  * (sum, valid rays) read from acc2 (partials == NULL) or summed from the forward's partials (acc2 then receives them). */
-int nsr_composite_flat_rays_per_wave(int rays); /* 4 (default), 8 or 16; 0 queries; returns the previous value */
+int nsr_composite_flat_rays_per_wave(int rays); /* Sample-partitioned compositing (round 6; nerfacc.render_weight_from_density + accumulate_along_rays, reference
+ * models/nerf.py:105-108, with trunc_exp + density bias of models/geometry.py:122-156 folded in): one lane per kept sample, a
+ * wave per 64 samples of the packed arrays whatever the ray boundaries.  ray_indices[n_samples] (int64) names each sample's
+ * ray, packed_info [n_rays][2] its (start, count) -- an exclusive scan over the rays.  n_samples = capacity of the sample
+ * arrays, n_samples_dev (may be NULL) the live count.  partials (may be NULL): nsr_composite_l1_partials_floats(n_rays) floats
+ * for the folded masked smooth-L1 (forward and backward of one step take the same n_rays / n_samples). */
+int nsr_composite_forward_samples(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                  const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
+                                  const int64_t *ray_indices, const float *background, float *weights, float *trans,
+                                  float *comp_rgb, float *opacity, float *depth, const float *gt_rgb, float *partials,
+                                  uint32_t n_rays, uint32_t n_samples, const int32_t *n_samples_dev, void *stream);
+int nsr_composite_backward_samples(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                   const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
+                                   const int64_t *ray_indices, const float *background, const float *weights,
+                                   const float *trans, const float *grad_comp_rgb, const float *grad_opacity,
+                                   const float *grad_depth, const float *grad_weights, const float *comp_rgb,
+                                   const float *opacity, const float *gt_rgb, const float *partials, float *acc2,
+                                   float grad_scale, float *grad_rgb, float *grad_logit, uint32_t n_rays, uint32_t n_samples,
+                                   const int32_t *n_samples_dev, void *stream);
+/* 4 (default), 8 or 16; 0 queries; returns the previous value */
 int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
                                const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
                                const float *background, float *weights, float *trans, float *comp_rgb, float *opacity,
@@ -967,6 +986,12 @@ typedef struct NsrVmlpDesc {
 } NsrVmlpDesc;
 uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *desc);
 uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *desc, uint32_t n);
+/* The same for a call whose n_full / p_in are known: rows >= n_full (finite-difference taps, models/geometry.py:181-199)
+ * keep no activations, p_in == NULL needs no second-order rows.  (n, n, 1) is the worst case the plain function returns. */
+uint64_t nsr_vmlp_backward_workspace_floats_ex(const NsrVmlpDesc *desc, uint32_t n, uint32_t n_full, int second);
+/* Launch shape of nsr_vmlp_backward: key 1 = waves of the weight-gradient kernel per layer, 2 = waves of the data-gradient
+ * kernel (both default 2,048 = two per SIMD).  Call before sizing the workspace. */
+int nsr_vmlp_tune(int key, int value);
 /* The nn.Linear tensors of a reference VanillaMLP layer (models/network_utils.py:95-139): weight_v [n_out][n_in] with
  * weight_g [n_out] (old-style torch weight_norm, W[r] = g[r] v[r] / |v[r]|) or the plain weight in weight_v with weight_g
  * NULL; grad_* receive the gradients (unfold).  nsr_vmlp_fold builds the padded parameter blob from n_hidden + 1 layers,

@@ -170,7 +170,7 @@ struct HelperStream {
     }
 };
 static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
-static int g_variant[12] = {1, 0, 1, 0, 0, 1, 0, 0, 0, 128, 0, 0};  // nsr_nerf_step_variant (below)
+static int g_variant[12] = {1, 0, 2, 0, 0, 1, 0, 0, 0, 128, 0, 0};  // nsr_nerf_step_variant (below)
 #define HEV (g_helper.ev[g_variant[6] ? 1 : 0])
 
 // the helper stream's handle (created on first use), for callers that queue follow-up work behind the weight-gradient
@@ -591,10 +591,18 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                    n_kept_dev, stream));
     }
     g_ht.mark(2);
-    if (flat) {  // one lane per sample (csrc/fused.hip k_composite_forward_flat); the loss partials ride along when folded
+    if (flat && g_variant[2] == 1) {  // (A/B: round 5's ray-partitioned flat form)
         NSR_TRY(nsr_composite_forward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                            comp_rgb, opacity, depth, l1_folded ? gt_rgb : nullptr,
                                            l1_folded ? acc + 2 : nullptr, n_rays, stream));
+        if (!l1_folded && gt_rgb)
+            NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
+    } else if (flat) {  // one lane per sample, a wave per 64 samples (csrc/fused.hip k_composite_forward_samples); the loss
+                        // partials ride along when folded
+        NSR_TRY(nsr_composite_forward_samples(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept,
+                                              (const int64_t *)(ws + L.ray_indices), background, weights, trans, comp_rgb,
+                                              opacity, depth, l1_folded ? gt_rgb : nullptr, l1_folded ? acc + 2 : nullptr,
+                                              n_rays, S, n_kept_dev, stream));
         if (!l1_folded && gt_rgb)
             NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
     } else if (l1_folded) {  // the loss reduction rides in the two compositing kernels (per-block partials behind acc)
@@ -664,14 +672,25 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // dgrad and the table backward -- only dx continues down the main chain
     static const bool wgrad_inline = getenv("NSR_WGRAD_INLINE") != nullptr;  // diagnostic A/B switch
     void *wg = (overlap_bins && !wgrad_inline) ? (void *)g_helper.stream : nullptr;
-    if (flat && up)
+    const int64_t *ray_kept = (const int64_t *)(ws + L.ray_indices);
+    if (flat && g_variant[2] == 1 && up)
         NSR_TRY(nsr_composite_backward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                             up->comp_rgb, up->opacity, up->depth, up->weights, nullptr, nullptr, nullptr,
                                             nullptr, nullptr, d->loss_scale, d_rgb, d_logit, n_rays, stream));
-    else if (flat)  // built-in masked smooth-L1: (sum, valid rays) from the forward's partials when folded, from acc otherwise
+    else if (flat && g_variant[2] == 1)
         NSR_TRY(nsr_composite_backward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                             nullptr, nullptr, nullptr, nullptr, comp_rgb, opacity, gt_rgb,
                                             l1_folded ? acc + 2 : nullptr, acc, d->loss_scale, d_rgb, d_logit, n_rays, stream));
+    else if (flat && up)
+        NSR_TRY(nsr_composite_backward_samples(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, ray_kept, background,
+                                               weights, trans, up->comp_rgb, up->opacity, up->depth, up->weights, nullptr,
+                                               nullptr, nullptr, nullptr, nullptr, d->loss_scale, d_rgb, d_logit, n_rays, S,
+                                               n_kept_dev, stream));
+    else if (flat)  // built-in masked smooth-L1: (sum, valid rays) from the forward's partials when folded, from acc otherwise
+        NSR_TRY(nsr_composite_backward_samples(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, ray_kept, background,
+                                               weights, trans, nullptr, nullptr, nullptr, nullptr, comp_rgb, opacity, gt_rgb,
+                                               l1_folded ? acc + 2 : nullptr, acc, d->loss_scale, d_rgb, d_logit, n_rays, S,
+                                               n_kept_dev, stream));
     else if (up)  // the caller's loss: arbitrary dL/d comp_rgb, dL/d opacity, dL/d depth (+ dL/d weights: distortion loss)
         NSR_TRY(nsr_composite_backward_ex(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
                                           up->comp_rgb, up->opacity, up->depth, up->weights, d_rgb, d_logit, n_rays, stream));

@@ -232,6 +232,9 @@ SIGNATURES = {
     "nsr_visibility_prefix_sums": [_P, _U, _F, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_copy_kept_rows_scan": [_P] * 18 + [_U, _U, _U, _U, _P, _P, _P, _U, _P],
     "nsr_composite_flat_rays_per_wave": [_I],
+    "nsr_composite_forward_samples": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P],
+    "nsr_composite_backward_samples": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
+                                       _P, _P, _U, _U, _P, _P],
     "nsr_composite_forward_flat": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward_flat": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_step_variant": [_I, _I],
@@ -257,6 +260,8 @@ SIGNATURES = {
                                     _I, _I, _I, _F, _F, _F, _I, _P],
     "nsr_vmlp_blob_floats": [_VD],
     "nsr_vmlp_backward_workspace_floats": [_VD, _U],
+    "nsr_vmlp_backward_workspace_floats_ex": [_VD, _U, _U, _I],
+    "nsr_vmlp_tune": [_I, _I],
     "nsr_vmlp_forward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _U, _U, _P, _P],
     "nsr_vmlp_backward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _P, _U, _U, _U, _U, _P, _I, _P, _U, _U, _P, _P],
     "nsr_neus_points": [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _U, _P, _P],
@@ -294,6 +299,7 @@ _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": c
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
+             "nsr_vmlp_backward_workspace_floats_ex": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_taps_workspace_floats": ctypes.c_uint64,
              "nsr_profile_enable": None, "nsr_grid_bricks_words64": ctypes.c_uint64, "nsr_ray_march_capacity": ctypes.c_uint32}

@@ -35,6 +35,12 @@ for kept in (45000, 100000):
         r[f"composite_forward_flat{rpw}_us"] = median_us(lambda: check(lib.nsr_composite_forward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(w), ptr(tr), ptr(rgb), ptr(op), ptr(dp), ptr(gt), ptr(part), n_rays, s), "f"))
         r[f"composite_backward_flat{rpw}_us"] = median_us(lambda: check(lib.nsr_composite_backward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(w), ptr(tr), None, None, None, None, ptr(rgb), ptr(op), ptr(gt), ptr(part), ptr(acc), 1.0, ptr(d_rgb), ptr(d_logit), n_rays, s), "b"))
     lib.nsr_composite_flat_rays_per_wave(4)
+    ri = torch.repeat_interleave(torch.arange(n_rays), counts).cuda()
+    r["composite_forward_samples_us"] = median_us(lambda: check(lib.nsr_composite_forward_samples(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(ri), ptr(bg), ptr(w), ptr(tr), ptr(rgb), ptr(op), ptr(dp), ptr(gt), ptr(part), n_rays, n, None, s), "f"))
+    r["composite_backward_samples_us"] = median_us(lambda: check(lib.nsr_composite_backward_samples(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(ri), ptr(bg), ptr(w), ptr(tr), None, None, None, None, ptr(rgb), ptr(op), ptr(gt), ptr(part), ptr(acc), 1.0, ptr(d_rgb), ptr(d_logit), n_rays, n, None, s), "b"))
+    if os.environ.get("ONLY_COMPOSITE"):
+        res[str(kept)] = r
+        continue
     # the two networks' data gradients
     dc, dd = nsr_hip.make_mlp_desc(32, 3, 2, "sigmoid"), nsr_hip.make_mlp_desc(32, 16, 1, "none")
     wc = (torch.randn(7168, generator=g) * 0.2).half().cuda(); wd = (torch.randn(3072, generator=g) * 0.2).half().cuda()

@@ -31,6 +31,7 @@ SETTINGS = {
     "defer_pack_only": ((0, 0, 0, 0, 0, 0, 0, 0, 0), True, False, 4, 512),
     "defer_weights_only": ((0, 0, 0, 0, 0, 0, 0, 0, 0), False, True, 4, 512),
     "round5_forms": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
+    "round6_sample_partitioned_compositing": ((1, 0, 2, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
     "round5_without_pair": ((0, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
     "round5_plus_dense_atomics": ((1, 1, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
     "round5_plus_pipelined_encode": ((1, 0, 1, 0, 0, 1, 0, 0, 1), True, True, 4, 128),
