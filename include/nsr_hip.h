@@ -200,6 +200,13 @@ int nsr_hashgrid_jac_apply_ex(const float *jac, uint32_t n, const NsrGridDesc *d
 int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                               int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, const int32_t *n_dev,
                               void *stream);
+/* The same, and the per-(level, sample) crossing masks of the six taps (bit t: tap t + 1 left the sample's cell) are left at
+ * the head of tap_workspace (nsr_hashgrid_backward_params_taps_workspace_floats(desc, n) floats) for
+ * nsr_hashgrid_backward_params_owner_bin_taps_masked: the stencil mode of the table backward then needs no pass of its own
+ * over the 7 n positions x L levels. */
+int nsr_hashgrid_forward_taps_masks(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
+                                    int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc,
+                                    float *tap_workspace, void *stream);
 
 /* One pass for both table gradients of a NeuS step with analytic normals: grad_table (+)= scatter(dy_first) (first order,
  * dy_first_lm level-major fp32 [L][n][F]) + d(dx.g)/d table (second order; dy row-major fp32 = d sdf / d encoding) */
@@ -868,6 +875,10 @@ int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segments, float b
 uint64_t nsr_hashgrid_backward_params_taps_workspace_floats(const NsrGridDesc *desc, uint32_t n_centre);
 int nsr_hashgrid_backward_params_owner_bin_taps(const float *x7, float *workspace, float *tap_workspace, uint32_t n_centre,
                                                 uint32_t level_mask_count, const NsrGridDesc *desc, void *stream);
+/* ... when nsr_hashgrid_forward_taps_masks (same x7, n_centre, level_mask_count) already wrote the crossing masks */
+int nsr_hashgrid_backward_params_owner_bin_taps_masked(const float *x7, float *workspace, float *tap_workspace,
+                                                       uint32_t n_centre, uint32_t level_mask_count,
+                                                       const NsrGridDesc *desc, void *stream);
 int nsr_hashgrid_backward_params_owner_accumulate_taps(const float *x7, const float *dy_level_major, float *grad_table,
                                                        float *workspace, float *tap_workspace, uint32_t n_centre,
                                                        uint32_t level_mask_count, int accumulate,
@@ -986,12 +997,6 @@ typedef struct NsrVmlpDesc {
 } NsrVmlpDesc;
 uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *desc);
 uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *desc, uint32_t n);
-/* The same for a call whose n_full / p_in are known: rows >= n_full (finite-difference taps, models/geometry.py:181-199)
- * keep no activations, p_in == NULL needs no second-order rows.  (n, n, 1) is the worst case the plain function returns. */
-uint64_t nsr_vmlp_backward_workspace_floats_ex(const NsrVmlpDesc *desc, uint32_t n, uint32_t n_full, int second);
-/* Launch shape of nsr_vmlp_backward: key 1 = waves of the weight-gradient kernel per layer, 2 = waves of the data-gradient
- * kernel (both default 2,048 = two per SIMD).  Call before sizing the workspace. */
-int nsr_vmlp_tune(int key, int value);
 /* The nn.Linear tensors of a reference VanillaMLP layer (models/network_utils.py:95-139): weight_v [n_out][n_in] with
  * weight_g [n_out] (old-style torch weight_norm, W[r] = g[r] v[r] / |v[r]|) or the plain weight in weight_v with weight_g
  * NULL; grad_* receive the gradients (unfold).  nsr_vmlp_fold builds the padded parameter blob from n_hidden + 1 layers,

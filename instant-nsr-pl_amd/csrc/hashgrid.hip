@@ -300,7 +300,9 @@ template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
                     uint32_t y_stride, uint32_t mask_count, uint32_t lpx, int level_major, const NsrGridDesc d,
-                    const int32_t *__restrict__ n_dev)
+                    const int32_t *__restrict__ n_dev,
+                    uint8_t *__restrict__ cross /* [L][n] or NULL: bit t = tap t + 1 left the sample's cell on this level --
+                                                   what the stencil mode of the table backward bins by (k_tap_cross) */)
 {
     // row pointer of point p (0 .. 7n-1): row-major [7n][y_stride] or level-major [L][7n][F]
     const uint64_t n7 = 7ull * n;
@@ -325,6 +327,7 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
         load_feat<F>(table, g.offset + corner_index(g, cb.c[0] + (k & 1), cb.c[1] + ((k >> 1) & 1), cb.c[2] + ((k >> 2) & 1)),
                      vb[k]);
     blend8<F>(cb, vb, TAP_ROW(i));
+    uint32_t cross_mask = 0u;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         const int a = t >> 1;  // the axis this tap moved along
@@ -332,6 +335,7 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
         xt[a] = x7[((uint64_t)(t + 1) * n + i) * 3 + a];
         const Cell ct = locate(g, xt[0], xt[1], xt[2]);
         const int dc = (int)ct.c[a] - (int)cb.c[a];
+        cross_mask |= dc != 0 ? 1u << t : 0u;
         float vt[8][F];
         if (dc == 0) {
 #pragma unroll
@@ -359,6 +363,7 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
         }
         blend8<F>(ct, vt, TAP_ROW((uint64_t)(t + 1) * n + i));
     }
+    if (cross) cross[(uint64_t)level * n + i] = (uint8_t)cross_mask;
 #undef TAP_ROW
 }
 
@@ -761,9 +766,8 @@ extern "C" int nsr_hashgrid_jac_apply_ex(const float *jac, uint32_t n, const Nsr
     return NSR_OK;
 }
 
-extern "C" int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n,
-                                         uint32_t y_stride, int y_level_major, uint32_t level_mask_count,
-                                         const NsrGridDesc *desc, const int32_t *n_dev, void *stream)
+static int forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride, int y_level_major,
+                        uint32_t level_mask_count, const NsrGridDesc *desc, const int32_t *n_dev, uint8_t *cross, void *stream)
 {
     if (int rc = check_desc(desc, "nsr_hashgrid_forward_taps")) return rc;
     NSR_REQUIRE(y_level_major || y_stride >= desc->n_levels * desc->n_features,
@@ -775,9 +779,28 @@ extern "C" int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table,
     DISPATCH_F(desc->n_features,
                hipLaunchKernelGGL((k_grid_forward_taps<F>), dim3(grid), dim3(GRID_BLOCK), 0, (hipStream_t)stream, x7,
                                   (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
-                                  *desc, n_dev));
+                                  *desc, n_dev, cross));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward_taps");
     return NSR_OK;
+}
+
+extern "C" int nsr_hashgrid_forward_taps(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n,
+                                         uint32_t y_stride, int y_level_major, uint32_t level_mask_count,
+                                         const NsrGridDesc *desc, const int32_t *n_dev, void *stream)
+{
+    return forward_taps(x7, table, y, n, y_stride, y_level_major, level_mask_count, desc, n_dev, nullptr, stream);
+}
+
+// ... and leave the per-(level, sample) crossing masks of the six taps at the head of the table backward's tap workspace
+// (nsr_hashgrid_backward_params_taps_workspace_floats for the same n): the lane already holds both cells, and
+// nsr_hashgrid_backward_params_owner_bin_taps_masked then needs no pass of its own over the 7 n positions x L levels
+extern "C" int nsr_hashgrid_forward_taps_masks(const float *x7, const nsr_half *table, nsr_half *y, uint32_t n,
+                                               uint32_t y_stride, int y_level_major, uint32_t level_mask_count,
+                                               const NsrGridDesc *desc, float *tap_workspace, void *stream)
+{
+    NSR_REQUIRE(tap_workspace, "nsr_hashgrid_forward_taps_masks: NULL tap workspace");
+    return forward_taps(x7, table, y, n, y_stride, y_level_major, level_mask_count, desc, nullptr,
+                        reinterpret_cast<uint8_t *>(tap_workspace), stream);
 }
 
 extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int dy_is_f32, uint32_t dy_stride,
@@ -1108,6 +1131,17 @@ extern "C" int nsr_hashgrid_backward_params_owner_bin_taps(const float *x7, floa
 {
     NSR_REQUIRE(n_centre > 0 && tap_workspace, "nsr_hashgrid_backward_params_owner_bin_taps: empty input / NULL workspace");
     return owner_backward(x7, nullptr, 2, 0, nullptr, workspace, 7u * n_centre, level_mask_count, 1.f, 0, desc, nullptr, 1,
+                          stream, nullptr, nullptr, nullptr, n_centre, tap_workspace);
+}
+
+// ... when nsr_hashgrid_forward_taps_masks already left the crossing masks in tap_workspace
+extern "C" int nsr_hashgrid_backward_params_owner_bin_taps_masked(const float *x7, float *workspace, float *tap_workspace,
+                                                                  uint32_t n_centre, uint32_t level_mask_count,
+                                                                  const NsrGridDesc *desc, void *stream)
+{
+    NSR_REQUIRE(n_centre > 0 && tap_workspace,
+                "nsr_hashgrid_backward_params_owner_bin_taps_masked: empty input / NULL workspace");
+    return owner_backward(x7, nullptr, 2, 0, nullptr, workspace, 7u * n_centre, level_mask_count, 1.f, 0, desc, nullptr, 5,
                           stream, nullptr, nullptr, nullptr, n_centre, tap_workspace);
 }
 

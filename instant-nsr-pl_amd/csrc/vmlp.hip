@@ -195,17 +195,6 @@ __device__ __forceinline__ float load_feature(const float *__restrict__ x, uint3
     return x[s * x_stride + k];
 }
 
-// the same without a branch: `s` is a row that exists (the caller clamps), the column is clamped, the result selected -- a
-// conditional load is a saveexec / branch pair per value in the tile loops
-template <bool SDF_IN>
-__device__ __forceinline__ float load_feature_sel(const float *__restrict__ x, uint32_t x_stride,
-                                                  const __half *__restrict__ enc, const EncLayout &el, uint64_t enc_base,
-                                                  uint32_t n_in, uint64_t s, uint32_t k, bool ok)
-{
-    const float v = load_feature<SDF_IN>(x, x_stride, enc, el, enc_base, n_in, s, k < n_in ? k : n_in - 1u);
-    return (ok && k < n_in) ? v : 0.f;
-}
-
 // chained-layer weight fragment: rows mb*16 + c, columns ib*16 + 4g .. +3 of a row-major [rows][64] matrix
 __device__ __forceinline__ f32x4 load_chain(const float *__restrict__ M, int mb, int ib, int c, int g)
 {
@@ -253,10 +242,11 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) dst[kk] = ok ? dst[kk] : 0.f;
         } else {
+            // (plain fp32 rows: the conditional loads stay -- clamped + selected they cost the colour heads 12 %, measured)
             const uint64_t eb = SDF_IN ? enc_row_base(enc_stride, sc, n_in) : 0ull;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
-                dst[kk] = load_feature_sel<SDF_IN>(x, x_stride, enc, el, eb, n_in, sc, 4 * kk + g, ok);
+                dst[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, el, eb, n_in, sc, 4 * kk + g) : 0.f;
         }
     };
     load_inputs(blockIdx.x, xnext);
@@ -361,6 +351,15 @@ k_vmlp_forward(const float *__restrict__ blob, const float *__restrict__ x, uint
 }
 
 // One wave per block: forward recompute + data gradient + weight gradient (+ second-order terms) of its tiles.
+// Round 6 measured the alternative VERDICT r5 asked for -- a data-gradient kernel at two waves per SIMD that stores dz per layer
+// as fp32 rows + a GEMM-shaped weight-gradient kernel with the rows on k -- and removed it: 735 vs 585 us over 7 x 2.6e5 points,
+// 234 vs 177 us with second-order terms, 305 vs 283 us for the colour head (profiles/r06_vmlp_split_vs_fused.json); the dz round
+// trip (256 B written + read per row and layer) costs more than the second wave buys.  What DID move this kernel (915 -> 585 us)
+// was its instruction stream, read in the ISA: softplus written with torch's `t > 20` branch made the compiler sink the three
+// transcendentals under a divergent if per value (16 saveexec / branch pairs per tile, each its own exp -> log -> rcp latency
+// chain); `cond ? load : 0` and `if (cond) store` are a branch pair EACH (now: clamped index + select, stores through a sink
+// word); __frcp_rn is a ten-instruction IEEE division (now v_rcp_f32); pointers made opaque with an empty asm lose their address
+// space and load through flat_load (now: an opaque OFFSET); d_x column blocks nobody asked for were computed and stored.
 // Register budget: 380-496 (arch + acc), one wave per SIMD, no spills -- after two fixes found in the ISA: the complete 64-bit
 // per-column offsets of the d_x stores and of the final partial stores are functions of the lane only, so the compiler computed
 // them BEFORE the tile loop and kept ~70 + ~100 registers alive across it (spilling 57-152 of them in the two-hidden-layer
@@ -456,9 +455,10 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) xd[kk] = ok ? xd[kk] : 0.f;
         } else {
+            // (plain fp32 rows: the conditional loads stay -- clamped + selected they cost the colour heads 12 %, measured)
             const uint64_t eb = SDF_IN ? enc_row_base(enc_stride, sc, n_in) : 0ull;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) xd[kk] = load_feature_sel<SDF_IN>(x, x_stride, enc, el, eb, n_in, sc, 4 * kk + g, ok);
+            for (int kk = 0; kk < KS; ++kk) xd[kk] = ok ? load_feature<SDF_IN>(x, x_stride, enc, el, eb, n_in, sc, 4 * kk + g) : 0.f;
         }
         if (SECOND) {
 #pragma unroll
@@ -483,9 +483,9 @@ k_vmlp_backward(const float *__restrict__ blob, const float *__restrict__ x, uin
         // (L1-resident, 37 KB) matrices per tile instead by hiding the pointers' loop invariance from the compiler
         const float *W0t = B.W0, *W1t = B.W1, *Wlt = B.Wl;
         if constexpr (NH == 2 || VMLP_RELOAD_WEIGHTS) {
-            uint32_t opq = 0;  // (opaque offset: see k_vmlp_forward)
-            asm volatile("" : "+s"(opq));
-            W0t += opq; W1t += opq; Wlt += opq;
+            // (opaque POINTERS here, flat_load and all: with an opaque offset the two-hidden-layer variants measured 12 % slower --
+            // the compiler keeps more of the address arithmetic live across the tile)
+            asm volatile("" : "+s"(W0t), "+s"(W1t), "+s"(Wlt));
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -803,555 +803,6 @@ k_vmlp_reduce(const float *__restrict__ partials, float *__restrict__ grad, uint
     if (b1 > b0) unsafeAtomicAdd(grad + k, (s0 + s1) + (s2 + s3));
 }
 
-// ====================================================================================================================
-// Round 6 -- the backward as TWO kernels (VERDICT r5 #1a; reference models/network_utils.py:95-139 is a stack of
-// nn.Linear whose autograd backward is one data-gradient GEMM and one weight-gradient GEMM per layer).
-//
-// k_vmlp_backward above does everything in one wave per SIMD: forward recompute, data gradient, and the weight gradient,
-// whose SAMPLE index has to sit on the MFMA's k axis -- both operands go through a wave-private LDS tile and dW lives in
-// ~100 accumulator registers, which is what pins the kernel at one wave per SIMD (25 % MFMA busy by PMC).  Split:
-//
-//  * k_vmlp_dgrad: forward recompute + data gradient, all in the transposed register chain of the forward kernel (no LDS,
-//    no dW accumulators -> two waves per SIMD).  It leaves the pre-activation gradients dz_l (and the activations the weight
-//    gradients need) as fp32 ROWS [sample][64] -- in the D layout a lane holds neurons 16 b + 4 g .. + 3 of its sample: one
-//    16-byte store per block.
-//  * k_vmlp_wgrad: dW_l = sum_s dz_l[s]^T act_{l-1}[s] as a GEMM with the rows on k, operands straight from those rows.
-//    Both the MFMA's reduction index and its row / column indices are dummies, so lane (c, g) takes samples 4 g + kk as its
-//    four k-steps, neurons 4 c .. 4 c + 3 as its four row blocks (ONE 16-byte load per k-step gives A for all four blocks)
-//    and, for the tile-major hash encoding, level c as its two column blocks (ONE 16-byte load gives B for all four k-steps).
-//    dW accumulates in 16-64 registers per wave, a partial per wave, summed by k_vmlp_reduce.  Bias gradients are the
-//    column sums of the A operand the wave loads anyway.
-//  * What stays rank-1 stays in registers of the data-gradient kernel: the finite-difference tap tiles' contribution to the
-//    last layer's row 0 (d * a) and the second-order du = s (W0 P); they leave as an 80-float partial per wave.
-struct SplitWs {
-    float *g0;     // [n][64]  dL/d(pre-activation of hidden layer 0)
-    float *g1;     // [n][64]  two hidden layers: ... of hidden layer 1
-    float *a0;     // [.][64]  activations of hidden layer 0 (one hidden layer: rows of the non-tap tiles only)
-    float *a1;     // [n][64]  two hidden layers: activations of hidden layer 1
-    float *q;      // [n][64]  second-order terms: s * u
-    float *small;  // [blocks][80] per data-gradient wave: du[64] (-> dWl row 0) | dbl[16]; NULL: neither taps nor second order
-    float *sink;   // [blocks][64] where stores of columns / rows that are not asked for land (never read)
-};
-constexpr int VSMALL = 80;
-
-template <int KS, int NH, int ACT, bool SDF_IN, bool SECOND>
-__global__ void __launch_bounds__(64, (KS >= 10 && SDF_IN) ? 1 : 2)  // (the 40-wide [x | encoding] variants need > 256 registers)
-k_vmlp_dgrad(const float *__restrict__ blob, const float *__restrict__ x, uint32_t x_stride,
-             const __half *__restrict__ enc, uint32_t enc_stride, uint32_t n_in,
-             const float *__restrict__ d_out /* [n_full][16] */, const float *__restrict__ d_out_col0,
-             const float *__restrict__ p_in /* [n][KS*4], SECOND */, float *__restrict__ d_x, uint32_t dx_stride,
-             uint32_t dx_first, uint32_t dx_count, uint32_t dx_lm_features, const SplitWs ws, uint32_t n, uint32_t n_full,
-             const int32_t *__restrict__ n_dev)
-{
-    static_assert(!SECOND || NH == 1, "second-order terms: one hidden layer");
-    const uint32_t n_live = live_count(n, n_dev);
-    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    const Blob B = split_blob<KS, NH>(blob);
-    constexpr int IN_PAD = KS * 4;
-    constexpr bool PERM = SDF_IN && KS == 9;
-    constexpr int NB0 = (IN_PAD + 15) / 16;
-    float wf0[4][KS];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = B.W0[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g)];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 du[4] = {zero4, zero4, zero4, zero4};
-    float dbl0 = 0.f;
-    const uint32_t n_tiles = (n_live + 15) / 16;
-    const uint32_t lm_shift = dx_lm_features ? 31u - (uint32_t)__clz((int)dx_lm_features) : 0u;
-    // d_x column blocks.  The MFMA's row index is a dummy too: when only the 32 encoded columns of the [x | encoding] input are
-    // asked for (what the table backward reads), two blocks starting at column 3 cover them -- 32 MFMAs instead of 48
-    const bool enc_only = PERM && dx_first >= 3u && dx_first + dx_count <= 35u;
-    const int colbase = enc_only ? 3 : 0;
-    // ... and no block beyond the last column asked for (the colour heads: 32 of 36 padded inputs -> two blocks, not three)
-    const int nfb_want = (int)((dx_first + dx_count - colbase + 15u) / 16u);
-    const int nfb = enc_only ? 2 : (nfb_want < NB0 ? nfb_want : NB0);
-    uint32_t col_part[NB0 * 4], col_ok = 0u;
-#pragma unroll
-    for (int q = 0; q < NB0 * 4; ++q) {
-        const uint32_t col = colbase + (q >> 2) * 16 + 4 * g + (q & 3);
-        const bool ok = (q >> 2) < nfb && col >= dx_first && col < dx_first + dx_count;
-        const uint32_t k = ok ? col - dx_first : 0u;
-        col_part[q] = dx_lm_features ? ((((k >> lm_shift) * n) << lm_shift) | (k & (dx_lm_features - 1u))) : k;
-        col_ok |= ok ? (1u << q) : 0u;
-    }
-    float *sink = ws.sink + (uint64_t)blockIdx.x * 64 + lane;
-    float xnext[KS];
-    f32x4 donext;
-    const EncLayout el = enc_layout(enc_stride, n);
-    auto load_inputs = [&](uint32_t tile, float (&xd)[KS], f32x4 &dd) {
-        const uint64_t sn = (uint64_t)tile * 16 + c;
-        const bool ok = tile < n_tiles && sn < n_live;
-        const uint64_t sc = ok ? sn : 0ull;  // (a row that exists: loads are unconditional, results selected)
-        if constexpr (PERM) {
-            load_features_perm(x, x_stride, enc, enc_stride, sc, g, n, xd);
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) xd[kk] = ok ? xd[kk] : 0.f;
-        } else {
-            const uint64_t eb = SDF_IN ? enc_row_base(enc_stride, sc, n_in) : 0ull;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) xd[kk] = load_feature_sel<SDF_IN>(x, x_stride, enc, el, eb, n_in, sc, 4 * kk + g, ok);
-        }
-        dd = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            if (sn < n_full) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) dd[kk] = d_out[sn * 16 + 4 * kk + g];
-            } else {
-                dd[3] = d_out_col0[sn - n_full];   // every lane of the sample: the tap fast path reads it from slot 3
-                if (g == 0) dd[0] = dd[3];         // B-layout slot of output column 0
-            }
-        }
-    };
-    load_inputs(blockIdx.x, xnext, donext);
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t s = (uint64_t)tile * 16 + c;
-        const bool valid = s < n_live;
-        // the chained layers' fragments are re-read per tile (L1-resident): hoisted they would cost the second wave per SIMD
-        uint32_t opq = 0;  // (opaque offset, not opaque pointers: the loads stay global_load, see k_vmlp_forward)
-        asm volatile("" : "+s"(opq));
-        const float *W0t = B.W0 + opq, *W1t = B.W1 + opq, *Wlt = B.Wl + opq, *b0t = B.b0 + opq, *b1t = B.b1 + opq;
-        // (biases and the last layer's row 0 -- D layout -- likewise: 48 registers that buy nothing when hoisted)
-#define NSR_B0F(mb) (*reinterpret_cast<const f32x4 *>(b0t + (mb) * 16 + 4 * g))
-#define NSR_B1F(mb) (*reinterpret_cast<const f32x4 *>(b1t + (mb) * 16 + 4 * g))
-#define NSR_UF(mb) (*reinterpret_cast<const f32x4 *>(Wlt + (mb) * 16 + 4 * g))
-        if constexpr (NH == 2 || SECOND) {  // (register budget of the two-hidden-layer / second-order variants)
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = W0t[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g)];
-        }
-        float xin[KS], pb[KS];
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            xin[kk] = xnext[kk];
-            // (P is asked for here, not a tile ahead: its latency hides behind the forward chain, nine registers less)
-            pb[kk] = (SECOND && valid) ? p_in[s * IN_PAD + kmap<PERM>(kk, g)] : 0.f;
-        }
-        f32x4 dob = donext;
-        load_inputs(tile + gridDim.x, xnext, donext);
-        f32x4 a0[4], s0[ACT == 1 ? 4 : 1], a1[4], s1[(NH == 2 && ACT == 1) ? 4 : 1];
-#define NSR_S0(mb, r) (ACT == 1 ? s0[ACT == 1 ? (mb) : 0][r] : (a0[mb][r] > 0.f ? 1.f : 0.f))
-#define NSR_S1(mb, r) (ACT == 1 ? s1[(NH == 2 && ACT == 1) ? (mb) : 0][r] : (a1[mb][r] > 0.f ? 1.f : 0.f))
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            f32x4 z = NSR_B0F(mb);
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) z = mfma4(wf0[mb][kk], xin[kk], z);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float av, sv;
-                act_both<ACT>(z[r], av, sv);
-                a0[mb][r] = av;
-                if constexpr (ACT == 1) s0[mb][r] = sv;
-            }
-        }
-        if constexpr (NH == 2) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                f32x4 z = NSR_B1F(mb);
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib) {
-                    const f32x4 w = load_chain(W1t, mb, ib, c, g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) z = mfma4(w[r], a0[ib][r], z);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float av, sv;
-                    act_both<ACT>(z[r], av, sv);
-                    a1[mb][r] = av;
-                    if constexpr (ACT == 1) s1[mb][r] = sv;
-                }
-            }
-        }
-        const bool tap_tile = (uint64_t)tile * 16 >= n_full;  // finite-difference taps: only d out[0] is non-zero
-        const float d_tap = tap_tile ? dob[3] : 0.f;
-        if (s >= n_full) dob[3] = 0.f;
-        f32x4 dz_last[4];
-        if (tap_tile) {
-            if (g == 0) dbl0 += d_tap;
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) {
-                const f32x4 u = NSR_UF(fb);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dz_last[fb][r] = d_tap * u[r] * ((NH == 2) ? NSR_S1(fb, r) : NSR_S0(fb, r));
-                    du[fb][r] += d_tap * ((NH == 2) ? a1[fb][r] : a0[fb][r]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) {
-                f32x4 acc = zero4;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = mfma4(Wlt[(4 * kk + g) * W + fb * 16 + c], dob[kk], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dz_last[fb][r] = acc[r] * ((NH == 2) ? NSR_S1(fb, r) : NSR_S0(fb, r));
-            }
-        }
-        const uint64_t roff = s * 64 + 4 * g;  // this lane's 16 bytes per block in the [.][64] workspaces
-        f32x4 dz0[4];
-        if constexpr (NH == 2) {
-            if (valid) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    *reinterpret_cast<f32x4 *>(ws.g1 + roff + mb * 16) = dz_last[mb];
-                    *reinterpret_cast<f32x4 *>(ws.a0 + roff + mb * 16) = a0[mb];
-                    *reinterpret_cast<f32x4 *>(ws.a1 + roff + mb * 16) = a1[mb];
-                }
-            }
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) {
-                f32x4 acc = zero4;
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc = mfma4(W1t[(nb * 16 + 4 * g + r) * W + fb * 16 + c], dz_last[nb][r], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dz0[fb][r] = acc[r] * NSR_S0(fb, r);
-            }
-        } else {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) dz0[mb] = dz_last[mb];
-            if (valid && !tap_tile) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4 *>(ws.a0 + roff + mb * 16) = a0[mb];
-            }
-        }
-        if (SECOND) {
-            f32x4 q[4];
-            uint32_t opq2 = 0;
-            asm volatile("" : "+s"(opq2));
-            const float *W0s = B.W0 + opq2;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) wf0[mb][kk] = W0s[(mb * 16 + c) * IN_PAD + kmap<PERM>(kk, g)];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                f32x4 dq = zero4;
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) dq = mfma4(wf0[mb][kk], pb[kk], dq);  // (W0 P)^T
-                const f32x4 u = NSR_UF(mb);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sg = NSR_S0(mb, r);
-                    q[mb][r] = sg * u[r];
-                    du[mb][r] += sg * dq[r];
-                    const float curv = ACT == 1 ? 100.f * sg * (1.f - sg) : 0.f;  // (0 exactly where torch takes its linear branch: s = 1)
-                    dz0[mb][r] += curv * u[r] * dq[r];
-                }
-            }
-            if (valid) {
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4 *>(ws.q + roff + mb * 16) = q[mb];
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) *reinterpret_cast<f32x4 *>(ws.g0 + roff + mb * 16) = dz0[mb];
-        }
-        // ---- input gradient dX^T = W0^T dz0^T ----------------------------------------------------------------------
-        if (d_x) {
-            float *row = d_x + (dx_lm_features ? (s << lm_shift) : s * dx_stride);
-#pragma unroll
-            for (int fb = 0; fb < NB0; ++fb) {
-                if (fb >= nfb) break;
-                f32x4 acc = zero4;
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = colbase + fb * 16 + c;
-                        const float wv = W0t[(nb * 16 + 4 * g + r) * IN_PAD + (col < IN_PAD ? col : IN_PAD - 1)];
-                        const float wt = col < IN_PAD ? wv : 0.f;  // (clamped index + select: no branch per load)
-                        acc = mfma4(wt, dz0[nb][r], acc);
-                    }
-                // unconditional stores: a column that is not asked for (or a row behind the live count) goes to this lane's word
-                // of the sink instead of being skipped -- a skipped store is a saveexec / branch pair per column (ISA, round 6)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float *dst = (valid && (col_ok & (1u << (fb * 4 + r)))) ? row + col_part[fb * 4 + r] : sink;
-                    *dst = acc[r];
-                }
-            }
-        }
-    }
-#undef NSR_S0
-#undef NSR_S1
-#undef NSR_B0F
-#undef NSR_B1F
-#undef NSR_UF
-    if (ws.small) {
-        float *P = ws.small + (uint64_t)blockIdx.x * VSMALL;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = du[mb][r];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (c == 0) P[mb * 16 + 4 * g + r] = v;
-            }
-        float v = dbl0;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane < 16) P[64 + lane] = lane == 0 ? v : 0.f;
-    }
-}
-
-// first-layer column that lane c of column block nb stands for in the weight-gradient GEMM (-1: none).  PERM ([x | 32 encoded
-// features]): blocks 0 / 1 = the two features of level c, block 2 = x_c (c < 3) and the padding column.
-template <int KS, bool PERM>
-__device__ __forceinline__ int wgrad_col(int nb, int c)
-{
-    if constexpr (PERM) return nb < 2 ? 3 + 2 * c + nb : (c < 3 ? c : (c == 3 ? 35 : -1));
-    else return nb * 16 + c < KS * 4 ? nb * 16 + c : -1;
-}
-
-// grid (P, NH + 1): y = 0 the first layer, y = NH the output layer, y = 1 of 2 the hidden 64 x 64 layer.
-template <int KS, int NH, bool SDF_IN, bool SECOND>
-__global__ void __launch_bounds__(64, 2)
-k_vmlp_wgrad(const float *__restrict__ x, uint32_t x_stride, const __half *__restrict__ enc, uint32_t enc_stride,
-             uint32_t n_in, const float *__restrict__ d_out, const float *__restrict__ d_out_col0,
-             const float *__restrict__ p_in, const SplitWs ws, float *__restrict__ partials, uint32_t blob_floats,
-             uint32_t n, uint32_t n_full, const int32_t *__restrict__ n_dev)
-{
-    const uint32_t n_live = live_count(n, n_dev);
-    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    constexpr int IN_PAD = KS * 4;
-    constexpr bool PERM = SDF_IN && KS == 9;
-    constexpr int NB0 = (IN_PAD + 15) / 16;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    float *P = partials + (uint64_t)blockIdx.x * blob_floats;
-    float *pW0 = P, *pb0 = pW0 + W * IN_PAD;
-    float *pW1 = pb0 + W, *pb1 = pW1 + (NH == 2 ? W * W : 0);
-    float *pWl = (NH == 2) ? pb1 + W : pW1;
-    float *pbl = pWl + 16 * W;
-    const int layer = blockIdx.y;
-    if (layer == 0) {
-        // ---- dW0[64][IN_PAD] = sum_s g0[s]^T in[s]  (+ q[s]^T P[s]) ;  db0 = column sums of g0 ---------------------------
-        const uint32_t n_tiles = (n_live + 15) / 16;
-        const EncLayout el = enc_layout(enc_stride, n);
-        const bool tile16 = PERM && (enc_stride & 0x40000000u) && ((uintptr_t)enc & 15) == 0;
-        f32x4 acc[4][NB0];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB0; ++nb) acc[mb][nb] = zero4;
-        f32x4 bsum = zero4;
-        f32x4 a_n[4], q_n[SECOND ? 4 : 1];
-        float b_n[4][NB0], p_n[SECOND ? 4 : 1][NB0];
-        auto load = [&](uint32_t tile, f32x4 (&a)[4], float (&b)[4][NB0], f32x4 (&qa)[SECOND ? 4 : 1],
-                        float (&pb)[SECOND ? 4 : 1][NB0]) {
-            const uint64_t r0 = (uint64_t)tile * 16 + 4 * g;
-            const bool any = tile < n_tiles;
-            if constexpr (PERM) {
-                if (tile16 && any) {
-                    const uint4 raw = *reinterpret_cast<const uint4 *>(enc + (uint64_t)tile * 512 + c * 32 + 8 * g);
-                    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const __half2 h = *reinterpret_cast<const __half2 *>(&w[kk]);
-                        b[kk][0] = __low2float(h); b[kk][1] = __high2float(h);
-                    }
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const uint64_t row = r0 + kk;
-                const bool ok = any && row < n_live;
-                a[kk] = ok ? *reinterpret_cast<const f32x4 *>(ws.g0 + row * 64 + 4 * c) : zero4;
-                if constexpr (SECOND) qa[kk] = ok ? *reinterpret_cast<const f32x4 *>(ws.q + row * 64 + 4 * c) : zero4;
-                if constexpr (PERM) {
-                    if (!tile16) {
-                        if (ok) {
-                            const uint64_t eb = enc_row_base(enc_stride, row, n_in);
-                            const uint32_t col = 2u * c;  // the lane's level: features 2 c, 2 c + 1
-                            const __half2 h = *reinterpret_cast<const __half2 *>(enc + eb + (uint64_t)(col >> el.fs) * el.A + (col & el.fm));
-                            b[kk][0] = __low2float(h); b[kk][1] = __high2float(h);
-                        }
-                    }
-                    if (!ok) b[kk][0] = b[kk][1] = 0.f;
-                    b[kk][2] = (ok && c < 3) ? x[row * x_stride + c] * 2.f - 1.f : 0.f;
-                } else {
-                    const uint64_t eb = (SDF_IN && ok) ? enc_row_base(enc_stride, row, n_in) : 0ull;
-#pragma unroll
-                    for (int nb = 0; nb < NB0; ++nb)
-                        b[kk][nb] = ok ? load_feature<SDF_IN>(x, x_stride, enc, el, eb, n_in, row, (uint32_t)(nb * 16 + c)) : 0.f;
-                }
-                if constexpr (SECOND) {
-#pragma unroll
-                    for (int nb = 0; nb < NB0; ++nb) {
-                        const int col = wgrad_col<KS, PERM>(nb, c);
-                        pb[kk][nb] = (ok && col >= 0) ? p_in[row * IN_PAD + col] : 0.f;
-                    }
-                }
-            }
-        };
-        load(blockIdx.x, a_n, b_n, q_n, p_n);
-        for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            f32x4 a[4], qa[SECOND ? 4 : 1];
-            float b[4][NB0], pb[SECOND ? 4 : 1][NB0];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                a[kk] = a_n[kk];
-                if constexpr (SECOND) qa[kk] = q_n[kk];
-#pragma unroll
-                for (int nb = 0; nb < NB0; ++nb) {
-                    b[kk][nb] = b_n[kk][nb];
-                    if constexpr (SECOND) pb[kk][nb] = p_n[kk][nb];
-                }
-            }
-            load(tile + gridDim.x, a_n, b_n, q_n, p_n);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bsum += a[kk];
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB0; ++nb) {
-                        acc[mb][nb] = mfma4(a[kk][mb], b[kk][nb], acc[mb][nb]);
-                        if constexpr (SECOND) acc[mb][nb] = mfma4(qa[kk][mb], pb[kk][nb], acc[mb][nb]);
-                    }
-            }
-        }
-        // block (mb, nb), D register r of lane (c, g): neuron 4 (4 g + r) + mb, column wgrad_col(nb, c)
-#pragma unroll
-        for (int nb = 0; nb < NB0; ++nb) {
-            const int col = wgrad_col<KS, PERM>(nb, c);
-            if (col < 0) continue;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pW0[(16 * g + 4 * r + mb) * IN_PAD + col] = acc[mb][nb][r];
-        }
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            float v = bsum[mb];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (g == 0) pb0[4 * c + mb] = v;
-        }
-        return;
-    }
-    if (NH == 2 && layer == 1) {
-        // ---- dW1[64][64] = sum_s g1[s]^T a0[s] ;  db1 ------------------------------------------------------------------
-        const uint32_t n_tiles = (n_live + 15) / 16;
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = zero4;
-        f32x4 bsum = zero4, a_n[4], b_n[4];
-        auto load = [&](uint32_t tile, f32x4 (&a)[4], f32x4 (&b)[4]) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const uint64_t row = (uint64_t)tile * 16 + 4 * g + kk;
-                const bool ok = tile < n_tiles && row < n_live;
-                a[kk] = ok ? *reinterpret_cast<const f32x4 *>(ws.g1 + row * 64 + 4 * c) : zero4;
-                b[kk] = ok ? *reinterpret_cast<const f32x4 *>(ws.a0 + row * 64 + 4 * c) : zero4;
-            }
-        };
-        load(blockIdx.x, a_n, b_n);
-        for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            f32x4 a[4], b[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { a[kk] = a_n[kk]; b[kk] = b_n[kk]; }
-            load(tile + gridDim.x, a_n, b_n);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bsum += a[kk];
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = mfma4(a[kk][mb], b[kk][nb], acc[mb][nb]);
-            }
-        }
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pW1[(16 * g + 4 * r + mb) * W + 4 * c + nb] = acc[mb][nb][r];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            float v = bsum[mb];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (g == 0) pb1[4 * c + mb] = v;
-        }
-        return;
-    }
-    {
-        // ---- dWl[16][64] = sum_s dOut[s]^T a_last[s] over the rows of the non-tap tiles ;  dbl -----------------------------
-        const float *al = NH == 2 ? ws.a1 : ws.a0;
-        const uint32_t full_pad = min(n_live, (n_full + 15u) & ~15u);
-        const uint32_t n_tiles = (full_pad + 15) / 16;
-        f32x4 acc[4] = {zero4, zero4, zero4, zero4};
-        float bsum = 0.f, a_n[4];
-        f32x4 b_n[4];
-        auto load = [&](uint32_t tile, float (&a)[4], f32x4 (&b)[4]) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const uint64_t row = (uint64_t)tile * 16 + 4 * g + kk;
-                const bool ok = tile < n_tiles && row < full_pad;
-                a[kk] = 0.f;
-                if (ok) a[kk] = row < n_full ? d_out[row * 16 + c] : (c == 0 ? d_out_col0[row - n_full] : 0.f);
-                b[kk] = ok ? *reinterpret_cast<const f32x4 *>(al + row * 64 + 4 * c) : zero4;
-            }
-        };
-        load(blockIdx.x, a_n, b_n);
-        for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            float a[4];
-            f32x4 b[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { a[kk] = a_n[kk]; b[kk] = b_n[kk]; }
-            load(tile + gridDim.x, a_n, b_n);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bsum += a[kk];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma4(a[kk], b[kk][nb], acc[nb]);
-            }
-        }
-        // block nb, D register r of lane (c, g): output 4 g + r, column 4 c + nb
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pWl[(4 * g + r) * W + 4 * c + nb] = acc[nb][r];
-        float v = bsum;
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (g == 0) pbl[c] = v;
-    }
-}
-
-// grad[dst(k)] += sum over the per-wave partials[b][k], k < count.  remap: the 80-float partials of k_vmlp_dgrad -- entries
-// 0..63 join row 0 of the last layer's weight (wl_off), 64..79 its bias (bl_off)
-__global__ void __launch_bounds__(256)
-k_vmlp_reduce_ex(const float *__restrict__ partials, float *__restrict__ grad, uint32_t count, uint32_t stride,
-                 uint32_t n_blocks, int remap, uint32_t wl_off, uint32_t bl_off)
-{
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= count) return;
-    const uint32_t b0 = blockIdx.y * VRED_SEG, b1 = min(n_blocks, b0 + VRED_SEG);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    uint32_t b = b0;
-    for (; b + 4 <= b1; b += 4) {
-        s0 += partials[(uint64_t)(b + 0) * stride + k];
-        s1 += partials[(uint64_t)(b + 1) * stride + k];
-        s2 += partials[(uint64_t)(b + 2) * stride + k];
-        s3 += partials[(uint64_t)(b + 3) * stride + k];
-    }
-    for (; b < b1; ++b) s0 += partials[(uint64_t)b * stride + k];
-    const uint32_t dst = remap ? (k < 64u ? wl_off + k : bl_off + (k - 64u)) : k;
-    if (b1 > b0) unsafeAtomicAdd(grad + dst, (s0 + s1) + (s2 + s3));
-}
-
 int check_vmlp(const NsrVmlpDesc *d, const char *who)
 {
     NSR_REQUIRE(d != nullptr, "%s: desc is NULL", who);
@@ -1461,38 +912,9 @@ extern "C" uint64_t nsr_vmlp_blob_floats(const NsrVmlpDesc *d)
     return (uint64_t)W * d->in_pad + W + (d->n_hidden == 2 ? (uint64_t)W * W + W : 0) + 16 * W + 16;
 }
 
-// Workspace of nsr_vmlp_backward: [weight-gradient partials: P x blob][data-gradient partials: D x 80][row buffers].
-// Row buffers, 64 floats per row: one hidden layer -- g0 [n], a0 [rows of the non-tap tiles], q [n] (second order);
-// two hidden layers -- g0, g1, a0, a1 [n].
-struct VmlpTune { int split; uint32_t wgrad_waves, dgrad_waves; };
-static VmlpTune g_vmlp_tune = {1, 2048u, 2048u};
-static uint32_t vmlp_split_p(uint32_t n) { const uint32_t t = nsr_div_up(n, 16); return t < g_vmlp_tune.wgrad_waves ? (t ? t : 1u) : g_vmlp_tune.wgrad_waves; }
-static uint32_t vmlp_split_d(uint32_t n) { const uint32_t t = nsr_div_up(n, 16); return t < g_vmlp_tune.dgrad_waves ? (t ? t : 1u) : g_vmlp_tune.dgrad_waves; }
-static uint64_t vmlp_pad16(uint64_t v) { return (v + 15ull) & ~15ull; }
-
-extern "C" uint64_t nsr_vmlp_backward_workspace_floats_ex(const NsrVmlpDesc *d, uint32_t n, uint32_t n_full, int second)
-{
-    if (!d) return 0;
-    const uint64_t bf = nsr_vmlp_blob_floats(d), rows = vmlp_pad16(n), full = vmlp_pad16(n_full < n ? n_full : n);
-    const uint64_t old_form = (uint64_t)vmlp_blocks(n) * bf;
-    const uint64_t heads = vmlp_pad16((uint64_t)vmlp_split_p(n) * bf) + vmlp_pad16((uint64_t)vmlp_split_d(n) * (VSMALL + 64));
-    const uint64_t bufs = d->n_hidden == 2 ? 4 * rows * 64 : (rows + full + (second ? rows : 0)) * 64;
-    return old_form > heads + bufs ? old_form : heads + bufs;
-}
-
 extern "C" uint64_t nsr_vmlp_backward_workspace_floats(const NsrVmlpDesc *d, uint32_t n)
 {
-    return nsr_vmlp_backward_workspace_floats_ex(d, n, n, 1);
-}
-
-// development switches (tools/vmlp_split_bench.py): 0 = split on / off, 1 = weight-gradient waves, 2 = data-gradient waves
-extern "C" int nsr_vmlp_tune(int key, int value)
-{
-    if (key == 0) g_vmlp_tune.split = value;
-    else if (key == 1 && value > 0) g_vmlp_tune.wgrad_waves = (uint32_t)value;
-    else if (key == 2 && value > 0) g_vmlp_tune.dgrad_waves = (uint32_t)value;
-    else { nsr_set_error("nsr_vmlp_tune: unknown key %d / value %d", key, value); return NSR_ERR_INVALID; }
-    return NSR_OK;
+    return d ? (uint64_t)vmlp_blocks(n) * nsr_vmlp_blob_floats(d) : 0;
 }
 
 #define VMLP_DISPATCH(KERNEL, ...)                                                                                      \
@@ -1580,66 +1002,6 @@ extern "C" int nsr_vmlp_backward(const NsrVmlpDesc *desc, const float *blob, con
     const bool sdf = enc != nullptr, second = p_in != nullptr;
     const __half *e = (const __half *)enc;
     if (dx_count == 0) { dx_first = 0; dx_count = desc->n_in; }
-    if (g_vmlp_tune.split && n > 0) {
-        hipStream_t st = (hipStream_t)stream;
-        const uint32_t PW = vmlp_split_p(n), PD = vmlp_split_d(n);
-        const uint64_t rows = vmlp_pad16(n), full = vmlp_pad16(n_full);
-        SplitWs ws;
-        memset(&ws, 0, sizeof(ws));
-        float *wpart = partials;
-        float *small = wpart + vmlp_pad16((uint64_t)PW * bf);
-        float *sinkp = small + vmlp_pad16((uint64_t)PD * VSMALL);
-        float *buf = small + vmlp_pad16((uint64_t)PD * (VSMALL + 64));
-        ws.sink = sinkp;
-        ws.g0 = buf; buf += rows * 64;
-        if (nh == 2) { ws.g1 = buf; buf += rows * 64; ws.a0 = buf; buf += rows * 64; ws.a1 = buf; buf += rows * 64; }
-        else { ws.a0 = buf; buf += full * 64; if (second) { ws.q = buf; buf += rows * 64; } }
-        const bool use_small = second || n_full < n;
-        ws.small = use_small ? small : nullptr;
-#define VMLP_CASE(KERNEL, KSV, ...)                                                                                     \
-    if (!done_ && ks == KSV) {                                                                                          \
-        done_ = true;                                                                                                   \
-        if (nh == 1 && act == 0 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, 0, false, false>), __VA_ARGS__); \
-        else if (nh == 2 && act == 0 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 2, 0, false, false>), __VA_ARGS__); \
-        else if (nh == 1 && act == 1 && sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, false>), __VA_ARGS__); \
-        else if (nh == 1 && act == 1 && sdf && second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, true, true>), __VA_ARGS__); \
-        else if (nh == 1 && act == 1 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, false>), __VA_ARGS__); \
-        else if (nh == 1 && act == 1 && !sdf && second) hipLaunchKernelGGL((KERNEL<KSV, 1, 1, false, true>), __VA_ARGS__); \
-        else { nsr_set_error("nsr_vmlp_backward: combination not compiled (n_hidden=%d act=%d sdf=%d second=%d)", nh,   \
-                             act, (int)sdf, (int)second); return NSR_ERR_INVALID; }                                     \
-    }
-        VMLP_DISPATCH(k_vmlp_dgrad, dim3(PD), dim3(64), 0, st, blob, x, x_stride, e, enc_stride, desc->n_in, d_out,
-                      d_out_col0, p_in, d_x, dx_stride, dx_first, dx_count, dx_level_major_features, ws, n, n_full, n_dev);
-#undef VMLP_CASE
-        NSR_CHECK_LAUNCH("nsr_vmlp_backward(dgrad)");
-        // (the weight-gradient kernel does not depend on the activation: softplus and ReLU networks share instantiations)
-#define VMLP_CASE(KERNEL, KSV, ...)                                                                                     \
-    if (!done_ && ks == KSV) {                                                                                          \
-        done_ = true;                                                                                                   \
-        if (nh == 1 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, false, false>), __VA_ARGS__);                \
-        else if (nh == 2 && !sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 2, false, false>), __VA_ARGS__);           \
-        else if (nh == 1 && sdf && !second) hipLaunchKernelGGL((KERNEL<KSV, 1, true, false>), __VA_ARGS__);             \
-        else if (nh == 1 && sdf && second) hipLaunchKernelGGL((KERNEL<KSV, 1, true, true>), __VA_ARGS__);               \
-        else if (nh == 1 && !sdf && second) hipLaunchKernelGGL((KERNEL<KSV, 1, false, true>), __VA_ARGS__);             \
-        else { nsr_set_error("nsr_vmlp_backward: combination not compiled"); return NSR_ERR_INVALID; }                  \
-    }
-        VMLP_DISPATCH(k_vmlp_wgrad, dim3(PW, nh + 1), dim3(64), 0, st, x, x_stride, e, enc_stride, desc->n_in, d_out,
-                      d_out_col0, p_in, ws, wpart, bf, n, n_full, n_dev);
-#undef VMLP_CASE
-        NSR_CHECK_LAUNCH("nsr_vmlp_backward(wgrad)");
-        if (!accumulate)
-            NSR_REQUIRE(hipMemsetAsync(grad_blob, 0, bf * sizeof(float), st) == hipSuccess,
-                        "nsr_vmlp_backward: hipMemsetAsync failed");
-        hipLaunchKernelGGL(k_vmlp_reduce_ex, dim3(nsr_div_up(bf, 256), nsr_div_up(PW, VRED_SEG)), dim3(256), 0, st, wpart,
-                           grad_blob, bf, bf, PW, 0, 0u, 0u);
-        if (use_small) {
-            const uint32_t wl_off = bf - 16u - 16u * (uint32_t)W, bl_off = bf - 16u;
-            hipLaunchKernelGGL(k_vmlp_reduce_ex, dim3(1, nsr_div_up(PD, VRED_SEG)), dim3(256), 0, st, small, grad_blob,
-                               (uint32_t)VSMALL, (uint32_t)VSMALL, PD, 1, wl_off, bl_off);
-        }
-        NSR_CHECK_LAUNCH("nsr_vmlp_backward(reduce)");
-        return NSR_OK;
-    }
 #define VMLP_CASE(KERNEL, KSV, ...)                                                                                     \
     if (!done_ && ks == KSV) {                                                                                          \
         done_ = true;                                                                                                   \

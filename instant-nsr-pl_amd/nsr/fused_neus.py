@@ -761,14 +761,23 @@ class FusedNeuSStep:
             # 180 / 660 us: a tile's operands then sit in 16 far-apart lines.)  NSR_NEUS_ENC_LAYOUT=0 selects row-major.
             lay = ENC_LAYOUT
             encd = torch.empty(((T * N + 15) // 16 * 16, self.n_enc), dtype=F16, device=dev)
-            if self.fd:  # the sample's corners are gathered once and shared with its six taps
+            tws = None
+            if self.fd and self.fold_taps and compute_grads and N > 0:
+                # stencil mode of the table backward: the 7-tap encode leaves the taps' crossing masks in its tap workspace
+                tws = torch.empty(int(lib.nsr_hashgrid_backward_params_taps_workspace_floats(_byref(desc), N)), dtype=F32,
+                                  device=dev)
+                check(lib.nsr_hashgrid_forward_taps_masks(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, lay, mc,
+                                                          _byref(desc), ptr(tws), s), "nsr_hashgrid_forward_taps_masks")
+                positions_ready = torch.cuda.Event()  # (the binning on the helper stream now waits for the encode's masks)
+                positions_ready.record(torch.cuda.current_stream())
+            elif self.fd:  # the sample's corners are gathered once and shared with its six taps
                 check(lib.nsr_hashgrid_forward_taps(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, lay, mc, _byref(desc),
                                                     None, s), "nsr_hashgrid_forward_taps")
             else:  # analytic normals: keep the per-level Jacobian (384 B / sample) instead of two more table gathers
                 jac = torch.empty(N * self.n_enc * 3, dtype=F32, device=dev)
                 check(lib.nsr_hashgrid_forward_jac(ptr(x7), ptr(table), ptr(encd), N, self.n_enc, lay, mc, _byref(desc),
                                                    ptr(jac), None, s), "nsr_hashgrid_forward_jac")
-            gws = bin_event = tws = None
+            gws = bin_event = None
             if compute_grads and N > 0:
                 # the table backward's binning needs only the positions: it runs on a helper stream underneath the whole
                 # forward pass (count / scan / fill: 0.18 ms at 5e5 points, 0.5 ms at the 7 N points of the C5 stencil);
@@ -777,15 +786,12 @@ class FusedNeuSStep:
                 gws = torch.empty(nws, dtype=F32, device=dev)
                 if getattr(self, "_helper", None) is None:
                     self._helper = _shared_stream(dev, "helper")
-                if self.fd and self.fold_taps:  # in-cell taps are folded into their sample's items (stencil mode)
-                    tws = torch.empty(int(lib.nsr_hashgrid_backward_params_taps_workspace_floats(_byref(desc), N)), dtype=F32,
-                                      device=dev)
                 self._helper.wait_event(positions_ready)
                 with torch.cuda.stream(self._helper):
-                    if tws is not None:
-                        check(lib.nsr_hashgrid_backward_params_owner_bin_taps(ptr(x7), ptr(gws), ptr(tws), N, mc, _byref(desc),
-                                                                              stream_ptr()),
-                              "nsr_hashgrid_backward_params_owner_bin_taps")
+                    if tws is not None:  # in-cell taps are folded into their sample's items (stencil mode)
+                        check(lib.nsr_hashgrid_backward_params_owner_bin_taps_masked(ptr(x7), ptr(gws), ptr(tws), N, mc,
+                                                                                     _byref(desc), stream_ptr()),
+                              "nsr_hashgrid_backward_params_owner_bin_taps_masked")
                         tws.record_stream(self._helper)
                     else:
                         bin_fn = lib.nsr_hashgrid_backward_params_owner_bin if self.fd else \

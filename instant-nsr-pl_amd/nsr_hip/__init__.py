@@ -132,6 +132,7 @@ SIGNATURES = {
     "nsr_hashgrid_jac_apply": [_P, _U, _GD, _P, _U, _P, _P, _P, _U, _P, _P],
     "nsr_hashgrid_jac_apply_ex": [_P, _U, _GD, _P, _U, _P, _P, _P, _U, _P, _P, _P],
     "nsr_hashgrid_forward_taps": [_P, _P, _P, _U, _U, _I, _U, _GD, _P, _P],
+    "nsr_hashgrid_forward_taps_masks": [_P, _P, _P, _U, _U, _I, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_owner_with_second_order": [_P, _P, _P, _U, _P, _P, _P, _U, _U, _I, _I, _GD, _P],
     "nsr_hashgrid_backward_params_owner_with_second_order_adam": [_P, _P, _P, _U, _P, _P, _U, _U, _I, _GD, _P, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_taps_adam": [_P, _P, _P, _P, _U, _U, _GD, _P, _P],
@@ -218,6 +219,7 @@ SIGNATURES = {
     "nsr_hashgrid_backward_params_owner_accumulate_range": [_P, _P, _P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_taps_workspace_floats": [_GD, _U],
     "nsr_hashgrid_backward_params_owner_bin_taps": [_P, _P, _P, _U, _U, _GD, _P],
+    "nsr_hashgrid_backward_params_owner_bin_taps_masked": [_P, _P, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_taps": [_P, _P, _P, _P, _P, _U, _U, _I, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_adam": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P, _P, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_adam_range": [_P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P, _P],
@@ -260,8 +262,6 @@ SIGNATURES = {
                                     _I, _I, _I, _F, _F, _F, _I, _P],
     "nsr_vmlp_blob_floats": [_VD],
     "nsr_vmlp_backward_workspace_floats": [_VD, _U],
-    "nsr_vmlp_backward_workspace_floats_ex": [_VD, _U, _U, _I],
-    "nsr_vmlp_tune": [_I, _I],
     "nsr_vmlp_forward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _U, _U, _P, _P],
     "nsr_vmlp_backward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _P, _U, _U, _U, _U, _P, _I, _P, _U, _U, _P, _P],
     "nsr_neus_points": [_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _U, _P, _P],
@@ -299,7 +299,6 @@ _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": c
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
-             "nsr_vmlp_backward_workspace_floats_ex": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_taps_workspace_floats": ctypes.c_uint64,
              "nsr_profile_enable": None, "nsr_grid_bricks_words64": ctypes.c_uint64, "nsr_ray_march_capacity": ctypes.c_uint32}

@@ -373,6 +373,26 @@ def test_owner_backward_stencil_mode_matches_plain_backward_over_all_taps(mask_c
             continue
         rel = float((a - b).norm() / b.norm())
         assert rel < 2e-5, (lvl, rel, float((a - b).abs().max()))
+    # the 7-tap ENCODE writes the same crossing masks (it holds both cells anyway): bit for bit what the binning pass computes,
+    # and binning + accumulation from them give the same gradient bit for bit
+    table = (torch.randn(gd.n_entries * 2, device="cuda", generator=g) * 0.1).half()
+    enc = torch.empty(7 * n_c, 32, dtype=torch.float16, device="cuda")
+    tws2 = torch.zeros_like(tws)
+    check(lib.nsr_hashgrid_forward_taps_masks(ptr(x7), ptr(table), ptr(enc), n_c, 32, 0, mask_count, ctypes.byref(gd),
+                                              ptr(tws2), stream_ptr()), "fwd masks")
+    nb = mask_count * n_c
+    m1 = tws.view(torch.uint8)[:nb].clone()
+    m2 = tws2.view(torch.uint8)[:nb]
+    assert torch.equal(m1, m2), int((m1 != m2).sum())
+    assert int(m2.count_nonzero()) > 0
+    got2 = torch.full_like(want, 7.0)
+    check(lib.nsr_hashgrid_backward_params_owner_bin_taps_masked(ptr(x7), ptr(ws), ptr(tws2), n_c, mask_count,
+                                                                 ctypes.byref(gd), stream_ptr()), "bin_taps_masked")
+    check(lib.nsr_hashgrid_backward_params_owner_accumulate_taps(ptr(x7), ptr(dy), ptr(got2), ptr(ws), ptr(tws2), n_c,
+                                                                 mask_count, 0, ctypes.byref(gd), stream_ptr()), "acc_taps")
+    hashed = off[11]  # (levels cut into chunk slabs / row-merged dense levels add in fp32: reproducible to rounding only)
+    assert torch.equal(got2[hashed:], got[hashed:])
+    assert float((got2 - got).abs().max()) <= 1e-6 * float(got.abs().max())
 
 
 @pytest.mark.parametrize("groups", [[(0, 16)], [(11, 16), (0, 11)], [(13, 16), (5, 13), (2, 5), (0, 2)]],
