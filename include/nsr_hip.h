@@ -889,6 +889,17 @@ int nsr_hashgrid_backward_params_owner_accumulate_taps(const float *x7, const fl
  * step / hyper: the device schedule state of nsr_adam_tick / nsr_adamw_step_scheduled -- read here, NOT advanced: the
  * caller advances it afterwards with nsr_adamw_step_scheduled over the remaining (MLP) parameters.  Bit-identical to
  * nsr_hashgrid_backward_params_owner_accumulate + nsr_adamw_step on the same tensors. */
+/* Overflow guard of the fused fp16 training step -- Lightning's `precision: 16` (reference configs/nerf-blender.yaml:103):
+ * torch.cuda.amp.GradScaler skips the optimizer step when a gradient is inf / NaN, halves the loss scale and doubles it again
+ * after growth_interval clean steps.  state: int32[8] in device memory {found-inf flag of even steps, of odd steps, scale
+ * (float bits), clean steps, skipped steps, growth interval, -, -}.  Registered (state != NULL) around the launches of ONE
+ * trainer's step and withdrawn (NULL) afterwards -- it is read on the host when a launch is queued: nsr_mlp_dgrad_pair scales
+ * dL/dy by state[2] instead of its grad_scale argument and raises this step's flag on a non-finite encoding gradient, the
+ * table backward's fused AdamW (NsrTableAdam) and nsr_adamw_step_scheduled* leave weights, moments and fp16 images untouched
+ * when it is set, and the latter updates the scale.  scale0 = the constant the weight-gradient reductions unscale by (the step
+ * descriptor's grad_scale).  Returns the current parity. */
+int nsr_overflow_guard(int32_t *state, float scale0);
+
 typedef struct NsrTableAdam {
     float *params, *exp_avg, *exp_avg_sq;
     nsr_half *shadow; /* may be NULL */

@@ -363,8 +363,16 @@ k_mlp_dgrad_pair(const float *__restrict__ d_rgb /* [n,3] */, const float *__res
                  const __half *__restrict__ Wc_, __half *__restrict__ gpre_c, __half *__restrict__ gout_c,
                  const __half *__restrict__ acts_d, const __half *__restrict__ Wd_, __half *__restrict__ gpre_d,
                  __half *__restrict__ gout_d, float *__restrict__ d_enc /* level-major [16][n][2] */, uint32_t ldn,
-                 uint32_t n, float grad_scale, const int32_t *__restrict__ n_dev)
+                 uint32_t n, float grad_scale, const int32_t *__restrict__ n_dev,
+                 int32_t *__restrict__ guard /* NsrGuard state or NULL */, int parity)
 {
+    // overflow guard (nsr_common.h): the scale lives on the device, a non-finite d_enc -- every fp16 overflow upstream ends there,
+    // the chain is dense -- sets this step's flag; the other step's flag is cleared here, where none of its readers is left
+    if (guard) {
+        grad_scale = __int_as_float(guard[2]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) guard[1 - parity] = 0;
+    }
+    bool bad = false;
     const uint32_t n_live = live_count(n, n_dev);
     constexpr int IN_PAD = 32;
     constexpr int NP_C = WIDTH * IN_PAD + (NHC - 1) * WIDTH * WIDTH + 16 * WIDTH;
@@ -540,11 +548,13 @@ k_mlp_dgrad_pair(const float *__restrict__ d_rgb /* [n,3] */, const float *__res
                         const uint32_t lv = 8 * ib + 2 * g;
                         *reinterpret_cast<float2 *>(d_enc + ((uint64_t)lv * n + s) * 2) = make_float2(c[0] * inv_scale, c[1] * inv_scale);
                         *reinterpret_cast<float2 *>(d_enc + ((uint64_t)(lv + 1) * n + s) * 2) = make_float2(c[2] * inv_scale, c[3] * inv_scale);
+                        bad |= !(fabsf(c[0]) + fabsf(c[1]) + fabsf(c[2]) + fabsf(c[3]) <= 3.4028234e38f);
                     }
                 }
             }
         }
     }
+    if (guard && __any(bad) && lane == 0) atomicOr(guard + parity, 1);
 }
 
 // ---- wgrad ------------------------------------------------------------------------------------------------------
@@ -955,7 +965,12 @@ extern "C" int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, cons
     NSR_LAUNCH_STOP((k_mlp_dgrad_pair<NHC, NHD>), dim3(blocks), dim3(MLP_BLOCK), lds, (hipStream_t)stream, d_rgb, d_logit, \
                        (const __half *)out_color, (const __half *)acts_color, (const __half *)w_color, gpre_c, gout_c,    \
                        (const __half *)acts_density, (const __half *)w_density, gpre_d, gout_d, d_enc_level_major, ldn, n, \
-                       grad_scale, n_dev)
+                       grad_scale, n_dev, guard, parity)
+    // overflow guard (registered around a trainer's step, nsr_overflow_guard): this launch opens the step -- its flag is the
+    // other one than the last step's; the optimizer launches queued behind it read nsr_guard.parity as it is left here
+    int32_t *guard = nsr_guard.state;
+    if (guard) nsr_guard.parity ^= 1;
+    const int parity = nsr_guard.parity;
     switch (color->n_hidden * 10 + density->n_hidden) {
     case 11: NSR_PAIR(1, 1); break;
     case 12: NSR_PAIR(1, 2); break;

@@ -44,6 +44,17 @@ extern thread_local hipEvent_t nsr_next_stop_event;
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
     } while (0)
 
+// Overflow guard of the fused fp16 training step (the reference trains under Lightning's `precision: 16`,
+// configs/nerf-blender.yaml:103: GradScaler skips the optimizer step when a gradient is inf / NaN, halves the scale, and doubles
+// it again after growth_interval clean steps).  state = int32[8] in device memory:
+//   [0], [1] found-inf flags of alternating steps (the data-gradient kernel of step t sets [t & 1] and clears the other one;
+//            every optimizer launch of step t reads [t & 1]: nothing ever resets a flag another kernel may still read)
+//   [2] the scale (float bits)   [3] clean steps since the last change   [4] skipped steps   [5] growth interval
+// Host-side registration only: the pointer is read when a launch is QUEUED (nsr_overflow_guard around a trainer's step), the
+// kernels get it as an argument; nothing consults it afterwards.
+struct NsrGuard { int32_t *state; int parity; float scale0; };
+extern NsrGuard nsr_guard;
+
 // Device-side row counts: an entry point that takes (n, n_dev) launches for the CAPACITY n and uses n for array
 // strides; when n_dev != NULL only the first min(*n_dev, n) rows are live.  Lets a whole training step be queued
 // without the host ever reading a sample count.

@@ -330,11 +330,26 @@ __device__ __forceinline__ void adamw_span(float *__restrict__ p, float *__restr
     }
 }
 
+// a skipped step still clears the gradients it would have consumed (the weight-gradient kernels accumulate into them)
+__device__ __forceinline__ void zero_span(float *__restrict__ g, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 4;
+    for (uint64_t base = ((uint64_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 4; base < n; base += stride) {
+        if (base + 4 <= n) *reinterpret_cast<float4 *>(g + base) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (uint64_t j = base; j < n; ++j) g[j] = 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(EW_BLOCK)
 k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *step, float *hyper /* 12 floats */, int32_t *step_out, float *hyper_out,
                   double base_lr, double b1d, double b2d, double gamma, int32_t m0, int32_t m1, int32_t m2, float b1,
-                  float b2, float eps, float wd, float unscale, int zero_grad)
+                  float b2, float eps, float wd, float unscale, int zero_grad,
+                  int32_t *guard /* NsrGuard state or NULL */, int parity, float scale0)
 {
+    // overflow guard: this step's found-inf flag and scale.  The gradients were unscaled by scale0 (the host's constant) where
+    // they were reduced; the data-gradient kernel scaled by the device-side value -- the ratio is applied here.
+    const bool skip = guard && guard[parity] != 0;
+    if (guard) unscale *= scale0 / __int_as_float(guard[2]);
     __shared__ float hs[3];
     __shared__ double pws[2];
     // the advanced schedule state goes to (step_out, hyper_out): the same words, or the other half of a double buffer when
@@ -351,8 +366,12 @@ k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *step, float *hyper /* 12 floats
     }
     __syncthreads();
     const float lr = hs[0], bc1 = hs[1], bc2 = hs[2];
-    adamw_span(a.p, a.g, a.m, a.v, a.shadow, a.n, a.zero_first_n, lr, b1, b2, eps, wd, bc1, bc2, unscale, zero_grad);
-    if (b.n) adamw_span(b.p, b.g, b.m, b.v, b.shadow, b.n, b.zero_first_n, lr, b1, b2, eps, wd, bc1, bc2, unscale, zero_grad);
+    if (skip) {  // weights, moments and the fp16 images stay as they are
+        if (zero_grad) { zero_span(a.g, a.zero_first_n < a.n ? a.zero_first_n : a.n); if (b.n) zero_span(b.g, b.n); }
+    } else {
+        adamw_span(a.p, a.g, a.m, a.v, a.shadow, a.n, a.zero_first_n, lr, b1, b2, eps, wd, bc1, bc2, unscale, zero_grad);
+        if (b.n) adamw_span(b.p, b.g, b.m, b.v, b.shadow, b.n, b.zero_first_n, lr, b1, b2, eps, wd, bc1, bc2, unscale, zero_grad);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         // no fence: the only cross-workgroup ordering needed is "every workgroup READ the old schedule state before the
@@ -361,9 +380,22 @@ k_adamw_scheduled(AdamSeg a, AdamSeg b, int32_t *step, float *hyper /* 12 floats
         uint32_t *ticket = reinterpret_cast<uint32_t *>(hyper + 8);
         if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
             *ticket = 0;
-            *step_out = s;
-            pw[0] = pws[0]; pw[1] = pws[1]; *pw_step = s;
-            hyper_out[0] = hs[0]; hyper_out[1] = hs[1]; hyper_out[2] = hs[2];
+            if (skip) {  // the optimizer step did not happen: the schedule state is carried over unchanged (GradScaler.step)
+                const double *pw_in = reinterpret_cast<const double *>(hyper + 4);
+                *step_out = *step;
+                pw[0] = pw_in[0]; pw[1] = pw_in[1]; *pw_step = *reinterpret_cast<const int32_t *>(hyper + 3);
+                hyper_out[0] = hyper[0]; hyper_out[1] = hyper[1]; hyper_out[2] = hyper[2];
+            } else {
+                *step_out = s;
+                pw[0] = pws[0]; pw[1] = pws[1]; *pw_step = s;
+                hyper_out[0] = hs[0]; hyper_out[1] = hs[1]; hyper_out[2] = hs[2];
+            }
+            if (guard) {  // GradScaler.update(): backoff 0.5 on overflow, growth 2 after growth_interval clean steps
+                float sc = __int_as_float(guard[2]);
+                if (skip) { sc = fmaxf(sc * 0.5f, 1.f); guard[3] = 0; guard[4] += 1; }
+                else if (++guard[3] >= guard[5]) { sc = fminf(sc * 2.f, 1.8446744e19f); guard[3] = 0; }
+                guard[2] = __float_as_int(sc);
+            }
         }
     }
 }
@@ -640,9 +672,24 @@ extern "C" int nsr_adamw_step_scheduled_to(float *params_a, float *grad_a, float
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adamw_scheduled, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, step,
                        hyper12, step_out, hyper12_out, base_lr, beta1, beta2, gamma, milestone0, milestone1, milestone2, (float)beta1,
-                       (float)beta2, eps, weight_decay, grad_unscale, zero_grad);
+                       (float)beta2, eps, weight_decay, grad_unscale, zero_grad, nsr_guard.state, nsr_guard.parity,
+                       nsr_guard.scale0);
     NSR_CHECK_LAUNCH("nsr_adamw_step_scheduled");
     return NSR_OK;
+}
+
+NsrGuard nsr_guard = {nullptr, 0, 1.f};
+
+// Register (state != NULL) / withdraw (NULL) the overflow guard for the launches QUEUED from now on by this process: the fused
+// NeRF step's data-gradient kernel takes its loss scale from state[2] and reports non-finite gradients in state[parity], the
+// table backward's fused AdamW and nsr_adamw_step_scheduled* skip the update when it is set, the latter also runs
+// GradScaler.update() on the scale.  scale0: the constant the step descriptor's grad_scale holds.  Returns the parity the next
+// step will use.
+extern "C" int nsr_overflow_guard(int32_t *state, float scale0)
+{
+    nsr_guard.state = state;
+    if (state) nsr_guard.scale0 = scale0 > 0.f ? scale0 : 1.f;
+    return nsr_guard.parity;
 }
 
 extern "C" int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *exp_avg_a, float *exp_avg_sq_a,

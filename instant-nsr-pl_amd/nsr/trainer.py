@@ -689,7 +689,43 @@ class Trainer:
                 "truncated": int(st[2]) + int(st[10]), "m_cap": a["m_cap"], "s_cap": a["s_cap"]}
 
     def _train_step_async(self):
-        return self._train_step_async_graphable() if self.use_graphs else self._train_step_async_ahead()
+        if self.use_graphs:
+            return self._train_step_async_graphable()
+        g = self._overflow_guard_state()
+        if g is None:
+            return self._train_step_async_ahead()
+        # Lightning's precision-16 protocol (reference configs/nerf-blender.yaml:103) on the device: registered around THIS
+        # trainer's launches only (the library reads it when a launch is queued)
+        _lib.nsr_overflow_guard(ctypes.c_void_p(g.data_ptr()), self.fused.grad_scale)
+        try:
+            return self._train_step_async_ahead()
+        finally:
+            _lib.nsr_overflow_guard(None, 0.0)
+
+    def _overflow_guard_state(self):
+        """int32[8] on the device: {found-inf flag of even / odd steps, loss scale (float bits), clean steps, skipped steps,
+        growth interval, -, -} -- torch.cuda.amp.GradScaler's state (init_scale = the step's grad_scale, backoff 0.5, growth 2
+        every 2,000 clean steps) kept where the kernels read it: an overflowing data gradient skips the WHOLE optimizer step
+        (table, both MLPs, moments, fp16 images) and halves the scale without the host ever looking.  One GPU, table update
+        fused into the table backward (the sharded exchange does not carry the flag across ranks yet); None: off."""
+        if not getattr(self, "overflow_guard", True) or self.world_size > 1 or not self.fuse_table_update:
+            return None
+        g = getattr(self, "_guard", None)
+        if g is None:
+            import struct
+            bits = struct.unpack("<i", struct.pack("<f", float(self.fused.grad_scale)))[0]
+            g = self._guard = torch.tensor([0, 0, bits, 0, 0, int(getattr(self, "overflow_growth_interval", 2000)), 0, 0],
+                                           dtype=torch.int32, device=self.device)
+        return g
+
+    def overflow_guard_stats(self):
+        """(loss scale, clean steps since its last change, skipped steps) -- synchronises"""
+        g = self._overflow_guard_state()
+        if g is None:
+            return None
+        self.settle()
+        v = g.cpu()
+        return {"scale": float(v[2:3].view(torch.float32)[0]), "clean_steps": int(v[3]), "skipped_steps": int(v[4])}
 
     def _helper_stream(self):
         """the C orchestration's helper stream (csrc/step.hip) as a torch stream, or None (NSR_ADAM_ON_MAIN: A/B switch)"""

@@ -260,6 +260,7 @@ SIGNATURES = {
     "nsr_sigma_rays_blocks": [_U],
     "nsr_adamw_step_scheduled_to": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _D, _D, _D, _D,
                                     _I, _I, _I, _F, _F, _F, _I, _P],
+    "nsr_overflow_guard": [_P, _F],
     "nsr_vmlp_blob_floats": [_VD],
     "nsr_vmlp_backward_workspace_floats": [_VD, _U],
     "nsr_vmlp_forward": [_VD, _P, _P, _U, _P, _U, _P, _P, _P, _U, _U, _P, _P],
