@@ -788,16 +788,16 @@ def main():
         tot[0] = tmax[0]
     dt, n_samples, n_rays = (float(v) for v in tot.tolist())
 
-    # Same-process A/B of the step's round-5 forms against the round-4 forms of the same kernels (nsr.trainer.ROUND4_FORMS:
+    # Same-process A/B of the step's current forms against the round-4 forms of the same kernels (nsr.trainer.ROUND4_FORMS:
     # two data-gradient launches, one wave per ray compositing, scan + copy, events recorded behind kernels, the step's stream
     # waiting for the MLP optimizer in front of the encode): windows of 160 steps, interleaved A B B A, same trainer, same
     # regime -- box-to-box variation (+-5 % on this pool) cancels, which it does not between rounds
     forms_ab = None
     if world == 1 and tr.async_mode and not shared_device and not os.environ.get("NSR_BENCH_NO_FORMS_AB"):
-        from nsr.trainer import ROUND4_FORMS, ROUND5_FORMS, set_step_forms
-        acc = {"round4_forms": [], "round5_forms": []}
-        for name in ("round4_forms", "round5_forms", "round5_forms", "round4_forms"):
-            set_step_forms(tr, ROUND4_FORMS if name == "round4_forms" else ROUND5_FORMS)
+        from nsr.trainer import ROUND4_FORMS, CURRENT_FORMS, set_step_forms
+        acc = {"round4_forms": [], "current_forms": []}
+        for name in ("round4_forms", "current_forms", "current_forms", "round4_forms"):
+            set_step_forms(tr, ROUND4_FORMS if name == "round4_forms" else CURRENT_FORMS)
             for _ in range(16):
                 tr.train_step()
             sync()
@@ -808,10 +808,10 @@ def main():
             dta = time.perf_counter() - ta
             a1 = tr.counters()
             acc[name].append((1e3 * dta / 160, (a1["samples"] - a0["samples"]) / 160))
-        set_step_forms(tr, ROUND5_FORMS)
+        set_step_forms(tr, CURRENT_FORMS)
         forms_ab = {k: {"ms_per_step": [round(x[0], 4) for x in v], "kept_samples_per_step": [round(x[1]) for x in v],
                         "mean_ms_per_step": sum(x[0] for x in v) / len(v)} for k, v in acc.items()}
-        forms_ab["round5_over_round4"] = forms_ab["round5_forms"]["mean_ms_per_step"] / forms_ab["round4_forms"]["mean_ms_per_step"]
+        forms_ab["current_over_round4"] = forms_ab["current_forms"]["mean_ms_per_step"] / forms_ab["round4_forms"]["mean_ms_per_step"]
         forms_ab["at_step"] = int(tr.global_step)
 
     whole = late = None

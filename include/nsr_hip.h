@@ -176,10 +176,6 @@ int nsr_hashgrid_forward_variant(int lds_levels, int levels_per_lane);
  * the corner values it already holds, and the two dense products the analytic normal needs from it
  * (models/geometry.py:176-180): dx = J^T dy (first-order input gradient) and d_dy = J g (its double backward) --
  * instead of gathering the table a second and a third time (nsr_hashgrid_backward_input / _backward_backward_input). */
-/* levels [0, 8) (half = 1) or [8, 16) (half = 2) of a 16-level grid only; both halves together == nsr_hashgrid_forward_ex */
-int nsr_hashgrid_forward_half(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
-                              int y_level_major, uint32_t level_mask_count, int half, const NsrGridDesc *desc,
-                              const int32_t *n_dev, void *stream);
 int nsr_hashgrid_forward_jac(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
                              int y_level_major, uint32_t level_mask_count, const NsrGridDesc *desc, float *jac,
                              const int32_t *n_dev, void *stream);
@@ -326,25 +322,6 @@ int nsr_grid_mlp_supported(const NsrGridDesc *grid, const NsrMlpDesc *mlp);
 int nsr_grid_mlp_forward(const float *x, const nsr_half *table, const nsr_half *weights, nsr_half *out, nsr_half *acts,
                          nsr_half *enc, uint32_t enc_stride, int enc_level_major, uint32_t n, uint32_t level_mask_count,
                          const NsrGridDesc *grid, const NsrMlpDesc *mlp, const int32_t *n_dev, void *stream);
-/* The sigma pass of occupancy-grid ray marching (reference models/nerf.py:65-93: `sigma_fn` evaluated on every marched sample
- * inside nerfacc.ray_marching, then the transmittance cut T >= early_stop_eps) as ONE ray-ordered kernel: a workgroup takes a
- * ray and evaluates hash encode + density MLP on its samples 64 at a time, runs the visibility prefix of
- * nsr_visibility_prefix on them and STOPS once the ray's transmittance fell below early_stop_eps -- the samples behind the cut
- * (~60 % on a trained scene) are never encoded.  x: unit-cube positions of the marched samples [n_rows, 3] in ray order,
- * packed_info (start, count) per ray, t_starts / t_ends [n_rows].  Outputs for the samples in front of (and in the 64-sample
- * window that reaches) the cut, bit-identical to nsr_hashgrid_forward (level-major) + nsr_mlp_forward + nsr_visibility_prefix:
- * enc level-major [L][n_rows][F] half, acts [n_hidden][n_rows][64] (may be NULL), out [n_rows, 16], kept_counts [n_rays].
- * Rows behind the cut are left untouched.  Needs nsr_grid_mlp_supported(grid, mlp) and no output activation. */
-int nsr_sigma_rays(const float *x, const nsr_half *table, const nsr_half *weights, nsr_half *out, nsr_half *acts,
-                   nsr_half *enc, uint32_t n_rows, const int32_t *packed_info, const float *t_starts, const float *t_ends,
-                   float density_bias, float early_stop_eps, int32_t *kept_counts, uint32_t n_rays, const NsrGridDesc *grid,
-                   const NsrMlpDesc *mlp, void *stream);
-/* workgroups of a nsr_sigma_rays launch (persistent: ray r -> workgroup r mod blocks; default 768); 0 only queries */
-uint32_t nsr_sigma_rays_blocks(uint32_t blocks);
-/* which sigma pass nsr_nerf_prune_pass takes: 0 (default) the three stand-alone launches, 1 nsr_sigma_rays (measured slower on
- * MI355X: its gathers lose the per-XCD level placement of the stand-alone encode); mode < 0 only
- * queries.  Returns the previous mode. */
-int nsr_nerf_sigma_mode(int mode);
 uint32_t nsr_grid_mlp_forward_max_blocks(uint32_t max_blocks);
 /* Backward of the pair in one call: MLP data gradient written level-major (what the table backward reads: no transpose,
  * one trip through HBM), weight gradients (grad_weights fp32, ACCUMULATED, may be NULL), item binning + owner-computes
@@ -617,15 +594,7 @@ int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out, uint32_t 
                                               const float *opacity, const float *gt_rgb, const float *partials,
                                               float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
                                               uint32_t n_rays, void *stream);
-/* Round 5 -- flat segmented compositing (models/nerf.py:105-109 and its backward): one lane per SAMPLE over the packed
- * arrays instead of one wave per ray (a ray of the step keeps 10-15 samples: > 80 % idle lanes) -- a wave takes 8 consecutive
- * rays, i.e. one contiguous sample range, transmittance and the per-ray sums are segmented DPP scans with a carry between
- * 64-sample chunks.  packed_info must be an exclusive scan over the rays (what nsr_pack_from_counts* / the folded packing
- * write).  forward: partials (may be NULL) = the loss partials of the folded masked smooth-L1 against gt_rgb
- * (nsr_composite_l1_partials_floats(n_rays) floats).  backward: EITHER the upstream gradients grad_comp_rgb [R,3] (+
- * optional grad_opacity [R], grad_depth [R], grad_weights [n]) OR the built-in loss on (comp_rgb, opacity, gt_rgb) with its
- * (sum, valid rays) read from acc2 (partials == NULL) or summed from the forward's partials (acc2 then receives them). */
-int nsr_composite_flat_rays_per_wave(int rays); /* Sample-partitioned compositing (round 6; nerfacc.render_weight_from_density + accumulate_along_rays, reference
+ /* Sample-partitioned compositing (round 6; nerfacc.render_weight_from_density + accumulate_along_rays, reference
  * models/nerf.py:105-108, with trunc_exp + density bias of models/geometry.py:122-156 folded in): one lane per kept sample, a
  * wave per 64 samples of the packed arrays whatever the ray boundaries.  ray_indices[n_samples] (int64) names each sample's
  * ray, packed_info [n_rays][2] its (start, count) -- an exclusive scan over the rays.  n_samples = capacity of the sample
@@ -644,18 +613,6 @@ int nsr_composite_backward_samples(const nsr_half *mlp_out, uint32_t stride, flo
                                    const float *opacity, const float *gt_rgb, const float *partials, float *acc2,
                                    float grad_scale, float *grad_rgb, float *grad_logit, uint32_t n_rays, uint32_t n_samples,
                                    const int32_t *n_samples_dev, void *stream);
-/* 4 (default), 8 or 16; 0 queries; returns the previous value */
-int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
-                               const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
-                               const float *background, float *weights, float *trans, float *comp_rgb, float *opacity,
-                               float *depth, const float *gt_rgb, float *partials, uint32_t n_rays, void *stream);
-int nsr_composite_backward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
-                                const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
-                                const float *background, const float *weights, const float *trans,
-                                const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
-                                const float *grad_weights, const float *comp_rgb, const float *opacity, const float *gt_rgb,
-                                const float *partials, float *acc2, float grad_scale, float *grad_rgb, float *grad_logit,
-                                uint32_t n_rays, void *stream);
 /* acc2[0] += sum of smooth_l1 over valid rays (opacity > 0) x 3 channels, acc2[1] += number of valid rays
  * (loss = acc2[0] / (3*acc2[1]), systems/nerf.py:97); backward writes grad_scale * dloss/dcomp_rgb */
 int nsr_smooth_l1_valid(const float *comp_rgb, const float *opacity, const float *gt_rgb, float *acc2,
@@ -723,38 +680,19 @@ typedef struct NsrNerfMainLayout {
 #define NSR_PROF_MLP_BACKWARD_COLOR 4
 #define NSR_PROF_MLP_BACKWARD_DENSITY 5
 #define NSR_PROF_GRID_BACKWARD_BIN 6 /* item binning of the table backward, on the main pass's helper stream */
-#define NSR_PROF_GRID_BACKWARD_DENSE 7 /* dense levels of the table backward (nsr_hashgrid_backward_params_dense), own stream */
-/* Round 5 -- forms of the step's kernels, switchable for same-process A/B runs and as a fallback (keys 0, 2, 5 default to 1,
- * keys 1 and 3 -- measured slower inside the step -- to 0):
- * key 0: nsr_mlp_dgrad_pair instead of two data-gradient launches; key 1: the dense levels of the table backward through
- * nsr_hashgrid_backward_params_dense on a stream of their own, the owner launch covering the hashed levels only; key 2:
- * nsr_composite_*_flat instead of one wave per ray; key 3: the two networks' weight-gradient kernels on two helper streams
- * (with key 0); key 5: the pass's fork events ride on the kernels in front of them (hipExtLaunchKernelGGL stop event)
- * instead of being recorded behind them; key 6: the pass's events are created with hipEventReleaseToDevice; key 7: the table
- * backward is issued before the helper streams' weight-gradient launches (host order); key 9: the value is the block cap of
- * the pass's own weight-gradient launches (nsr_mlp_wgrad_max_blocks around them only; default 128, 0 = leave the library's).
+/* Forms of the step's kernels that stay switchable for same-process A/B runs (bench.py `step_forms_ab`) and as a fallback:
+ * key 0: nsr_mlp_dgrad_pair instead of two data-gradient launches; key 2: sample-partitioned compositing
+ * (nsr_composite_*_samples) instead of one wave per ray; key 5: the pass's fork events ride on the kernels in front of them
+ * (hipExtLaunchKernelGGL stop event) instead of being recorded behind them; key 9: the value is the block cap of the pass's
+ * own weight-gradient launches (nsr_mlp_wgrad_max_blocks around them only; default 128, 0 = leave the library's).
  * value < 0 queries; returns the previous value (-1: unknown key). */
 int nsr_nerf_step_variant(int key, int value);
-/* key 4 of the above (default 0): the weight-gradient kernels of nsr_mlp_dgrad_pair's networks are queued BEHIND the table
- * backward instead of beside it, for a caller that defers its join with them (nsr_nerf_defer_wgrad_join) and hands the event
- * of its optimizer launch for the network weights to nsr_nerf_wait_before_mlp: one-shot -- the NEXT pruning pass makes its
- * stream wait for that hipEvent_t between its hash encode and its density MLP instead of the step's stream waiting in front
- * of the encode.  NULL clears.  The caller must wait for the event itself before anything else reads the weights. */
+/* One-shot: the NEXT pruning pass makes its stream wait for that hipEvent_t between its hash encode and its density MLP (the
+ * first kernel that reads network weights) -- for a caller that defers its join with the weight-gradient kernels
+ * (nsr_nerf_defer_wgrad_join) and hands over the event of its optimizer launch for the network weights, instead of the step's
+ * stream waiting in front of the encode.  NULL clears.  The caller must wait for the event itself before anything else reads
+ * the weights. */
 int nsr_nerf_wait_before_mlp(void *event);
-/* key 10 of nsr_nerf_step_variant (default 0): nsr_nerf_main_pass queues its table backward (with AdamW inside) on the helper
- * stream, in order behind its own binning launch -- no join in front of it on the caller's stream -- and the weight-gradient
- * kernels of both networks inline on the caller's stream behind the data-gradient kernel -- no fork.  Only for a caller that
- * set nsr_nerf_defer_wgrad_join and passes table_adam (no exchange).  nsr_nerf_last_pass_form(): bit 0 = the last main pass took
- * this form: the caller's optimizer launch for the MLP weights then belongs on ITS stream, followed by nsr_nerf_wait_table(stream)
- * (a no-op when nothing is pending; the next pruning / main pass calls it itself for a caller that did not). */
-int nsr_nerf_last_pass_form(void);
-int nsr_nerf_wait_table(void *stream);
-/* key 8 of nsr_nerf_step_variant (default 0): the table backward with AdamW inside runs as two launches (levels [0, 8), then
- * [8, 16)) and the NEXT pruning pass encodes levels [0, 8) on a helper stream beside the second launch (nsr_hashgrid_forward_half).
- * That helper stream must wait for the pruning pass's inputs itself: hand the hipEvent_t behind which positions / marched count
- * exist (recorded on the caller's marching stream) to nsr_nerf_set_inputs_event before every pruning pass (one-shot; without
- * it the pass encodes in one launch as before). */
-int nsr_nerf_set_inputs_event(void *event);
 /* the stream the main pass runs its overlapped work on (item binning, weight-gradient kernels); created on first use */
 void *nsr_nerf_helper_stream(void);
 /* `stream` waits for the point of the last main pass where its kept rows exist (behind nsr_nerf_main_pass*'s first kernel) */
@@ -913,35 +851,8 @@ int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x, const voi
                                                        float *workspace, uint32_t n, uint32_t level_mask_count,
                                                        float grad_scale, const NsrGridDesc *desc, const int32_t *n_dev,
                                                        const NsrTableAdam *adam, void *stream);
-/* ... over the run of levels [level_begin, level_end) only (dy level-major fp32, items binned beforehand): the fused NeRF step
- * launches the small dense levels (chunk slabs + slab reduction, the slowest workgroups of a trained scene) on a stream of
- * their own beside the other levels (measured slower than one launch: csrc/step.hip).  nsr_hashgrid_owner_first_unchunked_level:
- * where that cut is for a launch of n points. */
-int nsr_hashgrid_backward_params_owner_accumulate_adam_range(const float *x, const float *dy_level_major, float *workspace,
-                                                             uint32_t n, uint32_t level_mask_count, float grad_scale,
-                                                             uint32_t level_begin, uint32_t level_end,
-                                                             const NsrGridDesc *desc, const int32_t *n_dev,
-                                                             const NsrTableAdam *adam, void *stream);
 uint32_t nsr_hashgrid_owner_first_unchunked_level(const NsrGridDesc *desc, uint32_t n);
 
-/* Round 5 -- the leading DENSE levels (resolution^3 <= size) of the table backward without owner workgroups
- * (csrc/hashgrid_dense.inc; serves the backward of reference models/network_utils.py:209-214): the samples of a step are in
- * ray order and consecutive samples of a ray stay in one cell of a coarse level, so runs of lanes in the same cell are merged
- * in registers (segmented DPP scan) and only a run's last lane adds its 8 corner sums to a Q27.36 fixed-point buffer with
- * device-scope integer atomics (order-independent sums).  nsr_hashgrid_dense_levels: how many leading levels that is (the
- * owner calls of the same step then take [that, L): nsr_hashgrid_backward_params_owner_bin_range +
- * ..._owner_accumulate_range / ..._owner_accumulate_adam_range).  phases: 1 = clear the accumulators (memset on `stream`),
- * 2 = accumulate (x [n,3], dy level-major fp32 [L][n][F]), 4 = write out -- AdamW on those levels' parameters (adam), or
- * their gradient as fp32 (grad_table: the TABLE's base, accumulate != 0 adds) or bf16 (grad_bf16: the table's base); exactly
- * one of the three.  workspace / n: the owner calls' (nsr_hashgrid_backward_params_workspace_floats has room for both). */
-uint32_t nsr_hashgrid_dense_levels(const NsrGridDesc *desc);
-int nsr_hashgrid_backward_params_dense(const float *x, const float *dy_level_major, float *grad_table, void *grad_bf16,
-                                       const NsrTableAdam *adam, float *workspace, uint32_t n, uint32_t level_mask_count,
-                                       float grad_scale, int accumulate, const NsrGridDesc *desc, const int32_t *n_dev,
-                                       int phases, void *stream);
-int nsr_hashgrid_backward_params_owner_bin_range(const float *x, float *workspace, uint32_t n, uint32_t level_mask_count,
-                                                 uint32_t level_begin, uint32_t level_end, const NsrGridDesc *desc,
-                                                 const int32_t *n_dev, void *stream);
 
 /* The same write-out for the two other accumulation modes (the fused NeuS steps, nsr/fused_neus.py): first + second order
  * in one pass (analytic normals; items already binned when binned != 0) and the finite-difference stencil mode. */

@@ -641,16 +641,7 @@ k_composite_backward(const __half *__restrict__ mlp_out, uint32_t stride, float 
     }
 }
 
-// ---- flat segmented compositing (round 5) ------------------------------------------------------------------------------------
-// The wave-per-ray kernels above leave > 80 % of their lanes idle at the step's operating point (8,192 ray slots, ~1e5 kept
-// samples: a ray keeps 10-15 samples, two thirds of the slots keep none) and cost 30-45 us of the step's chain.  Here a wave
-// takes FLAT_RPW consecutive rays; their kept samples are ONE contiguous range of the packed arrays (packed_info of the step is
-// an exclusive scan: start[r + 1] = start[r] + count[r], empty rays included), which the wave walks 64 samples at a time, one
-// lane per SAMPLE whatever the ray boundaries: the transmittance prefix and the five per-ray sums are segmented scans (DPP
-// row shifts + row broadcasts, registers only), a ray that straddles two 64-sample chunks hands a wave-uniform carry to the
-// next chunk.  No atomics, no LDS except the block's loss partial, every sum in a fixed order: deterministic.
-constexpr int FLAT_BLOCK = 256;                      // threads per block; a wave takes RPW rays (4, 8 or 16: nsr_composite_flat_rays_per_wave)
-
+// segmented wave scans of the compositing kernels below: DPP row shifts + row broadcasts, registers only
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float flat_dpp(float v)
 {
@@ -670,229 +661,11 @@ __device__ __forceinline__ float flat_seg_scan(float v, uint32_t dist, uint32_t 
     return v;
 }
 
-// the wave's rays: lanes 0 .. FLAT_RPW-1 hold (start, count) of ray r0 + lane; [begin, end) = the samples of all of them
-template <int RPW> struct FlatRays { uint32_t r0, nv, begin, end; int st, cn; uint32_t e[RPW]; /* ends of the rays: wave-uniform */ };
-template <int RPW>
-__device__ __forceinline__ FlatRays<RPW> flat_rays(const int32_t *__restrict__ packed, uint32_t n_rays, uint32_t lane)
-{
-    FlatRays<RPW> f;
-    f.r0 = (blockIdx.x * (FLAT_BLOCK / 64) + (threadIdx.x >> 6)) * RPW;
-    f.nv = f.r0 < n_rays ? min((uint32_t)RPW, n_rays - f.r0) : 0u;
-    f.st = 0; f.cn = 0;
-    if (lane < f.nv) {
-        f.st = packed[2ull * (f.r0 + lane)];  // (two 4-byte loads: callers hand in 4-byte aligned views)
-        f.cn = packed[2ull * (f.r0 + lane) + 1];
-    }
-    const int ev = f.st + f.cn;
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) f.e[j] = (uint32_t)__builtin_amdgcn_readlane(ev, j);
-    f.begin = f.nv ? (uint32_t)__builtin_amdgcn_readlane(f.st, 0) : 0u;
-    f.end = 0u;
-#pragma unroll
-    for (int j = 0; j < RPW; ++j)
-        if ((uint32_t)j < f.nv) f.end = f.e[j];  // (the last valid ray's end: starts and ends never decrease)
-    return f;
-}
-// local ray (0 .. nv-1) of sample i in [begin, end): the first one whose end lies behind i
-template <int RPW>
-__device__ __forceinline__ uint32_t flat_ray_of(const FlatRays<RPW> &f, uint32_t i)
-{
-    uint32_t q = 0;
-#pragma unroll
-    for (int j = 0; j < RPW - 1; ++j) q += ((uint32_t)j + 1u < f.nv && i >= f.e[j]) ? 1u : 0u;
-    return q;
-}
-
-template <int RPW>
-__global__ void __launch_bounds__(FLAT_BLOCK)
-k_composite_forward_flat(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
-                         const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
-                         const int32_t *__restrict__ packed, const float *__restrict__ bg, float *__restrict__ weights,
-                         float *__restrict__ trans, float *__restrict__ comp_rgb, float *__restrict__ opacity,
-                         float *__restrict__ depth, uint32_t n_rays, const float *__restrict__ l1_gt,
-                         float *__restrict__ l1_part /* [2][gridDim.x] or NULL */)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const FlatRays<RPW> f = flat_rays<RPW>(packed, n_rays, lane);
-    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
-    float l1_s = 0.f, l1_c = 0.f;
-    if (lane < f.nv && f.cn == 0) {  // a ray without samples: background, outside the loss (opacity 0)
-        const uint32_t r = f.r0 + lane;
-        opacity[r] = 0.f;
-        depth[r] = 0.f;
-        comp_rgb[3ull * r] = b0; comp_rgb[3ull * r + 1] = b1; comp_rgb[3ull * r + 2] = b2;
-    }
-    float c_sd = 0.f, c_acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // carries of the ray that is open at the chunk's first lane
-    for (uint32_t c = f.begin; c < f.end; c += 64) {
-        const uint32_t i = c + lane;
-        const bool ok = i < f.end;
-        const uint32_t q = flat_ray_of(f, ok ? i : f.end - 1u);
-        const uint32_t rs = (uint32_t)__shfl(f.st, (int)q, 64), rc = (uint32_t)__shfl(f.cn, (int)q, 64);
-        const uint32_t k = (ok ? i : f.end - 1u) - rs;        // position inside the ray
-        const bool open = k > lane;                            // the ray began in an earlier chunk
-        const uint32_t dist = open ? lane : k;
-        float sd = 0.f, a = 0.f, mid = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-        if (ok) {
-            const float ts = t0[i], te = t1[i];
-            const float sigma = expf(__half2float(mlp_out[(uint64_t)i * stride]) + bias);
-            sd = sigma * (te - ts);
-            a = 1.f - expf(-sd);
-            mid = (ts + te) / 2.f;
-            const __half *c3 = rgb + (uint64_t)i * rgb_stride;
-            cr = __half2float(c3[0]); cg = __half2float(c3[1]); cb = __half2float(c3[2]);
-        }
-        const float inc = flat_seg_scan(sd, dist, lane);
-        // exclusive prefix by shift, not as inc - sd: an overflowed density gives inf - inf = NaN (see k_composite_forward)
-        float exc = __shfl_up(inc, 1, 64);
-        if (dist == 0u) exc = 0.f;
-        const float T = expf(-((open ? c_sd : 0.f) + exc));
-        const float w = ok ? T * a : 0.f;
-        float v[5] = {w, w * mid, w * cr, w * cg, w * cb};
-#pragma unroll
-        for (int j = 0; j < 5; ++j) v[j] = flat_seg_scan(v[j], dist, lane) + (open ? c_acc[j] : 0.f);
-        if (ok) {
-            weights[i] = w;
-            trans[i] = T;
-            if (k + 1u == rc) {  // last sample of its ray: the sums are complete
-                const uint32_t r = f.r0 + q;
-                opacity[r] = v[0];
-                depth[r] = v[1];
-                const float rest = 1.f - v[0];
-                const float o3[3] = {v[2] + b0 * rest, v[3] + b1 * rest, v[4] + b2 * rest};
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    comp_rgb[3ull * r + j] = o3[j];
-                    if (l1_part && v[0] > 0.f) {
-                        const float d = fabsf(o3[j] - l1_gt[3ull * r + j]);
-                        l1_s += d < 1.f ? 0.5f * d * d : d - 0.5f;
-                    }
-                }
-                if (l1_part && v[0] > 0.f) l1_c += 1.f;
-            }
-        }
-        // carry: the ray of lane 63 continues behind this chunk iff lane 63 is not its last sample
-        const float n_sd = (open ? c_sd : 0.f) + inc;
-        const bool cont = ok && (k + 1u < rc);
-        c_sd = __shfl(cont ? n_sd : 0.f, 63, 64);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) c_acc[j] = __shfl(cont ? v[j] : 0.f, 63, 64);
-    }
-    if (l1_part) {
-        __shared__ float sh[2][FLAT_BLOCK / 64];
-        l1_s = wave_sum(l1_s);
-        l1_c = wave_sum(l1_c);
-        if (lane == 0) { sh[0][threadIdx.x >> 6] = l1_s; sh[1][threadIdx.x >> 6] = l1_c; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float ts = 0.f, tc = 0.f;
-#pragma unroll
-            for (int w = 0; w < FLAT_BLOCK / 64; ++w) { ts += sh[0][w]; tc += sh[1][w]; }
-            l1_part[blockIdx.x] = ts;
-            l1_part[gridDim.x + blockIdx.x] = tc;
-        }
-    }
-}
-
-// backward of the above w.r.t. rgb and the density logit; the ray's samples are walked from its END (suffix sums)
-template <int RPW>
-__global__ void __launch_bounds__(FLAT_BLOCK)
-k_composite_backward_flat(const __half *__restrict__ mlp_out, uint32_t stride, float bias, const float *__restrict__ t0,
-                          const float *__restrict__ t1, const __half *__restrict__ rgb, uint32_t rgb_stride,
-                          const int32_t *__restrict__ packed, const float *__restrict__ bg,
-                          const float *__restrict__ weights, const float *__restrict__ trans,
-                          const float *__restrict__ g_comp, const float *__restrict__ g_opacity,
-                          const float *__restrict__ g_depth, float *__restrict__ d_rgb, float *__restrict__ d_logit,
-                          uint32_t n_rays, const float *__restrict__ l1_comp, const float *__restrict__ l1_opacity,
-                          const float *__restrict__ l1_gt, const float *__restrict__ l1_acc, float l1_scale,
-                          const float *__restrict__ g_weights, const float *__restrict__ l1_part,
-                          float *__restrict__ l1_acc_out)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    float n_valid = 0.f;
-    if (l1_part) {  // every block sums the forward's partials itself, same order everywhere
-        __shared__ float tot[2][FLAT_BLOCK / 64];
-        float s = 0.f, c = 0.f;
-        for (uint32_t k = threadIdx.x; k < gridDim.x; k += FLAT_BLOCK) { s += l1_part[k]; c += l1_part[gridDim.x + k]; }
-        s = wave_sum(s);
-        c = wave_sum(c);
-        if (lane == 0) { tot[0][threadIdx.x >> 6] = s; tot[1][threadIdx.x >> 6] = c; }
-        __syncthreads();
-        s = c = 0.f;
-#pragma unroll
-        for (int w = 0; w < FLAT_BLOCK / 64; ++w) { s += tot[0][w]; c += tot[1][w]; }
-        n_valid = c;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { l1_acc_out[0] = s; l1_acc_out[1] = c; }
-    }
-    const FlatRays<RPW> f = flat_rays<RPW>(packed, n_rays, lane);
-    if (f.end <= f.begin) return;
-    // the upstream gradients of this wave's rays, held by lanes 0 .. nv-1
-    float rg0 = 0.f, rg1 = 0.f, rg2 = 0.f, rgo = 0.f, rgd = 0.f;
-    if (lane < f.nv) {
-        const uint32_t r = f.r0 + lane;
-        if (l1_comp) {
-            const bool valid = l1_opacity[r] > 0.f;
-            const float inv = l1_scale / fmaxf(3.f * (l1_part ? n_valid : l1_acc[1]), 1.f);
-            float g[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float d = l1_comp[3ull * r + j] - l1_gt[3ull * r + j];
-                const float gq = fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
-                g[j] = valid ? gq * inv : 0.f;
-            }
-            rg0 = g[0]; rg1 = g[1]; rg2 = g[2];
-        } else {
-            rg0 = g_comp[3ull * r]; rg1 = g_comp[3ull * r + 1]; rg2 = g_comp[3ull * r + 2];
-        }
-        rgo = g_opacity ? g_opacity[r] : 0.f;
-        rgd = g_depth ? g_depth[r] : 0.f;
-    }
-    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
-    float c_v = 0.f;  // suffix sum of gT_i T_i of the ray that is open at the chunk's first lane
-    const uint32_t total = f.end - f.begin;
-    for (uint32_t c = 0; c < total; c += 64) {
-        const uint32_t j = c + lane;
-        const bool ok = j < total;
-        const uint32_t i = f.end - 1u - (ok ? j : total - 1u);
-        const uint32_t q = flat_ray_of(f, i);
-        const uint32_t rs = (uint32_t)__shfl(f.st, (int)q, 64), rc = (uint32_t)__shfl(f.cn, (int)q, 64);
-        const uint32_t k = rs + rc - 1u - i;                   // position counted from the ray's end
-        const bool open = k > lane;
-        const uint32_t dist = open ? lane : k;
-        const float g0 = __shfl(rg0, (int)q, 64), g1 = __shfl(rg1, (int)q, 64), g2 = __shfl(rg2, (int)q, 64);
-        const float gop = __shfl(rgo, (int)q, 64), gdp = __shfl(rgd, (int)q, 64);
-        float v = 0.f, gw = 0.f, T = 0.f, a = 0.f, dt = 0.f, z = 0.f;
-        if (ok) {
-            const float ts = t0[i], te = t1[i];
-            dt = te - ts;
-            z = __half2float(mlp_out[(uint64_t)i * stride]) + bias;
-            const float sd = expf(z) * dt;
-            a = 1.f - expf(-sd);
-            T = trans[i];
-            const __half *c3 = rgb + (uint64_t)i * rgb_stride;
-            const float w = weights[i];
-            gw = g0 * (__half2float(c3[0]) - b0) + g1 * (__half2float(c3[1]) - b1) + g2 * (__half2float(c3[2]) - b2) +
-                 gop + gdp * ((ts + te) / 2.f) + (g_weights ? g_weights[i] : 0.f);
-            d_rgb[3ull * i] = w * g0;
-            d_rgb[3ull * i + 1] = w * g1;
-            d_rgb[3ull * i + 2] = w * g2;
-            v = gw * a * T;  // gT_i * T_i
-        }
-        const float inc = flat_seg_scan(v, dist, lane);
-        float exc = __shfl_up(inc, 1, 64);
-        if (dist == 0u) exc = 0.f;
-        if (ok) {
-            const float g_sd = gw * T * (1.f - a) - ((open ? c_v : 0.f) + exc);
-            d_logit[i] = g_sd * dt * expf(fminf(z, 15.f));
-        }
-        const bool cont = ok && (k + 1u < rc);
-        c_v = __shfl(cont ? (open ? c_v : 0.f) + inc : 0.f, 63, 64);
-    }
-}
-
 // ---- sample-partitioned compositing (round 6) --------------------------------------------------------------------------------
-// The flat kernels above are still partitioned by RAYS: a wave owns four consecutive rays and walks their samples 64 at a time,
-// serially -- with two thirds of the ray slots empty and ~36 samples on the rest most waves run one under-filled chunk while a
-// few walk 5-10 dependent ones, and the tail sets the time (32-38 us for < 8 MB, VERDICT r5 weak #4a).  Here a wave owns 64
+// The wave-per-ray kernels above leave > 80 % of their lanes idle at the step's operating point (8,192 ray slots, ~1e5 kept
+// samples: a ray keeps 10-15 samples, two thirds of the slots keep none); round 5's flat kernels (a wave per FOUR rays, walking
+// their samples 64 at a time, serially) had a tail -- most waves one under-filled chunk, a few 5-10 dependent ones -- and are
+// gone (profiles/r06_step_variants_compositing.json: same-process A/B in the step).  Here a wave owns 64
 // consecutive SAMPLES of the packed arrays whatever the ray boundaries (ray id from the kept rows' ray_indices, its segment
 // from packed_info).  What a chunk needs from outside is the state of the ONE ray that is open at its first lane: the wave
 // recomputes it itself from that ray's earlier samples (forward: sum of sigma dt and the five weighted sums; backward: the
@@ -1437,72 +1210,6 @@ extern "C" int nsr_composite_backward_smooth_l1_partials(const nsr_half *mlp_out
                        nullptr, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, nullptr, grad_scale, nullptr,
                        partials, acc2);
     NSR_CHECK_LAUNCH("nsr_composite_backward_smooth_l1_partials");
-    return NSR_OK;
-}
-
-// rays per wave of the flat compositing kernels (4, 8 or 16; forward and backward of one step must see the same value: the
-// loss partials are per block); 0 queries.  Returns the previous value.
-static int g_flat_rpw = 4;  // (measured in the step: 4 -> 0.3775, 8 -> 0.3802, 16 -> 0.3817 ms)
-extern "C" int nsr_composite_flat_rays_per_wave(int rays)
-{
-    const int old = g_flat_rpw;
-    if (rays == 4 || rays == 8 || rays == 16) g_flat_rpw = rays;
-    return old;
-}
-
-// flat forms of the compositing pair (k_composite_*_flat): packed_info must be an exclusive scan over the rays (what
-// nsr_pack_from_counts* / the fused compaction write).  partials (may be NULL): the loss partials of the folded smooth-L1,
-// nsr_composite_l1_partials_floats(n_rays) floats as for the wave-per-ray pair.
-extern "C" int nsr_composite_forward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
-                                          const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
-                                          const int32_t *packed_info, const float *background, float *weights, float *trans,
-                                          float *comp_rgb, float *opacity, float *depth, const float *gt_rgb, float *partials,
-                                          uint32_t n_rays, void *stream)
-{
-    if (n_rays == 0) return NSR_OK;
-    NSR_REQUIRE(packed_info && background && comp_rgb && opacity && depth && weights && trans,
-                "nsr_composite_forward_flat: NULL pointer");
-    NSR_REQUIRE(!partials || gt_rgb, "nsr_composite_forward_flat: the loss partials need gt_rgb");
-#define NSR_FLAT_FWD(RPW)                                                                                                    \
-    hipLaunchKernelGGL((k_composite_forward_flat<RPW>), dim3(nsr_div_up(n_rays, RPW * FLAT_BLOCK / 64)), dim3(FLAT_BLOCK), 0,     \
-                       (hipStream_t)stream, (const __half *)mlp_out, stride, density_bias, t_starts, t_ends,                     \
-                       (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, comp_rgb, opacity, depth,       \
-                       n_rays, gt_rgb, partials)
-    if (g_flat_rpw == 4) NSR_FLAT_FWD(4);
-    else if (g_flat_rpw == 16) NSR_FLAT_FWD(16);
-    else NSR_FLAT_FWD(8);
-#undef NSR_FLAT_FWD
-    NSR_CHECK_LAUNCH("nsr_composite_forward_flat");
-    return NSR_OK;
-}
-
-// upstream gradients: either (grad_comp_rgb [+ grad_opacity, grad_depth, grad_weights]) or the masked smooth-L1 loss on
-// (comp_rgb, opacity, gt_rgb) with its (sum, valid) either in acc2 (partials == NULL) or as the forward's partials (then
-// acc2 receives the totals)
-extern "C" int nsr_composite_backward_flat(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
-                                           const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
-                                           const int32_t *packed_info, const float *background, const float *weights,
-                                           const float *trans, const float *grad_comp_rgb, const float *grad_opacity,
-                                           const float *grad_depth, const float *grad_weights, const float *comp_rgb,
-                                           const float *opacity, const float *gt_rgb, const float *partials, float *acc2,
-                                           float grad_scale, float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream)
-{
-    if (n_rays == 0) return NSR_OK;
-    NSR_REQUIRE(packed_info && background && weights && trans && grad_rgb && grad_logit, "nsr_composite_backward_flat: NULL pointer");
-    NSR_REQUIRE((grad_comp_rgb != nullptr) != (comp_rgb != nullptr), "nsr_composite_backward_flat: either upstream gradients "
-                "or the built-in loss");
-    NSR_REQUIRE(!comp_rgb || (opacity && gt_rgb && acc2), "nsr_composite_backward_flat: the built-in loss needs opacity, gt_rgb, acc2");
-#define NSR_FLAT_BWD(RPW)                                                                                                    \
-    hipLaunchKernelGGL((k_composite_backward_flat<RPW>), dim3(nsr_div_up(n_rays, RPW * FLAT_BLOCK / 64)), dim3(FLAT_BLOCK), 0,    \
-                       (hipStream_t)stream, (const __half *)mlp_out, stride, density_bias, t_starts, t_ends,                     \
-                       (const __half *)rgb, rgb_stride, packed_info, background, weights, trans, grad_comp_rgb, grad_opacity,    \
-                       grad_depth, grad_rgb, grad_logit, n_rays, comp_rgb, opacity, gt_rgb, partials ? nullptr : acc2,           \
-                       grad_scale, grad_weights, partials, partials ? acc2 : nullptr)
-    if (g_flat_rpw == 4) NSR_FLAT_BWD(4);
-    else if (g_flat_rpw == 16) NSR_FLAT_BWD(16);
-    else NSR_FLAT_BWD(8);
-#undef NSR_FLAT_BWD
-    NSR_CHECK_LAUNCH("nsr_composite_backward_flat");
     return NSR_OK;
 }
 

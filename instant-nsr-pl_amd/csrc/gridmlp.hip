@@ -142,151 +142,6 @@ k_grid_mlp_forward(const float *__restrict__ x, const __half *__restrict__ table
     }
 }
 
-// ---- the sigma pass of ray marching (reference models/nerf.py:65-93: sigma_fn inside nerfacc.ray_marching, then the
-// transmittance cut `T >= early_stop_eps`) as ONE ray-ordered kernel that STOPS AT THE CUT ------------------------------------
-// The samples a ray keeps are a prefix of the samples it marched (transmittance only falls), and on a trained scene ~60 % of
-// the marched samples lie behind their ray's cut (tools/early_exit_fraction.py: 2.5e5 marched, 9.2e4 kept, 1.5e5 inside
-// 64-sample windows that reach the cut) -- the stand-alone encode + MLP evaluate all of them.  Here a WORKGROUP takes a ray:
-// per iteration its four waves encode and push through the MLP the ray's next 64 samples (wave w: samples [16 w, 16 w + 16)
-// of the window, one MFMA tile, exactly the lane roles of k_grid_mlp_forward), the 64 values of 1 - alpha meet in LDS, and
-// every wave runs the SAME 64-lane product scan k_visibility_prefix runs over them: same operations in the same order, so the
-// kept counts, and the features / activations / logits of every sample in front of the cut, are bit-identical to the
-// three-launch path (nsr_hashgrid_forward + nsr_mlp_forward + nsr_visibility_prefix).  Samples behind the window that
-// crossed the cut are never touched; nothing downstream reads them (the kept rows are copied out).
-template <int F, int NH>
-__global__ void __launch_bounds__(MLP_BLOCK)
-k_sigma_rays(const float *__restrict__ x, const __half *__restrict__ table, const __half *__restrict__ W_,
-             __half *__restrict__ out, __half *__restrict__ acts, __half *__restrict__ enc, uint32_t n /* rows of the
-             buffers = plane stride */, uint32_t mask_count, uint32_t n_in, const NsrGridDesc d,
-             const int32_t *__restrict__ packed, const float *__restrict__ t0, const float *__restrict__ t1, float bias,
-             float eps, int32_t *__restrict__ kept, uint32_t n_rays)
-{
-    constexpr int IN_PAD = 32, LPL = 8 / F;  // levels per lane
-    __shared__ float s_oma[2][64];
-    const int lane = threadIdx.x & 63, nl = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
-    const _Float16 *W = reinterpret_cast<const _Float16 *>(W_);
-    LevelGeom geo[LPL];
-    bool live[LPL];
-#pragma unroll
-    for (int i = 0; i < LPL; ++i) {
-        const uint32_t level = (uint32_t)(g * LPL + i);
-        geo[i].scale = 0.f; geo[i].res = 1u; geo[i].size = 8u; geo[i].offset = 0u; geo[i].dense = true;
-#pragma unroll
-        for (uint32_t l = 0; l < NSR_MAX_LEVELS; ++l) {
-            if (l == level && l < d.n_levels) geo[i] = load_level(d, l);
-        }
-        live[i] = level < d.n_levels && level < mask_count;
-    }
-    half8 a0[4];
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) a0[ob] = load_a_natural(W, IN_PAD, ob * 16 + nl, 0, g, IN_PAD);
-    half8 ah[NH > 1 ? NH - 1 : 1][4][2];
-#pragma unroll
-    for (int h = 0; h < NH - 1; ++h) {
-        const _Float16 *Wh = W + WIDTH * IN_PAD + h * WIDTH * WIDTH;
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) ah[h][ob][kc] = load_a_sigma(Wh, WIDTH, ob * 16 + nl, kc, g);
-    }
-    const _Float16 *Wl = W + WIDTH * IN_PAD + (NH - 1) * WIDTH * WIDTH;
-    half8 al[2];
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) al[kc] = load_a_sigma(Wl, WIDTH, nl, kc, g);
-
-    int buf = 0;
-    // persistent workgroups: the 14 KB of weight fragments per wave are loaded once, not once per ray
-    for (uint32_t r = blockIdx.x; r < n_rays; r += gridDim.x) {
-    const uint32_t start = (uint32_t)packed[2ull * r], count = (uint32_t)packed[2ull * r + 1];
-    if (count == 0) {  // (most slots of a step: rays that miss everything occupied)
-        if (threadIdx.x == 0) kept[r] = 0;
-        continue;
-    }
-    float carry = 1.f;
-    uint32_t n_kept = 0;
-    for (uint32_t c = 0; c < count; c += 64, buf ^= 1) {
-        const uint32_t k = c + 16u * (uint32_t)w + (uint32_t)nl;
-        const bool valid = k < count;
-        float oma = 1.f;
-        if (c + 16u * (uint32_t)w < count) {  // (wave-uniform: this wave's tile of the window has samples)
-            const uint32_t s = start + (valid ? k : 0u);
-            const float x0 = x[3ull * s], x1 = x[3ull * s + 1], x2 = x[3ull * s + 2];
-            half8 b;
-#pragma unroll
-            for (int i = 0; i < LPL; ++i) {
-                float v[F];
-#pragma unroll
-                for (int f = 0; f < F; ++f) v[f] = 0.f;
-                if (live[i] && valid) encode_level_from<F>(table + (uint64_t)geo[i].offset * F, geo[i], x0, x1, x2, v);
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    const int col = 8 * g + i * F + f;
-                    b[i * F + f] = col < (int)n_in ? (_Float16)__half2float(__float2half_rn(v[f])) : (_Float16)1;
-                }
-            }
-            if (!valid) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b[j] = (_Float16)0;
-            }
-            if (valid) {
-#pragma unroll
-                for (int i = 0; i < LPL; ++i) {
-                    const uint32_t level = (uint32_t)(g * LPL + i);
-                    if (level >= d.n_levels) continue;
-                    _Float16 *dst = reinterpret_cast<_Float16 *>(enc) + ((uint64_t)level * n + s) * F;
-#pragma unroll
-                    for (int f = 0; f < F; ++f) dst[f] = b[i * F + f];
-                }
-            }
-            f32x4 acc[4];
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma32(a0[ob], b, f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[ob][q] = fmaxf(acc[ob][q], 0.f);
-                    if (acts && valid) store_h4(acts + ((uint64_t)h * n + s) * WIDTH + ob * 16 + 4 * g, acc[ob]);
-                }
-                const half8 b0 = pack_b(acc[0], acc[1]), b1 = pack_b(acc[2], acc[3]);
-                if (h < NH - 1) {
-#pragma unroll
-                    for (int ob = 0; ob < 4; ++ob) {
-                        f32x4 cc = {0.f, 0.f, 0.f, 0.f};
-                        cc = mfma32(ah[h][ob][0], b0, cc);
-                        acc[ob] = mfma32(ah[h][ob][1], b1, cc);
-                    }
-                } else {
-                    f32x4 cc = {0.f, 0.f, 0.f, 0.f};
-                    cc = mfma32(al[0], b0, cc);
-                    cc = mfma32(al[1], b1, cc);
-                    if (valid) {
-                        store_h4(out + (uint64_t)s * 16 + 4 * g, cc);
-                        if (g == 0) {  // the density logit is output 0: the arithmetic of k_visibility_prefix on the STORED half
-                            const float sigma = expf(__half2float(__float2half_rn(cc[0])) + bias);
-                            const float alpha = 1.f - expf(-sigma * (t1[s] - t0[s]));
-                            oma = 1.f - alpha;
-                        }
-                    }
-                }
-            }
-        }
-        if (g == 0) s_oma[buf][16 * w + nl] = oma;
-        __syncthreads();  // (one barrier per window: the buffers alternate, a window's values are read before the
-                          // barrier of the next one and overwritten after it)
-        const bool ok = c + (uint32_t)lane < count;
-        const float inc = wave_incl_scan_mul(s_oma[buf][lane]);
-        float exc = __shfl_up(inc, 1, 64);
-        if (lane == 0) exc = 1.f;
-        const float T = carry * exc;
-        n_kept += (uint32_t)__popcll(__ballot(ok && T >= eps));
-        carry *= __shfl(inc, 63, 64);
-        if (carry < eps) { buf ^= 1; break; }  // (identical in every wave of the workgroup)
-    }
-    if (threadIdx.x == 0) kept[r] = (int32_t)n_kept;
-    }
-}
 
 // measured (tools/grid_mlp_ab.py): 512 workgroups beat 2048 / 8192 at every size -- a wave fetches 14 KB of weights before its
 // first tile, and more than ~8 waves per CU only add gather requests in flight to an L2 that is already missing
@@ -350,32 +205,6 @@ extern "C" int nsr_grid_mlp_forward(const float *x, const nsr_half *table, const
     return NSR_OK;
 }
 
-static uint32_t g_sigma_blocks = 768;  // 3 workgroups per CU at 136 VGPRs
-extern "C" uint32_t nsr_sigma_rays_blocks(uint32_t blocks)
-{
-    const uint32_t old = g_sigma_blocks;
-    if (blocks) g_sigma_blocks = blocks;
-    return old;
-}
-
-extern "C" int nsr_sigma_rays(const float *x, const nsr_half *table, const nsr_half *weights, nsr_half *out, nsr_half *acts,
-                              nsr_half *enc, uint32_t n_rows, const int32_t *packed_info, const float *t_starts,
-                              const float *t_ends, float density_bias, float early_stop_eps, int32_t *kept_counts,
-                              uint32_t n_rays, const NsrGridDesc *grid, const NsrMlpDesc *mlp, void *stream)
-{
-    NSR_REQUIRE(grid && mlp && nsr_grid_mlp_supported(grid, mlp) && mlp->output_activation == NSR_ACT_NONE,
-                "nsr_sigma_rays: unsupported grid / MLP pair (see nsr_grid_mlp_supported; no output activation)");
-    if (n_rays == 0) return NSR_OK;
-    NSR_REQUIRE(x && table && weights && out && enc && packed_info && t_starts && t_ends && kept_counts,
-                "nsr_sigma_rays: NULL pointer");
-    GM_DISPATCH(grid->n_features, mlp->n_hidden,
-                hipLaunchKernelGGL((k_sigma_rays<F, NH>), dim3(n_rays < g_sigma_blocks ? n_rays : g_sigma_blocks), dim3(MLP_BLOCK), 0, (hipStream_t)stream, x,
-                                   (const __half *)table, (const __half *)weights, (__half *)out, (__half *)acts,
-                                   (__half *)enc, n_rows, grid->n_levels, mlp->n_in, *grid, packed_info, t_starts, t_ends,
-                                   density_bias, early_stop_eps, kept_counts, n_rays));
-    NSR_CHECK_LAUNCH("nsr_sigma_rays");
-    return NSR_OK;
-}
 
 // Backward of the pair: nothing to fuse into one kernel -- the MLP's data gradient already leaves k_mlp_dgrad level-major,
 // exactly as the owner-computes table backward reads it, so the encoding's gradient makes one trip through HBM and no

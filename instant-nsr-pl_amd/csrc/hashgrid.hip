@@ -208,19 +208,16 @@ template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward_pair(const float *__restrict__ x, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
                     uint32_t y_stride, uint32_t mask_count, uint32_t level_begin, int level_major, const NsrGridDesc d,
-                    const int32_t *__restrict__ n_dev,
-                    uint32_t half /* 0: all 16 levels; 1 / 2: levels [0, 8) / [8, 16) only (round 5: the encode of the next step's
-                                     first half runs beside the table backward of the second -- csrc/step.hip).  A half launch pairs
-                                     levels (lo + p, lo + p + 4) on XCDs p and p + 4: still two levels = 4 MB of table per L2 */)
+                    const int32_t *__restrict__ n_dev)
 {
     const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t blk = half ? (blockIdx.x >> 3) * 2u + (xcd >> 2) : blockIdx.x >> 3;
+    const uint32_t blk = blockIdx.x >> 3;
     const uint32_t i = blk * GRID_BLOCK + threadIdx.x;
     if (i >= live_count(n, n_dev)) return;
     const float x0 = x[3ull * i], x1 = x[3ull * i + 1], x2 = x[3ull * i + 2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const uint32_t level = half ? (half - 1u) * 8u + (xcd & 3u) + 4u * h : xcd + 8u * h;
+        const uint32_t level = xcd + 8u * h;
         if (level >= d.n_levels || level < level_begin) continue;
         float acc[F];
         if (level < mask_count) {
@@ -639,7 +636,7 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
         DISPATCH_F(desc->n_features,
                    hipLaunchKernelGGL((k_grid_forward_pair<F>), dim3(8u * nsr_div_up(n, GRID_BLOCK)), dim3(GRID_BLOCK), 0,
                                       (hipStream_t)stream, x, (const __half *)table, (__half *)y, n, y_stride,
-                                      level_mask_count, level_begin, y_level_major, *desc, n_dev, 0u));
+                                      level_mask_count, level_begin, y_level_major, *desc, n_dev));
         NSR_CHECK_LAUNCH("nsr_hashgrid_forward(pair)");
         return NSR_OK;
     }
@@ -648,25 +645,6 @@ extern "C" int nsr_hashgrid_forward_ex(const float *x, const nsr_half *table, ns
                                   (const __half *)table, (__half *)y, n, y_stride, level_mask_count, lpx, y_level_major,
                                   *desc, n_dev, (float *)nullptr, level_begin));
     NSR_CHECK_LAUNCH("nsr_hashgrid_forward");
-    return NSR_OK;
-}
-
-// levels [0, 8) (half = 1) or [8, 16) (half = 2) of a 16-level grid only, in the pair kernel's XCD placement; the two halves
-// together write exactly what nsr_hashgrid_forward_ex writes (bit for bit: the same per-level arithmetic)
-extern "C" int nsr_hashgrid_forward_half(const float *x, const nsr_half *table, nsr_half *y, uint32_t n, uint32_t y_stride,
-                                         int y_level_major, uint32_t level_mask_count, int half, const NsrGridDesc *desc,
-                                         const int32_t *n_dev, void *stream)
-{
-    if (int rc = check_desc(desc, "nsr_hashgrid_forward_half")) return rc;
-    NSR_REQUIRE(desc->n_levels == 16 && (half == 1 || half == 2), "nsr_hashgrid_forward_half: 16 levels, half 1 or 2");
-    NSR_REQUIRE(y_level_major || y_stride >= desc->n_levels * desc->n_features, "nsr_hashgrid_forward_half: y_stride too small");
-    if (n == 0) return NSR_OK;
-    NSR_REQUIRE(x && table && y, "nsr_hashgrid_forward_half: NULL pointer");
-    DISPATCH_F(desc->n_features,
-               hipLaunchKernelGGL((k_grid_forward_pair<F>), dim3(8u * nsr_div_up(nsr_div_up(n, GRID_BLOCK), 2)), dim3(GRID_BLOCK), 0,
-                                  (hipStream_t)stream, x, (const __half *)table, (__half *)y, n, y_stride, level_mask_count, 0u,
-                                  y_level_major, *desc, n_dev, (uint32_t)half));
-    NSR_CHECK_LAUNCH("nsr_hashgrid_forward_half");
     return NSR_OK;
 }
 
@@ -922,8 +900,6 @@ extern "C" int nsr_hashgrid_owner_debug_map(const NsrGridDesc *desc, int large, 
     return NSR_OK;
 }
 
-#include "hashgrid_dense.inc"
-
 // the owner's part of the workspace (either configuration), rounded to 16 bytes: where the dense-level accumulators start
 static uint64_t owner_workspace_floats(const NsrGridDesc *desc, uint32_t n)
 {
@@ -934,82 +910,9 @@ static uint64_t owner_workspace_floats(const NsrGridDesc *desc, uint32_t n)
 extern "C" uint64_t nsr_hashgrid_backward_params_workspace_floats(const NsrGridDesc *desc, uint32_t n)
 {
     if (!desc || check_desc(desc, "nsr_hashgrid_backward_params_workspace_floats")) return 0;
-    return owner_workspace_floats(desc, n) + dense_levels::dl_workspace_floats(desc);
+    return owner_workspace_floats(desc, n);
 }
 
-// ---- the dense (coarse) levels through ray-run merged fixed-point atomics (hashgrid_dense.inc) -------------------------------
-// number of leading dense levels: the level range [0, k) this path covers; the owner launch of the same step takes [k, L)
-extern "C" uint32_t nsr_hashgrid_dense_levels(const NsrGridDesc *desc)
-{
-    if (!desc || check_desc(desc, "nsr_hashgrid_dense_levels")) return 0;
-    return dense_levels::dl_count(desc);
-}
-
-static int g_dense_probe = 0;  // timing probes of tools/dense_levels_bench.py (NSR_DENSE_PROBE, read once): never set in product runs
-// phases: 1 = clear the accumulators (a memset on `stream`), 2 = accumulate the samples' contributions (x [n,3] in RAY ORDER --
-// any order is correct, ray order is what makes it cheap --, dy level-major fp32 [L][n][F]), 4 = write out: AdamW on the dense
-// levels' parameters (adam), or their gradient as fp32 (grad_table, the table's base; accumulate != 0 adds) or bf16
-// (grad_bf16, the table's base).  workspace / n as for the owner calls of the same step (same workspace, same n).
-extern "C" int nsr_hashgrid_backward_params_dense(const float *x, const float *dy_level_major, float *grad_table,
-                                                  void *grad_bf16, const NsrTableAdam *adam, float *workspace, uint32_t n,
-                                                  uint32_t level_mask_count, float grad_scale, int accumulate,
-                                                  const NsrGridDesc *desc, const int32_t *n_dev, int phases, void *stream)
-{
-    if (int rc = check_desc(desc, "nsr_hashgrid_backward_params_dense")) return rc;
-    NSR_REQUIRE(workspace, "nsr_hashgrid_backward_params_dense: workspace is NULL");
-    NSR_REQUIRE(phases >= 1 && phases <= 7, "nsr_hashgrid_backward_params_dense: phases is a mask of 1 | 2 | 4");
-    const uint32_t D = dense_levels::dl_count(desc), F = desc->n_features;
-    if (D == 0) return NSR_OK;
-    static const bool probe_read = [] { if (const char *e = getenv("NSR_DENSE_PROBE")) g_dense_probe = atoi(e); return true; }();
-    (void)probe_read;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned long long *acc = reinterpret_cast<unsigned long long *>(workspace + owner_workspace_floats(desc, n));
-    const uint64_t words = dense_levels::dl_acc_words64(desc);
-    uint32_t *flags = reinterpret_cast<uint32_t *>(acc + words);
-    if (phases & 1)
-        NSR_REQUIRE(hipMemsetAsync(acc, 0, words * 8 + 32 * 4, st) == hipSuccess,
-                    "nsr_hashgrid_backward_params_dense: hipMemsetAsync failed");
-    if ((phases & 2) && n > 0) {
-        NSR_REQUIRE(x && dy_level_major, "nsr_hashgrid_backward_params_dense: NULL pointer");
-        const uint32_t lv = level_mask_count < D ? level_mask_count : D;
-        if (lv > 0) {
-            DISPATCH_F(F, hipLaunchKernelGGL((dense_levels::k_dense_levels_accumulate<F>),
-                                             dim3(nsr_div_up(n, dense_levels::DL_BLOCK), lv), dim3(dense_levels::DL_BLOCK), 0,
-                                             st, x, dy_level_major, n, level_mask_count, grad_scale, acc, flags, *desc, n_dev,
-                                             g_dense_probe));
-            NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_dense(accumulate)");
-        }
-    }
-    if (phases & 4) {
-        NSR_REQUIRE((adam != nullptr) + (grad_table != nullptr) + (grad_bf16 != nullptr) == 1,
-                    "nsr_hashgrid_backward_params_dense: exactly one of adam / grad_table / grad_bf16");
-        own_small::OwnerAdam ad;
-        memset(&ad, 0, sizeof(ad));
-        if (adam) {
-            NSR_REQUIRE(adam->params && adam->exp_avg && adam->exp_avg_sq && adam->step && adam->hyper && !accumulate,
-                        "nsr_hashgrid_backward_params_dense: fused AdamW needs params / moments / schedule state and "
-                        "accumulate == 0");
-            NSR_REQUIRE((((uintptr_t)adam->params | (uintptr_t)adam->exp_avg | (uintptr_t)adam->exp_avg_sq) & 15) == 0 &&
-                            ((uintptr_t)adam->shadow & 7) == 0 && ((uintptr_t)adam->hyper & 7) == 0,
-                        "nsr_hashgrid_backward_params_dense: fused AdamW buffers must be 16-byte aligned (fp16 image: 8)");
-            ad.p = adam->params; ad.m = adam->exp_avg; ad.v = adam->exp_avg_sq; ad.shadow = (__half *)adam->shadow;
-            ad.step = adam->step; ad.hyper = adam->hyper;
-            ad.base_lr = adam->base_lr; ad.b1d = adam->beta1; ad.b2d = adam->beta2; ad.gamma = adam->gamma;
-            ad.m0 = adam->milestone0; ad.m1 = adam->milestone1; ad.m2 = adam->milestone2;
-            ad.b1 = (float)adam->beta1; ad.b2 = (float)adam->beta2; ad.eps = adam->eps; ad.wd = adam->weight_decay;
-        }
-        NSR_REQUIRE(!grad_bf16 || (!accumulate && ((uintptr_t)grad_bf16 & 7) == 0),
-                    "nsr_hashgrid_backward_params_dense: the bf16 gradient is written once into an 8-byte aligned buffer");
-        NSR_REQUIRE(!grad_table || ((uintptr_t)grad_table & 15) == 0,
-                    "nsr_hashgrid_backward_params_dense: grad_table must be 16-byte aligned");
-        const uint32_t blocks = nsr_div_up(words, (uint64_t)dense_levels::DL_BLOCK * 4);
-        DISPATCH_F(F, hipLaunchKernelGGL((dense_levels::k_dense_levels_finish<F>), dim3(blocks < 1024 ? blocks : 1024),
-                                         dim3(dense_levels::DL_BLOCK), 0, st, acc, flags, D, grad_table, accumulate,
-                                         (uint16_t *)grad_bf16, *desc, ad));
-        NSR_CHECK_LAUNCH("nsr_hashgrid_backward_params_dense(finish)");
-    }
-    return NSR_OK;
-}
 
 template <typename... A>
 static int owner_backward(const float *x, const void *dy, int dy_layout, uint32_t dy_stride, float *grad_table,
@@ -1033,17 +936,6 @@ extern "C" int nsr_hashgrid_backward_params_owner_bin(const float *x, float *wor
                                                       const int32_t *n_dev, void *stream)
 {
     return owner_backward(x, nullptr, 2, 0, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, n_dev, 1, stream);
-}
-
-// ... of the levels [level_begin, level_end) only (the others' items are then never looked at: their gradient comes from
-// elsewhere -- nsr_hashgrid_backward_params_dense for the leading dense levels)
-extern "C" int nsr_hashgrid_backward_params_owner_bin_range(const float *x, float *workspace, uint32_t n,
-                                                            uint32_t level_mask_count, uint32_t level_begin,
-                                                            uint32_t level_end, const NsrGridDesc *desc,
-                                                            const int32_t *n_dev, void *stream)
-{
-    return owner_backward(x, nullptr, 2, 0, nullptr, workspace, n, level_mask_count, 1.f, 0, desc, n_dev, 1, stream, nullptr,
-                          nullptr, nullptr, 0, nullptr, nullptr, level_begin, level_end);
 }
 
 // ... for items that a ..._with_second_order accumulation (binned != 0) will consume: the slice configuration of a launch is
@@ -1091,21 +983,6 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x
     NSR_REQUIRE(adam, "nsr_hashgrid_backward_params_owner_accumulate_adam: adam is NULL");
     return owner_backward(x, dy, dy_layout, dy_stride, nullptr, workspace, n, level_mask_count, grad_scale, 0, desc, n_dev,
                           2, stream, nullptr, nullptr, adam);
-}
-
-// ... over the run of levels [level_begin, level_end) only (level-major fp32 dy, items binned beforehand): a step may put the
-// small dense levels -- whose hot chunks are the slowest workgroups of a trained scene, and whose chunk slabs need the
-// reduction launch behind them -- on a stream of their own beside the other levels (csrc/step.hip)
-extern "C" int nsr_hashgrid_backward_params_owner_accumulate_adam_range(const float *x, const float *dy_level_major,
-                                                                        float *workspace, uint32_t n,
-                                                                        uint32_t level_mask_count, float grad_scale,
-                                                                        uint32_t level_begin, uint32_t level_end,
-                                                                        const NsrGridDesc *desc, const int32_t *n_dev,
-                                                                        const NsrTableAdam *adam, void *stream)
-{
-    NSR_REQUIRE(adam, "nsr_hashgrid_backward_params_owner_accumulate_adam_range: adam is NULL");
-    return owner_backward(x, dy_level_major, 2, 0, nullptr, workspace, n, level_mask_count, grad_scale, 0, desc, n_dev, 2,
-                          stream, nullptr, nullptr, adam, 0, nullptr, nullptr, level_begin, level_end);
 }
 
 // first level that is NOT cut into item chunks in the slice configuration a launch of n points takes

@@ -138,40 +138,25 @@ extern "C" int nsr_profile_collect(int tag, double *total_ms, uint64_t *launches
 
 // Helper stream of the main pass: the item binning of the table backward depends only on the sample positions, so it runs
 // beside the colour MLP / compositing / MLP backward chain instead of in front of the accumulation kernel.
-// (round 5) two more streams: `stream_b` takes the density network's weight-gradient kernels beside the colour network's on
-// `stream`, `stream_c` the dense levels' table backward (csrc/hashgrid_dense.inc) beside the owner launch of the hashed levels
-struct HelperEvents { hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr, dgrad_done = nullptr,
-                                  wgrad_b_done = nullptr, dense_done = nullptr, table_a_done = nullptr, enc_a_done = nullptr,
-                                  table_done = nullptr; };
+// (ONE helper stream: HIP maps streams to a pool of 4 hardware queues in first-use order; every further stream measured slower
+// -- profiles/r05_step_variants_*.json -- and is gone with the forms that used it)
+struct HelperEvents { hipEvent_t fork = nullptr, join = nullptr, join_wgrad = nullptr, fork_wgrad = nullptr, dgrad_done = nullptr; };
 struct HelperStream {
-    hipStream_t stream = nullptr, stream_b = nullptr, stream_c = nullptr;
-    // two sets of the pass's events: [0] plain, [1] created with hipEventReleaseToDevice (a device-scope release when the event
-    // is recorded instead of the default system-scope one: every waiter is a stream of this device) -- nsr_nerf_step_variant key 6
-    HelperEvents ev[2];
+    hipStream_t stream = nullptr;
+    HelperEvents ev;
     bool ok = false;
     bool init()
     {
         if (ok) return true;
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
-        // (stream_b / stream_c only when a form that uses them is switched on -- need_extra(): HIP maps streams to a pool of 4
-        // hardware queues; streams nobody uses must not shift which queue the step's three working streams get)
-        for (int k = 0; k < 2; ++k)
-            for (hipEvent_t *e : {&ev[k].fork, &ev[k].join, &ev[k].join_wgrad, &ev[k].fork_wgrad, &ev[k].dgrad_done,
-                                  &ev[k].wgrad_b_done, &ev[k].dense_done, &ev[k].table_a_done, &ev[k].enc_a_done, &ev[k].table_done})
-                if (hipEventCreateWithFlags(e, hipEventDisableTiming | (k ? hipEventReleaseToDevice : 0u)) != hipSuccess) return false;
+        for (hipEvent_t *e : {&ev.fork, &ev.join, &ev.join_wgrad, &ev.fork_wgrad, &ev.dgrad_done})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return false;
         return ok = true;
-    }
-    bool need_extra()
-    {
-        if (!init()) return false;
-        if (!stream_b && hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking) != hipSuccess) return false;
-        if (!stream_c && hipStreamCreateWithFlags(&stream_c, hipStreamNonBlocking) != hipSuccess) return false;
-        return true;
     }
 };
 static HelperStream g_helper;  // one per process (= per GPU: one process per GPU)
-static int g_variant[12] = {1, 0, 2, 0, 0, 1, 0, 0, 0, 128, 0, 0};  // nsr_nerf_step_variant (below)
-#define HEV (g_helper.ev[g_variant[6] ? 1 : 0])
+static int g_variant[12] = {1, 0, 1, 0, 0, 1, 0, 0, 0, 128, 0, 0};  // nsr_nerf_step_variant (below)
+#define HEV (g_helper.ev)
 
 // the helper stream's handle (created on first use), for callers that queue follow-up work behind the weight-gradient
 // kernels themselves (the trainer's optimizer launch for the MLP weights); NULL if it could not be created
@@ -187,34 +172,20 @@ extern "C" int nsr_nerf_wait_kept_rows(void *stream)
     return NSR_OK;
 }
 
-// Round-5 forms of the step's kernels, switchable for same-process A/B runs (tools/step_variants.py) and as a fallback:
+// Forms of the step's kernels that stay switchable for the same-process A/B block of bench.py (`step_forms_ab`: this round's
+// step against the round-4 forms of the same kernels) and as a fallback:
 //   key 0: both networks' data gradients in ONE kernel (nsr_mlp_dgrad_pair) instead of two launches + a d_feature round trip
-//   key 1: the dense levels' table gradient through ray-run merged fixed-point atomics on a stream of their own
-//          (nsr_hashgrid_backward_params_dense), the owner launch covering the hashed levels only.  DEFAULT 0: measured
-//          (profiles/r05_dense_levels_bench.json, r05_step_variants*.json) -- isolated, the dense path is 41 + 11 us beside
-//          a 79 us owner launch instead of one 97 us launch; inside the step its 8e5 device-scope atomics and the extra
-//          launches contend with the weight-gradient kernels and the owner itself (150 us instead of 123): +4 % per step
-//   key 2: flat segmented compositing (nsr_composite_*_flat) instead of one wave per ray
-//   key 3: the two networks' weight-gradient kernels on two helper streams (only with key 0).  DEFAULT 0: measured with the
-//          rest of the forms on, one stream 0.363 ms per step, two streams 0.371 (more kernels beside the table backward)
-//   key 4: the weight-gradient kernels queued behind the table backward (under the next step's encode) instead of beside it;
-//          needs a caller that defers its join with them to nsr_nerf_wait_before_mlp (default 0)
+//   key 2: sample-partitioned compositing (nsr_composite_*_samples) instead of one wave per ray
 //   key 5: the pass's fork events ride on the kernels in front of them (hipExtLaunchKernelGGL stop event) instead of being
 //          recorded behind them
-//   key 6: the pass's events are the set created with hipEventReleaseToDevice (device-scope release at the record)
-//   key 7: the table backward is ISSUED before the weight-gradient launches of the helper streams (host order only)
 //   key 9: block cap of the pass's weight-gradient launches (nsr_mlp_wgrad_max_blocks, set around the pass's own launches only;
 //          default 128 -- measured in the step: 512 -> 0.373, 256 -> 0.368, 128 -> 0.365, 64 -> 0.370, 32 -> 0.391 ms: with the
 //          join deferred to the next density MLP fewer 64 KB-LDS blocks leave the table backward more of the chip; 0 = leave it)
-//   key 10: the table backward (with AdamW inside) on the HELPER stream, in order behind its own binning launch -- no join in
-//          front of it on the step's stream --, the weight-gradient kernels inline on the step's stream behind the data-gradient
-//          kernel -- no fork --; the caller queues its MLP optimizer launch on the step's stream and then
-//          nsr_nerf_wait_table(stream).  Only with nsr_nerf_defer_wgrad_join, the fused table update and no exchange;
-//          nsr_nerf_last_pass_form() says whether the last pass took it
-//   key 8: the table backward (with AdamW inside) as TWO launches, levels [0, 8) then [8, 16), and the NEXT pruning pass's encode
-//          as two halves: levels [0, 8) on a helper stream as soon as the first launch has retired -- beside the second --, levels
-//          [8, 16) on the step's stream; needs nsr_nerf_set_inputs_event (the next step's positions come from another stream)
-// value < 0 queries; returns the previous value.  Keys 0, 2, 5 default to 1.
+// The forms rounds 4-5 measured and rejected -- dense levels through merged atomics, two weight-gradient streams, weight gradients
+// behind the table backward, release-to-device events, a different host issue order, pipelined half encodes, the table backward
+// on the helper stream, the ray-ordered sigma pass, ray-partitioned flat compositing -- are recorded in profiles/r04_*, r05_*,
+// r06_step_variants_compositing.json and DESIGN.md section 5.1; their code is gone.
+// value < 0 queries; returns the previous value.
 
 extern "C" int nsr_nerf_step_variant(int key, int value)
 {
@@ -229,16 +200,6 @@ extern "C" int nsr_nerf_step_variant(int key, int value)
 // that launch's event over instead of making the step's stream wait for it in front of the encode: the weight-gradient
 // kernels + the optimizer then have the encode's duration to finish.  NULL clears.  The caller must make its stream wait for
 // the event itself before anything ELSE reads the weights on it (occupancy refresh, evaluation, checkpoints).
-// (key 8) one-shot: the event behind which the NEXT pruning pass's inputs (positions, marched count: written on the caller's
-// marching stream) exist -- its first encode half runs on a helper stream that has to wait for them itself
-static hipEvent_t g_inputs_event = nullptr;
-static bool g_table_a_pending = false;  // the last main pass recorded HEV.table_a_done between its two table-backward launches
-extern "C" int nsr_nerf_set_inputs_event(void *event)
-{
-    g_inputs_event = (hipEvent_t)event;
-    return NSR_OK;
-}
-
 static hipEvent_t g_wait_before_mlp = nullptr;
 extern "C" int nsr_nerf_wait_before_mlp(void *event)
 {
@@ -287,40 +248,6 @@ static uint64_t prune_sums_offset(const NsrNerfStepDesc *d, uint32_t n_marched)
     return L.total_bytes - align_up(PRUNE_SUMS_BYTES);
 }
 
-// the sigma pass of nsr_nerf_prune_pass: 0 (default) = stand-alone encode + MLP + visibility prefix over every marched sample,
-// 1 = the ray-ordered kernel that stops at the transmittance cut (nsr_sigma_rays).  Returns the previous mode.
-// Measured (tools/sigma_rays_bench.py, profiles/r04_sigma_rays_bench.json: ray sets of a trained model, 2.5e5 marched / 9.1e4
-// kept samples, 1.5e5 inside windows that reach their ray's cut): 85-87 us for the three launches, 109-121 us for the
-// ray-ordered kernel although it touches 60 % of the samples -- every wave of it gathers from all 16 levels (24 MB of table
-// against 4 MB of L2 per XCD: the gathers are served by the Infinity Cache), while the stand-alone encode keeps two levels per
-// XCD and hits its L2 94 % of the time.  The step: 0.569 vs 0.538 ms.  Kept as an entry point with its parity tests.
-static int g_sigma_rays = 0;
-extern "C" int nsr_nerf_sigma_mode(int mode)
-{
-    const int old = g_sigma_rays;
-    if (mode >= 0) g_sigma_rays = mode != 0;
-    return old;
-}
-
-// key 10: the last main pass left its table update running on the helper stream (HEV.table_done is recorded behind it)
-static bool g_table_pending = false;
-static hipEvent_t g_table_event = nullptr;
-static int g_last_form = 0;
-// bit 0: the last nsr_nerf_main_pass ran its table backward on the helper stream and its weight gradients on the caller's
-// stream (key 10): the MLP optimizer launch belongs on the caller's stream, followed by nsr_nerf_wait_table
-extern "C" int nsr_nerf_last_pass_form(void) { return g_last_form; }
-// make `stream` wait for the table update of the last main pass if it is still running on the helper stream (key 10); a no-op
-// otherwise.  Every later reader of the table on `stream` -- the next step's encode, an occupancy refresh, a checkpoint -- is
-// then ordered behind it.
-extern "C" int nsr_nerf_wait_table(void *stream)
-{
-    if (!g_table_pending) return NSR_OK;
-    NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_table_event, 0) == hipSuccess,
-                "nsr_nerf_wait_table: hipStreamWaitEvent failed");
-    g_table_pending = false;
-    return NSR_OK;
-}
-
 static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float *rays_d,
                       const int64_t *ray_indices, const float *t_starts, const float *t_ends,
                       const int32_t *packed_info, const nsr_half *table, const nsr_half *w_density,
@@ -330,7 +257,6 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
 {
     NSR_REQUIRE(d && workspace && kept_counts && packed_kept && total_kept, "nsr_nerf_prune_pass: NULL pointer");
     g_deferred.pending = false;
-    NSR_TRY(nsr_nerf_wait_table(stream));  // (a caller that did not order its stream behind a key-10 table update itself)
     NsrNerfPruneLayout L;
     NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &L));
     char *ws = (char *)workspace;
@@ -342,41 +268,8 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
     if (!x01_marched)
         NSR_TRY(nsr_sample_positions_unit(rays_o, rays_d, ray_indices, t_starts, t_ends, d->radius, d->contraction,
                                           (float *)(ws + L.x01), nullptr, n_marched, n_marched_dev, stream));
-    if (g_sigma_rays && nsr_grid_mlp_supported(&d->grid, &d->mlp_density) &&
-        d->mlp_density.output_activation == NSR_ACT_NONE) {
-        // encode + density MLP + transmittance cut in ONE ray-ordered kernel that stops at each ray's cut (csrc/gridmlp.hip:
-        // ~40 % of the marched samples lie behind it); bit-identical kept counts / rows to the three launches below
-        if (g_wait_before_mlp) {
-            NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_wait_before_mlp, 0) == hipSuccess,
-                        "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
-            g_wait_before_mlp = nullptr;
-        }
-        ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
-        NSR_TRY(nsr_sigma_rays(x01, table, w_density, out1, acts1, enc, n_marched, packed_info, t_starts, t_ends,
-                               d->density_bias, d->early_stop_eps, kept_counts, n_rays, &d->grid, &d->mlp_density, stream));
-    } else {
-        // (only when the positions were written AHEAD of the pass, on the caller's marching stream: formed inside this pass they
-        // exist on `stream` alone, and the helper stream's half would race with the kernel that writes them)
-        const bool split_encode = g_variant[8] && g_table_a_pending && g_inputs_event && x01_marched && d->grid.n_levels == 16 &&
-                                  g_helper.need_extra();
-        hipEvent_t inputs_event = g_inputs_event;
-        g_table_a_pending = false;
-        g_inputs_event = nullptr;
-        if (split_encode) {
-            // levels [0, 8) were final behind the previous main pass's first table-backward launch: their encode runs on the
-            // helper stream beside the second launch; levels [8, 16) follow on this stream
-            NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_c, inputs_event, 0) == hipSuccess &&
-                            hipStreamWaitEvent(g_helper.stream_c, HEV.table_a_done, 0) == hipSuccess,
-                        "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
-            NSR_TRY(nsr_hashgrid_forward_half(x01, table, enc, n_marched, C, 1, d->grid.n_levels, 1, &d->grid, n_marched_dev,
-                                              g_helper.stream_c));
-            NSR_REQUIRE(hipEventRecord(HEV.enc_a_done, g_helper.stream_c) == hipSuccess, "nsr_nerf_prune_pass: hipEventRecord failed");
-            ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
-            NSR_TRY(nsr_hashgrid_forward_half(x01, table, enc, n_marched, C, 1, d->grid.n_levels, 2, &d->grid, n_marched_dev,
-                                              stream));
-            NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, HEV.enc_a_done, 0) == hipSuccess,
-                        "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
-        } else {
+    {
+        {
             ProfScope p(NSR_PROF_GRID_FORWARD, n_marched, stream);
             NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
                                             stream));
@@ -489,8 +382,6 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     NSR_REQUIRE(d->mlp_color.n_in == 32 && d->mlp_density.n_out == 16, "nsr_nerf_main_pass: the texture input is "
                 "[16 features | 16 SH] (reference models/texture.py:26 with feature_dim 16)");
     g_ht.start();
-    NSR_TRY(nsr_nerf_wait_table(stream));  // (a key-10 table update of an earlier pass still running on the helper stream)
-    g_last_form = 0;
     NsrNerfPruneLayout P;
     NsrNerfMainLayout L;
     NSR_TRY(nsr_nerf_prune_layout(d, n_marched, &P));
@@ -530,10 +421,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     // compositing kernels instead of a one-workgroup kernel between them (NSR_L1_SEPARATE: A/B switch)
     static const bool l1_separate = getenv("NSR_L1_SEPARATE") != nullptr;
     const bool l1_folded = phases == 3 && compute_grads && gt_rgb && !up && S > 0 && n_rays > 0 && !l1_separate;
-    // round-5 forms (nsr_nerf_step_variant): the dense levels of the table backward on their own stream, flat compositing
-    const uint32_t n_dense = nsr_hashgrid_dense_levels(&d->grid);
-    const bool use_dense = g_variant[1] && overlap_bins && !xchg && n_dense > 0 && n_dense < Lv && g_helper.need_extra();
-    const bool flat = g_variant[2] != 0;
+    const bool flat = g_variant[2] != 0;  // (nsr_nerf_step_variant key 2: sample-partitioned compositing)
     // (a stream that is being captured into a graph takes plain launches + event records only)
     hipStreamCaptureStatus capture_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &capture_status);
@@ -591,13 +479,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                    n_kept_dev, stream));
     }
     g_ht.mark(2);
-    if (flat && g_variant[2] == 1) {  // (A/B: round 5's ray-partitioned flat form)
-        NSR_TRY(nsr_composite_forward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
-                                           comp_rgb, opacity, depth, l1_folded ? gt_rgb : nullptr,
-                                           l1_folded ? acc + 2 : nullptr, n_rays, stream));
-        if (!l1_folded && gt_rgb)
-            NSR_TRY(nsr_smooth_l1_valid_set(comp_rgb, opacity, gt_rgb, acc, n_rays, stream));
-    } else if (flat) {  // one lane per sample, a wave per 64 samples (csrc/fused.hip k_composite_forward_samples); the loss
+    if (flat) {  // one lane per sample, a wave per 64 samples (csrc/fused.hip k_composite_forward_samples); the loss
                         // partials ride along when folded
         NSR_TRY(nsr_composite_forward_samples(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept,
                                               (const int64_t *)(ws + L.ray_indices), background, weights, trans, comp_rgb,
@@ -618,15 +500,8 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     if (overlap_bins) {
         NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, HEV.fork, 0) == hipSuccess,
                     "nsr_nerf_main_pass: helper stream fork failed");
-        if (use_dense)  // (its accumulators are cleared on the stream the dense kernels run on: ordered behind last step's)
-            NSR_TRY(nsr_hashgrid_backward_params_dense(nullptr, nullptr, nullptr, nullptr, nullptr, (float *)(ws + L.grid_ws), S,
-                                                       Lv, 1.0f, 0, &d->grid, n_kept_dev, 1, g_helper.stream_c));
         {
             ProfScope p(NSR_PROF_GRID_BACKWARD_BIN, S, g_helper.stream);
-            if (use_dense)  // the owner launch takes the hashed levels only: nothing else needs items
-                NSR_TRY(nsr_hashgrid_backward_params_owner_bin_range(x01, (float *)(ws + L.grid_ws), S, Lv, n_dense, Lv,
-                                                                     &d->grid, n_kept_dev, g_helper.stream));
-            else
             NSR_TRY(nsr_hashgrid_backward_params_owner_bin(x01, (float *)(ws + L.grid_ws), S, d->grid.n_levels, &d->grid,
                                                            n_kept_dev, g_helper.stream));
         }
@@ -673,15 +548,7 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
     static const bool wgrad_inline = getenv("NSR_WGRAD_INLINE") != nullptr;  // diagnostic A/B switch
     void *wg = (overlap_bins && !wgrad_inline) ? (void *)g_helper.stream : nullptr;
     const int64_t *ray_kept = (const int64_t *)(ws + L.ray_indices);
-    if (flat && g_variant[2] == 1 && up)
-        NSR_TRY(nsr_composite_backward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
-                                            up->comp_rgb, up->opacity, up->depth, up->weights, nullptr, nullptr, nullptr,
-                                            nullptr, nullptr, d->loss_scale, d_rgb, d_logit, n_rays, stream));
-    else if (flat && g_variant[2] == 1)
-        NSR_TRY(nsr_composite_backward_flat(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background, weights, trans,
-                                            nullptr, nullptr, nullptr, nullptr, comp_rgb, opacity, gt_rgb,
-                                            l1_folded ? acc + 2 : nullptr, acc, d->loss_scale, d_rgb, d_logit, n_rays, stream));
-    else if (flat && up)
+    if (flat && up)
         NSR_TRY(nsr_composite_backward_samples(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, ray_kept, background,
                                                weights, trans, up->comp_rgb, up->opacity, up->depth, up->weights, nullptr,
                                                nullptr, nullptr, nullptr, nullptr, d->loss_scale, d_rgb, d_logit, n_rays, S,
@@ -702,12 +569,6 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         NSR_TRY(nsr_composite_backward_smooth_l1(out1, 16, d->density_bias, t0, t1, out2, 16, packed_kept, background,
                                                  weights, trans, comp_rgb, opacity, gt_rgb, acc, d->loss_scale, d_rgb,
                                                  d_logit, n_rays, stream));
-    // Every event a stream records costs IT ~8-10 us before its next kernel starts (the HIP-event scopes around the two dgrads
-    // read 37 us for 27 us kernels; with ONE fork for both networks' weight-gradient kernels, behind the second dgrad, 30 and
-    // 22 us).  Measured in the step, round 4: the single fork is nevertheless SLOWER (0.525 vs 0.505 ms) -- the colour
-    // network's kernels start 35 us later and the helper stream's chain (weight gradients, reductions, the optimizer launch)
-    // ends behind the table backward instead of underneath it.  So: one fork per network; NSR_WGRAD_ONE_FORK for A/B.
-    static const bool two_forks = getenv("NSR_WGRAD_ONE_FORK") == nullptr;
     g_ht.mark(5);
     // (the weight-gradient block cap is a library-wide knob other callers -- the NeuS steps, the drop-in tcnn modules -- leave at
     // its default: lowered for this pass's launches only, restored on every way out)
@@ -718,99 +579,30 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
         ~WgradCap() { if (set) (void)nsr_mlp_wgrad_max_blocks(old); }
     } wgrad_cap(wg && g_defer_wgrad_join ? g_variant[9] : 0);
     const bool pair = g_variant[0] && nsr_mlp_dgrad_pair_supported(&d->mlp_color, &d->mlp_density) && C == 32;
-    bool dgrad_event = false;  // HEV.dgrad_done recorded behind the last data-gradient kernel
-    bool late_wgrad = false, wgrads_after_issue = false;
-    // key 10: the table backward goes to the helper stream (behind its binning launch: no join on `st`), the weight gradients
-    // stay on `st` (no fork): the step's stream meets the helper stream once, in nsr_nerf_wait_table
-    const bool owner_on_helper = g_variant[10] && pair && wg && g_defer_wgrad_join && !xchg && !use_dense && overlap_bins &&
-                                 table_adam && !capturing && !g_variant[8] && !g_variant[4] && phases == 3;
     // the weight-gradient kernels + reductions of both networks (behind nsr_mlp_dgrad_pair), forked from `st` through `fork`
-    auto queue_wgrads = [&](hipEvent_t fork, bool *recorded, bool already_recorded) -> int {
-        void *wg_c = wg, *wg_d = wg;
-        if (wg) {
+    auto queue_wgrads = [&](hipEvent_t fork, bool already_recorded) -> int {
+        if (wg)
             NSR_REQUIRE((already_recorded || hipEventRecord(fork, st) == hipSuccess) &&
                             hipStreamWaitEvent(g_helper.stream, fork, 0) == hipSuccess,
                         "nsr_nerf_main_pass: weight-gradient fork failed");
-            if (recorded) *recorded = true;
-            if (g_variant[3] && g_helper.need_extra()) {  // the density network's weight-gradient kernels beside the colour network's
-                wg_d = (void *)g_helper.stream_b;
-                NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_b, fork, 0) == hipSuccess,
-                            "nsr_nerf_main_pass: weight-gradient fork failed");
-            }
-        }
         NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, nullptr, 32, 0,
-                                        part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, wg_c ? wg_c : stream, 2));
+                                        part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, wg ? wg : stream, 2));
         NSR_TRY(nsr_mlp_backward_phases(d_enc, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
                                         grad_density_mlp, nullptr, C, d->grid.n_features, part1, S, d->grad_scale,
-                                        &d->mlp_density, n_kept_dev, wg_d ? wg_d : stream, 2));
-        if (wg && wg_d != wg)  // whatever is queued on the helper stream from here on sees both networks' gradients
-            NSR_REQUIRE(hipEventRecord(HEV.wgrad_b_done, g_helper.stream_b) == hipSuccess &&
-                            hipStreamWaitEvent(g_helper.stream, HEV.wgrad_b_done, 0) == hipSuccess,
-                        "nsr_nerf_main_pass: weight-gradient join failed");
+                                        &d->mlp_density, n_kept_dev, wg ? wg : stream, 2));
         return NSR_OK;
     };
     if (pair) {
-        late_wgrad = wg && g_variant[4] && g_defer_wgrad_join && !xchg;
-        const bool ride = wg && g_variant[5] && !capturing && !late_wgrad && !g_prof_on;  // (the profiling scope records its own events)
+        const bool ride = wg && g_variant[5] && !capturing && !g_prof_on;  // (the profiling scope records its own events)
         if (ride) nsr_next_stop_event = HEV.dgrad_done;
         {   // both networks' data gradients in one launch; d_feature stays in registers (csrc/mlp.hip k_mlp_dgrad_pair)
             ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
             NSR_TRY(nsr_mlp_dgrad_pair(d_rgb, d_logit, out2, acts2, w_color, part2, acts1, w_density, part1, d_enc, S,
                                        d->grad_scale, &d->mlp_color, &d->mlp_density, n_kept_dev, stream));
         }
-        // key 4: the weight-gradient kernels are queued BEHIND the table backward instead of beside it (they then run under the
-        // next step's encode; only for a caller that defers its join with them: nsr_nerf_defer_wgrad_join + nsr_nerf_wait_before_mlp)
         const bool rode = ride && nsr_next_stop_event == nullptr;
         nsr_next_stop_event = nullptr;
-        if (rode) dgrad_event = true;
-        if (owner_on_helper) {
-            if (!rode) NSR_REQUIRE(hipEventRecord(HEV.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: table-backward fork failed");
-            dgrad_event = true;
-            // the table backward first (host order): in order behind this pass's binning launch on the helper stream
-            NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream, HEV.dgrad_done, 0) == hipSuccess,
-                        "nsr_nerf_main_pass: table-backward fork failed");
-            {
-                ProfScope p(NSR_PROF_GRID_BACKWARD, S, g_helper.stream);
-                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam(x01, d_enc, 2, 0, (float *)(ws + L.grid_ws), S,
-                                                                           d->grid.n_levels, 1.0f, &d->grid, n_kept_dev,
-                                                                           table_adam, g_helper.stream));
-            }
-            NSR_REQUIRE(hipEventRecord(HEV.table_done, g_helper.stream) == hipSuccess, "nsr_nerf_main_pass: hipEventRecord failed");
-            g_table_event = HEV.table_done;
-            g_table_pending = true;
-            g_last_form = 1;
-            // the weight gradients of both networks inline, behind the data-gradient kernel they read from
-            NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, nullptr, 32,
-                                            0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream, 2));
-            NSR_TRY(nsr_mlp_backward_phases(d_enc, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
-                                            grad_density_mlp, nullptr, C, d->grid.n_features, part1, S, d->grad_scale,
-                                            &d->mlp_density, n_kept_dev, stream, 2));
-        } else if (!late_wgrad && wg && g_variant[7] && !xchg) {
-            // (host order only: the fork event is recorded now, the helper streams' launches are issued behind the table backward's)
-            if (!rode) NSR_REQUIRE(hipEventRecord(HEV.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: weight-gradient fork failed");
-            dgrad_event = true;
-            wgrads_after_issue = true;
-        } else if (!late_wgrad) NSR_TRY(queue_wgrads(HEV.dgrad_done, &dgrad_event, rode));
-    } else if (wg && !two_forks) {
-        {
-            ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
-            NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex,
-                                            32, 0, part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, stream, 1));
-        }
-        {
-            ProfScope p(NSR_PROF_MLP_BACKWARD_DENSITY, S, stream);
-            NSR_TRY(nsr_mlp_backward_phases(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
-                                            grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
-                                            &d->mlp_density, n_kept_dev, stream, 1));
-        }
-        NSR_REQUIRE(hipEventRecord(HEV.fork_wgrad, st) == hipSuccess &&
-                        hipStreamWaitEvent(g_helper.stream, HEV.fork_wgrad, 0) == hipSuccess,
-                    "nsr_nerf_main_pass: weight-gradient fork failed");
-        NSR_TRY(nsr_mlp_backward_phases(d_rgb, 1, 3, nullptr, out2, tex_in, 0, 32, 0, acts2, w_color, grad_color_mlp, d_tex, 32, 0,
-                                        part2, S, d->grad_scale, &d->mlp_color, n_kept_dev, wg, 2));
-        NSR_TRY(nsr_mlp_backward_phases(d_tex, 1, 32, d_logit, out1, enc, 0, C, d->grid.n_features, acts1, w_density,
-                                        grad_density_mlp, d_enc, C, d->grid.n_features, part1, S, d->grad_scale,
-                                        &d->mlp_density, n_kept_dev, wg, 2));
+        NSR_TRY(queue_wgrads(HEV.dgrad_done, rode));
     } else {
     {
         ProfScope p(NSR_PROF_MLP_BACKWARD_COLOR, S, stream);
@@ -842,48 +634,12 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                 NSR_REQUIRE(hipEventRecord((hipEvent_t)xchg->event_group[g], st) == hipSuccess,
                             "nsr_nerf_main_pass_exchange: hipEventRecord failed");
         }
-    } else if (use_dense) {
-        // dense levels: ray-run merged atomics + their write-out on stream_c, beside the owner launch of the hashed levels
-        if (!dgrad_event)
-            NSR_REQUIRE(hipEventRecord(HEV.dgrad_done, st) == hipSuccess, "nsr_nerf_main_pass: dense-level fork failed");
-        NSR_REQUIRE(hipStreamWaitEvent(g_helper.stream_c, HEV.dgrad_done, 0) == hipSuccess,
-                    "nsr_nerf_main_pass: dense-level fork failed");
-        {
-            ProfScope p(NSR_PROF_GRID_BACKWARD_DENSE, S, g_helper.stream_c);
-            NSR_TRY(nsr_hashgrid_backward_params_dense(x01, d_enc, table_adam ? nullptr : grad_table, nullptr, table_adam,
-                                                       (float *)(ws + L.grid_ws), S, Lv, 1.0f, 0, &d->grid, n_kept_dev, 2 | 4,
-                                                       g_helper.stream_c));
-        }
-        NSR_REQUIRE(hipEventRecord(HEV.dense_done, g_helper.stream_c) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
-        NSR_REQUIRE(hipStreamWaitEvent(st, HEV.join, 0) == hipSuccess, "nsr_nerf_main_pass: helper stream join failed");
-        {
-            ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
-            if (table_adam)
-                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam_range(x01, d_enc, (float *)(ws + L.grid_ws), S, Lv,
-                                                                                 1.0f, n_dense, Lv, &d->grid, n_kept_dev,
-                                                                                 table_adam, stream));
-            else
-                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_range(x01, d_enc, grad_table, nullptr,
-                                                                            (float *)(ws + L.grid_ws), S, Lv, 1.0f, n_dense, Lv,
-                                                                            &d->grid, n_kept_dev, stream));
-        }
-        // (whoever reads the table next on this stream -- the next step's encode, the caller's optimizer -- sees all levels)
-        NSR_REQUIRE(hipStreamWaitEvent(st, HEV.dense_done, 0) == hipSuccess, "nsr_nerf_main_pass: dense-level join failed");
-    } else if (!owner_on_helper) {
+    } else {
         ProfScope p(NSR_PROF_GRID_BACKWARD, S, stream);
         if (overlap_bins) {
             NSR_REQUIRE(hipStreamWaitEvent(st, HEV.join, 0) == hipSuccess,
                         "nsr_nerf_main_pass: helper stream join failed");
-            if (table_adam && g_variant[8] && Lv == 16 && !capturing) {
-                // two launches, levels [0, 8) then [8, 16), an event between them: the next pruning pass's encode of the first
-                // half starts behind it (prune_pass above)
-                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam_range(x01, d_enc, (float *)(ws + L.grid_ws), S, Lv, 1.0f,
-                                                                                 0, 8, &d->grid, n_kept_dev, table_adam, stream));
-                NSR_REQUIRE(hipEventRecord(HEV.table_a_done, st) == hipSuccess, "nsr_nerf_main_pass: hipEventRecord failed");
-                NSR_TRY(nsr_hashgrid_backward_params_owner_accumulate_adam_range(x01, d_enc, (float *)(ws + L.grid_ws), S, Lv, 1.0f,
-                                                                                 8, 16, &d->grid, n_kept_dev, table_adam, stream));
-                g_table_a_pending = true;
-            } else if (table_adam)  // the optimizer's update of the table happens inside the backward (no gradient store)
+            if (table_adam)  // the optimizer's update of the table happens inside the backward (no gradient store)
                 // (round 4: launching the small dense levels -- the slowest workgroups on a trained scene -- on a stream of their own
                 // beside the other levels was built and measured: 125-135 us for that launch alone, step 0.511 -> 0.546 ms; their
                 // chains are hidden better INSIDE the one launch, where they are dispatched first)
@@ -900,8 +656,6 @@ static int main_pass(const NsrNerfStepDesc *d, const void *prune_workspace, uint
                                                        d->grid.n_levels, 1.0f, 0, &d->grid, n_kept_dev, stream));
         }
     }
-    if (late_wgrad) NSR_TRY(queue_wgrads(HEV.fork_wgrad, nullptr, false));  // (the fork event sits behind the table backward)
-    if (wgrads_after_issue) NSR_TRY(queue_wgrads(HEV.dgrad_done, nullptr, true));
     g_ht.mark(8);
     if (wg && !g_defer_wgrad_join)  // join: the optimizer step that follows on `stream` reads the MLP gradients
         NSR_REQUIRE(hipEventRecord(HEV.join_wgrad, g_helper.stream) == hipSuccess &&

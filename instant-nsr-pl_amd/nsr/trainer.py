@@ -338,22 +338,21 @@ def multistep_lr_scale(step, milestones=(10000, 15000, 18000), gamma=0.33):
     return gamma ** sum(step >= m for m in milestones)
 
 
-# The forms of the asynchronous NeRF step (csrc/step.hip nsr_nerf_step_variant keys 0..5 + the host-side switches), for
-# same-process A/B runs: bench.py's `step_forms_ab` block and tools/step_variants.py run windows of steps under each
-ROUND5_FORMS = dict(keys=(1, 0, 1, 0, 0, 1), defer_pack=True, defer_weights_wait=True, flat_rays_per_wave=4, wgrad_max_blocks=128)
-ROUND4_FORMS = dict(keys=(0, 0, 0, 0, 0, 0), defer_pack=False, defer_weights_wait=False, flat_rays_per_wave=4, wgrad_max_blocks=0)
+# The forms of the asynchronous NeRF step (csrc/step.hip nsr_nerf_step_variant keys 0, 2, 5, 9 + the host-side switches), for
+# same-process A/B runs: bench.py's `step_forms_ab` block and tools/step_variants.py run windows of steps under each.
+# CURRENT_FORMS: both networks' data gradients in one kernel, sample-partitioned compositing, fork events riding on kernels,
+# the packing folded into the kept-row copy, the weights wait in front of the density MLP, capped weight-gradient grids.
+CURRENT_FORMS = dict(keys={0: 1, 2: 1, 5: 1}, defer_pack=True, defer_weights_wait=True, wgrad_max_blocks=128)
+ROUND4_FORMS = dict(keys={0: 0, 2: 0, 5: 0}, defer_pack=False, defer_weights_wait=False, wgrad_max_blocks=0)
 
 
 def set_step_forms(trainer, forms):
     """switch a (fused, asynchronous) trainer's step between the forms above; synchronises (the knobs are read per launch)"""
     trainer.settle()
     torch.cuda.synchronize()
-    for k, v in enumerate(forms["keys"]):
-        _lib.nsr_nerf_step_variant(k, int(v))
-    _lib.nsr_composite_flat_rays_per_wave(int(forms["flat_rays_per_wave"]))
+    for k, v in forms["keys"].items():
+        _lib.nsr_nerf_step_variant(int(k), int(v))
     _lib.nsr_nerf_step_variant(9, int(forms["wgrad_max_blocks"]))  # (0: the pass leaves the library's cap of 512 alone)
-    # key 10: table backward on the helper stream, weight gradients + MLP optimizer on the step's stream (csrc/step.hip)
-    _lib.nsr_nerf_step_variant(10, int(forms.get("table_on_helper", 0)))
     trainer.fused.defer_pack = bool(forms["defer_pack"])
     trainer.defer_weights_wait = bool(forms["defer_weights_wait"])
 
@@ -473,8 +472,6 @@ class Trainer:
             torch.cuda.current_stream().wait_event(a["weights_event"])
             _check(_lib.nsr_nerf_wait_before_mlp(None), "nsr_nerf_wait_before_mlp")
             a["weights_event"] = None
-        if a is not None:  # (a table update still running on the helper stream: nsr_nerf_step_variant key 10)
-            _check(_lib.nsr_nerf_wait_table(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "nsr_nerf_wait_table")
 
     def _all_reduce_grads(self):
         if self.world_size > 1 and self.sharded is None:
@@ -835,10 +832,6 @@ class Trainer:
         if a["packed_upto"] < t:
             queue_pack(t, main)
         main.wait_event(ev[("pack", t)])
-        if _lib.nsr_nerf_step_variant(8, -1) > 0:
-            # (the pruning pass encodes its first level half on a helper stream beside the previous step's second table-backward
-            # launch: that stream waits for this step's positions itself -- csrc/step.hip nsr_nerf_set_inputs_event)
-            _check(_lib.nsr_nerf_set_inputs_event(ctypes.c_void_p(ev[("pack", t)].cuda_event)), "nsr_nerf_set_inputs_event")
         rs = sets[t % W]
         model.background_color = rs["bg"]
 
@@ -874,15 +867,7 @@ class Trainer:
         with _ops.timed("phase:all_reduce"):
             self._all_reduce_grads()
         with _ops.timed("phase:optimizer"):
-            if fuse_table and (_lib.nsr_nerf_last_pass_form() & 1):
-                # the pass ran its table backward on the helper stream and its weight gradients HERE (nsr_nerf_step_variant key
-                # 10): the optimizer launch for the MLP weights follows them on this stream -- no event towards the next
-                # density MLP --, then this stream meets the helper stream once, behind the table update
-                mp = ctypes.c_void_p(main.cuda_stream)
-                self.opt.step_device(skip_table_of=fused.ewn, other_stream_reads=True, stream=mp)
-                _check(_lib.nsr_nerf_wait_table(mp), "nsr_nerf_wait_table")
-                a["weights_event"] = None
-            elif fuse_table and self._helper_stream() is not None:
+            if fuse_table and self._helper_stream() is not None:
                 # what is left for the optimizer (the MLP weights: one launch that also advances the device-side schedule) runs
                 # on the main pass's helper stream, right behind the weight-gradient kernels it reads from -- underneath the
                 # table backward, off the step's own chain; the main stream only waits for its event

@@ -222,29 +222,18 @@ SIGNATURES = {
     "nsr_hashgrid_backward_params_owner_bin_taps_masked": [_P, _P, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_taps": [_P, _P, _P, _P, _P, _U, _U, _I, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_adam": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P, _P, _P],
-    "nsr_hashgrid_backward_params_owner_accumulate_adam_range": [_P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P, _P],
     "nsr_hashgrid_owner_first_unchunked_level": [_GD, _U],
-    "nsr_hashgrid_dense_levels": [_GD],
-    "nsr_hashgrid_backward_params_dense": [_P, _P, _P, _P, _P, _P, _U, _U, _F, _I, _GD, _P, _I, _P],
-    "nsr_hashgrid_backward_params_owner_bin_range": [_P, _P, _U, _U, _U, _U, _GD, _P, _P],
     "nsr_mlp_wgrad_max_blocks": [_U],
     "nsr_mlp_dgrad_pair_supported": [_MD, _MD],
     "nsr_mlp_dgrad_pair_max_blocks": [_U],
     "nsr_mlp_dgrad_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _F, _MD, _MD, _P, _P],
     "nsr_visibility_prefix_sums": [_P, _U, _F, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_copy_kept_rows_scan": [_P] * 18 + [_U, _U, _U, _U, _P, _P, _P, _U, _P],
-    "nsr_composite_flat_rays_per_wave": [_I],
     "nsr_composite_forward_samples": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P],
     "nsr_composite_backward_samples": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                                        _P, _P, _U, _U, _P, _P],
-    "nsr_composite_forward_flat": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
-    "nsr_composite_backward_flat": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_step_variant": [_I, _I],
     "nsr_nerf_wait_before_mlp": [_P],
-    "nsr_nerf_wait_table": [_P],
-    "nsr_nerf_last_pass_form": [],
-    "nsr_nerf_set_inputs_event": [_P],
-    "nsr_hashgrid_forward_half": [_P, _P, _P, _U, _U, _I, _U, _I, _GD, _P, _P],
     "nsr_nerf_prune_pass_deferred": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
@@ -255,9 +244,6 @@ SIGNATURES = {
     "nsr_adam_tick": [_P, _P, _D, _D, _D, _D, _I, _I, _I, _P],
     "nsr_adamw_step_scheduled": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _D, _D, _D, _D, _I, _I,
                                  _I, _F, _F, _F, _I, _P],
-    "nsr_sigma_rays": [_P, _P, _P, _P, _P, _P, _U, _P, _P, _P, _F, _F, _P, _U, _GD, _MD, _P],
-    "nsr_nerf_sigma_mode": [_I],
-    "nsr_sigma_rays_blocks": [_U],
     "nsr_adamw_step_scheduled_to": [_P, _P, _P, _P, _P, _U64, _U64, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _D, _D, _D, _D,
                                     _I, _I, _I, _F, _F, _F, _I, _P],
     "nsr_overflow_guard": [_P, _F],
@@ -296,7 +282,7 @@ SIGNATURES = {
                                 _P, _U, _P, _P],
 }
 _RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_hashgrid_owner_first_unchunked_level": ctypes.c_uint32,
-             "nsr_hashgrid_dense_levels": ctypes.c_uint32, "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32, "nsr_masked_loss_out_floats": ctypes.c_uint32,
+             "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32, "nsr_masked_loss_out_floats": ctypes.c_uint32,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
@@ -329,13 +315,6 @@ lib = load_library()
 # (nsr_hashgrid_owner_tune; e.g. "0=0" = the round-3 placement of the work units)
 for _kv in filter(None, os.environ.get("NSR_OWN_TUNE", "").split(",")):
     lib.nsr_hashgrid_owner_tune(int(_kv.split("=")[0]), float(_kv.split("=")[1]))
-
-
-# NSR_SIGMA_MODE=0: the sigma pass of the NeRF step as three stand-alone launches (A/B switch for nsr_nerf_sigma_mode)
-if os.environ.get("NSR_SIGMA_MODE") is not None:
-    lib.nsr_nerf_sigma_mode(int(os.environ["NSR_SIGMA_MODE"]))
-if os.environ.get("NSR_SIGMA_BLOCKS"):
-    lib.nsr_sigma_rays_blocks(int(os.environ["NSR_SIGMA_BLOCKS"]))
 
 
 def check(rc, what=""):

@@ -63,5 +63,5 @@ def test_round5_blocks_are_on_the_line():
 def test_step_forms_are_named_in_one_place():
     """the forms bench.py's A/B switches between are the trainer module's (no second copy of the key tuples)"""
     src = open(os.path.join(ROOT, "instant-nsr-pl_amd", "nsr", "trainer.py")).read()
-    assert "ROUND5_FORMS = dict(keys=(1, 0, 1, 0, 0, 1)" in src and "ROUND4_FORMS = dict(keys=(0, 0, 0, 0, 0, 0)" in src
-    assert "from nsr.trainer import ROUND4_FORMS, ROUND5_FORMS, set_step_forms" in open(os.path.join(ROOT, "bench.py")).read()
+    assert "CURRENT_FORMS = dict(keys={0: 1, 2: 1, 5: 1}" in src and "ROUND4_FORMS = dict(keys={0: 0, 2: 0, 5: 0}" in src
+    assert "from nsr.trainer import ROUND4_FORMS, CURRENT_FORMS, set_step_forms" in open(os.path.join(ROOT, "bench.py")).read()

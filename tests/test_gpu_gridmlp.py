@@ -154,114 +154,3 @@ def test_network_with_input_encoding_uses_it_and_matches_the_large_batch_path(mo
     n_w = 64 * 32 + 16 * 64
     _assert_same_table_gradient(res["fused"][1][n_w:], res["pair"][1][n_w:], m.grid_desc)
     assert torch.allclose(res["fused"][1][:n_w], res["pair"][1][:n_w], rtol=1e-5, atol=1e-7)
-
-
-# ---- the ray-ordered sigma pass that stops at the transmittance cut (nsr_sigma_rays) ------------------------------------------
-def _ray_samples(n_rays, max_len, seed, empty_every=3):
-    """ray-ordered positions + packed_info with empty rays, one-sample rays and rays of several 64-sample windows"""
-    g = torch.Generator().manual_seed(seed)
-    counts = torch.randint(0, max_len + 1, (n_rays,), generator=g)
-    counts[::empty_every] = 0
-    counts[1] = 1
-    counts[2] = 64
-    counts[4] = 65
-    counts[5] = max_len
-    starts = torch.cumsum(counts, 0) - counts
-    n = int(counts.sum())
-    o = torch.rand(n_rays, 3, generator=g) * 0.5 + 0.25
-    dvec = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1)
-    ri = torch.repeat_interleave(torch.arange(n_rays), counts)
-    k = torch.arange(n) - starts[ri]
-    dt = 0.004
-    x = (o[ri] + dvec[ri] * (k[:, None] * dt)).clamp(0, 1)
-    t0 = (k * dt).float()
-    t1 = t0 + dt
-    packed = torch.stack([starts, counts], 1).int()
-    return x.cuda().contiguous(), packed.cuda().contiguous(), t0.cuda(), t1.cuda(), n
-
-
-@pytest.mark.parametrize("F,n_hidden,bias,max_len", [(2, 1, 3.0, 300), (2, 1, -1.0, 200), (2, 2, 4.0, 150), (4, 1, 3.0, 100)])
-def test_sigma_rays_matches_encode_mlp_visibility_prefix_bit_for_bit(F, n_hidden, bias, max_len):
-    """kept counts of every ray, and features / activations / logits of every sample in front of its ray's cut, against
-    nsr_hashgrid_forward (level-major) + nsr_mlp_forward + nsr_visibility_prefix; rows behind the window that reached the cut
-    stay untouched"""
-    import nsr_hip
-    from nsr_hip import check, lib, ptr, stream_ptr
-    L = 32 // F
-    gd, md, table, w, _ = _setup(L, F, 17, 16, 1.5, n_hidden, "none", 8, seed=11)
-    n_rays, eps = 257, 1e-4
-    x, packed, t0, t1, n = _ray_samples(n_rays, max_len, seed=3)
-    C = L * F
-    # reference: every marched sample
-    enc_ref = torch.empty(L, n, F, dtype=torch.float16, device="cuda")
-    check(lib.nsr_hashgrid_forward_ex(ptr(x), ptr(table), ptr(enc_ref), n, C, 1, L, ctypes.byref(gd), None, stream_ptr()), "enc")
-    out_ref = torch.empty(n, 16, dtype=torch.float16, device="cuda")
-    acts_ref = torch.empty(n_hidden, n, 64, dtype=torch.float16, device="cuda")
-    check(lib.nsr_mlp_forward_ex(ptr(enc_ref), 0, C, F, ptr(w), ptr(out_ref), ptr(acts_ref), n, ctypes.byref(md), None,
-                                 stream_ptr()), "mlp")
-    kept_ref = torch.empty(n_rays, dtype=torch.int32, device="cuda")
-    check(lib.nsr_visibility_prefix(ptr(out_ref), 16, bias, ptr(t0), ptr(t1), ptr(packed), eps, ptr(kept_ref), n_rays,
-                                    stream_ptr()), "vis")
-    # the ray-ordered pass into poisoned buffers
-    poison = 0x7bff  # 65504: a finite half nobody computes here
-    enc = torch.full((L, n, F), poison, dtype=torch.int16, device="cuda").view(torch.float16)
-    out = torch.full((n, 16), poison, dtype=torch.int16, device="cuda").view(torch.float16)
-    acts = torch.full((n_hidden, n, 64), poison, dtype=torch.int16, device="cuda").view(torch.float16)
-    kept = torch.full((n_rays,), -7, dtype=torch.int32, device="cuda")
-    check(lib.nsr_sigma_rays(ptr(x), ptr(table), ptr(w), ptr(out), ptr(acts), ptr(enc), n, ptr(packed), ptr(t0), ptr(t1),
-                             bias, eps, ptr(kept), n_rays, ctypes.byref(gd), ctypes.byref(md), stream_ptr()), "sigma_rays")
-    torch.cuda.synchronize()
-    assert torch.equal(kept, kept_ref)
-    kept_c, packed_c = kept.cpu().long(), packed.cpu().long()
-    # (a low-density case keeps every sample: the pass must then evaluate everything; the first case must have real cuts)
-    expect_cuts = int((kept_c + 64 <= packed_c[:, 1]).sum()) > 0
-    assert 0 < int(kept_c.sum()) <= n
-    if (F, n_hidden, bias) == (2, 1, 3.0):
-        assert expect_cuts and int((kept_c < packed_c[:, 1]).sum()) > 10  # some rays are cut, some are not
-    # rows in front of the cut: identical; rows behind the 64-sample window that reached the cut: untouched
-    k = torch.arange(n) - packed_c[:, 0][torch.repeat_interleave(torch.arange(n_rays), packed_c[:, 1])]
-    ray = torch.repeat_interleave(torch.arange(n_rays), packed_c[:, 1])
-    front = (k < kept_c[ray]).cuda()
-    window_end = torch.minimum(packed_c[:, 1], (kept_c // 64 + 1) * 64)  # (a ray whose cut falls on a window edge goes one further)
-    behind = (k >= window_end[ray]).cuda()
-    assert torch.equal(out[front], out_ref[front])
-    assert torch.equal(enc[:, front], enc_ref[:, front])
-    assert torch.equal(acts[:, front], acts_ref[:, front])
-    assert bool((out[behind].view(torch.int16) == poison).all()) and bool((enc[:, behind].view(torch.int16) == poison).all())
-    if expect_cuts:
-        assert int(behind.sum()) > 0 and float((~behind).float().mean()) < 0.95
-    else:
-        assert int(behind.sum()) == 0
-
-
-def test_prune_pass_sigma_modes_agree():
-    """nsr_nerf_prune_pass with the ray-ordered sigma pass vs the three stand-alone launches, through the fused step:
-    identical kept counts / packing, identical rendering"""
-    import nsr
-    from nsr_hip import lib
-    from nsr.fused import FusedNeRFStep
-    torch.manual_seed(0)
-    cfg = nsr.configs.get("nerf-blender")
-    model = nsr.build(cfg).cuda().train()
-    with torch.no_grad():
-        model.geometry.encoding_with_network.params[3072:].normal_(0, 0.4)  # dense enough for cuts inside the rays
-    model.occupancy_grid._binary[:] = True
-    model.randomized = False
-    g = torch.Generator().manual_seed(1)
-    o = torch.tensor([[0.0, 0.0, 4.0]]).repeat(512, 1)
-    dvec = torch.nn.functional.normalize(torch.randn(512, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
-    rays = torch.cat([o, dvec], -1).cuda()
-    res = {}
-    try:
-        for mode in (0, 1):
-            lib.nsr_nerf_sigma_mode(mode)
-            step = FusedNeRFStep(model)
-            model.zero_grad(set_to_none=True)
-            out = step.forward_backward(rays, torch.full((512, 3), 0.5, device="cuda"), torch.ones(3, device="cuda"))
-            res[mode] = (int(out["num_samples"]), out["comp_rgb"].clone(), out["ray_indices"].clone(),
-                         model.geometry.encoding_with_network.params.grad[:3072].clone())
-    finally:
-        lib.nsr_nerf_sigma_mode(0)
-    assert res[0][0] == res[1][0] > 1000
-    assert torch.equal(res[0][2], res[1][2])
-    assert torch.equal(res[0][1], res[1][1])

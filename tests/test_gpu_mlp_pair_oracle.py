@@ -1,0 +1,77 @@
+"""The NeRF step's backward through BOTH tcnn networks -- k_mlp_dgrad_pair (csrc/mlp.hip: the colour and the density network's
+data gradients in one kernel) + k_mlp_wgrad -- DIRECTLY against fp32 autograd of the oracle's FullyFusedMLP restatement
+(oracle/tcnn_ref.mlp_forward: fp16-rounded activations, fp32 accumulation; reference models/network_utils.py:181,209,
+models/geometry.py:122-156, models/texture.py:23-30) on the shapes of configs/nerf-blender.yaml (64 x 1 density network with 16
+outputs, 64 x 2 colour network on [16 features | 16 SH]).  SURVEY.md A.8: rel-L2 <= 1e-2 and cosine >= 0.999 against the
+fp16-emulating oracle; the weight gradient of the first of two hidden layers carries the measured floor of an fp16 gradient
+chain against fp32 autograd (1.2-1.8e-2) and is asserted at 2e-2."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(name, got, want, rel_tol):
+    got, want = got.double().flatten().cpu(), want.double().flatten().cpu()
+    rel = float((got - want).norm() / want.norm())
+    cos = float(torch.nn.functional.cosine_similarity(got, want, dim=0))
+    assert rel <= rel_tol and cos >= 0.999, (name, rel, cos)
+    return rel, cos
+
+
+@pytest.mark.parametrize("nhc,nhd,n", [(2, 1, 100000), (2, 1, 4099), (1, 1, 777)])
+def test_dgrad_pair_and_wgrad_match_fp32_autograd_of_the_oracle(nhc, nhd, n):
+    import nsr_hip
+    from nsr_hip import check, lib, ops, ptr, stream_ptr
+    from oracle import tcnn_ref
+    g = torch.Generator().manual_seed(n + nhc * 10 + nhd)
+    dc = nsr_hip.make_mlp_desc(32, 3, nhc, "sigmoid")
+    dd = nsr_hip.make_mlp_desc(32, 16, nhd, "none")
+    oc = tcnn_ref.MLPDesc(32, 3, {"n_neurons": 64, "n_hidden_layers": nhc, "activation": "ReLU", "output_activation": "Sigmoid"})
+    od = tcnn_ref.MLPDesc(32, 16, {"n_neurons": 64, "n_hidden_layers": nhd, "activation": "ReLU", "output_activation": "None"})
+    wc32 = tcnn_ref.init_mlp_params(oc, 3).half().float()
+    wd32 = tcnn_ref.init_mlp_params(od, 4).half().float()
+    enc32 = (torch.randn(n, 32, generator=g) * 0.5).half().float()
+    sh32 = torch.rand(n, 16, generator=g).half().float()
+    d_rgb = torch.randn(n, 3, generator=g) * 1e-3
+    d_logit = torch.randn(n, generator=g) * 1e-3
+    # ---- oracle: CPU autograd through the fp16-emulating forward
+    e = enc32.clone().requires_grad_(True)
+    pc, pd = wc32.clone().requires_grad_(True), wd32.clone().requires_grad_(True)
+    o1 = tcnn_ref.mlp_forward(e, pd, od, return_padded=True)                       # [n, 16] features, column 0 the logit
+    o2 = tcnn_ref.mlp_forward(torch.cat([o1, sh32], 1), pc, oc, return_padded=True)  # [n, 16], columns 0..2 rgb
+    ((o2[:, :3] * d_rgb).sum() + (o1[:, 0] * d_logit).sum()).backward()
+    # ---- HIP: forward (saved activations), pair dgrad, weight gradients
+    wc, wd = wc32.half().cuda(), wd32.half().cuda()
+    enc_lm = enc32.half().view(n, 16, 2).permute(1, 0, 2).contiguous().cuda()  # level-major [16][n][2]
+    s = stream_ptr()
+    out1 = torch.empty(n, 16).half().cuda()
+    acts1 = torch.empty(nhd, n, 64).half().cuda()
+    check(lib.nsr_mlp_forward_ex(ptr(enc_lm), 0, 32, 2, ptr(wd), ptr(out1), ptr(acts1), n, ctypes.byref(dd), None, s), "fwd density")
+    tex_in = torch.cat([out1, sh32.half().cuda()], 1).contiguous()
+    out2, acts2 = ops.mlp_forward(tex_in, wc, dc, save_acts=True)
+    assert torch.allclose(out1.float().cpu(), o1.detach(), rtol=4e-3, atol=2e-3)
+    assert torch.allclose(out2.float().cpu()[:, :3], o2.detach()[:, :3], rtol=4e-3, atol=2e-3)
+    scale = 65536.0
+    pw_c = torch.zeros(int(lib.nsr_mlp_backward_workspace_floats(ctypes.byref(dc), n)), device="cuda")
+    pw_d = torch.zeros(int(lib.nsr_mlp_backward_workspace_floats(ctypes.byref(dd), n)), device="cuda")
+    g_c, g_d = torch.zeros(oc.n_params).cuda(), torch.zeros(od.n_params).cuda()
+    d_enc = torch.zeros(16, n, 2).cuda()
+    dr, dl = d_rgb.cuda(), d_logit.cuda()
+    check(lib.nsr_mlp_dgrad_pair(ptr(dr), ptr(dl), ptr(out2), ptr(acts2), ptr(wc), ptr(pw_c), ptr(acts1), ptr(wd), ptr(pw_d),
+                                 ptr(d_enc), n, scale, ctypes.byref(dc), ctypes.byref(dd), None, s), "pair")
+    check(lib.nsr_mlp_backward_phases(ptr(dr), 1, 3, None, ptr(out2), ptr(tex_in), 0, 32, 0, ptr(acts2), ptr(wc), ptr(g_c), None,
+                                      32, 0, ptr(pw_c), n, scale, ctypes.byref(dc), None, s, 2), "colour wgrad")
+    check(lib.nsr_mlp_backward_phases(ptr(d_enc), 1, 32, ptr(dl), ptr(out1), ptr(enc_lm), 0, 32, 2, ptr(acts1), ptr(wd), ptr(g_d),
+                                      None, 32, 2, ptr(pw_d), n, scale, ctypes.byref(dd), None, s, 2), "density wgrad")
+    torch.cuda.synchronize()
+    got_d_enc = d_enc.permute(1, 0, 2).reshape(n, 32)
+    _cmp("d_enc", got_d_enc, e.grad, 1e-2)
+    # weight gradients, per matrix (the padded output rows of the oracle's last layers carry no gradient on either side)
+    for name, got, want, desc in (("density", g_d, pd.grad, od), ("colour", g_c, pc.grad, oc)):
+        gs, ws = desc.split(got.cpu()), desc.split(want)
+        for li, (a, b) in enumerate(zip(gs, ws)):
+            first_of_two = desc.n_hidden >= 2 and li == 0
+            _cmp(f"{name} W{li}", a, b, 2e-2 if first_of_two else 1e-2)

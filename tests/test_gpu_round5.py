@@ -1,8 +1,7 @@
-"""Round-5 kernels of the NeRF step against the kernels they replace (which are pinned to the oracle elsewhere):
-flat segmented compositing vs one wave per ray, the packing folded into the kept-row copy vs scan + copy, both networks'
-data gradients in one kernel vs two launches, the dense levels of the table backward through ray-run merged fixed-point
-atomics vs the owner workgroups, and the whole step with every form switched off / on (reference models/nerf.py:95-109,
-systems/nerf.py:97, models/network_utils.py:181,209)."""
+"""Forms of the NeRF step's kernels against the forms they replace: the packing folded into the kept-row copy vs scan + copy,
+both networks' data gradients in one kernel vs two launches, and the whole step with every switchable form off / on
+(reference models/nerf.py:95-109, systems/nerf.py:97, models/network_utils.py:181,209).  The compositing pair is pinned to the
+oracle directly in tests/test_gpu_composite_samples.py, the data / weight gradients in tests/test_gpu_mlp_pair_oracle.py."""
 import ctypes
 
 import pytest
@@ -19,105 +18,6 @@ def _packed(n_rays, max_count, seed, long_every=0):
         counts[3::long_every] = torch.randint(65, 400, counts[3::long_every].shape, generator=g)  # rays that span 64-sample chunks
     starts = torch.cumsum(counts, 0) - counts
     return torch.stack([starts, counts], 1).int().cuda(), int(counts.sum()), g
-
-
-@pytest.mark.parametrize("n_rays,long_every", [(8192, 0), (1147, 5), (3, 0), (9, 2), (64, 1)])
-@pytest.mark.parametrize("mode", ["folded", "acc", "upstream"])
-def test_flat_compositing_matches_wave_per_ray(n_rays, long_every, mode):
-    from nsr_hip import check, lib, ptr, stream_ptr
-    packed, n, g = _packed(n_rays, 40, 100 + n_rays, long_every)
-    m = max(n, 1)
-    out1 = (torch.randn(m, 16, generator=g) * 2 - 1).half().cuda()
-    out2 = torch.rand(m, 16, generator=g).half().cuda()
-    t0 = torch.rand(m, generator=g).cuda()
-    t1 = t0 + 0.01
-    bg = torch.tensor([1.0, 0.5, 0.25]).cuda()
-    gt = torch.rand(n_rays, 3, generator=g).cuda()
-    up = dict(c=(torch.randn(n_rays, 3, generator=g) * 0.1).cuda(), o=(torch.randn(n_rays, generator=g) * 0.1).cuda(),
-              d=(torch.randn(n_rays, generator=g) * 0.1).cuda(), w=(torch.randn(m, generator=g) * 0.1).cuda())
-    s = stream_ptr()
-
-    def buffers():
-        return dict(w=torch.zeros(m).cuda(), tr=torch.zeros(m).cuda(), rgb=torch.full((n_rays, 3), -7.0).cuda(),
-                    op=torch.full((n_rays,), -7.0).cuda(), dp=torch.full((n_rays,), -7.0).cuda(),
-                    acc=torch.full((2,), -1.0).cuda(), d_rgb=torch.zeros(m, 3).cuda(), d_logit=torch.zeros(m).cuda())
-
-    a, b = buffers(), buffers()
-    part_a = torch.full((int(lib.nsr_composite_l1_partials_floats(n_rays)),), float("nan")).cuda()
-    part_b = part_a.clone()
-    # wave per ray
-    if mode == "folded":
-        check(lib.nsr_composite_forward_smooth_l1(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg),
-                                                  ptr(a["w"]), ptr(a["tr"]), ptr(a["rgb"]), ptr(a["op"]), ptr(a["dp"]), ptr(gt),
-                                                  ptr(part_a), n_rays, s), "fwd")
-        check(lib.nsr_composite_backward_smooth_l1_partials(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed),
-                                                            ptr(bg), ptr(a["w"]), ptr(a["tr"]), ptr(a["rgb"]), ptr(a["op"]),
-                                                            ptr(gt), ptr(part_a), ptr(a["acc"]), 2.0, ptr(a["d_rgb"]),
-                                                            ptr(a["d_logit"]), n_rays, s), "bwd")
-    else:
-        check(lib.nsr_composite_forward(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(a["w"]),
-                                        ptr(a["tr"]), ptr(a["rgb"]), ptr(a["op"]), ptr(a["dp"]), n_rays, s), "fwd")
-        if mode == "acc":
-            check(lib.nsr_smooth_l1_valid_set(ptr(a["rgb"]), ptr(a["op"]), ptr(gt), ptr(a["acc"]), n_rays, s), "l1")
-            check(lib.nsr_composite_backward_smooth_l1(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed),
-                                                       ptr(bg), ptr(a["w"]), ptr(a["tr"]), ptr(a["rgb"]), ptr(a["op"]), ptr(gt),
-                                                       ptr(a["acc"]), 2.0, ptr(a["d_rgb"]), ptr(a["d_logit"]), n_rays, s), "bwd")
-        else:
-            check(lib.nsr_composite_backward_ex(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg),
-                                                ptr(a["w"]), ptr(a["tr"]), ptr(up["c"]), ptr(up["o"]), ptr(up["d"]), ptr(up["w"]),
-                                                ptr(a["d_rgb"]), ptr(a["d_logit"]), n_rays, s), "bwd")
-    # flat
-    check(lib.nsr_composite_forward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(b["w"]),
-                                         ptr(b["tr"]), ptr(b["rgb"]), ptr(b["op"]), ptr(b["dp"]),
-                                         ptr(gt) if mode == "folded" else None, ptr(part_b) if mode == "folded" else None,
-                                         n_rays, s), "fwd flat")
-    if mode == "folded":
-        check(lib.nsr_composite_backward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg),
-                                              ptr(b["w"]), ptr(b["tr"]), None, None, None, None, ptr(b["rgb"]), ptr(b["op"]),
-                                              ptr(gt), ptr(part_b), ptr(b["acc"]), 2.0, ptr(b["d_rgb"]), ptr(b["d_logit"]),
-                                              n_rays, s), "bwd flat")
-    elif mode == "acc":
-        check(lib.nsr_smooth_l1_valid_set(ptr(b["rgb"]), ptr(b["op"]), ptr(gt), ptr(b["acc"]), n_rays, s), "l1")
-        check(lib.nsr_composite_backward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg),
-                                              ptr(b["w"]), ptr(b["tr"]), None, None, None, None, ptr(b["rgb"]), ptr(b["op"]),
-                                              ptr(gt), None, ptr(b["acc"]), 2.0, ptr(b["d_rgb"]), ptr(b["d_logit"]), n_rays, s),
-              "bwd flat")
-    else:
-        check(lib.nsr_composite_backward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg),
-                                              ptr(b["w"]), ptr(b["tr"]), ptr(up["c"]), ptr(up["o"]), ptr(up["d"]), ptr(up["w"]),
-                                              None, None, None, None, None, 1.0, ptr(b["d_rgb"]), ptr(b["d_logit"]), n_rays, s),
-              "bwd flat")
-    torch.cuda.synchronize()
-    # the scans associate differently (64-lane segmented scan vs per-ray scan): agreement to fp32 rounding
-    for k, tol in (("w", 1e-6), ("tr", 1e-6), ("rgb", 2e-6), ("op", 2e-6), ("dp", 2e-6)):
-        assert torch.allclose(a[k], b[k], rtol=2e-5, atol=tol), (k, (a[k] - b[k]).abs().max())
-    for k in ("d_rgb", "d_logit"):
-        scale = float(a[k].abs().max()) + 1e-12
-        assert float((a[k] - b[k]).abs().max()) <= 3e-5 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
-    assert float(a["d_rgb"].abs().max()) > 0 or n == 0
-    if mode != "upstream":
-        assert float(a["acc"][1]) == float(b["acc"][1]) == float((a["op"] > 0).sum())
-        assert abs(float(a["acc"][0]) - float(b["acc"][0])) <= 1e-5 * abs(float(a["acc"][0])) + 1e-7
-    # rays without samples: background, opacity 0 -- written, not left over
-    empty = packed[:, 1] == 0
-    assert bool((b["op"][empty] == 0).all()) and bool((b["rgb"][empty] == bg).all()) and bool((b["dp"][empty] == 0).all())
-
-
-def test_flat_compositing_overflowed_density_does_not_poison_the_ray():
-    """exp(logit) = inf: T = 0 behind the sample (nerfacc's sequential loop), never NaN"""
-    from nsr_hip import check, lib, ptr, stream_ptr
-    packed = torch.tensor([[0, 100]], dtype=torch.int32).cuda()
-    out1 = torch.zeros(100, 16).half().cuda()
-    out1[40, 0] = 200.0
-    out2 = torch.rand(100, 16).half().cuda()
-    t0 = torch.arange(100).float().cuda() * 0.01
-    t1 = t0 + 0.01
-    bg = torch.zeros(3).cuda()
-    w, tr = torch.zeros(100).cuda(), torch.zeros(100).cuda()
-    rgb, op, dp = torch.zeros(1, 3).cuda(), torch.zeros(1).cuda(), torch.zeros(1).cuda()
-    check(lib.nsr_composite_forward_flat(ptr(out1), 16, 0.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(w), ptr(tr),
-                                         ptr(rgb), ptr(op), ptr(dp), None, None, 1, stream_ptr()), "fwd flat")
-    assert bool(torch.isfinite(w).all()) and bool(torch.isfinite(rgb).all()) and float(tr[41:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("n_rays,cap", [(8192, 0), (1147, 0), (8192, 30000), (5, 0), (9, 17)])
@@ -171,6 +71,30 @@ def test_packing_folded_into_the_kept_row_copy(n_rays, cap, nh):
     assert int(a["total"]) > 0
     if cap:
         assert int(a["total"]) == cap and int(a["stats"][2]) == 1  # truncated, and reported
+    # ... and DIRECTLY against the definition (nerfacc's pack_info semantics, reference models/nerf.py:95-103): the kept counts
+    # are the oracle's transmittance cut, packed_info is their exclusive cumsum (clamped at the capacity), the rows a ray keeps
+    # are the first `kept` rows of its marched segment, ray_indices name it
+    from oracle import nerfacc_ref as R
+    pm = packed_m.cpu().long()
+    ri_m = torch.repeat_interleave(torch.arange(n_rays), pm[:, 1])
+    sigma = torch.exp(out1[:M, 0].float().cpu() - 1.0).view(-1, 1)
+    alpha = 1.0 - torch.exp(-sigma * 0.02)
+    vis = R.render_visibility(alpha, ray_indices=ri_m, early_stop_eps=1e-4) if M else torch.zeros(0, dtype=torch.bool)
+    want_kept = torch.zeros(n_rays, dtype=torch.long).index_add_(0, ri_m, vis.long())
+    got_kept = b["kept"].cpu().long()
+    # (fp32 prefix products against the oracle's fp64: a sample exactly at the 1e-4 cut may fall on either side)
+    assert int((got_kept - want_kept).abs().max()) <= 1 and int((got_kept != want_kept).sum()) <= max(1, n_rays // 500)
+    starts = torch.cumsum(got_kept, 0) - got_kept
+    limit = cap if cap else S
+    want_start = starts.clamp(max=limit)
+    want_count = (starts + got_kept).clamp(max=limit) - want_start
+    pk = b["packed"].cpu().long()
+    assert torch.equal(pk[:, 0], want_start) and torch.equal(pk[:, 1], want_count)
+    assert int(b["total"]) == int(want_count.sum())
+    src = torch.cat([pm[r, 0] + torch.arange(int(want_count[r])) for r in range(n_rays)]) if int(want_count.sum()) else torch.zeros(0, dtype=torch.long)
+    tot = int(want_count.sum())
+    assert torch.equal(b["t0"][:tot].cpu(), t0.cpu()[src]) and torch.equal(b["out1"][:tot].cpu(), out1.cpu()[src])
+    assert torch.equal(b["ri"][:tot].cpu(), torch.repeat_interleave(torch.arange(n_rays), want_count))
 
 
 @pytest.mark.parametrize("nhc,nhd,n", [(2, 1, 100000), (2, 1, 4099), (1, 1, 777), (2, 2, 5000), (1, 2, 31), (2, 1, 7)])
@@ -255,111 +179,6 @@ def _ray_ordered_positions(n, gen):
     return torch.cat(xs)[:n].contiguous()
 
 
-@pytest.mark.parametrize("n,mask", [(100000, 16), (30011, 16), (257, 16), (5000, 3), (63, 16)])
-def test_dense_levels_through_merged_atomics_match_the_owner_workgroups(n, mask):
-    """nsr_hashgrid_backward_params_dense (levels [0, D)) + the owner launch over [D, L) == the owner launch over all levels:
-    hashed levels bit for bit (integer sums), dense levels to fp32 rounding (both add runs in fp32, in different orders); the
-    same through AdamW; masked levels get exactly zero"""
-    import nsr_hip
-    from nsr_hip import check, lib, ptr, stream_ptr
-    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
-    D = int(lib.nsr_hashgrid_dense_levels(ctypes.byref(gd)))
-    assert D == 5
-    g = torch.Generator().manual_seed(n)
-    x = _ray_ordered_positions(n, g).cuda()
-    x[:7] = torch.round(x[:7])  # corners / faces of the box
-    dy = (torch.randn(16, n, 2, generator=g) * 1e-3).cuda()
-    n_tab = gd.n_entries * 2
-    ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
-    s = stream_ptr()
-    off = [int(o) * 2 for o in gd.offset[:17]]
-    # (a) owner, all levels
-    ga = torch.full((n_tab,), 7.0, device="cuda")
-    check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws), n, mask, ctypes.byref(gd), None, s), "bin")
-    check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(x), ptr(dy), 2, 0, ptr(ga), ptr(ws), n, mask, 1.0, 0,
-                                                            ctypes.byref(gd), None, s), "accumulate")
-    # (b) dense levels through the atomics path, the rest through a ranged owner launch
-    gb = torch.full((n_tab,), 7.0, device="cuda")
-    check(lib.nsr_hashgrid_backward_params_owner_bin_range(ptr(x), ptr(ws), n, mask, D, 16, ctypes.byref(gd), None, s), "bin range")
-    check(lib.nsr_hashgrid_backward_params_dense(ptr(x), ptr(dy), ptr(gb), None, None, ptr(ws), n, mask, 1.0, 0, ctypes.byref(gd),
-                                                 None, 7, s), "dense")
-    check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), ptr(gb), None, ptr(ws), n, mask, 1.0, D, 16,
-                                                                  ctypes.byref(gd), None, s), "accumulate range")
-    torch.cuda.synchronize()
-    for lvl in range(16):
-        a, b = ga[off[lvl]:off[lvl + 1]], gb[off[lvl]:off[lvl + 1]]
-        if lvl >= mask:
-            assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0, lvl
-        elif lvl >= D:
-            assert torch.equal(a, b), lvl
-        else:
-            assert float((a - b).norm()) <= 2e-5 * float(a.norm()), (lvl, float((a - b).norm()), float(a.norm()))
-            assert float(a.abs().max()) > 0
-    # bf16 transport image of the dense levels
-    gh = torch.zeros(n_tab, dtype=torch.bfloat16, device="cuda")
-    check(lib.nsr_hashgrid_backward_params_dense(ptr(x), ptr(dy), None, ptr(gh), None, ptr(ws), n, mask, 1.0, 0, ctypes.byref(gd),
-                                                 None, 7, s), "dense bf16")
-    torch.cuda.synchronize()
-    assert torch.equal(gh[:off[D]], gb[:off[D]].bfloat16())
-    # a non-finite gradient is SEEN: the level it reached leaves as NaN
-    dy2 = dy.clone()
-    dy2[1, n // 2, 0] = float("inf")
-    gc = torch.zeros(n_tab, device="cuda")
-    check(lib.nsr_hashgrid_backward_params_dense(ptr(x), ptr(dy2), ptr(gc), None, None, ptr(ws), n, mask, 1.0, 0, ctypes.byref(gd),
-                                                 None, 7, s), "dense inf")
-    torch.cuda.synchronize()
-    if mask > 1:
-        assert bool(torch.isnan(gc[off[1]:off[2]]).all()) and bool(torch.isfinite(gc[off[0]:off[1]]).all())
-
-
-def test_dense_levels_with_adamw_match_gradient_plus_optimizer():
-    """the write-out of the dense path as AdamW == its gradient + nsr_adamw_step on those levels, bit for bit, over three
-    steps (pow() start + running beta products); the ranged owner launch updates the hashed levels as before"""
-    import nsr_hip
-    from nsr_hip import check, lib, ops, ptr, stream_ptr
-    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
-    D = int(lib.nsr_hashgrid_dense_levels(ctypes.byref(gd)))
-    n, n_tab = 30000, gd.n_entries * 2
-    g = torch.Generator().manual_seed(3)
-    ws = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(ctypes.byref(gd), n)), device="cuda")
-    s = stream_ptr()
-
-    def fresh():
-        gg = torch.Generator(device="cuda").manual_seed(5)
-        p = torch.randn(n_tab, device="cuda", generator=gg) * 0.1
-        return dict(p=p, m=torch.zeros_like(p), v=torch.zeros_like(p), h=torch.empty(n_tab, dtype=torch.float16, device="cuda"),
-                    step=torch.zeros(1, dtype=torch.int32, device="cuda"), hyper=torch.zeros(12, device="cuda"))
-
-    a, b = fresh(), fresh()
-    grad = torch.empty(n_tab, device="cuda")
-    ms = (2, 0x7fffffff, 0x7fffffff)
-    for it in range(3):
-        x = _ray_ordered_positions(n, g).cuda()
-        dy = (torch.randn(16, n, 2, generator=g) * 1e-3).cuda()
-        check(lib.nsr_hashgrid_backward_params_owner_bin_range(ptr(x), ptr(ws), n, 16, D, 16, ctypes.byref(gd), None, s), "bin")
-        # (a) gradient of every level (dense path + ranged owner), then the optimizer kernel
-        check(lib.nsr_hashgrid_backward_params_dense(ptr(x), ptr(dy), ptr(grad), None, None, ptr(ws), n, 16, 1.0, 0,
-                                                     ctypes.byref(gd), None, 7, s), "dense grad")
-        check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), ptr(grad), None, ptr(ws), n, 16, 1.0, D, 16,
-                                                                      ctypes.byref(gd), None, s), "range grad")
-        ops.adam_tick(a["step"], a["hyper"], 0.01, 0.9, 0.99, 0.33, ms)
-        ops.adamw_step(a["p"], grad, a["m"], a["v"], a["h"], 0.01, 0.9, 0.99, 1e-15, 0.01, it + 1, zero_grad=False,
-                       hyper=a["hyper"])
-        # (b) AdamW inside both write-outs
-        d = _adam_desc(b)
-        check(lib.nsr_hashgrid_backward_params_dense(ptr(x), ptr(dy), None, None, ctypes.byref(d), ptr(ws), n, 16, 1.0, 0,
-                                                     ctypes.byref(gd), None, 7, s), "dense adam")
-        check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam_range(ptr(x), ptr(dy), ptr(ws), n, 16, 1.0, D, 16,
-                                                                           ctypes.byref(gd), None, ctypes.byref(d), s), "range adam")
-        ops.adam_tick(b["step"], b["hyper"], 0.01, 0.9, 0.99, 0.33, ms)
-        torch.cuda.synchronize()
-        off = [int(o) * 2 for o in gd.offset[:17]]
-        for k in ("p", "m", "v", "h"):
-            if not torch.equal(a[k], b[k]):
-                bad = [(lvl, int((a[k][off[lvl]:off[lvl + 1]] != b[k][off[lvl]:off[lvl + 1]]).sum())) for lvl in range(16)]
-                raise AssertionError((it, k, [t for t in bad if t[1]]))
-
-
 def _model(seed=0):
     import nsr
     import refmirror
@@ -383,7 +202,7 @@ def _rays(n, seed=1):
     return torch.cat([o, d], -1).cuda(), torch.rand(n, 3, generator=g).cuda()
 
 
-def test_the_step_with_the_round5_forms_matches_the_step_without_them():
+def test_the_step_with_the_current_forms_matches_the_step_with_the_round4_forms():
     """one fused step (native orchestration) with every nsr_nerf_step_variant off vs on: outputs to scan rounding, gradients of
     the hashed levels and of the networks to the noise of the fp16 chain's float-atomic weight-gradient reduction"""
     from nsr.fused import FusedNeRFStep
@@ -392,10 +211,11 @@ def test_the_step_with_the_round5_forms_matches_the_step_without_them():
     rays, gt = _rays(700)
     bg = torch.tensor([0.3, 0.6, 0.9], device="cuda")
     res, grads = {}, {}
-    old = [lib.nsr_nerf_step_variant(k, -1) for k in range(4)]
+    KEYS = (0, 2, 5)  # pair dgrad, sample-partitioned compositing, fork events riding on kernels
+    old = [lib.nsr_nerf_step_variant(k, -1) for k in KEYS]
     try:
         for on in (0, 1):
-            for k in range(4):
+            for k in KEYS:
                 lib.nsr_nerf_step_variant(k, on)
             model.zero_grad(set_to_none=True)
             step = FusedNeRFStep(model, native=True)
@@ -405,8 +225,8 @@ def test_the_step_with_the_round5_forms_matches_the_step_without_them():
                                                                                     "ray_indices", "loss_acc", "num_samples")}
             grads[on] = (model.geometry.encoding_with_network.params.grad.clone(), model.texture.network.params.grad.clone())
     finally:
-        for k in range(4):
-            lib.nsr_nerf_step_variant(k, old[k])
+        for k, v in zip(KEYS, old):
+            lib.nsr_nerf_step_variant(k, v)
     assert res[0]["num_samples"] == res[1]["num_samples"] > 0 and torch.equal(res[0]["ray_indices"], res[1]["ray_indices"])
     for k in ("comp_rgb", "opacity", "depth", "weights"):
         assert torch.allclose(res[0][k], res[1][k], rtol=2e-5, atol=2e-6), k
@@ -416,8 +236,8 @@ def test_the_step_with_the_round5_forms_matches_the_step_without_them():
         assert cos > 0.99999 and float((a - b).norm()) <= 2e-4 * float(a.norm()), (float(cos), float((a - b).norm() / a.norm()))
 
 
-def test_async_trainer_with_and_without_the_round5_forms():
-    """the asynchronous trainer (deferred packing, dense levels on their own stream, pair dgrad, flat compositing) against the
+def test_async_trainer_with_and_without_the_current_forms():
+    """the asynchronous trainer (deferred packing, pair dgrad, sample-partitioned compositing, riding events) against the
     same trainer with the forms off: same first loss, trajectories within the run-to-run noise of the step"""
     import nsr
     import refmirror
@@ -428,26 +248,25 @@ def test_async_trainer_with_and_without_the_round5_forms():
     cfg = dict(nsr.configs.get("nerf-blender"))
     cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
     out = {}
-    old = [lib.nsr_nerf_step_variant(k, -1) for k in range(4)]
+    KEYS = (0, 2, 5)
+    old = [lib.nsr_nerf_step_variant(k, -1) for k in KEYS]
     try:
         for on in (0, 1):
-            for k in range(4):
+            for k in KEYS:
                 lib.nsr_nerf_step_variant(k, on)
             torch.manual_seed(0)
             model = refmirror.NeRFModel(cfg).cuda().train()
             tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
             tr.fused.defer_pack = bool(on)
             tr.defer_weights_wait = bool(on)
-            lib.nsr_nerf_step_variant(4, on)  # (with it: the weight-gradient kernels behind the table backward)
             losses = [float(tr.train_step()["loss"]) for _ in range(48)]
             torch.cuda.synchronize()
             c = tr.counters()
             out[on] = dict(losses=losses, samples=c["samples"], rays=c["rays"], truncated=c["truncated"],
                            p=tr.fused.ewn.params.detach().clone())
     finally:
-        for k in range(4):
-            lib.nsr_nerf_step_variant(k, old[k])
-        lib.nsr_nerf_step_variant(4, 0)
+        for k, v in zip(KEYS, old):
+            lib.nsr_nerf_step_variant(k, v)
     a, b = out[0], out[1]
     assert abs(a["losses"][0] - b["losses"][0]) <= 1e-5 * abs(a["losses"][0])
     for x, y in zip(a["losses"], b["losses"]):
@@ -503,100 +322,6 @@ def test_model_entry_lazy_outputs_match_the_synchronising_ones():
     sel = l2["out"]["comp_rgb"][l2["valid"]]
     assert sel.shape == (int(l2["valid"].sum()), 3) and torch.equal(sel.detach(), l2["out"]["comp_rgb"].detach()[l2["valid"].as_subclass(torch.Tensor)])
     assert model._runner().render_truncated == 0
-
-
-@pytest.mark.parametrize("n", [100000, 4097, 5])
-def test_encode_in_two_level_halves_equals_the_one_launch_encode(n):
-    import nsr_hip
-    from nsr_hip import check, lib, ptr, stream_ptr
-    gd = nsr_hip.make_grid_desc(16, 2, 19, 16, 1.447269237440378)
-    g = torch.Generator().manual_seed(n)
-    x = torch.rand(n, 3, generator=g).cuda()
-    table = (torch.randn(gd.n_entries * 2, generator=g) * 0.1).half().cuda()
-    a = torch.full((16, n, 2), 7.0).half().cuda()
-    b = torch.full((16, n, 2), -7.0).half().cuda()
-    s = stream_ptr()
-    check(lib.nsr_hashgrid_forward_ex(ptr(x), ptr(table), ptr(a), n, 32, 1, 16, ctypes.byref(gd), None, s), "fwd")
-    for half in (1, 2):
-        check(lib.nsr_hashgrid_forward_half(ptr(x), ptr(table), ptr(b), n, 32, 1, 16, half, ctypes.byref(gd), None, s), "half")
-    torch.cuda.synchronize()
-    assert torch.equal(a, b)
-
-
-def test_async_trainer_with_the_pipelined_encode_matches_without():
-    """key 8 (two table-backward launches, the next encode's first level half beside the second) is scheduling only: the same
-    trajectory as without, to the run-to-run noise of the step"""
-    import nsr
-    import refmirror
-    from nsr.scene import SyntheticBlender
-    from nsr.trainer import Trainer
-    from nsr_hip import lib
-    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
-    cfg = dict(nsr.configs.get("nerf-blender"))
-    cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
-    out = {}
-    try:
-        for on in (0, 1):
-            lib.nsr_nerf_step_variant(8, on)
-            torch.manual_seed(0)
-            model = refmirror.NeRFModel(cfg).cuda().train()
-            tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
-            losses = [float(tr.train_step()["loss"]) for _ in range(48)]
-            torch.cuda.synchronize()
-            c = tr.counters()
-            out[on] = dict(losses=losses, samples=c["samples"], truncated=c["truncated"])
-    finally:
-        lib.nsr_nerf_step_variant(8, 0)
-    a, b = out[0], out[1]
-    assert abs(a["losses"][0] - b["losses"][0]) <= 1e-5 * abs(a["losses"][0])
-    for x, y in zip(a["losses"], b["losses"]):
-        assert abs(x - y) <= 3e-2 * abs(x) + 1e-6, (x, y)
-    assert b["losses"][-1] < 0.7 * b["losses"][0] and a["truncated"] == b["truncated"] == 0
-    assert abs(a["samples"] - b["samples"]) <= 0.02 * a["samples"]
-
-
-def test_async_trainer_with_the_table_backward_on_the_helper_stream_matches_without():
-    """key 10 (table backward on the helper stream behind its binning, weight gradients and the MLP optimizer launch on the
-    step's stream, one meeting of the two streams per step) is scheduling only: the pass reports the form, the trajectory is
-    the one without it to the run-to-run noise of the step, checkpoints and evaluation see the finished table"""
-    import nsr
-    import refmirror
-    from nsr.scene import SyntheticBlender
-    from nsr.trainer import Trainer
-    from nsr_hip import lib
-    data = SyntheticBlender(n_images=6, w=80, h=80, device="cuda", seed=1)
-    cfg = dict(nsr.configs.get("nerf-blender"))
-    cfg["train_num_rays"], cfg["max_train_num_rays"] = 512, 2048
-    out = {}
-    try:
-        for on in (0, 1):
-            lib.nsr_nerf_step_variant(10, on)
-            torch.manual_seed(0)
-            model = refmirror.NeRFModel(cfg).cuda().train()
-            tr = Trainer(model, data, cfg, fused=True, seed=7, async_mode=True)
-            losses, forms = [], set()
-            for _ in range(48):
-                losses.append(float(tr.train_step()["loss"]))
-                forms.add(int(lib.nsr_nerf_last_pass_form()))
-            sd = tr.state_dict()  # (settles: the table update on the helper stream is behind it)
-            torch.cuda.synchronize()
-            c = tr.counters()
-            table = model.geometry.encoding_with_network.params.detach().float().clone()
-            out[on] = dict(losses=losses, samples=c["samples"], truncated=c["truncated"], forms=forms, table=table,
-                           finite=all(bool(torch.isfinite(v).all()) for v in sd.values() if torch.is_tensor(v) and v.is_floating_point()))
-    finally:
-        lib.nsr_nerf_step_variant(10, 0)
-    a, b = out[0], out[1]
-    assert a["forms"] == {0} and b["forms"] == {1}
-    assert abs(a["losses"][0] - b["losses"][0]) <= 1e-5 * abs(a["losses"][0])
-    for x, y in zip(a["losses"], b["losses"]):
-        assert abs(x - y) <= 3e-2 * abs(x) + 1e-6, (x, y)
-    assert b["losses"][-1] < 0.7 * b["losses"][0] and a["truncated"] == b["truncated"] == 0
-    assert abs(a["samples"] - b["samples"]) <= 0.02 * a["samples"]
-    assert a["finite"] and b["finite"]
-    # (no entry-wise comparison of the tables: with Adam's eps = 1e-15 a last-bit difference in a rarely-hit entry's gradient
-    # moves it by a full learning-rate step -- the two runs differ in summation order of the weight-gradient partials)
-    assert bool(torch.isfinite(b["table"]).all()) and float(b["table"].norm()) > 0
 
 
 @pytest.mark.parametrize("kind", ["smooth_l1", "smooth_l1_beta", "mse", "l1", "huber"])

@@ -8,17 +8,17 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "instant-nsr-pl_amd")]
 import torch
 import nsr
 from nsr.scene import SyntheticBlender
-from nsr.trainer import Trainer, ROUND4_FORMS, ROUND5_FORMS, set_step_forms
+from nsr.trainer import Trainer, ROUND4_FORMS, CURRENT_FORMS, set_step_forms
 
 dev = torch.device("cuda", 0)
 cfg = nsr.configs.get("nerf-blender")
 data = SyntheticBlender(n_images=100, w=800, h=800, device=dev, seed=0)
-FORMS = {"round4_forms": ROUND4_FORMS, "round5_forms": ROUND5_FORMS}
+FORMS = {"round4_forms": ROUND4_FORMS, "current_forms": CURRENT_FORMS}
 for spec in sys.argv[1:]:
     name, rest = spec.split("=")
-    keys, dp, dw, rpw, cap = rest.split(":")
-    FORMS[name] = dict(keys=tuple(int(c) for c in keys), defer_pack=bool(int(dp)), defer_weights_wait=bool(int(dw)),
-                       flat_rays_per_wave=int(rpw), wgrad_max_blocks=int(cap))
+    keys, dp, dw, cap = rest.split(":")  # e.g. mine=101:1:1:128 -> keys 0, 2, 5
+    FORMS[name] = dict(keys=dict(zip((0, 2, 5), (int(c) for c in keys))), defer_pack=bool(int(dp)),
+                       defer_weights_wait=bool(int(dw)), wgrad_max_blocks=int(cap))
 WINDOWS = [(305, 325), (325, 525), (600, 800), (1500, 1700)]
 # box warm-up (a throwaway model), as bench.py does
 torch.manual_seed(1)
@@ -47,5 +47,5 @@ for name in order:
         res[name][f"{a}-{b}"].append((round(1e3 * dt / (b - a), 4), round((c1["samples"] - c0["samples"]) / (b - a))))
     del tr
     torch.cuda.empty_cache()
-set_step_forms(type("T", (), {"settle": lambda s: None, "fused": type("F", (), {})(), "defer_weights_wait": True})(), ROUND5_FORMS)
+set_step_forms(type("T", (), {"settle": lambda s: None, "fused": type("F", (), {})(), "defer_weights_wait": True})(), CURRENT_FORMS)
 print(json.dumps({"windows": res, "forms": {k: {kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in v.items()} for k, v in FORMS.items()}}))

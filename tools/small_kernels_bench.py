@@ -1,5 +1,5 @@
 """Isolated timings (HIP events, median of 50) of the step's small per-ray / per-sample kernels at the LATE regime's shape: 8,192 ray
-slots, ~1/3 of them with samples, `kept` samples in all -- wave-per-ray vs flat compositing (4 / 8 / 16 rays per wave), scan +
+slots, ~1/3 of them with samples, `kept` samples in all -- wave-per-ray vs sample-partitioned compositing, scan +
 copy vs the copy with the packing folded in, two data-gradient launches vs the pair kernel.   python tools/small_kernels_bench.py"""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,11 +30,6 @@ for kept in (45000, 100000):
     r = {"kept": n}
     r["composite_forward_wave_us"] = median_us(lambda: check(lib.nsr_composite_forward_smooth_l1(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(w), ptr(tr), ptr(rgb), ptr(op), ptr(dp), ptr(gt), ptr(part), n_rays, s), "f"))
     r["composite_backward_wave_us"] = median_us(lambda: check(lib.nsr_composite_backward_smooth_l1_partials(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(w), ptr(tr), ptr(rgb), ptr(op), ptr(gt), ptr(part), ptr(acc), 1.0, ptr(d_rgb), ptr(d_logit), n_rays, s), "b"))
-    for rpw in (4, 8, 16):
-        lib.nsr_composite_flat_rays_per_wave(rpw)
-        r[f"composite_forward_flat{rpw}_us"] = median_us(lambda: check(lib.nsr_composite_forward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(w), ptr(tr), ptr(rgb), ptr(op), ptr(dp), ptr(gt), ptr(part), n_rays, s), "f"))
-        r[f"composite_backward_flat{rpw}_us"] = median_us(lambda: check(lib.nsr_composite_backward_flat(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(bg), ptr(w), ptr(tr), None, None, None, None, ptr(rgb), ptr(op), ptr(gt), ptr(part), ptr(acc), 1.0, ptr(d_rgb), ptr(d_logit), n_rays, s), "b"))
-    lib.nsr_composite_flat_rays_per_wave(4)
     ri = torch.repeat_interleave(torch.arange(n_rays), counts).cuda()
     r["composite_forward_samples_us"] = median_us(lambda: check(lib.nsr_composite_forward_samples(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(ri), ptr(bg), ptr(w), ptr(tr), ptr(rgb), ptr(op), ptr(dp), ptr(gt), ptr(part), n_rays, n, None, s), "f"))
     r["composite_backward_samples_us"] = median_us(lambda: check(lib.nsr_composite_backward_samples(ptr(out1), 16, -1.0, ptr(t0), ptr(t1), ptr(out2), 16, ptr(packed), ptr(ri), ptr(bg), ptr(w), ptr(tr), None, None, None, None, ptr(rgb), ptr(op), ptr(gt), ptr(part), ptr(acc), 1.0, ptr(d_rgb), ptr(d_logit), n_rays, n, None, s), "b"))

@@ -1,4 +1,4 @@
-"""Same-process A/B of the round-5 forms of the NeRF step (nsr_nerf_step_variant + FusedNeRFStep.defer_pack): ONE trainer is
+"""Same-process A/B of the forms of the NeRF step (nsr_nerf_step_variant + FusedNeRFStep.defer_pack): ONE trainer is
 brought to a regime (steady ~step 700, late ~step 10,000), then windows of `timed` steps are run with each setting in turn,
 interleaved over `rounds` rounds so that the slow drift of the sample counts hits every setting alike.
     python tools/step_variants.py [train_steps] [timed_steps] [rounds]  -> one JSON line"""
@@ -21,29 +21,14 @@ model = nsr.build(cfg).to(dev).train()
 data = SyntheticBlender(n_images=int(os.environ.get("NSR_LATE_IMAGES", "100")), w=400, h=400, device=dev, seed=0)
 tr = Trainer(model, data, cfg, seed=42, async_mode=True)
 
-# name -> (variant keys 0..8, defer_pack, defer_weights_wait, rays per wave of the flat compositing, wgrad block cap)
-# keys: 0 pair dgrad, 1 dense levels through atomics, 2 flat compositing, 3 two wgrad streams, 4 wgrads behind the table backward,
-#       5 fork events ride on kernels, 6 events with a device-scope release, 7 table backward issued first, 8 pipelined half encodes
+# name -> (nsr_nerf_step_variant keys {0: pair dgrad, 2: sample-partitioned compositing, 5: fork events ride on kernels},
+#          defer_pack, defer_weights_wait, wgrad block cap)
 SETTINGS = {
-    "round4_forms": ((0, 0, 0, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
-    "pair_only": ((1, 0, 0, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
-    "flat_only": ((0, 0, 1, 0, 0, 0, 0, 0, 0), False, False, 4, 512),
-    "defer_pack_only": ((0, 0, 0, 0, 0, 0, 0, 0, 0), True, False, 4, 512),
-    "defer_weights_only": ((0, 0, 0, 0, 0, 0, 0, 0, 0), False, True, 4, 512),
-    "round5_forms": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
-    "round6_sample_partitioned_compositing": ((1, 0, 2, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
-    "round5_without_pair": ((0, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
-    "round5_plus_dense_atomics": ((1, 1, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128),
-    "round5_plus_pipelined_encode": ((1, 0, 1, 0, 0, 1, 0, 0, 1), True, True, 4, 128),
-    "round5_cap256": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 256),
-    "round5_cap512": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 512),
-    "round5_without_pair_cap512": ((0, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 512),
-    "round5_two_wgrad_streams_cap512": ((1, 0, 1, 1, 0, 1, 0, 0, 0), True, True, 4, 512),
-    # (sixth field: nsr_nerf_sigma_mode -- 1 = the ray-ordered sigma pass that stops at each ray's transmittance cut)
-    "round5_sigma_rays": ((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128, 1),
-    # (key 10: the table backward on the helper stream behind its binning, weight gradients + MLP optimizer on the step's stream)
-    "round5_table_on_helper": ((1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1), True, True, 4, 128),
-    "round5_table_on_helper_cap512": ((1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1), True, True, 4, 512),
+    "round4_forms": ({0: 0, 2: 0, 5: 0}, False, False, 512),
+    "current_forms": ({0: 1, 2: 1, 5: 1}, True, True, 128),
+    "current_wave_per_ray_compositing": ({0: 1, 2: 0, 5: 1}, True, True, 128),
+    "current_without_pair": ({0: 0, 2: 1, 5: 1}, True, True, 128),
+    "current_cap512": ({0: 1, 2: 1, 5: 1}, True, True, 512),
 }
 HOST_DELAY = float(os.environ.get("NSR_HOST_DELAY_US", "0")) * 1e-6
 only = os.environ.get("NSR_VARIANTS")
@@ -51,16 +36,12 @@ if only:
     SETTINGS = {k: v for k, v in SETTINGS.items() if k in only.split(",")}
 
 
-def apply(keys, defer, defer_w, rpw, cap=512, sigma_mode=0):
+def apply(keys, defer, defer_w, cap=512):
     tr.settle()
     torch.cuda.synchronize()
-    lib.nsr_nerf_sigma_mode(sigma_mode)
-    lib.nsr_nerf_step_variant(10, 0)
-    for k, v in enumerate(keys):
-        if k != 9:
-            lib.nsr_nerf_step_variant(k, v)
+    for k, v in keys.items():
+        lib.nsr_nerf_step_variant(k, v)
     lib.nsr_nerf_step_variant(9, 0 if cap >= 512 else cap)
-    lib.nsr_composite_flat_rays_per_wave(rpw)
     tr.fused.defer_pack = defer
     tr.defer_weights_wait = defer_w
 
@@ -95,7 +76,7 @@ for r in range(rounds):
                           "kept_per_step": (c1["samples"] - c0["samples"]) / n_timed,
                           "marched_per_step": (c1["marched"] - c0["marched"]) / n_timed,
                           "loss": float(tr.last["loss"])})
-apply((1, 0, 1, 0, 0, 1, 0, 0, 0), True, True, 4, 128)
+apply(*SETTINGS["current_forms"])
 out = {"train_steps": n_train, "timed_steps": n_timed, "rounds": rounds, "global_step": tr.global_step,
        "settings": {k: {"ms_per_step": [round(x["ms_per_step"], 4) for x in v],
                         "host_ms_per_step": [round(x["host_ms_per_step"], 4) for x in v],
