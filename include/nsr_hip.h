@@ -509,9 +509,6 @@ int nsr_sample_positions_unit(const float *rays_o, const float *rays_d, const in
 int nsr_visibility_prefix(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
                           const float *t_ends, const int32_t *packed_info, float early_stop_eps, int32_t *kept_counts,
                           uint32_t n_rays, void *stream);
-int nsr_copy_ray_prefixes(const int32_t *packed_old, const int32_t *packed_new, const float *t_starts,
-                          const float *t_ends, int64_t *ray_indices_out, float *t_starts_out, float *t_ends_out,
-                          uint32_t n_rays, void *stream);
 /* Same compaction for up to 8 per-sample row arrays (host arrays of device pointers; row_bytes multiples of 4): the
  * kept prefix of a ray is contiguous before and after pruning, so this is a per-ray memcpy.  Lets the main pass
  * reuse the encodings / MLP activations the sigma pass already computed.  dirs_out / ray_indices_out may be NULL. */
@@ -851,7 +848,6 @@ int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x, const voi
                                                        float *workspace, uint32_t n, uint32_t level_mask_count,
                                                        float grad_scale, const NsrGridDesc *desc, const int32_t *n_dev,
                                                        const NsrTableAdam *adam, void *stream);
-uint32_t nsr_hashgrid_owner_first_unchunked_level(const NsrGridDesc *desc, uint32_t n);
 
 
 /* The same write-out for the two other accumulation modes (the fused NeuS steps, nsr/fused_neus.py): first + second order

@@ -1046,18 +1046,6 @@ extern "C" int nsr_visibility_prefix(const nsr_half *mlp_out, uint32_t stride, f
     return NSR_OK;
 }
 
-extern "C" int nsr_copy_ray_prefixes(const int32_t *packed_old, const int32_t *packed_new, const float *t_starts,
-                                     const float *t_ends, int64_t *ray_indices_out, float *t_starts_out,
-                                     float *t_ends_out, uint32_t n_rays, void *stream)
-{
-    if (n_rays == 0) return NSR_OK;
-    NSR_REQUIRE(packed_old && packed_new, "nsr_copy_ray_prefixes: NULL pointer");
-    hipLaunchKernelGGL(k_copy_ray_prefixes, RAY_GRID(n_rays), packed_old, packed_new, t_starts, t_ends, ray_indices_out,
-                       t_starts_out, t_ends_out, n_rays);
-    NSR_CHECK_LAUNCH("nsr_copy_ray_prefixes");
-    return NSR_OK;
-}
-
 extern "C" int nsr_texture_input(const nsr_half *mlp_out, uint32_t stride, const float *dirs, nsr_half *tex_in,
                                  uint32_t n, const int32_t *n_dev, void *stream)
 {

@@ -985,13 +985,6 @@ extern "C" int nsr_hashgrid_backward_params_owner_accumulate_adam(const float *x
                           2, stream, nullptr, nullptr, adam);
 }
 
-// first level that is NOT cut into item chunks in the slice configuration a launch of n points takes
-extern "C" uint32_t nsr_hashgrid_owner_first_unchunked_level(const NsrGridDesc *desc, uint32_t n)
-{
-    if (!desc || check_desc(desc, "nsr_hashgrid_owner_first_unchunked_level")) return 0;
-    return own_use_large(n) ? own_large::owner_first_unchunked_level(desc) : own_small::owner_first_unchunked_level(desc);
-}
-
 // ---- stencil mode: the 7 n_centre points of a finite-difference step (positions [7][n_centre][3]: sample, then the six
 // +-eps taps; dy level-major [L][7 n_centre][F]).  Taps that stay in their sample's cell are folded into the sample's items
 // (see k_tap_cross / k_tap_reduce); the result equals the plain call over all 7 n_centre points up to fp32 rounding.

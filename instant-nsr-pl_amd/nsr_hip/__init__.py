@@ -153,7 +153,6 @@ SIGNATURES = {
     "nsr_mlp_backward_phases": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P, _I],
     "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P, _P],
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
-    "nsr_copy_ray_prefixes": [_P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_copy_ray_prefix_rows": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_nerf_copy_kept_rows": [_P] * 14 + [_U, _U, _U, _U, _P, _P, _P, _U, _P],
     "nsr_copy_ray_prefix_rows_ex": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P, _U, _P],
@@ -222,7 +221,6 @@ SIGNATURES = {
     "nsr_hashgrid_backward_params_owner_bin_taps_masked": [_P, _P, _P, _U, _U, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_taps": [_P, _P, _P, _P, _P, _U, _U, _I, _GD, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_adam": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P, _P, _P],
-    "nsr_hashgrid_owner_first_unchunked_level": [_GD, _U],
     "nsr_mlp_wgrad_max_blocks": [_U],
     "nsr_mlp_dgrad_pair_supported": [_MD, _MD],
     "nsr_mlp_dgrad_pair_max_blocks": [_U],
@@ -281,8 +279,7 @@ SIGNATURES = {
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }
-_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_hashgrid_owner_first_unchunked_level": ctypes.c_uint32,
-             "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32, "nsr_masked_loss_out_floats": ctypes.c_uint32,
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32, "nsr_masked_loss_out_floats": ctypes.c_uint32,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
              "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
