@@ -687,9 +687,10 @@ int nsr_nerf_step_variant(int key, int value);
 /* One-shot: the NEXT pruning pass makes its stream wait for that hipEvent_t between its hash encode and its density MLP (the
  * first kernel that reads network weights) -- for a caller that defers its join with the weight-gradient kernels
  * (nsr_nerf_defer_wgrad_join) and hands over the event of its optimizer launch for the network weights, instead of the step's
- * stream waiting in front of the encode.  NULL clears.  The caller must wait for the event itself before anything else reads
- * the weights. */
-int nsr_nerf_wait_before_mlp(void *event);
+ * stream waiting in front of the encode.  owner: the step descriptor that pass will be called with (a pass of any other
+ * descriptor leaves the wait armed); event == NULL clears (only the owner's own).  The caller must wait for the event itself
+ * before anything else reads the weights, and clear it before the event is destroyed. */
+int nsr_nerf_wait_before_mlp(const NsrNerfStepDesc *owner, void *event);
 /* the stream the main pass runs its overlapped work on (item binning, weight-gradient kernels); created on first use */
 void *nsr_nerf_helper_stream(void);
 /* `stream` waits for the point of the last main pass where its kept rows exist (behind nsr_nerf_main_pass*'s first kernel) */

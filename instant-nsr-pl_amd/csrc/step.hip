@@ -200,10 +200,14 @@ extern "C" int nsr_nerf_step_variant(int key, int value)
 // that launch's event over instead of making the step's stream wait for it in front of the encode: the weight-gradient
 // kernels + the optimizer then have the encode's duration to finish.  NULL clears.  The caller must make its stream wait for
 // the event itself before anything ELSE reads the weights on it (occupancy refresh, evaluation, checkpoints).
-static hipEvent_t g_wait_before_mlp = nullptr;
-extern "C" int nsr_nerf_wait_before_mlp(void *event)
+// (keyed to its OWNER -- the step descriptor the trainer's pruning passes are called with: a pruning pass of any other
+// FusedNeRFStep, trainer or evaluation in the process leaves it armed; owner == NULL: whoever comes next)
+static struct { hipEvent_t event = nullptr; const void *owner = nullptr; } g_wait_before_mlp;
+extern "C" int nsr_nerf_wait_before_mlp(const NsrNerfStepDesc *owner, void *event)
 {
-    g_wait_before_mlp = (hipEvent_t)event;
+    if (!event && owner && g_wait_before_mlp.owner && g_wait_before_mlp.owner != owner) return NSR_OK;  // (not this caller's to clear)
+    g_wait_before_mlp.event = (hipEvent_t)event;
+    g_wait_before_mlp.owner = event ? (const void *)owner : nullptr;
     return NSR_OK;
 }
 
@@ -274,10 +278,12 @@ static int prune_pass(const NsrNerfStepDesc *d, const float *rays_o, const float
             NSR_TRY(nsr_hashgrid_forward_ex(x01, table, enc, n_marched, C, 1, d->grid.n_levels, &d->grid, n_marched_dev,
                                             stream));
         }
-        if (g_wait_before_mlp) {  // (nsr_nerf_wait_before_mlp: the network weights of this step are final behind this event)
-            NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_wait_before_mlp, 0) == hipSuccess,
+        if (g_wait_before_mlp.event && (!g_wait_before_mlp.owner || g_wait_before_mlp.owner == (const void *)d)) {
+            // (nsr_nerf_wait_before_mlp: the network weights of this step are final behind this event)
+            NSR_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, g_wait_before_mlp.event, 0) == hipSuccess,
                         "nsr_nerf_prune_pass: hipStreamWaitEvent failed");
-            g_wait_before_mlp = nullptr;
+            g_wait_before_mlp.event = nullptr;
+            g_wait_before_mlp.owner = nullptr;
         }
         {
             ProfScope p(NSR_PROF_MLP_FORWARD_DENSITY, n_marched, stream);

@@ -31,7 +31,7 @@ class _PendingCount:
         return self._prev
 
     def current(self):
-        host, ev = self._pending
+        host, ev = self._pending[:2]
         ev.synchronize()
         return int(host[0]), int(host[8])
 
@@ -265,20 +265,33 @@ class FusedNeRFStep:
             table, w1, w2 = half[ewn.n_network_params:], half[:ewn.n_network_params], tex.half_params(tex.params)
             bg = background.to(F32).contiguous()
             import copy
-            if lazy and bb["pending"] is not None:
+            if lazy and bb["pending"] is None:
+                # the first lazy call has no counts to size its buffers from: it takes the synchronising path (which re-queues
+                # until everything fits) and leaves its counts for the next one (fixed initial capacities truncated)
+                lazy = False
+            if lazy:
                 # the counts of the PREVIOUS lazy call (its pass finished long ago: the host is one step behind at most)
-                host_p, ev_p = bb["pending"]
+                host_p, ev_p, caps_p = bb["pending"]
                 ev_p.synchronize()
                 Mp, Sp = int(host_p[0]), int(host_p[8])
-                bb["prev_counts"], bb["pending"] = (Mp, Sp), None
+                # (what that call's buffers held is what it rendered and what the system is told)
+                bb["prev_counts"], bb["pending"] = (min(Mp, caps_p[0]), min(Sp, caps_p[1])), None
                 # (capacities follow the counts one call late: more head-room than the synchronising path's 1.3 x)
                 grow = lambda n: -(-int(1.6 * n) // 65536) * 65536  # noqa: E731
-                if Mp > bb["m_cap"] or Sp > bb["s_cap"]:
-                    self.render_truncated += 1  # that call's samples were cut at its capacities
                 if Mp > 0.75 * bb["m_cap"] or Mp < 0.3 * bb["m_cap"]:
                     bb["m_cap"] = max(grow(max(Mp, 1)), 1 << 18)
                 if Sp > 0.75 * bb["s_cap"] or Sp < 0.3 * bb["s_cap"]:
                     bb["s_cap"] = max(grow(max(Sp, 1)), 1 << 17)
+                if Mp > caps_p[0] or Sp > caps_p[1]:
+                    # that call's samples were cut at its capacities (a jump of the dynamic ray count, a grid refresh): its
+                    # rays past the cut got no samples.  Say so once, and take THIS call through the synchronising path so
+                    # that two steps in a row cannot be truncated
+                    self.render_truncated += 1
+                    if self.render_truncated == 1:
+                        import warnings
+                        warnings.warn(f"FusedNeRFStep.render_forward(lazy): a call was cut at its sample capacity (marched {Mp} "
+                                      f"> {caps_p[0]} or kept {Sp} > {caps_p[1]}); this call synchronises, capacities grown")
+                    lazy = False
             while True:
                 m_cap, s_cap = bb["m_cap"], bb["s_cap"]
                 meta = torch.empty(5 * n_rays + 2, dtype=torch.int32, device=dev)  # packed | kept | packed_kept | totals
@@ -312,7 +325,7 @@ class FusedNeRFStep:
                     host.copy_(stats, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream())
-                    bb["pending"] = (host, ev)
+                    bb["pending"] = (host, ev, (m_cap, s_cap))
                     M = S = None
                     break
                 # the ONE synchronisation of the forward: both counts (unclamped) in one pinned read-back
@@ -332,6 +345,14 @@ class FusedNeRFStep:
                     bb["m_cap"] = grow(M)
                 elif S > s_cap:
                     bb["s_cap"] = grow(S)
+
+        if not lazy:  # a synchronising call: its counts size the next lazy call (and are what that one reports as "previous")
+            hostc = bb["hosts"][bb["flip"]]
+            bb["flip"] ^= 1
+            hostc.copy_(bb["host"])
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            bb["pending"], bb["prev_counts"] = (hostc, ev, (bb["m_cap"], bb["s_cap"])), (M, S)
 
         def view(off, n, dtype, shape):
             return ws[off:off + n * dtype.itemsize].view(dtype).view(shape)

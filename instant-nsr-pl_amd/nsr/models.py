@@ -58,7 +58,8 @@ def _fp16_backward_scale(model, under_autocast):
 
 # ---- outputs that do not stall the host (round 5) -----------------------------------------------------------------------------
 # The reference's training_step (systems/nerf.py:87-99) synchronises three times on the model's outputs: ``.sum().item()`` on
-# num_samples and two boolean-mask indexings with rays_valid (a nonzero each).  With ``model.lazy_outputs`` (default in training)
+# num_samples and two boolean-mask indexings with rays_valid (a nonzero each).  With ``model.lazy_outputs = True`` (OPT-IN since
+# round 6 -- the default is the reference-exact synchronising entry: ``num_samples`` of THIS forward; NSR_BOUNDARY_LAZY=1 too)
 # the fused forward queues its launches and returns at once; the system's OWN statements then run unchanged on:
 #   * ``num_samples``: a count whose ``.sum().item()`` gives the kept samples of the PREVIOUS forward (already in pinned memory:
 #     the dynamic ray count is a 0.9 / 0.1 moving average, one step of lag moves it by nothing measurable -- PSNR checked,
@@ -165,10 +166,15 @@ class _MaskedRows:
             if fused is not None:
                 return fused
             kwargs["reduction"] = "none"
-            per = func(a.base, b.base, **kwargs)
-            m = a.mask.view(-1, *([1] * (per.dim() - 1))).to(per.dtype)
-            n = (m.sum() * (per.numel() // max(per.shape[0], 1))).clamp(min=1.0)
-            return (per * m).sum() / n
+            # (rows outside the mask never reach the reference's loss -- pred[valid] gathers them away: zeroed on BOTH inputs
+            # before the function, so an inf / NaN there touches neither the value nor the gradients; no valid row: NaN, as
+            # the mean of an empty selection is)
+            mb = a.mask.view(-1, *([1] * (a.base.dim() - 1))).bool()
+            zero = a.base.new_zeros(())
+            per = func(torch.where(mb, a.base, zero), torch.where(mb, b.base, zero.to(b.base.dtype)), **kwargs)
+            per = torch.where(mb, per, per.new_zeros(()))
+            n = mb.sum() * (per.numel() // max(per.shape[0], 1))
+            return per.sum() / n
         args = tuple(x.materialize() if isinstance(x, _MaskedRows) else x for x in args)
         kwargs = {k: (v.materialize() if isinstance(v, _MaskedRows) else v) for k, v in kwargs.items()}
         return func(*args, **kwargs)
@@ -251,7 +257,10 @@ class _MaskedLoss(torch.autograd.Function):
 
 
 class _LazyOutputs(dict):
-    """the model's output dict whose per-sample entries are capacity-sized until read (then: one wait for the count)"""
+    """the model's output dict whose per-sample entries are capacity-sized until read (then: one wait for the count).  A dict
+    subclass (the reference's systems test and update the model's output as a dict), so C fast paths that bypass
+    ``__getitem__`` -- ``{**out}``, ``dict(out)``, ``out.copy()``, ``out.pop(k)``, ``out.setdefault`` -- would see the
+    placeholders: every one of them resolves the pending entries first."""
 
     def __init__(self, eager, lazy, count):
         super().__init__(eager)
@@ -265,24 +274,57 @@ class _LazyOutputs(dict):
             v = self._lazy.pop(k)
             dict.__setitem__(self, k, (v() if callable(v) else v)[:S])  # (callable: derived arrays nobody may ever read)
 
+    def _resolve_all(self):
+        for k in list(self._lazy):
+            self._resolve(k)
+
     def __getitem__(self, k):
         self._resolve(k)
         return dict.__getitem__(self, k)
+
+    def __setitem__(self, k, v):
+        self._lazy.pop(k, None)
+        dict.__setitem__(self, k, v)
 
     def get(self, k, default=None):
         if k in self:
             return self[k]
         return default
 
+    def pop(self, k, *default):
+        self._resolve(k)
+        return dict.pop(self, k, *default)
+
+    def setdefault(self, k, default=None):
+        self._resolve(k)
+        return dict.setdefault(self, k, default)
+
     def items(self):
-        for k in list(self._lazy):
-            self._resolve(k)
+        self._resolve_all()
         return dict.items(self)
 
     def values(self):
-        for k in list(self._lazy):
-            self._resolve(k)
+        self._resolve_all()
         return dict.values(self)
+
+    def keys(self):  # (``{**out}`` / ``dict(out)`` of a dict SUBCLASS that overrides keys() go through keys() + __getitem__)
+        return dict.keys(self)
+
+    def copy(self):
+        self._resolve_all()
+        return dict(dict.items(self))
+
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def __or__(self, other):
+        return self.copy() | other
+
+    def __ror__(self, other):
+        return other | self.copy()
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))
 
 
 class _RenderNeRF(torch.autograd.Function):
@@ -329,9 +371,10 @@ class FusedNeRFModel(HotPathState):
         super().__init__(cfg)
         self._step, self._last, self._bricks = None, None, None
         import os
-        # training forwards return without a host synchronisation (see _LazyCount / _ValidMask above); False: the round-4
-        # behaviour (one synchronisation per forward, num_samples a CPU tensor, plain bool rays_valid)
-        self.lazy_outputs = not os.environ.get("NSR_BOUNDARY_EAGER")
+        # False (default): the reference's behaviour -- one synchronisation per forward, num_samples a CPU tensor holding THIS
+        # forward's count, plain bool rays_valid.  True (opt-in; NSR_BOUNDARY_LAZY=1): training forwards return without a host
+        # synchronisation (see _LazyCount / _ValidMask above): num_samples is then one forward late
+        self.lazy_outputs = bool(os.environ.get("NSR_BOUNDARY_LAZY"))
 
     def _runner(self):
         if self._step is None:
@@ -515,7 +558,10 @@ class FusedNeuSModel(HotPathState):
     def forward(self, rays):
         if self.training:
             out = self.forward_(rays)
-            if not os.environ.get("NSR_BOUNDARY_EAGER"):
+            # (every count of this entry is the current forward's -- its host reads them anyway; what is deferred are only the
+            # boolean-mask selections, whose losses have the same value: on unless model.defer_mask_selections = False /
+            # NSR_BOUNDARY_EAGER)
+            if getattr(self, "defer_mask_selections", not os.environ.get("NSR_BOUNDARY_EAGER")):
                 # systems/neus.py:98,102 index comp_rgb_full / rgb with rays_valid_full[..., 0]: deferred selections, the MSE /
                 # L1 over them as masked means on the device (see _ValidMask / _MaskedLoss above) -- no nonzero(), no wait
                 for k in ("rays_valid", "rays_valid_bg", "rays_valid_full"):

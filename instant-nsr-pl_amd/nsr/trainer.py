@@ -157,7 +157,12 @@ class FusedAdamW:
             m0, n0 = skip_table_of, int(skip_table_of.n_network_params)
             if other_stream_reads and stream is not None and m0.params.grad is not None:
                 # the asynchronous step's launch, with its arguments resolved once per half of the schedule's double buffer
-                ck = (id(m0), self._cur, m0.params.data_ptr(), m0.params.grad.data_ptr(), tuple(milestones), gamma)
+                # (every pointer and scalar that is baked into the cached argument list is part of the key: ADVICE r5)
+                others = [m for m in self.tcnn_modules if m is not m0]
+                ck = (id(m0), self._cur, tuple(milestones), gamma, float(self.lr), float(self.eps), float(self.wd),
+                      tuple(self.betas)) + tuple(
+                    t.data_ptr() for m in [m0] + others
+                    for t in (m.params.data, m.params.grad) + tuple(self.state[m.params]) if t is not None)
                 cache = self.__dict__.setdefault("_step_args_cache", {})
                 args = cache.get(ck)
                 if args is None:
@@ -407,8 +412,16 @@ class Trainer:
         # the step's stream waits for the helper stream's optimizer launch (network weights) in front of the next density MLP
         # instead of in front of the next encode (csrc/step.hip nsr_nerf_wait_before_mlp); settle() for every other reader
         self.defer_weights_wait = not os.environ.get("NSR_WEIGHTS_WAIT_EARLY")
-        for mod in [model] + list(model.children()):
-            mod.register_forward_pre_hook(lambda _m, _inp: self.settle())
+        # (through a weak reference, handles kept: a second trainer built around the same model must not keep this one -- and its
+        # GPU buffers -- alive through the hooks; close() removes them)
+        import weakref
+        wself = weakref.ref(self)
+
+        def _settle_hook(_m, _inp):
+            me = wself()
+            if me is not None:
+                me.settle()
+        self._hook_handles = [mod.register_forward_pre_hook(_settle_hook) for mod in [model] + list(model.children())]
         # developer A/B switches of the asynchronous step, read once (an environment lookup per step is host time)
         self._write_inline = bool(os.environ.get("NSR_WRITE_INLINE"))
         self._exchange_unfused = bool(os.environ.get("NSR_EXCHANGE_UNFUSED")) or getattr(self, "_force_unfused_exchange", False)
@@ -463,6 +476,25 @@ class Trainer:
             self._as["events"].clear()
             self._as["last_step_event"] = None  # (belongs to the run that was replaced)
 
+    def close(self):
+        """withdraw what this trainer left armed in the library / on the model: the pending weights wait (its event dies with
+        the trainer) and the forward pre-hooks"""
+        try:
+            if getattr(self, "fused", None) is not None and getattr(self, "_as", None) is not None:
+                self.settle()
+                _lib.nsr_nerf_wait_before_mlp(ctypes.byref(self.fused.desc), None)
+        except Exception:
+            pass
+        for h in getattr(self, "_hook_handles", []):
+            h.remove()
+        self._hook_handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def settle(self):
         """make the current stream wait for work the asynchronous step left pending on its helper streams (the optimizer
         launch for the network weights when ``defer_weights_wait``): called before anything but the next training step reads
@@ -470,7 +502,7 @@ class Trainer:
         a = self._as
         if a is not None and a.get("weights_event") is not None:
             torch.cuda.current_stream().wait_event(a["weights_event"])
-            _check(_lib.nsr_nerf_wait_before_mlp(None), "nsr_nerf_wait_before_mlp")
+            _check(_lib.nsr_nerf_wait_before_mlp(ctypes.byref(self.fused.desc), None), "nsr_nerf_wait_before_mlp")
             a["weights_event"] = None
 
     def _all_reduce_grads(self):
@@ -878,7 +910,8 @@ class Trainer:
                 if self.defer_weights_wait and not (cfg["grid_prune"] and (t + 1) % 16 == 0):
                     # the next step's stream waits for the new network weights between its encode and its density MLP, not in
                     # front of the encode (csrc/step.hip nsr_nerf_wait_before_mlp); anything else that reads them: settle()
-                    _check(_lib.nsr_nerf_wait_before_mlp(ctypes.c_void_p(ev_opt.cuda_event)), "nsr_nerf_wait_before_mlp")
+                    _check(_lib.nsr_nerf_wait_before_mlp(ctypes.byref(fused.desc), ctypes.c_void_p(ev_opt.cuda_event)),
+                           "nsr_nerf_wait_before_mlp")
                     a["weights_event"] = ev_opt
                 else:  # (the next step starts with the occupancy refresh, which evaluates the density network)
                     main.wait_event(ev_opt)

@@ -231,7 +231,7 @@ SIGNATURES = {
     "nsr_composite_backward_samples": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                                        _P, _P, _U, _U, _P, _P],
     "nsr_nerf_step_variant": [_I, _I],
-    "nsr_nerf_wait_before_mlp": [_P],
+    "nsr_nerf_wait_before_mlp": [_P, _P],
     "nsr_nerf_prune_pass_deferred": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_profile_enable": [_I],
     "nsr_profile_collect": [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),

@@ -310,7 +310,7 @@ def test_model_entry_lazy_outputs_match_the_synchronising_ones():
                              weights=out["weights"].detach().clone(), ri=out["ray_indices"].clone())
     e, l1, l2 = res[0], res[1], res[2]
     assert type(l1["out"]).__name__ == "_LazyOutputs" and type(l1["valid"]).__name__ == "_ValidMask"
-    assert l1["n_item"] == l1["current"] > 0            # first lazy forward: no predecessor, its own count
+    assert l1["n_item"] == e["n_item"] and l1["current"] > 0   # first lazy forward: the count of the (eager) forward before it
     assert l2["n_item"] == l1["current"]                # second: the PREVIOUS forward's count ...
     assert l2["current"] == e["n_item"]                 # ... while .current() is this forward's (same rays as the eager pass)
     assert abs(l2["loss"] - e["loss"]) <= 1e-6 * abs(e["loss"]) + 1e-9
