@@ -189,10 +189,10 @@ def cpu_config0_step(cores, seconds_budget=5.0):
 
 def pmc_traffic(name, samples_per_launch, warmup=None, steps=None):
     """HBM-side bytes per launch of the dominant operation from the PMC passes of THIS round (tools/collect_profiles.sh ->
-    profiles/r05_pmc_traffic.json, assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
+    profiles/r06_pmc_traffic.json (older rounds' files behind it), assembled by tools/pmc_traffic.py: one entry per (warmup, steps) regime the passes were
     run in) -- used only when a pass ran in the same regime (same warmup / steps, or its recorded samples per launch
     within 15 % of this run's); otherwise the field is null"""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
                                                                          "r02_pmc_traffic.json")) if os.path.exists(q)), None)
     if path is None:
         return None, "no PMC file"
@@ -880,11 +880,13 @@ def main():
                     "frac": ach_b / HBM_PEAK_GBS}
         # what north_star asks to be evidenced beside the dominant kernel: HBM GB/s on the hash gather, MFMA utilisation on the
         # fused fp16 MLP.  Durations are THIS run's HIP-event averages; counters come from the PMC passes of the round
-        # (tools/secondary_pmc.sh -> profiles/r04_secondary_pmc.json, 2^18 ray-coherent samples: labelled, never mixed into `value`)
+        # (tools/secondary_pmc.sh -> profiles/r06_secondary_pmc.json, 2^18 ray-coherent samples: labelled, never mixed into `value`)
         secondary = None
         try:
-            sp = os.path.join(ROOT, "profiles", "r04_secondary_pmc.json")
-            pm = json.load(open(sp))["E2"]["kernels"] if os.path.exists(sp) else {}
+            sp_name = next((f for f in ("r06_secondary_pmc.json", "r04_secondary_pmc.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+            sp = os.path.join(ROOT, "profiles", sp_name) if sp_name else ""
+            pm = json.load(open(sp))["E2"]["kernels"] if sp_name else {}
             pick = lambda pre: next((v for k, v in pm.items() if k.startswith(pre)), {})  # noqa: E731
             gk, fk, dk, wk = pick("k_grid_forward"), pick("k_mlp_forward"), pick("k_mlp_dgrad"), pick("k_mlp_wgrad")
             secondary = {}
@@ -911,7 +913,7 @@ def main():
                                                "orders of magnitude below the MFMA peak; the MFMA pipe's busy share is the PMC figure"}
             secondary["mlp_backward_pmc_mfma_busy_per_wave_cycle"] = {"k_mlp_dgrad": dk.get("mfma_busy_per_wave_cycle"),
                                                                       "k_mlp_wgrad": wk.get("mfma_busy_per_wave_cycle")}
-            secondary["pmc_source"] = "profiles/r04_secondary_pmc.json" if pm else None
+            secondary["pmc_source"] = f"profiles/{sp_name}" if pm else None
         except Exception as e:  # noqa: BLE001
             secondary = {"error": repr(e)[:200]}
         res = {

@@ -1159,3 +1159,15 @@ extern "C" int nsr_hashgrid_backward_backward_input_ws(const float *x, const nsr
     return owner_backward(x, dy, dy_is_f32 ? 1 : 0, dy_stride, grad_table, workspace, n, level_mask_count, 1.f, 1, desc,
                           nullptr, 3, stream, g);
 }
+
+#ifdef NSR_OWN_TIMING
+// debug build only (tools/owner_phases.sh): read + clear the per-level phase ticks of the 2^13 x 1,024 configuration
+extern "C" int nsr_debug_owner_timing(unsigned long long *out /* [NSR_MAX_LEVELS][8] host */, int large)
+{
+    const void *sym = large ? (const void *)&own_large::g_own_timing : (const void *)&own_small::g_own_timing;
+    if (hipMemcpyFromSymbol(out, sym, sizeof(unsigned long long) * NSR_MAX_LEVELS * 8) != hipSuccess) return NSR_ERR_LAUNCH;
+    static unsigned long long zeros[NSR_MAX_LEVELS * 8] = {0};
+    if (hipMemcpyToSymbol(sym, zeros, sizeof(zeros)) != hipSuccess) return NSR_ERR_LAUNCH;
+    return NSR_OK;
+}
+#endif

@@ -362,6 +362,9 @@ def set_step_forms(trainer, forms):
     trainer.defer_weights_wait = bool(forms["defer_weights_wait"])
 
 
+_GUARD_DEFAULT = not os.environ.get("NSR_NO_OVERFLOW_GUARD")  # (A/B switch, read once)
+
+
 class Trainer:
     def __init__(self, model, dataset, config, rank=0, world_size=1, seed=42, fused=True, async_mode=False):
         self.model, self.dataset, self.config = model, dataset, config
@@ -737,7 +740,7 @@ class Trainer:
         every 2,000 clean steps) kept where the kernels read it: an overflowing data gradient skips the WHOLE optimizer step
         (table, both MLPs, moments, fp16 images) and halves the scale without the host ever looking.  One GPU, table update
         fused into the table backward (the sharded exchange does not carry the flag across ranks yet); None: off."""
-        if not getattr(self, "overflow_guard", True) or self.world_size > 1 or not self.fuse_table_update:
+        if not getattr(self, "overflow_guard", _GUARD_DEFAULT) or self.world_size > 1 or not self.fuse_table_update:
             return None
         g = getattr(self, "_guard", None)
         if g is None:

@@ -20,7 +20,8 @@ def _bench():
 
 def test_committed_pmc_passes_cover_both_command_lines():
     bench = _bench()
-    name = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+    name = next(f for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")
+                if os.path.exists(os.path.join(ROOT, "profiles", f)))
     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))  # (bench.py takes the newest round's passes)
     assert {"w20_s200", "w5_s20"} <= set(pmc["regimes"])
     for key, (w, s) in {"w20_s200": (20, 200), "w5_s20": (5, 20)}.items():
@@ -53,7 +54,7 @@ def test_round5_blocks_are_on_the_line():
     for key in ('"whole_run": whole', '"late_regime": late', '"step_forms_ab": forms_ab', '"--whole-run-steps", type=int, default=20000',
                 '"test_psnr"', '"at_step": late_at'):
         assert key in src, key
-    assert src.index('"r05_pmc_traffic.json"') < src.index('"r04_pmc_traffic.json"')
+    assert src.index('"r06_pmc_traffic.json"') < src.index('"r05_pmc_traffic.json"') < src.index('"r04_pmc_traffic.json"')
     cal = os.path.join(ROOT, "profiles", "r05_fetch_calibration.json")
     if os.path.exists(cal):  # the stand-alone k_adamw sweep: FETCH_SIZE under-reports by 2 on gfx950, WRITE_SIZE is exact
         c = json.load(open(cal))

@@ -41,6 +41,34 @@ if __name__ == "__main__":
            "mlp_backward_us": median_us(lambda: ops.mlp_backward(dout, out, enc, acts, w, md, grad_weights=gw, want_dx=True,
                                                                  grad_scale=128.0), 5, 20),
            "grid_mlp_forward_us": median_us(lambda: ops.grid_mlp_forward(x, table, w, gd, md), 5, 20)}
+    # round 6: the step's own backward kernels -- both networks' data gradients in one launch (k_mlp_dgrad_pair) and the
+    # weight-gradient kernels behind it, on the nerf-blender shapes (density 32 -> 64 -> 16, colour 32 -> 64 -> 64 -> 3)
+    dc, dd = nsr_hip.make_mlp_desc(32, 3, 2, "sigmoid"), md
+    wc = (torch.randn(64 * 32 + 4096 + 1024, generator=g) * 0.1).half().cuda()
+    enc_l = torch.randn(16, n, 2, generator=g).half().cuda()
+    o1, a1 = torch.empty(n, 16).half().cuda(), torch.empty(1, n, 64).half().cuda()
+    s_ = stream_ptr()
+    check(lib.nsr_mlp_forward_ex(ptr(enc_l), 0, 32, 2, ptr(w), ptr(o1), ptr(a1), n, ctypes.byref(dd), None, s_), "fwd")
+    tex = torch.cat([o1, torch.rand(n, 16, generator=g).half().cuda()], 1).contiguous()
+    o2, a2 = ops.mlp_forward(tex, wc, dc, save_acts=True)
+    dr, dl = (torch.randn(n, 3, generator=g) * 1e-3).cuda(), (torch.randn(n, generator=g) * 1e-3).cuda()
+    wsz = lambda d: torch.zeros(int(lib.nsr_mlp_backward_workspace_floats(ctypes.byref(d), n)), device="cuda")  # noqa: E731
+    pc, pd = wsz(dc), wsz(dd)
+    gc, gdd = torch.zeros_like(wc, dtype=torch.float32), torch.zeros_like(w, dtype=torch.float32)
+    denc = torch.zeros(16, n, 2).cuda()
+
+    def pair():
+        check(lib.nsr_mlp_dgrad_pair(ptr(dr), ptr(dl), ptr(o2), ptr(a2), ptr(wc), ptr(pc), ptr(a1), ptr(w), ptr(pd), ptr(denc),
+                                     n, 65536.0, ctypes.byref(dc), ctypes.byref(dd), None, s_), "pair")
+
+    def wgrads():
+        check(lib.nsr_mlp_backward_phases(ptr(dr), 1, 3, None, ptr(o2), ptr(tex), 0, 32, 0, ptr(a2), ptr(wc), ptr(gc), None, 32, 0,
+                                          ptr(pc), n, 65536.0, ctypes.byref(dc), None, s_, 2), "c")
+        check(lib.nsr_mlp_backward_phases(ptr(denc), 1, 32, ptr(dl), ptr(o1), ptr(enc_l), 0, 32, 2, ptr(a1), ptr(w), ptr(gdd), None,
+                                          32, 2, ptr(pd), n, 65536.0, ctypes.byref(dd), None, s_, 2), "d")
+
+    res["dgrad_pair_us"] = median_us(pair, 5, 20)
+    res["wgrad_both_networks_us"] = median_us(wgrads, 5, 20)
     torch.cuda.synchronize()
     if len(sys.argv) > 2:
         json.dump(res, open(sys.argv[2], "w"))
