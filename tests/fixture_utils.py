@@ -31,9 +31,11 @@ def rel_l2(got, want):
 _GRAD_REPORT = []
 
 
-def assert_grad(got, want, what, rel=1e-2, cos_min=0.999):
+def assert_grad(got, want, what, rel=1e-2, cos_min=0.999, floor=None):
     """SURVEY.md A.8's gradient-parity statement, both halves: rel-L2 <= `rel` AND cosine >= `cos_min`; the measured pair is in
-    the assertion message.  Sites that cannot meet 1e-2 pass their own `rel` with the measured value and the reason beside it.
+    the assertion message.  A site that cannot meet 1e-2 passes its own `rel` TOGETHER WITH `floor` = (measured rel-L2 range,
+    reason): the bound must then sit within 2 x the measured floor (a named, measured floor, not a loosened tolerance), and
+    both travel in the report and in the assertion message.
     NSR_GRAD_REPORT=<file>: every measurement of the session is appended there as JSON lines (tools: the parity table of
     DESIGN.md section 2); NSR_GRAD_NO_ASSERT=1 turns the assertion off for such a collection run."""
     import json
@@ -41,13 +43,17 @@ def assert_grad(got, want, what, rel=1e-2, cos_min=0.999):
     a, b = got.detach().reshape(-1).double().cpu(), want.detach().reshape(-1).double().cpu()
     e = float((a - b).norm() / max(float(b.norm()), 1e-30))
     c = float(torch.nn.functional.cosine_similarity(a, b, dim=0)) if float(b.norm()) > 0 and float(a.norm()) > 0 else 1.0
+    if rel > 1e-2:
+        assert floor is not None and len(floor) == 2 and rel <= 2.0 * float(floor[0][1]), \
+            (what, "a bound above 1e-2 needs floor=((measured lo, hi), reason) and must stay within 2 x the measured floor", rel, floor)
     path = os.environ.get("NSR_GRAD_REPORT")
     if path:
         with open(path, "a") as f:
             f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": str(what), "rel_l2": e,
-                                "cosine": c, "rel_bound": rel, "cos_bound": cos_min}) + "\n")
+                                "cosine": c, "rel_bound": rel, "cos_bound": cos_min,
+                                "floor": None if floor is None else {"measured": list(floor[0]), "reason": floor[1]}}) + "\n")
     if not os.environ.get("NSR_GRAD_NO_ASSERT"):
-        assert e <= rel and c >= cos_min, (what, {"rel_l2": e, "cosine": c, "bounds": (rel, cos_min)})
+        assert e <= rel and c >= cos_min, (what, {"rel_l2": e, "cosine": c, "bounds": (rel, cos_min), "floor": floor})
     return e, c
 
 

@@ -79,8 +79,10 @@ def test_backward_parity(n_in, n_out, n_hidden, act, n):
     # (profiles/r05_grad_parity.json) -- the fp16 chain's floor against an fp32 reference, so those shapes take 2e-2 (cosine
     # still >= 0.999: measured 0.99985-0.99993); the fused paths, compared with fp16-emulating fixtures, all meet 1e-2
     rel = 1e-2 if n_hidden == 1 else 2e-2
-    fu.assert_grad(gw, ref_w, ("weights", n_in, n_out, n_hidden, act), rel=rel)
-    fu.assert_grad(dx, ref_x, ("input", n_in, n_out, n_hidden, act), rel=rel)
+    floor = None if n_hidden == 1 else ((1.2e-2, 1.8e-2), "fp16 activations + fp16 gradient chain through >= 2 hidden layers "
+                                                            "against FP32 autograd (tcnn has the same; profiles/r05_grad_parity.json)")
+    fu.assert_grad(gw, ref_w, ("weights", n_in, n_out, n_hidden, act), rel=rel, floor=floor)
+    fu.assert_grad(dx, ref_x, ("input", n_in, n_out, n_hidden, act), rel=rel, floor=floor)
 
 
 def test_backward_accumulates_into_grad():
