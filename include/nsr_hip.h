@@ -122,19 +122,15 @@ uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points);
 /* Run-time knobs of the owner-computes decomposition (A/B switches; the gradient is the same bits under every setting).
  * key 0: placement of the (level, slice, chunk) work units on the eight XCDs -- 0: dealt round-robin; 1: XCD k
  * takes the k-th contiguous, cost-balanced range of the unit list (one or two levels per L2: the least x / dy fetch); 2: level
- * l belongs to the XCD pair l mod 4, a pair's units are dealt to its two XCDs (a level's dy is fetched by 2 L2s instead of 8; default).
+ * l belongs to the XCD pair l mod 4, a pair's units are dealt to its two XCDs (a level's dy is fetched by 2 L2s instead of 8);
+ * 3: the same per-pair lists, finest level first, but a workgroup claims its unit when it starts (an atomic cursor per pair) and
+ * takes from the next pair's list once its own is empty; 4 (default): 3 in the 2^13 x 1024 configuration, 2 in the 2^11 x 256 one.
  * key 1 / 2: weight of a unit's write-out share / item share in the cost balance of placement 1 (default 1 / 3).
  * key 3: log2 of the entries per slice of a dense level (default 11).  key 4: workgroups a dense level is cut into at least,
  * slices x item chunks (default 64).  key 5: fp32 merge of runs of same-entry lanes before the LDS atomics -- 0: off, 1: on the
  * chunked dense levels (default; their result is summed from fp32 chunk slabs anyway), 2: on every dense level.
  * Returns the previous value. */
 float nsr_hashgrid_owner_tune(int key, float value);
-/* The unit -> XCD map a launch over the levels [level_begin, level_end) would use (host arithmetic only, no GPU):
- * out[0] = blocks, out[1..9] = first unit of XCD 0..8, out[10..10+L] = first unit of level 0..L, then n_slices[L],
- * n_chunks[L].  large: the 2^13 x 1024 configuration instead of 2^11 x 256. */
-int nsr_hashgrid_owner_debug_map(const NsrGridDesc *desc, int large, uint32_t level_begin, uint32_t level_end,
-                                 int with_adam, uint32_t *out);
-
 /* _accumulate over the run of levels [level_begin, level_end) only (items binned beforehand, dy level-major fp32
  * [L][n][F]), the gradient written either as fp32 into grad_table or as bf16 (round to nearest even) into grad_bf16 --
  * exactly one of the two is non-NULL; both are indexed like the table (entry 0 of level 0 first) and OVERWRITTEN.

@@ -817,14 +817,34 @@ extern "C" int nsr_hashgrid_backward_params(const float *x, const void *dy, int 
 // gradient of the hashed levels is the same bits under every setting (integer sums); on the dense levels the chunk slabs and
 // the row merge add in fp32, so placement / chunking / merge settings change their association (agreement to ~1e-6):
 struct OwnTune {
-    int placement;         // 0: units dealt over the XCDs, 1: contiguous cost-balanced ranges, 2: levels striped over XCD pairs (default)
+    int placement;         // 0: units dealt over the XCDs, 1: contiguous cost-balanced ranges, 2: levels striped over XCD pairs, 3: striped lists claimed at run time, 4: 3 for the large configuration / 2 for the small one (default)
     float cost_adam;       // weight of a unit's write-out share in the balance
     float cost_items;      // weight of a unit's item share
     uint32_t dense_epb_log2;  // entries per slice of a dense level (log2)
     uint32_t dense_wgs;       // workgroups a dense level is cut into at least (slices x item chunks)
     uint32_t merge_dense;     // 2: every dense level merges runs of same-entry lanes in fp32 registers, 1: the chunked ones (default), 0: none
 };
-static OwnTune g_own_tune = {2, 1.0f, 3.0f, 11u, 64u, 1u};
+static OwnTune g_own_tune = {4, 1.0f, 3.0f, 11u, 64u, 1u};
+
+// The claimed placement's cursors: five words per launch, zero when the launch starts and cleared again by the workgroup that
+// takes its last unit.  Launches in flight at the same time (two tables on two streams, a step queued behind the previous
+// one) must not share them, so every launch takes the next of 256 slots of a per-device pool -- a slot comes round again
+// 256 owner launches later, long after its launch has drained.
+static uint32_t *owner_claim_slot()
+{
+    constexpr int SLOTS = 256, WORDS = 8, MAX_DEV = 16;
+    static uint32_t *pool[MAX_DEV] = {nullptr};
+    static uint32_t next[MAX_DEV] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    if (!pool[dev]) {
+        uint32_t *p = nullptr;
+        if (hipMalloc(&p, SLOTS * WORDS * sizeof(uint32_t)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, SLOTS * WORDS * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        pool[dev] = p;
+    }
+    return pool[dev] + WORDS * (next[dev]++ % SLOTS);
+}
 
 #ifndef NSR_OWN_SMALL_LOG2
 #define NSR_OWN_SMALL_LOG2 11
@@ -871,12 +891,12 @@ extern "C" uint32_t nsr_hashgrid_owner_large_from(uint32_t n_points)
     return old;
 }
 
-// key 0: placement (0 dealt / 1 listed / 2 striped), 1: cost_adam, 2: cost_items, 3: dense_epb_log2, 4: dense_wgs, 5: merge_dense
+// key 0: placement (0 dealt / 1 listed / 2 striped / 3 claimed / 4 by configuration), 1: cost_adam, 2: cost_items, 3: dense_epb_log2, 4: dense_wgs, 5: merge_dense
 extern "C" float nsr_hashgrid_owner_tune(int key, float value)
 {
     float old = 0.f;
     switch (key) {
-    case 0: old = (float)g_own_tune.placement; g_own_tune.placement = value < 0.5f ? 0 : (value < 1.5f ? 1 : 2); break;
+    case 0: old = (float)g_own_tune.placement; g_own_tune.placement = value < 0.5f ? 0 : (value < 1.5f ? 1 : (value < 2.5f ? 2 : (value < 3.5f ? 3 : 4))); break;
     case 1: old = g_own_tune.cost_adam; g_own_tune.cost_adam = value; break;
     case 2: old = g_own_tune.cost_items; g_own_tune.cost_items = value; break;
     case 3: old = (float)g_own_tune.dense_epb_log2; g_own_tune.dense_epb_log2 = (uint32_t)value; break;
@@ -885,19 +905,6 @@ extern "C" float nsr_hashgrid_owner_tune(int key, float value)
     default: break;
     }
     return old;
-}
-
-// the unit -> XCD map a launch over the levels [level_begin, level_end) would use (host arithmetic only: tests/test_capi.py)
-// out[0] = blocks, out[1..9] = xcd_start, out[10..10+L] = unit_start, then n_slices[L], n_chunks[L]
-extern "C" int nsr_hashgrid_owner_debug_map(const NsrGridDesc *desc, int large, uint32_t level_begin, uint32_t level_end,
-                                            int with_adam, uint32_t *out)
-{
-    if (int rc = check_desc(desc, "nsr_hashgrid_owner_debug_map")) return rc;
-    NSR_REQUIRE(out, "nsr_hashgrid_owner_debug_map: out is NULL");
-    if (level_end > desc->n_levels) level_end = desc->n_levels;
-    if (large) own_large::owner_debug_map(desc, level_begin, level_end, with_adam, out);
-    else own_small::owner_debug_map(desc, level_begin, level_end, with_adam, out);
-    return NSR_OK;
 }
 
 // the owner's part of the workspace (either configuration), rounded to 16 bytes: where the dense-level accumulators start

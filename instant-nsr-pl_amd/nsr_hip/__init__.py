@@ -214,7 +214,6 @@ SIGNATURES = {
     "nsr_nerf_wait_kept_rows": [_P],
     "nsr_nerf_defer_wgrad_join": [ctypes.c_int],
     "nsr_hashgrid_owner_tune": [ctypes.c_int, ctypes.c_float],
-    "nsr_hashgrid_owner_debug_map": [_GD, ctypes.c_int, _U, _U, ctypes.c_int, _P],
     "nsr_hashgrid_backward_params_owner_accumulate_range": [_P, _P, _P, _P, _P, _U, _U, _F, _U, _U, _GD, _P, _P],
     "nsr_hashgrid_backward_params_taps_workspace_floats": [_GD, _U],
     "nsr_hashgrid_backward_params_owner_bin_taps": [_P, _P, _P, _U, _U, _GD, _P],

@@ -509,3 +509,79 @@ def test_forward_tile_major_layout_holds_the_same_values(F, n):
     check(lib.nsr_hashgrid_forward_jac(ptr(x), ptr(table), ptr(tm), n, 0, 2, L - 1, ctypes.byref(gd), ptr(jac), None,
                                        stream_ptr()), "nsr_hashgrid_forward_jac")
     assert torch.equal(tm.permute(0, 2, 1, 3).reshape(rows, L * F)[:n], want)
+
+
+def test_owner_backward_placements_agree_and_claim_cursors_reset():
+    """every placement of the work units (nsr_hashgrid_owner_tune key 0: dealt / listed / striped / claimed at run time) gives
+    the same table gradient in both configurations -- the same bits on the hashed levels, fp32 rounding on the chunked dense
+    ones.  The claimed placement takes its units with atomic cursors that the launch itself clears: 300 launches (more than
+    the 256 cursor slots, so slots are reused) on two streams at once must all give that gradient, and it must equal the
+    oracle's (oracle/hashgrid_ref.py)"""
+    import ctypes
+    import nsr_hip
+    from nsr_hip import check, lib, ptr
+    from oracle import tcnn_ref
+    gd = nsr_hip.make_grid_desc(NERF_GRID["n_levels"], NERF_GRID["n_features_per_level"], NERF_GRID["log2_hashmap_size"],
+                                NERF_GRID["base_resolution"], NERF_GRID["per_level_scale"])
+    n, n_tab = 30000, gd.n_entries * 2
+    g = torch.Generator(device="cuda").manual_seed(33)
+    x = torch.rand(n, 3, device="cuda", generator=g)
+    x[: n // 2] = x[: n // 2] * 0.05 + 0.4  # (half of the samples in a few cells: uneven units)
+    dy = torch.randn(16, n, 2, device="cuda", generator=g) * 1e-3
+    D = ctypes.byref(gd)
+    off = [int(o) * 2 for o in gd.offset[:17]]
+    n_ws = int(lib.nsr_hashgrid_backward_params_workspace_floats(D, n))
+
+    def run(stream, ws):
+        a = torch.empty(n_tab, device="cuda")
+        with torch.cuda.stream(stream):
+            check(lib.nsr_hashgrid_backward_params_owner(ptr(x), ptr(dy), 2, 0, ptr(a), ptr(ws), n, 16, 1.0, 0, D, None,
+                                                         stream.cuda_stream), "owner")
+        return a
+
+    def same(a, b, what):
+        for lvl in range(16):
+            sl = slice(off[lvl], off[lvl + 1])
+            if (int(gd.resolution[lvl]) ** 3) <= int(gd.size[lvl]):
+                assert float((a[sl] - b[sl]).norm() / b[sl].norm()) < 1e-5, (what, lvl)
+            else:
+                assert torch.equal(a[sl], b[sl]), (what, lvl)
+
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    ws0, ws1 = torch.empty(n_ws, device="cuda"), torch.empty(n_ws, device="cuda")
+    torch.cuda.synchronize()
+    old_thr = lib.nsr_hashgrid_owner_large_from(0)
+    old_pl = lib.nsr_hashgrid_owner_tune(0, 2.0)
+    try:
+        ref = None
+        for thr in (0, 0xffffffff):
+            lib.nsr_hashgrid_owner_large_from(thr)
+            for pl in (2, 0, 1, 3, 4):
+                lib.nsr_hashgrid_owner_tune(0, float(pl))
+                a = run(s0, ws0)
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = a
+                    assert float(ref.abs().sum()) > 0
+                same(a, ref, (thr, pl))
+        lib.nsr_hashgrid_owner_tune(0, 3.0)
+        for thr, rounds in ((0, 100), (0xffffffff, 50)):
+            lib.nsr_hashgrid_owner_large_from(thr)
+            outs = []
+            for _ in range(rounds):
+                outs.append(run(s0, ws0))
+                outs.append(run(s1, ws1))
+                if len(outs) > 8:
+                    same(outs.pop(0), ref, "repeat")
+            torch.cuda.synchronize()
+            for o in outs:
+                same(o, ref, "repeat")
+    finally:
+        lib.nsr_hashgrid_owner_tune(0, old_pl)
+        lib.nsr_hashgrid_owner_large_from(old_thr)
+    # the oracle's gradient of the same (x, dy): autograd through oracle/tcnn_ref.py's encode
+    od = tcnn_ref.GridDesc.from_config(NERF_GRID)
+    t = torch.zeros(od.n_params, requires_grad=True)
+    tcnn_ref.hashgrid_encode(x.cpu(), t.view(-1, od.F), od, fp16=False).backward(dy.permute(1, 0, 2).reshape(n, 32).cpu())
+    rel = (ref.cpu() - t.grad).norm() / t.grad.norm()
+    assert rel < 1e-5, rel
