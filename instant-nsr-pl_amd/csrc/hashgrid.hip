@@ -293,6 +293,27 @@ __device__ __forceinline__ void blend8(const Cell &c, const float (&v)[8][F], __
     }
 }
 
+// the corners (cx, cy, cz) and (cx + 1, cy, cz).  F == 2, hashed level, even cx: they are the two halves of one aligned 8-byte
+// pair (hash(cx | 1, ..) = hash(cx, ..) ^ 1, see k_grid_forward) -- one gather instead of two
+template <int F>
+__device__ __forceinline__ void load_x_pair(const __half *__restrict__ table, const LevelGeom &g, uint32_t cx, uint32_t cy,
+                                            uint32_t cz, bool paired, float (&v0)[F], float (&v1)[F])
+{
+    if constexpr (F == 2) {
+        if (paired) {
+            const uint32_t e0 = corner_index(g, cx, cy, cz);
+            const uint2 raw = *reinterpret_cast<const uint2 *>(table + (uint64_t)(g.offset + (e0 & ~1u)) * 2);
+            const __half2 lo = *reinterpret_cast<const __half2 *>(&raw.x), hi = *reinterpret_cast<const __half2 *>(&raw.y);
+            const __half2 a = (e0 & 1u) ? hi : lo, b = (e0 & 1u) ? lo : hi;  // entry e0, entry e0 ^ 1
+            v0[0] = __low2float(a); v0[1] = __high2float(a);
+            v1[0] = __low2float(b); v1[1] = __high2float(b);
+            return;
+        }
+    }
+    load_feat<F>(table, g.offset + corner_index(g, cx, cy, cz), v0);
+    load_feat<F>(table, g.offset + corner_index(g, cx + 1u, cy, cz), v1);
+}
+
 template <int F>
 __global__ void __launch_bounds__(GRID_BLOCK)
 k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ table, __half *__restrict__ y, uint32_t n,
@@ -318,11 +339,13 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
     const LevelGeom g = load_level(d, level);
     const float xb[3] = {x7[3ull * i], x7[3ull * i + 1], x7[3ull * i + 2]};
     const Cell cb = locate(g, xb[0], xb[1], xb[2]);
+    // the forward is bound by the L2 request rate: x-neighbours of an even cell of a hashed level come as one 8-byte gather
+    // (the y / z taps stay in the sample's x column, so their far faces pair up the same way)
+    const bool paired = F == 2 && !g.dense && !(cb.c[0] & 1u);
     float vb[8][F];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        load_feat<F>(table, g.offset + corner_index(g, cb.c[0] + (k & 1), cb.c[1] + ((k >> 1) & 1), cb.c[2] + ((k >> 2) & 1)),
-                     vb[k]);
+    for (int j = 0; j < 4; ++j)
+        load_x_pair<F>(table, g, cb.c[0], cb.c[1] + (j & 1), cb.c[2] + (j >> 1), paired, vb[2 * j], vb[2 * j + 1]);
     blend8<F>(cb, vb, TAP_ROW(i));
     uint32_t cross_mask = 0u;
 #pragma unroll
@@ -342,14 +365,29 @@ k_grid_forward_taps(const float *__restrict__ x7, const __half *__restrict__ tab
         } else if (dc == 1 || dc == -1) {
             // corner k of the tap's cell with bit a == (dc < 0) is corner k ^ (1 << a) of the sample's cell (shared face)
             const int shared_bit = dc < 0 ? 1 : 0;
+            if (a == 0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (((k >> a) & 1) == shared_bit) {
+                for (int k = 0; k < 8; ++k) {
+                    if ((k & 1) == shared_bit) {
 #pragma unroll
-                    for (int f = 0; f < F; ++f) vt[k][f] = vb[k ^ (1 << a)][f];
-                } else {
-                    load_feat<F>(table, g.offset + corner_index(g, ct.c[0] + (k & 1), ct.c[1] + ((k >> 1) & 1),
-                                                                ct.c[2] + ((k >> 2) & 1)), vt[k]);
+                        for (int f = 0; f < F; ++f) vt[k][f] = vb[k ^ 1][f];
+                    } else {
+                        load_feat<F>(table, g.offset + corner_index(g, ct.c[0] + (k & 1), ct.c[1] + ((k >> 1) & 1),
+                                                                    ct.c[2] + ((k >> 2) & 1)), vt[k]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // corners 2j, 2j + 1: the x pair at (y bit, z bit) = (j & 1, j >> 1)
+                    if ((((2 * j) >> a) & 1) == shared_bit) {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) {
+                            vt[2 * j][f] = vb[(2 * j) ^ (1 << a)][f];
+                            vt[2 * j + 1][f] = vb[(2 * j + 1) ^ (1 << a)][f];
+                        }
+                    } else {
+                        load_x_pair<F>(table, g, ct.c[0], ct.c[1] + (j & 1), ct.c[2] + (j >> 1), paired, vt[2 * j], vt[2 * j + 1]);
+                    }
                 }
             }
         } else {
