@@ -311,9 +311,9 @@ class FusedNeuSStep:
                                        None, n, n, None, stream_ptr()), "nsr_vmlp_forward(bg occupancy)")
             return torch.exp(out[:, :1] + self.bg_bias) * float(m.render_step_size_bg)
 
-    def _bg_prune(self, handle):
-        """sigma_fn pass of ray_marching: encode + density head on every marched sample, keep each ray's leading samples
-        with transmittance >= 1e-4 -> kept sample count on the host (the branch's second host sync)"""
+    def _bg_prune_begin(self, handle):
+        """sigma_fn pass of ray_marching: encode + density head on every marched sample, each ray's leading samples with
+        transmittance >= 1e-4 counted and the total sent to the host -- queued without waiting for it"""
         m, enc = self.model, self.bg_enc
         rays_o, rays_d = handle.args[0], handle.args[1]
         dev, n_rays = rays_o.device, rays_o.shape[0]
@@ -336,22 +336,31 @@ class FusedNeuSStep:
         check(lib.nsr_bg_visibility_prefix(ptr(out_m), self.bg_bias, ptr(t0_m), ptr(t1_m), ptr(pk_m), 1e-4, ptr(kept),
                                            n_rays, s), "nsr_bg_visibility_prefix")
         check(lib.nsr_pack_from_counts(ptr(kept), ptr(pk), ptr(total), n_rays, s), "nsr_pack_from_counts")
-        S = int(total.item())
-        Sa = max(S, 1)  # (nothing kept -- e.g. an empty background grid: the ray kernels still run, on non-NULL arrays)
-        c = dict(packed=pk, S=S, M=M, rays_d=rays_d, n_rays=n_rays,
-                 ri=torch.empty(Sa, dtype=torch.int64, device=dev)[:S], t0=torch.empty(Sa, dtype=F32, device=dev)[:S],
-                 t1=torch.empty(Sa, dtype=F32, device=dev)[:S], x01=torch.empty((Sa, 3), dtype=F32, device=dev)[:S],
-                 xin=torch.empty((Sa, self.bg_n_enc), dtype=F32, device=dev)[:S],
-                 out=torch.empty((Sa, 16), dtype=F32, device=dev)[:S])
-        if S == 0:
+        return dict(packed=pk, M=M, rays_d=rays_d, n_rays=n_rays, _count=_ops.read_count_begin(total),
+                    _marched=(pk_m, [t0_m, t1_m, x01_m, xin_m, out_m]))
+
+    def _bg_prune_finish(self, c):
+        """the kept sample count reaches the host (the branch's second host sync; the caller has queued the foreground's encode
+        and SDF network behind the pruning pass by now, so the GPU works while the host waits -- done right after the pruning
+        pass, the wait and the host's queueing after it left the main stream idle ~0.1 ms per step) -> the kept samples' arrays"""
+        dev, n_rays = c["rays_d"].device, c["n_rays"]
+        rows = c["S"] = _ops.read_count_finish(c.pop("_count"))
+        pk_m, srcs = c.pop("_marched")
+        R = max(rows, 1)  # (nothing kept -- e.g. an empty background grid: the ray kernels still run, on non-NULL arrays)
+        c.update(ri=torch.empty(R, dtype=torch.int64, device=dev)[:rows],
+                 t0=torch.empty(R, dtype=F32, device=dev)[:rows], t1=torch.empty(R, dtype=F32, device=dev)[:rows],
+                 x01=torch.empty((R, 3), dtype=F32, device=dev)[:rows],
+                 xin=torch.empty((R, self.bg_n_enc), dtype=F32, device=dev)[:rows],
+                 out=torch.empty((R, 16), dtype=F32, device=dev)[:rows])
+        if rows == 0:
             return c
-        srcs, dsts = [t0_m, t1_m, x01_m, xin_m, out_m], [c["t0"], c["t1"], c["x01"], c["xin"], c["out"]]
+        dsts = [c["t0"], c["t1"], c["x01"], c["xin"], c["out"]]
         k = len(srcs)
         sp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
         dp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dsts])
         rb = (ctypes.c_uint32 * k)(*[(t.stride(0) if t.dim() > 1 else 1) * t.element_size() for t in srcs])
-        check(lib.nsr_copy_ray_prefix_rows(ptr(pk_m), ptr(pk), k, sp, dp, rb, ptr(rays_d), None, ptr(c["ri"]), n_rays, s),
-              "nsr_copy_ray_prefix_rows")
+        check(lib.nsr_copy_ray_prefix_rows(ptr(pk_m), ptr(c["packed"]), k, sp, dp, rb, ptr(c["rays_d"]), None, ptr(c["ri"]),
+                                           n_rays, stream_ptr()), "nsr_copy_ray_prefix_rows")
         return c
 
     def _bg_forward(self, c, background):
@@ -741,7 +750,7 @@ class FusedNeuSStep:
             bgc = None
             if self.bg:  # the background's pruning pass decides its sample count: num_samples_full = N + S
                 self._bg_grads = compute_grads
-                bgc = self._bg_prune(bg_handle)
+                bgc = self._bg_prune_begin(bg_handle)
             self._n_samples = N
             T = 7 if self.fd else 1
             eps = self._fd_eps() if self.fd else 0.0
@@ -816,6 +825,8 @@ class FusedNeuSStep:
             g_in = None if self.fd else torch.empty((N, P), dtype=F32, device=dev)
             check(lib.nsr_vmlp_forward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(out), ptr(taps),
                                        ptr(g_in), T * N, N, None, s), "nsr_vmlp_forward(sdf)")
+            if bgc is not None:
+                self._bg_prune_finish(bgc)
             if after_march is not None:
                 # the sample count of this step is known: a trainer queues the next batch's ray preparation + marching
                 # (side stream) here -- AFTER the first ~0.6 ms of this step's kernels are in the queue, so that the host
@@ -887,7 +898,7 @@ class FusedNeuSStep:
             if bgc is not None:
                 res.update({"comp_rgb_bg": bgc["comp_rgb"], "opacity_bg": bgc["opacity"], "depth_bg": bgc["depth"],
                             "rays_valid_bg": None if lean else bgc["opacity"] > 0, "num_samples_bg": bgc["S"],
-                            "num_samples_full": N + bgc["S"],
+                            "num_marched_bg": bgc["M"], "num_samples_full": N + bgc["S"],
                             "rays_valid_full": None if lean else (opacity > 0) | (bgc["opacity"] > 0),
                             "weights_bg": bgc["weights"], "ray_indices_bg": bgc["ri"], "t_starts_bg": bgc["t0"],
                             "t_ends_bg": bgc["t1"]})
@@ -1279,5 +1290,5 @@ class NeuSTrainer:
         self.opt_rest.step(lr_scale=scale)
         self.global_step += 1
         self.last = {"loss_acc": res["loss_acc"], "n_rays": rays.shape[0], "n_samples": n,
-                     "n_samples_bg": res.get("num_samples_bg", 0)}
+                     "n_samples_bg": res.get("num_samples_bg", 0), "n_marched_bg": res.get("num_marched_bg", 0)}
         return self.last

@@ -4,6 +4,7 @@ Everything here is host-side plumbing: allocate outputs with torch, pass raw poi
 stream to ``libnsr_hip.so``.  No arithmetic of the hot path happens in Python.
 """
 import ctypes
+import time
 
 import os
 
@@ -439,7 +440,18 @@ def _pinned_int32():
     return _PINNED[_PINNED[-1]]
 
 
+SPIN_SECONDS = [0.0]  # total host time spent waiting for device counts (tools/neus_operating_point.py reads it)
+
+
 def _spin_until_changed(host_word, sentinel, fallback_sync):
+    t_begin = time.perf_counter()
+    try:
+        return _spin_until_changed_(host_word, sentinel, fallback_sync)
+    finally:
+        SPIN_SECONDS[0] += time.perf_counter() - t_begin
+
+
+def _spin_until_changed_(host_word, sentinel, fallback_sync):
     spins = 0
     while int(host_word[0]) == sentinel:
         spins += 1
@@ -459,6 +471,22 @@ def read_count_when_ready(dev_word):
     host[0] = -0x7fffffff
     host.copy_(dev_word, non_blocking=True)
     return _spin_until_changed(host, -0x7fffffff, torch.cuda.current_stream().synchronize)
+
+
+def read_count_begin(dev_word):
+    """first half of ``read_count_when_ready``: queue the copy into a pinned word on the current stream and return at once;
+    ``read_count_finish`` waits.  Between the two the host may queue work that does not depend on the count."""
+    host = _pinned_int32()
+    host[0] = -0x7fffffff
+    host[0:1].copy_(dev_word, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    return host, ev
+
+
+def read_count_finish(pending):
+    host, ev = pending
+    return _spin_until_changed(host, -0x7fffffff, ev.synchronize)
 
 
 class MarchHandle:

@@ -39,5 +39,6 @@ torch.cuda.synchronize()
 buf = io.StringIO()
 st = pstats.Stats(pr, stream=buf)
 st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumulative").print_stats(45)
 print(json.dumps({"config": name, "ms_per_step_unprofiled": plain, "steps": n_steps}))
 print(buf.getvalue())

@@ -32,13 +32,17 @@ if name == "neuralangelo":
 for _ in range(n_steps):
     tr.train_step()
 torch.cuda.synchronize()
-t0, n, host = time.perf_counter(), 0, 0.0
+import nsr_hip.ops as _ops
+_ops.SPIN_SECONDS[0] = 0.0
+t0, n, host, n_fg, n_bg, m_bg = time.perf_counter(), 0, 0.0, 0, 0, 0
 for _ in range(n_steps):
     h0 = time.perf_counter()
     last = tr.train_step()
     host += time.perf_counter() - h0
     n += last["n_samples"] + last["n_samples_bg"]
+    n_fg += last["n_samples"]; n_bg += last["n_samples_bg"]; m_bg += last.get("n_marched_bg", 0)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps({"config": name, "ms_per_step": 1e3 * dt / n_steps, "host_ms_in_train_step": 1e3 * host / n_steps,
-                  "samples_per_step": n / n_steps, "rays_per_step": tr.train_num_rays, "samples_per_sec": n / dt}))
+print(json.dumps({"config": name, "ms_per_step": 1e3 * dt / n_steps, "host_ms_in_train_step": 1e3 * host / n_steps, "host_ms_waiting_for_counts": 1e3 * _ops.SPIN_SECONDS[0] / n_steps,
+                  "samples_per_step": n / n_steps, "fg_samples_per_step": n_fg / n_steps, "bg_kept_per_step": n_bg / n_steps,
+                  "bg_marched_per_step": m_bg / n_steps, "rays_per_step": tr.train_num_rays, "samples_per_sec": n / dt}))
