@@ -458,7 +458,9 @@ int nsr_neus_alpha_backward(const float *sdf, const float *normal, const float *
  * without a host sync; csrc/occupancy.hip.  (1) select_cells: all cells (all_cells != 0, capacity >= res^3) or n_uniform
  * cells floor(u_cell * res^3) + the occupied cells of the 4^3-brick bitfield (n_uniform of them, picked with replacement by
  * u_pick, when more than n_uniform are occupied); writes cells[], their jittered positions x_unit[,3] =
- * (cell coordinate + jitter) / res in grid-unit space and the device count n_cells.  jitter: capacity x 3 uniforms;
+ * (cell coordinate + jitter) / res in grid-unit space and the device count n_cells.  all_cells | 2: the grid lives on a
+ * sphere-contracted space -- samples with |x_unit - 0.5| >= 0.5 are dropped here (nerfacc grid.py drops them before it
+ * evaluates them), n_cells counts the survivors, appended workgroup by workgroup (4,096 slots each, in slot order inside).  jitter: capacity x 3 uniforms;
  * brick_offset: one word per brick; occupied_cells: res^3 words.  (2) the caller evaluates the density network on those
  * positions with n_dev = n_cells.  (3) update: occs_new = occs_old, occs_new[cell] = max(occs_old[cell] * ema_decay,
  * exp(mlp_out[i, 0] + density_bias) * step_size); threshold[0] = min(mean(occs_new), occ_thre); binary = occs_new > it.

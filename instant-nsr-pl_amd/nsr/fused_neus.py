@@ -586,11 +586,11 @@ class FusedNeuSStep:
                 else:
                     ob["u"].uniform_()
             check(lib.nsr_occupancy_select_cells(ptr(bricks), rx, ry, rz, ptr(ob["u"][:n_uniform]),
-                                                 ptr(ob["u"][n_uniform:]), ptr(ob["jitter"]), n_uniform, int(all_cells),
+                                                 ptr(ob["u"][n_uniform:]), ptr(ob["jitter"]), n_uniform, int(all_cells) | 2,
                                                  cap, ptr(ob["brick_offset"]), ptr(ob["occupied"]), ptr(n_occ),
                                                  ptr(ob["cells"]), ptr(ob["x_unit"]), ptr(n_cells), s),
                   "nsr_occupancy_select_cells")
-            # (samples outside the unit sphere have no world position: whatever the two maps make of them is discarded below)
+            # (flag 2: samples outside the unit sphere -- no world position -- are dropped by the selection)
             check(lib.nsr_contract_inv(ptr(ob["x_unit"]), ptr(grid.roi_aabb), sphere, ptr(ob["world"]), cap, s),
                   "nsr_contract_inv")
             check(lib.nsr_contract_to_unisphere(ptr(ob["world"]), self.radius, sphere, ptr(ob["x01"]), cap, s),

@@ -192,7 +192,7 @@ def test_device_background_refresh_matches_torch_update(step):
     """FusedNeuSStep.refresh_bg_occupancy_async (cell selection, tile-major encode, density head on the encoding alone,
     exp(logit + bias) * step inside the unit sphere, EMA / threshold / binarise, bricks) == nerfacc's
     OccupancyGrid._update_cells with the reference's background occ_eval_fn (models/neus.py:103-106) on the cells / jitter
-    the kernels selected: cells whose sample fell outside the unit sphere keep their value untouched"""
+    the kernels selected: samples outside the unit sphere are dropped by the selection, their cells keep their value"""
     import copy
     import nsr
     from nsr.fused_neus import FusedNeuSStep
@@ -211,17 +211,27 @@ def test_device_background_refresh_matches_torch_update(step):
     ob = run._occ_buf_bg
     n = int(ob["counts"][1])
     N = grid.num_cells
-    assert n == (N if step < 256 else N // 4 + min(int(ref._binary.sum()), N // 4))
+    # the selection drops the samples outside the unit sphere (as nerfacc does before evaluating anything) and appends the
+    # rest wave by wave: the survivors' jitter is recovered from their positions
+    slots = N if step < 256 else N // 4 + min(int(ref._binary.sum()), N // 4)
     cells = ob["cells"][:n].long()
-    jitter = ob["jitter"][:3 * n].view(n, 3)
+    x_sel = ob["x_unit"][:3 * n].view(n, 3)
+    jitter = (x_sel * ref.resolution - ref._cell_coords(cells)).clamp(0.0, 1.0)
+    if step < 256:  # every cell was a candidate, slot i = cell i with jitter[i]: the survivors are exactly the inside ones
+        x_all = (ref._cell_coords(torch.arange(N, device="cuda")) + ob["jitter"][:3 * N].view(N, 3)) / ref.resolution
+        r_all = (x_all - 0.5).norm(dim=1)
+        assert abs(n - int((r_all < 0.5).sum())) <= int(((r_all - 0.5).abs() < 1e-5).sum())
+        assert int(torch.bincount(cells, minlength=N).max()) == 1
+    else:
+        assert 0.4 * slots < n < 0.65 * slots  # (a sphere fills 52 % of its cube)
     with torch.no_grad():
         ref._update_cells(cells, jitter, run.bg_occ_eval_fn, occ_thre=thre, ema_decay=0.95)
     once = torch.bincount(cells, minlength=N) <= 1
-    # some samples fall outside the unit sphere (corner cells): their cells are left alone by both paths; a sample within
-    # rounding of the sphere's surface may be classified differently by sqrtf and torch's norm -- not compared
+    # no sample outside the unit sphere survives (their cells are left alone, as in the reference); a sample within rounding
+    # of the sphere's surface may be classified differently by sqrtf and torch's norm -- not compared
     x = (ref._cell_coords(cells) + jitter) / ref.resolution
     r = (x - 0.5).norm(dim=1)
-    assert int((r >= 0.5).sum()) > 0
+    assert int((r >= 0.5 + 1e-5).sum()) == 0 and float(r.max()) > 0.49
     on_surface = torch.zeros(N, dtype=torch.bool, device="cuda")
     on_surface[cells[(r - 0.5).abs() < 1e-5]] = True
     sel = once & ~on_surface
