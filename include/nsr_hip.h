@@ -264,15 +264,7 @@ int nsr_mlp_backward_ex(const void *dout, int dout_is_f32, uint32_t dout_stride,
                         const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
                         uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
                         const NsrMlpDesc *desc, const int32_t *n_dev, void *stream);
-/* ... with the weight-gradient kernels + reduction queued on `wgrad_stream` behind the dgrad kernel (NULL / == stream: in
- * line).  The caller joins `wgrad_stream` before anything reads grad_weights. */
-int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
-                        const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
-                        uint32_t x_level_major_features, const nsr_half *acts,
-                        const nsr_half *weights, float *grad_weights, float *dx, uint32_t dx_stride,
-                        uint32_t dx_level_major_features, float *partials, uint32_t n, float grad_scale,
-                        const NsrMlpDesc *desc, const int32_t *n_dev, void *stream, void *wgrad_stream);
-/* The two halves of nsr_mlp_backward_split as separate calls: phases 1 = the dgrad kernel (it also saves what the
+/* nsr_mlp_backward_ex in two halves: phases 1 = the dgrad kernel (it also saves what the
  * weight-gradient kernels need in `partials`), 2 = the weight-gradient kernels + their reduction on `stream` (dout may be
  * NULL), 3 = both on `stream`.  The fused NeRF step forks its helper stream once, behind the second network's dgrad. */
 int nsr_mlp_backward_phases(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
@@ -288,12 +280,11 @@ int nsr_mlp_backward_phases(const void *dout, int dout_is_f32, uint32_t dout_str
  * registers.  d_rgb [n,3], d_logit [n] in; d_enc level-major fp32 [16][n][2] out; the pre-activation gradients are saved in the
  * two networks' backward workspaces where nsr_mlp_backward_phases(..., 1) puts them, so nsr_mlp_backward_phases(..., 2)
  * follows unchanged; every value is bit-identical to the two-launch sequence.  _supported: colour 32 -> 64 x (1..2) -> 3
- * sigmoid, density 32 -> 64 x (1..2) -> 16 linear.  _max_blocks: launch-size knob (0 queries), returns the previous value. */
+ * sigmoid, density 32 -> 64 x (1..2) -> 16 linear. */
 /* at most `blocks` workgroups per weight-gradient launch (1 .. 512, default 512 or NSR_WGRAD_MAX_BLOCKS; 0 queries); returns the
  * previous cap.  Both halves of one backward must see the same value. */
 uint32_t nsr_mlp_wgrad_max_blocks(uint32_t blocks);
 int nsr_mlp_dgrad_pair_supported(const NsrMlpDesc *color, const NsrMlpDesc *density);
-uint32_t nsr_mlp_dgrad_pair_max_blocks(uint32_t blocks);
 int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, const nsr_half *out_color, const nsr_half *acts_color,
                        const nsr_half *w_color, float *partials_color, const nsr_half *acts_density,
                        const nsr_half *w_density, float *partials_density, float *d_enc_level_major, uint32_t n,
@@ -312,13 +303,11 @@ int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, const nsr_half 
  *   backward: row-major [n, enc_stride] half with enc_stride % 8 == 0, or level-major [L][n][F] with enc_level_major).
  * It trades the XCD placement of the stand-alone encode for one launch and 128 B / sample less traffic: faster for small
  * launches, slower for large ones (DESIGN.md section 4 has the measured crossover; nsr_hip/ops.py picks by n).
- * nsr_grid_mlp_forward_max_blocks: developer switch (grid size cap; 0 = query), returns the previous value.
  * ------------------------------------------------------------------------------------------------ */
 int nsr_grid_mlp_supported(const NsrGridDesc *grid, const NsrMlpDesc *mlp);
 int nsr_grid_mlp_forward(const float *x, const nsr_half *table, const nsr_half *weights, nsr_half *out, nsr_half *acts,
                          nsr_half *enc, uint32_t enc_stride, int enc_level_major, uint32_t n, uint32_t level_mask_count,
                          const NsrGridDesc *grid, const NsrMlpDesc *mlp, const int32_t *n_dev, void *stream);
-uint32_t nsr_grid_mlp_forward_max_blocks(uint32_t max_blocks);
 /* Backward of the pair in one call: MLP data gradient written level-major (what the table backward reads: no transpose,
  * one trip through HBM), weight gradients (grad_weights fp32, ACCUMULATED, may be NULL), item binning + owner-computes
  * accumulation into grad_table (fp32, OVERWRITTEN).  dout / out / acts / grad_scale as nsr_mlp_backward; enc as written
@@ -513,14 +502,6 @@ int nsr_visibility_prefix(const nsr_half *mlp_out, uint32_t stride, float densit
 int nsr_copy_ray_prefix_rows(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
                              const void *const *src, void *const *dst, const uint32_t *row_bytes, const float *rays_d,
                              float *dirs_out, int64_t *ray_indices_out, uint32_t n_rays, void *stream);
-/* ... with per-array plane counts for level-major arrays (planes[q] row-arrays spaced src/dst_plane_bytes[q] apart) */
-int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
-                                const void *const *src, void *const *dst, const uint32_t *row_bytes,
-                                const uint32_t *planes, const uint64_t *src_plane_bytes, const uint64_t *dst_plane_bytes,
-                                const float *rays_d, float *dirs_out, int64_t *ray_indices_out, const nsr_half *tex_src,
-                                uint32_t tex_src_stride, nsr_half *tex_in, uint32_t n_rays, void *stream);
-/* tex_in (may be NULL): additionally writes the texture network's input rows [n_kept, 32] = [first 16 halfs of the
- * marched-layout feature row tex_src[sample] | SH4(ray direction)] (what nsr_texture_input computes per sample) */
 /* The fused step's instance of that copy (F = 2 level-major encoding, 16-half feature rows, n_hidden <= 2 saved
  * activation rows), one lane per kept sample with every row's load issued before the first store; *_capacity are the row
  * strides of the level-major / per-layer arrays in the marched and the kept layout.  Also writes ray_indices and tex_in */
@@ -558,13 +539,6 @@ int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, float densi
                            const float *background, const float *weights, const float *trans,
                            const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
                            float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream);
-/* ... and with dL/d weights[n] of the caller's own loss terms on the per-sample weights (grad_weights may be NULL; e.g. the
- * distortion loss of systems/nerf.py:103-106 when it is formed outside) */
-int nsr_composite_backward_ex(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
-                              const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride, const int32_t *packed_info,
-                              const float *background, const float *weights, const float *trans,
-                              const float *grad_comp_rgb, const float *grad_opacity, const float *grad_depth,
-                              const float *grad_weights, float *grad_rgb, float *grad_logit, uint32_t n_rays, void *stream);
 /* composite backward with the gradient of the masked smooth-L1 loss (nsr_smooth_l1_valid_backward) evaluated inside */
 int nsr_composite_backward_smooth_l1(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
                                      const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,

@@ -1121,7 +1121,7 @@ extern "C" int nsr_composite_backward(const nsr_half *mlp_out, uint32_t stride, 
     return NSR_OK;
 }
 
-extern "C" int nsr_composite_backward_ex(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+NSR_INTERNAL int nsr_composite_backward_ex(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
                                          const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
                                          const int32_t *packed_info, const float *background, const float *weights,
                                          const float *trans, const float *grad_comp_rgb, const float *grad_opacity,
@@ -1276,7 +1276,7 @@ extern "C" int nsr_gather_train_rays(const float *images, const float *masks, co
     return NSR_OK;
 }
 
-extern "C" int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
+NSR_INTERNAL int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
                                            const void *const *src, void *const *dst, const uint32_t *row_bytes,
                                            const uint32_t *planes, const uint64_t *src_plane_bytes,
                                            const uint64_t *dst_plane_bytes, const float *rays_d, float *dirs_out,

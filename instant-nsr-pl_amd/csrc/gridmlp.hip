@@ -145,16 +145,9 @@ k_grid_mlp_forward(const float *__restrict__ x, const __half *__restrict__ table
 
 // measured (tools/grid_mlp_ab.py): 512 workgroups beat 2048 / 8192 at every size -- a wave fetches 14 KB of weights before its
 // first tile, and more than ~8 waves per CU only add gather requests in flight to an L2 that is already missing
-uint32_t g_max_blocks = 512;
+constexpr uint32_t g_max_blocks = 512;
 
 }  // namespace
-
-extern "C" uint32_t nsr_grid_mlp_forward_max_blocks(uint32_t max_blocks)
-{
-    const uint32_t old = g_max_blocks;
-    if (max_blocks) g_max_blocks = max_blocks;
-    return old;
-}
 
 #define GM_DISPATCH(F_, NH_, ...)                                                  \
     switch ((F_) * 10 + (NH_)) {                                                   \

@@ -929,14 +929,7 @@ extern "C" int nsr_mlp_dgrad_pair_supported(const NsrMlpDesc *color, const NsrMl
            density->output_activation == NSR_ACT_NONE && density->n_hidden >= 1 && density->n_hidden <= 2;
 }
 
-static uint32_t g_dgrad_pair_max_blocks = 2048;
-extern "C" uint32_t nsr_mlp_dgrad_pair_max_blocks(uint32_t blocks)
-{
-    const uint32_t old = g_dgrad_pair_max_blocks;
-    if (blocks) g_dgrad_pair_max_blocks = blocks;
-    return old;
-}
-
+constexpr uint32_t g_dgrad_pair_max_blocks = 2048;
 // d_rgb [n,3] fp32 and d_logit [n] fp32 in, d_enc level-major fp32 [16][n][2] out; the pre-activation gradients the
 // weight-gradient kernels read are saved into the two networks' backward workspaces exactly where nsr_mlp_backward_phases(..., 1)
 // puts them, so nsr_mlp_backward_phases(..., 2) follows unchanged.
@@ -982,7 +975,7 @@ extern "C" int nsr_mlp_dgrad_pair(const float *d_rgb, const float *d_logit, cons
     return NSR_OK;
 }
 
-extern "C" int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+NSR_INTERNAL int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
                                       const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
                                       uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
                                       float *grad_weights, float *dx, uint32_t dx_stride,

@@ -141,3 +141,29 @@ __device__ __forceinline__ void nsr_adam_schedule(const int32_t *step, const flo
     bc1 = (float)(1.0 - p1);
     bc2 = (float)(1.0 - p2);
 }
+
+// ---- entry points shared between translation units of the library, NOT part of the C ABI (hidden visibility) ----------------
+#define NSR_INTERNAL extern "C" __attribute__((visibility("hidden")))
+// nsr_mlp_backward_ex with the weight-gradient kernels + reduction queued on `wgrad_stream` behind the dgrad kernel (NULL / ==
+// stream: in line); the caller joins `wgrad_stream` before anything reads grad_weights  (csrc/mlp.hip, used by csrc/step.hip)
+NSR_INTERNAL int nsr_mlp_backward_split(const void *dout, int dout_is_f32, uint32_t dout_stride, const float *dout_extra_col0,
+                                        const nsr_half *out, const void *x, int x_is_f32, uint32_t x_stride,
+                                        uint32_t x_level_major_features, const nsr_half *acts, const nsr_half *weights,
+                                        float *grad_weights, float *dx, uint32_t dx_stride, uint32_t dx_level_major_features,
+                                        float *partials, uint32_t n, float grad_scale, const NsrMlpDesc *desc,
+                                        const int32_t *n_dev, void *stream, void *wgrad_stream);
+// nsr_copy_ray_prefix_rows with per-array plane counts for level-major arrays (planes[q] row-arrays spaced src/dst_plane_bytes[q]
+// apart) and, with tex_in, the texture network's input rows [n_kept, 32] = [first 16 halfs of tex_src[sample] | SH4(direction)]
+NSR_INTERNAL int nsr_copy_ray_prefix_rows_ex(const int32_t *packed_old, const int32_t *packed_new, uint32_t n_arrays,
+                                             const void *const *src, void *const *dst, const uint32_t *row_bytes,
+                                             const uint32_t *planes, const uint64_t *src_plane_bytes,
+                                             const uint64_t *dst_plane_bytes, const float *rays_d, float *dirs_out,
+                                             int64_t *ray_indices_out, const nsr_half *tex_src, uint32_t tex_src_stride,
+                                             nsr_half *tex_in, uint32_t n_rays, void *stream);
+// nsr_composite_backward with dL/d weights[n] of further loss terms on the per-sample weights (grad_weights may be NULL)
+NSR_INTERNAL int nsr_composite_backward_ex(const nsr_half *mlp_out, uint32_t stride, float density_bias, const float *t_starts,
+                                           const float *t_ends, const nsr_half *rgb, uint32_t rgb_stride,
+                                           const int32_t *packed_info, const float *background, const float *weights,
+                                           const float *trans, const float *grad_comp_rgb, const float *grad_opacity,
+                                           const float *grad_depth, const float *grad_weights, float *grad_rgb,
+                                           float *grad_logit, uint32_t n_rays, void *stream);

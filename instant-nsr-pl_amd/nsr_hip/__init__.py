@@ -143,19 +143,16 @@ SIGNATURES = {
     "nsr_mlp_forward_ex": [_P, _I, _U, _U, _P, _P, _P, _U, _MD, _P, _P],
     "nsr_grid_mlp_supported": [_GD, _MD],
     "nsr_grid_mlp_forward": [_P, _P, _P, _P, _P, _P, _U, _I, _U, _U, _GD, _MD, _P, _P],
-    "nsr_grid_mlp_forward_max_blocks": [_U],
     "nsr_grid_mlp_backward_workspace_floats": [_GD, _MD, _U],
     "nsr_grid_mlp_backward": [_P, _I, _U, _P, _P, _P, _U, _I, _P, _P, _P, _P, _P, _U, _U, _F, _GD, _MD, _P],
     "nsr_mlp_backward_workspace_floats": [_MD, _U],
     "nsr_mlp_backward": [_P, _I, _U, _P, _P, _I, _U, _P, _P, _P, _P, _U, _P, _U, _F, _MD, _P],
     "nsr_mlp_backward_ex": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P],
-    "nsr_mlp_backward_split": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P, _P],
     "nsr_mlp_backward_phases": [_P, _I, _U, _P, _P, _P, _I, _U, _U, _P, _P, _P, _P, _U, _U, _P, _U, _F, _MD, _P, _P, _I],
     "nsr_sample_positions_unit": [_P, _P, _P, _P, _P, _F, _I, _P, _P, _U, _P, _P],
     "nsr_visibility_prefix": [_P, _U, _F, _P, _P, _P, _F, _P, _U, _P],
     "nsr_copy_ray_prefix_rows": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_nerf_copy_kept_rows": [_P] * 14 + [_U, _U, _U, _U, _P, _P, _P, _U, _P],
-    "nsr_copy_ray_prefix_rows_ex": [_P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P, _U, _P],
     "nsr_texture_input": [_P, _U, _P, _P, _U, _P, _P],
     "nsr_composite_forward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_composite_backward": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
@@ -203,7 +200,6 @@ SIGNATURES = {
     "nsr_nerf_prune_pass": [_SD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _U, _P, _P, _P],
     "nsr_nerf_main_layout": [_SD, _U, _U, ctypes.POINTER(NsrNerfMainLayout)],
     "nsr_nerf_main_pass": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P, _P],
-    "nsr_composite_backward_ex": [_P, _U, _F, _P, _P, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _P],
     "nsr_nerf_render_forward": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _I, _P, _P, _P],
     "nsr_nerf_render_backward": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P],
     "nsr_nerf_main_pass_exchange": [_SD, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P, _P, _P],
@@ -222,7 +218,6 @@ SIGNATURES = {
     "nsr_hashgrid_backward_params_owner_accumulate_adam": [_P, _P, _I, _U, _P, _U, _U, _F, _GD, _P, _P, _P],
     "nsr_mlp_wgrad_max_blocks": [_U],
     "nsr_mlp_dgrad_pair_supported": [_MD, _MD],
-    "nsr_mlp_dgrad_pair_max_blocks": [_U],
     "nsr_mlp_dgrad_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _U, _F, _MD, _MD, _P, _P],
     "nsr_visibility_prefix_sums": [_P, _U, _F, _P, _P, _P, _F, _P, _P, _U, _P],
     "nsr_nerf_copy_kept_rows_scan": [_P] * 18 + [_U, _U, _U, _U, _P, _P, _P, _U, _P],
@@ -278,9 +273,9 @@ SIGNATURES = {
     "nsr_neus_shade_backward": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _F, _F, _P, _P, _U, _P, _F, _F, _P, _P, _P, _U, _P,
                                 _P, _U, _P, _P],
 }
-_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_mlp_dgrad_pair_max_blocks": ctypes.c_uint32, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32, "nsr_masked_loss_out_floats": ctypes.c_uint32,
+_RESTYPES = {"nsr_last_error": ctypes.c_char_p, "nsr_ray_march_rays_per_wave": ctypes.c_uint32, "nsr_nerf_helper_stream": ctypes.c_void_p, "nsr_hashgrid_owner_large_from": ctypes.c_uint32, "nsr_hashgrid_owner_tune": ctypes.c_float, "nsr_mlp_wgrad_max_blocks": ctypes.c_uint32, "nsr_masked_loss_out_floats": ctypes.c_uint32,
              "nsr_composite_l1_partials_floats": ctypes.c_uint64,
-             "nsr_grid_mlp_forward_max_blocks": ctypes.c_uint32, "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
+             "nsr_grid_mlp_backward_workspace_floats": ctypes.c_uint64, "nsr_mlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_vmlp_blob_floats": ctypes.c_uint64, "nsr_vmlp_backward_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_workspace_floats": ctypes.c_uint64,
              "nsr_hashgrid_backward_params_taps_workspace_floats": ctypes.c_uint64,

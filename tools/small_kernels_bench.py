@@ -53,10 +53,6 @@ for kept in (45000, 100000):
         check(lib.nsr_mlp_backward_phases(ptr(dtex), 1, 32, ptr(dl), ptr(o1), ptr(enc), 0, 32, 2, ptr(a1), ptr(wd), ptr(gdd), ptr(denc), 32, 2, ptr(pd), n, 65536.0, ctypes.byref(dd), None, s, 1), "d")
     r["dgrad_two_launches_us"] = median_us(two)
     r["dgrad_pair_us"] = median_us(lambda: check(lib.nsr_mlp_dgrad_pair(ptr(dr), ptr(dl), ptr(o2), ptr(a2), ptr(wc), ptr(pc), ptr(a1), ptr(wd), ptr(pd), ptr(denc), n, 65536.0, ctypes.byref(dc), ctypes.byref(dd), None, s), "p"))
-    for mb in (512, 1024):
-        lib.nsr_mlp_dgrad_pair_max_blocks(mb)
-        r[f"dgrad_pair_max{mb}_us"] = median_us(lambda: check(lib.nsr_mlp_dgrad_pair(ptr(dr), ptr(dl), ptr(o2), ptr(a2), ptr(wc), ptr(pc), ptr(a1), ptr(wd), ptr(pd), ptr(denc), n, 65536.0, ctypes.byref(dc), ctypes.byref(dd), None, s), "p"))
-    lib.nsr_mlp_dgrad_pair_max_blocks(2048)
     def wg():
         check(lib.nsr_mlp_backward_phases(ptr(dr), 1, 3, None, ptr(o2), ptr(tex), 0, 32, 0, ptr(a2), ptr(wc), ptr(gc), None, 32, 0, ptr(pc), n, 65536.0, ctypes.byref(dc), None, s, 2), "c")
         check(lib.nsr_mlp_backward_phases(ptr(denc), 1, 32, ptr(dl), ptr(o1), ptr(enc), 0, 32, 2, ptr(a1), ptr(wd), ptr(gdd), None, 32, 2, ptr(pd), n, 65536.0, ctypes.byref(dd), None, s, 2), "d")
