@@ -332,11 +332,12 @@ def test_owner_backward_with_fused_adamw_matches_gradient_plus_optimizer():
                 raise AssertionError((it, k, [t for t in bad if t[1]]))
 
 
-@pytest.mark.parametrize("mask_count,eps_level", [(16, 15), (9, 8), (4, 3)])
+@pytest.mark.parametrize("mask_count,eps_level", [(16, 15), (9, 8), (4, 3), (16, 12)])
 def test_owner_backward_stencil_mode_matches_plain_backward_over_all_taps(mask_count, eps_level):
     """nsr_hashgrid_backward_params_owner_{bin,accumulate}_taps (in-cell taps folded into their sample's items) == the plain
     owner backward over all 7 N points; eps = one cell of the finest active level (models/geometry.py:224-236), taps clamped
-    to the box like k_neus_points does, some samples ON the box faces"""
+    to the box like k_neus_points does, some samples ON the box faces.  (16, 12): eps is 1.3 - 2.3 cells on levels 13 - 15 --
+    taps that land beyond the face neighbour"""
     import ctypes
     import nsr_hip
     from nsr_hip import check, lib, ptr, stream_ptr
