@@ -773,8 +773,14 @@ typedef struct NsrAdamSegment {
     uint64_t n;
     float lr;
 } NsrAdamSegment;
+/* step_dev / hyper_dev (both or neither; int32[1] / float[4] on the device): the optimizer's step count lives on the device --
+ * a one-thread launch ahead of the update advances it and leaves 1 - beta^step in hyper_dev[1..2] (bias_correction1/2 are then
+ * ignored) UNLESS a registered overflow guard (nsr_overflow_guard) has flagged the step: then nothing is touched, as
+ * GradScaler.step() skips optimizer.step().  That launch also performs GradScaler.update() on the guard's state: call this
+ * entry LAST among a step's optimizer launches. */
 int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segments, float beta1, float beta2, float eps,
-                    float weight_decay, float bias_correction1, float bias_correction2, int zero_grad, void *stream);
+                    float weight_decay, float bias_correction1, float bias_correction2, int zero_grad, int32_t *step_dev,
+                    float *hyper_dev, void *stream);
 /* Stencil mode of the owner-computes table backward (finite-difference normals, reference models/geometry.py:181-199):
  * x7 = positions [7][n_centre][3] (sample, then the six +-eps taps), dy_level_major = [L][7 n_centre][F] fp32.  A tap that
  * stays in its sample's cell moves one coordinate inside a trilinear cell, so it is folded exactly into the sample's items
@@ -805,7 +811,10 @@ int nsr_hashgrid_backward_params_owner_accumulate_taps(const float *x7, const fl
  * dL/dy by state[2] instead of its grad_scale argument and raises this step's flag on a non-finite encoding gradient, the
  * table backward's fused AdamW (NsrTableAdam) and nsr_adamw_step_scheduled* leave weights, moments and fp16 images untouched
  * when it is set, and the latter updates the scale.  scale0 = the constant the weight-gradient reductions unscale by (the step
- * descriptor's grad_scale).  Returns the current parity. */
+ * descriptor's grad_scale).  The NeuS step: nsr_neus_composite_backward* (the first kernel of its backward) starts the step --
+ * it raises the flag on a non-finite loss gradient, nsr_neus_shade_backward* on a non-finite gradient at the SDF network's
+ * output (an overflow of the fp16 colour network lands there) -- nsr_adam_tick, nsr_adamw_step and nsr_adamw_multi skip when it
+ * is set, and nsr_adamw_multi (with a device-side step count) updates the scale.  Returns the current parity. */
 int nsr_overflow_guard(int32_t *state, float scale0);
 
 typedef struct NsrTableAdam {

@@ -330,8 +330,12 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
                      float *__restrict__ d_rgb_raw /* [n][16] fp32, cols 0..2 (3..15 zeroed) */,
                      float *__restrict__ d_bg /* per-ray background: dL/d comp_rgb_bg [n_rays][3] (may be NULL) */,
                      uint32_t n_rays, const int32_t *__restrict__ n_active, const NeusUpstream up,
-                     const float *__restrict__ t0, const float *__restrict__ t1)
+                     const float *__restrict__ t0, const float *__restrict__ t1,
+                     int32_t *__restrict__ guard /* overflow guard of a trainer (nsr_common.h NsrGuard) or NULL */, int parity)
 {
+    // the first kernel of a step's backward: the OTHER step parity's found-inf flag (the previous step's, read by its
+    // optimizer kernels long ago) is cleared for the next step; a non-finite loss gradient raises this step's
+    if (guard && blockIdx.x == 0 && threadIdx.x == 0) guard[1 - parity] = 0;
     uint32_t r, start, count;
     if (!wave_ray(packed, n_rays, r, start, count)) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -374,6 +378,8 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
     if (d_bg && (threadIdx.x & 63) == 0)
 #pragma unroll
         for (int q = 0; q < 3; ++q) d_bg[3ull * r + q] = dC[q] * (1.f - op);
+    bool bad = !(fabsf(dC[0]) + fabsf(dC[1]) + fabsf(dC[2]) + fabsf(dCr[0]) + fabsf(dCr[1]) + fabsf(dCr[2]) + fabsf(dO) +
+                 fabsf(dD) <= 3.4028235e38f);
     // per sample: g_w = dC . rgb + dO ; d alpha_i = g_w_i T_i - (sum_{j>i} g_w_j w_j) / max(1 - alpha_i, 1e-10)
     float carry = 0.f;  // sum of g_w_j w_j over the samples AFTER this chunk (walking backwards)
     for (uint32_t c = 0; c < count; c += 64) {
@@ -394,7 +400,9 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
         const float inc = wave_incl_scan_add(v);
         if (ok) {
             const float after = carry + (inc - v);
-            d_alpha[i] = gw * trans[i] - after / fmaxf(1.f - a, 1e-10f);
+            const float da = gw * trans[i] - after / fmaxf(1.f - a, 1e-10f);
+            d_alpha[i] = da;
+            bad |= !(fabsf(da) <= 3.4028235e38f);
             float *row = d_rgb_raw + 16 * i;
 #pragma unroll
             for (int q = 0; q < 3; ++q) row[q] = w * (dC[q] + dCr[q]) * rgb[q] * (1.f - rgb[q]);
@@ -403,6 +411,7 @@ k_neus_composite_bwd(const int32_t *__restrict__ packed, const float *__restrict
         }
         carry += __shfl(inc, 63, 64);
     }
+    if (guard && __any(bad) && lane == 0) atomicOr(guard + parity, 1);
 }
 
 template <bool FD>
@@ -415,9 +424,10 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
                  float *__restrict__ d_out /* [n][16] */, float *__restrict__ gx /* analytic: dL/d(dx01) [n][3] */,
                  float *__restrict__ p_in /* analytic: [n][p_stride], cols 0..2 written */, uint32_t p_stride,
                  float *__restrict__ d_taps /* FD: [6][n] */, float *__restrict__ acc, uint32_t n,
-                 const int32_t *__restrict__ n_dev, const NeusUpstream up)
+                 const int32_t *__restrict__ n_dev, const NeusUpstream up, int32_t *__restrict__ guard, int parity)
 {
     float gs_local = 0.f;
+    bool bad = false;  // a non-finite gradient reached the SDF network's output (e.g. the fp16 colour network overflowed)
     const uint32_t n_live = live_count(n, n_dev);
     for (uint32_t i = blockIdx.x * EW_BLOCK + threadIdx.x; i < n_live; i += gridDim.x * EW_BLOCK) {
         const float sdf = sdf_out[16ull * i];
@@ -483,9 +493,12 @@ k_neus_shade_bwd(const float *__restrict__ sdf_out, const float *__restrict__ gr
             }
         }
         row[0] = d_sdf + dt[0];
-        for (uint32_t k = 1; k < n_feat; ++k) row[k] = dt[k];
+        float chk = fabsf(d_sdf + dt[0]) + fabsf(G[0]) + fabsf(G[1]) + fabsf(G[2]);
+        for (uint32_t k = 1; k < n_feat; ++k) { row[k] = dt[k]; chk += fabsf(dt[k]); }
         for (uint32_t k = n_feat; k < 16; ++k) row[k] = 0.f;
+        bad |= !(chk <= 3.4028235e38f);
     }
+    if (guard && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(guard + parity, 1);
     __shared__ float red[EW_BLOCK / 64];
     gs_local = wave_sum(gs_local);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs_local;
@@ -754,14 +767,19 @@ extern "C" int nsr_neus_composite_backward_ex(const int32_t *packed_info, const 
     NSR_REQUIRE(background_stride == 0 || background_stride == 3, "nsr_neus_composite_backward: background_stride is 0 or 3");
     NeusLossWeights lw;
     memcpy(&lw, loss_weights8, sizeof(lw));
+    // a trainer's overflow guard (nsr_overflow_guard): this is the first kernel of a step's backward -- the step takes the
+    // other parity's flag (see the kernel); the shade backward, the table backwards and the optimizer kernels follow it
+    if (nsr_guard.state) nsr_guard.parity ^= 1;
     if (rgb_is_f32)
         hipLaunchKernelGGL(k_neus_composite_bwd<true>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
                            background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
-                           d_alpha, d_rgb_raw, d_background, n_rays, n_active, up, t_starts, t_ends);
+                           d_alpha, d_rgb_raw, d_background, n_rays, n_active, up, t_starts, t_ends, nsr_guard.state,
+                           nsr_guard.parity);
     else
         hipLaunchKernelGGL(k_neus_composite_bwd<false>, RAY_GRID(n_rays), packed_info, alpha, rgb_raw, weights, trans, background,
                            background_stride, opacity_bg, comp_rgb_full, opacity, gt_rgb, fg_mask, acc, lw, loss_scale,
-                           d_alpha, d_rgb_raw, d_background, n_rays, n_active, up, t_starts, t_ends);
+                           d_alpha, d_rgb_raw, d_background, n_rays, n_active, up, t_starts, t_ends, nsr_guard.state,
+                           nsr_guard.parity);
     NSR_CHECK_LAUNCH("nsr_neus_composite_backward");
     return NSR_OK;
 }
@@ -814,11 +832,11 @@ extern "C" int nsr_neus_shade_backward_ex(const float *sdf_out, const float *gra
     if (fd)
         hipLaunchKernelGGL(k_neus_shade_bwd<true>, EW_GRID_CAPPED(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
                            cos_anneal_ratio, laplace, eps, radius, d_alpha, d_tex_in, n_feat, lw, loss_scale, n_samples,
-                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev, up);
+                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev, up, nsr_guard.state, nsr_guard.parity);
     else
         hipLaunchKernelGGL(k_neus_shade_bwd<false>, EW_GRID_CAPPED(n), sdf_out, grad, normal, dirs, t_starts, t_ends, inv_s,
                            cos_anneal_ratio, laplace, eps, radius, d_alpha, d_tex_in, n_feat, lw, loss_scale, n_samples,
-                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev, up);
+                           d_out, gx, p_in, p_stride, d_taps, acc, n, n_dev, up, nsr_guard.state, nsr_guard.parity);
     NSR_CHECK_LAUNCH("nsr_neus_shade_backward");
     return NSR_OK;
 }

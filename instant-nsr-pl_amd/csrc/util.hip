@@ -188,8 +188,10 @@ k_neus_alpha_bwd(const float *__restrict__ sdf, const float *__restrict__ normal
 __global__ void __launch_bounds__(EW_BLOCK)
 k_adamw(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
         __half *__restrict__ shadow, uint64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
-        float bc2, float unscale, int zero_grad, const float *__restrict__ hyper, uint64_t zero_first_n)
+        float bc2, float unscale, int zero_grad, const float *__restrict__ hyper, uint64_t zero_first_n,
+        const int32_t *__restrict__ skip /* overflow guard: this step's found-inf flag, or NULL */)
 {
+    if (skip && *skip) return;
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }  // device-side schedule (nsr_adam_tick): graph-replayable
     const uint64_t stride = (uint64_t)gridDim.x * EW_BLOCK * 4;
     for (uint64_t base = ((uint64_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 4; base < n; base += stride) {
@@ -262,9 +264,10 @@ k_scale_from_half(const __half *__restrict__ src, float *__restrict__ dst, uint6
 // step counter, MultiStepLR-scaled learning rate and bias corrections on the device, in the double arithmetic the host
 // path uses: a captured step (hipGraph) then needs no per-step host scalar
 __global__ void k_adam_tick(int32_t *__restrict__ step, float *__restrict__ hyper, double base_lr, double b1, double b2,
-                            double gamma, int32_t m0, int32_t m1, int32_t m2)
+                            double gamma, int32_t m0, int32_t m1, int32_t m2, const int32_t *__restrict__ guard, int parity)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (guard && guard[parity]) return;  // overflow guard: the step is skipped, the optimizer's step count does not advance
     const int32_t done = *step;  // optimizer steps taken so far == the trainer's global_step
     const int32_t s = done + 1;
     *step = s;
@@ -409,9 +412,35 @@ struct AdamMulti {
     float lr[ADAM_MULTI_MAX];
 };
 
-__global__ void __launch_bounds__(EW_BLOCK)
-k_adamw_multi(const AdamMulti t, float b1, float b2, float eps, float wd, float bc1, float bc2, int zero_grad)
+// the device-side step count of nsr_adamw_multi (step_dev / hyper_dev given): advanced -- and the bias corrections 1 - beta^step
+// left in hyper[1..2] -- unless the overflow guard has flagged this step; then GradScaler.update() for the step, whose last
+// optimizer launch this is (skip: scale x 0.5, else x 2 after `growth interval` clean steps; csrc/nsr_common.h NsrGuard)
+__global__ void k_adam_multi_tick(int32_t *__restrict__ step, float *__restrict__ hyper, double b1, double b2,
+                                  int32_t *__restrict__ guard, int parity)
 {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const bool skip = guard && guard[parity];
+    if (!skip) {
+        const int32_t s = *step + 1;
+        *step = s;
+        hyper[1] = (float)(1.0 - pow(b1, (double)s));
+        hyper[2] = (float)(1.0 - pow(b2, (double)s));
+    }
+    if (guard) {
+        float sc = __int_as_float(guard[2]);
+        if (skip) { sc = fmaxf(sc * 0.5f, 1.f); guard[3] = 0; guard[4] += 1; }
+        else if (++guard[3] >= guard[5]) { sc = fminf(sc * 2.f, 1.8446744e19f); guard[3] = 0; }
+        guard[2] = __float_as_int(sc);
+    }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK)
+k_adamw_multi(const AdamMulti t, float b1, float b2, float eps, float wd, float bc1, float bc2, int zero_grad,
+              const float *__restrict__ hyper /* device-side bias corrections, or NULL */,
+              const int32_t *__restrict__ skip /* overflow guard: this step's found-inf flag, or NULL */)
+{
+    if (skip && *skip) return;
+    if (hyper) { bc1 = hyper[1]; bc2 = hyper[2]; }
     const uint32_t s = blockIdx.y, n = t.n[s];
     float *p = t.p[s], *g = t.g[s], *m = t.m[s], *v = t.v[s];
     const float lr = t.lr[s];
@@ -607,7 +636,8 @@ extern "C" int nsr_adamw_step(float *params, float *grad, float *exp_avg, float 
     if (blocks > 2048) blocks = 2048;  // grid-stride: ~8 blocks per CU
     hipLaunchKernelGGL(k_adamw, dim3((uint32_t)blocks), dim3(EW_BLOCK), 0, (hipStream_t)stream, params, grad, exp_avg,
                        exp_avg_sq, (__half *)shadow_half, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
-                       bias_correction2, grad_unscale, zero_grad, hyper, zero_first_n);
+                       bias_correction2, grad_unscale, zero_grad, hyper, zero_first_n,
+                       nsr_guard.state ? nsr_guard.state + nsr_guard.parity : nullptr);
     NSR_CHECK_LAUNCH("nsr_adamw_step");
     return NSR_OK;
 }
@@ -643,7 +673,7 @@ extern "C" int nsr_adam_tick(int32_t *step, float *hyper, double base_lr, double
 {
     NSR_REQUIRE(step && hyper, "nsr_adam_tick: NULL pointer");
     hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, (hipStream_t)stream, step, hyper, base_lr, beta1, beta2, gamma,
-                       milestone0, milestone1, milestone2);
+                       milestone0, milestone1, milestone2, nsr_guard.state, nsr_guard.parity);
     NSR_CHECK_LAUNCH("nsr_adam_tick");
     return NSR_OK;
 }
@@ -708,8 +738,15 @@ extern "C" int nsr_adamw_step_scheduled(float *params_a, float *grad_a, float *e
 
 extern "C" int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segments, float beta1, float beta2, float eps,
                                float weight_decay, float bias_correction1, float bias_correction2, int zero_grad,
-                               void *stream)
+                               int32_t *step_dev, float *hyper_dev, void *stream)
 {
+    NSR_REQUIRE((step_dev == nullptr) == (hyper_dev == nullptr), "nsr_adamw_multi: step_dev and hyper_dev come together");
+    int32_t *guard = nsr_guard.state;
+    if (step_dev) {  // (also with no live segment: the step count and the guard's scale move once per optimizer step)
+        hipLaunchKernelGGL(k_adam_multi_tick, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, hyper_dev, (double)beta1,
+                           (double)beta2, guard, nsr_guard.parity);
+        NSR_CHECK_LAUNCH("nsr_adamw_multi(tick)");
+    }
     if (n_segments == 0) return NSR_OK;
     NSR_REQUIRE(segments && n_segments <= (uint32_t)ADAM_MULTI_MAX, "nsr_adamw_multi: 1..%d segments", ADAM_MULTI_MAX);
     AdamMulti t;
@@ -726,7 +763,8 @@ extern "C" int nsr_adamw_multi(const NsrAdamSegment *segments, uint32_t n_segmen
     if (bx > 64) bx = 64;
     if (bx == 0) bx = 1;
     hipLaunchKernelGGL(k_adamw_multi, dim3(bx, n_segments), dim3(EW_BLOCK), 0, (hipStream_t)stream, t, beta1, beta2, eps,
-                       weight_decay, bias_correction1, bias_correction2, zero_grad);
+                       weight_decay, bias_correction1, bias_correction2, zero_grad, hyper_dev,
+                       guard ? guard + nsr_guard.parity : nullptr);
     NSR_CHECK_LAUNCH("nsr_adamw_multi");
     return NSR_OK;
 }

@@ -1070,6 +1070,9 @@ class SmallAdamW:
             raise NotImplementedError("SmallAdamW: at most 32 tensors")
         self.betas, self.eps, self.wd = betas, eps, weight_decay
         self.step_count = 0
+        # ``device_step``: the step count (and the bias corrections) live on the device, where an overflow guard can hold them
+        # back for a skipped step (nsr_adamw_multi); ``step_count`` then counts the calls, skipped ones included
+        self._dev_state = None
         n = sum(p.numel() for p, _ in self.items)
         dev = self.items[0][0].device if self.items else None
         self._m = torch.zeros(n, dtype=F32, device=dev) if self.items else None
@@ -1081,30 +1084,47 @@ class SmallAdamW:
             self.state[p] = (self._m[off:off + p.numel()], self._v[off:off + p.numel()])
             off += p.numel()
 
-    def step(self, lr_scale=1.0):
+    def _device_state(self):
+        if self._dev_state is None:
+            dev = self.items[0][0].device
+            self._dev_state = (torch.full((4,), self.step_count, dtype=torch.int32, device=dev)[:1],
+                               torch.zeros(4, dtype=F32, device=dev))
+        return self._dev_state
+
+    def taken_steps(self):
+        """optimizer steps really taken (a device-side count excludes the ones an overflow guard skipped) -- synchronises"""
+        return self.step_count if self._dev_state is None else int(self._dev_state[0].item())
+
+    def step(self, lr_scale=1.0, device_step=False):
         live = [(p, lr) for p, lr in self.items if p.grad is not None]
+        if device_step or self._dev_state is not None:
+            step_dev, hyper_dev = self._device_state()
+        else:
+            step_dev = hyper_dev = None
         self.step_count += 1
-        if not live:
+        if not live and step_dev is None:
             return
-        segs = (NsrAdamSegment * len(live))()
+        segs = (NsrAdamSegment * max(len(live), 1))()
         for sg, (p, lr) in zip(segs, live):
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             m, v = self.state[p]
             sg.params, sg.grad, sg.exp_avg, sg.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
             sg.n, sg.lr = p.numel(), lr * lr_scale
         bc1, bc2 = 1.0 - self.betas[0] ** self.step_count, 1.0 - self.betas[1] ** self.step_count
-        with torch.cuda.device(live[0][0].device):
+        with torch.cuda.device(self.items[0][0].device):
             check(lib.nsr_adamw_multi(segs, len(live), self.betas[0], self.betas[1], self.eps, self.wd, bc1, bc2, 0,
-                                      stream_ptr()), "nsr_adamw_multi")
+                                      ptr(step_dev), ptr(hyper_dev), stream_ptr()), "nsr_adamw_multi")
         for p, _ in live:
             p.grad = None
 
     def state_dict(self):
-        return {"step_count": self.step_count, "m": None if self._m is None else self._m.detach().clone(),
+        return {"step_count": self.taken_steps(), "m": None if self._m is None else self._m.detach().clone(),
                 "v": None if self._v is None else self._v.detach().clone()}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step_count"])
+        if self._dev_state is not None:
+            self._dev_state[0].fill_(self.step_count)
         if self._m is not None and sd.get("m") is not None:
             self._m.copy_(sd["m"])
             self._v.copy_(sd["v"])
@@ -1271,6 +1291,57 @@ class NeuSTrainer:
             # multi-GPU: the table backwards write the exchange's bf16 send buffers themselves
             self.fused.table_bf16 = {k: self.sharded.send_buffer(m) for k, m in self._table_of.items()
                                      if self.sharded.state[m]["head"] == 0 and len(self.sharded.ranges(m)) == 1}
+        guard = self._overflow_guard_state()
+        if guard is not None:
+            # Lightning's precision-16 protocol (the reference's NeuS configs train under it too) on the device, registered
+            # around THIS step's launches: see _overflow_guard_state
+            hs = float(self._guard_host[2:3].view(torch.float32)[0])  # (the scale as of one or two steps ago)
+            if hs >= 1.0:
+                self.fused.grad_scale = hs
+            lib.nsr_overflow_guard(ctypes.c_void_p(guard.data_ptr()), float(self.fused.grad_scale))
+        try:
+            return self._finish_step(rays, rgb, fg, bg, handle, after_march, scale, guard)
+        finally:
+            if guard is not None:
+                lib.nsr_overflow_guard(None, 0.0)
+                self._guard_host.copy_(guard, non_blocking=True)
+
+    def _overflow_guard_state(self):
+        """int32[8] on the device, torch.cuda.amp.GradScaler's state where the kernels read it: {found-inf flag of even / odd
+        steps, loss scale (float bits), clean steps, skipped steps, growth interval, -, -}.  A non-finite loss gradient (first
+        kernel of the backward) or a non-finite gradient at the SDF network's output (an overflow of the fp16 colour network
+        lands there) raises the step's flag; the tables' AdamW inside their backward, the networks' and the small tensors'
+        optimizer launches then leave parameters, moments and step counts untouched, and the last of them halves the scale
+        (x 2 again after ``overflow_growth_interval`` = 2,000 clean steps).  The scale is what the fp16 colour network's
+        backward multiplies dL/dy by before rounding (``FusedNeuSStep.grad_scale``, 65,536): the host follows the device's
+        value one or two steps late (an asynchronous read-back), so a run of overflowing steps may halve it once more than
+        GradScaler would.  One GPU, table updates fused into the table backward; None: off (``NSR_NO_OVERFLOW_GUARD``)."""
+        from .trainer import _GUARD_DEFAULT
+        if not getattr(self, "overflow_guard", _GUARD_DEFAULT) or self.world_size > 1 or self.sharded is not None or \
+                not self.fuse_table_adam:
+            return None
+        g = getattr(self, "_guard", None)
+        if g is None:
+            import struct
+            bits = struct.unpack("<i", struct.pack("<f", float(self.fused.grad_scale)))[0]
+            g = self._guard = torch.tensor([0, 0, bits, 0, 0, int(getattr(self, "overflow_growth_interval", 2000)), 0, 0],
+                                           dtype=torch.int32, device=self.device)
+            self._guard_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        return g
+
+    def overflow_guard_stats(self):
+        """(loss scale, clean steps since its last change, skipped steps, optimizer steps taken) -- synchronises"""
+        g = self._overflow_guard_state()
+        if g is None:
+            return None
+        torch.cuda.synchronize(self.device)
+        v = g.cpu()
+        return {"scale": float(v[2:3].view(torch.float32)[0]), "clean_steps": int(v[3]), "skipped_steps": int(v[4]),
+                "optimizer_steps": self.opt_rest.taken_steps()}
+
+    def _finish_step(self, rays, rgb, fg, bg, handle, after_march, scale, guard):
+        from .parallel import all_reduce_gradients
+        model = self.model
         res = self.fused.forward_backward(rays, rgb, fg, bg, march_handle=handle, after_march=after_march)
         n = res["num_samples"]
         if self.sharded is not None:
@@ -1287,7 +1358,7 @@ class NeuSTrainer:
             if self.world_size > 1:
                 all_reduce_gradients(list(model.parameters()))
             self.opt.step(lr_scale=scale, updated_in_backward=[self._table_of[k] for k in self.fused.adam_applied])
-        self.opt_rest.step(lr_scale=scale)
+        self.opt_rest.step(lr_scale=scale, device_step=guard is not None)  # (last: it updates the guard's scale)
         self.global_step += 1
         self.last = {"loss_acc": res["loss_acc"], "n_rays": rays.shape[0], "n_samples": n,
                      "n_samples_bg": res.get("num_samples_bg", 0), "n_marched_bg": res.get("num_marched_bg", 0)}

@@ -253,7 +253,7 @@ SIGNATURES = {
     "nsr_masked_loss_backward": [_P, _P, _P, _U, _U, _I, _F, _P, _P, _P, _P],
     "nsr_vmlp_fold": [_VD, _P, _U, _P, _P],
     "nsr_vmlp_unfold_gradient": [_VD, _P, _U, _P, _I, _P],
-    "nsr_adamw_multi": [_P, _U, _F, _F, _F, _F, _F, _F, _I, _P],
+    "nsr_adamw_multi": [_P, _U, _F, _F, _F, _F, _F, _F, _I, _P, _P, _P],
     "nsr_neus_inv_s": [_P, _P, _P],
     "nsr_neus_occupancy_values": [_P, _P, _F, _P, _U, _P, _P],
     "nsr_occupancy_update_values": [_P, _F, _F, _P, _P, _P, _P, _P, _U, _U, _P, _P],

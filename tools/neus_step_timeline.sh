@@ -1,3 +1,6 @@
+# usage (on the GPU box): bash tools/neus_step_timeline.sh neus-blender|neus-dtu|neuralangelo  ->  gpurun_out/<config>_refresh_timeline.csv:
+# rocprofv3 --kernel-trace of tools/neus_operating_point.py, cut to the last occupancy-refresh step and the two steps after it
+# (start_us, dur_us, queue, kernel)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 c=${1:-neus-dtu}
