@@ -566,6 +566,18 @@ def test_owner_backward_placements_agree_and_claim_cursors_reset():
                     assert float(ref.abs().sum()) > 0
                 same(a, ref, (thr, pl))
         lib.nsr_hashgrid_owner_tune(0, 3.0)
+        # runs of levels (what the ray-sharded step launches, finest first) under the claimed placement, both configurations:
+        # a launch's pair lists hold the levels of its range only
+        from nsr_hip import stream_ptr
+        for thr in (0, 0xffffffff):
+            lib.nsr_hashgrid_owner_large_from(thr)
+            check(lib.nsr_hashgrid_backward_params_owner_bin(ptr(x), ptr(ws0), n, 16, D, None, stream_ptr()), "bin")
+            part = torch.full((n_tab,), float("nan"), device="cuda")
+            for lo, hi in ((11, 16), (5, 11), (0, 5)):
+                check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(ptr(x), ptr(dy), ptr(part), None, ptr(ws0), n, 16, 1.0,
+                                                                              lo, hi, D, None, stream_ptr()), "range")
+            torch.cuda.synchronize()
+            same(part, ref, ("ranges", thr))
         for thr, rounds in ((0, 100), (0xffffffff, 50)):
             lib.nsr_hashgrid_owner_large_from(thr)
             outs = []
