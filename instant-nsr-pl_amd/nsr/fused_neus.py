@@ -144,6 +144,7 @@ class FusedNeuSStep:
             raise NotImplementedError("FusedNeuSStep marches through the occupancy grid(s) (grid_prune: true)")
         self.model = model
         self.bg = bool(cfg["learned_background"])
+        self.defer_bg_count = False  # a trainer sets it: its steps read the background's kept count at their end
         if self.bg:
             self._bg_setup(cfg)
         # finite differences: fold the taps that stay in their sample's cell into the sample's table-backward items
@@ -336,18 +337,44 @@ class FusedNeuSStep:
         check(lib.nsr_bg_visibility_prefix(ptr(out_m), self.bg_bias, ptr(t0_m), ptr(t1_m), ptr(pk_m), 1e-4, ptr(kept),
                                            n_rays, s), "nsr_bg_visibility_prefix")
         check(lib.nsr_pack_from_counts(ptr(kept), ptr(pk), ptr(total), n_rays, s), "nsr_pack_from_counts")
-        return dict(packed=pk, M=M, rays_d=rays_d, n_rays=n_rays, _count=_ops.read_count_begin(total),
+        return dict(packed=pk, M=M, rays_d=rays_d, n_rays=n_rays, _count=_ops.read_count_begin(total), _total=total,
                     _marched=(pk_m, [t0_m, t1_m, x01_m, xin_m, out_m]))
 
     def _bg_prune_finish(self, c):
         """the kept sample count reaches the host (the branch's second host sync; the caller has queued the foreground's encode
         and SDF network behind the pruning pass by now, so the GPU works while the host waits -- done right after the pruning
         pass, the wait and the host's queueing after it left the main stream idle ~0.1 ms per step) -> the kept samples' arrays"""
+        c["S"] = _ops.read_count_finish(c.pop("_count"))
+        return self._bg_gather_kept(c, c["S"], None)
+
+    def _bg_prune_defer(self, c):
+        """... or the count does NOT reach the host here (a trainer's own step, ``defer_bg_count``): the kept arrays get a row per
+        MARCHED sample, every kernel of the branch takes the kept count from the device (``n_dev``), and the trainer reads it
+        when the whole step is queued (``bg_count_deferred``).  With the branch on its own stream the host is what a step waits
+        for: a wait for the GPU in the middle of the forward leaves both streams idle while the host catches up afterwards."""
+        c["S"] = None
+        return self._bg_gather_kept(c, c["M"], c["_total"])
+
+    def bg_count_deferred(self, res):
+        """end of a step whose background count was deferred: the count (long on its way) -> ``res``; the per-sample outputs
+        are cut to it.  -> S"""
+        c, hook = res.pop("_bg_deferred")
+        if hook is not None:
+            hook(block=True)  # (a no-op when one of the step's polls has already queued the next batch)
+        elif "_count" in c:
+            c["S"] = _ops.read_count_finish(c.pop("_count"))
+        S = c["S"]
+        res["num_samples_bg"], res["num_samples_full"] = S, res["num_samples"] + S
+        for k in ("weights_bg", "ray_indices_bg", "t_starts_bg", "t_ends_bg"):
+            res[k] = res[k][:S]
+        return S
+
+    def _bg_gather_kept(self, c, rows, n_dev):
+        """the kept samples' arrays (``rows`` rows) <- each ray's leading samples of the marched arrays"""
         dev, n_rays = c["rays_d"].device, c["n_rays"]
-        rows = c["S"] = _ops.read_count_finish(c.pop("_count"))
         pk_m, srcs = c.pop("_marched")
         R = max(rows, 1)  # (nothing kept -- e.g. an empty background grid: the ray kernels still run, on non-NULL arrays)
-        c.update(ri=torch.empty(R, dtype=torch.int64, device=dev)[:rows],
+        c.update(n=rows, n_dev=n_dev, ri=torch.empty(R, dtype=torch.int64, device=dev)[:rows],
                  t0=torch.empty(R, dtype=F32, device=dev)[:rows], t1=torch.empty(R, dtype=F32, device=dev)[:rows],
                  x01=torch.empty((R, 3), dtype=F32, device=dev)[:rows],
                  xin=torch.empty((R, self.bg_n_enc), dtype=F32, device=dev)[:rows],
@@ -365,14 +392,15 @@ class FusedNeuSStep:
 
     def _bg_forward(self, c, background):
         """density / colour heads on the kept samples and density compositing -> comp_rgb_bg, opacity_bg"""
-        dev, S, n_rays, s = c["x01"].device, c["S"], c["n_rays"], stream_ptr()
+        # S rows (the kept count on the host) or one row per marched sample + the kept count on the device (_bg_prune_defer)
+        dev, S, nd, n_rays, s = c["x01"].device, c["n"], ptr(c["n_dev"]), c["n_rays"], stream_ptr()
         st = self.bg_tex_stride
         c["tex_in"] = torch.empty((S, st), dtype=F32, device=dev)
         check(lib.nsr_bg_texture_input(ptr(c["out"]), self.bg_n_feat, ptr(c["rays_d"]), ptr(c["ri"]), ptr(c["tex_in"]), st, S,
-                                       None, s), "nsr_bg_texture_input")
+                                       nd, s), "nsr_bg_texture_input")
         c["rgb_raw"] = torch.empty((S, 16), dtype=F32, device=dev)
         check(lib.nsr_vmlp_forward(_byref(self.bg_tex.desc), ptr(self._bg_blob_t.detach()), ptr(c["tex_in"]), st, None, 0,
-                                   ptr(c["rgb_raw"]), None, None, S, S, None, s), "nsr_vmlp_forward(bg colour)")
+                                   ptr(c["rgb_raw"]), None, None, S, S, nd, s), "nsr_vmlp_forward(bg colour)")
         c["weights"], c["trans"] = torch.empty(S, dtype=F32, device=dev), torch.empty(S, dtype=F32, device=dev)
         c["comp_rgb"] = torch.empty((n_rays, 3), dtype=F32, device=dev)
         c["opacity"] = torch.empty((n_rays, 1), dtype=F32, device=dev)
@@ -388,13 +416,13 @@ class FusedNeuSStep:
             desc = self.bg_enc.grid_desc
             c["gws"] = torch.empty(int(lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), S)), dtype=F32, device=dev)
             c["bin_event"] = self._on_helper(lambda hs: check(lib.nsr_hashgrid_backward_params_owner_bin(
-                ptr(c["x01"]), ptr(c["gws"]), S, desc.n_levels, _byref(desc), None, hs),
+                ptr(c["x01"]), ptr(c["gws"]), S, desc.n_levels, _byref(desc), nd, hs),
                 "nsr_hashgrid_backward_params_owner_bin(bg)"), (c["gws"], c["x01"]))
 
     def _bg_backward(self, c, d_comp):
         """d comp_rgb_bg [n_rays, 3] -> gradients of the background's table / density head / colour head.
         -> (g_geo blob gradient, g_tex blob gradient) for the host-side push"""
-        dev, S, n_rays, s = c["x01"].device, c["S"], c["n_rays"], stream_ptr()
+        dev, S, nd, n_rays, s = c["x01"].device, c["n"], ptr(c["n_dev"]), c["n_rays"], stream_ptr()
         enc, desc, st = self.bg_enc, self.bg_enc.grid_desc, self.bg_tex_stride
         gd, td = self.bg_geo.desc, self.bg_tex.desc
         d_logit = torch.empty(S, dtype=F32, device=dev)
@@ -407,17 +435,17 @@ class FusedNeuSStep:
         g_tex = torch.empty(self.bg_tex.n_floats, dtype=F32, device=dev)
         ws = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(_byref(td), S)), dtype=F32, device=dev)
         check(lib.nsr_vmlp_backward(_byref(td), ptr(self._bg_blob_t.detach()), ptr(c["tex_in"]), st, None, 0, ptr(d_rgb), None,
-                                    None, ptr(d_tex), st, 0, st, 0, ptr(g_tex), 0, ptr(ws), S, S, None, s),
+                                    None, ptr(d_tex), st, 0, st, 0, ptr(g_tex), 0, ptr(ws), S, S, nd, s),
               "nsr_vmlp_backward(bg colour)")
         d_out = torch.empty((S, 16), dtype=F32, device=dev)
-        check(lib.nsr_bg_join_gradients(ptr(d_logit), ptr(d_tex), st, self.bg_n_feat, ptr(d_out), S, None, s),
+        check(lib.nsr_bg_join_gradients(ptr(d_logit), ptr(d_tex), st, self.bg_n_feat, ptr(d_out), S, nd, s),
               "nsr_bg_join_gradients")
         C, F = self.bg_n_enc, int(desc.n_features)
         d_enc = torch.empty(C * S, dtype=F32, device=dev)  # level-major: what the owner-computes table backward reads
         g_geo = torch.empty(self.bg_geo.n_floats, dtype=F32, device=dev)
         ws2 = torch.empty(int(lib.nsr_vmlp_backward_workspace_floats(_byref(gd), S)), dtype=F32, device=dev)
         check(lib.nsr_vmlp_backward(_byref(gd), ptr(self._bg_blob_g.detach()), ptr(c["xin"]), C, None, 0, ptr(d_out), None, None,
-                                    ptr(d_enc), 0, 0, C, F, ptr(g_geo), 0, ptr(ws2), S, S, None, s),
+                                    ptr(d_enc), 0, 0, C, F, ptr(g_geo), 0, ptr(ws2), S, S, nd, s),
               "nsr_vmlp_backward(bg density)")
         if enc.params.grad is None:
             enc.params.grad = torch.zeros_like(enc.params)
@@ -427,19 +455,19 @@ class FusedNeuSStep:
             torch.cuda.current_stream().wait_event(c["bin_event"])
             check(lib.nsr_hashgrid_backward_params_owner_accumulate_range(
                 ptr(c["x01"]), ptr(d_enc), None, ptr(bf), ptr(c["gws"]), S, desc.n_levels, 1.0, 0, desc.n_levels, _byref(desc),
-                None, s), "nsr_hashgrid_backward_params_owner_accumulate_range(bg)")
+                nd, s), "nsr_hashgrid_backward_params_owner_accumulate_range(bg)")
             self.bf16_written.add("bg")
         elif S > 0 and ad is not None:
             torch.cuda.current_stream().wait_event(c["bin_event"])
             check(lib.nsr_hashgrid_backward_params_owner_accumulate_adam(ptr(c["x01"]), ptr(d_enc), 2, 0, ptr(c["gws"]), S,
-                                                                         desc.n_levels, 1.0, _byref(desc), None, _byref(ad), s),
+                                                                         desc.n_levels, 1.0, _byref(desc), nd, _byref(ad), s),
                   "nsr_hashgrid_backward_params_owner_accumulate_adam(bg)")
             self.adam_applied.add("bg")
         elif S > 0:
             torch.cuda.current_stream().wait_event(c["bin_event"])
             check(lib.nsr_hashgrid_backward_params_owner_accumulate(ptr(c["x01"]), ptr(d_enc), 2, 0, ptr(enc.params.grad),
                                                                     ptr(c["gws"]), S, desc.n_levels, 1.0, 0, _byref(desc),
-                                                                    None, s),
+                                                                    nd, s),
                   "nsr_hashgrid_backward_params_owner_accumulate(bg)")
             self.grad_written.add("bg")
         else:
@@ -452,6 +480,45 @@ class FusedNeuSStep:
             self.bg_geo.push_gradient(g_bg[0])
             self.bg_tex.push_gradient(g_bg[1])
         return res
+
+    def _bg_ctx(self, dev, behind_main=True, behind=None):
+        """``with self._bg_ctx(dev):`` -- the background branch's kernels go to their own stream, behind everything the main
+        stream has queued so far (``behind_main``).  The branch is ~25 launches of 5-90 us on 1e5 / 4e4 samples; on the main
+        stream they sat in front of the foreground's encode (pruning pass) and colour backward (its backward): 0.4 ms of a 2.2
+        ms step that now runs beside the foreground's networks.  ``NSR_NEUS_BG_ON_MAIN``: the old order (A/B switch)."""
+        import contextlib
+        if os.environ.get("NSR_NEUS_BG_ON_MAIN"):
+            return contextlib.nullcontext()
+        if getattr(self, "_bg_stream", None) is None:
+            self._bg_stream = _shared_stream(dev, "bg")
+        if behind is not None:  # (an event of the main stream recorded earlier: e.g. the start of the step)
+            self._bg_stream.wait_event(behind)
+        elif behind_main:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._bg_stream.wait_event(ev)
+        return torch.cuda.stream(self._bg_stream)
+
+    def _bg_join(self, tensors):
+        """the current (main) stream waits for the background stream; ``tensors`` were allocated there and are used here"""
+        bgs = getattr(self, "_bg_stream", None)
+        if bgs is None or os.environ.get("NSR_NEUS_BG_ON_MAIN"):
+            return
+        ev = torch.cuda.Event()
+        ev.record(bgs)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for t in tensors:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
+
+    def _bg_uses(self, *tensors):
+        """tensors of the main stream that the background stream's kernels read"""
+        bgs = getattr(self, "_bg_stream", None)
+        if bgs is not None and not os.environ.get("NSR_NEUS_BG_ON_MAIN"):
+            for t in tensors:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(bgs)
 
     def _on_helper(self, fn, tensors):
         """run ``fn(stream_ptr)`` on the helper stream behind everything queued so far; -> completion event"""
@@ -736,6 +803,8 @@ class FusedNeuSStep:
         desc = enc.grid_desc
         with torch.no_grad(), torch.cuda.device(dev):
             s = stream_ptr()
+            step_start = torch.cuda.Event()
+            step_start.record(torch.cuda.current_stream())
             if march_handle is None:
                 rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
                 march_handle = self.march_begin(rays_o, rays_d)
@@ -748,9 +817,6 @@ class FusedNeuSStep:
             packed, ri, t0, t1 = _ops.ray_march_finish(march_handle)
             N = ri.shape[0]
             bgc = None
-            if self.bg:  # the background's pruning pass decides its sample count: num_samples_full = N + S
-                self._bg_grads = compute_grads
-                bgc = self._bg_prune_begin(bg_handle)
             self._n_samples = N
             T = 7 if self.fd else 1
             eps = self._fd_eps() if self.fd else 0.0
@@ -825,9 +891,30 @@ class FusedNeuSStep:
             g_in = None if self.fd else torch.empty((N, P), dtype=F32, device=dev)
             check(lib.nsr_vmlp_forward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(out), ptr(taps),
                                        ptr(g_in), T * N, N, None, s), "nsr_vmlp_forward(sdf)")
-            if bgc is not None:
-                self._bg_prune_finish(bgc)
-            if after_march is not None:
+            # the background's pruning pass decides its sample count (num_samples_full = N + S).  It is queued HERE, on the
+            # background stream, once the foreground's positions / encode / SDF network are in the main stream's queue: queued
+            # first, its dozen launches kept the main stream idle for as long as the host needed for them.
+            # A trainer's own step (defer_bg_count): the kept count stays on the device (_bg_prune_defer); `hook` below queues
+            # the next batch once the count has reached the host -- polled once, where the main stream is fullest, else waited for by
+            # the trainer when the whole step is queued.
+            defer, hook = False, None
+            if self.bg:
+                self._bg_grads = compute_grads
+                self._bg_uses(rays_o, rays_d)
+                with self._bg_ctx(dev, behind=step_start):  # (behind the previous step's optimizer and a grid refresh only)
+                    bgc = self._bg_prune_begin(bg_handle)
+                    defer = self.defer_bg_count and not external and bgc["M"] > 0
+                    if defer:
+                        self._bg_prune_defer(bgc)
+                    else:
+                        self._bg_prune_finish(bgc)
+            if defer and after_march is not None:
+                def hook(block=False):
+                    if "_count" not in bgc or not (block or _ops.read_count_ready(bgc["_count"])):
+                        return
+                    bgc["S"] = _ops.read_count_finish(bgc.pop("_count"))
+                    after_march(N + bgc["S"])
+            if after_march is not None and not defer:
                 # the sample count of this step is known: a trainer queues the next batch's ray preparation + marching
                 # (side stream) here -- AFTER the first ~0.6 ms of this step's kernels are in the queue, so that the host
                 # time it takes does not leave the main stream idle.  (Later is worse: measured, the marching pass then
@@ -868,7 +955,10 @@ class FusedNeuSStep:
             bg = background.to(F32).contiguous()
             bg_arg, bg_stride, op_bg = bg, 0, None
             if bgc is not None:  # per-ray background = the NeRF++ branch's colour (models/neus.py:273-283)
-                self._bg_forward(bgc, bg)
+                self._bg_uses(bg)
+                with self._bg_ctx(dev):  # (behind the main stream: `bg` above, and a model-entry caller's own work)
+                    self._bg_forward(bgc, bg)
+                self._bg_join([v for v in bgc.values()])
                 bg_arg, bg_stride, op_bg = bgc["comp_rgb"], 3, bgc["opacity"]
             n1 = max(N, 1)  # the ray kernels run for every ray: no NULL sample arrays when nothing was marched
             weights, trans = torch.empty(n1, dtype=F32, device=dev), torch.empty(n1, dtype=F32, device=dev)
@@ -898,10 +988,12 @@ class FusedNeuSStep:
             if bgc is not None:
                 res.update({"comp_rgb_bg": bgc["comp_rgb"], "opacity_bg": bgc["opacity"], "depth_bg": bgc["depth"],
                             "rays_valid_bg": None if lean else bgc["opacity"] > 0, "num_samples_bg": bgc["S"],
-                            "num_marched_bg": bgc["M"], "num_samples_full": N + bgc["S"],
+                            "num_marched_bg": bgc["M"], "num_samples_full": None if defer else N + bgc["S"],
                             "rays_valid_full": None if lean else (opacity > 0) | (bgc["opacity"] > 0),
                             "weights_bg": bgc["weights"], "ray_indices_bg": bgc["ri"], "t_starts_bg": bgc["t0"],
                             "t_ends_bg": bgc["t1"]})
+                if defer:
+                    res["_bg_deferred"] = (bgc, hook)
             done = not compute_grads or (N == 0 and bgc is None)
         if done:
             return res
@@ -933,8 +1025,13 @@ class FusedNeuSStep:
                                                      ptr(opacity), ptr(gt), ptr(fg), ptr(acc), lw8c, float(loss_scale),
                                                      ptr(d_alpha), ptr(d_rgb), ptr(d_bg), n_rays, None, upp, ptr(t0), ptr(t1),
                                                      s), "nsr_neus_composite_backward")
-            g_bg = None if bgc is None else self._bg_backward(bgc, d_bg)
+            g_bg = None
+            if bgc is not None:  # beside the foreground's backward; joined before the gradients are pushed below
+                self._bg_uses(d_bg)
+                with self._bg_ctx(dev):
+                    g_bg = self._bg_backward(bgc, d_bg)
             if N == 0:  # background only: nothing flows into the foreground networks
+                self._bg_join(g_bg)
                 return self._finish_bg_only(res, g_bg)
             # colour network backward -> d tex_in (fp32 [N, 32])
             if self.tex_fused:
@@ -978,6 +1075,10 @@ class FusedNeuSStep:
             check(lib.nsr_vmlp_backward(_byref(sd), ptr(sdf_blob.detach()), ptr(x7), 3, ptr(encd), ENC_LM, ptr(d_out),
                                         ptr(d_taps), ptr(p_in), ptr(d_enc), 0, 3, C, F, ptr(g_sdf), 0, ptr(ws), T * N, N,
                                         None, s), "nsr_vmlp_backward(sdf)")
+            if hook is not None:
+                # the one place where the step polls for the background's kept count: the main stream holds ~0.5 ms of queued
+                # kernels here (colour backward, shade backward, SDF backward), more than queueing the next batch costs the host
+                hook()
             torch.cuda.current_stream().wait_event(bin_event)  # the items are binned (helper stream)
             # a trainer on one GPU hands over AdamW for the table (self.table_adam): the owner workgroups apply it in their
             # write-out -- no 50 MB gradient store, no optimizer sweep over the table
@@ -1029,6 +1130,7 @@ class FusedNeuSStep:
                 self.grad_written.add("fg")
         # weight norm / bias gradients through the host-side fold
         if g_bg is not None:
+            self._bg_join(g_bg)
             self.bg_geo.push_gradient(g_bg[0])
             self.bg_tex.push_gradient(g_bg[1])
         self.sdf.push_gradient(g_sdf)
@@ -1182,7 +1284,9 @@ class NeuSTrainer:
         self.opt_rest = SmallAdamW([(p, 0.01) for p in rest] + [(p, 0.001) for p in var])
         self.fused.lean_outputs = True  # no per-ray validity masks etc. in the step's result dict
         self.device_occupancy_refresh = not os.environ.get("NSR_NEUS_TORCH_REFRESH")  # foreground grid (A/B switch)
-        self._pending, self._side = None, None
+        self._pending, self._side, self._grids_ready = None, None, None
+        self.fused.defer_bg_count = self.fused.bg and not os.environ.get("NSR_NEUS_BG_SYNC_COUNT") and \
+            not os.environ.get("NSR_NEUS_BG_ON_MAIN")
         self.last = {}
         from .trainer import resync_after_model_load
         resync_after_model_load(self)
@@ -1259,6 +1363,9 @@ class NeuSTrainer:
         main = torch.cuda.current_stream()
         if self._pending is None:
             self._pending = self._next_batch(contextlib.nullcontext())
+            if self.fused.defer_bg_count:  # (the grids and their brick images are final on the main stream from here on)
+                self._grids_ready = torch.cuda.Event()
+                self._grids_ready.record(main)
         rays, rgb, fg, bg, handle = self._pending
         self._pending = None
         model.background_color = bg
@@ -1272,9 +1379,15 @@ class NeuSTrainer:
             if cfg["grid_prune"] and (t + 1) % 16 != 0:
                 if self._side is None:
                     self._side = _shared_stream(self.device, "side")
-                ev = torch.cuda.Event()
-                ev.record(main)
-                self._side.wait_event(ev)
+                if self.fused.defer_bg_count:
+                    # called when the whole step is queued (the background's kept count is read there): the batch must not
+                    # wait for this step's kernels, only for the occupancy grids it marches through (refreshed on the main stream)
+                    if self._grids_ready is not None:
+                        self._side.wait_event(self._grids_ready)
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    self._side.wait_event(ev)
                 self._pending = self._next_batch(torch.cuda.stream(self._side))
                 for x in self._pending[:4]:
                     x.record_stream(main)
@@ -1344,6 +1457,11 @@ class NeuSTrainer:
         model = self.model
         res = self.fused.forward_backward(rays, rgb, fg, bg, march_handle=handle, after_march=after_march)
         n = res["num_samples"]
+        if "_bg_deferred" in res:
+            # forward and backward are queued (> 1 ms of GPU work): if none of the step's polls has seen the background's kept
+            # count yet, the host waits for it now and queues the next batch (its marching, side stream, ~0.25 ms, runs while
+            # the host queues the optimizer steps below)
+            self.fused.bg_count_deferred(res)
         if self.sharded is not None:
             for p in self._rest:  # every rank contributes the same tensor list (a rank may have marched nothing)
                 if p.grad is None:

@@ -484,6 +484,11 @@ def read_count_begin(dev_word):
     return host, ev
 
 
+def read_count_ready(pending):
+    """has the copy queued by ``read_count_begin`` started to land?  (no wait; ``read_count_finish`` is then nearly free)"""
+    return int(pending[0][0]) != -0x7fffffff
+
+
 def read_count_finish(pending):
     host, ev = pending
     return _spin_until_changed(host, -0x7fffffff, ev.synchronize)
