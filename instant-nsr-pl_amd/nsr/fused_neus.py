@@ -20,7 +20,7 @@ import os
 import torch
 
 from nerfacc import ContractionType
-from nsr_hip import NsrAdamSegment, NsrVanillaLayer, NsrVmlpDesc, check, lib, ptr, stream_ptr
+from nsr_hip import NsrAdamSegment, NsrVanillaLayer, NsrVmlpDesc, check, device_guard, lib, ptr, stream_ptr
 from nsr_hip import shared_stream as _shared_stream
 from nsr_hip import ops as _ops
 
@@ -90,7 +90,7 @@ class VanillaBlob:
         dev = self.layers[0].bias.device
         if self.blob is None or self.blob.device != dev:
             self.blob = torch.empty(self.n_floats, dtype=F32, device=dev)
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             check(lib.nsr_vmlp_fold(_byref(self.desc), self._layer_array(), len(self.layers), ptr(self.blob), stream_ptr()),
                   "nsr_vmlp_fold")
         return self.blob
@@ -112,7 +112,7 @@ class VanillaBlob:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
         grads = [tuple(None if t is None else t.grad for t in self._tensors(layer)) for layer in self.layers]
-        with torch.cuda.device(grad_blob.device):
+        with device_guard(grad_blob.device):
             check(lib.nsr_vmlp_unfold_gradient(_byref(self.desc), self._layer_array(grads), len(self.layers), ptr(grad_blob),
                                                0 if fresh else 1, stream_ptr()), "nsr_vmlp_unfold_gradient")
 
@@ -214,7 +214,7 @@ class FusedNeuSStep:
         var = self.model.variance.variance
         if getattr(self, "_inv_s_buf", None) is None or self._inv_s_buf.device != var.device:
             self._inv_s_buf = torch.empty(1, dtype=F32, device=var.device)
-        with torch.cuda.device(var.device):
+        with device_guard(var.device):
             check(lib.nsr_neus_inv_s(ptr(var.detach()), ptr(self._inv_s_buf), stream_ptr()), "nsr_neus_inv_s")
         return self._inv_s_buf
 
@@ -247,7 +247,7 @@ class FusedNeuSStep:
         """occupancy statistic of models/neus.py:90-101 (closed-form alpha of one step at a flat SDF) on the kernels"""
         m, enc = self.model, self.enc
         n = x.shape[0]
-        with torch.no_grad(), torch.cuda.device(x.device):
+        with torch.no_grad(), device_guard(x.device):
             x01 = _ops.contract_to_unisphere(x.float().contiguous(), self.radius, ContractionType.AABB.value)
             e = _ops.hashgrid_forward(x01, enc.table_half(enc.params), enc.grid_desc, self._mask_count())
             blob = self.sdf.build(requires_grad=False)
@@ -303,7 +303,7 @@ class FusedNeuSStep:
         """occupancy statistic of the background grid (models/neus.py:103-106): density x step size"""
         m, enc = self.model, self.bg_enc
         n = x.shape[0]
-        with torch.no_grad(), torch.cuda.device(x.device):
+        with torch.no_grad(), device_guard(x.device):
             x01 = _ops.contract_to_unisphere(x.float().contiguous(), self.radius, ContractionType.UN_BOUNDED_SPHERE.value)
             e = _ops.hashgrid_forward(x01, enc.table_half(enc.params), enc.grid_desc).float()
             blob = self.bg_geo.build(requires_grad=False)
@@ -569,7 +569,7 @@ class FusedNeuSStep:
         table = enc.table_half(enc.params)
         blob = self.sdf.build(requires_grad=False)
         inv_s = self._inv_s()
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             s = stream_ptr()
             ob["jitter"][:cap * 3].uniform_()
             if not all_cells:
@@ -643,7 +643,7 @@ class FusedNeuSStep:
         table = enc.table_half(enc.params)
         blob = self.bg_geo.build(requires_grad=False)
         sphere = ContractionType.UN_BOUNDED_SPHERE.value
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             s = stream_ptr()
             ob["jitter"][:cap * 3].uniform_()
             if not all_cells:
@@ -692,7 +692,7 @@ class FusedNeuSStep:
         T = 7 if self.fd else 1
         eps = self._fd_eps() if self.fd else 0.0
         mc = self._mask_count()
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             s = stream_ptr()
             pts = points.float().contiguous()
             zeros3, zeros1 = torch.zeros((n, 3), dtype=F32, device=dev), torch.zeros(n, dtype=F32, device=dev)
@@ -801,7 +801,7 @@ class FusedNeuSStep:
         n_rays = rays.shape[0]
         grid = m.occupancy_grid
         desc = enc.grid_desc
-        with torch.no_grad(), torch.cuda.device(dev):
+        with torch.no_grad(), device_guard(dev):
             s = stream_ptr()
             step_start = torch.cuda.Event()
             step_start.record(torch.cuda.current_stream())
@@ -881,7 +881,7 @@ class FusedNeuSStep:
         tex_blob = None if self.tex_fused else self.tex.build(requires_grad=compute_grads)
         if self.bg:
             self._bg_blob_t = self.bg_tex.build(requires_grad=compute_grads)
-        with torch.no_grad(), torch.cuda.device(dev):
+        with torch.no_grad(), device_guard(dev):
             out = torch.empty((N, 16), dtype=F32, device=dev)
             taps = torch.empty(6 * N, dtype=F32, device=dev) if self.fd else None
             sd = self.sdf.desc
@@ -1011,7 +1011,7 @@ class FusedNeuSStep:
                     g_up = g_up.detach().to(F32).contiguous()
                     keep_up.append(g_up)
                     setattr(ups, field, g_up.data_ptr())
-        with torch.no_grad(), torch.cuda.device(dev):
+        with torch.no_grad(), device_guard(dev):
             s = stream_ptr()
             # the built-in loss terms are off when the caller owns the loss
             lw8c = (ctypes.c_float * 8)(*[0.0 if (external and k != "sparsity_scale") else float(lw.get(k, 0.0))
@@ -1141,7 +1141,7 @@ class FusedNeuSStep:
         fresh = var.grad is None
         if fresh:
             var.grad = torch.empty_like(var)
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             check(lib.nsr_neus_variance_gradient(ptr(acc), ptr(inv_s), ptr(var.grad), 0 if fresh else 1, stream_ptr()),
                   "nsr_neus_variance_gradient")
         return res
@@ -1213,7 +1213,7 @@ class SmallAdamW:
             sg.params, sg.grad, sg.exp_avg, sg.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
             sg.n, sg.lr = p.numel(), lr * lr_scale
         bc1, bc2 = 1.0 - self.betas[0] ** self.step_count, 1.0 - self.betas[1] ** self.step_count
-        with torch.cuda.device(self.items[0][0].device):
+        with device_guard(self.items[0][0].device):
             check(lib.nsr_adamw_multi(segs, len(live), self.betas[0], self.betas[1], self.eps, self.wd, bc1, bc2, 0,
                                       ptr(step_dev), ptr(hyper_dev), stream_ptr()), "nsr_adamw_multi")
         for p, _ in live:

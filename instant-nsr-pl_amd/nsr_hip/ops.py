@@ -104,7 +104,7 @@ def hashgrid_forward(x, table_half, desc, mask_count=None, out=None):
     C = desc.n_levels * desc.n_features
     y = torch.empty((n, C), dtype=F16, device=x.device) if out is None else out
     mc = desc.n_levels if mask_count is None else int(mask_count)
-    with torch.cuda.device(x.device), _timed("hashgrid_forward", n):
+    with device_guard(x.device), _timed("hashgrid_forward", n):
         check(lib.nsr_hashgrid_forward(ptr(x), ptr(table_half), ptr(y), n, y.stride(0), mc, _byref(desc),
                                        stream_ptr()), "nsr_hashgrid_forward")
     return y
@@ -116,7 +116,7 @@ def hashgrid_backward_params(x, dy, grad_table, desc, mask_count=None, grad_scal
     "atomic": one lane per (sample, level) with global fp32 atomics (always accumulates)."""
     mc = desc.n_levels if mask_count is None else int(mask_count)
     n = x.shape[0]
-    with torch.cuda.device(x.device), _timed("hashgrid_backward_params", n):
+    with device_guard(x.device), _timed("hashgrid_backward_params", n):
         if method == "atomic":
             if not accumulate:
                 grad_table.zero_()
@@ -136,7 +136,7 @@ def hashgrid_backward_params(x, dy, grad_table, desc, mask_count=None, grad_scal
 def hashgrid_backward_input(x, table_half, dy, desc, mask_count=None):
     mc = desc.n_levels if mask_count is None else int(mask_count)
     dx = torch.empty((x.shape[0], 3), dtype=F32, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib.nsr_hashgrid_backward_input(ptr(x), ptr(table_half), ptr(dy), _is_f32(dy), dy.stride(0), ptr(dx),
                                               x.shape[0], mc, _byref(desc), stream_ptr()),
               "nsr_hashgrid_backward_input")
@@ -149,7 +149,7 @@ def hashgrid_backward_backward_input(x, table_half, dy, g, desc, mask_count=None
     n, C = x.shape[0], desc.n_levels * desc.n_features
     d_dy = torch.empty((n, C), dtype=F32, device=x.device) if want_d_dy else None
     dx2 = torch.empty((n, 3), dtype=F32, device=x.device) if want_dx2 else None
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         ws = None
         if grad_table is not None and n > 0:  # table part through the binned owner-computes path (no global atomics)
             nws = lib.nsr_hashgrid_backward_params_workspace_floats(_byref(desc), n)
@@ -227,7 +227,7 @@ def grid_encode(x, params, owner):
 def sh4_forward(u, out=None):
     n = u.shape[0]
     y = torch.empty((n, 16), dtype=F16, device=u.device) if out is None else out
-    with torch.cuda.device(u.device):
+    with device_guard(u.device):
         check(lib.nsr_sh4_forward(ptr(u), ptr(y), n, y.stride(0), stream_ptr()), "nsr_sh4_forward")
     return y
 
@@ -239,7 +239,7 @@ def mlp_forward(x, weights_half, desc, save_acts):
     n = x.shape[0]
     out = torch.empty((n, desc.out_pad), dtype=F16, device=x.device)
     acts = torch.empty((desc.n_hidden, n, 64), dtype=F16, device=x.device) if save_acts else None
-    with torch.cuda.device(x.device), _timed(f"mlp_forward_h{desc.n_hidden}", n):
+    with device_guard(x.device), _timed(f"mlp_forward_h{desc.n_hidden}", n):
         check(lib.nsr_mlp_forward(ptr(x), _is_f32(x), x.stride(0), ptr(weights_half), ptr(out), ptr(acts), n,
                                   _byref(desc), stream_ptr()), "nsr_mlp_forward")
     return out, acts
@@ -252,7 +252,7 @@ def mlp_backward(dout, out, x, acts, weights_half, desc, grad_weights=None, want
     if grad_weights is not None:
         nws = lib.nsr_mlp_backward_workspace_floats(_byref(desc), n)
         partials = torch.empty(int(nws), dtype=F32, device=x.device)
-    with torch.cuda.device(x.device), _timed(f"mlp_backward_h{desc.n_hidden}", n):
+    with device_guard(x.device), _timed(f"mlp_backward_h{desc.n_hidden}", n):
         check(lib.nsr_mlp_backward(ptr(dout), _is_f32(dout), dout.stride(0), ptr(out), ptr(x), _is_f32(x), x.stride(0),
                                    ptr(acts), ptr(weights_half), ptr(grad_weights), ptr(dx),
                                    desc.n_in if want_dx else 0, ptr(partials), n, float(grad_scale), _byref(desc),
@@ -319,7 +319,7 @@ def grid_mlp_forward(x, table_half, weights_half, gdesc, mdesc, mask_count=None,
     enc = None
     if want_enc:
         enc = torch.empty((gdesc.n_levels, n, gdesc.n_features) if enc_level_major else (n, C), dtype=F16, device=x.device)
-    with torch.cuda.device(x.device), _timed("grid_mlp_forward", n):
+    with device_guard(x.device), _timed("grid_mlp_forward", n):
         check(lib.nsr_grid_mlp_forward(ptr(x), ptr(table_half), ptr(weights_half), ptr(out), ptr(acts), ptr(enc),
                                        0 if (enc is None or enc_level_major) else enc.stride(0), int(enc_level_major), n, mc,
                                        _byref(gdesc), _byref(mdesc), None, stream_ptr()), "nsr_grid_mlp_forward")
@@ -334,7 +334,7 @@ def grid_mlp_backward(dout, out, x, enc, acts, weights_half, gdesc, mdesc, grad_
     mc = gdesc.n_levels if mask_count is None else int(mask_count)
     nws = lib.nsr_grid_mlp_backward_workspace_floats(_byref(gdesc), _byref(mdesc), n)
     ws = torch.empty(int(nws), dtype=F32, device=x.device)
-    with torch.cuda.device(x.device), _timed("grid_mlp_backward", n):
+    with device_guard(x.device), _timed("grid_mlp_backward", n):
         check(lib.nsr_grid_mlp_backward(ptr(dout), _is_f32(dout), dout.stride(0), ptr(out), ptr(x), ptr(enc),
                                         0 if enc_level_major else enc.stride(0), int(enc_level_major), ptr(acts),
                                         ptr(weights_half), ptr(grad_weights), ptr(grad_table), ptr(ws), n, mc,
@@ -401,7 +401,7 @@ def ray_aabb_intersect(rays_o, rays_d, aabb):
     n = rays_o.shape[0]
     t_min = torch.empty(n, dtype=F32, device=rays_o.device)
     t_max = torch.empty(n, dtype=F32, device=rays_o.device)
-    with torch.cuda.device(rays_o.device):
+    with device_guard(rays_o.device):
         check(lib.nsr_ray_aabb_intersect(ptr(rays_o), ptr(rays_d), ptr(aabb), ptr(t_min), ptr(t_max), n, stream_ptr()),
               "nsr_ray_aabb_intersect")
     return t_min, t_max
@@ -420,7 +420,7 @@ def grid_bricks(binary, out=None):
         return tag[2]
     grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
     bricks = out if out is not None else torch.empty(words, dtype=torch.int64, device=binary.device)
-    with torch.cuda.device(binary.device):
+    with device_guard(binary.device):
         check(lib.nsr_grid_pack_bricks(ptr(grid_u8), rx, ry, rz, ptr(bricks), stream_ptr()), "nsr_grid_pack_bricks")
     try:
         binary._nsr_bricks = (binary._version, binary.data_ptr(), bricks)
@@ -517,7 +517,7 @@ def ray_march_begin(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step
     h.bricks = grid_bricks(binary) if method == "bricks" else None
     h.grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
     h.cap, h.scratch = 0, None
-    with torch.cuda.device(dev):
+    with device_guard(dev):
         s = stream_ptr()
         with _timed("ray_march_count", n):
             if h.bricks is None:
@@ -568,7 +568,7 @@ def ray_march_finish(h):
         # and the roi the capacity was derived from): the counts are still exact, so re-march in two-pass mode
         scratch = None
     if m > 0:
-        with torch.cuda.device(dev), _timed("ray_march_write", n):
+        with device_guard(dev), _timed("ray_march_write", n):
             s = stream_ptr()
             if h.bricks is None:
                 check(lib.nsr_ray_march_write(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), ptr(roi), ptr(h.grid_u8),
@@ -595,7 +595,7 @@ def ray_march(rays_o, rays_d, t_min, t_max, roi, binary, contraction, step, cone
 
 def pack_info(ray_indices, n_rays):
     packed = torch.empty((n_rays, 2), dtype=torch.int32, device=ray_indices.device)
-    with torch.cuda.device(ray_indices.device):
+    with device_guard(ray_indices.device):
         check(lib.nsr_pack_info(ptr(ray_indices), ptr(packed), ray_indices.shape[0], n_rays, stream_ptr()),
               "nsr_pack_info")
     return packed
@@ -604,7 +604,7 @@ def pack_info(ray_indices, n_rays):
 def contract(x, roi, contraction, inverse=False):
     out = torch.empty_like(x)
     fn = lib.nsr_contract_inv if inverse else lib.nsr_contract
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(fn(ptr(x), ptr(roi), int(contraction), ptr(out), x.shape[0], stream_ptr()), "nsr_contract")
     return out
 
@@ -613,7 +613,7 @@ def grid_query(x, roi, binary, contraction):
     rx, ry, rz = (int(s) for s in binary.shape)
     grid_u8 = binary.view(torch.uint8) if binary.dtype == torch.bool else binary
     out = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib.nsr_grid_query_u8(ptr(x), ptr(roi), ptr(grid_u8), rx, ry, rz, int(contraction), ptr(out), x.shape[0],
                                     stream_ptr()), "nsr_grid_query_u8")
     return out.bool()
@@ -623,7 +623,7 @@ def sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends, want_dirs=Tr
     n = ray_indices.shape[0]
     pos = torch.empty((n, 3), dtype=F32, device=rays_o.device)
     dirs = torch.empty((n, 3), dtype=F32, device=rays_o.device) if want_dirs else None
-    with torch.cuda.device(rays_o.device):
+    with device_guard(rays_o.device):
         check(lib.nsr_sample_positions(ptr(rays_o), ptr(rays_d), ptr(ray_indices), ptr(t_starts), ptr(t_ends), ptr(pos),
                                        ptr(dirs), n, stream_ptr()), "nsr_sample_positions")
     return pos, dirs
@@ -638,7 +638,7 @@ def compact_samples(mask, ray_indices, t_starts, t_ends):
     t0, t1 = torch.empty_like(t_starts), torch.empty_like(t_ends)
     n_kept = torch.zeros(1, dtype=torch.int32, device=dev)
     scratch = torch.empty((n + 255) // 256 + 1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with device_guard(dev):
         check(lib.nsr_compact_samples(ptr(mask_u8), ptr(ray_indices), ptr(t_starts), ptr(t_ends), ptr(ri), ptr(t0),
                                       ptr(t1), ptr(n_kept), ptr(scratch), n, stream_ptr()), "nsr_compact_samples")
     k = int(n_kept.item())
@@ -653,7 +653,7 @@ class _TransFromSigma(Function):
     def forward(ctx, sigmas, t_starts, t_ends, packed, n_rays):
         sig = _f32c(sigmas)
         T = torch.empty_like(sig)
-        with torch.cuda.device(sig.device):
+        with device_guard(sig.device):
             check(lib.nsr_transmittance_from_sigma_forward(ptr(packed), ptr(t_starts), ptr(t_ends), ptr(sig), ptr(T),
                                                            n_rays, stream_ptr()), "transmittance_from_sigma_forward")
         ctx.save_for_backward(T, t_starts, t_ends, packed)
@@ -666,7 +666,7 @@ class _TransFromSigma(Function):
         T, t_starts, t_ends, packed = ctx.saved_tensors
         g = torch.empty_like(T)
         gT = _f32c(gT)
-        with torch.cuda.device(T.device):
+        with device_guard(T.device):
             check(lib.nsr_transmittance_from_sigma_backward(ptr(packed), ptr(t_starts), ptr(t_ends), ptr(T), ptr(gT),
                                                             ptr(g), ctx.n_rays, stream_ptr()),
                   "transmittance_from_sigma_backward")
@@ -678,7 +678,7 @@ class _TransFromAlpha(Function):
     def forward(ctx, alphas, packed, n_rays):
         a = _f32c(alphas)
         T = torch.empty_like(a)
-        with torch.cuda.device(a.device):
+        with device_guard(a.device):
             check(lib.nsr_transmittance_from_alpha_forward(ptr(packed), ptr(a), ptr(T), n_rays, stream_ptr()),
                   "transmittance_from_alpha_forward")
         ctx.save_for_backward(T, a, packed)
@@ -691,7 +691,7 @@ class _TransFromAlpha(Function):
         T, a, packed = ctx.saved_tensors
         g = torch.empty_like(T)
         gT = _f32c(gT)
-        with torch.cuda.device(T.device):
+        with device_guard(T.device):
             check(lib.nsr_transmittance_from_alpha_backward(ptr(packed), ptr(a), ptr(T), ptr(gT), ptr(g), ctx.n_rays,
                                                             stream_ptr()), "transmittance_from_alpha_backward")
         return g, None, None
@@ -712,7 +712,7 @@ class _Accumulate(Function):
         v = None if values is None else _f32c(values)
         dim = 1 if v is None else v.shape[-1]
         out = torch.empty((n_rays, dim), dtype=F32, device=w.device)
-        with torch.cuda.device(w.device):
+        with device_guard(w.device):
             check(lib.nsr_accumulate_along_rays_forward(ptr(packed), ptr(w), ptr(v), dim, ptr(out), n_rays,
                                                         stream_ptr()), "accumulate_along_rays_forward")
         ctx.save_for_backward(w, v, ray_indices)
@@ -727,7 +727,7 @@ class _Accumulate(Function):
         g_out = _f32c(g_out)
         gw = torch.empty_like(w) if need_w else None
         gv = torch.empty_like(v) if need_v else None
-        with torch.cuda.device(w.device):
+        with device_guard(w.device):
             check(lib.nsr_accumulate_along_rays_backward(ptr(ray_indices), ptr(w), ptr(v), ctx.dim, ptr(g_out), ptr(gw),
                                                          ptr(gv), w.shape[0], stream_ptr()),
                   "accumulate_along_rays_backward")
@@ -743,7 +743,7 @@ def accumulate_along_rays(weights, values, ray_indices, packed, n_rays):
 # ------------------------------------------------------------------------------------------------
 def contract_to_unisphere(x, radius, contraction):
     out = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with device_guard(x.device):
         check(lib.nsr_contract_to_unisphere(ptr(x), float(radius), int(contraction), ptr(out), x.shape[0], stream_ptr()),
               "nsr_contract_to_unisphere")
     return out
@@ -753,7 +753,7 @@ def density_activation(mlp_out, n_feat, bias, want_feature=True):
     n = mlp_out.shape[0]
     density = torch.empty(n, dtype=F32, device=mlp_out.device)
     feature = torch.empty((n, n_feat), dtype=F32, device=mlp_out.device) if want_feature else None
-    with torch.cuda.device(mlp_out.device):
+    with device_guard(mlp_out.device):
         check(lib.nsr_density_activation_forward(ptr(mlp_out), mlp_out.stride(0), n_feat, float(bias), ptr(density),
                                                  ptr(feature), n, stream_ptr()), "nsr_density_activation_forward")
     return density, feature
@@ -765,7 +765,7 @@ class _NeusAlpha(Function):
         sdf, normal, dirs, dists = _f32c(sdf).view(-1), _f32c(normal), _f32c(dirs), _f32c(dists).view(-1)
         inv_s_c = _f32c(inv_s).view(-1)[:1]
         alpha = torch.empty_like(sdf)
-        with torch.cuda.device(sdf.device):
+        with device_guard(sdf.device):
             check(lib.nsr_neus_alpha_forward(ptr(sdf), ptr(normal), ptr(dirs), ptr(dists), ptr(inv_s_c), float(anneal),
                                              ptr(alpha), sdf.shape[0], stream_ptr()), "nsr_neus_alpha_forward")
         ctx.save_for_backward(sdf, normal, dirs, dists, inv_s_c)
@@ -779,7 +779,7 @@ class _NeusAlpha(Function):
         g_alpha = _f32c(g_alpha).view(-1)
         g_sdf, g_normal = torch.empty_like(sdf), torch.empty_like(normal)
         g_inv_s = torch.zeros(1, dtype=F32, device=sdf.device)
-        with torch.cuda.device(sdf.device):
+        with device_guard(sdf.device):
             check(lib.nsr_neus_alpha_backward(ptr(sdf), ptr(normal), ptr(dirs), ptr(dists), ptr(inv_s_c), ctx.anneal,
                                               ptr(g_alpha), ptr(g_sdf), ptr(g_normal), ptr(g_inv_s), sdf.shape[0],
                                               stream_ptr()), "nsr_neus_alpha_backward")
@@ -794,7 +794,7 @@ def adamw_step(params, grad, exp_avg, exp_avg_sq, shadow_half, lr, beta1, beta2,
                grad_unscale=1.0, zero_grad=True, hyper=None, zero_first_n=0):
     """``hyper`` (device float[3] written by ``adam_tick``) overrides lr and the bias corrections on the device"""
     bc1, bc2 = 1.0 - beta1 ** max(step, 1), 1.0 - beta2 ** max(step, 1)
-    with torch.cuda.device(params.device):
+    with device_guard(params.device):
         check(lib.nsr_adamw_step(ptr(params), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(shadow_half),
                                  params.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                  float(bc1), float(bc2), float(grad_unscale), int(zero_grad), ptr(hyper),
@@ -823,6 +823,6 @@ def adamw_step_scheduled(tensors, step_dev, hyper12, base_lr, beta1, beta2, gamm
 
 def adam_tick(step_dev, hyper_dev, base_lr, beta1, beta2, gamma, milestones):
     ms = [int(m) for m in milestones][:3] + [0x7fffffff] * (3 - min(len(milestones), 3))
-    with torch.cuda.device(step_dev.device):
+    with device_guard(step_dev.device):
         check(lib.nsr_adam_tick(ptr(step_dev), ptr(hyper_dev), float(base_lr), float(beta1), float(beta2), float(gamma),
                                 ms[0], ms[1], ms[2], stream_ptr()), "nsr_adam_tick")
