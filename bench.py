@@ -262,7 +262,29 @@ def other_workloads(dev, rank=0, world=1, sync=None, n_steps=60):
     return out
 
 
-def boundary_path(dev, warmup=300, steps=200, late_at=3000, late_steps=200):
+def _median_pass(fn, passes):
+    """``passes`` runs of a host-bound side measurement back to back; the MEDIAN pass (by ms per step) with every pass's figure:
+    one pass of these python-driven loops moves by 30-50 % from run to run on the same code (profiles/
+    r06_modular_path_r4_vs_now.json; boundary_path in round 6: 1.29 / 1.64 / 1.98 ms in one process)"""
+    runs = [fn() for _ in range(max(1, passes))]
+    order = sorted(range(len(runs)), key=lambda k: runs[k]["ms_per_step"])
+    res = dict(runs[order[len(order) // 2]])
+    res["passes_ms_per_step"] = [round(r["ms_per_step"], 3) for r in runs]
+    res["reported"] = "median pass"
+    return res
+
+
+def boundary_path(dev, passes=3):
+    """three passes of ``boundary_pass``, the median reported (see _median_pass)"""
+    return _median_pass(lambda: boundary_pass(dev), passes)
+
+
+def boundary_path_neus(dev, passes=3):
+    """three passes of ``boundary_pass_neus``, the median reported (see _median_pass)"""
+    return _median_pass(lambda: boundary_pass_neus(dev), passes)
+
+
+def boundary_pass(dev, warmup=300, steps=200, late_at=3000, late_steps=200):
     """The same training step driven THROUGH THE DROP-IN BOUNDARY the way the reference's system drives its model
     (systems/nerf.py:33-99, systems/base.py:54-57): torch ray sampling -> model.update_step -> out = model(rays) ->
     dynamic ray count from out['num_samples'] -> smooth-L1 on the valid rays in torch -> loss.backward() ->
@@ -346,12 +368,7 @@ def modular_path(dev, warmup=60, steps=100, passes=3):
     from one pass to the next on the same code (profiles/r06_modular_path_r4_vs_now.json: round 5's "3.31 -> 3.81 ms
     regression" was one pass against one pass inside that spread -- the round-4 tree re-measured beside this one gives
     3.4 - 4.1 ms)."""
-    runs = [modular_pass(dev, warmup, steps) for _ in range(max(1, passes))]
-    order = sorted(range(len(runs)), key=lambda k: runs[k]["ms_per_step"])
-    res = dict(runs[order[len(order) // 2]])
-    res["passes_ms_per_step"] = [round(r["ms_per_step"], 3) for r in runs]
-    res["reported"] = "median pass"
-    return res
+    return _median_pass(lambda: modular_pass(dev, warmup, steps), passes)
 
 
 def modular_pass(dev, warmup=60, steps=100):
@@ -414,7 +431,7 @@ def modular_pass(dev, warmup=60, steps=100):
                     "early in training (steps 60-160 of a fresh model: few rays, dense grid)"}
 
 
-def boundary_path_neus(dev, warmup=100, steps=100):
+def boundary_pass_neus(dev, warmup=100, steps=100):
     """configs[2] (neus-blender) driven through the drop-in boundary the way the reference's NeuS system drives its model
     (systems/neus.py:88-139): torch ray sampling -> model.update_step -> out = model(rays) -> dynamic ray count from
     out['num_samples_full'] -> MSE / L1 on the valid rays, eikonal on sdf_grad_samples, mask BCE on opacity, in torch ->
